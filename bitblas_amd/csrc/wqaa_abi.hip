@@ -1,0 +1,286 @@
+// wqaa_abi.hip - extern "C" entry points of libwqaa_hip.so (see include/wqaa.h).
+//
+// Replaces the reference's generated per-config wrapper (`init()` + `call()`,
+// bitblas/builder/wrapper/tl.py:90-166 and :200-305) and its host-side kernel choice
+// (`MatmulDequantizeScheduler.dispatch_*`, tilelang/dequantize/matmul_dequantize.py:65-155:
+// M < 8 -> GEMV, otherwise the tensor-core GEMM).
+#include <hip/hip_ext.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <mutex>
+
+#include "wqaa_common.h"
+
+namespace wqaa {
+
+static thread_local int g_last_error = WQAA_OK;
+static thread_local char g_last_error_msg[512] = "";
+
+void set_error(int code, const char* fmt, ...) {
+  g_last_error = code;
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_last_error_msg, sizeof(g_last_error_msg), fmt, ap);
+  va_end(ap);
+}
+
+static DeviceInfo g_dev = {0, 256, 160 * 1024, "gfx950"};
+static std::once_flag g_dev_once;
+
+const DeviceInfo& device_info() {
+  std::call_once(g_dev_once, [] {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+      (void)hipGetLastError();
+      return;
+    }
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    hipDeviceProp_t p;
+    if (hipGetDeviceProperties(&p, dev) == hipSuccess) {
+      g_dev.ok = 1;
+      g_dev.cus = p.multiProcessorCount;
+      g_dev.lds_per_block = (int)p.maxSharedMemoryPerMultiProcessor;
+      snprintf(g_dev.arch, sizeof(g_dev.arch), "%s", p.gcnArchName);
+    }
+  });
+  return g_dev;
+}
+
+static bool valid_desc(const wqaa_matmul_desc* d) {
+  if (!d) {
+    set_error(WQAA_ERR_BAD_DESC, "null descriptor");
+    return false;
+  }
+  if (d->struct_size != (int32_t)sizeof(wqaa_matmul_desc)) {
+    set_error(WQAA_ERR_BAD_DESC, "descriptor size %d != %zu (ABI mismatch)", d->struct_size, sizeof(wqaa_matmul_desc));
+    return false;
+  }
+  if (d->N <= 0 || d->K <= 0) {
+    set_error(WQAA_ERR_BAD_DESC, "N=%d K=%d must be positive", d->N, d->K);
+    return false;
+  }
+  return true;
+}
+
+// M < 8 -> GEMV (reference threshold, matmul_dequantize.py:93-102); larger m -> MFMA GEMM when a
+// member exists for the dtype pair, else the GEMV family iterates over batch tiles of 8 rows.
+static int dispatch(const wqaa_matmul_desc& d, int m, bool* use_gemm) {
+  *use_gemm = false;
+  if (m >= 8) {
+    wqaa_plan p;
+    const int saved = g_last_error;
+    char saved_msg[sizeof(g_last_error_msg)];
+    memcpy(saved_msg, g_last_error_msg, sizeof(saved_msg));
+    if (gemm_plan(d, m, &p) == WQAA_OK) {
+      *use_gemm = true;
+    } else {
+      g_last_error = saved;
+      memcpy(g_last_error_msg, saved_msg, sizeof(saved_msg));
+    }
+  }
+  return WQAA_OK;
+}
+
+static int matmul_impl(const wqaa_matmul_desc* desc, const void* A, const void* B, const void* LUT,
+                       const void* Scale, const void* Zeros, const void* Bias, void* C, int m,
+                       void* stream, void* ev0, void* ev1) {
+  if (!valid_desc(desc)) return WQAA_ERR_BAD_DESC;
+  if (m == 0) return WQAA_OK;  // wrapper/tl.py:277
+  if (m < 0 || !A || !B || !C) {
+    set_error(WQAA_ERR_BAD_DESC, "bad call: m=%d A=%p B=%p C=%p", m, A, B, C);
+    return WQAA_ERR_BAD_DESC;
+  }
+  if (desc->with_scaling && !Scale) {
+    set_error(WQAA_ERR_BAD_DESC, "with_scaling set but Scale is NULL");
+    return WQAA_ERR_BAD_DESC;
+  }
+  if (desc->zeros_mode != WQAA_Z_NONE && !Zeros) {
+    set_error(WQAA_ERR_BAD_DESC, "zeros_mode=%d but Zeros is NULL", desc->zeros_mode);
+    return WQAA_ERR_BAD_DESC;
+  }
+  if (desc->with_bias && !Bias) {
+    set_error(WQAA_ERR_BAD_DESC, "with_bias set but Bias is NULL");
+    return WQAA_ERR_BAD_DESC;
+  }
+  if (desc->w_format == WQAA_W_NF && !LUT) {
+    set_error(WQAA_ERR_BAD_DESC, "nf weights need the LUT pointer");
+    return WQAA_ERR_BAD_DESC;
+  }
+  if (!device_info().ok) {
+    set_error(WQAA_ERR_NO_DEVICE, "no HIP device visible");
+    return WQAA_ERR_NO_DEVICE;
+  }
+  bool use_gemm = false;
+  dispatch(*desc, m, &use_gemm);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  hipEvent_t e0 = reinterpret_cast<hipEvent_t>(ev0), e1 = reinterpret_cast<hipEvent_t>(ev1);
+  int st = use_gemm ? gemm_launch(*desc, A, B, LUT, Scale, Zeros, Bias, C, m, s, e0, e1)
+                    : gemv_launch(*desc, A, B, LUT, Scale, Zeros, Bias, C, m, s, e0, e1);
+  if (st == WQAA_OK) g_last_error = WQAA_OK;
+  return st;
+}
+
+// ------------------------------------------------------------------------------------------
+// CPU weight packer: general_compress order (quantization/utils.py:54-70) + optional LOP3
+// interleave (lop3_permutate_impl.py:12-132).  One 32-bit word at a time.
+// ------------------------------------------------------------------------------------------
+static inline int nibble_move(int bits, int S, int nib) {
+  static const int id[8] = {0, 1, 2, 3, 4, 5, 6, 7};
+  static const int i8_1b[8] = {0, 4, 2, 6, 1, 5, 3, 7};
+  static const int f16_2b[8] = {0, 1, 4, 5, 2, 3, 6, 7};
+  static const int f16_1b[8] = {0, 2, 4, 6, 1, 3, 5, 7};
+  const int* t = id;
+  if (bits == 1 && S == 8) t = i8_1b;
+  else if (bits == 2 && S == 16) t = f16_2b;
+  else if (bits == 1 && S == 16) t = f16_1b;
+  return t[nib];
+}
+static inline int dst_bit(int bits, int S, int o) {
+  const int G = 32 / S;
+  const int b = (o % G) * S + (o / G) * bits;
+  return nibble_move(bits, S, b / 4) * 4 + (b % 4);
+}
+
+}  // namespace wqaa
+
+using namespace wqaa;
+
+extern "C" {
+
+void init(void) {
+  static std::once_flag once;
+  std::call_once(once, [] {
+    if (!device_info().ok) return;
+    gemv_init();
+    gemm_init();
+  });
+}
+
+int wqaa_abi_version(void) { return WQAA_ABI_VERSION; }
+
+int wqaa_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return n;
+}
+
+int wqaa_matmul(const wqaa_matmul_desc* desc, const void* A, const void* B, const void* LUT,
+                const void* Scale, const void* Zeros, const void* Bias, void* C, int m, void* stream) {
+  return matmul_impl(desc, A, B, LUT, Scale, Zeros, Bias, C, m, stream, nullptr, nullptr);
+}
+
+int wqaa_matmul_timed(const wqaa_matmul_desc* desc, const void* A, const void* B, const void* LUT,
+                      const void* Scale, const void* Zeros, const void* Bias, void* C, int m,
+                      void* stream, void* start_event, void* stop_event) {
+  return matmul_impl(desc, A, B, LUT, Scale, Zeros, Bias, C, m, stream, start_event, stop_event);
+}
+
+int wqaa_select(const wqaa_matmul_desc* desc, int m, wqaa_plan* plan) {
+  if (!valid_desc(desc)) return WQAA_ERR_BAD_DESC;
+  if (plan) memset(plan, 0, sizeof(*plan));
+  if (m <= 0) m = 1;
+  bool use_gemm = false;
+  dispatch(*desc, m, &use_gemm);
+  return use_gemm ? gemm_plan(*desc, m, plan) : gemv_plan(*desc, m, plan);
+}
+
+int wqaa_pack_weight(const int8_t* codes, int64_t rows, int64_t cols, int bits, int layout,
+                     int a_dtype, int8_t* out) {
+  if (!codes || !out || rows < 0 || cols < 0 || !(bits == 1 || bits == 2 || bits == 4 || bits == 8)) {
+    set_error(WQAA_ERR_BAD_DESC, "pack_weight: bad arguments (bits=%d)", bits);
+    return WQAA_ERR_BAD_DESC;
+  }
+  const int epb = 8 / bits;
+  if (cols % epb) {
+    set_error(WQAA_ERR_BAD_DESC, "pack_weight: cols=%ld not a multiple of %d", (long)cols, epb);
+    return WQAA_ERR_BAD_DESC;
+  }
+  const int64_t row_bytes = cols / epb;
+  const uint32_t mask = (1u << bits) - 1u;
+  if (bits == 8) {
+    memcpy(out, codes, (size_t)(rows * cols));
+    return WQAA_OK;
+  }
+  if (layout == WQAA_LAYOUT_LOP3 && row_bytes % 4) {
+    set_error(WQAA_ERR_BAD_DESC, "pack_weight: LOP3 layout needs K*bits %% 32 == 0");
+    return WQAA_ERR_BAD_DESC;
+  }
+  const int S = a_dtype == WQAA_I8 ? 8 : 16;
+  const int epw = 32 / bits;
+  int dst[32];
+  for (int o = 0; o < epw; ++o) dst[o] = layout == WQAA_LAYOUT_LOP3 ? dst_bit(bits, S, o) : o * bits;
+  for (int64_t r = 0; r < rows; ++r) {
+    const int8_t* src = codes + r * cols;
+    uint8_t* dstp = reinterpret_cast<uint8_t*>(out) + r * row_bytes;
+    int64_t c = 0;
+    if (layout == WQAA_LAYOUT_LOP3 || row_bytes % 4 == 0) {
+      for (; c + epw <= cols; c += epw) {
+        uint32_t w = 0;
+        for (int o = 0; o < epw; ++o) w |= ((uint32_t)(uint8_t)src[c + o] & mask) << dst[o];
+        memcpy(dstp + (c / epw) * 4, &w, 4);
+      }
+    }
+    for (; c < cols; c += epb) {  // plain tail, byte at a time
+      uint8_t b = 0;
+      for (int k = 0; k < epb; ++k) b |= (uint8_t)(((uint8_t)src[c + k] & mask) << (bits * k));
+      dstp[c / epb] = b;
+    }
+  }
+  return WQAA_OK;
+}
+
+int wqaa_unpack_weight(const int8_t* packed, int64_t rows, int64_t cols, int bits, int layout,
+                       int a_dtype, int8_t* codes) {
+  if (!codes || !packed || !(bits == 1 || bits == 2 || bits == 4 || bits == 8)) {
+    set_error(WQAA_ERR_BAD_DESC, "unpack_weight: bad arguments");
+    return WQAA_ERR_BAD_DESC;
+  }
+  if (bits == 8) {
+    memcpy(codes, packed, (size_t)(rows * cols));
+    return WQAA_OK;
+  }
+  const int epb = 8 / bits, epw = 32 / bits;
+  const int64_t row_bytes = cols / epb;
+  const uint32_t mask = (1u << bits) - 1u;
+  const int S = a_dtype == WQAA_I8 ? 8 : 16;
+  if (layout == WQAA_LAYOUT_LOP3 && row_bytes % 4) {
+    set_error(WQAA_ERR_BAD_DESC, "unpack_weight: LOP3 layout needs K*bits %% 32 == 0");
+    return WQAA_ERR_BAD_DESC;
+  }
+  for (int64_t r = 0; r < rows; ++r) {
+    const uint8_t* src = reinterpret_cast<const uint8_t*>(packed) + r * row_bytes;
+    int8_t* dstp = codes + r * cols;
+    if (layout == WQAA_LAYOUT_LOP3) {
+      for (int64_t c = 0; c < cols; c += epw) {
+        uint32_t w;
+        memcpy(&w, src + (c / epw) * 4, 4);
+        for (int o = 0; o < epw; ++o) dstp[c + o] = (int8_t)((w >> dst_bit(bits, S, o)) & mask);
+      }
+    } else {
+      for (int64_t c = 0; c < cols; ++c) dstp[c] = (int8_t)((src[c / epb] >> (bits * (c % epb))) & mask);
+    }
+  }
+  return WQAA_OK;
+}
+
+int wqaa_debug_decode(const void* packed_dev, int64_t nwords, int w_format, int bits, int layout,
+                      int a_dtype, int strict_reference, const void* lut_dev, void* out_dev,
+                      void* stream) {
+  if (!device_info().ok) {
+    set_error(WQAA_ERR_NO_DEVICE, "no HIP device visible");
+    return WQAA_ERR_NO_DEVICE;
+  }
+  return debug_decode_launch(packed_dev, nwords, w_format, bits, layout, a_dtype, strict_reference,
+                             lut_dev, out_dev, reinterpret_cast<hipStream_t>(stream));
+}
+
+int wqaa_last_error(void) { return g_last_error; }
+const char* wqaa_last_error_string(void) { return g_last_error_msg; }
+
+}  // extern "C"

@@ -1,0 +1,99 @@
+// wqaa_common.h - shared host/device declarations of libwqaa_hip.so (not part of the public ABI)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/wqaa.h"
+
+namespace wqaa {
+
+// weight decode kinds: one static kernel family member per kind
+enum DecodeKind : int {
+  DK_INT4 = 0,   // uint4 / int4 (zero point folded)
+  DK_INT2 = 1,
+  DK_INT1 = 2,
+  DK_INT8 = 3,   // uint8 / int8 weights
+  DK_LUT4 = 4,   // nf4 (LUT from caller) / fp4_e2m1 (built-in table)
+  DK_E4M3 = 5,
+  DK_E5M2 = 6,
+  DK_NATIVE = 7  // W stored in A_dtype
+};
+
+struct GemvArgs {
+  const void* A;
+  const void* B;
+  const void* lut;
+  const void* scale;
+  const void* zeros;
+  const void* bias;
+  void* C;
+  int m;            // activation rows in this call
+  int N, K;
+  int kg;           // groups per weight row (K / group_size)
+  int g_log2;       // log2(group_size) or -1 when not a power of two
+  int g;            // group size (elements)
+  int nc;           // 64-lane chunks per weight row
+  long row_bytes;   // bytes per weight row
+  int zmode;        // wqaa_zeros_mode
+  int has_scale, has_bias;
+  int out_dtype;    // wqaa_dtype
+  int is_signed;    // WQAA_W_INT
+  int strict;       // reference e4m3 bit trick
+  int fp4_table;    // DK_LUT4: 1 = built-in fp4 table, 0 = caller LUT
+  int zq_row_bytes; // quantized zeros: bytes per group row (N*bits/8)
+};
+
+struct LaunchCfg {
+  int grid_x, grid_y;
+  int threads;
+  int lds_bytes;
+  hipStream_t stream;
+  hipEvent_t start, stop;  // optional (nullptr): kernel begin/end timestamps
+};
+
+void set_error(int code, const char* fmt, ...);
+
+// kernel families (each returns a wqaa_status)
+int gemv_plan(const wqaa_matmul_desc& d, int m, wqaa_plan* plan);
+int gemv_launch(const wqaa_matmul_desc& d, const void* A, const void* B, const void* LUT,
+                const void* Scale, const void* Zeros, const void* Bias, void* C, int m,
+                hipStream_t stream, hipEvent_t start, hipEvent_t stop);
+void gemv_init();
+
+int gemm_plan(const wqaa_matmul_desc& d, int m, wqaa_plan* plan);
+int gemm_launch(const wqaa_matmul_desc& d, const void* A, const void* B, const void* LUT,
+                const void* Scale, const void* Zeros, const void* Bias, void* C, int m,
+                hipStream_t stream, hipEvent_t start, hipEvent_t stop);
+void gemm_init();
+
+int debug_decode_launch(const void* packed, int64_t nwords, int w_format, int bits, int layout,
+                        int a_dtype, int strict, const void* lut, void* out, hipStream_t stream);
+
+struct DeviceInfo {
+  int ok;
+  int cus;
+  int lds_per_block;
+  char arch[64];
+};
+const DeviceInfo& device_info();
+
+template <typename K>
+inline hipError_t launch_kernel(K kernel, const LaunchCfg& cfg, void* args_struct) {
+  void* params[] = {args_struct};
+  dim3 grid(cfg.grid_x, cfg.grid_y, 1), block(cfg.threads, 1, 1);
+  if (cfg.start != nullptr || cfg.stop != nullptr) {
+    return hipExtLaunchKernel(reinterpret_cast<const void*>(kernel), grid, block, params,
+                              cfg.lds_bytes, cfg.stream, cfg.start, cfg.stop, 0);
+  }
+  return hipLaunchKernel(reinterpret_cast<const void*>(kernel), grid, block, params, cfg.lds_bytes,
+                         cfg.stream);
+}
+
+inline int ilog2_exact(int v) {
+  if (v <= 0 || (v & (v - 1))) return -1;
+  int l = 0;
+  while ((1 << l) < v) ++l;
+  return l;
+}
+
+}  // namespace wqaa

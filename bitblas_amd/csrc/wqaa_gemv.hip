@@ -1,0 +1,851 @@
+// wqaa_gemv.hip - W_q x A GEMV family for gfx950 (M < 8: the HBM-bound decode case).
+//
+// Replaces the reference's `GemvDequantizeSIMTScheduler` / `GemvFineGrainSIMTScheduler` kernel
+// templates (bitblas/ops/general_matmul/tilelang/dequantize/gemv_dequantize_simt.py:83-262,
+// tilelang/dense/gemv_simt.py:81-185).  Same computation,
+//     C[m, n] = cast_out( sum_k A[m, k] * dq(B[n, k]) ) (+ Bias[n]),
+// different machine mapping:
+//   * one wave64 streams R weight rows; every lane issues 16-byte non-temporal loads, so a wave
+//     instruction fetches 1 KiB of contiguous packed weights (the reference's default issues
+//     4-byte loads per thread);
+//   * D stages of those loads are in flight per wave before anything is consumed - at
+//     N = K = 4096 the whole 8.4 MB weight matrix is requested in the first few hundred cycles;
+//   * the activation rows are staged once per workgroup into LDS as [piece][lane] 16-byte slots,
+//     already permuted into the order the unpack produces (wqaa_decode.h), so ds_read_b128 is
+//     conflict free and the inner loop has no shuffles;
+//   * unpack -> (zero, scale) in packed fp16 exactly as the TE definition does it
+//     (tirscript/matmul_dequantize_impl.py:391-451) -> V_DOT2_F32_F16 / V_DOT4_I32_I8 into
+//     fp32 / int32 accumulators -> DPP row reduction + readlane.
+#include "wqaa_common.h"
+#include "wqaa_decode.h"
+
+namespace wqaa {
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+enum : int { AT_F16 = 0, AT_I8 = 1 };
+
+constexpr int cmax(int a, int b) { return a > b ? a : b; }
+
+template <int KIND, int AT>
+struct KindTraits {
+  static constexpr int BITS = (KIND == DK_INT4 || KIND == DK_LUT4) ? 4
+                              : (KIND == DK_INT2)                  ? 2
+                              : (KIND == DK_INT1)                  ? 1
+                              : (KIND == DK_NATIVE && AT == AT_F16) ? 16
+                                                                    : 8;
+  static constexpr int EPW = 32 / BITS;          // elements per 32-bit word
+  static constexpr int E = 128 / BITS;           // elements per 16-byte lane chunk
+  static constexpr int PE = AT == AT_F16 ? 8 : 16;  // activation elements per 16-byte LDS piece
+  static constexpr int G = cmax(EPW, PE);        // decode unit (elements)
+  static constexpr int WPU = G / EPW;            // words per unit
+  static constexpr int PU = G / PE;              // LDS pieces per unit
+  static constexpr int UNITS = E / G;            // units per lane chunk
+  static constexpr int PIECES = E / PE;          // LDS pieces per lane chunk
+  static constexpr int S = AT == AT_F16 ? 16 : 8;   // LOP3 interleave target width
+  static constexpr bool SUBBYTE = BITS < 8;
+
+  static constexpr int field_of_slot(int xs) {
+    if (!SUBBYTE) return xs;
+    if (AT == AT_I8) return I8Unpack<BITS < 8 ? BITS : 4>::field_of_slot(xs);
+    if (KIND == DK_LUT4) return lut_field_of_slot(xs);
+    return F16Unpack<BITS < 8 ? BITS : 4>::field_of_slot(xs);
+  }
+  // source element (inside the unit) that lands in extraction slot x
+  static constexpr int src_elem(int layout, int x) {
+    const int wi = x / EPW, xs = x % EPW;
+    if (!SUBBYTE) return x;
+    return wi * EPW + src_of_field(BITS, S, layout, field_of_slot(xs));
+  }
+};
+
+// ------------------------------------------------------------------------------------------
+// wave reductions: DPP inside a 16-lane row, readlane across the four rows
+// ------------------------------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+  return __builtin_bit_cast(
+      float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true);
+}
+__device__ __forceinline__ float wave_sum(float v) {
+  v += dpp_f<0xB1>(v);   // quad_perm [1,0,3,2]
+  v += dpp_f<0x4E>(v);   // quad_perm [2,3,0,1]
+  v += dpp_f<0x141>(v);  // row_half_mirror
+  v += dpp_f<0x140>(v);  // row_mirror -> every lane holds its 16-lane row sum
+  const int b = __builtin_bit_cast(int, v);
+  const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 0));
+  const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 16));
+  const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 32));
+  const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(b, 48));
+  return (r0 + r1) + (r2 + r3);
+}
+__device__ __forceinline__ int wave_sum(int v) {
+  v += dpp_i<0xB1>(v);
+  v += dpp_i<0x4E>(v);
+  v += dpp_i<0x141>(v);
+  v += dpp_i<0x140>(v);
+  return (__builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16)) +
+         (__builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48));
+}
+
+// ------------------------------------------------------------------------------------------
+// epilogue: cast to out_dtype, then + bias in out_dtype (the TE graph adds Bias after the cast,
+// matmul_dequantize_impl.py:462-477)
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float bf16_round(float x) {
+  uint32_t u = __builtin_bit_cast(uint32_t, x);
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return __builtin_bit_cast(float, u & 0xFFFF0000u);
+}
+
+__device__ __forceinline__ void store_out(void* C, long idx, float acc, int out_dtype, bool has_bias,
+                                          float bias) {
+  switch (out_dtype) {
+    case WQAA_F16: {
+      half_t v = (half_t)acc;
+      if (has_bias) v = v + (half_t)bias;
+      reinterpret_cast<half_t*>(C)[idx] = v;
+    } break;
+    case WQAA_F32: {
+      float v = acc;
+      if (has_bias) v = v + bias;
+      reinterpret_cast<float*>(C)[idx] = v;
+    } break;
+    case WQAA_BF16: {
+      float v = bf16_round(acc);
+      if (has_bias) v = bf16_round(v + bias);
+      reinterpret_cast<uint16_t*>(C)[idx] = (uint16_t)(__builtin_bit_cast(uint32_t, v) >> 16);
+    } break;
+    default: break;
+  }
+}
+__device__ __forceinline__ void store_out(void* C, long idx, int acc, int out_dtype, bool has_bias,
+                                          int bias) {
+  switch (out_dtype) {
+    case WQAA_I32: reinterpret_cast<int*>(C)[idx] = acc + (has_bias ? bias : 0); break;
+    case WQAA_I8: reinterpret_cast<int8_t*>(C)[idx] = (int8_t)((int8_t)acc + (has_bias ? (int8_t)bias : 0)); break;
+    case WQAA_F32: reinterpret_cast<float*>(C)[idx] = (float)acc + (has_bias ? (float)bias : 0.f); break;
+    case WQAA_F16: {
+      half_t v = (half_t)(float)acc;
+      if (has_bias) v = v + (half_t)(float)bias;
+      reinterpret_cast<half_t*>(C)[idx] = v;
+    } break;
+    default: break;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// the kernel
+// ------------------------------------------------------------------------------------------
+template <int KIND_, int LAYOUT_, int AT_, int MB_, int R_, int D_>
+struct GemvPolicy {
+  static constexpr int KIND = KIND_, LAYOUT = LAYOUT_, AT = AT_, MB = MB_, R = R_, D = D_;
+  static constexpr int THREADS = 256;
+  using T = KindTraits<KIND_, AT_>;
+};
+
+template <class P>
+struct Stage {
+  u32x4 w[P::R];
+  uint32_t sz[P::R];  // scale bits | zero bits << 16 (kept in one 32-bit register per row)
+};
+
+__device__ __forceinline__ half_t stage_scale(uint32_t sz) { return __builtin_bit_cast(half_t, (uint16_t)(sz & 0xFFFFu)); }
+__device__ __forceinline__ half_t stage_zero(uint32_t sz) { return __builtin_bit_cast(half_t, (uint16_t)(sz >> 16)); }
+
+// source activation dtype handled while staging (A may be fp16, or fp8 widened to fp16)
+enum : int { ASRC_F16 = 0, ASRC_E4M3 = 1, ASRC_E5M2 = 2, ASRC_I8 = 3 };
+
+__device__ __forceinline__ half_t fp8_to_half(uint8_t v, bool e5m2) {
+  if (e5m2) return __builtin_bit_cast(half_t, (uint16_t)((uint16_t)v << 8));
+  const uint16_t mag = (uint16_t)((v & 0x7Fu) << 7);
+  half_t h = __builtin_bit_cast(half_t, mag) * (half_t)256.0f;
+  const uint16_t bits = (uint16_t)(__builtin_bit_cast(uint16_t, h) | ((uint16_t)(v & 0x80u) << 8));
+  return __builtin_bit_cast(half_t, bits);
+}
+
+template <class P>
+__device__ __forceinline__ void stage_activations(const GemvArgs& a, int m0, int a_src, u32x4* a_lds) {
+  using T = typename P::T;
+  constexpr int G = T::G, PE = T::PE, PU = T::PU, UNITS = T::UNITS, PIECES = T::PIECES, E = T::E;
+  const int nc = a.nc;
+  const int total = P::MB * nc * 64 * UNITS;
+  for (int idx = threadIdx.x; idx < total; idx += P::THREADS) {
+    const int l = idx & 63;
+    int t = idx >> 6;
+    const int u = t % UNITS;
+    t /= UNITS;
+    const int c = t % nc;
+    const int mi = t / nc;
+    const long kb = (long)(c * 64 + l) * E + u * G;
+    const bool valid = kb < a.K && (m0 + mi) < a.m;
+    const long src_off = (long)(m0 + mi) * a.K + kb;
+    if constexpr (P::AT == AT_F16) {
+      half_t src[G];
+      if (valid) {
+        if (a_src == ASRC_F16) {
+          const u32x4* p = reinterpret_cast<const u32x4*>(reinterpret_cast<const half_t*>(a.A) + src_off);
+#pragma unroll
+          for (int q = 0; q < G / 8; ++q) {
+            const u32x4 v = p[q];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const half2_t h = as_h2(v[e]);
+              src[q * 8 + 2 * e] = h[0];
+              src[q * 8 + 2 * e + 1] = h[1];
+            }
+          }
+        } else {
+          const uint8_t* p = reinterpret_cast<const uint8_t*>(a.A) + src_off;
+#pragma unroll
+          for (int e = 0; e < G; ++e) src[e] = fp8_to_half(p[e], a_src == ASRC_E5M2);
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < G; ++e) src[e] = (half_t)0.0f;
+      }
+#pragma unroll
+      for (int pp = 0; pp < PU; ++pp) {
+        u32x4 out;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const half2_t h = {src[T::src_elem(P::LAYOUT, pp * PE + 2 * e)],
+                             src[T::src_elem(P::LAYOUT, pp * PE + 2 * e + 1)]};
+          out[e] = as_u32(h);
+        }
+        a_lds[((long)(mi * nc + c) * PIECES + u * PU + pp) * 64 + l] = out;
+      }
+    } else {
+      uint8_t src[G];
+      if (valid) {
+        const uint32_t* p = reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(a.A) + src_off);
+#pragma unroll
+        for (int q = 0; q < G / 4; ++q) {
+          const uint32_t v = p[q];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) src[q * 4 + e] = (uint8_t)(v >> (8 * e));
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < G; ++e) src[e] = 0;
+      }
+#pragma unroll
+      for (int pp = 0; pp < PU; ++pp) {
+        u32x4 out;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          uint32_t v = 0;
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            v |= (uint32_t)src[T::src_elem(P::LAYOUT, pp * PE + 4 * q + e)] << (8 * e);
+          out[q] = v;
+        }
+        a_lds[((long)(mi * nc + c) * PIECES + u * PU + pp) * 64 + l] = out;
+      }
+    }
+  }
+}
+
+// decode one unit of row r into fp16 pairs (exact field values minus folded zero point)
+template <class P>
+__device__ __forceinline__ void decode_unit_f16(const u32x4& w, int u, half_t zf, const GemvArgs& a,
+                                                const Lut16& lut, half2_t (&q)[P::T::G / 2]) {
+  using T = typename P::T;
+  constexpr int WPU = T::WPU;
+  if constexpr (P::KIND == DK_INT4 || P::KIND == DK_INT2 || P::KIND == DK_INT1) {
+    F16Unpack<T::BITS>::run(w[u], zf, q);
+  } else if constexpr (P::KIND == DK_LUT4) {
+    lut16_word(lut, w[u], q);
+  } else if constexpr (P::KIND == DK_INT8) {
+#pragma unroll
+    for (int j = 0; j < WPU; ++j) {
+      half2_t t[2];
+      if (a.is_signed) unpack8_f16<true>(w[u * WPU + j], zf, t);
+      else unpack8_f16<false>(w[u * WPU + j], zf, t);
+      q[2 * j] = t[0];
+      q[2 * j + 1] = t[1];
+    }
+  } else if constexpr (P::KIND == DK_E4M3) {
+#pragma unroll
+    for (int j = 0; j < WPU; ++j) {
+      half2_t t[2];
+      if (a.strict) unpack_e4m3_f16<true>(w[u * WPU + j], t);
+      else unpack_e4m3_f16<false>(w[u * WPU + j], t);
+      q[2 * j] = t[0];
+      q[2 * j + 1] = t[1];
+    }
+  } else if constexpr (P::KIND == DK_E5M2) {
+#pragma unroll
+    for (int j = 0; j < WPU; ++j) {
+      half2_t t[2];
+      unpack_e5m2_f16(w[u * WPU + j], t);
+      q[2 * j] = t[0];
+      q[2 * j + 1] = t[1];
+    }
+  } else {  // native fp16 weights
+#pragma unroll
+    for (int j = 0; j < WPU; ++j) q[j] = as_h2(w[u * WPU + j]);
+  }
+}
+
+template <class P>
+__device__ __forceinline__ void decode_unit_i8(const u32x4& w, int u, uint32_t zp4,
+                                               uint32_t (&q)[P::T::G / 4]) {
+  using T = typename P::T;
+  if constexpr (T::SUBBYTE) {
+    constexpr int NQ = I8Unpack<T::BITS>::NQUAD;
+#pragma unroll
+    for (int j = 0; j < T::WPU; ++j) {
+      uint32_t t[NQ];
+      I8Unpack<T::BITS>::run(w[u * T::WPU + j], t);
+#pragma unroll
+      for (int i = 0; i < NQ; ++i) q[j * NQ + i] = zp4 ? sub_bytes(t[i], zp4) : t[i];
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < T::WPU; ++j) q[j] = w[u * T::WPU + j];
+  }
+}
+
+template <class P>
+__global__ void __launch_bounds__(256) wq_gemv_kernel(const GemvArgs a, const int a_src) {
+  using T = typename P::T;
+  constexpr int R = P::R, MB = P::MB, D = P::D;
+  constexpr int E = T::E, G = T::G, PE = T::PE, PU = T::PU, UNITS = T::UNITS, PIECES = T::PIECES;
+  constexpr int NW = P::THREADS / 64;
+  constexpr bool F16 = P::AT == AT_F16;
+  using acc_t = typename std::conditional<F16, float, int>::type;
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  u32x4* a_lds = reinterpret_cast<u32x4*>(smem_raw);
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nc = a.nc;
+  const int n_rg = (a.N + R - 1) / R;
+  const int total_waves = gridDim.x * NW;
+  const int wg = blockIdx.x * NW + wave;
+  const int m0 = blockIdx.y * MB;
+  const uint8_t* Bp = reinterpret_cast<const uint8_t*>(a.B);
+  const uint16_t* Sp = reinterpret_cast<const uint16_t*>(a.scale);
+
+  Stage<P> st[D];
+  int ld_rg = wg, ld_c = 0;
+
+  auto issue = [&](Stage<P>& s) {
+    const int chunk = ld_c * 64 + lane;
+    const long k0 = (long)chunk * E;
+    const bool kvalid = k0 < a.K;
+    int gi = 0;
+    if (a.kg > 1) gi = a.g_log2 >= 0 ? (int)(k0 >> a.g_log2) : (int)(k0 / a.g);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      int n = ld_rg * R + r;
+      n = n < a.N ? n : a.N - 1;
+      s.w[r] = u32x4{0u, 0u, 0u, 0u};
+      uint32_t sbits = 0, zbits = 0;
+      if (kvalid) {
+        s.w[r] = __builtin_nontemporal_load(
+            reinterpret_cast<const u32x4*>(Bp + (long)n * a.row_bytes + (long)chunk * 16));
+        if constexpr (F16) {
+          if (a.has_scale) sbits = Sp[(long)n * a.kg + gi];
+          if (a.zmode == WQAA_Z_ORIGINAL || a.zmode == WQAA_Z_RESCALE) {
+            zbits = reinterpret_cast<const uint16_t*>(a.zeros)[(long)n * a.kg + gi];
+          } else if (a.zmode == WQAA_Z_QUANTIZED) {
+            constexpr int ZB = T::SUBBYTE ? T::BITS : 8;
+            constexpr int ZPB = 8 / ZB;
+            const uint8_t zb = reinterpret_cast<const uint8_t*>(a.zeros)[(long)gi * a.zq_row_bytes + n / ZPB];
+            const uint32_t zq = (zb >> ((n % ZPB) * ZB)) & ((1u << ZB) - 1u);
+            zbits = __builtin_bit_cast(uint16_t, (half_t)(float)zq);
+          }
+        }
+      }
+      s.sz[r] = sbits | (zbits << 16);
+    }
+    if (++ld_c == nc) {
+      ld_c = 0;
+      ld_rg += total_waves;
+    }
+  };
+
+  // ---- prologue: put D stages of weight loads in flight, then stage the activations ----
+#pragma unroll
+  for (int d = 0; d < D; ++d)
+    if (ld_rg < n_rg) issue(st[d]);
+
+  stage_activations<P>(a, m0, a_src, a_lds);
+
+  Lut16 lut;
+  if constexpr (P::KIND == DK_LUT4) {
+    if (a.fp4_table) {
+      lut = make_fp4_lut();
+    } else {
+      lut = make_lut16(reinterpret_cast<const half_t*>(a.lut));
+    }
+  }
+  __syncthreads();
+
+  acc_t acc[R][MB];
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+#pragma unroll
+    for (int mi = 0; mi < MB; ++mi) acc[r][mi] = 0;
+
+  const half_t zf_const = (F16 && a.is_signed && T::SUBBYTE) ? (half_t)(float)(1 << (T::BITS - 1)) : (half_t)0.0f;
+  const uint32_t zp4 = (!F16 && a.is_signed && T::SUBBYTE) ? (uint32_t)(1u << (T::BITS - 1)) * 0x01010101u : 0u;
+
+  int cs_rg = wg, cs_c = 0;
+
+  auto consume = [&](const Stage<P>& s) {
+#pragma unroll
+    for (int u = 0; u < UNITS; ++u) {
+      if constexpr (F16) {
+        half2_t q[R][G / 2];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const half_t zf = a.zmode == WQAA_Z_QUANTIZED ? stage_zero(s.sz[r]) : zf_const;
+          decode_unit_f16<P>(s.w[r], u, zf, a, lut, q[r]);
+          if (a.zmode == WQAA_Z_ORIGINAL) {
+            const half2_t z2 = splat(stage_zero(s.sz[r])), s2 = splat(stage_scale(s.sz[r]));
+#pragma unroll
+            for (int i = 0; i < G / 2; ++i) q[r][i] = (q[r][i] - z2) * s2;
+          } else if (a.zmode == WQAA_Z_RESCALE) {
+            const half2_t z2 = splat(stage_zero(s.sz[r])), s2 = splat(stage_scale(s.sz[r]));
+#pragma unroll
+            for (int i = 0; i < G / 2; ++i) {
+              half2_t t = q[r][i] * s2;
+              // keep the two roundings of `w * Scale - Zeros` (no contraction into an fma)
+              asm volatile("" : "+v"(t));
+              q[r][i] = t - z2;
+            }
+          } else if (a.has_scale) {
+            const half2_t s2 = splat(stage_scale(s.sz[r]));
+#pragma unroll
+            for (int i = 0; i < G / 2; ++i) q[r][i] = q[r][i] * s2;
+          }
+        }
+#pragma unroll
+        for (int pp = 0; pp < PU; ++pp) {
+#pragma unroll
+          for (int mi = 0; mi < MB; ++mi) {
+            const u32x4 av = a_lds[((long)(mi * nc + cs_c) * PIECES + u * PU + pp) * 64 + lane];
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+                acc[r][mi] = __builtin_amdgcn_fdot2(q[r][pp * 4 + e], as_h2(av[e]), acc[r][mi], false);
+          }
+        }
+      } else {
+        uint32_t q[R][G / 4];
+#pragma unroll
+        for (int r = 0; r < R; ++r) decode_unit_i8<P>(s.w[r], u, zp4, q[r]);
+#pragma unroll
+        for (int pp = 0; pp < PU; ++pp) {
+#pragma unroll
+          for (int mi = 0; mi < MB; ++mi) {
+            const u32x4 av = a_lds[((long)(mi * nc + cs_c) * PIECES + u * PU + pp) * 64 + lane];
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+                acc[r][mi] = __builtin_amdgcn_sdot4((int)av[e], (int)q[r][pp * 4 + e], acc[r][mi], false);
+          }
+        }
+      }
+    }
+  };
+
+  auto finish = [&]() {
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int n = cs_rg * R + r;
+#pragma unroll
+      for (int mi = 0; mi < MB; ++mi) {
+        const acc_t tot = wave_sum(acc[r][mi]);
+        acc[r][mi] = 0;
+        if (lane == 0 && n < a.N && (m0 + mi) < a.m) {
+          if constexpr (F16) {
+            const float b = a.has_bias ? (float)reinterpret_cast<const half_t*>(a.bias)[n] : 0.f;
+            store_out(a.C, (long)(m0 + mi) * a.N + n, tot, a.out_dtype, a.has_bias != 0, b);
+          } else {
+            const int b = a.has_bias ? (int)reinterpret_cast<const int8_t*>(a.bias)[n] : 0;
+            store_out(a.C, (long)(m0 + mi) * a.N + n, tot, a.out_dtype, a.has_bias != 0, b);
+          }
+        }
+      }
+    }
+  };
+
+  while (cs_rg < n_rg) {
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      if (cs_rg < n_rg) {
+        consume(st[d]);
+        if (cs_c == nc - 1) finish();
+        if (++cs_c == nc) {
+          cs_c = 0;
+          cs_rg += total_waves;
+        }
+        if (ld_rg < n_rg) issue(st[d]);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// host side: kernel table + tile-config selector
+// ------------------------------------------------------------------------------------------
+typedef void (*gemv_fn)(const GemvArgs, const int);
+
+// widest batch tile instantiated per kind (register budget: 1-/2-bit units decode 32/16 values)
+static int max_mb(int kind, int at) {
+  if (at == AT_F16 && kind == DK_INT1) return 2;
+  if (at == AT_F16 && kind == DK_INT2) return 4;
+  return 8;
+}
+
+template <int KIND, int LAYOUT, int AT>
+static gemv_fn pick_mb(int mb, int* R, int* D) {
+  constexpr int MAXMB = (AT == AT_F16 && KIND == DK_INT1) ? 2 : (AT == AT_F16 && KIND == DK_INT2) ? 4 : 8;
+  if constexpr (MAXMB < 8) {
+    if (mb > MAXMB) return nullptr;
+  }
+  switch (mb) {
+    case 1: *R = 2; *D = 2; return wq_gemv_kernel<GemvPolicy<KIND, LAYOUT, AT, 1, 2, 2>>;
+    case 2: *R = 2; *D = 2; return wq_gemv_kernel<GemvPolicy<KIND, LAYOUT, AT, 2, 2, 2>>;
+    case 4:
+      if constexpr (MAXMB >= 4) { *R = 2; *D = 2; return wq_gemv_kernel<GemvPolicy<KIND, LAYOUT, AT, 4, 2, 2>>; }
+      return nullptr;
+    default:
+      if constexpr (MAXMB >= 8) { *R = 2; *D = 1; return wq_gemv_kernel<GemvPolicy<KIND, LAYOUT, AT, 8, 2, 1>>; }
+      return nullptr;
+  }
+}
+
+static gemv_fn pick_kernel(int kind, int layout, int at, int mb, int* R, int* D) {
+#define WQAA_PICK(K, L, A) \
+  if (kind == K && layout == L && at == A) return pick_mb<K, L, A>(mb, R, D)
+  WQAA_PICK(DK_INT4, LAYOUT_LOP3, AT_F16);
+  WQAA_PICK(DK_INT4, LAYOUT_PLAIN, AT_F16);
+  WQAA_PICK(DK_INT2, LAYOUT_LOP3, AT_F16);
+  WQAA_PICK(DK_INT2, LAYOUT_PLAIN, AT_F16);
+  WQAA_PICK(DK_INT1, LAYOUT_LOP3, AT_F16);
+  WQAA_PICK(DK_INT1, LAYOUT_PLAIN, AT_F16);
+  WQAA_PICK(DK_INT8, LAYOUT_PLAIN, AT_F16);
+  WQAA_PICK(DK_LUT4, LAYOUT_PLAIN, AT_F16);
+  WQAA_PICK(DK_E4M3, LAYOUT_PLAIN, AT_F16);
+  WQAA_PICK(DK_E5M2, LAYOUT_PLAIN, AT_F16);
+  WQAA_PICK(DK_NATIVE, LAYOUT_PLAIN, AT_F16);
+  WQAA_PICK(DK_INT4, LAYOUT_LOP3, AT_I8);
+  WQAA_PICK(DK_INT4, LAYOUT_PLAIN, AT_I8);
+  WQAA_PICK(DK_INT2, LAYOUT_LOP3, AT_I8);
+  WQAA_PICK(DK_INT2, LAYOUT_PLAIN, AT_I8);
+  WQAA_PICK(DK_INT1, LAYOUT_LOP3, AT_I8);
+  WQAA_PICK(DK_INT1, LAYOUT_PLAIN, AT_I8);
+  WQAA_PICK(DK_NATIVE, LAYOUT_PLAIN, AT_I8);
+#undef WQAA_PICK
+  return nullptr;
+}
+
+struct GemvChoice {
+  gemv_fn fn;
+  int kind, layout, at, a_src, mb, R, D;
+  int bits;
+  int E;
+  int nc;
+  int grid_x, grid_y, lds;
+  int fp4_table;
+};
+
+static int classify(const wqaa_matmul_desc& d, GemvChoice* c) {
+  const int a = d.a_dtype;
+  c->fp4_table = 0;
+  c->layout = d.w_layout == WQAA_LAYOUT_LOP3 ? LAYOUT_LOP3 : LAYOUT_PLAIN;
+  if (a == WQAA_F16) {
+    c->at = AT_F16;
+    c->a_src = ASRC_F16;
+  } else if (a == WQAA_I8) {
+    c->at = AT_I8;
+    c->a_src = ASRC_I8;
+  } else if (a == WQAA_E4M3 || a == WQAA_E5M2) {
+    c->at = AT_F16;
+    c->a_src = a == WQAA_E4M3 ? ASRC_E4M3 : ASRC_E5M2;
+  } else {
+    set_error(WQAA_ERR_UNSUPPORTED, "gemv: A dtype %d not supported", a);
+    return WQAA_ERR_UNSUPPORTED;
+  }
+  c->bits = d.w_bits;
+  switch (d.w_format) {
+    case WQAA_W_UINT:
+    case WQAA_W_INT:
+      c->kind = d.w_bits == 4 ? DK_INT4 : d.w_bits == 2 ? DK_INT2 : d.w_bits == 1 ? DK_INT1 : d.w_bits == 8 ? DK_INT8 : -1;
+      if (c->kind == DK_INT8 && c->at == AT_I8) c->kind = DK_NATIVE;
+      break;
+    case WQAA_W_NF: c->kind = d.w_bits == 4 ? DK_LUT4 : -1; break;
+    case WQAA_W_FP4: c->kind = d.w_bits == 4 ? DK_LUT4 : -1; c->fp4_table = 1; break;
+    case WQAA_W_E4M3: c->kind = DK_E4M3; break;
+    case WQAA_W_E5M2: c->kind = DK_E5M2; break;
+    case WQAA_W_NATIVE:
+      if (a == WQAA_E4M3) c->kind = DK_E4M3;
+      else if (a == WQAA_E5M2) c->kind = DK_E5M2;
+      else c->kind = DK_NATIVE;
+      c->bits = a == WQAA_F16 ? 16 : 8;
+      break;
+    default: c->kind = -1;
+  }
+  if (c->kind < 0) {
+    set_error(WQAA_ERR_UNSUPPORTED, "gemv: weight format %d / %d bits not supported", d.w_format, d.w_bits);
+    return WQAA_ERR_UNSUPPORTED;
+  }
+  if (c->kind != DK_INT4 && c->kind != DK_INT2 && c->kind != DK_INT1) c->layout = LAYOUT_PLAIN;
+  if (c->at == AT_I8 && (d.with_scaling || d.zeros_mode != WQAA_Z_NONE)) {
+    set_error(WQAA_ERR_UNSUPPORTED, "gemv: scale/zeros with int8 activations are not defined by the reference");
+    return WQAA_ERR_UNSUPPORTED;
+  }
+  c->E = 128 / c->bits;
+  if (d.K % c->E != 0) {
+    set_error(WQAA_ERR_UNSUPPORTED, "gemv: K=%d must be a multiple of %d for %d-bit weights", d.K, c->E, c->bits);
+    return WQAA_ERR_UNSUPPORTED;
+  }
+  const int g = d.group_size <= 0 ? d.K : d.group_size;
+  if (d.K % g != 0 || ((d.with_scaling || d.zeros_mode != WQAA_Z_NONE) && g % c->E != 0)) {
+    set_error(WQAA_ERR_UNSUPPORTED, "gemv: group_size=%d must divide K=%d and be a multiple of %d", g, d.K, c->E);
+    return WQAA_ERR_UNSUPPORTED;
+  }
+  c->nc = (d.K / c->E + 63) / 64;
+  return WQAA_OK;
+}
+
+// tile-config selection: batch tile MB, rows per wave R, pipeline depth D, grid.
+// The table is small on purpose: the GEMV is bandwidth bound, what matters is (a) every CU gets
+// work (grid >= 2 x CUs when N allows), (b) >= ~24 KiB of weight loads in flight per CU.
+static int choose(const wqaa_matmul_desc& d, int m, GemvChoice* c) {
+  int st = classify(d, c);
+  if (st != WQAA_OK) return st;
+  int mb = m <= 1 ? 1 : m <= 2 ? 2 : m <= 4 ? 4 : 8;
+  if (mb > max_mb(c->kind, c->at)) mb = max_mb(c->kind, c->at);
+  c->mb = mb;
+  c->fn = pick_kernel(c->kind, c->layout, c->at, mb, &c->R, &c->D);
+  if (!c->fn) {
+    set_error(WQAA_ERR_UNSUPPORTED, "gemv: no kernel for kind=%d layout=%d at=%d", c->kind, c->layout, c->at);
+    return WQAA_ERR_UNSUPPORTED;
+  }
+  const int cus = device_info().ok ? device_info().cus : 256;
+  const long kpad = (long)c->nc * 64 * c->E;
+  c->lds = (int)(mb * kpad * (c->at == AT_F16 ? 2 : 1));
+  if (c->lds > 160 * 1024) {
+    set_error(WQAA_ERR_UNSUPPORTED, "gemv: activation tile %d B exceeds LDS", c->lds);
+    return WQAA_ERR_UNSUPPORTED;
+  }
+  const int n_rg = (d.N + c->R - 1) / c->R;
+  const int waves_needed = n_rg;                 // one row group per wave at minimum
+  int blocks = (waves_needed + 3) / 4;
+  // cap: enough blocks to fill the chip several times over, grid-stride beyond that
+  int blocks_per_cu = 160 * 1024 / (c->lds > 0 ? c->lds : 1);
+  if (blocks_per_cu > 8) blocks_per_cu = 8;
+  if (blocks_per_cu < 1) blocks_per_cu = 1;
+  const int cap = cus * blocks_per_cu;
+  if (blocks > cap) blocks = cap;
+  if (blocks < 1) blocks = 1;
+  c->grid_x = blocks;
+  c->grid_y = (m + mb - 1) / mb;
+  return WQAA_OK;
+}
+
+static void fill_args(const wqaa_matmul_desc& d, const GemvChoice& c, const void* A, const void* B,
+                      const void* LUT, const void* Scale, const void* Zeros, const void* Bias, void* C,
+                      int m, GemvArgs* a) {
+  const int g = d.group_size <= 0 ? d.K : d.group_size;
+  a->A = A; a->B = B; a->lut = LUT; a->scale = Scale; a->zeros = Zeros; a->bias = Bias; a->C = C;
+  a->m = m; a->N = d.N; a->K = d.K;
+  a->kg = d.K / g;
+  a->g = g;
+  a->g_log2 = ilog2_exact(g);
+  a->nc = c.nc;
+  a->row_bytes = (long)d.K * c.bits / 8;
+  a->zmode = d.zeros_mode;
+  a->has_scale = d.with_scaling;
+  a->has_bias = d.with_bias;
+  a->out_dtype = d.out_dtype;
+  a->is_signed = d.w_format == WQAA_W_INT;
+  a->strict = d.strict_reference && d.w_format == WQAA_W_E4M3 && d.a_dtype == WQAA_F16;
+  a->fp4_table = c.fp4_table;
+  a->zq_row_bytes = d.N * (c.bits < 8 ? c.bits : 8) / 8;
+}
+
+static const char* short_dtype(int dt) {
+  switch (dt) {
+    case WQAA_F16: return "f16"; case WQAA_BF16: return "bf16"; case WQAA_F32: return "f32";
+    case WQAA_I8: return "i8"; case WQAA_I32: return "i32"; case WQAA_E4M3: return "e4m3"; case WQAA_E5M2: return "e5m2";
+  }
+  return "x";
+}
+static void short_wdtype(const wqaa_matmul_desc& d, char* buf, size_t n) {
+  switch (d.w_format) {
+    case WQAA_W_UINT: snprintf(buf, n, "u%d", d.w_bits); break;
+    case WQAA_W_INT: snprintf(buf, n, "i%d", d.w_bits); break;
+    case WQAA_W_NF: snprintf(buf, n, "nf%d", d.w_bits); break;
+    case WQAA_W_FP4: snprintf(buf, n, "fp4_e2m1"); break;
+    case WQAA_W_E4M3: snprintf(buf, n, "e4m3"); break;
+    case WQAA_W_E5M2: snprintf(buf, n, "e5m2"); break;
+    default: snprintf(buf, n, "%s", short_dtype(d.a_dtype));
+  }
+}
+
+int gemv_plan(const wqaa_matmul_desc& d, int m, wqaa_plan* plan) {
+  GemvChoice c;
+  int st = choose(d, m, &c);
+  if (st != WQAA_OK) return st;
+  if (plan) {
+    plan->kernel_family = 1;
+    plan->block_m = c.mb;
+    plan->block_n = c.R * 4;
+    plan->block_k = 64 * c.E;
+    plan->threads = 256;
+    plan->grid = c.grid_x * c.grid_y;
+    plan->rows_per_wave = c.R;
+    plan->batch_tile = c.mb;
+    plan->pipeline_depth = c.D;
+    plan->split_k = 1;
+    plan->lds_bytes = c.lds;
+    char wd[24];
+    short_wdtype(d, wd, sizeof(wd));
+    snprintf(plan->name, sizeof(plan->name), "matmul_m%dn%dk%d_%sx%s_gemv_b%dr%dd%d", m, d.N, d.K,
+             short_dtype(d.a_dtype), wd, c.mb, c.R, c.D);
+  }
+  return WQAA_OK;
+}
+
+int gemv_launch(const wqaa_matmul_desc& d, const void* A, const void* B, const void* LUT,
+                const void* Scale, const void* Zeros, const void* Bias, void* C, int m,
+                hipStream_t stream, hipEvent_t start, hipEvent_t stop) {
+  GemvChoice c;
+  int st = choose(d, m, &c);
+  if (st != WQAA_OK) return st;
+  GemvArgs a;
+  fill_args(d, c, A, B, LUT, Scale, Zeros, Bias, C, m, &a);
+  int a_src = c.a_src;
+  void* params[] = {&a, &a_src};
+  dim3 grid(c.grid_x, c.grid_y, 1), block(256, 1, 1);
+  hipError_t e;
+  if (start || stop) {
+    e = hipExtLaunchKernel(reinterpret_cast<const void*>(c.fn), grid, block, params, c.lds, stream, start, stop, 0);
+  } else {
+    e = hipLaunchKernel(reinterpret_cast<const void*>(c.fn), grid, block, params, c.lds, stream);
+  }
+  if (e != hipSuccess) {
+    set_error(WQAA_ERR_LAUNCH, "gemv launch failed: %s", hipGetErrorString(e));
+    return WQAA_ERR_LAUNCH;
+  }
+  return WQAA_OK;
+}
+
+void gemv_init() {
+  // raise the dynamic-LDS ceiling of every family member to the full 160 KiB
+  const int kinds[] = {DK_INT4, DK_INT2, DK_INT1, DK_INT8, DK_LUT4, DK_E4M3, DK_E5M2, DK_NATIVE};
+  for (int kind : kinds)
+    for (int layout = 0; layout < 2; ++layout)
+      for (int at = 0; at < 2; ++at)
+        for (int mb : {1, 2, 4, 8}) {
+          int R, D;
+          gemv_fn fn = pick_kernel(kind, layout, at, mb, &R, &D);
+          if (fn) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        }
+}
+
+// ------------------------------------------------------------------------------------------
+// decode known-answer kernel (HIP twin of testing/cpp/lop3_type_conversion/*.cu): decode packed
+// words with the exact routines above and scatter the values back to source order.
+// ------------------------------------------------------------------------------------------
+template <int KIND, int LAYOUT, int AT>
+__global__ void debug_decode_kernel(const uint32_t* packed, long nwords, int is_signed, int strict,
+                                    int fp4_table, const half_t* lut_p, void* out) {
+  using T = KindTraits<KIND, AT>;
+  constexpr int EPW = T::EPW;
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nwords) return;
+  const uint32_t w = packed[i];
+  if constexpr (AT == AT_F16) {
+    half2_t q[EPW / 2 > 0 ? EPW / 2 : 1];
+    const half_t zf = (is_signed && T::SUBBYTE) ? (half_t)(float)(1 << (T::BITS - 1)) : (half_t)0.0f;
+    if constexpr (KIND == DK_INT4 || KIND == DK_INT2 || KIND == DK_INT1) {
+      F16Unpack<T::BITS>::run(w, zf, q);
+    } else if constexpr (KIND == DK_LUT4) {
+      Lut16 lut = fp4_table ? make_fp4_lut() : make_lut16(lut_p);
+      lut16_word(lut, w, q);
+    } else if constexpr (KIND == DK_INT8) {
+      half2_t t[2];
+      if (is_signed) unpack8_f16<true>(w, zf, t); else unpack8_f16<false>(w, zf, t);
+      q[0] = t[0]; q[1] = t[1];
+    } else if constexpr (KIND == DK_E4M3) {
+      half2_t t[2];
+      if (strict) unpack_e4m3_f16<true>(w, t); else unpack_e4m3_f16<false>(w, t);
+      q[0] = t[0]; q[1] = t[1];
+    } else if constexpr (KIND == DK_E5M2) {
+      half2_t t[2];
+      unpack_e5m2_f16(w, t);
+      q[0] = t[0]; q[1] = t[1];
+    } else {
+      q[0] = as_h2(w);
+    }
+    half_t* o = reinterpret_cast<half_t*>(out) + i * EPW;
+#pragma unroll
+    for (int x = 0; x < EPW; ++x) {
+      const int src = T::SUBBYTE ? src_of_field(T::BITS, T::S, LAYOUT, T::field_of_slot(x)) : x;
+      o[src] = q[x / 2][x & 1];
+    }
+  } else {
+    int8_t* o = reinterpret_cast<int8_t*>(out) + i * EPW;
+    if constexpr (T::SUBBYTE) {
+      uint32_t q[I8Unpack<T::BITS>::NQUAD];
+      I8Unpack<T::BITS>::run(w, q);
+      const uint32_t zp4 = is_signed ? (uint32_t)(1u << (T::BITS - 1)) * 0x01010101u : 0u;
+#pragma unroll
+      for (int x = 0; x < EPW; ++x) {
+        const uint32_t v = zp4 ? sub_bytes(q[x / 4], zp4) : q[x / 4];
+        const int src = src_of_field(T::BITS, T::S, LAYOUT, T::field_of_slot(x));
+        o[src] = (int8_t)(v >> (8 * (x & 3)));
+      }
+    } else {
+#pragma unroll
+      for (int x = 0; x < 4; ++x) o[x] = (int8_t)(w >> (8 * x));
+    }
+  }
+}
+
+int debug_decode_launch(const void* packed, int64_t nwords, int w_format, int bits, int layout,
+                        int a_dtype, int strict, const void* lut, void* out, hipStream_t stream) {
+  wqaa_matmul_desc d = {};
+  d.a_dtype = a_dtype; d.w_format = w_format; d.w_bits = bits; d.w_layout = layout;
+  d.K = 128; d.N = 1; d.group_size = -1;
+  GemvChoice c;
+  int st = classify(d, &c);
+  if (st != WQAA_OK) return st;
+  const int is_signed = w_format == WQAA_W_INT;
+  const dim3 block(256), grid((unsigned)((nwords + 255) / 256));
+  const uint32_t* p = reinterpret_cast<const uint32_t*>(packed);
+  const half_t* lp = reinterpret_cast<const half_t*>(lut);
+  const int str = strict && w_format == WQAA_W_E4M3;
+#define WQAA_DBG(K, L, A) \
+  if (c.kind == K && c.layout == L && c.at == A) { \
+    hipLaunchKernelGGL((debug_decode_kernel<K, L, A>), grid, block, 0, stream, p, (long)nwords, is_signed, str, c.fp4_table, lp, out); \
+    return WQAA_OK; }
+  WQAA_DBG(DK_INT4, LAYOUT_LOP3, AT_F16) WQAA_DBG(DK_INT4, LAYOUT_PLAIN, AT_F16)
+  WQAA_DBG(DK_INT2, LAYOUT_LOP3, AT_F16) WQAA_DBG(DK_INT2, LAYOUT_PLAIN, AT_F16)
+  WQAA_DBG(DK_INT1, LAYOUT_LOP3, AT_F16) WQAA_DBG(DK_INT1, LAYOUT_PLAIN, AT_F16)
+  WQAA_DBG(DK_INT8, LAYOUT_PLAIN, AT_F16) WQAA_DBG(DK_LUT4, LAYOUT_PLAIN, AT_F16)
+  WQAA_DBG(DK_E4M3, LAYOUT_PLAIN, AT_F16) WQAA_DBG(DK_E5M2, LAYOUT_PLAIN, AT_F16)
+  WQAA_DBG(DK_INT4, LAYOUT_LOP3, AT_I8) WQAA_DBG(DK_INT4, LAYOUT_PLAIN, AT_I8)
+  WQAA_DBG(DK_INT2, LAYOUT_LOP3, AT_I8) WQAA_DBG(DK_INT2, LAYOUT_PLAIN, AT_I8)
+  WQAA_DBG(DK_INT1, LAYOUT_LOP3, AT_I8) WQAA_DBG(DK_INT1, LAYOUT_PLAIN, AT_I8)
+#undef WQAA_DBG
+  set_error(WQAA_ERR_UNSUPPORTED, "debug_decode: unsupported combination");
+  return WQAA_ERR_UNSUPPORTED;
+}
+
+}  // namespace wqaa

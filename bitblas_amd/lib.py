@@ -1,0 +1,252 @@
+"""ctypes binding of libwqaa_hip.so - the thin `cdll` shim between the Python operator API and
+the hand-written HIP kernels.
+
+Reference counterpart: `Operator.update_runtime_module(libpath=...)` -> `ctypes.CDLL(libpath);
+lib.init()` and `Operator._forward_from_prebuild_lib` (bitblas/ops/operator.py:458-485), where each
+config owns a JIT-compiled `.so` exporting `init()` / `call()`.  Here one prebuilt library serves every
+config; `BoundLib` gives each operator an object with the same `init()` / `call(*ptrs, [m], stream)`
+surface so code that drives `matmul.lib.call(...)` directly (e.g. `Linear.forward`,
+bitblas/module/__init__.py:267-289) keeps working.
+
+The library is mandatory: if it is missing or fails to load we raise - there is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import threading
+from typing import Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libwqaa_hip.so")
+
+# enums of include/wqaa.h
+F16, BF16, F32, I8, I32, E4M3, E5M2 = range(7)
+W_UINT, W_INT, W_NF, W_FP4, W_E4M3, W_E5M2, W_NATIVE = range(7)
+Z_NONE, Z_ORIGINAL, Z_RESCALE, Z_QUANTIZED = range(4)
+LAYOUT_PLAIN, LAYOUT_LOP3 = 0, 1
+OK, ERR_BAD_DESC, ERR_UNSUPPORTED, ERR_LAUNCH, ERR_NO_DEVICE = range(5)
+
+DTYPE_CODE = {
+    "float16": F16, "bfloat16": BF16, "float32": F32, "int8": I8, "int32": I32,
+    "e4m3_float8": E4M3, "e5m2_float8": E5M2,
+}
+WFORMAT_CODE = {"uint": W_UINT, "int": W_INT, "nf": W_NF, "fp": W_FP4, "fp_e4m3": W_E4M3,
+                "fp_e5m2": W_E5M2}
+ZEROS_CODE = {"original": Z_ORIGINAL, "rescale": Z_RESCALE, "quantized": Z_QUANTIZED}
+
+EXPORTED_SYMBOLS = (
+    "init", "wqaa_abi_version", "wqaa_device_count", "wqaa_matmul", "wqaa_matmul_timed",
+    "wqaa_select", "wqaa_pack_weight", "wqaa_unpack_weight", "wqaa_debug_decode",
+    "wqaa_last_error", "wqaa_last_error_string",
+)
+
+
+class MatmulDesc(ctypes.Structure):
+    """struct wqaa_matmul_desc (include/wqaa.h)."""
+    _fields_ = [
+        ("struct_size", ctypes.c_int32), ("N", ctypes.c_int32), ("K", ctypes.c_int32),
+        ("a_dtype", ctypes.c_int32), ("w_format", ctypes.c_int32), ("w_bits", ctypes.c_int32),
+        ("out_dtype", ctypes.c_int32), ("group_size", ctypes.c_int32),
+        ("with_scaling", ctypes.c_int32), ("zeros_mode", ctypes.c_int32),
+        ("with_bias", ctypes.c_int32), ("w_layout", ctypes.c_int32),
+        ("strict_reference", ctypes.c_int32), ("reserved", ctypes.c_int32 * 3),
+    ]
+
+
+class Plan(ctypes.Structure):
+    """struct wqaa_plan (include/wqaa.h)."""
+    _fields_ = [
+        ("kernel_family", ctypes.c_int32), ("block_m", ctypes.c_int32), ("block_n", ctypes.c_int32),
+        ("block_k", ctypes.c_int32), ("threads", ctypes.c_int32), ("grid", ctypes.c_int32),
+        ("rows_per_wave", ctypes.c_int32), ("batch_tile", ctypes.c_int32),
+        ("pipeline_depth", ctypes.c_int32), ("split_k", ctypes.c_int32),
+        ("lds_bytes", ctypes.c_int32), ("name", ctypes.c_char * 96),
+    ]
+
+    def as_dict(self):
+        d = {k: getattr(self, k) for k, _ in self._fields_ if k != "name"}
+        d["name"] = self.name.decode()
+        return d
+
+
+class WqaaError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__(f"libwqaa_hip error {code}: {message}")
+        self.code = code
+
+
+_lib = None
+_lib_lock = threading.Lock()
+
+
+def load_library(path: Optional[str] = None) -> ctypes.CDLL:
+    """dlopen the kernel library once, declare prototypes, call init()."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    with _lib_lock:
+        if _lib is not None and path is None:
+            return _lib
+        p = path or os.environ.get("WQAA_LIBRARY", LIB_PATH)
+        if not os.path.exists(p):
+            raise ImportError(
+                f"{p} not found: build the HIP kernel library first "
+                f"(`python -m bitblas_amd.build`); bitblas_amd has no CPU fallback")
+        lib = ctypes.CDLL(p)
+        vp, ci, i64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64
+        dp = ctypes.POINTER(MatmulDesc)
+        lib.init.restype = None
+        lib.init.argtypes = []
+        lib.wqaa_abi_version.restype = ci
+        lib.wqaa_device_count.restype = ci
+        lib.wqaa_matmul.restype = ci
+        lib.wqaa_matmul.argtypes = [dp, vp, vp, vp, vp, vp, vp, vp, ci, vp]
+        lib.wqaa_matmul_timed.restype = ci
+        lib.wqaa_matmul_timed.argtypes = [dp, vp, vp, vp, vp, vp, vp, vp, ci, vp, vp, vp]
+        lib.wqaa_select.restype = ci
+        lib.wqaa_select.argtypes = [dp, ci, ctypes.POINTER(Plan)]
+        lib.wqaa_pack_weight.restype = ci
+        lib.wqaa_pack_weight.argtypes = [vp, i64, i64, ci, ci, ci, vp]
+        lib.wqaa_unpack_weight.restype = ci
+        lib.wqaa_unpack_weight.argtypes = [vp, i64, i64, ci, ci, ci, vp]
+        lib.wqaa_debug_decode.restype = ci
+        lib.wqaa_debug_decode.argtypes = [vp, i64, ci, ci, ci, ci, ci, vp, vp, vp]
+        lib.wqaa_last_error.restype = ci
+        lib.wqaa_last_error_string.restype = ctypes.c_char_p
+        if lib.wqaa_abi_version() != 1:
+            raise ImportError(f"{p}: ABI version {lib.wqaa_abi_version()} != 1")
+        lib.init()
+        if path is None:
+            _lib = lib
+        return lib
+
+
+def check(status: int) -> None:
+    if status != OK:
+        lib = load_library()
+        raise WqaaError(status, lib.wqaa_last_error_string().decode(errors="replace"))
+
+
+def make_desc(*, N, K, a_dtype, w_format, w_bits, out_dtype, group_size=-1, with_scaling=False,
+              zeros_mode=Z_NONE, with_bias=False, w_layout=LAYOUT_PLAIN, strict_reference=True) -> MatmulDesc:
+    d = MatmulDesc()
+    d.struct_size = ctypes.sizeof(MatmulDesc)
+    d.N, d.K = int(N), int(K)
+    d.a_dtype, d.w_format, d.w_bits, d.out_dtype = int(a_dtype), int(w_format), int(w_bits), int(out_dtype)
+    d.group_size = int(group_size)
+    d.with_scaling = int(bool(with_scaling))
+    d.zeros_mode = int(zeros_mode)
+    d.with_bias = int(bool(with_bias))
+    d.w_layout = int(w_layout)
+    d.strict_reference = int(bool(strict_reference))
+    return d
+
+
+def select(desc: MatmulDesc, m: int) -> dict:
+    lib = load_library()
+    plan = Plan()
+    check(lib.wqaa_select(ctypes.byref(desc), int(m), ctypes.byref(plan)))
+    return plan.as_dict()
+
+
+def _ptr(x) -> Optional[int]:
+    if x is None:
+        return None
+    if isinstance(x, ctypes.c_void_p):
+        return x.value
+    if isinstance(x, int):
+        return x
+    return x.data_ptr()  # torch.Tensor
+
+
+class BoundLib:
+    """Per-operator view of the library with the reference's `init()` / `call()` convention.
+
+    call(A, B, [LUT], [Scale], [Zeros|QZeros], [Bias], C, [m], stream)
+      - pointer arguments: ctypes.c_void_p, raw ints or torch tensors
+      - `m` is present iff the operator was built for a dynamic M range
+      - `stream`: ctypes.c_void_p / int (hipStream_t)
+    (argument order: tirscript/matmul_dequantize_impl.py:465-478; caller: ops/operator.py:458-463)
+    """
+
+    def __init__(self, desc: MatmulDesc, *, has_lut: bool, dynamic_m: bool, static_m: int = 1,
+                 default_lut=None):
+        self._lib = load_library()
+        self.desc = desc
+        self._desc_ref = ctypes.byref(desc)
+        self.has_lut = has_lut
+        self.has_scale = bool(desc.with_scaling)
+        self.has_zeros = desc.zeros_mode != Z_NONE
+        self.has_bias = bool(desc.with_bias)
+        self.dynamic_m = dynamic_m
+        self.static_m = static_m
+        self.default_lut = default_lut
+        self._n_opt = int(self.has_scale) + int(self.has_zeros) + int(self.has_bias)
+        self._fn = self._lib.wqaa_matmul
+
+    def init(self):
+        self._lib.init()
+
+    def call(self, *args):
+        args = list(args)
+        stream = _ptr(args.pop())
+        m = int(args.pop()) if self.dynamic_m else self.static_m
+        ptrs = [_ptr(a) for a in args]
+        want = 3 + self._n_opt + int(self.has_lut)
+        lut = None
+        if self.has_lut:
+            if len(ptrs) == want:
+                lut = ptrs.pop(2)
+            elif len(ptrs) == want - 1:
+                # `Linear.forward` never passes the LUT (module/__init__.py:138-153)
+                lut = _ptr(self.default_lut)
+            else:
+                raise TypeError(f"call() expected {want} pointer arguments, got {len(ptrs)}")
+        elif len(ptrs) != want:
+            raise TypeError(f"call() expected {want} pointer arguments, got {len(ptrs)}")
+        it = iter(ptrs)
+        A, B = next(it), next(it)
+        scale = next(it) if self.has_scale else None
+        zeros = next(it) if self.has_zeros else None
+        bias = next(it) if self.has_bias else None
+        C = next(it)
+        status = self._fn(self._desc_ref, A, B, lut, scale, zeros, bias, C, m, stream)
+        if status != OK:
+            check(status)
+
+    def run(self, A, B, lut, scale, zeros, bias, C, m, stream):
+        """Fast path used by Matmul.forward: raw integer pointers, no list juggling."""
+        status = self._fn(self._desc_ref, A, B, lut, scale, zeros, bias, C, m, stream)
+        if status != OK:
+            check(status)
+
+    def run_timed(self, A, B, lut, scale, zeros, bias, C, m, stream, ev_start, ev_stop):
+        status = self._lib.wqaa_matmul_timed(self._desc_ref, A, B, lut, scale, zeros, bias, C, m,
+                                             stream, ev_start, ev_stop)
+        if status != OK:
+            check(status)
+
+    def plan(self, m: int) -> dict:
+        return select(self.desc, m)
+
+
+def pack_weight(codes, bits: int, layout: int, a_dtype_code: int):
+    """numpy int8 (rows, cols) unsigned codes -> numpy int8 (rows, cols*bits/8) via the C packer."""
+    import numpy as np
+    lib = load_library()
+    c = np.ascontiguousarray(codes, dtype=np.int8)
+    rows, cols = c.shape
+    out = np.empty((rows, cols * bits // 8), dtype=np.int8)
+    check(lib.wqaa_pack_weight(c.ctypes.data, rows, cols, bits, layout, a_dtype_code, out.ctypes.data))
+    return out
+
+
+def unpack_weight(packed, cols: int, bits: int, layout: int, a_dtype_code: int):
+    import numpy as np
+    lib = load_library()
+    p = np.ascontiguousarray(packed).view(np.int8)
+    rows = p.shape[0]
+    out = np.empty((rows, cols), dtype=np.int8)
+    check(lib.wqaa_unpack_weight(p.ctypes.data, rows, cols, bits, layout, a_dtype_code, out.ctypes.data))
+    return out

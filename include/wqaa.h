@@ -1,0 +1,156 @@
+/* wqaa.h - C ABI of libwqaa_hip.so: the MI355X (gfx950) W_q A_a matmul backend.
+ *
+ * This is the drop-in boundary.  In microsoft/BitBLAS every (config, tuned hint) pair is JIT-compiled
+ * into its own shared object that exports exactly two symbols
+ *
+ *     extern "C" void init();
+ *     extern "C" void call(T_A* A, int8_t* B, [T_A* LUT], [T_A* Scale], [T_A* Zeros | int8_t* QZeros],
+ *                          [T_A* Bias], T_out* C, [int m], hipStream_t stream);
+ *
+ * (reference: bitblas/builder/wrapper/base.py:9-19, bitblas/builder/wrapper/tl.py:104-120 and
+ * :254-305 for the dynamic-m dispatcher) and is driven through ctypes by
+ * `Operator._forward_from_prebuild_lib` (bitblas/ops/operator.py:458-463) and `Linear.forward`
+ * (bitblas/module/__init__.py:267-289).
+ *
+ * Here nothing is JIT-compiled: ONE prebuilt library holds the static kernel set, and the per-config
+ * `call` becomes `wqaa_matmul(desc, ...)` with the config passed as a plain struct.  Pointer order is
+ * the reference's prim_func order (tirscript/matmul_dequantize_impl.py:465-478).  All pointers are
+ * device pointers owned by the caller; the library never allocates, frees or synchronises.
+ *
+ * Plain C: no torch, no HIP types in signatures (hipStream_t is passed as void*).
+ */
+#ifndef WQAA_H_
+#define WQAA_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WQAA_ABI_VERSION 1
+
+/* element types of A / C / Scale / Bias */
+enum wqaa_dtype {
+  WQAA_F16 = 0,
+  WQAA_BF16 = 1,
+  WQAA_F32 = 2,
+  WQAA_I8 = 3,
+  WQAA_I32 = 4,
+  WQAA_E4M3 = 5, /* OCP float8_e4m3fn */
+  WQAA_E5M2 = 6
+};
+
+/* weight source formats: (format, bits) pairs of Matmul.BITBLAS_TRICK_DTYPE_MAP
+ * (bitblas/ops/general_matmul/__init__.py:324-345) */
+enum wqaa_wformat {
+  WQAA_W_UINT = 0,   /* uint{1,2,4,8}                          */
+  WQAA_W_INT = 1,    /* int{1,2,4,8}: stored as u, value u-2^(b-1) (int1: {0,-1}) */
+  WQAA_W_NF = 2,     /* nf4: LUT[u]                             */
+  WQAA_W_FP4 = 3,    /* "fp4_e2m1" as the reference decodes it  */
+  WQAA_W_E4M3 = 4,   /* e4m3 bytes dequantised to A_dtype       */
+  WQAA_W_E5M2 = 5,
+  WQAA_W_NATIVE = 6  /* W_dtype == A_dtype (dense path)         */
+};
+
+enum wqaa_zeros_mode { WQAA_Z_NONE = 0, WQAA_Z_ORIGINAL = 1, WQAA_Z_RESCALE = 2, WQAA_Z_QUANTIZED = 3 };
+
+/* byte layout of B, both are the reference's checkpoint layouts, shape (N, K*bits/8):
+ *   PLAIN : general_compress order (bitblas/quantization/utils.py:54-70)
+ *   LOP3  : PLAIN followed by the LOP3 interleave that `fast_decoding=True` applies
+ *           (bitblas/ops/lop3_permutate/lop3_permutate_impl.py:12-132); target width 16 for
+ *           A=float16, 8 for A=int8 */
+enum wqaa_layout { WQAA_LAYOUT_PLAIN = 0, WQAA_LAYOUT_LOP3 = 1 };
+
+enum wqaa_status {
+  WQAA_OK = 0,
+  WQAA_ERR_BAD_DESC = 1,      /* malformed descriptor / null pointer */
+  WQAA_ERR_UNSUPPORTED = 2,   /* no kernel for this (dtype, shape) combination */
+  WQAA_ERR_LAUNCH = 3,        /* hipLaunch failed; see wqaa_last_error_string */
+  WQAA_ERR_NO_DEVICE = 4
+};
+
+typedef struct wqaa_matmul_desc {
+  int32_t struct_size;   /* = sizeof(wqaa_matmul_desc), ABI guard */
+  int32_t N;             /* out features  */
+  int32_t K;             /* in features   */
+  int32_t a_dtype;       /* wqaa_dtype of A */
+  int32_t w_format;      /* wqaa_wformat  */
+  int32_t w_bits;        /* 1,2,4,8,16    */
+  int32_t out_dtype;     /* wqaa_dtype of C */
+  int32_t group_size;    /* -1 => K       */
+  int32_t with_scaling;  /* Scale (N, K/g) in A_dtype */
+  int32_t zeros_mode;    /* wqaa_zeros_mode; Zeros (N,K/g) A_dtype, or QZeros (K/g, N*bits/8) int8 */
+  int32_t with_bias;     /* Bias (N,) added after the cast to out_dtype */
+  int32_t w_layout;      /* wqaa_layout   */
+  int32_t strict_reference; /* 1: reproduce the reference's e4m3->f16 bit trick (0 -> 2^-7); 0: IEEE */
+  int32_t reserved[3];
+} wqaa_matmul_desc;
+
+/* what the selector chose for (desc, m): reported for tests, rocprof attribution and the cache */
+typedef struct wqaa_plan {
+  int32_t kernel_family;  /* 0 none, 1 gemv (VALU dot), 2 gemm (MFMA) */
+  int32_t block_m, block_n, block_k;
+  int32_t threads;
+  int32_t grid;
+  int32_t rows_per_wave;  /* gemv */
+  int32_t batch_tile;     /* gemv: activation rows handled per launch */
+  int32_t pipeline_depth;
+  int32_t split_k;
+  int32_t lds_bytes;
+  char name[96];          /* matmul_[m..]n..k.._AxW_<tile> style name
+                             (general_matmul/__init__.py:240-318) */
+} wqaa_plan;
+
+/* ---- lifecycle ------------------------------------------------------------------------------
+ * init(): idempotent; mirrors the generated `init()` (wrapper/base.py:5-13) - it raises the dynamic
+ * LDS limit of every kernel that needs it.  Safe to call without a GPU (returns without touching
+ * the device). */
+void init(void);
+int wqaa_abi_version(void);
+int wqaa_device_count(void);
+
+/* ---- the hot path ---------------------------------------------------------------------------
+ * replaces the generated `call` (wrapper/tl.py:104-120, dynamic form :254-305).
+ * A: (m, K) a_dtype row-major.  B: (N, K*bits/8) bytes.  C: (m, N) out_dtype.
+ * LUT/Scale/Zeros/Bias may be NULL when the descriptor says they are absent.
+ * m == 0 returns immediately (wrapper/tl.py:277).  Asynchronous on `stream`.
+ * Returns wqaa_status; the reference's `call` is void, so the shim also records the error for
+ * wqaa_last_error(). */
+int wqaa_matmul(const wqaa_matmul_desc* desc, const void* A, const void* B, const void* LUT,
+                const void* Scale, const void* Zeros, const void* Bias, void* C, int m, void* stream);
+
+/* same launch, bracketed by the kernel's own begin/end timestamps recorded into two hipEvent_t
+ * (hipExtLaunchKernel semantics): kernel-only duration without launch gaps, for bench.py */
+int wqaa_matmul_timed(const wqaa_matmul_desc* desc, const void* A, const void* B, const void* LUT,
+                      const void* Scale, const void* Zeros, const void* Bias, void* C, int m,
+                      void* stream, void* start_event, void* stop_event);
+
+/* tile-config selector: replaces roller + tuner (bitblas/base/roller, bitblas/base/tuner.py) */
+int wqaa_select(const wqaa_matmul_desc* desc, int m, wqaa_plan* plan);
+
+/* ---- weight pre-processing (CPU; replaces the TVM-llvm ops of Matmul.transform_weight,
+ * bitblas/ops/general_matmul/__init__.py:662-711: QuantCompress + LOP3Permutate) ---------------
+ * codes: (rows, cols) int8 unsigned field values; out: (rows, cols*bits/8) bytes. */
+int wqaa_pack_weight(const int8_t* codes, int64_t rows, int64_t cols, int bits, int layout,
+                     int a_dtype, int8_t* out);
+/* inverse: bytes in either layout -> unsigned field values */
+int wqaa_unpack_weight(const int8_t* packed, int64_t rows, int64_t cols, int bits, int layout,
+                       int a_dtype, int8_t* codes);
+
+/* ---- device self-test helper: decode `nwords` 32-bit words of packed weights with the kernels'
+ * own decode routines (the HIP twin of testing/cpp/lop3_type_conversion/ *.cu known-answer tests).
+ * out receives nwords*(32/bits) values: float16 (a_dtype F16) or int8 (a_dtype I8). */
+int wqaa_debug_decode(const void* packed_dev, int64_t nwords, int w_format, int bits, int layout,
+                      int a_dtype, int strict_reference, const void* lut_dev, void* out_dev,
+                      void* stream);
+
+/* ---- error side channel ---------------------------------------------------------------------- */
+int wqaa_last_error(void);
+const char* wqaa_last_error_string(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WQAA_H_ */

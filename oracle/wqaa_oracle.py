@@ -1,0 +1,405 @@
+"""CPU oracle for the WqAa matmul hot path.  TEST INFRASTRUCTURE ONLY.
+
+This module is the *checker*: a numpy restatement of what microsoft/BitBLAS defines for
+`bitblas.Matmul` with a quantised weight operand.  Nothing under `bitblas_amd/` may import
+it; only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg do.
+
+What it restates (paths relative to the reference checkout):
+
+* weight packing ........ `bitblas/quantization/utils.py:54-70`  (general_compress)
+* LOP3 interleave ....... `bitblas/quantization/utils.py:73-110` (numpy) and
+                          `bitblas/ops/lop3_permutate/lop3_permutate_impl.py:12-132` (TIR; the
+                          version `Matmul.transform_weight` really runs - it differs from the numpy
+                          helper for 1-bit/float16, where the numpy helper forgets its byte swizzle)
+* per-element decoders .. `bitblas/quantization/quantization.py:141-156` (fp4), `:169-176` (e4m3
+                          bit trick), `:185-230` (uint / int / int1 / uint-with-zeros)
+* compute graph ......... `bitblas/ops/general_matmul/tirscript/matmul_dequantize_impl.py:339-499`
+                          (decode -> scale/zeros in A_dtype -> sum over k in accum dtype -> cast to
+                          out_dtype -> + bias), dense variant `tirscript/matmul_impl.py:50-86`
+* NF4 table ............. `bitblas/ops/general_matmul/__init__.py:413-434`
+* code offset ........... `bitblas/ops/general_matmul/__init__.py:685-696` (`clamp(W)+2^(b-1)`)
+* the formulation the reference's own tests compare against (dequantise to half, matmul in
+  fp32, cast, add bias): `testing/python/operators/test_general_matmul_ops_backend_tl.py:227-273`
+* GPTQ unpack helpers ... `bitblas/module/__init__.py:24-74`
+
+PARITY PINNING STATUS
+---------------------
+The reference cannot be imported here (its tvm / tilelang submodules are empty) and it has no CPU
+matmul.  What *is* importable is `bitblas/quantization/utils.py`; `oracle/gen_golden.py` runs
+`general_compress` / `interleave_weight` from that file and commits the vectors under
+`tests/golden/`; `tests/test_oracle_golden.py` checks this module against them bit for bit.
+=> packing + interleave: PINNED by reference-generated fixtures.
+=> decode + matmul semantics: restated from the TE spec and the test `ref_program`; the reference
+   stores no golden outputs for them ("parity unpinned" for W_int2xA_int8, fp4_e2m1 and dense
+   fp8xfp8, which the reference never asserts on - SURVEY.md section 8c).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+# --------------------------------------------------------------------------------------
+# dtype tables  (reference: Matmul.BITBLAS_TRICK_DTYPE_MAP, general_matmul/__init__.py:324-345)
+# --------------------------------------------------------------------------------------
+W_DTYPE_MAP = {
+    "float64": ("fp", 64), "float32": ("fp", 32), "float16": ("fp", 16), "bfloat16": ("bf", 16),
+    "int32": ("int", 32), "uint32": ("uint", 32), "int16": ("int", 16), "uint16": ("uint", 16),
+    "int8": ("int", 8), "uint8": ("uint", 8), "int4": ("int", 4), "uint4": ("uint", 4),
+    "int2": ("int", 2), "uint2": ("uint", 2), "int1": ("int", 1), "uint1": ("uint", 1),
+    "nf4": ("nf", 4), "fp4_e2m1": ("fp", 4),
+    "e4m3_float8": ("fp_e4m3", 8), "e5m2_float8": ("fp_e5m2", 8),
+}
+
+# reference: general_matmul/__init__.py:413-434
+NF4_LUT = np.array([
+    -1.0, -0.6961928009986877, -0.5250730514526367, -0.39491748809814453,
+    -0.28444138169288635, -0.18477343022823334, -0.09105003625154495, 0.0,
+    0.07958029955625534, 0.16093020141124725, 0.24611230194568634, 0.33791524171829224,
+    0.44070982933044434, 0.5626170039176941, 0.7229568362236023, 1.0], dtype=np.float64)
+
+
+# --------------------------------------------------------------------------------------
+# packing
+# --------------------------------------------------------------------------------------
+def general_compress(codes: np.ndarray, source_bits: int = 4, storage_dtype=np.int8) -> np.ndarray:
+    """Little-field-first bit packing along the last axis.
+
+    out[..., j] = OR_k (codes[..., j*e + k] << (bits*k)),  e = 8 // bits
+    (reference: quantization/utils.py:54-70, TIR twin quant_compress_impl.py:22-31).
+    """
+    e = 8 // source_bits
+    c = np.asarray(codes)
+    if c.dtype == np.float16:
+        c = c.astype(np.int8)
+    assert c.shape[-1] % e == 0
+    c = c.astype(np.int64).reshape(*c.shape[:-1], c.shape[-1] // e, e)
+    out = np.zeros(c.shape[:-1], dtype=np.int64)
+    for k in range(e):
+        # the reference ORs int8 values shifted in int8 arithmetic: bits above 8 fall off
+        out |= (c[..., k] << (source_bits * k)) & 0xFF
+    return out.astype(np.uint8).view(np.int8).view(storage_dtype)
+
+
+def general_decompress(packed: np.ndarray, source_bits: int = 4) -> np.ndarray:
+    """Inverse of general_compress: unsigned field values, last axis expanded by 8//bits."""
+    e = 8 // source_bits
+    p = np.asarray(packed).view(np.uint8).astype(np.int32)
+    mask = (1 << source_bits) - 1
+    fields = [(p >> (source_bits * k)) & mask for k in range(e)]
+    return np.stack(fields, axis=-1).reshape(*p.shape[:-1], p.shape[-1] * e).astype(np.int8)
+
+
+def interleave_field_positions(nbits: int, target_bits: int):
+    """For one 32-bit word: dst bit offset of every source field (before the byte swizzles).
+
+    field `o` (source bits [o*nbits, (o+1)*nbits)) moves to bit
+        (o % G) * S + (o // G) * nbits,   S = target bits (16 | 8),  G = 32 // S
+    (reference: quantization/utils.py:80-88).
+    """
+    S = target_bits
+    G = 32 // S
+    n = 32 // nbits
+    return [(o % G) * S + (o // G) * nbits for o in range(n)]
+
+
+def interleave_weight(qweight: np.ndarray, nbits: int = 4, target_dtype: str = "float16",
+                      follow: str = "tir") -> np.ndarray:
+    """LOP3 interleave of packed weights, 32 bits at a time.
+
+    follow="tir"   -> what `LOP3Permutate` (the op `transform_weight` runs) computes
+                      (lop3_permutate_impl.py:27-132): byte swizzles for f16/2b, f16/1b, int8/1b.
+    follow="numpy" -> `quantization/utils.py:73-110` verbatim behaviour, including its missing
+                      `return` for nbits=1/float16 (the swizzled value is computed and dropped).
+    """
+    assert target_dtype in ("float16", "int8")
+    S = 8 if target_dtype == "int8" else 16
+    q = np.ascontiguousarray(qweight).view(np.uint32).astype(np.uint64)
+    out = np.zeros_like(q)
+    mask = (1 << nbits) - 1
+    for o, shift in enumerate(interleave_field_positions(nbits, S)):
+        out |= ((q >> (nbits * o)) & mask) << shift
+    out &= 0xFFFFFFFF
+
+    def mv(x, m, right, left):
+        return ((x & m) >> right) << left
+
+    if nbits == 1 and target_dtype == "int8":
+        r = out & 0xF0F00F0F
+        r |= mv(out, 0x000000F0, 4, 16)
+        r |= mv(out, 0x0000F000, 12, 24)
+        r |= mv(out, 0x000F0000, 16, 4)
+        r |= mv(out, 0x0F000000, 24, 12)
+        out = r
+    elif nbits == 2 and target_dtype == "float16":
+        r = out & 0xFF0000FF
+        r |= mv(out, 0x0000FF00, 8, 16)
+        r |= mv(out, 0x00FF0000, 16, 8)
+        out = r
+    elif nbits == 1 and target_dtype == "float16" and follow == "tir":
+        r = out & 0xF000000F
+        r |= mv(out, 0x000000F0, 4, 8)
+        r |= mv(out, 0x00000F00, 8, 16)
+        r |= mv(out, 0x0000F000, 12, 24)
+        r |= mv(out, 0x000F0000, 16, 4)
+        r |= mv(out, 0x00F00000, 20, 12)
+        r |= mv(out, 0x0F000000, 24, 20)
+        out = r
+    return (out & 0xFFFFFFFF).astype(np.uint32).view(np.int8).reshape(np.asarray(qweight).shape)
+
+
+def deinterleave_weight(qweight: np.ndarray, nbits: int, target_dtype: str) -> np.ndarray:
+    """Inverse of interleave_weight(follow="tir") - used to read reference-layout checkpoints."""
+    probe = np.zeros(32, dtype=np.uint32)
+    for b in range(32):
+        probe[b] = np.uint32(1) << np.uint32(b)
+    moved = interleave_weight(probe.view(np.int8), nbits, target_dtype).view(np.uint32)
+    dst_of_src = [int(np.log2(int(v))) for v in moved]
+    q = np.ascontiguousarray(qweight).view(np.uint32).astype(np.uint64)
+    out = np.zeros_like(q)
+    for src, dst in enumerate(dst_of_src):
+        out |= ((q >> dst) & 1) << src
+    return out.astype(np.uint32).view(np.int8).reshape(np.asarray(qweight).shape)
+
+
+# --------------------------------------------------------------------------------------
+# decoders: storage fields -> exact values (returned as float64 holding fp16-representable numbers,
+# or int64 for integer activations)
+# --------------------------------------------------------------------------------------
+def decode_fp4(codes: np.ndarray) -> np.ndarray:
+    """`fp4_e2m1` as the reference decodes it: 1 sign bit + 3 exponent bits, no mantissa.
+
+    s = f4 >> 3; e = f4 & 7; e == 0 -> 0 else (-1)^s * 2^(e + 8 - 15)   (quantization.py:141-156)
+    """
+    c = np.asarray(codes).astype(np.int64) & 0xF
+    s = c >> 3
+    e = c & 7
+    val = np.ldexp(1.0, (e | 8) - 15)
+    val = np.where(s == 1, -val, val)
+    return np.where(e == 0, 0.0, val)
+
+
+def _as_u8(x) -> np.ndarray:
+    x = np.asarray(x)
+    if x.dtype.itemsize == 1:
+        return x.view(np.uint8)
+    return (x.astype(np.int64) & 0xFF).astype(np.uint8)
+
+
+def decode_e4m3_strict(u8: np.ndarray) -> np.ndarray:
+    """e4m3 byte -> fp16 with the reference's bit trick (quantization.py:169-176).
+
+    f16 bits = s<<15 | (((v & 63) << 7) | (e4 << 8) | (e4 << 7)) ^ 0x2000,  e4 = v & 0x40.
+    Exact for normal numbers; zero maps to 2^-7, subnormals / NaN are wrong by construction.
+    """
+    v = _as_u8(u8).astype(np.uint32)
+    s = (v >> 7) << 15
+    e4 = v & 0x40
+    e = (((v & 63) << 7) | (e4 << 8) | (e4 << 7)) ^ 0x2000
+    bits = ((s | e) & 0xFFFF).astype(np.uint16)
+    return bits.view(np.float16).astype(np.float64)
+
+
+def decode_e4m3_ieee(u8: np.ndarray) -> np.ndarray:
+    """OCP e4m3fn byte -> exact value (what torch.float8_e4m3fn and gfx950 MFMA mean)."""
+    v = _as_u8(u8).astype(np.int64)
+    s = np.where((v >> 7) == 1, -1.0, 1.0)
+    e = (v >> 3) & 0xF
+    m = v & 7
+    normal = np.ldexp(1.0 + m / 8.0, e - 7)
+    sub = np.ldexp(m / 8.0, -6)
+    val = np.where(e == 0, sub, normal)
+    val = np.where((e == 15) & (m == 7), np.nan, val)
+    return s * val
+
+
+def decode_e5m2(u8: np.ndarray) -> np.ndarray:
+    """e5m2 byte -> value: it is the top byte of an IEEE half (quantization.py:179-182)."""
+    v = _as_u8(u8).astype(np.uint16) << 8
+    return v.view(np.float16).astype(np.float64)
+
+
+def decode_codes(codes: np.ndarray, source_format: str, bit: int, strict_reference: bool = True,
+                 lut: np.ndarray | None = None) -> np.ndarray:
+    """Unsigned storage fields (N, K) -> decoded value before scale/zeros (float64, exact).
+
+    uint: u;  int (bit>1): u - 2^(bit-1);  int1: sign-extend -> {0,-1};  nf: LUT[u];
+    fp (fp4_e2m1), fp_e4m3, fp_e5m2: see the helpers above.
+    (matmul_dequantize_impl.py:391-433; quantization.py:185-230)
+    """
+    c = np.asarray(codes)
+    u = c.astype(np.int64) & ((1 << bit) - 1)
+    if source_format == "uint":
+        return u.astype(np.float64)
+    if source_format == "int":
+        if bit == 8:
+            return np.asarray(codes).astype(np.int8).astype(np.float64)
+        if bit == 1:
+            return np.where(u == 1, -1.0, 0.0)  # sign-extended 1-bit field
+        return (u - (1 << (bit - 1))).astype(np.float64)
+    if source_format == "nf":
+        table = NF4_LUT if lut is None else np.asarray(lut, dtype=np.float64)
+        return table[u]
+    if source_format == "fp":
+        return decode_fp4(u)
+    if source_format == "fp_e4m3":
+        return decode_e4m3_strict(u) if strict_reference else decode_e4m3_ieee(u)
+    if source_format == "fp_e5m2":
+        return decode_e5m2(u)
+    raise ValueError(source_format)
+
+
+def f16(x: np.ndarray) -> np.ndarray:
+    return np.asarray(x).astype(np.float16)
+
+
+def dequantize_weight(codes: np.ndarray, source_format: str, bit: int, *, K: int | None = None,
+                      scale=None, zeros=None, zeros_mode: str = "original", group_size: int = -1,
+                      a_dtype: str = "float16", strict_reference: bool = True, lut=None) -> np.ndarray:
+    """B_decode of the TE spec, materialised in A_dtype (matmul_dequantize_impl.py:391-451).
+
+    codes: (N, K) unsigned storage fields (i.e. what general_compress packed).
+    scale: (N, K/g) in A_dtype.  zeros: (N, K/g) A_dtype for original/rescale, or the *packed*
+    (K/g, N*bit/8) int8 array for "quantized".
+    Every arithmetic step rounds to A_dtype exactly as the TE expression does:
+      original : (w - z) * s        rescale: w * s - z        quantized: (w_u - z_u) * s
+    """
+    codes = np.asarray(codes)
+    N, Kc = codes.shape
+    K = Kc if K is None else K
+    g = K if group_size in (-1, None) else group_size
+    gi = np.arange(K) // g
+    if a_dtype == "int8":
+        assert scale is None and zeros is None
+        return decode_codes(codes, source_format, bit, strict_reference, lut).astype(np.int64)
+    ft = {"float16": np.float16, "float32": np.float32, "bfloat16": np.float32}[a_dtype]
+    with_zeros = zeros is not None
+    if with_zeros and zeros_mode == "quantized":
+        zq = general_decompress(np.asarray(zeros), bit).astype(np.int64)  # (K/g, N)
+        u = codes.astype(np.int64) & ((1 << bit) - 1)
+        w = (u - zq[gi, :].T).astype(ft)  # integer subtraction, then cast (quantization.py:208-217)
+    else:
+        w = decode_codes(codes, source_format, bit, strict_reference, lut).astype(ft)
+    if scale is None:
+        return w
+    s = np.asarray(scale).astype(ft)[:, gi]
+    if not with_zeros:
+        return (w * s).astype(ft)
+    if zeros_mode == "original":
+        z = np.asarray(zeros).astype(ft)[:, gi]
+        return ((w - z).astype(ft) * s).astype(ft)
+    if zeros_mode == "rescale":
+        z = np.asarray(zeros).astype(ft)[:, gi]
+        return ((w * s).astype(ft) - z).astype(ft)
+    if zeros_mode == "quantized":
+        return (w * s).astype(ft)
+    raise ValueError(zeros_mode)
+
+
+_OUT_NP = {"float16": np.float16, "float32": np.float32, "int32": np.int32, "int8": np.int8,
+           "bfloat16": np.float32}
+
+
+def matmul_dequant(A: np.ndarray, codes: np.ndarray, *, source_format: str, bit: int,
+                   scale=None, zeros=None, zeros_mode="original", group_size=-1, bias=None,
+                   a_dtype="float16", out_dtype="float16", strict_reference=True, lut=None,
+                   wide: bool = True) -> np.ndarray:
+    """C = cast_out(sum_k A[m,k] * B_decode[n,k]) (+ bias after the cast).
+
+    The sum is taken in float64 (wide=True) or float32; the reference leaves the accumulation
+    order to its code generator, the tests compare against an fp32 matmul.  Integer activations
+    accumulate exactly.
+    """
+    A = np.asarray(A)
+    K = A.shape[-1]
+    Wd = dequantize_weight(codes, source_format, bit, K=K, scale=scale, zeros=zeros,
+                           zeros_mode=zeros_mode, group_size=group_size, a_dtype=a_dtype,
+                           strict_reference=strict_reference, lut=lut)
+    A2 = A.reshape(-1, K)
+    if a_dtype == "int8":
+        acc = A2.astype(np.int64) @ Wd.astype(np.int64).T
+        out = acc.astype(_OUT_NP[out_dtype]) if out_dtype.startswith("int") else acc.astype(_OUT_NP[out_dtype])
+    else:
+        ct = np.float64 if wide else np.float32
+        acc = A2.astype(ct) @ Wd.astype(ct).T
+        out = acc.astype(np.float32).astype(_OUT_NP[out_dtype])
+    if bias is not None:
+        out = (out + np.asarray(bias).astype(out.dtype)).astype(out.dtype)
+    return out.reshape(*A.shape[:-1], Wd.shape[0])
+
+
+def matmul_dense(A: np.ndarray, W: np.ndarray, *, a_dtype: str, w_dtype: str | None = None,
+                 out_dtype: str = "float16", bias=None) -> np.ndarray:
+    """Dense nt matmul C = A @ W^T (tirscript/matmul_impl.py:50-86). fp8 operands come as bytes."""
+    w_dtype = a_dtype if w_dtype is None else w_dtype
+
+    def val(x, dt):
+        if dt == "e4m3_float8":
+            return decode_e4m3_ieee(x)
+        if dt == "e5m2_float8":
+            return decode_e5m2(x)
+        return np.asarray(x)
+
+    Av, Wv = val(A, a_dtype), val(W, w_dtype)
+    K = Av.shape[-1]
+    if a_dtype in ("int8", "uint8"):
+        acc = Av.reshape(-1, K).astype(np.int64) @ Wv.astype(np.int64).T
+        out = acc.astype(_OUT_NP[out_dtype])
+    else:
+        acc = Av.reshape(-1, K).astype(np.float64) @ Wv.astype(np.float64).T
+        out = acc.astype(np.float32).astype(_OUT_NP[out_dtype])
+    if bias is not None:
+        out = (out + np.asarray(bias).astype(out.dtype)).astype(out.dtype)
+    return out.reshape(*Av.shape[:-1], Wv.shape[0])
+
+
+# --------------------------------------------------------------------------------------
+# weight preparation as Matmul.transform_weight does it (general_matmul/__init__.py:662-711)
+# --------------------------------------------------------------------------------------
+def weight_to_codes(weight: np.ndarray, source_format: str, bit: int) -> np.ndarray:
+    """int formats (<8 bit): clamp(W, -2^(b-1), 2^(b-1)) + 2^(b-1), in int8 arithmetic; others: as int8."""
+    w = np.asarray(weight)
+    if source_format == "int" and bit < 8:
+        maxq = 1 << (bit - 1)
+        return (np.clip(w, -maxq, maxq).astype(np.int8) + np.int8(maxq)).astype(np.int8)
+    return w.astype(np.int8) if w.dtype != np.int8 else w
+
+
+def transform_weight(weight: np.ndarray, source_format: str, bit: int, *, fast_decoding: bool,
+                     a_dtype: str = "float16") -> np.ndarray:
+    """codes -> (N, K*bit/8) int8 bytes in the reference's checkpoint layout."""
+    codes = weight_to_codes(weight, source_format, bit)
+    if bit not in (1, 2, 4):
+        return codes
+    packed = general_compress(codes, bit)
+    if fast_decoding:
+        packed = interleave_weight(packed, bit, "int8" if a_dtype == "int8" else "float16")
+    return packed
+
+
+# --------------------------------------------------------------------------------------
+# GPTQ helpers (module/__init__.py:24-74)
+# --------------------------------------------------------------------------------------
+def unpack_qzeros(qzeros: np.ndarray, bits: int, v2: bool = False) -> np.ndarray:
+    q = np.ascontiguousarray(qzeros).view(np.int32)
+    e = 32 // bits
+    cols = [(q >> (bits * i)).astype(np.int8) for i in range(e)]
+    un = np.stack(cols, axis=-1).reshape(q.shape[0], q.shape[1] * e)
+    if not v2:
+        un = (un + 1).astype(np.int8)
+    return un & np.int8((1 << bits) - 1)
+
+
+def unpack_qweight(qweight: np.ndarray, bits: int) -> np.ndarray:
+    q = np.ascontiguousarray(qweight).view(np.int8)
+    e = 8 // bits
+    cols = [(q >> (bits * i)).astype(np.int8) for i in range(e)]
+    un = np.stack(cols, axis=-1).reshape(q.shape[0], q.shape[1] * e)
+    return un & np.int8((1 << bits) - 1)
+
+
+# --------------------------------------------------------------------------------------
+# tolerance helper with the reference's semantics (bitblas/testing/__init__.py:29-91)
+# --------------------------------------------------------------------------------------
+def count_mismatch(a: np.ndarray, b: np.ndarray, rtol: float, atol: float) -> int:
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return int((np.abs(a - b) > atol + rtol * np.abs(b)).sum())

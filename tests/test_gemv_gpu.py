@@ -1,0 +1,156 @@
+"""GEMV (M < 8) parity: HIP kernel through the C ABI vs the CPU oracle on the same seeded inputs.
+
+Case list restates the reference's op tests (test_general_matmul_ops_backend_tl.py:327-343 GEMV
+half, test_general_matmul_ops_backend.py:211-229, test_general_matmul_ops_nf4.py:64-66,
+test_general_matmul_fp8.py:149-158) and adds BASELINE.json configs c1/c2/c4.
+Tolerance: 1e-3 relative (north star) with an absolute floor of 1e-3 * rms(output); integer
+paths must be bit exact.
+"""
+import numpy as np
+import pytest
+import torch
+
+from helpers import assert_fp_parity, hip_output, make_case, oracle_output
+
+pytestmark = pytest.mark.gpu
+
+REF_GEMV_CASES = [
+    # (M, N, K, W_dtype, group_size, with_scaling, with_zeros, zeros_mode, fast_decoding)
+    (1, 256, 256, "uint4", -1, False, False, "original", None),
+    (1, 256, 256, "uint4", -1, False, False, "original", False),
+    (1, 256, 256, "int4", -1, True, False, "original", None),
+    (1, 256, 256, "int4", 32, True, False, "original", None),
+    (1, 256, 256, "uint4", 32, True, True, "original", None),
+    (1, 256, 256, "uint4", 32, True, True, "rescale", None),
+    (1, 256, 256, "uint4", 32, True, True, "quantized", None),
+]
+
+
+@pytest.mark.parametrize("case_args", REF_GEMV_CASES)
+def test_reference_gemv_cases(case_args):
+    M, N, K, wd, g, ws, wz, zm, fd = case_args
+    case = make_case(M, N, K, W_dtype=wd, group_size=g, with_scaling=ws, with_zeros=wz, zeros_mode=zm,
+                     fast_decoding=fd)
+    got, mm = hip_output(case)
+    assert mm.plans[M]["kernel_family"] == 1
+    assert_fp_parity(got, oracle_output(case))
+
+
+def test_baseline_c1_plumbing():
+    case = make_case(1, 1024, 1024, W_dtype="int4", group_size=-1)
+    got, _ = hip_output(case)
+    assert_fp_parity(got, oracle_output(case))
+
+
+@pytest.mark.parametrize("N,K", [(4096, 4096), (11008, 4096), (4096, 11008)])
+def test_baseline_c2_llama7b_shapes(N, K):
+    case = make_case(1, N, K, W_dtype="int4", group_size=128, with_scaling=True, scale_mul=0.02)
+    got, _ = hip_output(case)
+    assert_fp_parity(got, oracle_output(case))
+
+
+@pytest.mark.parametrize("M", [1, 2, 3, 4, 5, 7])
+@pytest.mark.parametrize("with_bias", [False, True])
+def test_small_batches_and_bias(M, with_bias):
+    case = make_case(M, 512, 1024, W_dtype="uint4", group_size=128, with_scaling=True, with_zeros=True,
+                     zeros_mode="original", with_bias=with_bias, seed=M)
+    got, _ = hip_output(case)
+    assert_fp_parity(got, oracle_output(case))
+
+
+@pytest.mark.parametrize("wd", ["uint2", "int2", "uint1", "int1", "uint8", "int8"])
+@pytest.mark.parametrize("fd", [None, False])
+def test_other_integer_widths_fp16(wd, fd):
+    K = 1024
+    case = make_case(1, 256, K, W_dtype=wd, group_size=-1, with_scaling=True, fast_decoding=fd,
+                     scale_mul=0.05)
+    got, _ = hip_output(case)
+    assert_fp_parity(got, oracle_output(case))
+
+
+def test_nf4_lut():
+    case = make_case(1, 512, 1024, W_dtype="nf4", group_size=128, with_scaling=True)
+    got, _ = hip_output(case)
+    assert_fp_parity(got, oracle_output(case))
+
+
+def test_fp4_reference_decode():
+    case = make_case(2, 256, 512, W_dtype="fp4_e2m1", group_size=-1, with_scaling=True)
+    got, _ = hip_output(case)
+    assert_fp_parity(got, oracle_output(case))
+
+
+@pytest.mark.parametrize("strict", [True, False])
+@pytest.mark.parametrize("ws,g", [(False, -1), (True, 32)])
+def test_e4m3_weight_fp16_activation(strict, ws, g):
+    case = make_case(1, 256, 1024, W_dtype="e4m3_float8", group_size=g, with_scaling=ws)
+    got, _ = hip_output(case, strict_reference=strict)
+    assert_fp_parity(got, oracle_output(case, strict_reference=strict))
+
+
+@pytest.mark.parametrize("M", [1, 4])
+@pytest.mark.parametrize("wd,fd", [("int2", None), ("int2", False), ("int4", None), ("uint4", None), ("int1", None)])
+@pytest.mark.parametrize("out_dtype", ["int32", "float32"])
+def test_int8_activation_exact(M, wd, fd, out_dtype):
+    """BASELINE c4 family (BitNet W_int2 A_int8): int32 accumulation must be bit exact."""
+    case = make_case(M, 512, 2048, W_dtype=wd, A_dtype="int8", out_dtype=out_dtype, fast_decoding=fd)
+    got, _ = hip_output(case)
+    want = oracle_output(case)
+    assert np.array_equal(got, want)
+
+
+def test_baseline_c4_gemv_full_size():
+    case = make_case(1, 4096, 4096, W_dtype="int2", A_dtype="int8", out_dtype="int32")
+    got, _ = hip_output(case)
+    assert np.array_equal(got, oracle_output(case))
+
+
+def test_dense_fp16_and_int8_gemv():
+    rng = np.random.default_rng(0)
+    import bitblas_amd as bitblas
+    A = (rng.random((1, 1024), dtype=np.float32) - 0.5).astype(np.float16)
+    W = (rng.random((256, 1024), dtype=np.float32) - 0.5).astype(np.float16)
+    mm = bitblas.Matmul(bitblas.MatmulConfig(M=1, N=256, K=1024, A_dtype="float16", W_dtype="float16"),
+                        enable_tuning=False)
+    out = mm(torch.from_numpy(A).cuda(), torch.from_numpy(W).cuda()).cpu().numpy()
+    want = (A.astype(np.float64) @ W.astype(np.float64).T).astype(np.float16)
+    assert_fp_parity(out, want)
+    A8 = rng.integers(-128, 128, size=(2, 1024), dtype=np.int8)
+    W8 = rng.integers(-128, 128, size=(256, 1024), dtype=np.int8)
+    mm8 = bitblas.Matmul(bitblas.MatmulConfig(M=2, N=256, K=1024, A_dtype="int8", W_dtype="int8",
+                                              accum_dtype="int32", out_dtype="int32"), enable_tuning=False)
+    out8 = mm8(torch.from_numpy(A8).cuda(), torch.from_numpy(W8).cuda()).cpu().numpy()
+    assert np.array_equal(out8, A8.astype(np.int64) @ W8.astype(np.int64).T)
+
+
+def test_linearity_property_full_size():
+    """Size-independent check at BASELINE c2 size: f(a1 + a2) == f(a1) + f(a2) to fp16 rounding,
+    and scaling one weight row's scale scales exactly that output column."""
+    case = make_case(1, 4096, 4096, W_dtype="int4", group_size=128, with_scaling=True, scale_mul=0.02)
+    got, mm = hip_output(case)
+    case2 = dict(case)
+    case2["A"] = (case["A"] * np.float16(2.0)).astype(np.float16)
+    got2, _ = hip_output(case2, matmul=mm)
+    assert_fp_parity(got2, (got.astype(np.float32) * 2).astype(np.float16), rtol=1e-3)
+    case3 = dict(case)
+    s = case["scale"].copy()
+    s[7, :] = 0
+    case3["scale"] = s
+    got3, _ = hip_output(case3, matmul=mm)
+    assert got3[0, 7] == 0
+    assert np.array_equal(np.delete(got3, 7, axis=1), np.delete(got, 7, axis=1))
+
+
+def test_output_buffer_and_stream_semantics():
+    case = make_case(1, 256, 256, W_dtype="uint4")
+    import bitblas_amd as bitblas
+    mm = bitblas.Matmul(case["config"], enable_tuning=False)
+    W = mm.transform_weight(torch.from_numpy(case["w_user"]).cuda())
+    A = torch.from_numpy(case["A"]).cuda()
+    out = torch.full((1, 256), 7.0, dtype=torch.float16, device="cuda")
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        ret = mm(A, W, output=out)
+    s.synchronize()
+    assert ret.data_ptr() == out.data_ptr()
+    assert_fp_parity(out.cpu().numpy(), oracle_output(case))

@@ -1,0 +1,106 @@
+"""The oracle against vectors produced by the reference's own numpy helpers (oracle/gen_golden.py)."""
+import numpy as np
+
+import wqaa_oracle as oracle
+
+
+def test_compress_matches_reference(golden):
+    n = 0
+    for key in golden.files:
+        if key.startswith("compress_"):
+            tag = key[len("compress_"):]
+            bits = int(tag[1])
+            mine = oracle.general_compress(golden["codes_" + tag], bits)
+            assert np.array_equal(mine, golden[key]), key
+            assert np.array_equal(oracle.general_decompress(mine, bits), golden["codes_" + tag])
+            n += 1
+    assert n >= 9
+
+
+def test_interleave_matches_reference(golden):
+    n = 0
+    for key in golden.files:
+        if key.startswith("interleave_"):
+            _, tgt, tag = key.split("_", 2)
+            bits = int(tag[1])
+            mine = oracle.interleave_weight(golden["compress_" + tag], bits, tgt, follow="numpy")
+            assert np.array_equal(mine, golden[key]), key
+            n += 1
+    assert n >= 9  # 4b/f16, 4b/i8, 2b/i8 (the other variants crash upstream under numpy 2)
+
+
+def test_signed_source_offset(golden):
+    codes = oracle.weight_to_codes(golden["int4_signed_src"], "int", 4)
+    assert np.array_equal(oracle.general_compress(codes, 4), golden["int4_signed_compress"])
+
+
+def test_interleave_is_a_bit_permutation():
+    rng = np.random.default_rng(3)
+    for bits in (1, 2, 4):
+        for tgt in ("float16", "int8"):
+            x = rng.integers(-128, 128, size=(5, 64), dtype=np.int8)
+            y = oracle.interleave_weight(x, bits, tgt)
+            assert np.array_equal(oracle.deinterleave_weight(y, bits, tgt), x)
+            assert np.unpackbits(x.view(np.uint8)).sum() == np.unpackbits(y.view(np.uint8)).sum()
+
+
+def test_decoders_known_values():
+    # int4 code u -> u - 8 ; int2 -> u - 2 ; int1 -> {0,-1}  (quantization.py:185-230)
+    assert list(oracle.decode_codes(np.arange(16), "int", 4)) == [float(u - 8) for u in range(16)]
+    assert list(oracle.decode_codes(np.arange(4), "int", 2)) == [-2.0, -1.0, 0.0, 1.0]
+    assert list(oracle.decode_codes(np.arange(2), "int", 1)) == [0.0, -1.0]
+    # fp4: sign + 3 exponent bits (quantization.py:141-156)
+    fp4 = oracle.decode_codes(np.arange(16), "fp", 4)
+    assert fp4[0] == 0.0 and fp4[8] == 0.0
+    assert fp4[1] == 2.0 ** -6 and fp4[7] == 1.0 and fp4[15] == -1.0
+    # e4m3 trick: exact on normals, zero -> 2^-7 (quantization.py:169-176)
+    import torch
+    vals = torch.tensor([1.0, -1.5, 0.015625, 448.0, 0.0]).to(torch.float8_e4m3fn)
+    strict = oracle.decode_codes(vals.view(torch.int8).numpy(), "fp_e4m3", 8, True)
+    ieee = oracle.decode_codes(vals.view(torch.int8).numpy(), "fp_e4m3", 8, False)
+    assert list(ieee) == [1.0, -1.5, 0.015625, 448.0, 0.0]
+    assert list(strict[:4]) == [1.0, -1.5, 0.015625, 448.0] and strict[4] == 2.0 ** -7
+    # all e4m3 bytes: IEEE decode agrees with torch
+    allb = np.arange(256, dtype=np.uint8)
+    t = torch.from_numpy(allb.copy()).view(torch.float8_e4m3fn).float().numpy()
+    mine = oracle.decode_e4m3_ieee(allb)
+    ok = np.isnan(t) | (t == mine)
+    assert ok.all()
+    t5 = torch.from_numpy(allb.copy()).view(torch.float8_e5m2).float().numpy()
+    m5 = oracle.decode_e5m2(allb)
+    assert (np.isnan(t5) | (t5 == m5)).all()
+
+
+def test_matmul_oracle_against_plain_float_math():
+    rng = np.random.default_rng(0)
+    M, N, K, g = 3, 8, 64, 32
+    A = (rng.random((M, K)) - 0.5).astype(np.float16)
+    codes = rng.integers(0, 16, size=(N, K)).astype(np.int8)
+    scale = rng.random((N, K // g)).astype(np.float16)
+    zeros = np.full((N, K // g), 8, dtype=np.float16)
+    out = oracle.matmul_dequant(A, codes, source_format="uint", bit=4, scale=scale, zeros=zeros,
+                                zeros_mode="original", group_size=g)
+    w = ((codes.astype(np.float16) - np.repeat(zeros, g, 1)).astype(np.float16) * np.repeat(scale, g, 1)).astype(np.float16)
+    ref = (A.astype(np.float64) @ w.astype(np.float64).T).astype(np.float16)
+    assert np.array_equal(out, ref)
+    # quantized zeros == original zeros when the zero points are the same integers
+    zq = oracle.general_compress(np.full((K // g, N), 8, dtype=np.int8), 4)
+    out_q = oracle.matmul_dequant(A, codes, source_format="uint", bit=4, scale=scale, zeros=zq,
+                                  zeros_mode="quantized", group_size=g)
+    assert np.array_equal(out_q, out)
+    # bias is added after the cast
+    bias = rng.random(N).astype(np.float16)
+    out_b = oracle.matmul_dequant(A, codes, source_format="uint", bit=4, scale=scale, zeros=zeros,
+                                  group_size=g, bias=bias)
+    assert np.array_equal(out_b, (out + bias).astype(np.float16))
+
+
+def test_gptq_unpack_helpers():
+    rng = np.random.default_rng(1)
+    z = rng.integers(0, 15, size=(4, 16)).astype(np.int64)   # stored zero points (value - 1)
+    packed = np.zeros((4, 2), dtype=np.int64)
+    for c in range(16):
+        packed[:, c // 8] |= z[:, c] << (4 * (c % 8))
+    q = packed.astype(np.uint32).view(np.int32)
+    assert np.array_equal(oracle.unpack_qzeros(q, 4), (z + 1) & 15)
+    assert np.array_equal(oracle.unpack_qzeros(q, 4, v2=True), z)
