@@ -256,7 +256,11 @@ __device__ __forceinline__ void decode_unit_f16(const u32x4& w, int u, half_t zf
                                                 const Lut16& lut, half2_t (&q)[P::T::G / 2]) {
   using T = typename P::T;
   constexpr int WPU = T::WPU;
-  if constexpr (P::KIND == DK_INT4 || P::KIND == DK_INT2 || P::KIND == DK_INT1) {
+  if constexpr (P::KIND == DK_INT1) {
+    // int1 is a sign-extended 1-bit field (quantization.py:220-230): value = -u = (1 - u) - 1, so
+    // invert the word and reuse the generic "field - 2^(bits-1)" path
+    F16Unpack<T::BITS>::run(a.is_signed ? ~w[u] : w[u], zf, q);
+  } else if constexpr (P::KIND == DK_INT4 || P::KIND == DK_INT2) {
     F16Unpack<T::BITS>::run(w[u], zf, q);
   } else if constexpr (P::KIND == DK_LUT4) {
     lut16_word(lut, w[u], q);
@@ -301,7 +305,8 @@ __device__ __forceinline__ void decode_unit_i8(const u32x4& w, int u, uint32_t z
 #pragma unroll
     for (int j = 0; j < T::WPU; ++j) {
       uint32_t t[NQ];
-      I8Unpack<T::BITS>::run(w[u * T::WPU + j], t);
+      // int1 signed: value = -u = (1 - u) - 1 -> invert the word first (see decode_unit_f16)
+      I8Unpack<T::BITS>::run((T::BITS == 1 && zp4) ? ~w[u * T::WPU + j] : w[u * T::WPU + j], t);
 #pragma unroll
       for (int i = 0; i < NQ; ++i) q[j * NQ + i] = zp4 ? sub_bytes(t[i], zp4) : t[i];
     }
@@ -774,7 +779,7 @@ __global__ void debug_decode_kernel(const uint32_t* packed, long nwords, int is_
     half2_t q[EPW / 2 > 0 ? EPW / 2 : 1];
     const half_t zf = (is_signed && T::SUBBYTE) ? (half_t)(float)(1 << (T::BITS - 1)) : (half_t)0.0f;
     if constexpr (KIND == DK_INT4 || KIND == DK_INT2 || KIND == DK_INT1) {
-      F16Unpack<T::BITS>::run(w, zf, q);
+      F16Unpack<T::BITS>::run((KIND == DK_INT1 && is_signed) ? ~w : w, zf, q);
     } else if constexpr (KIND == DK_LUT4) {
       Lut16 lut = fp4_table ? make_fp4_lut() : make_lut16(lut_p);
       lut16_word(lut, w, q);
@@ -803,7 +808,7 @@ __global__ void debug_decode_kernel(const uint32_t* packed, long nwords, int is_
     int8_t* o = reinterpret_cast<int8_t*>(out) + i * EPW;
     if constexpr (T::SUBBYTE) {
       uint32_t q[I8Unpack<T::BITS>::NQUAD];
-      I8Unpack<T::BITS>::run(w, q);
+      I8Unpack<T::BITS>::run((T::BITS == 1 && is_signed) ? ~w : w, q);
       const uint32_t zp4 = is_signed ? (uint32_t)(1u << (T::BITS - 1)) * 0x01010101u : 0u;
 #pragma unroll
       for (int x = 0; x < EPW; ++x) {

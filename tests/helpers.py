@@ -106,8 +106,13 @@ def hip_output(case, device="cuda", m_rows=None, matmul=None, strict_reference=T
     mm = matmul or bitblas.Matmul(case["config"], enable_tuning=False, strict_reference=strict_reference)
     w_user = case["w_user"]
     wt = w_user if isinstance(w_user, torch.Tensor) else torch.from_numpy(w_user)
-    if case["source_format"] == "int" and case["bit"] == 1:
-        # transform_weight clamps/offsets signed sources; int1 codes are fed pre-offset
+    cfg = case["config"]
+    if case["source_format"] == "int" and case["bit"] < 8 and (
+            case["bit"] == 1 or cfg.with_scaling or cfg.with_zeros):
+        # transform_weight clamps/offsets signed sources and (like the reference, general_matmul/
+        # __init__.py:685-687) refuses int formats with scale/zeros; the reference's own op test
+        # feeds `intweight + maxq` straight to weight_transform in that case
+        # (test_general_matmul_ops_backend_tl.py:187-194).  int1 codes are fed pre-offset too.
         W = mm.weight_transform(torch.from_numpy(case["codes"])).to(device)
     else:
         W = mm.transform_weight(wt.to(device))
