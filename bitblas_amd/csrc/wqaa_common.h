@@ -32,14 +32,17 @@ struct GemvArgs {
   int kg;           // groups per weight row (K / group_size)
   int g_log2;       // log2(group_size) or -1 when not a power of two
   int g;            // group size (elements)
+  int gq_shift;     // lane chunks per group = g / E as a shift (-1: use gq_magic)
+  uint32_t gq_magic;  // ceil(2^32 / (g / E)) for non power-of-two ratios
   int nc;           // 64-lane chunks per weight row
+  int ncp;          // nc rounded up to the step depth (LDS activation slots, zero beyond K)
+  int cpr;          // valid 16-byte lane chunks per weight row
   long row_bytes;   // bytes per weight row
-  int zmode;        // wqaa_zeros_mode
-  int has_scale, has_bias;
+  int has_bias;
   int out_dtype;    // wqaa_dtype
   int is_signed;    // WQAA_W_INT
-  int strict;       // reference e4m3 bit trick
   int fp4_table;    // DK_LUT4: 1 = built-in fp4 table, 0 = caller LUT
+  int a_fmt;        // wqaa_dtype of A as stored (fp8 activations are widened while staging)
   int zq_row_bytes; // quantized zeros: bytes per group row (N*bits/8)
 };
 

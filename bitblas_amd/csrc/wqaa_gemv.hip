@@ -8,11 +8,16 @@
 //   * one wave64 streams R weight rows; every lane issues 16-byte non-temporal loads, so a wave
 //     instruction fetches 1 KiB of contiguous packed weights (the reference's default issues
 //     4-byte loads per thread);
-//   * D stages of those loads are in flight per wave before anything is consumed - at
-//     N = K = 4096 the whole 8.4 MB weight matrix is requested in the first few hundred cycles;
+//   * a step = D lane-chunks x R rows of loads, all issued before anything is consumed; every load
+//     is unconditional (out-of-range lanes/rows are clamped to a valid address and meet a
+//     zero-filled activation slot), so the compiler can count them: the .s has `vmcnt(N)` ladders,
+//     no `vmcnt(0)` between loads;
 //   * the activation rows are staged once per workgroup into LDS as [piece][lane] 16-byte slots,
 //     already permuted into the order the unpack produces (wqaa_decode.h), so ds_read_b128 is
-//     conflict free and the inner loop has no shuffles;
+//     conflict free and the inner loop has no shuffles.  Their global loads are issued BEFORE the
+//     first weight step and written to LDS after it, so they never queue behind HBM traffic;
+//   * everything that selects code (weight kind, layout, zero mode, batch tile) is a template
+//     parameter: no runtime branch sits between loads;
 //   * unpack -> (zero, scale) in packed fp16 exactly as the TE definition does it
 //     (tirscript/matmul_dequantize_impl.py:391-451) -> V_DOT2_F32_F16 / V_DOT4_I32_I8 into
 //     fp32 / int32 accumulators -> DPP row reduction + readlane.
@@ -22,8 +27,12 @@
 namespace wqaa {
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
 enum : int { AT_F16 = 0, AT_I8 = 1 };
+// dequant arithmetic (matmul_dequantize_impl.py:435-449)
+enum : int { MD_NONE = 0, MD_S = 1, MD_ZO = 2, MD_ZR = 3, MD_ZQ = 4 };
+enum : int { FL_STRICT = 1, FL_A8 = 2 };  // e4m3 reference bit trick; activations stored as fp8
 
 constexpr int cmax(int a, int b) { return a > b ? a : b; }
 
@@ -139,26 +148,30 @@ __device__ __forceinline__ void store_out(void* C, long idx, int acc, int out_dt
 }
 
 // ------------------------------------------------------------------------------------------
-// the kernel
+// policy
 // ------------------------------------------------------------------------------------------
-template <int KIND_, int LAYOUT_, int AT_, int MB_, int R_, int D_>
+template <int KIND_, int LAYOUT_, int AT_, int MB_, int MODE_, int FLAGS_, int R_ = 2, int D_ = 2>
 struct GemvPolicy {
-  static constexpr int KIND = KIND_, LAYOUT = LAYOUT_, AT = AT_, MB = MB_, R = R_, D = D_;
-  static constexpr int THREADS = 256;
+  static constexpr int KIND = KIND_, LAYOUT = LAYOUT_, AT = AT_, MB = MB_, MODE = MODE_, FLAGS = FLAGS_;
+  static constexpr int R = R_;       // weight rows per wave per step
+  static constexpr int D = D_;       // lane chunks per step
+  static constexpr bool STRICT = (FLAGS_ & FL_STRICT) != 0;
+  static constexpr bool A8 = (FLAGS_ & FL_A8) != 0;
   using T = KindTraits<KIND_, AT_>;
+  // words of raw activation data per staging item (one decode unit = G elements)
+  static constexpr int AW = (AT_ == AT_I8 || A8) ? T::G / 4 : T::G / 2;
+  // activation items per thread loaded ahead of the weights (<= 32 VGPRs)
+  static constexpr int NA = 32 / AW > 8 ? 8 : (32 / AW < 1 ? 1 : 32 / AW);
 };
 
 template <class P>
 struct Stage {
   u32x4 w[P::R];
-  uint32_t sz[P::R];  // scale bits | zero bits << 16 (kept in one 32-bit register per row)
+  uint32_t s[P::R];  // scale bits (low 16)
+  uint32_t z[P::R];  // zero bits (low 16) / raw qzeros byte
 };
 
-__device__ __forceinline__ half_t stage_scale(uint32_t sz) { return __builtin_bit_cast(half_t, (uint16_t)(sz & 0xFFFFu)); }
-__device__ __forceinline__ half_t stage_zero(uint32_t sz) { return __builtin_bit_cast(half_t, (uint16_t)(sz >> 16)); }
-
-// source activation dtype handled while staging (A may be fp16, or fp8 widened to fp16)
-enum : int { ASRC_F16 = 0, ASRC_E4M3 = 1, ASRC_E5M2 = 2, ASRC_I8 = 3 };
+__device__ __forceinline__ half_t bits_to_half(uint32_t b) { return __builtin_bit_cast(half_t, (uint16_t)(b & 0xFFFFu)); }
 
 __device__ __forceinline__ half_t fp8_to_half(uint8_t v, bool e5m2) {
   if (e5m2) return __builtin_bit_cast(half_t, (uint16_t)((uint16_t)v << 8));
@@ -168,98 +181,115 @@ __device__ __forceinline__ half_t fp8_to_half(uint8_t v, bool e5m2) {
   return __builtin_bit_cast(half_t, bits);
 }
 
+template <int NWORDS>
+__device__ __forceinline__ void load_words(const void* p, uint32_t (&w)[NWORDS]) {
+  if constexpr (NWORDS % 4 == 0) {
+#pragma unroll
+    for (int q = 0; q < NWORDS / 4; ++q) {
+      const u32x4 v = reinterpret_cast<const u32x4*>(p)[q];
+      w[4 * q] = v[0]; w[4 * q + 1] = v[1]; w[4 * q + 2] = v[2]; w[4 * q + 3] = v[3];
+    }
+  } else if constexpr (NWORDS == 2) {
+    const u32x2 v = *reinterpret_cast<const u32x2*>(p);
+    w[0] = v[0]; w[1] = v[1];
+  } else {
+    static_assert(NWORDS == 1, "unsupported activation item width");
+    w[0] = *reinterpret_cast<const uint32_t*>(p);
+  }
+}
+
+// ---- activation staging: item idx = ((mi * ncp + c) * UNITS + u) * 64 + lane -----------------
 template <class P>
-__device__ __forceinline__ void stage_activations(const GemvArgs& a, int m0, int a_src, u32x4* a_lds) {
+struct AItem {
+  uint32_t w[P::AW];
+  bool valid;
+};
+
+template <class P>
+__device__ __forceinline__ void a_item_load(const GemvArgs& a, int m0, int idx, AItem<P>& it) {
   using T = typename P::T;
-  constexpr int G = T::G, PE = T::PE, PU = T::PU, UNITS = T::UNITS, PIECES = T::PIECES, E = T::E;
-  const int nc = a.nc;
-  const int total = P::MB * nc * 64 * UNITS;
-  for (int idx = threadIdx.x; idx < total; idx += P::THREADS) {
-    const int l = idx & 63;
-    int t = idx >> 6;
-    const int u = t % UNITS;
-    t /= UNITS;
-    const int c = t % nc;
-    const int mi = t / nc;
-    const long kb = (long)(c * 64 + l) * E + u * G;
-    const bool valid = kb < a.K && (m0 + mi) < a.m;
-    const long src_off = (long)(m0 + mi) * a.K + kb;
-    if constexpr (P::AT == AT_F16) {
-      half_t src[G];
-      if (valid) {
-        if (a_src == ASRC_F16) {
-          const u32x4* p = reinterpret_cast<const u32x4*>(reinterpret_cast<const half_t*>(a.A) + src_off);
+  const int mi = idx % P::MB;          // all divisors are compile-time powers of two
+  const int i = idx / P::MB;
+  const int l = i & 63;
+  const int u = (i >> 6) % T::UNITS;
+  const int c = (i >> 6) / T::UNITS;
+  const int kb = (c * 64 + l) * T::E + u * T::G;
+  it.valid = kb < a.K && (m0 + mi) < a.m;
+  const long off = it.valid ? (long)(m0 + mi) * a.K + kb : 0;   // clamped: always a readable address
+  constexpr int esz = (P::AT == AT_I8 || P::A8) ? 1 : 2;
+  load_words<P::AW>(reinterpret_cast<const uint8_t*>(a.A) + off * esz, it.w);
+}
+
+template <class P>
+__device__ __forceinline__ void a_item_store(const GemvArgs& a, int ncp, int idx, const AItem<P>& it, u32x4* a_lds) {
+  using T = typename P::T;
+  constexpr int G = T::G, PE = T::PE, PU = T::PU, UNITS = T::UNITS, PIECES = T::PIECES;
+  const int mi = idx % P::MB;
+  const int i = idx / P::MB;
+  const int l = i & 63;
+  const int u = (i >> 6) % UNITS;
+  const int t = mi * ncp + (i >> 6) / UNITS;
+  if constexpr (P::AT == AT_F16) {
+    half_t src[G];
+    if constexpr (P::A8) {
 #pragma unroll
-          for (int q = 0; q < G / 8; ++q) {
-            const u32x4 v = p[q];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const half2_t h = as_h2(v[e]);
-              src[q * 8 + 2 * e] = h[0];
-              src[q * 8 + 2 * e + 1] = h[1];
-            }
-          }
-        } else {
-          const uint8_t* p = reinterpret_cast<const uint8_t*>(a.A) + src_off;
-#pragma unroll
-          for (int e = 0; e < G; ++e) src[e] = fp8_to_half(p[e], a_src == ASRC_E5M2);
-        }
-      } else {
-#pragma unroll
-        for (int e = 0; e < G; ++e) src[e] = (half_t)0.0f;
-      }
-#pragma unroll
-      for (int pp = 0; pp < PU; ++pp) {
-        u32x4 out;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const half2_t h = {src[T::src_elem(P::LAYOUT, pp * PE + 2 * e)],
-                             src[T::src_elem(P::LAYOUT, pp * PE + 2 * e + 1)]};
-          out[e] = as_u32(h);
-        }
-        a_lds[((long)(mi * nc + c) * PIECES + u * PU + pp) * 64 + l] = out;
-      }
+      for (int e = 0; e < G; ++e)
+        src[e] = fp8_to_half((uint8_t)(it.w[e / 4] >> (8 * (e % 4))), a.a_fmt == WQAA_E5M2);
     } else {
-      uint8_t src[G];
-      if (valid) {
-        const uint32_t* p = reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(a.A) + src_off);
 #pragma unroll
-        for (int q = 0; q < G / 4; ++q) {
-          const uint32_t v = p[q];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) src[q * 4 + e] = (uint8_t)(v >> (8 * e));
-        }
-      } else {
-#pragma unroll
-        for (int e = 0; e < G; ++e) src[e] = 0;
+      for (int e = 0; e < G / 2; ++e) {
+        const half2_t h = as_h2(it.w[e]);
+        src[2 * e] = h[0];
+        src[2 * e + 1] = h[1];
       }
+    }
 #pragma unroll
-      for (int pp = 0; pp < PU; ++pp) {
-        u32x4 out;
+    for (int pp = 0; pp < PU; ++pp) {
+      u32x4 out;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          uint32_t v = 0;
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            v |= (uint32_t)src[T::src_elem(P::LAYOUT, pp * PE + 4 * q + e)] << (8 * e);
-          out[q] = v;
-        }
-        a_lds[((long)(mi * nc + c) * PIECES + u * PU + pp) * 64 + l] = out;
+      for (int e = 0; e < 4; ++e) {
+        const half2_t h = {src[T::src_elem(P::LAYOUT, pp * PE + 2 * e)],
+                           src[T::src_elem(P::LAYOUT, pp * PE + 2 * e + 1)]};
+        out[e] = it.valid ? as_u32(h) : 0u;
       }
+      a_lds[((long)t * PIECES + u * PU + pp) * 64 + l] = out;
+    }
+  } else {
+    uint8_t src[G];
+#pragma unroll
+    for (int e = 0; e < G; ++e) src[e] = (uint8_t)(it.w[e / 4] >> (8 * (e % 4)));
+#pragma unroll
+    for (int pp = 0; pp < PU; ++pp) {
+      u32x4 out;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        uint32_t v = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          v |= (uint32_t)src[T::src_elem(P::LAYOUT, pp * PE + 4 * q + e)] << (8 * e);
+        out[q] = it.valid ? v : 0u;
+      }
+      a_lds[((long)t * PIECES + u * PU + pp) * 64 + l] = out;
     }
   }
 }
 
-// decode one unit of row r into fp16 pairs (exact field values minus folded zero point)
+// ---- decode one unit of one row into fp16 pairs (exact field values minus folded zero point) ----
+struct DecodeCtx {
+  half_t zf;        // folded integer zero point (signed formats: 2^(bits-1))
+  uint32_t flip;    // int1 signed: ~w ; int8 signed: w ^ 0x80808080
+  half_t off8;      // int8 weights: 1024 (+128 signed)
+};
+
 template <class P>
-__device__ __forceinline__ void decode_unit_f16(const u32x4& w, int u, half_t zf, const GemvArgs& a,
+__device__ __forceinline__ void decode_unit_f16(const u32x4& w, int u, half_t zf, const DecodeCtx& cx,
                                                 const Lut16& lut, half2_t (&q)[P::T::G / 2]) {
   using T = typename P::T;
   constexpr int WPU = T::WPU;
   if constexpr (P::KIND == DK_INT1) {
     // int1 is a sign-extended 1-bit field (quantization.py:220-230): value = -u = (1 - u) - 1, so
     // invert the word and reuse the generic "field - 2^(bits-1)" path
-    F16Unpack<T::BITS>::run(a.is_signed ? ~w[u] : w[u], zf, q);
+    F16Unpack<T::BITS>::run(w[u] ^ cx.flip, zf, q);
   } else if constexpr (P::KIND == DK_INT4 || P::KIND == DK_INT2) {
     F16Unpack<T::BITS>::run(w[u], zf, q);
   } else if constexpr (P::KIND == DK_LUT4) {
@@ -267,18 +297,18 @@ __device__ __forceinline__ void decode_unit_f16(const u32x4& w, int u, half_t zf
   } else if constexpr (P::KIND == DK_INT8) {
 #pragma unroll
     for (int j = 0; j < WPU; ++j) {
-      half2_t t[2];
-      if (a.is_signed) unpack8_f16<true>(w[u * WPU + j], zf, t);
-      else unpack8_f16<false>(w[u * WPU + j], zf, t);
-      q[2 * j] = t[0];
-      q[2 * j + 1] = t[1];
+      const uint32_t x = w[u * WPU + j] ^ cx.flip;
+      const uint32_t lo = __builtin_amdgcn_perm(0x64646464u, x, 0x04010400u);  // {b0,0x64,b1,0x64}
+      const uint32_t hi = __builtin_amdgcn_perm(0x64646464u, x, 0x04030402u);  // {b2,0x64,b3,0x64}
+      const half2_t off = splat(cx.off8 + zf);
+      q[2 * j] = as_h2(lo) - off;
+      q[2 * j + 1] = as_h2(hi) - off;
     }
   } else if constexpr (P::KIND == DK_E4M3) {
 #pragma unroll
     for (int j = 0; j < WPU; ++j) {
       half2_t t[2];
-      if (a.strict) unpack_e4m3_f16<true>(w[u * WPU + j], t);
-      else unpack_e4m3_f16<false>(w[u * WPU + j], t);
+      unpack_e4m3_f16<P::STRICT>(w[u * WPU + j], t);
       q[2 * j] = t[0];
       q[2 * j + 1] = t[1];
     }
@@ -297,7 +327,7 @@ __device__ __forceinline__ void decode_unit_f16(const u32x4& w, int u, half_t zf
 }
 
 template <class P>
-__device__ __forceinline__ void decode_unit_i8(const u32x4& w, int u, uint32_t zp4,
+__device__ __forceinline__ void decode_unit_i8(const u32x4& w, int u, uint32_t zp4, uint32_t flip,
                                                uint32_t (&q)[P::T::G / 4]) {
   using T = typename P::T;
   if constexpr (T::SUBBYTE) {
@@ -306,9 +336,9 @@ __device__ __forceinline__ void decode_unit_i8(const u32x4& w, int u, uint32_t z
     for (int j = 0; j < T::WPU; ++j) {
       uint32_t t[NQ];
       // int1 signed: value = -u = (1 - u) - 1 -> invert the word first (see decode_unit_f16)
-      I8Unpack<T::BITS>::run((T::BITS == 1 && zp4) ? ~w[u * T::WPU + j] : w[u * T::WPU + j], t);
+      I8Unpack<T::BITS>::run(w[u * T::WPU + j] ^ flip, t);
 #pragma unroll
-      for (int i = 0; i < NQ; ++i) q[j * NQ + i] = zp4 ? sub_bytes(t[i], zp4) : t[i];
+      for (int i = 0; i < NQ; ++i) q[j * NQ + i] = sub_bytes(t[i], zp4);
     }
   } else {
 #pragma unroll
@@ -316,73 +346,93 @@ __device__ __forceinline__ void decode_unit_i8(const u32x4& w, int u, uint32_t z
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// the kernel
+// ------------------------------------------------------------------------------------------
 template <class P>
-__global__ void __launch_bounds__(256) wq_gemv_kernel(const GemvArgs a, const int a_src) {
+__global__ void __launch_bounds__(1024) wq_gemv_kernel(const GemvArgs a) {
   using T = typename P::T;
-  constexpr int R = P::R, MB = P::MB, D = P::D;
-  constexpr int E = T::E, G = T::G, PE = T::PE, PU = T::PU, UNITS = T::UNITS, PIECES = T::PIECES;
-  constexpr int NW = P::THREADS / 64;
+  constexpr int R = P::R, MB = P::MB, D = P::D, NA = P::NA, MODE = P::MODE;
+  constexpr int E = T::E, G = T::G, PU = T::PU, UNITS = T::UNITS, PIECES = T::PIECES;
   constexpr bool F16 = P::AT == AT_F16;
   using acc_t = typename std::conditional<F16, float, int>::type;
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   u32x4* a_lds = reinterpret_cast<u32x4*>(smem_raw);
 
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int nc = a.nc;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nc = a.nc;                 // lane chunks (of 64 lanes) per row
+  const int ncp = a.ncp;               // rounded up to a multiple of D: LDS slots beyond K are zero
+  const int cpr = a.cpr;               // valid 16-byte lane chunks per row
   const int n_rg = (a.N + R - 1) / R;
+  const int nthreads = blockDim.x;      // 64 / 128 / 256: picked by the selector
+  const int NW = nthreads >> 6;
   const int total_waves = gridDim.x * NW;
-  const int wg = blockIdx.x * NW + wave;
+  // XCD-aware block order (block b runs on XCD b % 8): every XCD owns a contiguous range of rows,
+  // so the 2-byte results that share a 128-byte line of C are written through one L2
+  int blk = blockIdx.x;
+  if ((gridDim.x & 7) == 0) blk = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  const int wg = blk * NW + wave;
   const int m0 = blockIdx.y * MB;
   const uint8_t* Bp = reinterpret_cast<const uint8_t*>(a.B);
   const uint16_t* Sp = reinterpret_cast<const uint16_t*>(a.scale);
+  const uint16_t* Zp = reinterpret_cast<const uint16_t*>(a.zeros);
+  const uint8_t* Qp = reinterpret_cast<const uint8_t*>(a.zeros);
+  constexpr int ZB = T::SUBBYTE ? T::BITS : 8;   // quantized zeros field width
+  constexpr int ZPB = 8 / ZB;
 
-  Stage<P> st[D];
-  int ld_rg = wg, ld_c = 0;
-
-  auto issue = [&](Stage<P>& s) {
-    const int chunk = ld_c * 64 + lane;
-    const long k0 = (long)chunk * E;
-    const bool kvalid = k0 < a.K;
-    int gi = 0;
-    if (a.kg > 1) gi = a.g_log2 >= 0 ? (int)(k0 >> a.g_log2) : (int)(k0 / a.g);
+  // ---- activations: tiles larger than NA items/thread go through a plain loop first ----
+  const int total_items = MB * ncp * 64 * UNITS;
+  for (int idx = NA * nthreads + tid; idx < total_items; idx += nthreads) {
+    AItem<P> it;
+    a_item_load<P>(a, m0, idx, it);
+    a_item_store<P>(a, ncp, idx, it, a_lds);
+  }
+  // the first NA items per thread: loads now (ahead of the weight stream), LDS writes after the
+  // first weight step has been issued
+  AItem<P> ahead[NA];
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-      int n = ld_rg * R + r;
-      n = n < a.N ? n : a.N - 1;
-      s.w[r] = u32x4{0u, 0u, 0u, 0u};
-      uint32_t sbits = 0, zbits = 0;
-      if (kvalid) {
-        s.w[r] = __builtin_nontemporal_load(
+  for (int j = 0; j < NA; ++j) {
+    const int idx = j * nthreads + tid;
+    if (j * nthreads < total_items)   // wave-uniform: whole rounds beyond the tile are skipped
+      a_item_load<P>(a, m0, idx < total_items ? idx : 0, ahead[j]);
+  }
+
+  // one step: D lane chunks x R rows, every load unconditional
+  auto issue = [&](Stage<P> (&st)[D], int rg, int c0) {
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      int chunk = (c0 + d) * 64 + lane;
+      chunk = chunk < cpr ? chunk : 0;       // clamped lanes meet zero activations
+      // group of this lane chunk: chunk / (g / E), as a shift or a 32x32->hi multiply by ceil(2^32 / d)
+      // (exact for chunk, d < 2^16), selected without a branch
+      int gi = 0;
+      if (MODE != MD_NONE) gi = a.gq_shift >= 0 ? (chunk >> a.gq_shift) : (int)__umulhi((uint32_t)chunk, a.gq_magic);
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        int n = rg * R + r;
+        n = n < a.N ? n : a.N - 1;
+        st[d].w[r] = __builtin_nontemporal_load(
             reinterpret_cast<const u32x4*>(Bp + (long)n * a.row_bytes + (long)chunk * 16));
-        if constexpr (F16) {
-          if (a.has_scale) sbits = Sp[(long)n * a.kg + gi];
-          if (a.zmode == WQAA_Z_ORIGINAL || a.zmode == WQAA_Z_RESCALE) {
-            zbits = reinterpret_cast<const uint16_t*>(a.zeros)[(long)n * a.kg + gi];
-          } else if (a.zmode == WQAA_Z_QUANTIZED) {
-            constexpr int ZB = T::SUBBYTE ? T::BITS : 8;
-            constexpr int ZPB = 8 / ZB;
-            const uint8_t zb = reinterpret_cast<const uint8_t*>(a.zeros)[(long)gi * a.zq_row_bytes + n / ZPB];
-            const uint32_t zq = (zb >> ((n % ZPB) * ZB)) & ((1u << ZB) - 1u);
-            zbits = __builtin_bit_cast(uint16_t, (half_t)(float)zq);
-          }
-        }
+        if constexpr (MODE != MD_NONE) st[d].s[r] = Sp[(long)n * a.kg + gi];
+        if constexpr (MODE == MD_ZO || MODE == MD_ZR) st[d].z[r] = Zp[(long)n * a.kg + gi];
+        if constexpr (MODE == MD_ZQ) st[d].z[r] = Qp[(long)gi * a.zq_row_bytes + n / ZPB];
       }
-      s.sz[r] = sbits | (zbits << 16);
-    }
-    if (++ld_c == nc) {
-      ld_c = 0;
-      ld_rg += total_waves;
     }
   };
 
-  // ---- prologue: put D stages of weight loads in flight, then stage the activations ----
-#pragma unroll
-  for (int d = 0; d < D; ++d)
-    if (ld_rg < n_rg) issue(st[d]);
+  Stage<P> st[D];
+  int rg = wg;
+  const bool have_work = rg < n_rg;
+  issue(st, have_work ? rg : n_rg - 1, 0);
 
-  stage_activations<P>(a, m0, a_src, a_lds);
+#pragma unroll
+  for (int j = 0; j < NA; ++j) {
+    const int idx = j * nthreads + tid;
+    if (idx < total_items) a_item_store<P>(a, ncp, idx, ahead[j], a_lds);
+  }
 
   Lut16 lut;
   if constexpr (P::KIND == DK_LUT4) {
@@ -394,32 +444,45 @@ __global__ void __launch_bounds__(256) wq_gemv_kernel(const GemvArgs a, const in
   }
   __syncthreads();
 
+  DecodeCtx cx;
+  cx.zf = (F16 && a.is_signed && T::SUBBYTE) ? (half_t)(float)(1 << (T::BITS - 1)) : (half_t)0.0f;
+  cx.flip = 0u;
+  if (P::KIND == DK_INT1 && a.is_signed) cx.flip = 0xFFFFFFFFu;
+  if (P::KIND == DK_INT8 && a.is_signed) cx.flip = 0x80808080u;
+  cx.off8 = (half_t)(a.is_signed ? 1152.0f : 1024.0f);
+  const uint32_t zp4 = (!F16 && a.is_signed && T::SUBBYTE) ? (uint32_t)(1u << (T::BITS - 1)) * 0x01010101u : 0u;
+
   acc_t acc[R][MB];
 #pragma unroll
   for (int r = 0; r < R; ++r)
 #pragma unroll
     for (int mi = 0; mi < MB; ++mi) acc[r][mi] = 0;
 
-  const half_t zf_const = (F16 && a.is_signed && T::SUBBYTE) ? (half_t)(float)(1 << (T::BITS - 1)) : (half_t)0.0f;
-  const uint32_t zp4 = (!F16 && a.is_signed && T::SUBBYTE) ? (uint32_t)(1u << (T::BITS - 1)) * 0x01010101u : 0u;
-
-  int cs_rg = wg, cs_c = 0;
-
-  auto consume = [&](const Stage<P>& s) {
+  auto consume = [&](const Stage<P>& s, int c, int rg_now) {
 #pragma unroll
     for (int u = 0; u < UNITS; ++u) {
       if constexpr (F16) {
         half2_t q[R][G / 2];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-          const half_t zf = a.zmode == WQAA_Z_QUANTIZED ? stage_zero(s.sz[r]) : zf_const;
-          decode_unit_f16<P>(s.w[r], u, zf, a, lut, q[r]);
-          if (a.zmode == WQAA_Z_ORIGINAL) {
-            const half2_t z2 = splat(stage_zero(s.sz[r])), s2 = splat(stage_scale(s.sz[r]));
+          half_t zf = cx.zf;
+          if constexpr (MODE == MD_ZQ) {
+            // (w_u - zero_u) in the integer domain (quantization.py:208-217): ignores signedness
+            const int n = rg_now * R + r;
+            const uint32_t zq = (s.z[r] >> ((n % ZPB) * ZB)) & ((1u << ZB) - 1u);
+            zf = (half_t)(float)zq;
+          }
+          decode_unit_f16<P>(s.w[r], u, zf, cx, lut, q[r]);
+          if constexpr (MODE == MD_S || MODE == MD_ZQ) {
+            const half2_t s2 = splat(bits_to_half(s.s[r]));
+#pragma unroll
+            for (int i = 0; i < G / 2; ++i) q[r][i] = q[r][i] * s2;
+          } else if constexpr (MODE == MD_ZO) {
+            const half2_t z2 = splat(bits_to_half(s.z[r])), s2 = splat(bits_to_half(s.s[r]));
 #pragma unroll
             for (int i = 0; i < G / 2; ++i) q[r][i] = (q[r][i] - z2) * s2;
-          } else if (a.zmode == WQAA_Z_RESCALE) {
-            const half2_t z2 = splat(stage_zero(s.sz[r])), s2 = splat(stage_scale(s.sz[r]));
+          } else if constexpr (MODE == MD_ZR) {
+            const half2_t z2 = splat(bits_to_half(s.z[r])), s2 = splat(bits_to_half(s.s[r]));
 #pragma unroll
             for (int i = 0; i < G / 2; ++i) {
               half2_t t = q[r][i] * s2;
@@ -427,17 +490,13 @@ __global__ void __launch_bounds__(256) wq_gemv_kernel(const GemvArgs a, const in
               asm volatile("" : "+v"(t));
               q[r][i] = t - z2;
             }
-          } else if (a.has_scale) {
-            const half2_t s2 = splat(stage_scale(s.sz[r]));
-#pragma unroll
-            for (int i = 0; i < G / 2; ++i) q[r][i] = q[r][i] * s2;
           }
         }
 #pragma unroll
         for (int pp = 0; pp < PU; ++pp) {
 #pragma unroll
           for (int mi = 0; mi < MB; ++mi) {
-            const u32x4 av = a_lds[((long)(mi * nc + cs_c) * PIECES + u * PU + pp) * 64 + lane];
+            const u32x4 av = a_lds[((long)(mi * ncp + c) * PIECES + u * PU + pp) * 64 + lane];
 #pragma unroll
             for (int r = 0; r < R; ++r)
 #pragma unroll
@@ -448,12 +507,12 @@ __global__ void __launch_bounds__(256) wq_gemv_kernel(const GemvArgs a, const in
       } else {
         uint32_t q[R][G / 4];
 #pragma unroll
-        for (int r = 0; r < R; ++r) decode_unit_i8<P>(s.w[r], u, zp4, q[r]);
+        for (int r = 0; r < R; ++r) decode_unit_i8<P>(s.w[r], u, zp4, cx.flip, q[r]);
 #pragma unroll
         for (int pp = 0; pp < PU; ++pp) {
 #pragma unroll
           for (int mi = 0; mi < MB; ++mi) {
-            const u32x4 av = a_lds[((long)(mi * nc + cs_c) * PIECES + u * PU + pp) * 64 + lane];
+            const u32x4 av = a_lds[((long)(mi * ncp + c) * PIECES + u * PU + pp) * 64 + lane];
 #pragma unroll
             for (int r = 0; r < R; ++r)
 #pragma unroll
@@ -465,10 +524,10 @@ __global__ void __launch_bounds__(256) wq_gemv_kernel(const GemvArgs a, const in
     }
   };
 
-  auto finish = [&]() {
+  auto finish = [&](int rg_now) {
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      const int n = cs_rg * R + r;
+      const int n = rg_now * R + r;
 #pragma unroll
       for (int mi = 0; mi < MB; ++mi) {
         const acc_t tot = wave_sum(acc[r][mi]);
@@ -486,100 +545,117 @@ __global__ void __launch_bounds__(256) wq_gemv_kernel(const GemvArgs a, const in
     }
   };
 
-  while (cs_rg < n_rg) {
+  if (!have_work) return;
+  // first step was issued before the barrier; later steps are issued right after the previous
+  // step's registers are consumed
+  int c0 = 0;
+  while (true) {
 #pragma unroll
-    for (int d = 0; d < D; ++d) {
-      if (cs_rg < n_rg) {
-        consume(st[d]);
-        if (cs_c == nc - 1) finish();
-        if (++cs_c == nc) {
-          cs_c = 0;
-          cs_rg += total_waves;
-        }
-        if (ld_rg < n_rg) issue(st[d]);
-      }
+    for (int d = 0; d < D; ++d) consume(st[d], c0 + d, rg);
+    c0 += D;
+    if (c0 >= nc) {
+      finish(rg);
+      c0 = 0;
+      rg += total_waves;
+      if (rg >= n_rg) break;
     }
+    issue(st, rg, c0);
   }
 }
 
 // ------------------------------------------------------------------------------------------
 // host side: kernel table + tile-config selector
 // ------------------------------------------------------------------------------------------
-typedef void (*gemv_fn)(const GemvArgs, const int);
+typedef void (*gemv_fn)(const GemvArgs);
 
-// widest batch tile instantiated per kind (register budget: 1-/2-bit units decode 32/16 values)
-static int max_mb(int kind, int at) {
-  if (at == AT_F16 && kind == DK_INT1) return 2;
-  if (at == AT_F16 && kind == DK_INT2) return 4;
-  return 8;
-}
+static const int kBatchTiles[] = {1, 2, 4};
 
-template <int KIND, int LAYOUT, int AT>
-static gemv_fn pick_mb(int mb, int* R, int* D) {
-  constexpr int MAXMB = (AT == AT_F16 && KIND == DK_INT1) ? 2 : (AT == AT_F16 && KIND == DK_INT2) ? 4 : 8;
-  if constexpr (MAXMB < 8) {
-    if (mb > MAXMB) return nullptr;
-  }
+template <int KIND, int LAYOUT, int AT, int MODE, int FLAGS>
+static gemv_fn pick_mb(int mb) {
   switch (mb) {
-    case 1: *R = 2; *D = 2; return wq_gemv_kernel<GemvPolicy<KIND, LAYOUT, AT, 1, 2, 2>>;
-    case 2: *R = 2; *D = 2; return wq_gemv_kernel<GemvPolicy<KIND, LAYOUT, AT, 2, 2, 2>>;
-    case 4:
-      if constexpr (MAXMB >= 4) { *R = 2; *D = 2; return wq_gemv_kernel<GemvPolicy<KIND, LAYOUT, AT, 4, 2, 2>>; }
-      return nullptr;
-    default:
-      if constexpr (MAXMB >= 8) { *R = 2; *D = 1; return wq_gemv_kernel<GemvPolicy<KIND, LAYOUT, AT, 8, 2, 1>>; }
-      return nullptr;
+    case 1: return wq_gemv_kernel<GemvPolicy<KIND, LAYOUT, AT, 1, MODE, FLAGS>>;
+    case 2: return wq_gemv_kernel<GemvPolicy<KIND, LAYOUT, AT, 2, MODE, FLAGS>>;
+    case 4: return wq_gemv_kernel<GemvPolicy<KIND, LAYOUT, AT, 4, MODE, FLAGS>>;
+    default: return nullptr;
   }
 }
 
-static gemv_fn pick_kernel(int kind, int layout, int at, int mb, int* R, int* D) {
-#define WQAA_PICK(K, L, A) \
-  if (kind == K && layout == L && at == A) return pick_mb<K, L, A>(mb, R, D)
-  WQAA_PICK(DK_INT4, LAYOUT_LOP3, AT_F16);
-  WQAA_PICK(DK_INT4, LAYOUT_PLAIN, AT_F16);
-  WQAA_PICK(DK_INT2, LAYOUT_LOP3, AT_F16);
-  WQAA_PICK(DK_INT2, LAYOUT_PLAIN, AT_F16);
-  WQAA_PICK(DK_INT1, LAYOUT_LOP3, AT_F16);
-  WQAA_PICK(DK_INT1, LAYOUT_PLAIN, AT_F16);
-  WQAA_PICK(DK_INT8, LAYOUT_PLAIN, AT_F16);
-  WQAA_PICK(DK_LUT4, LAYOUT_PLAIN, AT_F16);
-  WQAA_PICK(DK_E4M3, LAYOUT_PLAIN, AT_F16);
-  WQAA_PICK(DK_E5M2, LAYOUT_PLAIN, AT_F16);
-  WQAA_PICK(DK_NATIVE, LAYOUT_PLAIN, AT_F16);
-  WQAA_PICK(DK_INT4, LAYOUT_LOP3, AT_I8);
-  WQAA_PICK(DK_INT4, LAYOUT_PLAIN, AT_I8);
-  WQAA_PICK(DK_INT2, LAYOUT_LOP3, AT_I8);
-  WQAA_PICK(DK_INT2, LAYOUT_PLAIN, AT_I8);
-  WQAA_PICK(DK_INT1, LAYOUT_LOP3, AT_I8);
-  WQAA_PICK(DK_INT1, LAYOUT_PLAIN, AT_I8);
-  WQAA_PICK(DK_NATIVE, LAYOUT_PLAIN, AT_I8);
-#undef WQAA_PICK
+template <int KIND, int LAYOUT>
+static gemv_fn pick_mode_f16(int mode, int mb) {
+  switch (mode) {
+    case MD_NONE: return pick_mb<KIND, LAYOUT, AT_F16, MD_NONE, 0>(mb);
+    case MD_S: return pick_mb<KIND, LAYOUT, AT_F16, MD_S, 0>(mb);
+    case MD_ZO: return pick_mb<KIND, LAYOUT, AT_F16, MD_ZO, 0>(mb);
+    case MD_ZR: return pick_mb<KIND, LAYOUT, AT_F16, MD_ZR, 0>(mb);
+    case MD_ZQ: return pick_mb<KIND, LAYOUT, AT_F16, MD_ZQ, 0>(mb);
+    default: return nullptr;
+  }
+}
+
+// formats the reference never pairs with zero points: plain and scaled members only
+template <int KIND, int FLAGS>
+static gemv_fn pick_mode_fp(int mode, int mb) {
+  switch (mode) {
+    case MD_NONE: return pick_mb<KIND, LAYOUT_PLAIN, AT_F16, MD_NONE, FLAGS>(mb);
+    case MD_S: return pick_mb<KIND, LAYOUT_PLAIN, AT_F16, MD_S, FLAGS>(mb);
+    default: return nullptr;
+  }
+}
+
+static gemv_fn pick_kernel(int kind, int layout, int at, int mode, int flags, int mb) {
+  if (at == AT_F16) {
+    if (flags & FL_A8) {  // dense fp8 x fp8: both operands widened to fp16, fp32 accumulate
+      if (mode != MD_NONE) return nullptr;
+      if (kind == DK_E4M3) return pick_mb<DK_E4M3, LAYOUT_PLAIN, AT_F16, MD_NONE, FL_A8>(mb);
+      if (kind == DK_E5M2) return pick_mb<DK_E5M2, LAYOUT_PLAIN, AT_F16, MD_NONE, FL_A8>(mb);
+      return nullptr;
+    }
+    switch (kind) {
+      case DK_INT4: return layout == LAYOUT_LOP3 ? pick_mode_f16<DK_INT4, LAYOUT_LOP3>(mode, mb) : pick_mode_f16<DK_INT4, LAYOUT_PLAIN>(mode, mb);
+      case DK_INT2: return layout == LAYOUT_LOP3 ? pick_mode_f16<DK_INT2, LAYOUT_LOP3>(mode, mb) : pick_mode_f16<DK_INT2, LAYOUT_PLAIN>(mode, mb);
+      case DK_INT1: return layout == LAYOUT_LOP3 ? pick_mode_f16<DK_INT1, LAYOUT_LOP3>(mode, mb) : pick_mode_f16<DK_INT1, LAYOUT_PLAIN>(mode, mb);
+      case DK_INT8: return pick_mode_f16<DK_INT8, LAYOUT_PLAIN>(mode, mb);
+      case DK_LUT4: return pick_mode_fp<DK_LUT4, 0>(mode, mb);
+      case DK_E4M3: return (flags & FL_STRICT) ? pick_mode_fp<DK_E4M3, FL_STRICT>(mode, mb) : pick_mode_fp<DK_E4M3, 0>(mode, mb);
+      case DK_E5M2: return pick_mode_fp<DK_E5M2, 0>(mode, mb);
+      case DK_NATIVE: return mode == MD_NONE ? pick_mb<DK_NATIVE, LAYOUT_PLAIN, AT_F16, MD_NONE, 0>(mb) : nullptr;
+    }
+    return nullptr;
+  }
+  if (mode != MD_NONE) return nullptr;
+  switch (kind) {
+    case DK_INT4: return layout == LAYOUT_LOP3 ? pick_mb<DK_INT4, LAYOUT_LOP3, AT_I8, MD_NONE, 0>(mb) : pick_mb<DK_INT4, LAYOUT_PLAIN, AT_I8, MD_NONE, 0>(mb);
+    case DK_INT2: return layout == LAYOUT_LOP3 ? pick_mb<DK_INT2, LAYOUT_LOP3, AT_I8, MD_NONE, 0>(mb) : pick_mb<DK_INT2, LAYOUT_PLAIN, AT_I8, MD_NONE, 0>(mb);
+    case DK_INT1: return layout == LAYOUT_LOP3 ? pick_mb<DK_INT1, LAYOUT_LOP3, AT_I8, MD_NONE, 0>(mb) : pick_mb<DK_INT1, LAYOUT_PLAIN, AT_I8, MD_NONE, 0>(mb);
+    case DK_NATIVE: return pick_mb<DK_NATIVE, LAYOUT_PLAIN, AT_I8, MD_NONE, 0>(mb);
+  }
   return nullptr;
 }
 
 struct GemvChoice {
   gemv_fn fn;
-  int kind, layout, at, a_src, mb, R, D;
+  int kind, layout, at, mode, flags, mb, R, D;
   int bits;
   int E;
-  int nc;
-  int grid_x, grid_y, lds;
+  int nc, ncp, cpr;
+  int grid_x, grid_y, lds, threads, variant;
   int fp4_table;
+  int a_fmt;
 };
 
 static int classify(const wqaa_matmul_desc& d, GemvChoice* c) {
   const int a = d.a_dtype;
   c->fp4_table = 0;
+  c->flags = 0;
+  c->a_fmt = a;
   c->layout = d.w_layout == WQAA_LAYOUT_LOP3 ? LAYOUT_LOP3 : LAYOUT_PLAIN;
   if (a == WQAA_F16) {
     c->at = AT_F16;
-    c->a_src = ASRC_F16;
   } else if (a == WQAA_I8) {
     c->at = AT_I8;
-    c->a_src = ASRC_I8;
   } else if (a == WQAA_E4M3 || a == WQAA_E5M2) {
     c->at = AT_F16;
-    c->a_src = a == WQAA_E4M3 ? ASRC_E4M3 : ASRC_E5M2;
+    c->flags |= FL_A8;
   } else {
     set_error(WQAA_ERR_UNSUPPORTED, "gemv: A dtype %d not supported", a);
     return WQAA_ERR_UNSUPPORTED;
@@ -607,56 +683,81 @@ static int classify(const wqaa_matmul_desc& d, GemvChoice* c) {
     set_error(WQAA_ERR_UNSUPPORTED, "gemv: weight format %d / %d bits not supported", d.w_format, d.w_bits);
     return WQAA_ERR_UNSUPPORTED;
   }
+  if ((c->flags & FL_A8) && c->kind != DK_E4M3 && c->kind != DK_E5M2) {
+    set_error(WQAA_ERR_UNSUPPORTED, "gemv: fp8 activations need fp8 weights");
+    return WQAA_ERR_UNSUPPORTED;
+  }
+  if (c->kind == DK_E4M3 && d.strict_reference && !(c->flags & FL_A8)) c->flags |= FL_STRICT;
   if (c->kind != DK_INT4 && c->kind != DK_INT2 && c->kind != DK_INT1) c->layout = LAYOUT_PLAIN;
   if (c->at == AT_I8 && (d.with_scaling || d.zeros_mode != WQAA_Z_NONE)) {
     set_error(WQAA_ERR_UNSUPPORTED, "gemv: scale/zeros with int8 activations are not defined by the reference");
     return WQAA_ERR_UNSUPPORTED;
   }
+  // zero points only act together with a scale (matmul_dequantize_impl.py:435-449)
+  c->mode = !d.with_scaling ? MD_NONE
+            : d.zeros_mode == WQAA_Z_ORIGINAL ? MD_ZO
+            : d.zeros_mode == WQAA_Z_RESCALE  ? MD_ZR
+            : d.zeros_mode == WQAA_Z_QUANTIZED ? MD_ZQ
+                                               : MD_S;
   c->E = 128 / c->bits;
   if (d.K % c->E != 0) {
     set_error(WQAA_ERR_UNSUPPORTED, "gemv: K=%d must be a multiple of %d for %d-bit weights", d.K, c->E, c->bits);
     return WQAA_ERR_UNSUPPORTED;
   }
   const int g = d.group_size <= 0 ? d.K : d.group_size;
-  if (d.K % g != 0 || ((d.with_scaling || d.zeros_mode != WQAA_Z_NONE) && g % c->E != 0)) {
+  if (d.K % g != 0 || (c->mode != MD_NONE && g % c->E != 0)) {
     set_error(WQAA_ERR_UNSUPPORTED, "gemv: group_size=%d must divide K=%d and be a multiple of %d", g, d.K, c->E);
     return WQAA_ERR_UNSUPPORTED;
   }
-  c->nc = (d.K / c->E + 63) / 64;
+  c->cpr = d.K / c->E;
+  c->nc = (c->cpr + 63) / 64;
   return WQAA_OK;
 }
 
-// tile-config selection: batch tile MB, rows per wave R, pipeline depth D, grid.
-// The table is small on purpose: the GEMV is bandwidth bound, what matters is (a) every CU gets
-// work (grid >= 2 x CUs when N allows), (b) >= ~24 KiB of weight loads in flight per CU.
+// tile-config selection: batch tile MB, waves per workgroup and the grid.
+// Measured on MI355X (tools/gemv_probe.hip, tools/wq_bench.cpp, profiles/): at M = 1 a small matrix
+// is one latency chain - dispatch, one HBM round trip with the whole weight stream in flight, the
+// per-wave decode, the store - and (R, D) = (2, 2) was the best or within 3 % of the best of the
+// nine (R, D) shapes tried on 4096x4096 ... 8192x28672.  What the selector has to get right is
+// residency: the activation tile lives in LDS once per workgroup, so for long K the workgroup is
+// widened (up to 16 waves) until the CU holds ~32 waves, i.e. >= 64 KiB of weight loads in flight.
 static int choose(const wqaa_matmul_desc& d, int m, GemvChoice* c) {
   int st = classify(d, c);
   if (st != WQAA_OK) return st;
-  int mb = m <= 1 ? 1 : m <= 2 ? 2 : m <= 4 ? 4 : 8;
-  if (mb > max_mb(c->kind, c->at)) mb = max_mb(c->kind, c->at);
+  const int mb = m <= 1 ? 1 : m <= 2 ? 2 : 4;
   c->mb = mb;
-  c->fn = pick_kernel(c->kind, c->layout, c->at, mb, &c->R, &c->D);
+  c->R = 2;
+  c->D = 2;
+  c->variant = 0;
+  c->fn = pick_kernel(c->kind, c->layout, c->at, c->mode, c->flags, mb);
   if (!c->fn) {
-    set_error(WQAA_ERR_UNSUPPORTED, "gemv: no kernel for kind=%d layout=%d at=%d", c->kind, c->layout, c->at);
+    set_error(WQAA_ERR_UNSUPPORTED, "gemv: no kernel for kind=%d layout=%d at=%d mode=%d flags=%d", c->kind,
+              c->layout, c->at, c->mode, c->flags);
     return WQAA_ERR_UNSUPPORTED;
   }
   const int cus = device_info().ok ? device_info().cus : 256;
-  const long kpad = (long)c->nc * 64 * c->E;
+  c->ncp = (c->nc + c->D - 1) / c->D * c->D;
+  const long kpad = (long)c->ncp * 64 * c->E;
   c->lds = (int)(mb * kpad * (c->at == AT_F16 ? 2 : 1));
   if (c->lds > 160 * 1024) {
     set_error(WQAA_ERR_UNSUPPORTED, "gemv: activation tile %d B exceeds LDS", c->lds);
     return WQAA_ERR_UNSUPPORTED;
   }
-  const int n_rg = (d.N + c->R - 1) / c->R;
-  const int waves_needed = n_rg;                 // one row group per wave at minimum
-  int blocks = (waves_needed + 3) / 4;
-  // cap: enough blocks to fill the chip several times over, grid-stride beyond that
   int blocks_per_cu = 160 * 1024 / (c->lds > 0 ? c->lds : 1);
   if (blocks_per_cu > 8) blocks_per_cu = 8;
   if (blocks_per_cu < 1) blocks_per_cu = 1;
+  int nw = 4;
+  while (nw < 16 && blocks_per_cu * nw < 32) nw *= 2;
+  const char* force = getenv("WQAA_GEMV_THREADS");   // tuning aid
+  if (force && atoi(force) >= 64) nw = atoi(force) / 64;
+  if (blocks_per_cu * nw > 32) blocks_per_cu = 32 / nw;
+  c->threads = nw * 64;
+  const int n_rg = (d.N + c->R - 1) / c->R;
+  int blocks = (n_rg + nw - 1) / nw;
   const int cap = cus * blocks_per_cu;
   if (blocks > cap) blocks = cap;
   if (blocks < 1) blocks = 1;
+  if (blocks >= 8) blocks = (blocks + 7) / 8 * 8;   // whole XCD rounds: keeps the block swizzle on
   c->grid_x = blocks;
   c->grid_y = (m + mb - 1) / mb;
   return WQAA_OK;
@@ -671,15 +772,20 @@ static void fill_args(const wqaa_matmul_desc& d, const GemvChoice& c, const void
   a->kg = d.K / g;
   a->g = g;
   a->g_log2 = ilog2_exact(g);
+  {
+    const int dq = g / c.E > 0 ? g / c.E : 1;      // lane chunks per group (mode != NONE => g % E == 0)
+    a->gq_shift = ilog2_exact(dq);
+    a->gq_magic = a->gq_shift >= 0 ? 0u : (uint32_t)(((1ull << 32) + dq - 1) / dq);
+  }
   a->nc = c.nc;
+  a->ncp = c.ncp;
+  a->cpr = c.cpr;
   a->row_bytes = (long)d.K * c.bits / 8;
-  a->zmode = d.zeros_mode;
-  a->has_scale = d.with_scaling;
   a->has_bias = d.with_bias;
   a->out_dtype = d.out_dtype;
   a->is_signed = d.w_format == WQAA_W_INT;
-  a->strict = d.strict_reference && d.w_format == WQAA_W_E4M3 && d.a_dtype == WQAA_F16;
   a->fp4_table = c.fp4_table;
+  a->a_fmt = c.a_fmt;
   a->zq_row_bytes = d.N * (c.bits < 8 ? c.bits : 8) / 8;
 }
 
@@ -709,9 +815,9 @@ int gemv_plan(const wqaa_matmul_desc& d, int m, wqaa_plan* plan) {
   if (plan) {
     plan->kernel_family = 1;
     plan->block_m = c.mb;
-    plan->block_n = c.R * 4;
-    plan->block_k = 64 * c.E;
-    plan->threads = 256;
+    plan->block_n = c.R * (c.threads / 64);
+    plan->block_k = 64 * c.E * c.D;
+    plan->threads = c.threads;
     plan->grid = c.grid_x * c.grid_y;
     plan->rows_per_wave = c.R;
     plan->batch_tile = c.mb;
@@ -734,9 +840,8 @@ int gemv_launch(const wqaa_matmul_desc& d, const void* A, const void* B, const v
   if (st != WQAA_OK) return st;
   GemvArgs a;
   fill_args(d, c, A, B, LUT, Scale, Zeros, Bias, C, m, &a);
-  int a_src = c.a_src;
-  void* params[] = {&a, &a_src};
-  dim3 grid(c.grid_x, c.grid_y, 1), block(256, 1, 1);
+  void* params[] = {&a};
+  dim3 grid(c.grid_x, c.grid_y, 1), block(c.threads, 1, 1);
   hipError_t e;
   if (start || stop) {
     e = hipExtLaunchKernel(reinterpret_cast<const void*>(c.fn), grid, block, params, c.lds, stream, start, stop, 0);
@@ -756,11 +861,13 @@ void gemv_init() {
   for (int kind : kinds)
     for (int layout = 0; layout < 2; ++layout)
       for (int at = 0; at < 2; ++at)
-        for (int mb : {1, 2, 4, 8}) {
-          int R, D;
-          gemv_fn fn = pick_kernel(kind, layout, at, mb, &R, &D);
-          if (fn) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        }
+        for (int mode = 0; mode <= MD_ZQ; ++mode)
+          for (int flags = 0; flags < 4; ++flags)
+            for (int mb : kBatchTiles) {
+              gemv_fn fn = pick_kernel(kind, layout, at, mode, flags, mb);
+              if (fn) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+
+            }
 }
 
 // ------------------------------------------------------------------------------------------

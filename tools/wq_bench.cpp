@@ -29,7 +29,7 @@ int main(int argc, char** argv) {
   init();
   wqaa_matmul_desc d; memset(&d, 0, sizeof d);
   d.struct_size = sizeof d; d.N = N; d.K = K; d.a_dtype = adt; d.w_format = wfmt; d.w_bits = bits;
-  d.out_dtype = odt; d.group_size = group; d.with_scaling = (adt != WQAA_I8 && wfmt != WQAA_W_NATIVE) ? 1 : 0;
+  d.out_dtype = odt; d.group_size = group; d.with_scaling = (adt == WQAA_F16 && wfmt != WQAA_W_NATIVE && getenv("WQ_NOSCALE") == nullptr) ? 1 : 0;
   d.zeros_mode = zmode; d.with_bias = 0; d.w_layout = (wfmt <= WQAA_W_INT && bits < 8 && getenv("WQ_PLAIN") == nullptr) ? WQAA_LAYOUT_LOP3 : WQAA_LAYOUT_PLAIN;
   d.strict_reference = 1;
   wqaa_plan plan;
