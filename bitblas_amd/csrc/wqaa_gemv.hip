@@ -23,50 +23,9 @@
 //     fp32 / int32 accumulators -> DPP row reduction + readlane.
 #include "wqaa_common.h"
 #include "wqaa_decode.h"
+#include "wqaa_kinds.h"
 
 namespace wqaa {
-
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-
-enum : int { AT_F16 = 0, AT_I8 = 1 };
-// dequant arithmetic (matmul_dequantize_impl.py:435-449)
-enum : int { MD_NONE = 0, MD_S = 1, MD_ZO = 2, MD_ZR = 3, MD_ZQ = 4 };
-enum : int { FL_STRICT = 1, FL_A8 = 2 };  // e4m3 reference bit trick; activations stored as fp8
-
-constexpr int cmax(int a, int b) { return a > b ? a : b; }
-
-template <int KIND, int AT>
-struct KindTraits {
-  static constexpr int BITS = (KIND == DK_INT4 || KIND == DK_LUT4) ? 4
-                              : (KIND == DK_INT2)                  ? 2
-                              : (KIND == DK_INT1)                  ? 1
-                              : (KIND == DK_NATIVE && AT == AT_F16) ? 16
-                                                                    : 8;
-  static constexpr int EPW = 32 / BITS;          // elements per 32-bit word
-  static constexpr int E = 128 / BITS;           // elements per 16-byte lane chunk
-  static constexpr int PE = AT == AT_F16 ? 8 : 16;  // activation elements per 16-byte LDS piece
-  static constexpr int G = cmax(EPW, PE);        // decode unit (elements)
-  static constexpr int WPU = G / EPW;            // words per unit
-  static constexpr int PU = G / PE;              // LDS pieces per unit
-  static constexpr int UNITS = E / G;            // units per lane chunk
-  static constexpr int PIECES = E / PE;          // LDS pieces per lane chunk
-  static constexpr int S = AT == AT_F16 ? 16 : 8;   // LOP3 interleave target width
-  static constexpr bool SUBBYTE = BITS < 8;
-
-  static constexpr int field_of_slot(int xs) {
-    if (!SUBBYTE) return xs;
-    if (AT == AT_I8) return I8Unpack<BITS < 8 ? BITS : 4>::field_of_slot(xs);
-    if (KIND == DK_LUT4) return lut_field_of_slot(xs);
-    return F16Unpack<BITS < 8 ? BITS : 4>::field_of_slot(xs);
-  }
-  // source element (inside the unit) that lands in extraction slot x
-  static constexpr int src_elem(int layout, int x) {
-    const int wi = x / EPW, xs = x % EPW;
-    if (!SUBBYTE) return x;
-    return wi * EPW + src_of_field(BITS, S, layout, field_of_slot(xs));
-  }
-};
 
 // ------------------------------------------------------------------------------------------
 // wave reductions: DPP inside a 16-lane row, readlane across the four rows
@@ -102,52 +61,6 @@ __device__ __forceinline__ int wave_sum(int v) {
 }
 
 // ------------------------------------------------------------------------------------------
-// epilogue: cast to out_dtype, then + bias in out_dtype (the TE graph adds Bias after the cast,
-// matmul_dequantize_impl.py:462-477)
-// ------------------------------------------------------------------------------------------
-__device__ __forceinline__ float bf16_round(float x) {
-  uint32_t u = __builtin_bit_cast(uint32_t, x);
-  u += 0x7FFFu + ((u >> 16) & 1u);
-  return __builtin_bit_cast(float, u & 0xFFFF0000u);
-}
-
-__device__ __forceinline__ void store_out(void* C, long idx, float acc, int out_dtype, bool has_bias,
-                                          float bias) {
-  switch (out_dtype) {
-    case WQAA_F16: {
-      half_t v = (half_t)acc;
-      if (has_bias) v = v + (half_t)bias;
-      reinterpret_cast<half_t*>(C)[idx] = v;
-    } break;
-    case WQAA_F32: {
-      float v = acc;
-      if (has_bias) v = v + bias;
-      reinterpret_cast<float*>(C)[idx] = v;
-    } break;
-    case WQAA_BF16: {
-      float v = bf16_round(acc);
-      if (has_bias) v = bf16_round(v + bias);
-      reinterpret_cast<uint16_t*>(C)[idx] = (uint16_t)(__builtin_bit_cast(uint32_t, v) >> 16);
-    } break;
-    default: break;
-  }
-}
-__device__ __forceinline__ void store_out(void* C, long idx, int acc, int out_dtype, bool has_bias,
-                                          int bias) {
-  switch (out_dtype) {
-    case WQAA_I32: reinterpret_cast<int*>(C)[idx] = acc + (has_bias ? bias : 0); break;
-    case WQAA_I8: reinterpret_cast<int8_t*>(C)[idx] = (int8_t)((int8_t)acc + (has_bias ? (int8_t)bias : 0)); break;
-    case WQAA_F32: reinterpret_cast<float*>(C)[idx] = (float)acc + (has_bias ? (float)bias : 0.f); break;
-    case WQAA_F16: {
-      half_t v = (half_t)(float)acc;
-      if (has_bias) v = v + (half_t)(float)bias;
-      reinterpret_cast<half_t*>(C)[idx] = v;
-    } break;
-    default: break;
-  }
-}
-
-// ------------------------------------------------------------------------------------------
 // policy
 // ------------------------------------------------------------------------------------------
 template <int KIND_, int LAYOUT_, int AT_, int MB_, int MODE_, int FLAGS_, int R_ = 2, int D_ = 2>
@@ -171,7 +84,6 @@ struct Stage {
   uint32_t z[P::R];  // zero bits (low 16) / raw qzeros byte
 };
 
-__device__ __forceinline__ half_t bits_to_half(uint32_t b) { return __builtin_bit_cast(half_t, (uint16_t)(b & 0xFFFFu)); }
 
 __device__ __forceinline__ half_t fp8_to_half(uint8_t v, bool e5m2) {
   if (e5m2) return __builtin_bit_cast(half_t, (uint16_t)((uint16_t)v << 8));
@@ -273,13 +185,6 @@ __device__ __forceinline__ void a_item_store(const GemvArgs& a, int ncp, int idx
     }
   }
 }
-
-// ---- decode one unit of one row into fp16 pairs (exact field values minus folded zero point) ----
-struct DecodeCtx {
-  half_t zf;        // folded integer zero point (signed formats: 2^(bits-1))
-  uint32_t flip;    // int1 signed: ~w ; int8 signed: w ^ 0x80808080
-  half_t off8;      // int8 weights: 1024 (+128 signed)
-};
 
 template <class P>
 __device__ __forceinline__ void decode_unit_f16(const u32x4& w, int u, half_t zf, const DecodeCtx& cx,

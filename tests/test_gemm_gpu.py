@@ -1,0 +1,157 @@
+"""MFMA GEMM (M >= 8) parity: HIP kernel through the C ABI vs the CPU oracle on the same seeded inputs.
+
+Case list restates the GEMM half of the reference's op tests
+(testing/python/operators/test_general_matmul_ops_backend_tl.py:336-343: M=256, N=K=256, uint4/int4,
+group -1/32, the three zero modes) and adds BASELINE.json configs c3 (uint4 g=128 + zeros,
+M in {16,128,4096}, N=K=4096) and c4 (int2 x int8, bit exact).  Tolerance: 1e-3 relative with an
+absolute floor of 1e-3 * rms(output); integer paths are bit exact.
+"""
+import numpy as np
+import pytest
+import torch
+
+import wqaa_oracle as oracle
+from helpers import assert_fp_parity, hip_output, make_case, oracle_output
+
+pytestmark = pytest.mark.gpu
+
+REF_GEMM_CASES = [
+    # (M, N, K, W_dtype, group_size, with_scaling, with_zeros, zeros_mode, fast_decoding)
+    (256, 256, 256, "uint4", -1, False, False, "original", None),
+    (256, 256, 256, "uint4", -1, False, False, "original", False),
+    (256, 256, 256, "int4", -1, True, False, "original", None),
+    (256, 256, 256, "int4", 32, True, False, "original", None),
+    (256, 256, 256, "uint4", 32, True, True, "original", None),
+    (256, 256, 256, "uint4", 32, True, True, "rescale", None),
+    (256, 256, 256, "uint4", 32, True, True, "quantized", None),
+    (256, 256, 256, "uint4", 32, True, True, "quantized", False),
+]
+
+
+@pytest.mark.parametrize("case_args", REF_GEMM_CASES)
+def test_reference_gemm_cases(case_args):
+    M, N, K, wd, g, ws, wz, zm, fd = case_args
+    case = make_case(M, N, K, W_dtype=wd, group_size=g, with_scaling=ws, with_zeros=wz, zeros_mode=zm,
+                     fast_decoding=fd)
+    got, mm = hip_output(case)
+    assert mm.plans[M]["kernel_family"] == 2
+    assert_fp_parity(got, oracle_output(case))
+
+
+@pytest.mark.parametrize("M", [8, 16, 17, 33, 100, 128, 200])
+@pytest.mark.parametrize("with_bias", [False, True])
+def test_ragged_m_and_bias(M, with_bias):
+    case = make_case(M, 384, 512, W_dtype="uint4", group_size=128, with_scaling=True, with_zeros=True,
+                     zeros_mode="original", with_bias=with_bias, seed=M)
+    got, mm = hip_output(case)
+    assert mm.plans[M]["kernel_family"] == 2
+    assert_fp_parity(got, oracle_output(case))
+
+
+@pytest.mark.parametrize("wd", ["uint2", "int2", "uint1", "int1", "uint8", "int8", "nf4", "fp4_e2m1"])
+@pytest.mark.parametrize("fd", [None, False])
+def test_other_weight_formats_fp16(wd, fd):
+    if wd in ("nf4", "fp4_e2m1") and fd is False:
+        pytest.skip("fast_decoding only exists for integer formats")
+    case = make_case(64, 256, 512, W_dtype=wd, group_size=128, with_scaling=True, fast_decoding=fd, scale_mul=0.05)
+    got, mm = hip_output(case)
+    assert mm.plans[64]["kernel_family"] == 2
+    assert_fp_parity(got, oracle_output(case))
+
+
+@pytest.mark.parametrize("strict", [True, False])
+def test_e4m3_weight_fp16_activation_gemm(strict):
+    case = make_case(32, 256, 256, W_dtype="e4m3_float8", group_size=32, with_scaling=True)
+    got, _ = hip_output(case, strict_reference=strict)
+    assert_fp_parity(got, oracle_output(case, strict_reference=strict))
+
+
+def test_dense_fp16_gemm():
+    rng = np.random.default_rng(0)
+    import bitblas_amd as bitblas
+    A = (rng.random((96, 512), dtype=np.float32) - 0.5).astype(np.float16)
+    W = (rng.random((256, 512), dtype=np.float32) - 0.5).astype(np.float16)
+    mm = bitblas.Matmul(bitblas.MatmulConfig(M=96, N=256, K=512, A_dtype="float16", W_dtype="float16"),
+                        enable_tuning=False)
+    assert mm.plans[96]["kernel_family"] == 2
+    out = mm(torch.from_numpy(A).cuda(), torch.from_numpy(W).cuda()).cpu().numpy()
+    want = (A.astype(np.float64) @ W.astype(np.float64).T).astype(np.float16)
+    assert_fp_parity(out, want)
+
+
+@pytest.mark.parametrize("M", [16, 256])
+@pytest.mark.parametrize("wd,fd", [("int2", None), ("int2", False), ("int4", None), ("uint4", None), ("int1", None), ("int1", False)])
+@pytest.mark.parametrize("out_dtype", ["int32", "float32"])
+def test_int8_activation_gemm_exact(M, wd, fd, out_dtype):
+    """BASELINE c4 family (BitNet W_int2 A_int8): int32 accumulation in the matrix core, bit exact."""
+    case = make_case(M, 256, 1024, W_dtype=wd, A_dtype="int8", out_dtype=out_dtype, fast_decoding=fd)
+    got, mm = hip_output(case)
+    assert mm.plans[M]["kernel_family"] == 2
+    assert np.array_equal(got, oracle_output(case))
+
+
+def test_int8_dense_gemm_exact():
+    rng = np.random.default_rng(1)
+    import bitblas_amd as bitblas
+    A8 = rng.integers(-128, 128, size=(48, 512), dtype=np.int8)
+    W8 = rng.integers(-128, 128, size=(256, 512), dtype=np.int8)
+    mm8 = bitblas.Matmul(bitblas.MatmulConfig(M=48, N=256, K=512, A_dtype="int8", W_dtype="int8",
+                                              accum_dtype="int32", out_dtype="int32"), enable_tuning=False)
+    out8 = mm8(torch.from_numpy(A8).cuda(), torch.from_numpy(W8).cuda()).cpu().numpy()
+    assert np.array_equal(out8, A8.astype(np.int64) @ W8.astype(np.int64).T)
+
+
+def _sampled_rows_check(case, got, rows, exact=False):
+    sub = dict(case)
+    sub["A"] = case["A"][rows]
+    want = oracle_output(sub)
+    if exact:
+        assert np.array_equal(got[rows], want)
+    else:
+        assert_fp_parity(got[rows], want)
+
+
+@pytest.mark.parametrize("M", [16, 128, 4096])
+def test_baseline_c3_uint4_zeros_full_size(M):
+    """BASELINE c3 at full size.  The oracle checks every row for M <= 128 and 64 sampled rows at
+    M = 4096 (each output row depends on its activation row only)."""
+    case = make_case(M, 4096, 4096, W_dtype="uint4", group_size=128, with_scaling=True, with_zeros=True,
+                     zeros_mode="original", scale_mul=0.02, seed=3)
+    got, mm = hip_output(case)
+    assert mm.plans[M]["kernel_family"] == 2
+    rows = np.arange(M) if M <= 128 else np.random.default_rng(0).choice(M, 64, replace=False)
+    _sampled_rows_check(case, got, rows)
+    if M == 4096:
+        # size-independent property: identical activation rows give identical output rows
+        case2 = dict(case)
+        A2 = case["A"].copy()
+        A2[1::2] = A2[0::2]
+        case2["A"] = A2
+        got2, _ = hip_output(case2, matmul=mm)
+        assert np.array_equal(got2[1::2], got2[0::2])
+        assert np.array_equal(got2[0::2], got[0::2])
+
+
+def test_baseline_c4_int2_int8_gemm_full_size():
+    case = make_case(4096, 4096, 4096, W_dtype="int2", A_dtype="int8", out_dtype="int32", seed=4)
+    got, mm = hip_output(case)
+    assert mm.plans[4096]["kernel_family"] == 2
+    rows = np.random.default_rng(1).choice(4096, 64, replace=False)
+    _sampled_rows_check(case, got, rows, exact=True)
+
+
+def test_gemv_and_gemm_agree_on_the_same_rows():
+    """Dynamic-M operator: rows pushed through the GEMV family (m < 8) and the GEMM family must match
+    to fp16 rounding of the fp32 accumulators."""
+    import bitblas_amd as bitblas
+    case = make_case(64, 512, 1024, W_dtype="uint4", group_size=128, with_scaling=True, with_zeros=True, seed=9)
+    cfg = bitblas.MatmulConfig(M=[1, 64], N=512, K=1024, A_dtype="float16", W_dtype="uint4", group_size=128,
+                               with_scaling=True, with_zeros=True)
+    mm = bitblas.Matmul(cfg, enable_tuning=False)
+    W = mm.transform_weight(torch.from_numpy(case["w_user"]).cuda())
+    sc, zr = torch.from_numpy(case["scale"]).cuda(), torch.from_numpy(case["zeros"]).cuda()
+    A = torch.from_numpy(case["A"]).cuda()
+    full = mm(A, W, scale=sc, zeros=zr).cpu().numpy()
+    one = mm(A[:1], W, scale=sc, zeros=zr).cpu().numpy()
+    assert_fp_parity(full, oracle_output(case))
+    assert_fp_parity(one, full[:1], rtol=2e-3)
