@@ -245,7 +245,7 @@ def main():
     if dist_on:
         flat_n = sum(N for (_, N, _) in LLAMA2_7B_LINEARS)
         local_out = torch.empty((args.layers, flat_n), dtype=torch.float16, device=device)
-        gathered = torch.empty((world, args.layers, flat_n), dtype=torch.float16, device=device)
+        gathered = torch.empty((world * args.layers, flat_n), dtype=torch.float16, device=device)
 
     def launch_layers():
         stream = torch.cuda.current_stream(device).cuda_stream

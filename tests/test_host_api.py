@@ -1,0 +1,149 @@
+"""Host-side mirror of the reference operator API (no GPU needed).
+
+`MatmulConfig` legalisation and kernel names are checked against vectors produced by RUNNING the
+reference's own classes (oracle/gen_config_golden.py -> tests/golden/matmul_config_golden.json):
+`repr(config)` is the operator-cache / database key upstream (cache/operator.py:62), so it must match
+character for character.  Cache and `Linear` buffer contracts restate testing/python/cache/
+test_operator_cache.py and testing/python/module/test_bitblas_linear.py as far as they go without a GPU.
+"""
+import json
+import os
+import threading
+
+import pytest
+import torch
+
+import bitblas_amd as bitblas
+from bitblas_amd.matmul import MatmulKernelNameGenerator, TransformKind
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = json.load(open(os.path.join(ROOT, "tests", "golden", "matmul_config_golden.json")))
+
+
+def test_matmul_config_matches_reference_class():
+    assert len(GOLDEN) >= 150
+    for g in GOLDEN:
+        cfg = bitblas.MatmulConfig(**g["kwargs"])
+        assert repr(cfg) == g["repr"], g["kwargs"]
+        for name, want in g["fields"].items():
+            got = getattr(cfg, name)
+            got = list(got) if isinstance(got, tuple) else (int(got) if isinstance(got, (TransformKind, bitblas.OptimizeStrategy)) else got)
+            assert got == want, (g["kwargs"], name)
+        assert MatmulKernelNameGenerator(cfg).generate() == g["kernel_name"]
+
+
+def test_config_is_hashable_and_frozen():
+    a = bitblas.MatmulConfig(M=1, N=256, K=256, W_dtype="int4")
+    b = bitblas.MatmulConfig(M=1, N=256, K=256, W_dtype="int4")
+    assert a == b and hash(a) == hash(b) and len({a, b}) == 1
+    with pytest.raises(Exception):
+        a.N = 3
+    with pytest.raises(ValueError):
+        bitblas.MatmulConfig(M=1, K=16)
+
+
+def test_operator_construction_plans_without_gpu():
+    """Operators are built (selector answers) without a device; forward needs one and says so."""
+    cfg = bitblas.MatmulConfig(M=[1, 16, 4096], N=4096, K=4096, A_dtype="float16", W_dtype="uint4", group_size=128,
+                               with_scaling=True, with_zeros=True)
+    op = bitblas.Matmul(cfg, enable_tuning=False)
+    assert op.plans[1]["kernel_family"] == 1 and op.plans[16]["kernel_family"] == 2
+    assert op.plans[4096]["block_m"] == 128
+    assert op.retrieve_weight_shape() == [4096, 2048]
+    assert op.propagate_a == TransformKind.NonTransform and op.propagate_b == TransformKind.NonTransform
+    w = torch.randint(0, 16, (4096, 4096), dtype=torch.int8)
+    assert tuple(op.transform_weight(w).shape) == (4096, 2048)
+    with pytest.raises(RuntimeError):
+        op(torch.zeros(1, 4096, dtype=torch.float16), torch.zeros(4096, 2048, dtype=torch.int8),
+           scale=torch.zeros(4096, 32, dtype=torch.float16), zeros=torch.zeros(4096, 32, dtype=torch.float16))
+
+
+def test_unsupported_config_fails_at_construction():
+    with pytest.raises(Exception):
+        bitblas.Matmul(bitblas.MatmulConfig(M=1, N=64, K=40, W_dtype="int4"), enable_tuning=False)
+    with pytest.raises(ValueError):
+        bitblas.Matmul(bitblas.MatmulConfig(M=1, N=64, K=64, layout="nn"), enable_tuning=False)
+
+
+def test_transform_weight_bytes_are_the_reference_layout():
+    import numpy as np
+    import wqaa_oracle as oracle
+    rng = np.random.default_rng(0)
+    w = rng.integers(-8, 8, size=(32, 128)).astype(np.int8)
+    for fd in (True, False):
+        op = bitblas.Matmul(bitblas.MatmulConfig(M=1, N=32, K=128, W_dtype="int4", fast_decoding=fd), enable_tuning=False)
+        got = op.transform_weight(torch.from_numpy(w)).numpy()
+        want = oracle.transform_weight(w, "int", 4, fast_decoding=fd)
+        assert np.array_equal(got, want)
+    # int2 x int8 (BitNet): interleave target width is 8
+    w2 = rng.integers(-2, 2, size=(32, 128)).astype(np.int8)
+    op = bitblas.Matmul(bitblas.MatmulConfig(M=1, N=32, K=128, A_dtype="int8", W_dtype="int2", accum_dtype="int32",
+                                             out_dtype="int32"), enable_tuning=False)
+    assert np.array_equal(op.transform_weight(torch.from_numpy(w2)).numpy(),
+                          oracle.transform_weight(w2, "int", 2, fast_decoding=True, a_dtype="int8"))
+
+
+def test_operator_cache_roundtrip(tmp_path):
+    """cache/test_operator_cache.py: add/get/size, save_into_database + load_from_database."""
+    cache = bitblas.OperatorCache()
+    cfg = bitblas.MatmulConfig(M=1, N=256, K=256, W_dtype="uint4", with_scaling=True, group_size=128)
+    assert cache.get(cfg) is None and cache.size() == 0
+    op = bitblas.Matmul(cfg, enable_tuning=False)
+    cache.add(cfg, op)
+    assert cache.get(bitblas.MatmulConfig(M=1, N=256, K=256, W_dtype="uint4", with_scaling=True, group_size=128)) is op
+    cache.save_into_database(str(tmp_path), target="hip -mcpu=gfx950")
+    fresh = bitblas.OperatorCache()
+    fresh.load_from_database(str(tmp_path), target="hip -mcpu=gfx950")
+    assert fresh.size() == 1 and fresh.get(cfg) is not None
+    assert repr(fresh.get(cfg).config) == repr(cfg)
+
+
+def test_operator_cache_concurrent_creation():
+    """cache/test_operator_cache_spin_lock.py: several threads asking for the same operator."""
+    cache = bitblas.OperatorCache()
+    cfg = bitblas.MatmulConfig(M=1, N=128, K=128, W_dtype="int4")
+    made = []
+
+    def worker():
+        with cache.cache_locker:
+            op = cache.get(cfg)
+            if op is None:
+                op = bitblas.Matmul(cfg, enable_tuning=False)
+                cache.add(cfg, op)
+                made.append(1)
+
+    threads = [threading.Thread(target=worker) for _ in range(4)]
+    [t.start() for t in threads]
+    [t.join() for t in threads]
+    assert len(made) == 1 and cache.size() == 1
+
+
+def test_linear_buffers_and_validation():
+    """module/test_bitblas_linear.py contracts that do not need a device: buffer names/shapes/dtypes,
+    state_dict round trip, argument validation (module/__init__.py:155-205)."""
+    lin = bitblas.Linear(1024, 512, bias=True, A_dtype="float16", W_dtype="uint4", group_size=128,
+                         with_scaling=True, with_zeros=True, zeros_mode="quantized", opt_M=[1, 16], enable_tuning=False)
+    sd = lin.state_dict()
+    assert tuple(sd["qweight"].shape) == (512, 512) and sd["qweight"].dtype == torch.int8
+    assert tuple(sd["scales"].shape) == (512, 8) and sd["scales"].dtype == torch.float16
+    assert tuple(sd["zeros"].shape) == (8, 512 // 8 * 4) and sd["zeros"].dtype == torch.int8
+    assert tuple(sd["bias"].shape) == (512,)
+    lin2 = bitblas.Linear(1024, 512, bias=True, A_dtype="float16", W_dtype="uint4", group_size=128,
+                          with_scaling=True, with_zeros=True, zeros_mode="quantized", opt_M=[1, 16], enable_tuning=False)
+    lin2.load_state_dict(sd)
+    assert lin2.bitblas_matmul is lin.bitblas_matmul      # global operator cache hit
+    with pytest.raises(ValueError):
+        bitblas.Linear(100, 512, W_dtype="uint4")
+    with pytest.raises(ValueError):
+        bitblas.Linear(1024, 512, W_dtype="uint4", group_size=100)
+    dense = bitblas.Linear(256, 128, A_dtype="float16", W_dtype="float16", opt_M=1, enable_tuning=False)
+    assert tuple(dense.weight.shape) == (128, 256)
+
+
+def test_public_names():
+    for name in ("Matmul", "MatmulConfig", "Linear", "set_log_level", "auto_detect_nvidia_target",
+                 "global_operator_cache", "general_compress", "interleave_weight"):
+        assert hasattr(bitblas, name)
+    assert bitblas.auto_detect_nvidia_target().startswith("hip")
+    bitblas.set_log_level("DEBUG")
+    bitblas.set_log_level("WARNING")
