@@ -87,8 +87,11 @@ struct F16Unpack {
   static __device__ __forceinline__ half_t magic_value(int b) { return (half_t)(float)(1 << (10 - b)); }
   static constexpr uint32_t magic_bits(int b) { return (uint32_t)((25 - b) << 10) * 0x00010001u; }
 
-  // out[i] = (q_lo - zf, q_hi - zf), zf integer valued (exact)
-  static __device__ __forceinline__ void run(uint32_t w, half_t zf, half2_t (&out)[NPAIR]) {
+  // out[i] = (q_lo - zf, q_hi - zf), zf integer valued (exact).
+  // `magic[b]` must hold magic_bits(b) in VGPRs (make_magic below): V_AND_OR_B32 takes one literal
+  // (gfx9 constant bus), so the mask stays a literal and the magic exponent word is a register the
+  // compiler cannot fold back - otherwise it splits the operation into v_and + v_or.
+  static __device__ __forceinline__ void run(uint32_t w, half_t zf, const uint32_t (&magic)[8], half2_t (&out)[NPAIR]) {
     constexpr uint32_t fmask = (1u << BITS) - 1u;
 #pragma unroll
     for (int i = 0; i < NPAIR; ++i) {
@@ -96,12 +99,21 @@ struct F16Unpack {
       const int b = bit & 7;              // position after the optional >> 8
       const uint32_t src = (bit >= 8) ? (w >> 8) : w;
       const uint32_t m = (fmask << b) * 0x00010001u;
-      const uint32_t t = (src & m) | magic_bits(b);   // V_AND_OR_B32
+      const uint32_t t = (src & m) | magic[b];          // V_AND_OR_B32
       const half_t off = (half_t)((float)(1 << (10 - b))) + zf;
       out[i] = as_h2(t) - splat(off);                  // V_PK_ADD_F16 (exact)
     }
   }
 };
+
+// the eight magic exponent words, pinned in VGPRs once per kernel
+__device__ __forceinline__ void make_magic(uint32_t (&magic)[8]) {
+#pragma unroll
+  for (int b = 0; b < 8; ++b) {
+    magic[b] = (uint32_t)((25 - b) << 10) * 0x00010001u;
+    asm volatile("" : "+v"(magic[b]));
+  }
+}
 
 // 8-bit integer weights -> half: byte | 0x6400 == 1024 + u   (u8), signed via u ^ 0x80
 template <bool SIGNED>

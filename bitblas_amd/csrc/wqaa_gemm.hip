@@ -57,13 +57,15 @@ struct GemmArgs {
 // ------------------------------------------------------------------------------------------
 // policy: one k-step is KS = 4 * KL deep; a lane owns KL consecutive k of one weight row
 // ------------------------------------------------------------------------------------------
-template <int KIND_, int LAYOUT_, int AT_, int MODE_, int FLAGS_, int MF_, int NFW_ = 2>
+template <int KIND_, int LAYOUT_, int AT_, int MODE_, int FLAGS_, int MF_, int NWAVES_ = 4, int NFW_ = 2>
 struct GemmPolicy {
   static constexpr int KIND = KIND_, LAYOUT = LAYOUT_, AT = AT_, MODE = MODE_, FLAGS = FLAGS_;
   static constexpr int MF = MF_;        // 16-row activation fragments per workgroup (BM = 16 * MF)
   static constexpr int NFW = NFW_;      // 16-row weight fragments per wave
-  static constexpr int NWAVES = 4;
-  static constexpr int THREADS = 256;
+  static constexpr int NWAVES = NWAVES_; // waves side by side along N
+  static constexpr int THREADS = 64 * NWAVES_;
+  static constexpr int AG = (16 * MF_ * 16) / (64 * NWAVES_);   // activation granules per thread per k-step
+  static_assert(AG >= 1 && AG * 64 * NWAVES_ == 16 * MF_ * 16, "tile / workgroup mismatch");
   static constexpr int BM = 16 * MF, BN = 16 * NFW * NWAVES;
   static constexpr bool STRICT = (FLAGS_ & FL_STRICT) != 0;
   using T = KindTraits<KIND_, AT_>;
@@ -145,7 +147,7 @@ __device__ __forceinline__ void dequant_lane_f16(const uint32_t (&w)[P::WL], hal
       if constexpr (P::KIND == DK_LUT4) {
         lut16_word(lut, w[wi], q);
       } else {
-        F16Unpack<T::BITS>::run(w[wi] ^ (P::KIND == DK_INT1 ? cx.flip : 0u), zf, q);
+        F16Unpack<T::BITS>::run(w[wi] ^ (P::KIND == DK_INT1 ? cx.flip : 0u), zf, cx.magic, q);
       }
 #pragma unroll
       for (int i = 0; i < EPW / 2; ++i) {
@@ -257,7 +259,7 @@ struct BLane {
 };
 
 template <class P>
-__global__ void __launch_bounds__(256) wq_gemm_kernel(const GemmArgs a) {
+__global__ void __launch_bounds__(P::THREADS) wq_gemm_kernel(const GemmArgs a) {
   using T = typename P::T;
   constexpr int MF = P::MF, NFW = P::NFW, NJ = P::NJ, WL = P::WL, MODE = P::MODE;
   constexpr bool F16 = P::AT == AT_F16;
@@ -289,28 +291,34 @@ __global__ void __launch_bounds__(256) wq_gemm_kernel(const GemmArgs a) {
   const uint16_t* Zp = reinterpret_cast<const uint16_t*>(a.zeros);
   const uint8_t* Qp = reinterpret_cast<const uint8_t*>(a.zeros);
 
-  // ---- activation staging: MF granules (16 B) per thread per k-step ----
-  // granule gid = it * 256 + tid: row r = gid >> 4, natural slot ns = gid & 15 = kb' * 4 + j'
-  u32x4 areg[MF];
-  auto a_load = [&](int t) {
+  // ---- activation staging: AG granules (16 B) per thread per k-step ----
+  // 16 consecutive threads cover one 256-byte row.  Inside a row the two 8-lane halves (the
+  // ds_write_b128 service groups, 128-byte bank window) take natural granules {0,1,4,5,8,9,12,13} and
+  // {2,3,6,7,...}: their physical slots (j*4+kb)^r are then distinct mod 8 - no write conflicts.
+  constexpr int AG = P::AG;
+  u32x4 areg[AG];
+  const uint8_t* aptr[AG];
+  int a_lds_off[AG];
 #pragma unroll
-    for (int it = 0; it < MF; ++it) {
-      const int gid = it * P::THREADS + tid;
-      const int r = gid >> 4, ns = gid & 15;
-      int m = m0 + r;
-      m = m < a.M ? m : a.M - 1;
-      const long off = ((long)m * a.K + (long)t * P::KS) * ASZ + ns * 16;
-      areg[it] = *reinterpret_cast<const u32x4*>(Ap + off);
-    }
+  for (int it = 0; it < AG; ++it) {
+    const int gid = it * P::THREADS + tid;
+    const int r = gid >> 4, q = gid & 15;
+    const int ns = ((q & 7) >> 1) * 4 + (q & 1) + ((q >> 3) << 1);   // natural granule = kb' * 4 + j'
+    int m = m0 + r;
+    m = m < a.M ? m : a.M - 1;
+    aptr[it] = Ap + (long)m * a.K * ASZ + ns * 16;
+    const int phys = (((ns & 3) << 2) | (ns >> 2)) ^ (r & 15);
+    a_lds_off[it] = r * P::ROW_BYTES + phys * 16;
+  }
+  auto a_load = [&](int t) {
+    const long koff = (long)t * (P::KS * ASZ);
+#pragma unroll
+    for (int it = 0; it < AG; ++it) areg[it] = *reinterpret_cast<const u32x4*>(aptr[it] + koff);
   };
   auto a_store = [&](int buf) {
 #pragma unroll
-    for (int it = 0; it < MF; ++it) {
-      const int gid = it * P::THREADS + tid;
-      const int r = gid >> 4, ns = gid & 15;
-      const int phys = (((ns & 3) << 2) | (ns >> 2)) ^ (r & 15);
-      *reinterpret_cast<u32x4*>(smem_raw + buf * (P::BM * P::ROW_BYTES) + r * P::ROW_BYTES + phys * 16) = areg[it];
-    }
+    for (int it = 0; it < AG; ++it)
+      *reinterpret_cast<u32x4*>(smem_raw + buf * (P::BM * P::ROW_BYTES) + a_lds_off[it]) = areg[it];
   };
 
   // ---- weight lane loads ----
@@ -320,13 +328,16 @@ __global__ void __launch_bounds__(256) wq_gemm_kernel(const GemmArgs a) {
     const int n = n0 + nf * 16 + fr;
     nrow[nf] = n < a.N ? n : a.N - 1;
   }
+  const uint8_t* bptr[NFW];
+#pragma unroll
+  for (int nf = 0; nf < NFW; ++nf) bptr[nf] = Bp + (long)nrow[nf] * a.row_bytes + (long)kb * (WL * 4);
   auto b_load = [&](int t, BLane<P>& b) {
     const int kidx = t * 4 + kb;    // index of the lane's KL-wide k-block
     int gi = 0;
     if (MODE != MD_NONE) gi = a.gq_shift >= 0 ? (kidx >> a.gq_shift) : (int)__umulhi((uint32_t)kidx, a.gq_magic);
 #pragma unroll
     for (int nf = 0; nf < NFW; ++nf) {
-      load_lane_words<WL>(Bp + (long)nrow[nf] * a.row_bytes + (long)kidx * (WL * 4), b.w[nf]);
+      load_lane_words<WL>(bptr[nf] + (long)t * (4 * WL * 4), b.w[nf]);
       if constexpr (MODE != MD_NONE) b.s[nf] = Sp[(long)nrow[nf] * a.kg + gi];
       if constexpr (MODE == MD_ZO || MODE == MD_ZR) b.z[nf] = Zp[(long)nrow[nf] * a.kg + gi];
       if constexpr (MODE == MD_ZQ) b.z[nf] = Qp[(long)gi * a.zq_row_bytes + nrow[nf] / ZPB];
@@ -339,6 +350,7 @@ __global__ void __launch_bounds__(256) wq_gemm_kernel(const GemmArgs a) {
   if (P::KIND == DK_INT1 && a.is_signed) cx.flip = 0xFFFFFFFFu;
   if (P::KIND == DK_INT8 && a.is_signed) cx.flip = 0x80808080u;
   cx.off8 = (half_t)(a.is_signed ? 1152.0f : 1024.0f);
+  make_magic(cx.magic);
   const uint32_t zp4 = (!F16 && a.is_signed && T::SUBBYTE) ? (uint32_t)(1u << (T::BITS - 1)) * 0x01010101u : 0u;
   Lut16 lut;
   if constexpr (P::KIND == DK_LUT4) {
@@ -460,6 +472,7 @@ typedef void (*gemm_fn)(const GemmArgs);
 template <int KIND, int LAYOUT, int AT, int MODE, int FLAGS>
 static gemm_fn pick_mf(int mf) {
   switch (mf) {
+    case 16: return wq_gemm_kernel<GemmPolicy<KIND, LAYOUT, AT, MODE, FLAGS, 16, 8>>;   // 256 x 256, 8 waves
     case 8: return wq_gemm_kernel<GemmPolicy<KIND, LAYOUT, AT, MODE, FLAGS, 8>>;
     case 4: return wq_gemm_kernel<GemmPolicy<KIND, LAYOUT, AT, MODE, FLAGS, 4>>;
     case 2: return wq_gemm_kernel<GemmPolicy<KIND, LAYOUT, AT, MODE, FLAGS, 2>>;
@@ -514,7 +527,7 @@ static gemm_fn pick_gemm(int kind, int layout, int at, int mode, int flags, int 
 struct GemmChoice {
   gemm_fn fn;
   int kind, layout, at, mode, flags, bits;
-  int mf, ks, kl;
+  int mf, ks, kl, nwaves, bn;
   int tiles_m, tiles_n, lds;
   int fp4_table;
 };
@@ -575,13 +588,16 @@ static int gemm_choose(const wqaa_matmul_desc& d, int m, GemmChoice* c) {
     return WQAA_ERR_UNSUPPORTED;
   }
   // BM: the largest tile that M fills; small M keeps more workgroups alive along N
-  c->mf = m >= 128 ? 8 : m > 32 ? 4 : m > 16 ? 2 : 1;
+  c->mf = (m >= 256 && d.N >= 256) ? 16 : m >= 128 ? 8 : m > 32 ? 4 : m > 16 ? 2 : 1;
+  if (const char* f = getenv("WQAA_GEMM_MF")) c->mf = atoi(f);   // tuning aid
+  c->nwaves = c->mf == 16 ? 8 : 4;
+  c->bn = c->nwaves * 32;
   c->fn = pick_gemm(c->kind, c->layout, c->at, c->mode, c->flags, c->mf);
   if (!c->fn) {
     set_error(WQAA_ERR_UNSUPPORTED, "gemm: no kernel for kind=%d layout=%d at=%d mode=%d", c->kind, c->layout, c->at, c->mode);
     return WQAA_ERR_UNSUPPORTED;
   }
-  const int bm = 16 * c->mf, bn = 128;
+  const int bm = 16 * c->mf, bn = c->bn;
   c->tiles_m = (m + bm - 1) / bm;
   c->tiles_n = (d.N + bn - 1) / bn;
   c->lds = 2 * bm * 256;
@@ -595,17 +611,17 @@ int gemm_plan(const wqaa_matmul_desc& d, int m, wqaa_plan* plan) {
   if (plan) {
     plan->kernel_family = 2;
     plan->block_m = 16 * c.mf;
-    plan->block_n = 128;
+    plan->block_n = c.bn;
     plan->block_k = c.ks;
-    plan->threads = 256;
+    plan->threads = 64 * c.nwaves;
     plan->grid = c.tiles_m * c.tiles_n;
     plan->rows_per_wave = 32;
     plan->batch_tile = 16 * c.mf;
     plan->pipeline_depth = 2;
     plan->split_k = 1;
     plan->lds_bytes = c.lds;
-    snprintf(plan->name, sizeof(plan->name), "matmul_m%dn%dk%d_a%dw%db%d_tcx%dx128x%d", m, d.N, d.K, d.a_dtype,
-             d.w_format, d.w_bits, 16 * c.mf, c.ks);
+    snprintf(plan->name, sizeof(plan->name), "matmul_m%dn%dk%d_a%dw%db%d_tcx%dx%dx%d", m, d.N, d.K, d.a_dtype,
+             d.w_format, d.w_bits, 16 * c.mf, c.bn, c.ks);
   }
   return WQAA_OK;
 }
@@ -636,7 +652,7 @@ int gemm_launch(const wqaa_matmul_desc& d, const void* A, const void* B, const v
   a.tiles_n = c.tiles_n;
   a.nsteps = d.K / c.ks;
   void* params[] = {&a};
-  dim3 grid(c.tiles_m * c.tiles_n, 1, 1), block(256, 1, 1);
+  dim3 grid(c.tiles_m * c.tiles_n, 1, 1), block(64 * c.nwaves, 1, 1);
   hipError_t e;
   if (start || stop) {
     e = hipExtLaunchKernel(reinterpret_cast<const void*>(c.fn), grid, block, params, c.lds, stream, start, stop, 0);
@@ -657,7 +673,7 @@ void gemm_init() {
       for (int at = 0; at < 2; ++at)
         for (int mode = 0; mode <= MD_ZQ; ++mode)
           for (int flags = 0; flags < 2; ++flags)
-            for (int mf : {1, 2, 4, 8}) {
+            for (int mf : {1, 2, 4, 8, 16}) {
               gemm_fn fn = pick_gemm(kind, layout, at, mode, flags, mf);
               if (fn) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             }

@@ -194,9 +194,9 @@ __device__ __forceinline__ void decode_unit_f16(const u32x4& w, int u, half_t zf
   if constexpr (P::KIND == DK_INT1) {
     // int1 is a sign-extended 1-bit field (quantization.py:220-230): value = -u = (1 - u) - 1, so
     // invert the word and reuse the generic "field - 2^(bits-1)" path
-    F16Unpack<T::BITS>::run(w[u] ^ cx.flip, zf, q);
+    F16Unpack<T::BITS>::run(w[u] ^ cx.flip, zf, cx.magic, q);
   } else if constexpr (P::KIND == DK_INT4 || P::KIND == DK_INT2) {
-    F16Unpack<T::BITS>::run(w[u], zf, q);
+    F16Unpack<T::BITS>::run(w[u], zf, cx.magic, q);
   } else if constexpr (P::KIND == DK_LUT4) {
     lut16_word(lut, w[u], q);
   } else if constexpr (P::KIND == DK_INT8) {
@@ -355,6 +355,7 @@ __global__ void __launch_bounds__(1024) wq_gemv_kernel(const GemvArgs a) {
   if (P::KIND == DK_INT1 && a.is_signed) cx.flip = 0xFFFFFFFFu;
   if (P::KIND == DK_INT8 && a.is_signed) cx.flip = 0x80808080u;
   cx.off8 = (half_t)(a.is_signed ? 1152.0f : 1024.0f);
+  make_magic(cx.magic);
   const uint32_t zp4 = (!F16 && a.is_signed && T::SUBBYTE) ? (uint32_t)(1u << (T::BITS - 1)) * 0x01010101u : 0u;
 
   acc_t acc[R][MB];
@@ -791,7 +792,9 @@ __global__ void debug_decode_kernel(const uint32_t* packed, long nwords, int is_
     half2_t q[EPW / 2 > 0 ? EPW / 2 : 1];
     const half_t zf = (is_signed && T::SUBBYTE) ? (half_t)(float)(1 << (T::BITS - 1)) : (half_t)0.0f;
     if constexpr (KIND == DK_INT4 || KIND == DK_INT2 || KIND == DK_INT1) {
-      F16Unpack<T::BITS>::run((KIND == DK_INT1 && is_signed) ? ~w : w, zf, q);
+      uint32_t magic[8];
+      make_magic(magic);
+      F16Unpack<T::BITS>::run((KIND == DK_INT1 && is_signed) ? ~w : w, zf, magic, q);
     } else if constexpr (KIND == DK_LUT4) {
       Lut16 lut = fp4_table ? make_fp4_lut() : make_lut16(lut_p);
       lut16_word(lut, w, q);

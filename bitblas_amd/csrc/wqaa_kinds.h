@@ -101,6 +101,7 @@ struct DecodeCtx {
   half_t zf;        // folded integer zero point (signed formats: 2^(bits-1))
   uint32_t flip;    // int1 signed: ~w ; int8 signed: w ^ 0x80808080
   half_t off8;      // int8 weights: 1024 (+128 signed)
+  uint32_t magic[8];  // F16Unpack magic exponent words, pinned in VGPRs (make_magic)
 };
 
 
