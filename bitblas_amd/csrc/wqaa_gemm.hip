@@ -26,8 +26,13 @@
 #include "wqaa_decode.h"
 #include "wqaa_kinds.h"
 
+#include <mutex>
 #include <type_traits>
 #include <utility>
+
+#ifndef WQ_SETPRIO
+#define WQ_SETPRIO 0   /* measured: -20 % at 256x256 (both waves of a SIMD raise priority together) */
+#endif
 
 namespace wqaa {
 
@@ -52,6 +57,8 @@ struct GemmArgs {
   int zq_row_bytes;
   int tiles_m, tiles_n;
   int nsteps;         // K / KS
+  int ksplit;         // > 1: workgroup (tile, s) covers k-steps [s*nsteps/ksplit, (s+1)*nsteps/ksplit) and
+  void* ws;           //      writes fp32 / int32 partial sums to ws[s][M][N]; a second kernel reduces
 };
 
 // ------------------------------------------------------------------------------------------
@@ -281,6 +288,9 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_kernel(const GemmArgs a) {
   int blk = blockIdx.x;
   const int nblk = gridDim.x;
   if ((nblk & 7) == 0) blk = (blockIdx.x & 7) * (nblk >> 3) + (blockIdx.x >> 3);
+  const int ntiles = a.tiles_m * a.tiles_n;
+  const int split = blk / ntiles;        // k-slice of this workgroup (0 when ksplit == 1)
+  blk -= split * ntiles;
   const int tile_m = blk / a.tiles_n, tile_n = blk % a.tiles_n;
   const int m0 = tile_m * P::BM;
   const int n0 = tile_n * P::BN + wave * (NFW * 16);
@@ -367,14 +377,15 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_kernel(const GemmArgs a) {
 #pragma unroll
     for (int nf = 0; nf < NFW; ++nf) acc[mf][nf] = acc_t{0, 0, 0, 0};
 
+  const int t_begin = (int)((long)split * a.nsteps / a.ksplit);
+  const int nsteps = (int)((long)(split + 1) * a.nsteps / a.ksplit);   // end of this workgroup's k range
   BLane<P> bcur, bnext;
-  a_load(0);
-  b_load(0, bcur);
-  a_store(0);
+  a_load(t_begin);
+  b_load(t_begin, bcur);
+  a_store(t_begin & 1);
   __syncthreads();
 
-  const int nsteps = a.nsteps;
-  for (int t = 0; t < nsteps; ++t) {
+  for (int t = t_begin; t < nsteps; ++t) {
     const int tn = t + 1 < nsteps ? t + 1 : t;    // last step reloads itself: loads stay unconditional
     a_load(tn);
     b_load(tn, bnext);
@@ -398,6 +409,7 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_kernel(const GemmArgs a) {
     }
 
     const unsigned char* abuf = smem_raw + (t & 1) * (P::BM * P::ROW_BYTES);
+    if (WQ_SETPRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
 #pragma unroll
@@ -418,12 +430,28 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_kernel(const GemmArgs a) {
       }
     }
 
+    if (WQ_SETPRIO) __builtin_amdgcn_s_setprio(0);
     a_store((t + 1) & 1);
     __syncthreads();
     bcur = bnext;
   }
 
   // ---- epilogue: D[i][col]: weight row n = nbase + kb * 4 + i, activation row m = mbase + fr ----
+  if (a.ksplit > 1) {
+    acc_t* ws = reinterpret_cast<acc_t*>(a.ws);
+#pragma unroll
+    for (int nf = 0; nf < NFW; ++nf) {
+      const int nb = n0 + nf * 16 + kb * 4;
+      if (nb >= a.N) continue;
+#pragma unroll
+      for (int mf = 0; mf < MF; ++mf) {
+        const int m = m0 + mf * 16 + fr;
+        if (m >= a.M) continue;
+        ws[(((long)split * a.M + m) * a.N + nb) >> 2] = acc[mf][nf];
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int nf = 0; nf < NFW; ++nf) {
     const int nb = n0 + nf * 16 + kb * 4;
@@ -462,6 +490,56 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_kernel(const GemmArgs a) {
       }
     }
   }
+}
+
+// ------------------------------------------------------------------------------------------
+// split-K reduction: C[m][n..n+3] = cast(sum_s ws[s][m][n..n+3]) (+ bias after the cast)
+// ------------------------------------------------------------------------------------------
+template <bool F16>
+__global__ void __launch_bounds__(256) wq_splitk_reduce_kernel(const void* ws_, void* C, const void* bias, int M, int N,
+                                                               int ksplit, int out_dtype, int has_bias) {
+  using acc_t = typename std::conditional<F16, f32x4, i32x4>::type;
+  const long quads = (long)M * N / 4;
+  const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= quads) return;
+  const acc_t* ws = reinterpret_cast<const acc_t*>(ws_);
+  acc_t sum = ws[q];
+  for (int s = 1; s < ksplit; ++s) sum += ws[(long)s * quads + q];
+  const long base = q * 4;
+  const int n = (int)(base % N);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if constexpr (F16) {
+      const float b = has_bias ? (float)reinterpret_cast<const half_t*>(bias)[n + i] : 0.f;
+      store_out(C, base + i, sum[i], out_dtype, has_bias != 0, b);
+    } else {
+      const int b = has_bias ? (int)reinterpret_cast<const int8_t*>(bias)[n + i] : 0;
+      store_out(C, base + i, sum[i], out_dtype, has_bias != 0, b);
+    }
+  }
+}
+
+// library-owned scratch for the partial sums (one per device, grown on demand, never shrunk).
+// Growing calls hipMalloc: do the first call of a new shape outside stream capture.
+static void* g_ws[16] = {nullptr};
+static size_t g_ws_bytes[16] = {0};
+static std::mutex g_ws_mu;
+static void* workspace(size_t bytes) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+  std::lock_guard<std::mutex> lk(g_ws_mu);
+  if (g_ws_bytes[dev] < bytes) {
+    if (g_ws[dev]) (void)hipFree(g_ws[dev]);
+    size_t want = bytes < (32u << 20) ? (32u << 20) : bytes;
+    if (hipMalloc(&g_ws[dev], want) != hipSuccess) {
+      g_ws[dev] = nullptr;
+      g_ws_bytes[dev] = 0;
+      (void)hipGetLastError();
+      return nullptr;
+    }
+    g_ws_bytes[dev] = want;
+  }
+  return g_ws[dev];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -527,7 +605,7 @@ static gemm_fn pick_gemm(int kind, int layout, int at, int mode, int flags, int 
 struct GemmChoice {
   gemm_fn fn;
   int kind, layout, at, mode, flags, bits;
-  int mf, ks, kl, nwaves, bn;
+  int mf, ks, kl, nwaves, bn, ksplit;
   int tiles_m, tiles_n, lds;
   int fp4_table;
 };
@@ -588,7 +666,13 @@ static int gemm_choose(const wqaa_matmul_desc& d, int m, GemmChoice* c) {
     return WQAA_ERR_UNSUPPORTED;
   }
   // BM: the largest tile that M fills; small M keeps more workgroups alive along N
-  c->mf = (m >= 256 && d.N >= 256) ? 16 : m >= 128 ? 8 : m > 32 ? 4 : m > 16 ? 2 : 1;
+  // BM (measured sweep, tools/sweep_gemm.sh, N = K = 4096): the 256 x 256 / 8-wave tile wins once it
+  // gives every CU a workgroup; below that 128-row tiles (+ split-K) keep more workgroups alive, and
+  // skinny M follows M down
+  const int cus_ = device_info().ok ? device_info().cus : 256;
+  const long tiles256 = (long)((m + 255) / 256) * ((d.N + 255) / 256);
+  c->mf = (m >= 256 && d.N >= 256 && tiles256 * 10 >= (long)cus_ * 9) ? 16
+          : m > 128 ? 8 : m > 32 ? 4 : m > 16 ? 2 : 1;
   if (const char* f = getenv("WQAA_GEMM_MF")) c->mf = atoi(f);   // tuning aid
   c->nwaves = c->mf == 16 ? 8 : 4;
   c->bn = c->nwaves * 32;
@@ -601,6 +685,17 @@ static int gemm_choose(const wqaa_matmul_desc& d, int m, GemmChoice* c) {
   c->tiles_m = (m + bm - 1) / bm;
   c->tiles_n = (d.N + bn - 1) / bn;
   c->lds = 2 * bm * 256;
+  // split-K: a skinny problem has too few tiles to fill 256 CUs; cut K until ~2 workgroups per CU
+  // (partials cost 4 B per output element per slice, so stop at 16)
+  const int cus = device_info().ok ? device_info().cus : 256;
+  const int tiles = c->tiles_m * c->tiles_n;
+  const int nsteps = d.K / c->ks;
+  int ks = 1;
+  while (tiles * ks < cus && ks * 2 <= 16 && nsteps / (ks * 2) >= 1) ks *= 2;
+  if (const char* f = getenv("WQAA_GEMM_KSPLIT")) ks = atoi(f);
+  if (ks > nsteps) ks = nsteps;
+  if (ks < 1) ks = 1;
+  c->ksplit = ks;
   return WQAA_OK;
 }
 
@@ -618,10 +713,11 @@ int gemm_plan(const wqaa_matmul_desc& d, int m, wqaa_plan* plan) {
     plan->rows_per_wave = 32;
     plan->batch_tile = 16 * c.mf;
     plan->pipeline_depth = 2;
-    plan->split_k = 1;
+    plan->split_k = c.ksplit;
     plan->lds_bytes = c.lds;
-    snprintf(plan->name, sizeof(plan->name), "matmul_m%dn%dk%d_a%dw%db%d_tcx%dx%dx%d", m, d.N, d.K, d.a_dtype,
-             d.w_format, d.w_bits, 16 * c.mf, c.bn, c.ks);
+    plan->grid = c.tiles_m * c.tiles_n * c.ksplit;
+    snprintf(plan->name, sizeof(plan->name), "matmul_m%dn%dk%d_a%dw%db%d_tcx%dx%dx%d%s", m, d.N, d.K, d.a_dtype,
+             d.w_format, d.w_bits, 16 * c.mf, c.bn, c.ks, c.ksplit > 1 ? "xr" : "");
   }
   return WQAA_OK;
 }
@@ -651,13 +747,34 @@ int gemm_launch(const wqaa_matmul_desc& d, const void* A, const void* B, const v
   a.tiles_m = c.tiles_m;
   a.tiles_n = c.tiles_n;
   a.nsteps = d.K / c.ks;
+  a.ksplit = c.ksplit;
+  a.ws = nullptr;
+  if (c.ksplit > 1) {
+    a.ws = workspace((size_t)c.ksplit * m * d.N * 4);
+    if (!a.ws) {
+      set_error(WQAA_ERR_LAUNCH, "gemm: cannot allocate %zu B of split-K scratch", (size_t)c.ksplit * m * d.N * 4);
+      return WQAA_ERR_LAUNCH;
+    }
+  }
   void* params[] = {&a};
-  dim3 grid(c.tiles_m * c.tiles_n, 1, 1), block(64 * c.nwaves, 1, 1);
+  dim3 grid(c.tiles_m * c.tiles_n * c.ksplit, 1, 1), block(64 * c.nwaves, 1, 1);
   hipError_t e;
   if (start || stop) {
-    e = hipExtLaunchKernel(reinterpret_cast<const void*>(c.fn), grid, block, params, c.lds, stream, start, stop, 0);
+    e = hipExtLaunchKernel(reinterpret_cast<const void*>(c.fn), grid, block, params, c.lds, stream, start,
+                           c.ksplit > 1 ? nullptr : stop, 0);
   } else {
     e = hipLaunchKernel(reinterpret_cast<const void*>(c.fn), grid, block, params, c.lds, stream);
+  }
+  if (e == hipSuccess && c.ksplit > 1) {
+    const long quads = (long)m * d.N / 4;
+    const dim3 rgrid((unsigned)((quads + 255) / 256)), rblock(256);
+    const void* ws = a.ws;
+    int M_ = m, N_ = d.N, ks_ = c.ksplit, od = d.out_dtype, hb = d.with_bias;
+    void* rparams[] = {&ws, &C, &Bias, &M_, &N_, &ks_, &od, &hb};
+    const void* rfn = c.at == AT_F16 ? reinterpret_cast<const void*>(wq_splitk_reduce_kernel<true>)
+                                     : reinterpret_cast<const void*>(wq_splitk_reduce_kernel<false>);
+    if (start || stop) e = hipExtLaunchKernel(rfn, rgrid, rblock, rparams, 0, stream, nullptr, stop, 0);
+    else e = hipLaunchKernel(rfn, rgrid, rblock, rparams, 0, stream);
   }
   if (e != hipSuccess) {
     set_error(WQAA_ERR_LAUNCH, "gemm launch failed: %s", hipGetErrorString(e));

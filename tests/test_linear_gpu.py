@@ -1,0 +1,124 @@
+"""`bitblas.Linear` on the GPU (reference: testing/python/module/test_bitblas_linear.py:15-176,
+test_repack_from_gptq.py:11-68).  The reference compares against nn.Linear / auto_gptq with very
+loose tolerances; here the comparison is against the CPU oracle at the 1e-3 bar."""
+import numpy as np
+import pytest
+import torch
+
+import wqaa_oracle as oracle
+import bitblas_amd as bitblas
+from helpers import assert_fp_parity
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("m", [1, 16, 1024])
+@pytest.mark.parametrize("bias", [False, True])
+def test_consistent_fp16_linear(m, bias):
+    """test_bitblas_linear.py:15-49 (A_dtype == W_dtype == float16, dynamic opt_M)."""
+    torch.manual_seed(0)
+    ref = torch.nn.Linear(1024, 1024, bias=bias).half().cuda()
+    lin = bitblas.Linear(1024, 1024, bias=bias, A_dtype="float16", W_dtype="float16", opt_M=[1, 16, 1024],
+                         enable_tuning=False).cuda()
+    lin.load_and_transform_weight(ref.weight.detach().clone())
+    if bias:
+        lin.bias = ref.bias.detach().clone()
+    x = (torch.rand(m, 1024, device="cuda") - 0.5).half()
+    got = lin(x).float().cpu().numpy()
+    want = (x.double().cpu() @ ref.weight.detach().double().cpu().T).numpy()
+    want = want.astype(np.float16)
+    if bias:
+        want = (want + ref.bias.detach().cpu().numpy()).astype(np.float16)
+    assert_fp_parity(got, want)
+
+
+@pytest.mark.parametrize("W_dtype,group_size,zeros_mode", [("uint4", -1, "original"), ("uint4", 128, "rescale"),
+                                                           ("uint4", 128, "quantized"), ("uint2", 128, "original")])
+@pytest.mark.parametrize("m", [1, 100])
+def test_weight_only_linear(W_dtype, group_size, zeros_mode, m):
+    """test_bitblas_linear.py:52-176: uint4/uint2, scaling + zeros, all zero modes, dynamic M."""
+    rng = np.random.default_rng(5)
+    N, K = 1024, 1024
+    bit = int(W_dtype[-1])
+    g = K if group_size == -1 else group_size
+    lin = bitblas.Linear(K, N, bias=True, A_dtype="float16", W_dtype=W_dtype, group_size=group_size, with_scaling=True,
+                         with_zeros=True, zeros_mode=zeros_mode, opt_M=[1, 16, 128], enable_tuning=False).cuda()
+    codes = rng.integers(0, 1 << bit, size=(N, K)).astype(np.int8)
+    scale = (rng.random((N, K // g), dtype=np.float32) * 0.05).astype(np.float16)
+    zint = rng.integers(0, 1 << bit, size=(N, K // g)).astype(np.int8)
+    bias = rng.random((N,), dtype=np.float32).astype(np.float16)
+    if zeros_mode == "original":
+        zeros = zint.astype(np.float16)
+    elif zeros_mode == "rescale":
+        zeros = (zint.astype(np.float16) * scale).astype(np.float16)
+    else:
+        zeros = oracle.general_compress(np.ascontiguousarray(zint.T), bit)
+    lin.load_and_transform_weight(torch.from_numpy(codes).cuda(), scales=torch.from_numpy(scale).cuda(),
+                                  zeros=torch.from_numpy(zeros).cuda(), bias=torch.from_numpy(bias).cuda())
+    assert tuple(lin.qweight.shape) == (N, K * bit // 8)
+    A = (rng.random((m, K), dtype=np.float32) - 0.5).astype(np.float16)
+    got = lin(torch.from_numpy(A).cuda()).cpu().numpy()
+    want = oracle.matmul_dequant(A, codes, source_format="uint", bit=bit, scale=scale, zeros=zeros,
+                                 zeros_mode=zeros_mode, group_size=g, bias=bias)
+    assert_fp_parity(got, want)
+    # the module round-trips through state_dict (checkpoint layout = the kernel operand layout)
+    lin2 = bitblas.Linear(K, N, bias=True, A_dtype="float16", W_dtype=W_dtype, group_size=group_size, with_scaling=True,
+                          with_zeros=True, zeros_mode=zeros_mode, opt_M=[1, 16, 128], enable_tuning=False).cuda()
+    lin2.load_state_dict(lin.state_dict())
+    assert np.array_equal(lin2(torch.from_numpy(A).cuda()).cpu().numpy(), got)
+
+
+class _FakeGPTQ(torch.nn.Module):
+    """The attributes of AutoGPTQ's CudaOldQuantLinear that repack_from_gptq reads
+    (module/__init__.py:315-338): qweight (K/8*bits, N) int32, qzeros (K/g, N/8*bits) int32,
+    scales (K/g, N) fp16, bias."""
+
+    def __init__(self, codes, zint, scale, bias, bits, v2):
+        super().__init__()
+        N, K = codes.shape
+        per = 32 // bits
+        q = np.zeros((K // per, N), dtype=np.int64)
+        for i in range(per):
+            q |= codes.T[i::per].astype(np.int64) << (bits * i)
+        self.qweight = torch.from_numpy(q.astype(np.uint32).view(np.int32))
+        zstore = zint if v2 else (zint - 1) & ((1 << bits) - 1)       # v1 stores zero - 1
+        z = np.zeros((zint.shape[1], N // per), dtype=np.int64)        # (K/g, N/per)
+        for i in range(per):
+            z |= zstore.T[:, i::per].astype(np.int64) << (bits * i)
+        self.qzeros = torch.from_numpy(z.astype(np.uint32).view(np.int32))
+        self.scales = torch.from_numpy(np.ascontiguousarray(scale.T))
+        self.bias = torch.nn.Parameter(torch.from_numpy(bias), requires_grad=False)
+
+
+@pytest.mark.parametrize("v2", [False, True])
+@pytest.mark.parametrize("zeros_mode", ["original", "quantized"])
+def test_repack_from_gptq(v2, zeros_mode):
+    rng = np.random.default_rng(11)
+    N, K, g, bits = 256, 512, 128, 4
+    codes = rng.integers(0, 16, size=(N, K)).astype(np.int8)
+    zint = rng.integers(1, 16, size=(N, K // g)).astype(np.int64)
+    scale = (rng.random((N, K // g), dtype=np.float32) * 0.05).astype(np.float16)
+    bias = rng.random((N,), dtype=np.float32).astype(np.float16)
+    fake = _FakeGPTQ(codes, zint, scale, bias, bits, v2)
+    lin = bitblas.Linear(K, N, bias=True, A_dtype="float16", W_dtype="uint4", group_size=g, with_scaling=True,
+                         with_zeros=True, zeros_mode=zeros_mode, opt_M=[1, 16], enable_tuning=False).cuda()
+    (lin.repack_from_gptq_v2 if v2 else lin.repack_from_gptq)(fake)
+    A = (rng.random((3, K), dtype=np.float32) - 0.5).astype(np.float16)
+    got = lin(torch.from_numpy(A).cuda()).cpu().numpy()
+    want = oracle.matmul_dequant(A, codes, source_format="uint", bit=bits, scale=scale, zeros=zint.astype(np.float16),
+                                 zeros_mode="original", group_size=g, bias=bias)
+    assert_fp_parity(got, want)
+
+
+def test_bitnet_style_int2_int8_linear():
+    """integration/BitNet/utils_quant.py:37-219 usage contract: W_int2 A_int8 -> int32, exact."""
+    rng = np.random.default_rng(2)
+    N, K = 512, 1024
+    lin = bitblas.Linear(K, N, bias=False, A_dtype="int8", W_dtype="int2", accum_dtype="int32", out_dtype="int32",
+                         with_scaling=False, with_zeros=False, opt_M=[1, 64], enable_tuning=False).cuda()
+    w = rng.integers(-1, 2, size=(N, K)).astype(np.int8)           # ternary weights
+    lin.load_and_transform_weight(torch.from_numpy(w).cuda())
+    for m in (1, 64):
+        A = rng.integers(-128, 128, size=(m, K), dtype=np.int8)
+        got = lin(torch.from_numpy(A).cuda()).cpu().numpy()
+        assert np.array_equal(got, A.astype(np.int64) @ w.astype(np.int64).T)
