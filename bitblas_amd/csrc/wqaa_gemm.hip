@@ -79,9 +79,11 @@ struct GemmPolicy {
   static constexpr int BITS = T::BITS;
   static constexpr int EPW = T::EPW;
   // elements of k per lane per MFMA, MFMAs per k-step, k per lane per k-step
-  static constexpr int KPM = AT_ == AT_F16 ? 8 : 16;
-  static constexpr int NJ = 4;
-  static constexpr int KL = KPM * NJ;                 // 32 (fp16) / 64 (int8)
+  static constexpr int KPM = AT_ == AT_I8 ? 16 : 8;
+  // MFMAs per 16-byte activation granule: fp8 operands are 8 bytes, so a granule feeds two
+  static constexpr int MPG = AT_ == AT_F8 ? 2 : 1;
+  static constexpr int NJ = 4 * MPG;
+  static constexpr int KL = KPM * NJ;                 // 32 (fp16) / 64 (int8, fp8)
   static constexpr int KS = 4 * KL;                   // 128 / 256: one LDS row is 256 bytes either way
   static constexpr int WL = KL * BITS / 32;           // 32-bit weight words per lane per k-step
   static constexpr int ROW_BYTES = 256;
@@ -270,8 +272,10 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_kernel(const GemmArgs a) {
   using T = typename P::T;
   constexpr int MF = P::MF, NFW = P::NFW, NJ = P::NJ, WL = P::WL, MODE = P::MODE;
   constexpr bool F16 = P::AT == AT_F16;
+  constexpr bool F8 = P::AT == AT_F8;
+  constexpr bool FACC = F16 || F8;                        // fp32 accumulators
   constexpr int ASZ = F16 ? 2 : 1;                        // bytes per activation element
-  using acc_t = typename std::conditional<F16, f32x4, i32x4>::type;
+  using acc_t = typename std::conditional<FACC, f32x4, i32x4>::type;
   constexpr int ZB = T::SUBBYTE ? T::BITS : 8;
   constexpr int ZPB = 8 / ZB;
 
@@ -403,6 +407,13 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_kernel(const GemmArgs a) {
         const half2_t s2 = MODE != MD_NONE ? splat(bits_to_half(bcur.s[nf])) : splat((half_t)1.0f);
         const half2_t z2 = (MODE == MD_ZO || MODE == MD_ZR) ? splat(bits_to_half(bcur.z[nf])) : splat((half_t)0.0f);
         dequant_lane_f16<P>(bcur.w[nf], zf, s2, z2, cx, lut, bfrag[nf]);
+      } else if constexpr (F8) {
+        // fp8 weights are MFMA operands as stored: fragment j = the lane's bytes [8j, 8j+8)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          bfrag[nf][j][0] = bcur.w[nf][2 * j];
+          bfrag[nf][j][1] = bcur.w[nf][2 * j + 1];
+        }
       } else {
         dequant_lane_i8<P>(bcur.w[nf], zp4, cx.flip, bfrag[nf]);
       }
@@ -411,18 +422,31 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_kernel(const GemmArgs a) {
     const unsigned char* abuf = smem_raw + (t & 1) * (P::BM * P::ROW_BYTES);
     if (WQ_SETPRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) {
+    for (int gq = 0; gq < 4; ++gq) {          // activation granule (kb, gq) of the lane's k-block
 #pragma unroll
       for (int mf = 0; mf < MF; ++mf) {
-        const int phys = ((j << 2) | kb) ^ fr;
+        const int phys = ((gq << 2) | kb) ^ fr;
         const u32x4 av = *reinterpret_cast<const u32x4*>(abuf + (mf * 16 + fr) * P::ROW_BYTES + phys * 16);
 #pragma unroll
         for (int nf = 0; nf < NFW; ++nf) {
-          const u32x4 bv = {bfrag[nf][j][0], bfrag[nf][j][1], bfrag[nf][j][2], bfrag[nf][j][3]};
           if constexpr (F16) {
+            const u32x4 bv = {bfrag[nf][gq][0], bfrag[nf][gq][1], bfrag[nf][gq][2], bfrag[nf][gq][3]};
             acc[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8_t, bv),
                                                                 __builtin_bit_cast(half8_t, av), acc[mf][nf], 0, 0, 0);
+          } else if constexpr (F8) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              const u32x2 b2 = {bfrag[nf][2 * gq + h][0], bfrag[nf][2 * gq + h][1]};
+              const u32x2 a2 = {av[2 * h], av[2 * h + 1]};
+              const long bl = __builtin_bit_cast(long, b2), al = __builtin_bit_cast(long, a2);
+              constexpr bool WB = P::KIND == DK_E5M2, AB = (P::FLAGS & FL_ABF8) != 0;
+              if constexpr (!WB && !AB) acc[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(bl, al, acc[mf][nf], 0, 0, 0);
+              if constexpr (!WB && AB) acc[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_bf8(bl, al, acc[mf][nf], 0, 0, 0);
+              if constexpr (WB && !AB) acc[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf8_fp8(bl, al, acc[mf][nf], 0, 0, 0);
+              if constexpr (WB && AB) acc[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf8_bf8(bl, al, acc[mf][nf], 0, 0, 0);
+            }
           } else {
+            const u32x4 bv = {bfrag[nf][gq][0], bfrag[nf][gq][1], bfrag[nf][gq][2], bfrag[nf][gq][3]};
             acc[mf][nf] = __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4, bv),
                                                                __builtin_bit_cast(i32x4, av), acc[mf][nf], 0, 0, 0);
           }
@@ -462,6 +486,7 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_kernel(const GemmArgs a) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         if constexpr (F16) bias_f[i] = (float)reinterpret_cast<const half_t*>(a.bias)[nb + i];
+        else if constexpr (F8) bias_f[i] = 0.f;   // the reference defines no fp8 bias operand
         else bias_i[i] = (int)reinterpret_cast<const int8_t*>(a.bias)[nb + i];
       }
     }
@@ -470,7 +495,7 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_kernel(const GemmArgs a) {
       const int m = m0 + mf * 16 + fr;
       if (m >= a.M) continue;
       const long base = (long)m * a.N + nb;
-      if constexpr (F16) {
+      if constexpr (FACC) {
         if (a.out_dtype == WQAA_F16) {
           half_t v[4];
 #pragma unroll
@@ -593,6 +618,12 @@ static gemm_fn pick_gemm(int kind, int layout, int at, int mode, int flags, int 
     return nullptr;
   }
   if (mode != MD_NONE) return nullptr;
+  if (at == AT_F8) {   // dense fp8 x fp8 (all four e4m3 / e5m2 pairings, general_matmul/__init__.py:33-51)
+    const bool ab = (flags & FL_ABF8) != 0;
+    if (kind == DK_E4M3) return ab ? pick_mf<DK_E4M3, LAYOUT_PLAIN, AT_F8, MD_NONE, FL_ABF8>(mf) : pick_mf<DK_E4M3, LAYOUT_PLAIN, AT_F8, MD_NONE, 0>(mf);
+    if (kind == DK_E5M2) return ab ? pick_mf<DK_E5M2, LAYOUT_PLAIN, AT_F8, MD_NONE, FL_ABF8>(mf) : pick_mf<DK_E5M2, LAYOUT_PLAIN, AT_F8, MD_NONE, 0>(mf);
+    return nullptr;
+  }
   switch (kind) {
     case DK_INT4: return layout == LAYOUT_LOP3 ? pick_mf<DK_INT4, LAYOUT_LOP3, AT_I8, MD_NONE, 0>(mf) : pick_mf<DK_INT4, LAYOUT_PLAIN, AT_I8, MD_NONE, 0>(mf);
     case DK_INT2: return layout == LAYOUT_LOP3 ? pick_mf<DK_INT2, LAYOUT_LOP3, AT_I8, MD_NONE, 0>(mf) : pick_mf<DK_INT2, LAYOUT_PLAIN, AT_I8, MD_NONE, 0>(mf);
@@ -617,7 +648,14 @@ static int gemm_choose(const wqaa_matmul_desc& d, int m, GemmChoice* c) {
   c->layout = d.w_layout == WQAA_LAYOUT_LOP3 ? LAYOUT_LOP3 : LAYOUT_PLAIN;
   if (a == WQAA_F16) c->at = AT_F16;
   else if (a == WQAA_I8) c->at = AT_I8;
-  else {
+  else if (a == WQAA_E4M3 || a == WQAA_E5M2) {
+    c->at = AT_F8;
+    if (a == WQAA_E5M2) c->flags |= FL_ABF8;
+    if (d.with_bias) {
+      set_error(WQAA_ERR_UNSUPPORTED, "gemm: fp8 x fp8 with bias is not defined by the reference");
+      return WQAA_ERR_UNSUPPORTED;
+    }
+  } else {
     set_error(WQAA_ERR_UNSUPPORTED, "gemm: A dtype %d has no MFMA member yet", a);
     return WQAA_ERR_UNSUPPORTED;
   }
@@ -632,17 +670,24 @@ static int gemm_choose(const wqaa_matmul_desc& d, int m, GemmChoice* c) {
     case WQAA_W_FP4: c->kind = d.w_bits == 4 ? DK_LUT4 : -1; c->fp4_table = 1; break;
     case WQAA_W_E4M3: c->kind = DK_E4M3; break;
     case WQAA_W_E5M2: c->kind = DK_E5M2; break;
-    case WQAA_W_NATIVE: c->kind = DK_NATIVE; c->bits = a == WQAA_F16 ? 16 : 8; break;
+    case WQAA_W_NATIVE:
+      c->kind = a == WQAA_E4M3 ? DK_E4M3 : a == WQAA_E5M2 ? DK_E5M2 : DK_NATIVE;
+      c->bits = a == WQAA_F16 ? 16 : 8;
+      break;
     default: c->kind = -1;
   }
   if (c->kind < 0) {
     set_error(WQAA_ERR_UNSUPPORTED, "gemm: weight format %d / %d bits not supported", d.w_format, d.w_bits);
     return WQAA_ERR_UNSUPPORTED;
   }
-  if (c->kind == DK_E4M3 && d.strict_reference) c->flags |= FL_STRICT;
+  if (c->at == AT_F8 && c->kind != DK_E4M3 && c->kind != DK_E5M2) {
+    set_error(WQAA_ERR_UNSUPPORTED, "gemm: fp8 activations need fp8 weights");
+    return WQAA_ERR_UNSUPPORTED;
+  }
+  if (c->kind == DK_E4M3 && d.strict_reference && c->at == AT_F16) c->flags |= FL_STRICT;
   if (c->kind != DK_INT4 && c->kind != DK_INT2 && c->kind != DK_INT1) c->layout = LAYOUT_PLAIN;
-  if (c->at == AT_I8 && (d.with_scaling || d.zeros_mode != WQAA_Z_NONE)) {
-    set_error(WQAA_ERR_UNSUPPORTED, "gemm: scale/zeros with int8 activations are not defined by the reference");
+  if (c->at != AT_F16 && (d.with_scaling || d.zeros_mode != WQAA_Z_NONE)) {
+    set_error(WQAA_ERR_UNSUPPORTED, "gemm: scale/zeros with int8 / fp8 activations are not defined by the reference");
     return WQAA_ERR_UNSUPPORTED;
   }
   c->mode = !d.with_scaling ? MD_NONE
@@ -650,7 +695,7 @@ static int gemm_choose(const wqaa_matmul_desc& d, int m, GemmChoice* c) {
             : d.zeros_mode == WQAA_Z_RESCALE  ? MD_ZR
             : d.zeros_mode == WQAA_Z_QUANTIZED ? MD_ZQ
                                                : MD_S;
-  c->kl = c->at == AT_F16 ? 32 : 64;
+  c->kl = c->at == AT_F16 ? 32 : 64;   // int8: 16 k per MFMA lane; fp8: 8 k per MFMA lane, two MFMAs per granule
   c->ks = 4 * c->kl;
   if (d.K % c->ks != 0) {
     set_error(WQAA_ERR_UNSUPPORTED, "gemm: K=%d must be a multiple of %d", d.K, c->ks);
@@ -771,7 +816,7 @@ int gemm_launch(const wqaa_matmul_desc& d, const void* A, const void* B, const v
     const void* ws = a.ws;
     int M_ = m, N_ = d.N, ks_ = c.ksplit, od = d.out_dtype, hb = d.with_bias;
     void* rparams[] = {&ws, &C, &Bias, &M_, &N_, &ks_, &od, &hb};
-    const void* rfn = c.at == AT_F16 ? reinterpret_cast<const void*>(wq_splitk_reduce_kernel<true>)
+    const void* rfn = c.at != AT_I8 ? reinterpret_cast<const void*>(wq_splitk_reduce_kernel<true>)
                                      : reinterpret_cast<const void*>(wq_splitk_reduce_kernel<false>);
     if (start || stop) e = hipExtLaunchKernel(rfn, rgrid, rblock, rparams, 0, stream, nullptr, stop, 0);
     else e = hipLaunchKernel(rfn, rgrid, rblock, rparams, 0, stream);
@@ -787,9 +832,9 @@ void gemm_init() {
   const int kinds[] = {DK_INT4, DK_INT2, DK_INT1, DK_INT8, DK_LUT4, DK_E4M3, DK_E5M2, DK_NATIVE};
   for (int kind : kinds)
     for (int layout = 0; layout < 2; ++layout)
-      for (int at = 0; at < 2; ++at)
+      for (int at = 0; at < 3; ++at)
         for (int mode = 0; mode <= MD_ZQ; ++mode)
-          for (int flags = 0; flags < 2; ++flags)
+          for (int flags : {0, (int)FL_STRICT, (int)FL_ABF8})
             for (int mf : {1, 2, 4, 8, 16}) {
               gemm_fn fn = pick_gemm(kind, layout, at, mode, flags, mf);
               if (fn) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

@@ -9,10 +9,10 @@ namespace wqaa {
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
-enum : int { AT_F16 = 0, AT_I8 = 1 };
+enum : int { AT_F16 = 0, AT_I8 = 1, AT_F8 = 2 };   // activation operand type of the kernel
 // dequant arithmetic (matmul_dequantize_impl.py:435-449)
 enum : int { MD_NONE = 0, MD_S = 1, MD_ZO = 2, MD_ZR = 3, MD_ZQ = 4 };
-enum : int { FL_STRICT = 1, FL_A8 = 2 };  // e4m3 reference bit trick; activations stored as fp8
+enum : int { FL_STRICT = 1, FL_A8 = 2, FL_ABF8 = 4 };  // e4m3 reference bit trick; activations stored as fp8 (GEMV); fp8 MFMA activations are e5m2
 
 constexpr int cmax(int a, int b) { return a > b ? a : b; }
 

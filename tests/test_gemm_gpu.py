@@ -155,3 +155,41 @@ def test_gemv_and_gemm_agree_on_the_same_rows():
     one = mm(A[:1], W, scale=sc, zeros=zr).cpu().numpy()
     assert_fp_parity(full, oracle_output(case))
     assert_fp_parity(one, full[:1], rtol=2e-3)
+
+
+@pytest.mark.parametrize("M", [8, 64, 300])
+@pytest.mark.parametrize("a_dt,w_dt", [("e4m3_float8", "e4m3_float8"), ("e4m3_float8", "e5m2_float8"),
+                                       ("e5m2_float8", "e4m3_float8"), ("e5m2_float8", "e5m2_float8")])
+def test_dense_fp8_gemm(M, a_dt, w_dt):
+    """BASELINE c5 family: fp8 x fp8 -> fp32 on the fp8 matrix core (reference: test_general_matmul_fp8.py:11-59,
+    which prints and never asserts - parity is against the exact OCP decode + fp64 matmul)."""
+    import bitblas_amd as bitblas
+    rng = np.random.default_rng(M)
+    tdt = {"e4m3_float8": torch.float8_e4m3fn, "e5m2_float8": torch.float8_e5m2}
+    N, K = 256, 512
+    A8 = torch.from_numpy((rng.random((M, K), dtype=np.float32) * 2 - 1)).to(tdt[a_dt])
+    W8 = torch.from_numpy((rng.random((N, K), dtype=np.float32) * 2 - 1)).to(tdt[w_dt])
+    mm = bitblas.Matmul(bitblas.MatmulConfig(M=M, N=N, K=K, A_dtype=a_dt, W_dtype=w_dt, accum_dtype="float32",
+                                             out_dtype="float32"), enable_tuning=False)
+    assert mm.plans[M]["kernel_family"] == 2
+    out = mm(A8.cuda(), W8.cuda()).cpu().numpy()
+    want = oracle.matmul_dense(A8.view(torch.int8).numpy(), W8.view(torch.int8).numpy(), a_dtype=a_dt, w_dtype=w_dt,
+                               out_dtype="float32")
+    assert_fp_parity(out, want, rtol=1e-4, atol_frac=1e-4)   # fp32 accumulation order inside the matrix core
+
+
+def test_dense_fp8_gemv_matches_gemm():
+    import bitblas_amd as bitblas
+    rng = np.random.default_rng(3)
+    N, K = 256, 1024
+    A8 = torch.from_numpy((rng.random((8, K), dtype=np.float32) * 2 - 1)).to(torch.float8_e4m3fn)
+    W8 = torch.from_numpy((rng.random((N, K), dtype=np.float32) * 2 - 1)).to(torch.float8_e4m3fn)
+    mm = bitblas.Matmul(bitblas.MatmulConfig(M=[1, 8], N=N, K=K, A_dtype="e4m3_float8", W_dtype="e4m3_float8",
+                                             accum_dtype="float32", out_dtype="float32"), enable_tuning=False)
+    assert mm.plans[1]["kernel_family"] == 1 and mm.plans[8]["kernel_family"] == 2
+    full = mm(A8.cuda(), W8.cuda()).cpu().numpy()
+    one = mm(A8[:1].cuda(), W8.cuda()).cpu().numpy()
+    want = oracle.matmul_dense(A8.view(torch.int8).numpy(), W8.view(torch.int8).numpy(), a_dtype="e4m3_float8",
+                               out_dtype="float32")
+    assert_fp_parity(full, want, rtol=1e-4, atol_frac=1e-4)
+    assert_fp_parity(one, want[:1], rtol=1e-4, atol_frac=1e-4)
