@@ -64,8 +64,12 @@ struct GemmArgs {
 // ------------------------------------------------------------------------------------------
 // policy: one k-step is KS = 4 * KL deep; a lane owns KL consecutive k of one weight row
 // ------------------------------------------------------------------------------------------
-template <int KIND_, int LAYOUT_, int AT_, int MODE_, int FLAGS_, int MF_, int NWAVES_ = 4, int NFW_ = 2>
+template <int KIND_, int LAYOUT_, int AT_, int MODE_, int FLAGS_, int MF_, int NWAVES_ = 4, int NFW_ = 2, int SK_ = 0>
 struct GemmPolicy {
+  // SK > 0: "skinny" member for decode batches - a workgroup owns SK consecutive k-steps of its tile,
+  // issues ALL their weight loads before anything is consumed and stages all SK activation tiles behind
+  // one barrier (the pipelined member is latency-bound when M is small: one HBM round trip per k-step)
+  static constexpr int SK = SK_;
   static constexpr int KIND = KIND_, LAYOUT = LAYOUT_, AT = AT_, MODE = MODE_, FLAGS = FLAGS_;
   static constexpr int MF = MF_;        // 16-row activation fragments per workgroup (BM = 16 * MF)
   static constexpr int NFW = NFW_;      // 16-row weight fragments per wave
@@ -87,7 +91,7 @@ struct GemmPolicy {
   static constexpr int KS = 4 * KL;                   // 128 / 256: one LDS row is 256 bytes either way
   static constexpr int WL = KL * BITS / 32;           // 32-bit weight words per lane per k-step
   static constexpr int ROW_BYTES = 256;
-  static constexpr int LDS_BYTES = 2 * BM * ROW_BYTES;
+  static constexpr int LDS_BYTES = (SK_ > 0 ? SK_ : 2) * BM * ROW_BYTES;
 };
 
 // ------------------------------------------------------------------------------------------
@@ -381,19 +385,9 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_kernel(const GemmArgs a) {
 #pragma unroll
     for (int nf = 0; nf < NFW; ++nf) acc[mf][nf] = acc_t{0, 0, 0, 0};
 
-  const int t_begin = (int)((long)split * a.nsteps / a.ksplit);
-  const int nsteps = (int)((long)(split + 1) * a.nsteps / a.ksplit);   // end of this workgroup's k range
-  BLane<P> bcur, bnext;
-  a_load(t_begin);
-  b_load(t_begin, bcur);
-  a_store(t_begin & 1);
-  __syncthreads();
-
-  for (int t = t_begin; t < nsteps; ++t) {
-    const int tn = t + 1 < nsteps ? t + 1 : t;    // last step reloads itself: loads stay unconditional
-    a_load(tn);
-    b_load(tn, bnext);
-
+  // one k-step of this wave: dequantise its NFW weight fragments, then MF x NFW x NJ MFMAs against the
+  // activation tile at `abuf`
+  auto compute_step = [&](const BLane<P>& bl, const unsigned char* abuf) {
     // dequantise this wave's weight fragments for the whole k-step
     uint32_t bfrag[NFW][NJ][4];
 #pragma unroll
@@ -401,26 +395,24 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_kernel(const GemmArgs a) {
       if constexpr (F16) {
         half_t zf = cx.zf;
         if constexpr (MODE == MD_ZQ) {
-          const uint32_t zq = (bcur.z[nf] >> ((nrow[nf] % ZPB) * ZB)) & ((1u << ZB) - 1u);
+          const uint32_t zq = (bl.z[nf] >> ((nrow[nf] % ZPB) * ZB)) & ((1u << ZB) - 1u);
           zf = (half_t)(float)zq;
         }
-        const half2_t s2 = MODE != MD_NONE ? splat(bits_to_half(bcur.s[nf])) : splat((half_t)1.0f);
-        const half2_t z2 = (MODE == MD_ZO || MODE == MD_ZR) ? splat(bits_to_half(bcur.z[nf])) : splat((half_t)0.0f);
-        dequant_lane_f16<P>(bcur.w[nf], zf, s2, z2, cx, lut, bfrag[nf]);
+        const half2_t s2 = MODE != MD_NONE ? splat(bits_to_half(bl.s[nf])) : splat((half_t)1.0f);
+        const half2_t z2 = (MODE == MD_ZO || MODE == MD_ZR) ? splat(bits_to_half(bl.z[nf])) : splat((half_t)0.0f);
+        dequant_lane_f16<P>(bl.w[nf], zf, s2, z2, cx, lut, bfrag[nf]);
       } else if constexpr (F8) {
         // fp8 weights are MFMA operands as stored: fragment j = the lane's bytes [8j, 8j+8)
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-          bfrag[nf][j][0] = bcur.w[nf][2 * j];
-          bfrag[nf][j][1] = bcur.w[nf][2 * j + 1];
+          bfrag[nf][j][0] = bl.w[nf][2 * j];
+          bfrag[nf][j][1] = bl.w[nf][2 * j + 1];
         }
       } else {
-        dequant_lane_i8<P>(bcur.w[nf], zp4, cx.flip, bfrag[nf]);
+        dequant_lane_i8<P>(bl.w[nf], zp4, cx.flip, bfrag[nf]);
       }
     }
 
-    const unsigned char* abuf = smem_raw + (t & 1) * (P::BM * P::ROW_BYTES);
-    if (WQ_SETPRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int gq = 0; gq < 4; ++gq) {          // activation granule (kb, gq) of the lane's k-block
 #pragma unroll
@@ -454,10 +446,49 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_kernel(const GemmArgs a) {
       }
     }
 
-    if (WQ_SETPRIO) __builtin_amdgcn_s_setprio(0);
-    a_store((t + 1) & 1);
+  };
+
+  if constexpr (P::SK > 0) {
+    constexpr int S = P::SK;
+    const int t0 = split * S;
+    u32x4 areg_s[S][AG];
+#pragma unroll
+    for (int q = 0; q < S; ++q) {
+      const int t = t0 + q < a.nsteps ? t0 + q : a.nsteps - 1;
+      const long koff = (long)t * (P::KS * ASZ);
+#pragma unroll
+      for (int it = 0; it < AG; ++it) areg_s[q][it] = *reinterpret_cast<const u32x4*>(aptr[it] + koff);
+    }
+    BLane<P> bs[S];
+#pragma unroll
+    for (int q = 0; q < S; ++q) b_load(t0 + q < a.nsteps ? t0 + q : a.nsteps - 1, bs[q]);
+#pragma unroll
+    for (int q = 0; q < S; ++q)
+#pragma unroll
+      for (int it = 0; it < AG; ++it)
+        *reinterpret_cast<u32x4*>(smem_raw + q * (P::BM * P::ROW_BYTES) + a_lds_off[it]) = areg_s[q][it];
     __syncthreads();
-    bcur = bnext;
+#pragma unroll
+    for (int q = 0; q < S; ++q)
+      if (t0 + q < a.nsteps) compute_step(bs[q], smem_raw + q * (P::BM * P::ROW_BYTES));
+  } else {
+    const int t_begin = (int)((long)split * a.nsteps / a.ksplit);
+    const int nsteps = (int)((long)(split + 1) * a.nsteps / a.ksplit);   // end of this workgroup's k range
+    BLane<P> bcur, bnext;
+    a_load(t_begin);
+    b_load(t_begin, bcur);
+    a_store(t_begin & 1);
+    __syncthreads();
+
+    for (int t = t_begin; t < nsteps; ++t) {
+      const int tn = t + 1 < nsteps ? t + 1 : t;    // last step reloads itself: loads stay unconditional
+      a_load(tn);
+      b_load(tn, bnext);
+      compute_step(bcur, smem_raw + (t & 1) * (P::BM * P::ROW_BYTES));
+      a_store((t + 1) & 1);
+      __syncthreads();
+      bcur = bnext;
+    }
   }
 
   // ---- epilogue: D[i][col]: weight row n = nbase + kb * 4 + i, activation row m = mbase + fr ----
@@ -528,8 +559,20 @@ __global__ void __launch_bounds__(256) wq_splitk_reduce_kernel(const void* ws_, 
   const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= quads) return;
   const acc_t* ws = reinterpret_cast<const acc_t*>(ws_);
-  acc_t sum = ws[q];
-  for (int s = 1; s < ksplit; ++s) sum += ws[(long)s * quads + q];
+  // slices are read 8 at a time with independent loads (clamped index, masked add): a plain loop
+  // waits for every 16-byte load before issuing the next one
+  acc_t sum = acc_t{0, 0, 0, 0};
+  for (int s0 = 0; s0 < ksplit; s0 += 8) {
+    acc_t part[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int sl = s0 + i < ksplit ? s0 + i : ksplit - 1;
+      part[i] = ws[(long)sl * quads + q];
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      if (s0 + i < ksplit) sum += part[i];
+  }
   const long base = q * 4;
   const int n = (int)(base % N);
 #pragma unroll
@@ -580,6 +623,10 @@ static gemm_fn pick_mf(int mf) {
     case 4: return wq_gemm_kernel<GemmPolicy<KIND, LAYOUT, AT, MODE, FLAGS, 4>>;
     case 2: return wq_gemm_kernel<GemmPolicy<KIND, LAYOUT, AT, MODE, FLAGS, 2>>;
     case 1: return wq_gemm_kernel<GemmPolicy<KIND, LAYOUT, AT, MODE, FLAGS, 1>>;
+    // skinny members: 4 waves x 1 fragment, 4 k-steps per workgroup (mf code 100 + MF)
+    case 101: return wq_gemm_kernel<GemmPolicy<KIND, LAYOUT, AT, MODE, FLAGS, 1, 4, 1, 4>>;
+    case 102: return wq_gemm_kernel<GemmPolicy<KIND, LAYOUT, AT, MODE, FLAGS, 2, 4, 1, 4>>;
+    case 104: return wq_gemm_kernel<GemmPolicy<KIND, LAYOUT, AT, MODE, FLAGS, 4, 4, 1, 4>>;
   }
   return nullptr;
 }
@@ -636,7 +683,7 @@ static gemm_fn pick_gemm(int kind, int layout, int at, int mode, int flags, int 
 struct GemmChoice {
   gemm_fn fn;
   int kind, layout, at, mode, flags, bits;
-  int mf, ks, kl, nwaves, bn, ksplit;
+  int mf, ks, kl, nwaves, bn, ksplit, skinny;
   int tiles_m, tiles_n, lds;
   int fp4_table;
 };
@@ -719,9 +766,12 @@ static int gemm_choose(const wqaa_matmul_desc& d, int m, GemmChoice* c) {
   c->mf = (m >= 256 && d.N >= 256 && tiles256 * 10 >= (long)cus_ * 9) ? 16
           : m > 128 ? 8 : m > 32 ? 4 : m > 16 ? 2 : 1;
   if (const char* f = getenv("WQAA_GEMM_MF")) c->mf = atoi(f);   // tuning aid
+  const int nsteps = d.K / c->ks;
+  // decode batches (M <= 64): the skinny member, unless disabled
+  c->skinny = (m <= 64 && c->mf <= 4 && getenv("WQAA_GEMM_NOSKINNY") == nullptr) ? 4 : 0;
   c->nwaves = c->mf == 16 ? 8 : 4;
-  c->bn = c->nwaves * 32;
-  c->fn = pick_gemm(c->kind, c->layout, c->at, c->mode, c->flags, c->mf);
+  c->bn = c->skinny ? 64 : c->nwaves * 32;
+  c->fn = pick_gemm(c->kind, c->layout, c->at, c->mode, c->flags, c->skinny ? 100 + c->mf : c->mf);
   if (!c->fn) {
     set_error(WQAA_ERR_UNSUPPORTED, "gemm: no kernel for kind=%d layout=%d at=%d mode=%d", c->kind, c->layout, c->at, c->mode);
     return WQAA_ERR_UNSUPPORTED;
@@ -729,12 +779,15 @@ static int gemm_choose(const wqaa_matmul_desc& d, int m, GemmChoice* c) {
   const int bm = 16 * c->mf, bn = c->bn;
   c->tiles_m = (m + bm - 1) / bm;
   c->tiles_n = (d.N + bn - 1) / bn;
-  c->lds = 2 * bm * 256;
-  // split-K: a skinny problem has too few tiles to fill 256 CUs; cut K until ~2 workgroups per CU
+  c->lds = (c->skinny ? c->skinny : 2) * bm * 256;
+  if (c->skinny) {
+    c->ksplit = (nsteps + c->skinny - 1) / c->skinny;
+    return WQAA_OK;
+  }
+  // split-K: a skinny problem has too few tiles to fill 256 CUs; cut K until ~1 workgroup per CU
   // (partials cost 4 B per output element per slice, so stop at 16)
   const int cus = device_info().ok ? device_info().cus : 256;
   const int tiles = c->tiles_m * c->tiles_n;
-  const int nsteps = d.K / c->ks;
   int ks = 1;
   while (tiles * ks < cus && ks * 2 <= 16 && nsteps / (ks * 2) >= 1) ks *= 2;
   if (const char* f = getenv("WQAA_GEMM_KSPLIT")) ks = atoi(f);
@@ -835,7 +888,7 @@ void gemm_init() {
       for (int at = 0; at < 3; ++at)
         for (int mode = 0; mode <= MD_ZQ; ++mode)
           for (int flags : {0, (int)FL_STRICT, (int)FL_ABF8})
-            for (int mf : {1, 2, 4, 8, 16}) {
+            for (int mf : {1, 2, 4, 8, 16, 101, 102, 104}) {
               gemm_fn fn = pick_gemm(kind, layout, at, mode, flags, mf);
               if (fn) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             }
