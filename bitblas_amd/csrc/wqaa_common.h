@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
 
 #include "../../include/wqaa.h"
 
@@ -91,6 +92,27 @@ inline hipError_t launch_kernel(K kernel, const LaunchCfg& cfg, void* args_struc
   return hipLaunchKernel(reinterpret_cast<const void*>(kernel), grid, block, params, cfg.lds_bytes,
                          cfg.stream);
 }
+
+// kernel-name fragments (general_matmul/__init__.py:240-318 spelling: f16, i4, u4, ...)
+inline const char* short_dtype(int dt) {
+  switch (dt) {
+    case WQAA_F16: return "f16"; case WQAA_BF16: return "bf16"; case WQAA_F32: return "f32";
+    case WQAA_I8: return "i8"; case WQAA_I32: return "i32"; case WQAA_E4M3: return "e4m3"; case WQAA_E5M2: return "e5m2";
+  }
+  return "x";
+}
+inline void short_wdtype(const wqaa_matmul_desc& d, char* buf, size_t n) {
+  switch (d.w_format) {
+    case WQAA_W_UINT: snprintf(buf, n, "u%d", d.w_bits); break;
+    case WQAA_W_INT: snprintf(buf, n, "i%d", d.w_bits); break;
+    case WQAA_W_NF: snprintf(buf, n, "nf%d", d.w_bits); break;
+    case WQAA_W_FP4: snprintf(buf, n, "fp4_e2m1"); break;
+    case WQAA_W_E4M3: snprintf(buf, n, "e4m3"); break;
+    case WQAA_W_E5M2: snprintf(buf, n, "e5m2"); break;
+    default: snprintf(buf, n, "%s", short_dtype(d.a_dtype));
+  }
+}
+
 
 inline int ilog2_exact(int v) {
   if (v <= 0 || (v & (v - 1))) return -1;

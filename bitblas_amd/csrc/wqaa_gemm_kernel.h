@@ -1,0 +1,634 @@
+// wqaa_gemm_kernel.h - W_q x A MFMA GEMM family for gfx950 (M >= 8: the matrix-core-bound case).
+//
+// Replaces the reference's tensor-core templates `MatmulDequantizeMMAScheduler` /
+// `MatmulMMAScheduler` (bitblas/ops/general_matmul/tilelang/dequantize/matmul_dequantize_mma.py:200-508,
+// tilelang/dense/matmul_mma.py:145-320).  Same computation as the GEMV family,
+//     C[m, n] = cast_out( sum_k A[m, k] * dq(B[n, k]) ) (+ Bias[n]),
+// but the machine mapping is built around the CDNA4 matrix core:
+//   * packed weights never touch LDS.  The reference moves B global -> smem (packed) -> registers ->
+//     dequantise -> smem (fp16) -> ldmatrix -> mma (two shared-memory round trips).  Here a lane owns
+//     row n = lane & 15 of a 16-row fragment and the k-block kb = lane >> 4, exactly the operand map of
+//     v_mfma_f32_16x16x32_f16 / v_mfma_i32_16x16x64_i8, so ONE 16-byte load per lane (32 int4 weights)
+//     is unpacked + (zero, scale)-dequantised in registers straight into the operands of FOUR MFMAs
+//     of a 128-deep k-step.  The sum over k is order-free, so "k-block kb" is free to mean "the
+//     lane's 32 consecutive k": no shuffles, no permuted checkpoint layout;
+//   * the weight fragment is the MFMA *A* operand and the activation fragment the *B* operand
+//     (D = W_frag x A_frag^T): a lane then owns 4 consecutive n of one output row m, i.e. one
+//     8-byte fp16 store instead of four 2-byte ones;
+//   * activations are staged global -> registers -> LDS (double buffered, one barrier per k-step) as
+//     [row][16 granules of 16 B]; granule (kb, j) of row r lives in physical slot ((j*4+kb) ^ (r&15)):
+//     both the 8-lane ds_write_b128 groups and the 16-lane ds_read_b128 groups hit 16 distinct slots;
+//   * a workgroup is 4 waves side by side along N; every wave multiplies the whole BM x 128
+//     activation tile by its own NFW weight fragments, so no weight word is decoded twice;
+//   * the dequant arithmetic is the TE definition's (tirscript/matmul_dequantize_impl.py:391-451),
+//     rounding in A_dtype per element; accumulation is fp32 / int32 in the matrix core.
+#pragma once
+#include "wqaa_common.h"
+#include "wqaa_decode.h"
+#include "wqaa_kinds.h"
+
+#include <mutex>
+#include <type_traits>
+#include <utility>
+
+#ifndef WQ_SETPRIO
+#define WQ_SETPRIO 0   /* measured: -20 % at 256x256 (both waves of a SIMD raise priority together) */
+#endif
+
+namespace wqaa {
+
+typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+struct GemmArgs {
+  const void* A;
+  const void* B;
+  const void* lut;
+  const void* scale;
+  const void* zeros;
+  const void* bias;
+  void* C;
+  int M, N, K;
+  int kg;             // groups per weight row
+  int gq_shift;       // 32-element k-blocks per group = g / KL as a shift (-1: use gq_magic)
+  uint32_t gq_magic;
+  long row_bytes;     // bytes per weight row
+  int has_bias, out_dtype, is_signed, fp4_table;
+  int zq_row_bytes;
+  int tiles_m, tiles_n;
+  int nsteps;         // K / KS
+  int ksplit;         // > 1: workgroup (tile, s) covers k-steps [s*nsteps/ksplit, (s+1)*nsteps/ksplit) and
+  void* ws;           //      writes fp32 / int32 partial sums to ws[s][M][N]; a second kernel reduces
+};
+
+// ------------------------------------------------------------------------------------------
+// policy: one k-step is KS = 4 * KL deep; a lane owns KL consecutive k of one weight row
+// ------------------------------------------------------------------------------------------
+template <int KIND_, int LAYOUT_, int AT_, int MODE_, int FLAGS_, int MF_, int NWAVES_ = 4, int NFW_ = 2, int SK_ = 0>
+struct GemmPolicy {
+  // SK > 0: "skinny" member for decode batches - a workgroup owns SK consecutive k-steps of its tile,
+  // issues ALL their weight loads before anything is consumed and stages all SK activation tiles behind
+  // one barrier (the pipelined member is latency-bound when M is small: one HBM round trip per k-step)
+  static constexpr int SK = SK_;
+  static constexpr int KIND = KIND_, LAYOUT = LAYOUT_, AT = AT_, MODE = MODE_, FLAGS = FLAGS_;
+  static constexpr int MF = MF_;        // 16-row activation fragments per workgroup (BM = 16 * MF)
+  static constexpr int NFW = NFW_;      // 16-row weight fragments per wave
+  static constexpr int NWAVES = NWAVES_; // waves side by side along N
+  static constexpr int THREADS = 64 * NWAVES_;
+  static constexpr int AG = (16 * MF_ * 16) / (64 * NWAVES_);   // activation granules per thread per k-step
+  static_assert(AG >= 1 && AG * 64 * NWAVES_ == 16 * MF_ * 16, "tile / workgroup mismatch");
+  static constexpr int BM = 16 * MF, BN = 16 * NFW * NWAVES;
+  static constexpr bool STRICT = (FLAGS_ & FL_STRICT) != 0;
+  using T = KindTraits<KIND_, AT_>;
+  static constexpr int BITS = T::BITS;
+  static constexpr int EPW = T::EPW;
+  // elements of k per lane per MFMA, MFMAs per k-step, k per lane per k-step
+  static constexpr int KPM = AT_ == AT_I8 ? 16 : 8;
+  // MFMAs per 16-byte activation granule: fp8 operands are 8 bytes, so a granule feeds two
+  static constexpr int MPG = AT_ == AT_F8 ? 2 : 1;
+  static constexpr int NJ = 4 * MPG;
+  static constexpr int KL = KPM * NJ;                 // 32 (fp16) / 64 (int8, fp8)
+  static constexpr int KS = 4 * KL;                   // 128 / 256: one LDS row is 256 bytes either way
+  static constexpr int WL = KL * BITS / 32;           // 32-bit weight words per lane per k-step
+  static constexpr int ROW_BYTES = 256;
+  static constexpr int LDS_BYTES = (SK_ > 0 ? SK_ : 2) * BM * ROW_BYTES;
+};
+
+// ------------------------------------------------------------------------------------------
+// extraction order -> natural k order, resolved at compile time (v_perm_b32 per output register;
+// nothing at all for the LOP3 layouts, whose extraction order already is the natural one)
+// ------------------------------------------------------------------------------------------
+template <class T, int LAYOUT>
+constexpr int slot_of_elem(int e) {
+  for (int x = 0; x < T::EPW; ++x)
+    if (T::src_elem(LAYOUT, x) == e) return x;
+  return -1;
+}
+
+template <class T, int LAYOUT, int I>
+__device__ __forceinline__ uint32_t natural_pair_f16(const half2_t (&q)[T::EPW / 2]) {
+  constexpr int sa = slot_of_elem<T, LAYOUT>(2 * I), sb = slot_of_elem<T, LAYOUT>(2 * I + 1);
+  if constexpr (sa == 2 * I && sb == 2 * I + 1) {
+    return as_u32(q[I]);
+  } else {
+    constexpr uint32_t sel = ((uint32_t)(4 + 2 * (sb % 2) + 1) << 24) | ((uint32_t)(4 + 2 * (sb % 2)) << 16) |
+                             ((uint32_t)(2 * (sa % 2) + 1) << 8) | (uint32_t)(2 * (sa % 2));
+    return __builtin_amdgcn_perm(as_u32(q[sb / 2]), as_u32(q[sa / 2]), sel);
+  }
+}
+template <class T, int LAYOUT, int... I>
+__device__ __forceinline__ void to_natural_f16(const half2_t (&q)[T::EPW / 2], uint32_t (&out)[T::EPW / 2],
+                                               std::integer_sequence<int, I...>) {
+  ((out[I] = natural_pair_f16<T, LAYOUT, I>(q)), ...);
+}
+
+template <class T, int LAYOUT, int I>
+__device__ __forceinline__ uint32_t natural_quad_i8(const uint32_t (&q)[T::EPW / 4]) {
+  constexpr int s0 = slot_of_elem<T, LAYOUT>(4 * I), s1 = slot_of_elem<T, LAYOUT>(4 * I + 1),
+                s2 = slot_of_elem<T, LAYOUT>(4 * I + 2), s3 = slot_of_elem<T, LAYOUT>(4 * I + 3);
+  if constexpr (s0 == 4 * I && s1 == 4 * I + 1 && s2 == 4 * I + 2 && s3 == 4 * I + 3) {
+    return q[I];
+  } else {
+    // two bytes at a time: {s0, s1} then {s2, s3}, then merge the halves
+    constexpr uint32_t selA = ((uint32_t)(4 + (s1 % 4)) << 8) | (uint32_t)(s0 % 4);
+    constexpr uint32_t selB = ((uint32_t)(4 + (s3 % 4)) << 8) | (uint32_t)(s2 % 4);
+    const uint32_t lo = __builtin_amdgcn_perm(q[s1 / 4], q[s0 / 4], selA | 0x0C0C0000u);
+    const uint32_t hi = __builtin_amdgcn_perm(q[s3 / 4], q[s2 / 4], selB | 0x0C0C0000u);
+    return lo | (hi << 16);
+  }
+}
+template <class T, int LAYOUT, int... I>
+__device__ __forceinline__ void to_natural_i8(const uint32_t (&q)[T::EPW / 4], uint32_t (&out)[T::EPW / 4],
+                                              std::integer_sequence<int, I...>) {
+  ((out[I] = natural_quad_i8<T, LAYOUT, I>(q)), ...);
+}
+
+// ------------------------------------------------------------------------------------------
+// weight words of one lane for one k-step -> NJ MFMA operands (4 x 32-bit each), natural k order
+// ------------------------------------------------------------------------------------------
+template <class P>
+__device__ __forceinline__ void dequant_lane_f16(const uint32_t (&w)[P::WL], half_t zf, half2_t s2, half2_t z2,
+                                                 const DecodeCtx& cx, const Lut16& lut,
+                                                 uint32_t (&frag)[P::NJ][4]) {
+  using T = typename P::T;
+  constexpr int EPW = P::EPW;
+  if constexpr (T::SUBBYTE) {
+    // one word holds EPW >= 8 elements = EPW / 8 fragments
+#pragma unroll
+    for (int wi = 0; wi < P::WL; ++wi) {
+      half2_t q[EPW / 2];
+      if constexpr (P::KIND == DK_LUT4) {
+        lut16_word(lut, w[wi], q);
+      } else {
+        F16Unpack<T::BITS>::run(w[wi] ^ (P::KIND == DK_INT1 ? cx.flip : 0u), zf, cx.magic, q);
+      }
+#pragma unroll
+      for (int i = 0; i < EPW / 2; ++i) {
+        if constexpr (P::MODE == MD_S || P::MODE == MD_ZQ) q[i] = q[i] * s2;
+        if constexpr (P::MODE == MD_ZO) q[i] = (q[i] - z2) * s2;
+        if constexpr (P::MODE == MD_ZR) {
+          half2_t t = q[i] * s2;
+          asm volatile("" : "+v"(t));   // two roundings, no fma contraction
+          q[i] = t - z2;
+        }
+      }
+      uint32_t nat[EPW / 2];
+      to_natural_f16<T, P::LAYOUT>(q, nat, std::make_integer_sequence<int, EPW / 2>{});
+#pragma unroll
+      for (int i = 0; i < EPW / 2; ++i) {
+        const int e = wi * EPW + 2 * i;   // element index inside the lane's KL
+        frag[e / 8][(e % 8) / 2] = nat[i];
+      }
+    }
+  } else {
+    // 8-bit (4 per word) and 16-bit (2 per word) weights: already in natural order
+#pragma unroll
+    for (int wi = 0; wi < P::WL; ++wi) {
+      half2_t q[EPW / 2 > 0 ? EPW / 2 : 1];
+      if constexpr (P::KIND == DK_INT8) {
+        const uint32_t x = w[wi] ^ cx.flip;
+        const half2_t off = splat(cx.off8 + zf);
+        q[0] = as_h2(__builtin_amdgcn_perm(0x64646464u, x, 0x04010400u)) - off;
+        q[1] = as_h2(__builtin_amdgcn_perm(0x64646464u, x, 0x04030402u)) - off;
+      } else if constexpr (P::KIND == DK_E4M3) {
+        half2_t t[2];
+        unpack_e4m3_f16<P::STRICT>(w[wi], t);
+        q[0] = t[0]; q[1] = t[1];
+      } else if constexpr (P::KIND == DK_E5M2) {
+        half2_t t[2];
+        unpack_e5m2_f16(w[wi], t);
+        q[0] = t[0]; q[1] = t[1];
+      } else {
+        q[0] = as_h2(w[wi]);
+      }
+#pragma unroll
+      for (int i = 0; i < EPW / 2; ++i) {
+        if constexpr (P::MODE == MD_S || P::MODE == MD_ZQ) q[i] = q[i] * s2;
+        if constexpr (P::MODE == MD_ZO) q[i] = (q[i] - z2) * s2;
+        if constexpr (P::MODE == MD_ZR) {
+          half2_t t = q[i] * s2;
+          asm volatile("" : "+v"(t));
+          q[i] = t - z2;
+        }
+        const int e = wi * EPW + 2 * i;
+        frag[e / 8][(e % 8) / 2] = as_u32(q[i]);
+      }
+    }
+  }
+}
+
+template <class P>
+__device__ __forceinline__ void dequant_lane_i8(const uint32_t (&w)[P::WL], uint32_t zp4, uint32_t flip,
+                                                uint32_t (&frag)[P::NJ][4]) {
+  using T = typename P::T;
+  constexpr int EPW = P::EPW;
+  if constexpr (T::SUBBYTE) {
+    constexpr int NQ = I8Unpack<T::BITS>::NQUAD;   // == EPW / 4
+#pragma unroll
+    for (int wi = 0; wi < P::WL; ++wi) {
+      uint32_t t[NQ];
+      I8Unpack<T::BITS>::run(w[wi] ^ flip, t);
+#pragma unroll
+      for (int i = 0; i < NQ; ++i) t[i] = sub_bytes(t[i], zp4);
+      uint32_t nat[NQ];
+      to_natural_i8<T, P::LAYOUT>(t, nat, std::make_integer_sequence<int, NQ>{});
+#pragma unroll
+      for (int i = 0; i < NQ; ++i) {
+        const int e = wi * EPW + 4 * i;
+        frag[e / 16][(e % 16) / 4] = nat[i];
+      }
+    }
+  } else {
+#pragma unroll
+    for (int wi = 0; wi < P::WL; ++wi) frag[wi / 4][wi % 4] = w[wi];
+  }
+}
+
+template <int NW_>
+__device__ __forceinline__ void load_lane_words(const uint8_t* p, uint32_t (&w)[NW_]) {
+  if constexpr (NW_ % 4 == 0) {
+#pragma unroll
+    for (int q = 0; q < NW_ / 4; ++q) {
+      const u32x4 v = reinterpret_cast<const u32x4*>(p)[q];
+      w[4 * q] = v[0]; w[4 * q + 1] = v[1]; w[4 * q + 2] = v[2]; w[4 * q + 3] = v[3];
+    }
+  } else if constexpr (NW_ == 2) {
+    const u32x2 v = *reinterpret_cast<const u32x2*>(p);
+    w[0] = v[0]; w[1] = v[1];
+  } else {
+    static_assert(NW_ == 1, "unsupported lane word count");
+    w[0] = *reinterpret_cast<const uint32_t*>(p);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// the kernel
+// ------------------------------------------------------------------------------------------
+template <class P>
+struct BLane {
+  uint32_t w[P::NFW][P::WL];
+  uint32_t s[P::NFW];
+  uint32_t z[P::NFW];
+};
+
+template <class P>
+__global__ void __launch_bounds__(P::THREADS) wq_gemm_kernel(const GemmArgs a) {
+  using T = typename P::T;
+  constexpr int MF = P::MF, NFW = P::NFW, NJ = P::NJ, WL = P::WL, MODE = P::MODE;
+  constexpr bool F16 = P::AT == AT_F16;
+  constexpr bool F8 = P::AT == AT_F8;
+  constexpr bool FACC = F16 || F8;                        // fp32 accumulators
+  constexpr int ASZ = F16 ? 2 : 1;                        // bytes per activation element
+  using acc_t = typename std::conditional<FACC, f32x4, i32x4>::type;
+  constexpr int ZB = T::SUBBYTE ? T::BITS : 8;
+  constexpr int ZPB = 8 / ZB;
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 15;          // fragment row (weight n / activation m)
+  const int kb = lane >> 4;          // k-block of the lane
+
+  // XCD-aware tile order: block b runs on XCD b % 8; give every XCD a contiguous band of M tiles so
+  // its L2 keeps one activation band and streams the (small, packed) weights
+  int blk = blockIdx.x;
+  const int nblk = gridDim.x;
+  if ((nblk & 7) == 0) blk = (blockIdx.x & 7) * (nblk >> 3) + (blockIdx.x >> 3);
+  const int ntiles = a.tiles_m * a.tiles_n;
+  const int split = blk / ntiles;        // k-slice of this workgroup (0 when ksplit == 1)
+  blk -= split * ntiles;
+  const int tile_m = blk / a.tiles_n, tile_n = blk % a.tiles_n;
+  const int m0 = tile_m * P::BM;
+  const int n0 = tile_n * P::BN + wave * (NFW * 16);
+
+  const uint8_t* Ap = reinterpret_cast<const uint8_t*>(a.A);
+  const uint8_t* Bp = reinterpret_cast<const uint8_t*>(a.B);
+  const uint16_t* Sp = reinterpret_cast<const uint16_t*>(a.scale);
+  const uint16_t* Zp = reinterpret_cast<const uint16_t*>(a.zeros);
+  const uint8_t* Qp = reinterpret_cast<const uint8_t*>(a.zeros);
+
+  // ---- activation staging: AG granules (16 B) per thread per k-step ----
+  // 16 consecutive threads cover one 256-byte row.  Inside a row the two 8-lane halves (the
+  // ds_write_b128 service groups, 128-byte bank window) take natural granules {0,1,4,5,8,9,12,13} and
+  // {2,3,6,7,...}: their physical slots (j*4+kb)^r are then distinct mod 8 - no write conflicts.
+  constexpr int AG = P::AG;
+  u32x4 areg[AG];
+  const uint8_t* aptr[AG];
+  int a_lds_off[AG];
+#pragma unroll
+  for (int it = 0; it < AG; ++it) {
+    const int gid = it * P::THREADS + tid;
+    const int r = gid >> 4, q = gid & 15;
+    const int ns = ((q & 7) >> 1) * 4 + (q & 1) + ((q >> 3) << 1);   // natural granule = kb' * 4 + j'
+    int m = m0 + r;
+    m = m < a.M ? m : a.M - 1;
+    aptr[it] = Ap + (long)m * a.K * ASZ + ns * 16;
+    const int phys = (((ns & 3) << 2) | (ns >> 2)) ^ (r & 15);
+    a_lds_off[it] = r * P::ROW_BYTES + phys * 16;
+  }
+  auto a_load = [&](int t) {
+    const long koff = (long)t * (P::KS * ASZ);
+#pragma unroll
+    for (int it = 0; it < AG; ++it) areg[it] = *reinterpret_cast<const u32x4*>(aptr[it] + koff);
+  };
+  auto a_store = [&](int buf) {
+#pragma unroll
+    for (int it = 0; it < AG; ++it)
+      *reinterpret_cast<u32x4*>(smem_raw + buf * (P::BM * P::ROW_BYTES) + a_lds_off[it]) = areg[it];
+  };
+
+  // ---- weight lane loads ----
+  int nrow[NFW];
+#pragma unroll
+  for (int nf = 0; nf < NFW; ++nf) {
+    const int n = n0 + nf * 16 + fr;
+    nrow[nf] = n < a.N ? n : a.N - 1;
+  }
+  const uint8_t* bptr[NFW];
+#pragma unroll
+  for (int nf = 0; nf < NFW; ++nf) bptr[nf] = Bp + (long)nrow[nf] * a.row_bytes + (long)kb * (WL * 4);
+  auto b_load = [&](int t, BLane<P>& b) {
+    const int kidx = t * 4 + kb;    // index of the lane's KL-wide k-block
+    int gi = 0;
+    if (MODE != MD_NONE) gi = a.gq_shift >= 0 ? (kidx >> a.gq_shift) : (int)__umulhi((uint32_t)kidx, a.gq_magic);
+#pragma unroll
+    for (int nf = 0; nf < NFW; ++nf) {
+      load_lane_words<WL>(bptr[nf] + (long)t * (4 * WL * 4), b.w[nf]);
+      if constexpr (MODE != MD_NONE) b.s[nf] = Sp[(long)nrow[nf] * a.kg + gi];
+      if constexpr (MODE == MD_ZO || MODE == MD_ZR) b.z[nf] = Zp[(long)nrow[nf] * a.kg + gi];
+      if constexpr (MODE == MD_ZQ) b.z[nf] = Qp[(long)gi * a.zq_row_bytes + nrow[nf] / ZPB];
+    }
+  };
+
+  DecodeCtx cx;
+  cx.zf = (F16 && a.is_signed && T::SUBBYTE) ? (half_t)(float)(1 << (T::BITS - 1)) : (half_t)0.0f;
+  cx.flip = 0u;
+  if (P::KIND == DK_INT1 && a.is_signed) cx.flip = 0xFFFFFFFFu;
+  if (P::KIND == DK_INT8 && a.is_signed) cx.flip = 0x80808080u;
+  cx.off8 = (half_t)(a.is_signed ? 1152.0f : 1024.0f);
+  make_magic(cx.magic);
+  const uint32_t zp4 = (!F16 && a.is_signed && T::SUBBYTE) ? (uint32_t)(1u << (T::BITS - 1)) * 0x01010101u : 0u;
+  Lut16 lut;
+  if constexpr (P::KIND == DK_LUT4) {
+    if (a.fp4_table) {
+      lut = make_fp4_lut();
+    } else {
+      lut = make_lut16(reinterpret_cast<const half_t*>(a.lut));
+    }
+  }
+
+  acc_t acc[MF][NFW];
+#pragma unroll
+  for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+    for (int nf = 0; nf < NFW; ++nf) acc[mf][nf] = acc_t{0, 0, 0, 0};
+
+  // one k-step of this wave: dequantise its NFW weight fragments, then MF x NFW x NJ MFMAs against the
+  // activation tile at `abuf`
+  auto compute_step = [&](const BLane<P>& bl, const unsigned char* abuf) {
+    // dequantise this wave's weight fragments for the whole k-step
+    uint32_t bfrag[NFW][NJ][4];
+#pragma unroll
+    for (int nf = 0; nf < NFW; ++nf) {
+      if constexpr (F16) {
+        half_t zf = cx.zf;
+        if constexpr (MODE == MD_ZQ) {
+          const uint32_t zq = (bl.z[nf] >> ((nrow[nf] % ZPB) * ZB)) & ((1u << ZB) - 1u);
+          zf = (half_t)(float)zq;
+        }
+        const half2_t s2 = MODE != MD_NONE ? splat(bits_to_half(bl.s[nf])) : splat((half_t)1.0f);
+        const half2_t z2 = (MODE == MD_ZO || MODE == MD_ZR) ? splat(bits_to_half(bl.z[nf])) : splat((half_t)0.0f);
+        dequant_lane_f16<P>(bl.w[nf], zf, s2, z2, cx, lut, bfrag[nf]);
+      } else if constexpr (F8) {
+        // fp8 weights are MFMA operands as stored: fragment j = the lane's bytes [8j, 8j+8)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          bfrag[nf][j][0] = bl.w[nf][2 * j];
+          bfrag[nf][j][1] = bl.w[nf][2 * j + 1];
+        }
+      } else {
+        dequant_lane_i8<P>(bl.w[nf], zp4, cx.flip, bfrag[nf]);
+      }
+    }
+
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {          // activation granule (kb, gq) of the lane's k-block
+#pragma unroll
+      for (int mf = 0; mf < MF; ++mf) {
+        const int phys = ((gq << 2) | kb) ^ fr;
+        const u32x4 av = *reinterpret_cast<const u32x4*>(abuf + (mf * 16 + fr) * P::ROW_BYTES + phys * 16);
+#pragma unroll
+        for (int nf = 0; nf < NFW; ++nf) {
+          if constexpr (F16) {
+            const u32x4 bv = {bfrag[nf][gq][0], bfrag[nf][gq][1], bfrag[nf][gq][2], bfrag[nf][gq][3]};
+            acc[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8_t, bv),
+                                                                __builtin_bit_cast(half8_t, av), acc[mf][nf], 0, 0, 0);
+          } else if constexpr (F8) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              const u32x2 b2 = {bfrag[nf][2 * gq + h][0], bfrag[nf][2 * gq + h][1]};
+              const u32x2 a2 = {av[2 * h], av[2 * h + 1]};
+              const long bl = __builtin_bit_cast(long, b2), al = __builtin_bit_cast(long, a2);
+              constexpr bool WB = P::KIND == DK_E5M2, AB = (P::FLAGS & FL_ABF8) != 0;
+              if constexpr (!WB && !AB) acc[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(bl, al, acc[mf][nf], 0, 0, 0);
+              if constexpr (!WB && AB) acc[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_bf8(bl, al, acc[mf][nf], 0, 0, 0);
+              if constexpr (WB && !AB) acc[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf8_fp8(bl, al, acc[mf][nf], 0, 0, 0);
+              if constexpr (WB && AB) acc[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf8_bf8(bl, al, acc[mf][nf], 0, 0, 0);
+            }
+          } else {
+            const u32x4 bv = {bfrag[nf][gq][0], bfrag[nf][gq][1], bfrag[nf][gq][2], bfrag[nf][gq][3]};
+            acc[mf][nf] = __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4, bv),
+                                                               __builtin_bit_cast(i32x4, av), acc[mf][nf], 0, 0, 0);
+          }
+        }
+      }
+    }
+
+  };
+
+  if constexpr (P::SK > 0) {
+    constexpr int S = P::SK;
+    const int t0 = split * S;
+    u32x4 areg_s[S][AG];
+#pragma unroll
+    for (int q = 0; q < S; ++q) {
+      const int t = t0 + q < a.nsteps ? t0 + q : a.nsteps - 1;
+      const long koff = (long)t * (P::KS * ASZ);
+#pragma unroll
+      for (int it = 0; it < AG; ++it) areg_s[q][it] = *reinterpret_cast<const u32x4*>(aptr[it] + koff);
+    }
+    BLane<P> bs[S];
+#pragma unroll
+    for (int q = 0; q < S; ++q) b_load(t0 + q < a.nsteps ? t0 + q : a.nsteps - 1, bs[q]);
+#pragma unroll
+    for (int q = 0; q < S; ++q)
+#pragma unroll
+      for (int it = 0; it < AG; ++it)
+        *reinterpret_cast<u32x4*>(smem_raw + q * (P::BM * P::ROW_BYTES) + a_lds_off[it]) = areg_s[q][it];
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < S; ++q)
+      if (t0 + q < a.nsteps) compute_step(bs[q], smem_raw + q * (P::BM * P::ROW_BYTES));
+  } else {
+    const int t_begin = (int)((long)split * a.nsteps / a.ksplit);
+    const int nsteps = (int)((long)(split + 1) * a.nsteps / a.ksplit);   // end of this workgroup's k range
+    BLane<P> bcur, bnext;
+    a_load(t_begin);
+    b_load(t_begin, bcur);
+    a_store(t_begin & 1);
+    __syncthreads();
+
+    for (int t = t_begin; t < nsteps; ++t) {
+      const int tn = t + 1 < nsteps ? t + 1 : t;    // last step reloads itself: loads stay unconditional
+      a_load(tn);
+      b_load(tn, bnext);
+      compute_step(bcur, smem_raw + (t & 1) * (P::BM * P::ROW_BYTES));
+      a_store((t + 1) & 1);
+      __syncthreads();
+      bcur = bnext;
+    }
+  }
+
+  // ---- epilogue: D[i][col]: weight row n = nbase + kb * 4 + i, activation row m = mbase + fr ----
+  if (a.ksplit > 1) {
+    acc_t* ws = reinterpret_cast<acc_t*>(a.ws);
+#pragma unroll
+    for (int nf = 0; nf < NFW; ++nf) {
+      const int nb = n0 + nf * 16 + kb * 4;
+      if (nb >= a.N) continue;
+#pragma unroll
+      for (int mf = 0; mf < MF; ++mf) {
+        const int m = m0 + mf * 16 + fr;
+        if (m >= a.M) continue;
+        ws[(((long)split * a.M + m) * a.N + nb) >> 2] = acc[mf][nf];
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int nf = 0; nf < NFW; ++nf) {
+    const int nb = n0 + nf * 16 + kb * 4;
+    if (nb >= a.N) continue;
+    float bias_f[4] = {0.f, 0.f, 0.f, 0.f};
+    int bias_i[4] = {0, 0, 0, 0};
+    if (a.has_bias) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if constexpr (F16) bias_f[i] = (float)reinterpret_cast<const half_t*>(a.bias)[nb + i];
+        else if constexpr (F8) bias_f[i] = 0.f;   // the reference defines no fp8 bias operand
+        else bias_i[i] = (int)reinterpret_cast<const int8_t*>(a.bias)[nb + i];
+      }
+    }
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf) {
+      const int m = m0 + mf * 16 + fr;
+      if (m >= a.M) continue;
+      const long base = (long)m * a.N + nb;
+      if constexpr (FACC) {
+        if (a.out_dtype == WQAA_F16) {
+          half_t v[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            v[i] = (half_t)acc[mf][nf][i];
+            if (a.has_bias) v[i] = v[i] + (half_t)bias_f[i];
+          }
+          const half2_t lo = {v[0], v[1]}, hi = {v[2], v[3]};
+          *reinterpret_cast<u32x2*>(reinterpret_cast<half_t*>(a.C) + base) = u32x2{as_u32(lo), as_u32(hi)};
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) store_out(a.C, base + i, acc[mf][nf][i], a.out_dtype, a.has_bias != 0, bias_f[i]);
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) store_out(a.C, base + i, acc[mf][nf][i], a.out_dtype, a.has_bias != 0, bias_i[i]);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// split-K reduction: C[m][n..n+3] = cast(sum_s ws[s][m][n..n+3]) (+ bias after the cast)
+// ------------------------------------------------------------------------------------------
+template <bool F16>
+__global__ void __launch_bounds__(256) wq_splitk_reduce_kernel(const void* ws_, void* C, const void* bias, int M, int N,
+                                                               int ksplit, int out_dtype, int has_bias) {
+  using acc_t = typename std::conditional<F16, f32x4, i32x4>::type;
+  const long quads = (long)M * N / 4;
+  const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= quads) return;
+  const acc_t* ws = reinterpret_cast<const acc_t*>(ws_);
+  // slices are read 8 at a time with independent loads (clamped index, masked add): a plain loop
+  // waits for every 16-byte load before issuing the next one
+  acc_t sum = acc_t{0, 0, 0, 0};
+  for (int s0 = 0; s0 < ksplit; s0 += 8) {
+    acc_t part[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int sl = s0 + i < ksplit ? s0 + i : ksplit - 1;
+      part[i] = ws[(long)sl * quads + q];
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      if (s0 + i < ksplit) sum += part[i];
+  }
+  const long base = q * 4;
+  const int n = (int)(base % N);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if constexpr (F16) {
+      const float b = has_bias ? (float)reinterpret_cast<const half_t*>(bias)[n + i] : 0.f;
+      store_out(C, base + i, sum[i], out_dtype, has_bias != 0, b);
+    } else {
+      const int b = has_bias ? (int)reinterpret_cast<const int8_t*>(bias)[n + i] : 0;
+      store_out(C, base + i, sum[i], out_dtype, has_bias != 0, b);
+    }
+  }
+}
+
+typedef void (*gemm_fn)(const GemmArgs);
+
+// member tables, one translation unit each (parallel builds): wqaa_gemm_inst_*.hip
+gemm_fn pick_gemm_f16_int4(int layout, int mode, int mf);
+gemm_fn pick_gemm_f16_int21(int kind, int layout, int mode, int mf);
+gemm_fn pick_gemm_f16_other(int kind, int mode, int flags, int mf);
+gemm_fn pick_gemm_i8_f8(int kind, int layout, int at, int flags, int mf);
+
+// mf codes: 1, 2, 4, 8 (16*mf x 128, 4 waves), 16 (256 x 256, 8 waves), 101/102/104 (skinny members)
+template <int KIND, int LAYOUT, int AT, int MODE, int FLAGS>
+static gemm_fn pick_mf(int mf) {
+  switch (mf) {
+    case 16: return wq_gemm_kernel<GemmPolicy<KIND, LAYOUT, AT, MODE, FLAGS, 16, 8>>;
+    case 8: return wq_gemm_kernel<GemmPolicy<KIND, LAYOUT, AT, MODE, FLAGS, 8>>;
+    case 4: return wq_gemm_kernel<GemmPolicy<KIND, LAYOUT, AT, MODE, FLAGS, 4>>;
+    case 2: return wq_gemm_kernel<GemmPolicy<KIND, LAYOUT, AT, MODE, FLAGS, 2>>;
+    case 1: return wq_gemm_kernel<GemmPolicy<KIND, LAYOUT, AT, MODE, FLAGS, 1>>;
+    case 101: return wq_gemm_kernel<GemmPolicy<KIND, LAYOUT, AT, MODE, FLAGS, 1, 4, 1, 4>>;
+    case 102: return wq_gemm_kernel<GemmPolicy<KIND, LAYOUT, AT, MODE, FLAGS, 2, 4, 1, 4>>;
+    case 104: return wq_gemm_kernel<GemmPolicy<KIND, LAYOUT, AT, MODE, FLAGS, 4, 4, 1, 4>>;
+  }
+  return nullptr;
+}
+template <int KIND, int LAYOUT>
+static gemm_fn pick_modes(int mode, int mf) {
+  switch (mode) {
+    case MD_NONE: return pick_mf<KIND, LAYOUT, AT_F16, MD_NONE, 0>(mf);
+    case MD_S: return pick_mf<KIND, LAYOUT, AT_F16, MD_S, 0>(mf);
+    case MD_ZO: return pick_mf<KIND, LAYOUT, AT_F16, MD_ZO, 0>(mf);
+    case MD_ZR: return pick_mf<KIND, LAYOUT, AT_F16, MD_ZR, 0>(mf);
+    case MD_ZQ: return pick_mf<KIND, LAYOUT, AT_F16, MD_ZQ, 0>(mf);
+  }
+  return nullptr;
+}
+template <int KIND, int FLAGS>
+static gemm_fn pick_modes_fp(int mode, int mf) {
+  switch (mode) {
+    case MD_NONE: return pick_mf<KIND, LAYOUT_PLAIN, AT_F16, MD_NONE, FLAGS>(mf);
+    case MD_S: return pick_mf<KIND, LAYOUT_PLAIN, AT_F16, MD_S, FLAGS>(mf);
+  }
+  return nullptr;
+}
+
+}  // namespace wqaa

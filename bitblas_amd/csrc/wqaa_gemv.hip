@@ -695,25 +695,6 @@ static void fill_args(const wqaa_matmul_desc& d, const GemvChoice& c, const void
   a->zq_row_bytes = d.N * (c.bits < 8 ? c.bits : 8) / 8;
 }
 
-static const char* short_dtype(int dt) {
-  switch (dt) {
-    case WQAA_F16: return "f16"; case WQAA_BF16: return "bf16"; case WQAA_F32: return "f32";
-    case WQAA_I8: return "i8"; case WQAA_I32: return "i32"; case WQAA_E4M3: return "e4m3"; case WQAA_E5M2: return "e5m2";
-  }
-  return "x";
-}
-static void short_wdtype(const wqaa_matmul_desc& d, char* buf, size_t n) {
-  switch (d.w_format) {
-    case WQAA_W_UINT: snprintf(buf, n, "u%d", d.w_bits); break;
-    case WQAA_W_INT: snprintf(buf, n, "i%d", d.w_bits); break;
-    case WQAA_W_NF: snprintf(buf, n, "nf%d", d.w_bits); break;
-    case WQAA_W_FP4: snprintf(buf, n, "fp4_e2m1"); break;
-    case WQAA_W_E4M3: snprintf(buf, n, "e4m3"); break;
-    case WQAA_W_E5M2: snprintf(buf, n, "e5m2"); break;
-    default: snprintf(buf, n, "%s", short_dtype(d.a_dtype));
-  }
-}
-
 int gemv_plan(const wqaa_matmul_desc& d, int m, wqaa_plan* plan) {
   GemvChoice c;
   int st = choose(d, m, &c);

@@ -15,7 +15,9 @@
  * Here nothing is JIT-compiled: ONE prebuilt library holds the static kernel set, and the per-config
  * `call` becomes `wqaa_matmul(desc, ...)` with the config passed as a plain struct.  Pointer order is
  * the reference's prim_func order (tirscript/matmul_dequantize_impl.py:465-478).  All pointers are
- * device pointers owned by the caller; the library never allocates, frees or synchronises.
+ * device pointers owned by the caller; the library never frees or synchronises, and allocates only one
+ * internal scratch buffer per device (fp32 partial sums of the split-K GEMM members, grown on demand:
+ * make the first call of a new skinny shape outside stream capture).
  *
  * Plain C: no torch, no HIP types in signatures (hipStream_t is passed as void*).
  */

@@ -48,7 +48,7 @@ def test_operator_construction_plans_without_gpu():
                                with_scaling=True, with_zeros=True)
     op = bitblas.Matmul(cfg, enable_tuning=False)
     assert op.plans[1]["kernel_family"] == 1 and op.plans[16]["kernel_family"] == 2
-    assert op.plans[4096]["block_m"] == 128
+    assert op.plans[4096]["block_m"] == 256 and op.plans[4096]["block_n"] == 256   # the 8-wave member
     assert op.retrieve_weight_shape() == [4096, 2048]
     assert op.propagate_a == TransformKind.NonTransform and op.propagate_b == TransformKind.NonTransform
     w = torch.randint(0, 16, (4096, 4096), dtype=torch.int8)
