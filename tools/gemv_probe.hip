@@ -112,6 +112,94 @@ __global__ void __launch_bounds__(NWAVE * 64) k_gemv(const uint8_t* __restrict__
   }
 }
 
+
+// pipelined variant: a wave owns row groups rg, rg + total_waves, ...; the loads of the NEXT row group
+// are in flight while the current one is decoded (two register stages, loop unrolled by two so that
+// every load is unconditional inside the steady state)
+template <int R, int NWAVE>
+__global__ void __launch_bounds__(NWAVE * 64) k_gemv_pipe(const uint8_t* __restrict__ B, const half_t* __restrict__ A,
+                                                          const uint16_t* __restrict__ S, half_t* __restrict__ C, int N) {
+  constexpr int K = 4096, NC = 2, KG = K / 128;
+  __shared__ u32x4 a_lds[K / 8];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int blk = blockIdx.x;
+  if ((gridDim.x & 7) == 0) { const int per = gridDim.x / 8; blk = (blockIdx.x % 8) * per + blockIdx.x / 8; }
+  const int total = gridDim.x * NWAVE;
+  const int n_rg = N / R;
+  int rg = blk * NWAVE + wave;
+  u32x4 areg[2];
+#pragma unroll
+  for (int j = 0; j < (K / 8 + NWAVE * 64 - 1) / (NWAVE * 64); ++j) {
+    const int i = j * NWAVE * 64 + tid;
+    areg[j] = reinterpret_cast<const u32x4*>(A)[i < K / 8 ? i : 0];
+  }
+  struct St { u32x4 w[R][NC]; uint32_t sc[R][NC]; };
+  auto issue = [&](St& st, int g) {
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        const int n = g * R + r;
+        st.w[r][c] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(B + (long)n * (K / 2) + (c * 64 + lane) * 16));
+        st.sc[r][c] = S[n * KG + (c * 64 + lane) / 4];
+      }
+  };
+  auto consume = [&](const St& st, int g) {
+    float acc[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const u32x4 av = a_lds[(c * 64 + lane) * 4 + u];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const uint32_t x = st.w[r][c][u];
+          const half_t sh = __builtin_bit_cast(half_t, (uint16_t)st.sc[r][c]);
+          const half2_t s2 = {sh, sh};
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int bit = 4 * i, b = bit & 7;
+            const uint32_t src = bit >= 8 ? (x >> 8) : x;
+            const uint32_t t = (src & ((0xFu << b) * 0x00010001u)) | ((uint32_t)((25 - b) << 10) * 0x00010001u);
+            const half_t off = (half_t)((float)(1 << (10 - b)) + 8.0f);
+            half2_t q = as_h2(t) - half2_t{off, off};
+            q = q * s2;
+            acc[r] = __builtin_amdgcn_fdot2(q, as_h2(av[i]), acc[r], false);
+          }
+        }
+      }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const float tot = wave_sum(acc[r]);
+      if (lane == 0) C[g * R + r] = (half_t)tot;
+    }
+  };
+  St s0, s1;
+  const bool work = rg < n_rg;
+  issue(s0, work ? rg : n_rg - 1);
+#pragma unroll
+  for (int j = 0; j < (K / 8 + NWAVE * 64 - 1) / (NWAVE * 64); ++j) {
+    const int i = j * NWAVE * 64 + tid;
+    if (i < K / 8) a_lds[i] = areg[j];
+  }
+  __syncthreads();
+  if (!work) return;
+  while (true) {
+    int nx = rg + total;
+    if (nx >= n_rg) { consume(s0, rg); break; }
+    issue(s1, nx);
+    consume(s0, rg);
+    rg = nx;
+    nx = rg + total;
+    if (nx >= n_rg) { consume(s1, rg); break; }
+    issue(s0, nx);
+    consume(s1, rg);
+    rg = nx;
+  }
+}
+
 template <class F>
 static double time_graph(F launch_one, int nbuf, hipStream_t s) {
   for (int i = 0; i < nbuf; ++i) launch_one(i);
@@ -147,5 +235,8 @@ int main(int argc, char** argv) {
 #define RUN(FLAGS, R, NWAVE) { double us = time_graph([&](int i) { hipLaunchKernelGGL((k_gemv<FLAGS, R, NWAVE>), dim3(N / (R * NWAVE)), dim3(NWAVE * 64), 0, s, (const uint8_t*)W[i], (const half_t*)A, (const uint16_t*)S[i], C, N); }, nbuf, s); \
     printf("flags=%3d (%s%s%s%s%s%s%s) R=%d waves/block=%d grid=%4d : %6.3f us  -> %6.1f GB/s\n", FLAGS, (FLAGS & 1) ? "compute " : "", (FLAGS & 2) ? "lds " : "", (FLAGS & 4) ? "store " : "", (FLAGS & 8) ? "scale " : "", (FLAGS & 16) ? "xcd " : "", (FLAGS & 32) ? "fold " : "", (FLAGS & 64) ? "adirect " : "", R, NWAVE, N / (R * NWAVE), us, alg / us * 1e-3); }
   RUN(0, 2, 4) RUN(4 + 16, 2, 4) RUN(8, 2, 4) RUN(2, 2, 4) RUN(1, 2, 4) RUN(15 + 16, 2, 4) RUN(15 + 16, 1, 4) RUN(15 + 16, 2, 2) RUN(15 + 16, 1, 2) RUN(15 + 16, 1, 1) RUN(15 + 16, 4, 4) RUN(15 + 16 + 32, 2, 4)
+#define RUNP(R, NWAVE, GRID) { double us = time_graph([&](int i) { hipLaunchKernelGGL((k_gemv_pipe<R, NWAVE>), dim3(GRID), dim3(NWAVE * 64), 0, s, (const uint8_t*)W[i], (const half_t*)A, (const uint16_t*)S[i], C, N); }, nbuf, s); \
+    printf("pipelined R=%d waves/block=%d grid=%4d : %6.3f us  -> %6.1f GB/s\n", R, NWAVE, GRID, us, alg / us * 1e-3); }
+  RUNP(2, 4, 256) RUNP(2, 4, 512) RUNP(2, 4, 768) RUNP(2, 4, 1024) RUNP(1, 4, 512) RUNP(1, 4, 1024) RUNP(1, 4, 2048) RUNP(2, 2, 1024) RUNP(2, 2, 2048) RUNP(2, 8, 256) RUNP(2, 8, 512) RUNP(4, 4, 256) RUNP(4, 4, 512)
   return 0;
 }
