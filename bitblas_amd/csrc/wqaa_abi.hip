@@ -86,7 +86,7 @@ static int dispatch(const wqaa_matmul_desc& d, int m, bool* use_gemm) {
 
 static int matmul_impl(const wqaa_matmul_desc* desc, const void* A, const void* B, const void* LUT,
                        const void* Scale, const void* Zeros, const void* Bias, void* C, int m,
-                       void* stream, void* ev0, void* ev1) {
+                       void* stream, void* ev0, void* ev1, const wqaa_epilogue* epi = nullptr) {
   if (!valid_desc(desc)) return WQAA_ERR_BAD_DESC;
   if (m == 0) return WQAA_OK;  // wrapper/tl.py:277
   if (m < 0 || !A || !B || !C) {
@@ -117,8 +117,12 @@ static int matmul_impl(const wqaa_matmul_desc* desc, const void* A, const void* 
   dispatch(*desc, m, &use_gemm);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   hipEvent_t e0 = reinterpret_cast<hipEvent_t>(ev0), e1 = reinterpret_cast<hipEvent_t>(ev1);
-  int st = use_gemm ? gemm_launch(*desc, A, B, LUT, Scale, Zeros, Bias, C, m, s, e0, e1)
-                    : gemv_launch(*desc, A, B, LUT, Scale, Zeros, Bias, C, m, s, e0, e1);
+  if (epi && (epi->struct_size != (int32_t)sizeof(wqaa_epilogue) || !epi->row_scale)) {
+    set_error(WQAA_ERR_BAD_DESC, "matmul_ex: malformed epilogue descriptor");
+    return WQAA_ERR_BAD_DESC;
+  }
+  int st = use_gemm ? gemm_launch(*desc, A, B, LUT, Scale, Zeros, Bias, C, m, s, e0, e1, epi)
+                    : gemv_launch(*desc, A, B, LUT, Scale, Zeros, Bias, C, m, s, e0, e1, epi);
   if (st == WQAA_OK) g_last_error = WQAA_OK;
   return st;
 }
@@ -179,6 +183,20 @@ int wqaa_matmul_timed(const wqaa_matmul_desc* desc, const void* A, const void* B
                       const void* Scale, const void* Zeros, const void* Bias, void* C, int m,
                       void* stream, void* start_event, void* stop_event) {
   return matmul_impl(desc, A, B, LUT, Scale, Zeros, Bias, C, m, stream, start_event, stop_event);
+}
+
+int wqaa_matmul_ex(const wqaa_matmul_desc* desc, const void* A, const void* B, const void* LUT,
+                   const void* Scale, const void* Zeros, const void* Bias, void* C, int m, void* stream,
+                   const wqaa_epilogue* epilogue) {
+  return matmul_impl(desc, A, B, LUT, Scale, Zeros, Bias, C, m, stream, nullptr, nullptr, epilogue);
+}
+
+int wqaa_act_quant_int8(const void* X, int64_t rows, int K, void* Q, float* S, void* stream) {
+  if (!device_info().ok) {
+    set_error(WQAA_ERR_NO_DEVICE, "no HIP device visible");
+    return WQAA_ERR_NO_DEVICE;
+  }
+  return act_quant_launch(X, rows, K, Q, S, reinterpret_cast<hipStream_t>(stream));
 }
 
 int wqaa_select(const wqaa_matmul_desc* desc, int m, wqaa_plan* plan) {

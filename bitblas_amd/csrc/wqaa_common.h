@@ -45,6 +45,8 @@ struct GemvArgs {
   int fp4_table;    // DK_LUT4: 1 = built-in fp4 table, 0 = caller LUT
   int a_fmt;        // wqaa_dtype of A as stored (fp8 activations are widened while staging)
   int zq_row_bytes; // quantized zeros: bytes per group row (N*bits/8)
+  const float* epi_row;   // fused caller epilogue (wqaa_matmul_ex): out = half(acc / epi_row[m] / epi_tensor)
+  float epi_tensor;
 };
 
 struct LaunchCfg {
@@ -61,13 +63,14 @@ void set_error(int code, const char* fmt, ...);
 int gemv_plan(const wqaa_matmul_desc& d, int m, wqaa_plan* plan);
 int gemv_launch(const wqaa_matmul_desc& d, const void* A, const void* B, const void* LUT,
                 const void* Scale, const void* Zeros, const void* Bias, void* C, int m,
-                hipStream_t stream, hipEvent_t start, hipEvent_t stop);
+                hipStream_t stream, hipEvent_t start, hipEvent_t stop, const wqaa_epilogue* epi = nullptr);
 void gemv_init();
 
 int gemm_plan(const wqaa_matmul_desc& d, int m, wqaa_plan* plan);
 int gemm_launch(const wqaa_matmul_desc& d, const void* A, const void* B, const void* LUT,
                 const void* Scale, const void* Zeros, const void* Bias, void* C, int m,
-                hipStream_t stream, hipEvent_t start, hipEvent_t stop);
+                hipStream_t stream, hipEvent_t start, hipEvent_t stop, const wqaa_epilogue* epi = nullptr);
+int act_quant_launch(const void* X, int64_t rows, int K, void* Q, float* S, hipStream_t stream);
 void gemm_init();
 
 int debug_decode_launch(const void* packed, int64_t nwords, int w_format, int bits, int layout,

@@ -184,7 +184,7 @@ int gemm_plan(const wqaa_matmul_desc& d, int m, wqaa_plan* plan) {
 
 int gemm_launch(const wqaa_matmul_desc& d, const void* A, const void* B, const void* LUT,
                 const void* Scale, const void* Zeros, const void* Bias, void* C, int m,
-                hipStream_t stream, hipEvent_t start, hipEvent_t stop) {
+                hipStream_t stream, hipEvent_t start, hipEvent_t stop, const wqaa_epilogue* epi) {
   GemmChoice c;
   int st = gemm_choose(d, m, &c);
   if (st != WQAA_OK) return st;
@@ -207,6 +207,16 @@ int gemm_launch(const wqaa_matmul_desc& d, const void* A, const void* B, const v
   a.tiles_m = c.tiles_m;
   a.tiles_n = c.tiles_n;
   a.nsteps = d.K / c.ks;
+  a.epi_row = nullptr;
+  a.epi_tensor = 1.f;
+  if (epi) {
+    if (c.at != AT_I8 || d.out_dtype != WQAA_F16) {
+      set_error(WQAA_ERR_UNSUPPORTED, "matmul_ex: the fused epilogue needs int8 activations and float16 output");
+      return WQAA_ERR_UNSUPPORTED;
+    }
+    a.epi_row = epi->row_scale;
+    a.epi_tensor = epi->tensor_scale;
+  }
   a.ksplit = c.ksplit;
   a.ws = nullptr;
   if (c.ksplit > 1) {
@@ -230,7 +240,9 @@ int gemm_launch(const wqaa_matmul_desc& d, const void* A, const void* B, const v
     const dim3 rgrid((unsigned)((quads + 255) / 256)), rblock(256);
     const void* ws = a.ws;
     int M_ = m, N_ = d.N, ks_ = c.ksplit, od = d.out_dtype, hb = d.with_bias;
-    void* rparams[] = {&ws, &C, &Bias, &M_, &N_, &ks_, &od, &hb};
+    const float* er = a.epi_row;
+    float et = a.epi_tensor;
+    void* rparams[] = {&ws, &C, &Bias, &M_, &N_, &ks_, &od, &hb, &er, &et};
     const void* rfn = c.at != AT_I8 ? reinterpret_cast<const void*>(wq_splitk_reduce_kernel<true>)
                                      : reinterpret_cast<const void*>(wq_splitk_reduce_kernel<false>);
     if (start || stop) e = hipExtLaunchKernel(rfn, rgrid, rblock, rparams, 0, stream, nullptr, stop, 0);

@@ -58,6 +58,8 @@ struct GemmArgs {
   int zq_row_bytes;
   int tiles_m, tiles_n;
   int nsteps;         // K / KS
+  const float* epi_row;   // fused caller epilogue (wqaa_matmul_ex): out = half(acc / epi_row[m] / epi_tensor)
+  float epi_tensor;
   int ksplit;         // > 1: workgroup (tile, s) covers k-steps [s*nsteps/ksplit, (s+1)*nsteps/ksplit) and
   void* ws;           //      writes fp32 / int32 partial sums to ws[s][M][N]; a second kernel reduces
 };
@@ -519,7 +521,7 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_kernel(const GemmArgs a) {
       for (int i = 0; i < 4; ++i) {
         if constexpr (F16) bias_f[i] = (float)reinterpret_cast<const half_t*>(a.bias)[nb + i];
         else if constexpr (F8) bias_f[i] = 0.f;   // the reference defines no fp8 bias operand
-        else bias_i[i] = (int)reinterpret_cast<const int8_t*>(a.bias)[nb + i];
+        else if (!a.epi_row) bias_i[i] = (int)reinterpret_cast<const int8_t*>(a.bias)[nb + i];
       }
     }
 #pragma unroll
@@ -543,7 +545,10 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_kernel(const GemmArgs a) {
         }
       } else {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) store_out(a.C, base + i, acc[mf][nf][i], a.out_dtype, a.has_bias != 0, bias_i[i]);
+        for (int i = 0; i < 4; ++i) {
+          if (a.epi_row) store_out_fused(a.C, base + i, acc[mf][nf][i], a.epi_row[m], a.epi_tensor, a.has_bias != 0, a.bias, nb + i);
+          else store_out(a.C, base + i, acc[mf][nf][i], a.out_dtype, a.has_bias != 0, bias_i[i]);
+        }
       }
     }
   }
@@ -554,7 +559,8 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_kernel(const GemmArgs a) {
 // ------------------------------------------------------------------------------------------
 template <bool F16>
 __global__ void __launch_bounds__(256) wq_splitk_reduce_kernel(const void* ws_, void* C, const void* bias, int M, int N,
-                                                               int ksplit, int out_dtype, int has_bias) {
+                                                               int ksplit, int out_dtype, int has_bias,
+                                                               const float* epi_row, float epi_tensor) {
   using acc_t = typename std::conditional<F16, f32x4, i32x4>::type;
   const long quads = (long)M * N / 4;
   const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -582,8 +588,12 @@ __global__ void __launch_bounds__(256) wq_splitk_reduce_kernel(const void* ws_, 
       const float b = has_bias ? (float)reinterpret_cast<const half_t*>(bias)[n + i] : 0.f;
       store_out(C, base + i, sum[i], out_dtype, has_bias != 0, b);
     } else {
-      const int b = has_bias ? (int)reinterpret_cast<const int8_t*>(bias)[n + i] : 0;
-      store_out(C, base + i, sum[i], out_dtype, has_bias != 0, b);
+      if (epi_row) {
+        store_out_fused(C, base + i, sum[i], epi_row[base / N], epi_tensor, has_bias != 0, bias, n + i);
+      } else {
+        const int b = has_bias ? (int)reinterpret_cast<const int8_t*>(bias)[n + i] : 0;
+        store_out(C, base + i, sum[i], out_dtype, has_bias != 0, b);
+      }
     }
   }
 }

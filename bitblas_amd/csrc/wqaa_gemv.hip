@@ -443,8 +443,12 @@ __global__ void __launch_bounds__(1024) wq_gemv_kernel(const GemvArgs a) {
             const float b = a.has_bias ? (float)reinterpret_cast<const half_t*>(a.bias)[n] : 0.f;
             store_out(a.C, (long)(m0 + mi) * a.N + n, tot, a.out_dtype, a.has_bias != 0, b);
           } else {
-            const int b = a.has_bias ? (int)reinterpret_cast<const int8_t*>(a.bias)[n] : 0;
-            store_out(a.C, (long)(m0 + mi) * a.N + n, tot, a.out_dtype, a.has_bias != 0, b);
+            if (a.epi_row) {
+              store_out_fused(a.C, (long)(m0 + mi) * a.N + n, tot, a.epi_row[m0 + mi], a.epi_tensor, a.has_bias != 0, a.bias, n);
+            } else {
+              const int b = a.has_bias ? (int)reinterpret_cast<const int8_t*>(a.bias)[n] : 0;
+              store_out(a.C, (long)(m0 + mi) * a.N + n, tot, a.out_dtype, a.has_bias != 0, b);
+            }
           }
         }
       }
@@ -693,6 +697,8 @@ static void fill_args(const wqaa_matmul_desc& d, const GemvChoice& c, const void
   a->fp4_table = c.fp4_table;
   a->a_fmt = c.a_fmt;
   a->zq_row_bytes = d.N * (c.bits < 8 ? c.bits : 8) / 8;
+  a->epi_row = nullptr;
+  a->epi_tensor = 1.f;
 }
 
 int gemv_plan(const wqaa_matmul_desc& d, int m, wqaa_plan* plan) {
@@ -721,12 +727,20 @@ int gemv_plan(const wqaa_matmul_desc& d, int m, wqaa_plan* plan) {
 
 int gemv_launch(const wqaa_matmul_desc& d, const void* A, const void* B, const void* LUT,
                 const void* Scale, const void* Zeros, const void* Bias, void* C, int m,
-                hipStream_t stream, hipEvent_t start, hipEvent_t stop) {
+                hipStream_t stream, hipEvent_t start, hipEvent_t stop, const wqaa_epilogue* epi) {
   GemvChoice c;
   int st = choose(d, m, &c);
   if (st != WQAA_OK) return st;
   GemvArgs a;
   fill_args(d, c, A, B, LUT, Scale, Zeros, Bias, C, m, &a);
+  if (epi) {
+    if (c.at != AT_I8 || d.out_dtype != WQAA_F16) {
+      set_error(WQAA_ERR_UNSUPPORTED, "matmul_ex: the fused epilogue needs int8 activations and float16 output");
+      return WQAA_ERR_UNSUPPORTED;
+    }
+    a.epi_row = epi->row_scale;
+    a.epi_tensor = epi->tensor_scale;
+  }
   void* params[] = {&a};
   dim3 grid(c.grid_x, c.grid_y, 1), block(c.threads, 1, 1);
   hipError_t e;
@@ -755,6 +769,66 @@ void gemv_init() {
               if (fn) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 
             }
+}
+
+
+// ------------------------------------------------------------------------------------------
+// per-row absmax int8 quantiser - the pre-op of BitNet-style callers (integration/BitNet/
+// utils_quant.py:161-168): s = 127 / clamp(max|x|, 1e-5), q = clamp(round(x * s), -128, 127).
+// One workgroup per row, 16-byte loads, wave DPP max + LDS across waves.  HBM-bound: 3 B per element.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) wq_act_quant_kernel(const half_t* __restrict__ X, int K, int8_t* __restrict__ Q,
+                                                           float* __restrict__ S) {
+  __shared__ float wmax[4];
+  const long row = blockIdx.x;
+  const u32x4* xr = reinterpret_cast<const u32x4*>(X + row * K);
+  const int nvec = K / 8;
+  float mx = 0.f;
+  for (int i = threadIdx.x; i < nvec; i += 256) {
+    const u32x4 v = xr[i];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const half2_t h = as_h2(v[e]);
+      mx = fmaxf(mx, fmaxf(fabsf((float)h[0]), fabsf((float)h[1])));
+    }
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+  if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+  // IEEE-exact quotient (fp64 divide, one rounding): the default fp32 division is not correctly rounded
+  const float s = (float)(127.0 / (double)fmaxf(mx, 1e-5f));
+  if (threadIdx.x == 0) S[row] = s;
+  u32x2* qr = reinterpret_cast<u32x2*>(Q + row * K);
+  for (int i = threadIdx.x; i < nvec; i += 256) {
+    const u32x4 v = xr[i];
+    uint32_t out[2] = {0u, 0u};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const half2_t h = as_h2(v[e >> 1]);
+      float q = rintf((float)h[e & 1] * s);           // torch.round: half to even
+      q = fminf(fmaxf(q, -128.f), 127.f);
+      out[e >> 2] |= ((uint32_t)(int)q & 0xFFu) << (8 * (e & 3));
+    }
+    qr[i] = u32x2{out[0], out[1]};
+  }
+}
+
+int act_quant_launch(const void* X, int64_t rows, int K, void* Q, float* S, hipStream_t stream) {
+  if (!X || !Q || !S || rows < 0 || K <= 0 || K % 8 != 0) {
+    set_error(WQAA_ERR_BAD_DESC, "act_quant: bad arguments (K=%d must be a multiple of 8)", K);
+    return WQAA_ERR_BAD_DESC;
+  }
+  if (rows == 0) return WQAA_OK;
+  hipLaunchKernelGGL(wq_act_quant_kernel, dim3((unsigned)rows), dim3(256), 0, stream, reinterpret_cast<const half_t*>(X), K,
+                     reinterpret_cast<int8_t*>(Q), S);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error(WQAA_ERR_LAUNCH, "act_quant launch failed: %s", hipGetErrorString(e));
+    return WQAA_ERR_LAUNCH;
+  }
+  return WQAA_OK;
 }
 
 // ------------------------------------------------------------------------------------------

@@ -94,6 +94,18 @@ __device__ __forceinline__ void store_out(void* C, long idx, int acc, int out_dt
   }
 }
 
+// caller epilogue of the int8 path (utils_quant.py:170-176): out = input / si; out = out / sw; half; + bias
+__device__ __forceinline__ void store_out_fused(void* C, long idx, int acc, float row_scale, float tensor_scale,
+                                                bool has_bias, const void* bias, int n) {
+  // two IEEE-exact fp32 divisions, like torch's: the quotient is taken in fp64 and rounded once to fp32
+  // (innocuous double rounding for p = 24), since the default fp32 division here is not correctly rounded
+  float v = (float)((double)(float)acc / (double)row_scale);
+  v = (float)((double)v / (double)tensor_scale);
+  half_t h = (half_t)v;
+  if (has_bias) h = h + reinterpret_cast<const half_t*>(bias)[n];
+  reinterpret_cast<half_t*>(C)[idx] = h;
+}
+
 __device__ __forceinline__ half_t bits_to_half(uint32_t b) { return __builtin_bit_cast(half_t, (uint16_t)(b & 0xFFFFu)); }
 
 // ---- runtime part of the decode: signedness is a data value, never a branch ----

@@ -37,7 +37,7 @@ ZEROS_CODE = {"original": Z_ORIGINAL, "rescale": Z_RESCALE, "quantized": Z_QUANT
 
 EXPORTED_SYMBOLS = (
     "init", "wqaa_abi_version", "wqaa_device_count", "wqaa_matmul", "wqaa_matmul_timed",
-    "wqaa_select", "wqaa_pack_weight", "wqaa_unpack_weight", "wqaa_debug_decode",
+    "wqaa_matmul_ex", "wqaa_act_quant_int8", "wqaa_select", "wqaa_pack_weight", "wqaa_unpack_weight", "wqaa_debug_decode",
     "wqaa_last_error", "wqaa_last_error_string",
 )
 
@@ -68,6 +68,13 @@ class Plan(ctypes.Structure):
         d = {k: getattr(self, k) for k, _ in self._fields_ if k != "name"}
         d["name"] = self.name.decode()
         return d
+
+
+class Epilogue(ctypes.Structure):
+    """struct wqaa_epilogue (include/wqaa.h): fused `out / si / sw -> half` of BitNet-style callers."""
+    _fields_ = [("struct_size", ctypes.c_int32), ("reserved", ctypes.c_int32),
+                ("row_scale", ctypes.c_void_p), ("tensor_scale", ctypes.c_float),
+                ("reserved2", ctypes.c_int32)]
 
 
 class WqaaError(RuntimeError):
@@ -104,6 +111,10 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
         lib.wqaa_matmul.argtypes = [dp, vp, vp, vp, vp, vp, vp, vp, ci, vp]
         lib.wqaa_matmul_timed.restype = ci
         lib.wqaa_matmul_timed.argtypes = [dp, vp, vp, vp, vp, vp, vp, vp, ci, vp, vp, vp]
+        lib.wqaa_matmul_ex.restype = ci
+        lib.wqaa_matmul_ex.argtypes = [dp, vp, vp, vp, vp, vp, vp, vp, ci, vp, ctypes.POINTER(Epilogue)]
+        lib.wqaa_act_quant_int8.restype = ci
+        lib.wqaa_act_quant_int8.argtypes = [vp, i64, ci, vp, vp, vp]
         lib.wqaa_select.restype = ci
         lib.wqaa_select.argtypes = [dp, ci, ctypes.POINTER(Plan)]
         lib.wqaa_pack_weight.restype = ci
@@ -227,8 +238,26 @@ class BoundLib:
         if status != OK:
             check(status)
 
+    def run_fused(self, A, B, bias, C, m, stream, row_scale_ptr, tensor_scale):
+        """int8 path with the caller's `out / si / sw -> half (+bias)` folded into the epilogue."""
+        epi = Epilogue()
+        epi.struct_size = ctypes.sizeof(Epilogue)
+        epi.row_scale = row_scale_ptr
+        epi.tensor_scale = float(tensor_scale)
+        status = self._lib.wqaa_matmul_ex(self._desc_ref, A, B, None, None, None, bias, C, m, stream,
+                                          ctypes.byref(epi))
+        if status != OK:
+            check(status)
+
     def plan(self, m: int) -> dict:
         return select(self.desc, m)
+
+
+def act_quant_int8(x, q, s, stream):
+    """x: (rows, K) float16 cuda tensor -> q int8 (rows, K), s float32 (rows,) through the HIP quantiser."""
+    lib = load_library()
+    rows = x.numel() // x.shape[-1]
+    check(lib.wqaa_act_quant_int8(x.data_ptr(), rows, int(x.shape[-1]), q.data_ptr(), s.data_ptr(), stream))
 
 
 def pack_weight(codes, bits: int, layout: int, a_dtype_code: int):

@@ -129,6 +129,28 @@ int wqaa_matmul_timed(const wqaa_matmul_desc* desc, const void* A, const void* B
                       const void* Scale, const void* Zeros, const void* Bias, void* C, int m,
                       void* stream, void* start_event, void* stop_event);
 
+/* ---- callers' pre/post ops of the int8 path, fused at the boundary --
+ * BitNet-style layers (integration/BitNet/utils_quant.py:161-216) wrap the W_int2 x A_int8 matmul in
+ * two tiny torch.compile kernels: a per-token absmax quantiser before it and `out / si / sw -> half`
+ * after it.  `wqaa_act_quant_int8` is the first; `wqaa_matmul_ex` folds the second into the matmul's
+ * epilogue:  C[m, n] = half( (float(acc[m, n]) / row_scale[m]) / tensor_scale ) (+ half Bias[n]).
+ * Only for int8 activations with out_dtype float16; desc.with_bias then means a float16 bias. */
+typedef struct wqaa_epilogue {
+  int32_t struct_size;      /* = sizeof(wqaa_epilogue) */
+  int32_t reserved;
+  const float* row_scale;   /* (m,) si of activation_quant, device pointer */
+  float tensor_scale;       /* sw = 1 / mean|W| */
+  int32_t reserved2;
+} wqaa_epilogue;
+
+int wqaa_matmul_ex(const wqaa_matmul_desc* desc, const void* A, const void* B, const void* LUT,
+                   const void* Scale, const void* Zeros, const void* Bias, void* C, int m, void* stream,
+                   const wqaa_epilogue* epilogue);
+
+/* per-row absmax quantiser (utils_quant.py:161-168): s = 127 / max(|x|, 1e-5), q = clamp(rint(x * s)).
+ * X: (rows, K) float16; Q: (rows, K) int8; S: (rows,) float32.  K % 8 == 0. */
+int wqaa_act_quant_int8(const void* X, int64_t rows, int K, void* Q, float* S, void* stream);
+
 /* tile-config selector: replaces roller + tuner (bitblas/base/roller, bitblas/base/tuner.py) */
 int wqaa_select(const wqaa_matmul_desc* desc, int m, wqaa_plan* plan);
 

@@ -397,6 +397,35 @@ def unpack_qweight(qweight: np.ndarray, bits: int) -> np.ndarray:
 
 
 # --------------------------------------------------------------------------------------
+# BitNet caller ops (integration/BitNet/utils_quant.py:150-176, 205-216)
+# --------------------------------------------------------------------------------------
+def bitnet_weight_quant(weight: np.ndarray):
+    """ternary weights: s = 1 / clamp(mean|W|, 1e-5); round(W * s) clamped to [-1, 1] (:150-155)."""
+    w = np.asarray(weight, dtype=np.float32)
+    s = np.float32(1.0) / np.maximum(np.abs(w).mean(dtype=np.float32), np.float32(1e-5))
+    return np.clip(np.rint(w * s), -1, 1).astype(np.int8), np.float32(s)
+
+
+def bitnet_activation_quant(x: np.ndarray):
+    """per-token int8: s = 127 / clamp(max|x|, 1e-5); round(x * s) clamped to [-128, 127] (:157-164)."""
+    xf = np.asarray(x).astype(np.float32)
+    s = np.float32(127.0) / np.maximum(np.abs(xf).max(axis=-1, keepdims=True), np.float32(1e-5))
+    q = np.clip(np.rint(xf * s), -128, 127).astype(np.int8)
+    return q, s.astype(np.float32)
+
+
+def bitnet_forward(x: np.ndarray, weight_q: np.ndarray, sw, bias=None) -> np.ndarray:
+    """`BitLinearBitBLAS.forward` (:205-216): quantise, exact int matmul -> float32, / si, / sw, half, + bias."""
+    q, si = bitnet_activation_quant(x)
+    acc = (q.astype(np.int64) @ np.asarray(weight_q).astype(np.int64).T).astype(np.float32)
+    out = (acc / si).astype(np.float32)
+    out = (out / np.float32(sw)).astype(np.float32).astype(np.float16)
+    if bias is not None:
+        out = (out + np.asarray(bias).astype(np.float16)).astype(np.float16)
+    return out
+
+
+# --------------------------------------------------------------------------------------
 # tolerance helper with the reference's semantics (bitblas/testing/__init__.py:29-91)
 # --------------------------------------------------------------------------------------
 def count_mismatch(a: np.ndarray, b: np.ndarray, rtol: float, atol: float) -> int:
