@@ -123,8 +123,10 @@ int wqaa_device_count(void);
 int wqaa_matmul(const wqaa_matmul_desc* desc, const void* A, const void* B, const void* LUT,
                 const void* Scale, const void* Zeros, const void* Bias, void* C, int m, void* stream);
 
-/* same launch, bracketed by the kernel's own begin/end timestamps recorded into two hipEvent_t
- * (hipExtLaunchKernel semantics): kernel-only duration without launch gaps, for bench.py */
+/* same launch through hipExtLaunchKernel with start/stop hipEvent_t.  Measured on MI355X / ROCm 7.2: the
+ * event pair reports ~4.0 us for an EMPTY 512-workgroup kernel (rocprofv3 sees 1.4 us for the same kernel
+ * launched plainly), so this is only meaningful for kernels of tens of microseconds; bench.py times
+ * hipGraph replays instead (profiles/r01_floor_bench.txt). */
 int wqaa_matmul_timed(const wqaa_matmul_desc* desc, const void* A, const void* B, const void* LUT,
                       const void* Scale, const void* Zeros, const void* Bias, void* C, int m,
                       void* stream, void* start_event, void* stop_event);
