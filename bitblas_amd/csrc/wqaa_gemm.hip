@@ -28,6 +28,7 @@ static void* workspace(size_t bytes) {
 }
 
 static gemm_fn pick_gemm(int kind, int layout, int at, int mode, int flags, int mf) {
+  if (at == AT_F16 && (flags & FL_BF16)) return layout == LAYOUT_PLAIN ? pick_gemm_bf16(kind, mode, mf) : nullptr;
   if (at == AT_F16) {
     switch (kind) {
       case DK_INT4: return pick_gemm_f16_int4(layout, mode, mf);
@@ -54,6 +55,7 @@ static int gemm_choose(const wqaa_matmul_desc& d, int m, GemmChoice* c) {
   c->flags = 0;
   c->layout = d.w_layout == WQAA_LAYOUT_LOP3 ? LAYOUT_LOP3 : LAYOUT_PLAIN;
   if (a == WQAA_F16) c->at = AT_F16;
+  else if (a == WQAA_BF16) { c->at = AT_F16; c->flags |= FL_BF16; }   // same machine path, bfloat16 arithmetic
   else if (a == WQAA_I8) c->at = AT_I8;
   else if (a == WQAA_E4M3 || a == WQAA_E5M2) {
     c->at = AT_F8;
@@ -79,7 +81,7 @@ static int gemm_choose(const wqaa_matmul_desc& d, int m, GemmChoice* c) {
     case WQAA_W_E5M2: c->kind = DK_E5M2; break;
     case WQAA_W_NATIVE:
       c->kind = a == WQAA_E4M3 ? DK_E4M3 : a == WQAA_E5M2 ? DK_E5M2 : DK_NATIVE;
-      c->bits = a == WQAA_F16 ? 16 : 8;
+      c->bits = (a == WQAA_F16 || a == WQAA_BF16) ? 16 : 8;
       break;
     default: c->kind = -1;
   }
@@ -92,6 +94,10 @@ static int gemm_choose(const wqaa_matmul_desc& d, int m, GemmChoice* c) {
     return WQAA_ERR_UNSUPPORTED;
   }
   if (c->kind == DK_E4M3 && d.strict_reference && c->at == AT_F16) c->flags |= FL_STRICT;
+  if ((c->flags & FL_BF16) && d.with_scaling && d.zeros_mode != WQAA_Z_NONE && d.zeros_mode != WQAA_Z_QUANTIZED) {
+    set_error(WQAA_ERR_UNSUPPORTED, "gemm: bfloat16 activations support scale and quantized zeros only");
+    return WQAA_ERR_UNSUPPORTED;
+  }
   if (c->kind != DK_INT4 && c->kind != DK_INT2 && c->kind != DK_INT1) c->layout = LAYOUT_PLAIN;
   if (c->at != AT_F16 && (d.with_scaling || d.zeros_mode != WQAA_Z_NONE)) {
     set_error(WQAA_ERR_UNSUPPORTED, "gemm: scale/zeros with int8 / fp8 activations are not defined by the reference");
@@ -239,7 +245,7 @@ int gemm_launch(const wqaa_matmul_desc& d, const void* A, const void* B, const v
     const long quads = (long)m * d.N / 4;
     const dim3 rgrid((unsigned)((quads + 255) / 256)), rblock(256);
     const void* ws = a.ws;
-    int M_ = m, N_ = d.N, ks_ = c.ksplit, od = d.out_dtype, hb = d.with_bias;
+    int M_ = m, N_ = d.N, ks_ = c.ksplit, od = d.out_dtype, hb = d.with_bias ? ((c.flags & FL_BF16) ? 2 : 1) : 0;
     const float* er = a.epi_row;
     float et = a.epi_tensor;
     void* rparams[] = {&ws, &C, &Bias, &M_, &N_, &ks_, &od, &hb, &er, &et};
@@ -261,7 +267,7 @@ void gemm_init() {
     for (int layout = 0; layout < 2; ++layout)
       for (int at = 0; at < 3; ++at)
         for (int mode = 0; mode <= MD_ZQ; ++mode)
-          for (int flags : {0, (int)FL_STRICT, (int)FL_ABF8})
+          for (int flags : {0, (int)FL_STRICT, (int)FL_ABF8, (int)FL_BF16})
             for (int mf : {1, 2, 4, 8, 16, 101, 102, 104}) {
               gemm_fn fn = pick_gemm(kind, layout, at, mode, flags, mf);
               if (fn) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

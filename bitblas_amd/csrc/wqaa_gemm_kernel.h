@@ -82,6 +82,7 @@ struct GemmPolicy {
   static_assert(AG >= 1 && AG * 64 * NWAVES_ == 16 * MF_ * 16, "tile / workgroup mismatch");
   static constexpr int BM = 16 * MF, BN = 16 * NFW * NWAVES;
   static constexpr bool STRICT = (FLAGS_ & FL_STRICT) != 0;
+  static constexpr bool BF = (FLAGS_ & FL_BF16) != 0;   // 16-bit float type is bfloat16
   using T = KindTraits<KIND_, AT_>;
   static constexpr int BITS = T::BITS;
   static constexpr int EPW = T::EPW;
@@ -217,6 +218,44 @@ __device__ __forceinline__ void dequant_lane_f16(const uint32_t (&w)[P::WL], hal
         frag[e / 8][(e % 8) / 2] = as_u32(q[i]);
       }
     }
+  }
+}
+
+// bfloat16 flavour: natural order straight away (plain layout), one rounding per element
+template <class P>
+__device__ __forceinline__ void dequant_lane_bf16(const uint32_t (&w)[P::WL], float zf, float s, bool is_signed,
+                                                  uint32_t flip, uint32_t (&frag)[P::NJ][4]) {
+  using T = typename P::T;
+  constexpr int EPW = P::EPW;
+  constexpr bool SC = P::MODE != MD_NONE;
+  if constexpr (T::SUBBYTE) {
+#pragma unroll
+    for (int wi = 0; wi < P::WL; ++wi) {
+      uint32_t pk[EPW / 2];
+      unpack_word_bf16<T::BITS, 1>(w[wi] ^ (P::KIND == DK_INT1 ? flip : 0u), zf, s, SC, pk);
+#pragma unroll
+      for (int i = 0; i < EPW / 2; ++i) {
+        const int e = wi * EPW + 2 * i;
+        frag[e / 8][(e % 8) / 2] = pk[i];
+      }
+    }
+  } else if constexpr (P::KIND == DK_INT8) {
+#pragma unroll
+    for (int wi = 0; wi < P::WL; ++wi) {
+      float v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int b8 = (int)((w[wi] >> (8 * e)) & 0xFFu);
+        v[e] = (float)(is_signed ? (int)(int8_t)b8 : b8) - (P::MODE == MD_ZQ ? zf : 0.f);
+        if (SC) v[e] *= s;
+      }
+      const int e0 = wi * 4;
+      frag[e0 / 8][(e0 % 8) / 2] = cvt_pk_bf16(v[0], v[1]);
+      frag[e0 / 8][(e0 % 8) / 2 + 1] = cvt_pk_bf16(v[2], v[3]);
+    }
+  } else {   // native bf16 weights: 2 per word
+#pragma unroll
+    for (int wi = 0; wi < P::WL; ++wi) frag[(wi * 2) / 8][((wi * 2) % 8) / 2] = w[wi];
   }
 }
 
@@ -403,7 +442,11 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_kernel(const GemmArgs a) {
         }
         const half2_t s2 = MODE != MD_NONE ? splat(bits_to_half(bl.s[nf])) : splat((half_t)1.0f);
         const half2_t z2 = (MODE == MD_ZO || MODE == MD_ZR) ? splat(bits_to_half(bl.z[nf])) : splat((half_t)0.0f);
-        dequant_lane_f16<P>(bl.w[nf], zf, s2, z2, cx, lut, bfrag[nf]);
+        if constexpr (P::BF)
+          dequant_lane_bf16<P>(bl.w[nf], (float)zf, MODE != MD_NONE ? bf16_bits_to_float(bl.s[nf]) : 1.f, a.is_signed != 0,
+                               cx.flip, bfrag[nf]);
+        else
+          dequant_lane_f16<P>(bl.w[nf], zf, s2, z2, cx, lut, bfrag[nf]);
       } else if constexpr (F8) {
         // fp8 weights are MFMA operands as stored: fragment j = the lane's bytes [8j, 8j+8)
 #pragma unroll
@@ -426,8 +469,12 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_kernel(const GemmArgs a) {
         for (int nf = 0; nf < NFW; ++nf) {
           if constexpr (F16) {
             const u32x4 bv = {bfrag[nf][gq][0], bfrag[nf][gq][1], bfrag[nf][gq][2], bfrag[nf][gq][3]};
-            acc[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8_t, bv),
-                                                                __builtin_bit_cast(half8_t, av), acc[mf][nf], 0, 0, 0);
+            if constexpr (P::BF)
+              acc[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, bv),
+                                                                   __builtin_bit_cast(bf16x8_t, av), acc[mf][nf], 0, 0, 0);
+            else
+              acc[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8_t, bv),
+                                                                  __builtin_bit_cast(half8_t, av), acc[mf][nf], 0, 0, 0);
           } else if constexpr (F8) {
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
@@ -519,7 +566,8 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_kernel(const GemmArgs a) {
     if (a.has_bias) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        if constexpr (F16) bias_f[i] = (float)reinterpret_cast<const half_t*>(a.bias)[nb + i];
+        if constexpr (F16 && P::BF) bias_f[i] = bf16_bits_to_float(reinterpret_cast<const uint16_t*>(a.bias)[nb + i]);
+        else if constexpr (F16) bias_f[i] = (float)reinterpret_cast<const half_t*>(a.bias)[nb + i];
         else if constexpr (F8) bias_f[i] = 0.f;   // the reference defines no fp8 bias operand
         else if (!a.epi_row) bias_i[i] = (int)reinterpret_cast<const int8_t*>(a.bias)[nb + i];
       }
@@ -585,7 +633,9 @@ __global__ void __launch_bounds__(256) wq_splitk_reduce_kernel(const void* ws_, 
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     if constexpr (F16) {
-      const float b = has_bias ? (float)reinterpret_cast<const half_t*>(bias)[n + i] : 0.f;
+      float b = 0.f;   // has_bias: 1 = float16 bias, 2 = bfloat16 bias
+      if (has_bias == 2) b = bf16_bits_to_float(reinterpret_cast<const uint16_t*>(bias)[n + i]);
+      else if (has_bias) b = (float)reinterpret_cast<const half_t*>(bias)[n + i];
       store_out(C, base + i, sum[i], out_dtype, has_bias != 0, b);
     } else {
       if (epi_row) {
@@ -604,6 +654,7 @@ typedef void (*gemm_fn)(const GemmArgs);
 gemm_fn pick_gemm_f16_int4(int layout, int mode, int mf);
 gemm_fn pick_gemm_f16_int21(int kind, int layout, int mode, int mf);
 gemm_fn pick_gemm_f16_other(int kind, int mode, int flags, int mf);
+gemm_fn pick_gemm_bf16(int kind, int mode, int mf);
 gemm_fn pick_gemm_i8_f8(int kind, int layout, int at, int flags, int mf);
 
 // mf codes: 1, 2, 4, 8 (16*mf x 128, 4 waves), 16 (256 x 256, 8 waves), 101/102/104 (skinny members)

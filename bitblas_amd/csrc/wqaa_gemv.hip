@@ -70,6 +70,7 @@ struct GemvPolicy {
   static constexpr int D = D_;       // lane chunks per step
   static constexpr bool STRICT = (FLAGS_ & FL_STRICT) != 0;
   static constexpr bool A8 = (FLAGS_ & FL_A8) != 0;
+  static constexpr bool BF = (FLAGS_ & FL_BF16) != 0;   // 16-bit float type is bfloat16
   using T = KindTraits<KIND_, AT_>;
   // words of raw activation data per staging item (one decode unit = G elements)
   static constexpr int AW = (AT_ == AT_I8 || A8) ? T::G / 4 : T::G / 2;
@@ -378,6 +379,35 @@ __global__ void __launch_bounds__(1024) wq_gemv_kernel(const GemvArgs a) {
             const uint32_t zq = (s.z[r] >> ((n % ZPB) * ZB)) & ((1u << ZB) - 1u);
             zf = (half_t)(float)zq;
           }
+          if constexpr (P::BF) {
+            // bf16: integer fields (minus the integer zero point) times the scale, one rounding
+            if constexpr (T::SUBBYTE) {
+              uint32_t pk[G / 2];
+              unpack_word_bf16<T::BITS, 0>(s.w[r][u] ^ (P::KIND == DK_INT1 ? cx.flip : 0u), (float)zf,
+                                           bf16_bits_to_float(s.s[r]), MODE != MD_NONE, pk);
+#pragma unroll
+              for (int i = 0; i < G / 2; ++i) q[r][i] = as_h2(pk[i]);
+            } else {
+#pragma unroll
+              for (int j = 0; j < T::WPU; ++j) {
+                const uint32_t x = s.w[r][u * T::WPU + j];
+                if constexpr (P::KIND == DK_INT8) {
+                  const float sc = bf16_bits_to_float(s.s[r]);
+                  float v[4];
+#pragma unroll
+                  for (int e = 0; e < 4; ++e) {
+                    const int b8 = (int)((x >> (8 * e)) & 0xFFu);
+                    v[e] = (float)(a.is_signed ? (int)(int8_t)b8 : b8) - (MODE == MD_ZQ ? (float)zf : 0.f);
+                    if (MODE != MD_NONE) v[e] *= sc;
+                  }
+                  q[r][2 * j] = as_h2(cvt_pk_bf16(v[0], v[1]));
+                  q[r][2 * j + 1] = as_h2(cvt_pk_bf16(v[2], v[3]));
+                } else {
+                  q[r][j] = as_h2(x);   // native bf16 weights
+                }
+              }
+            }
+          } else {
           decode_unit_f16<P>(s.w[r], u, zf, cx, lut, q[r]);
           if constexpr (MODE == MD_S || MODE == MD_ZQ) {
             const half2_t s2 = splat(bits_to_half(s.s[r]));
@@ -397,6 +427,7 @@ __global__ void __launch_bounds__(1024) wq_gemv_kernel(const GemvArgs a) {
               q[r][i] = t - z2;
             }
           }
+          }  // !BF
         }
 #pragma unroll
         for (int pp = 0; pp < PU; ++pp) {
@@ -406,8 +437,12 @@ __global__ void __launch_bounds__(1024) wq_gemv_kernel(const GemvArgs a) {
 #pragma unroll
             for (int r = 0; r < R; ++r)
 #pragma unroll
-              for (int e = 0; e < 4; ++e)
-                acc[r][mi] = __builtin_amdgcn_fdot2(q[r][pp * 4 + e], as_h2(av[e]), acc[r][mi], false);
+              for (int e = 0; e < 4; ++e) {
+                if constexpr (P::BF)
+                  acc[r][mi] = __builtin_amdgcn_fdot2_f32_bf16(as_bf2(as_u32(q[r][pp * 4 + e])), as_bf2(av[e]), acc[r][mi], false);
+                else
+                  acc[r][mi] = __builtin_amdgcn_fdot2(q[r][pp * 4 + e], as_h2(av[e]), acc[r][mi], false);
+              }
           }
         }
       } else {
@@ -440,7 +475,9 @@ __global__ void __launch_bounds__(1024) wq_gemv_kernel(const GemvArgs a) {
         acc[r][mi] = 0;
         if (lane == 0 && n < a.N && (m0 + mi) < a.m) {
           if constexpr (F16) {
-            const float b = a.has_bias ? (float)reinterpret_cast<const half_t*>(a.bias)[n] : 0.f;
+            float b = 0.f;
+            if (a.has_bias) b = P::BF ? bf16_bits_to_float(reinterpret_cast<const uint16_t*>(a.bias)[n])
+                                     : (float)reinterpret_cast<const half_t*>(a.bias)[n];
             store_out(a.C, (long)(m0 + mi) * a.N + n, tot, a.out_dtype, a.has_bias != 0, b);
           } else {
             if (a.epi_row) {
@@ -513,6 +550,22 @@ static gemv_fn pick_mode_fp(int mode, int mb) {
 }
 
 static gemv_fn pick_kernel(int kind, int layout, int at, int mode, int flags, int mb) {
+  if (at == AT_F16 && (flags & FL_BF16)) {   // bfloat16 activations: NONE / S / ZQ members, plain layout
+    if (mode != MD_NONE && mode != MD_S && mode != MD_ZQ) return nullptr;
+#define WQAA_BF_PICK(K) \
+    (mode == MD_NONE ? pick_mb<K, LAYOUT_PLAIN, AT_F16, MD_NONE, FL_BF16>(mb) \
+     : mode == MD_S  ? pick_mb<K, LAYOUT_PLAIN, AT_F16, MD_S, FL_BF16>(mb)    \
+                     : pick_mb<K, LAYOUT_PLAIN, AT_F16, MD_ZQ, FL_BF16>(mb))
+    switch (kind) {
+      case DK_INT4: return WQAA_BF_PICK(DK_INT4);
+      case DK_INT2: return WQAA_BF_PICK(DK_INT2);
+      case DK_INT1: return WQAA_BF_PICK(DK_INT1);
+      case DK_INT8: return WQAA_BF_PICK(DK_INT8);
+      case DK_NATIVE: return mode == MD_NONE ? pick_mb<DK_NATIVE, LAYOUT_PLAIN, AT_F16, MD_NONE, FL_BF16>(mb) : nullptr;
+    }
+#undef WQAA_BF_PICK
+    return nullptr;
+  }
   if (at == AT_F16) {
     if (flags & FL_A8) {  // dense fp8 x fp8: both operands widened to fp16, fp32 accumulate
       if (mode != MD_NONE) return nullptr;
@@ -561,6 +614,9 @@ static int classify(const wqaa_matmul_desc& d, GemvChoice* c) {
   c->layout = d.w_layout == WQAA_LAYOUT_LOP3 ? LAYOUT_LOP3 : LAYOUT_PLAIN;
   if (a == WQAA_F16) {
     c->at = AT_F16;
+  } else if (a == WQAA_BF16) {
+    c->at = AT_F16;          // same machine path, bfloat16 arithmetic (FL_BF16)
+    c->flags |= FL_BF16;
   } else if (a == WQAA_I8) {
     c->at = AT_I8;
   } else if (a == WQAA_E4M3 || a == WQAA_E5M2) {
@@ -585,7 +641,7 @@ static int classify(const wqaa_matmul_desc& d, GemvChoice* c) {
       if (a == WQAA_E4M3) c->kind = DK_E4M3;
       else if (a == WQAA_E5M2) c->kind = DK_E5M2;
       else c->kind = DK_NATIVE;
-      c->bits = a == WQAA_F16 ? 16 : 8;
+      c->bits = (a == WQAA_F16 || a == WQAA_BF16) ? 16 : 8;
       break;
     default: c->kind = -1;
   }
@@ -602,6 +658,15 @@ static int classify(const wqaa_matmul_desc& d, GemvChoice* c) {
   if (c->at == AT_I8 && (d.with_scaling || d.zeros_mode != WQAA_Z_NONE)) {
     set_error(WQAA_ERR_UNSUPPORTED, "gemv: scale/zeros with int8 activations are not defined by the reference");
     return WQAA_ERR_UNSUPPORTED;
+  }
+  if (c->flags & FL_BF16) {
+    const bool kind_ok = c->kind == DK_INT4 || c->kind == DK_INT2 || c->kind == DK_INT1 || c->kind == DK_INT8 || c->kind == DK_NATIVE;
+    const bool zeros_ok = d.zeros_mode == WQAA_Z_NONE || d.zeros_mode == WQAA_Z_QUANTIZED || !d.with_scaling;
+    if (!kind_ok || !zeros_ok || c->layout != LAYOUT_PLAIN) {
+      set_error(WQAA_ERR_UNSUPPORTED, "gemv: bfloat16 activations support plain-layout integer / bf16 weights with "
+                "scale and quantized zeros only");
+      return WQAA_ERR_UNSUPPORTED;
+    }
   }
   // zero points only act together with a scale (matmul_dequantize_impl.py:435-449)
   c->mode = !d.with_scaling ? MD_NONE
@@ -763,7 +828,7 @@ void gemv_init() {
     for (int layout = 0; layout < 2; ++layout)
       for (int at = 0; at < 2; ++at)
         for (int mode = 0; mode <= MD_ZQ; ++mode)
-          for (int flags = 0; flags < 4; ++flags)
+          for (int flags : {0, 1, 2, 3, (int)FL_BF16})
             for (int mb : kBatchTiles) {
               gemv_fn fn = pick_kernel(kind, layout, at, mode, flags, mb);
               if (fn) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

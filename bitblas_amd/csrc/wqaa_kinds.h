@@ -12,7 +12,7 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 enum : int { AT_F16 = 0, AT_I8 = 1, AT_F8 = 2 };   // activation operand type of the kernel
 // dequant arithmetic (matmul_dequantize_impl.py:435-449)
 enum : int { MD_NONE = 0, MD_S = 1, MD_ZO = 2, MD_ZR = 3, MD_ZQ = 4 };
-enum : int { FL_STRICT = 1, FL_A8 = 2, FL_ABF8 = 4 };  // e4m3 reference bit trick; activations stored as fp8 (GEMV); fp8 MFMA activations are e5m2
+enum : int { FL_STRICT = 1, FL_A8 = 2, FL_ABF8 = 4, FL_BF16 = 8 };   // FL_BF16: the 16-bit float type is bfloat16  // e4m3 reference bit trick; activations stored as fp8 (GEMV); fp8 MFMA activations are e5m2
 
 constexpr int cmax(int a, int b) { return a > b ? a : b; }
 
@@ -107,6 +107,36 @@ __device__ __forceinline__ void store_out_fused(void* C, long idx, int acc, floa
 }
 
 __device__ __forceinline__ half_t bits_to_half(uint32_t b) { return __builtin_bit_cast(half_t, (uint16_t)(b & 0xFFFFu)); }
+
+// ---- bfloat16 flavour of the 16-bit float path (A_dtype = bfloat16, test_general_matmul_bf16.py) ----
+// Integer fields are exact in bf16; `w * Scale` is one fp32 multiply rounded to bf16 by
+// v_cvt_pk_bf16_f32 (round to nearest even) - the TE definition's single rounding in A_dtype.
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ bf16x2_t as_bf2(uint32_t u) { return __builtin_bit_cast(bf16x2_t, u); }
+__device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {
+  uint32_t r;
+  asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+  return r;
+}
+__device__ __forceinline__ float bf16_bits_to_float(uint32_t b) { return __builtin_bit_cast(float, (b & 0xFFFFu) << 16); }
+
+// fields of one 32-bit word -> EPW/2 packed bf16 pairs.  PAIR_ORDER selects which two fields share a
+// register: 0 = F16Unpack's extraction order (field i, field i + EPW/2) used by the GEMV's permuted LDS
+// tile, 1 = natural order (2i, 2i+1) used by the MFMA fragments.  Plain layout only (bf16 has no LOP3).
+template <int BITS, int PAIR_ORDER>
+__device__ __forceinline__ void unpack_word_bf16(uint32_t w, float zf, float s, bool scale, uint32_t (&out)[32 / BITS / 2]) {
+  constexpr int EPW = 32 / BITS, NPAIR = EPW / 2;
+#pragma unroll
+  for (int i = 0; i < NPAIR; ++i) {
+    const int f0 = PAIR_ORDER ? 2 * i : i, f1 = PAIR_ORDER ? 2 * i + 1 : i + NPAIR;
+    float a = (float)__builtin_amdgcn_ubfe(w, f0 * BITS, BITS) - zf;
+    float b = (float)__builtin_amdgcn_ubfe(w, f1 * BITS, BITS) - zf;
+    if (scale) { a *= s; b *= s; }
+    out[i] = cvt_pk_bf16(a, b);
+  }
+}
 
 // ---- runtime part of the decode: signedness is a data value, never a branch ----
 struct DecodeCtx {

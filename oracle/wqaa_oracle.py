@@ -251,6 +251,16 @@ def f16(x: np.ndarray) -> np.ndarray:
     return np.asarray(x).astype(np.float16)
 
 
+def bf16_round(x: np.ndarray) -> np.ndarray:
+    """float32 -> nearest bfloat16 (ties to even), returned as float32 (what torch.bfloat16 arithmetic does
+    after every operation; the TE definition materialises B_decode in A_dtype)."""
+    u = np.ascontiguousarray(np.asarray(x, dtype=np.float32)).view(np.uint32).astype(np.uint64)
+    u = (u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000
+    return u.astype(np.uint32).view(np.float32)
+
+
+
+
 def dequantize_weight(codes: np.ndarray, source_format: str, bit: int, *, K: int | None = None,
                       scale=None, zeros=None, zeros_mode: str = "original", group_size: int = -1,
                       a_dtype: str = "float16", strict_reference: bool = True, lut=None) -> np.ndarray:
@@ -270,7 +280,9 @@ def dequantize_weight(codes: np.ndarray, source_format: str, bit: int, *, K: int
     if a_dtype == "int8":
         assert scale is None and zeros is None
         return decode_codes(codes, source_format, bit, strict_reference, lut).astype(np.int64)
-    ft = {"float16": np.float16, "float32": np.float32, "bfloat16": np.float32}[a_dtype]
+    if a_dtype == "bfloat16":
+        return _dequantize_weight_bf16(codes, source_format, bit, K, scale, zeros, zeros_mode, g, gi, lut)
+    ft = {"float16": np.float16, "float32": np.float32}[a_dtype]
     with_zeros = zeros is not None
     if with_zeros and zeros_mode == "quantized":
         zq = general_decompress(np.asarray(zeros), bit).astype(np.int64)  # (K/g, N)
@@ -291,6 +303,29 @@ def dequantize_weight(codes: np.ndarray, source_format: str, bit: int, *, K: int
         return ((w * s).astype(ft) - z).astype(ft)
     if zeros_mode == "quantized":
         return (w * s).astype(ft)
+    raise ValueError(zeros_mode)
+
+
+def _dequantize_weight_bf16(codes, source_format, bit, K, scale, zeros, zeros_mode, g, gi, lut):
+    """bfloat16 flavour of dequantize_weight: every operation rounds to bf16 (values held as float32).
+    Scale / Zeros arrive as float32 arrays holding bf16-representable values."""
+    with_zeros = zeros is not None
+    if with_zeros and zeros_mode == "quantized":
+        zq = general_decompress(np.asarray(zeros), bit).astype(np.int64)
+        u = np.asarray(codes).astype(np.int64) & ((1 << bit) - 1)
+        w = bf16_round((u - zq[gi, :].T).astype(np.float32))
+    else:
+        w = bf16_round(decode_codes(codes, source_format, bit, True, lut).astype(np.float32))
+    if scale is None:
+        return w
+    sc = bf16_round(np.asarray(scale, dtype=np.float32))[:, gi]
+    if not with_zeros or zeros_mode == "quantized":
+        return bf16_round(w * sc)
+    z = bf16_round(np.asarray(zeros, dtype=np.float32))[:, gi]
+    if zeros_mode == "original":
+        return bf16_round(bf16_round(w - z) * sc)
+    if zeros_mode == "rescale":
+        return bf16_round(bf16_round(w * sc) - z)
     raise ValueError(zeros_mode)
 
 

@@ -66,7 +66,7 @@ def test_selector_answers_without_gpu():
 
 def test_unsupported_is_loud_not_silent():
     with pytest.raises(wlib.WqaaError):
-        wlib.select(wlib.make_desc(N=64, K=64, a_dtype=wlib.BF16, w_format=wlib.W_INT, w_bits=4,
+        wlib.select(wlib.make_desc(N=64, K=64, a_dtype=wlib.F32, w_format=wlib.W_INT, w_bits=4,
                                    out_dtype=wlib.F16), 1)
 
 

@@ -193,3 +193,62 @@ def test_dense_fp8_gemv_matches_gemm():
                                out_dtype="float32")
     assert_fp_parity(full, want, rtol=1e-4, atol_frac=1e-4)
     assert_fp_parity(one, want[:1], rtol=1e-4, atol_frac=1e-4)
+
+
+def _bf16_case(M, N, K, W_dtype, g, with_scaling, zeros_mode=None, seed=0):
+    """A_dtype = bfloat16 case builder (reference: testing/python/operators/test_general_matmul_bf16.py:56-178)."""
+    import bitblas_amd as bitblas
+    rng = np.random.default_rng(seed)
+    src, bit = bitblas.Matmul.BITBLAS_TRICK_DTYPE_MAP[W_dtype]
+    A = (torch.from_numpy(rng.random((M, K), dtype=np.float32)) - 0.5).to(torch.bfloat16)
+    if src == "uint":
+        w_user = rng.integers(0, 1 << bit, size=(N, K)).astype(np.int8) if bit < 8 else rng.integers(0, 128, size=(N, K)).astype(np.int8)
+        codes = w_user
+    else:
+        maxq = 1 << (bit - 1)
+        w_user = rng.integers(-maxq, maxq, size=(N, K)).astype(np.int8)
+        codes = (w_user + maxq).astype(np.int8) if bit < 8 else w_user
+    gg = K if g == -1 else g
+    scale = zeros = None
+    if with_scaling:
+        scale = torch.from_numpy(rng.standard_normal((N, K // gg)).astype(np.float32) * 0.05).to(torch.bfloat16)
+    if zeros_mode == "quantized":
+        zint = np.clip((1 << (bit - 1)) + rng.integers(-2, 2, size=(K // gg, N)), 0, (1 << bit) - 1).astype(np.int8)
+        zeros = oracle.general_compress(zint, bit)
+    cfg = bitblas.MatmulConfig(M=M, N=N, K=K, A_dtype="bfloat16", W_dtype=W_dtype, accum_dtype="float32", out_dtype="float32",
+                               group_size=g, with_scaling=with_scaling, with_zeros=zeros is not None,
+                               zeros_mode=zeros_mode or "original")
+    mm = bitblas.Matmul(cfg, enable_tuning=False)
+    assert cfg.fast_decoding is False                 # the reference's legalisation: no LOP3 layout for bf16
+    Wt = mm.weight_transform(torch.from_numpy(codes)).cuda() if mm.weight_transform is not None else torch.from_numpy(codes).cuda()
+    out = mm(A.cuda(), Wt, scale=None if scale is None else scale.cuda(),
+             zeros=None if zeros is None else torch.from_numpy(zeros).cuda()).cpu().numpy()
+    want = oracle.matmul_dequant(A.float().numpy(), codes, source_format=src, bit=bit,
+                                 scale=None if scale is None else scale.float().numpy(), zeros=zeros,
+                                 zeros_mode=zeros_mode or "original", group_size=gg, a_dtype="bfloat16", out_dtype="float32")
+    return out, want, mm
+
+
+@pytest.mark.parametrize("M", [1, 3, 64, 1024])
+@pytest.mark.parametrize("W_dtype,g,ws,zm", [("uint4", -1, False, None), ("uint4", 32, True, None), ("int4", 128, True, None),
+                                             ("uint4", 128, True, "quantized"), ("uint2", 128, True, None), ("int8", 128, True, None)])
+def test_bf16_activations(M, W_dtype, g, ws, zm):
+    """reference cases test_general_matmul_bf16.py:170-178 (M in {1, 1024}, uint4, +-scale g=32) and neighbours."""
+    if W_dtype == "uint4" and g == 32 and M >= 8:
+        g = 32   # GEMM lane chunk is 32 elements: g = 32 is legal
+    out, want, mm = _bf16_case(M, 512, 1024, W_dtype, g, ws, zm, seed=M)
+    assert mm.plans[M]["kernel_family"] == (1 if M < 8 else 2)
+    assert_fp_parity(out, want, rtol=1e-5, atol_frac=1e-5)
+
+
+def test_bf16_dense():
+    import bitblas_amd as bitblas
+    rng = np.random.default_rng(1)
+    for M in (2, 96):
+        A = (torch.from_numpy(rng.random((M, 512), dtype=np.float32)) - 0.5).to(torch.bfloat16)
+        W = (torch.from_numpy(rng.random((256, 512), dtype=np.float32)) - 0.5).to(torch.bfloat16)
+        mm = bitblas.Matmul(bitblas.MatmulConfig(M=M, N=256, K=512, A_dtype="bfloat16", W_dtype="bfloat16", accum_dtype="float32",
+                                                 out_dtype="float32"), enable_tuning=False)
+        out = mm(A.cuda(), W.cuda()).cpu().numpy()
+        want = (A.double().numpy() @ W.double().numpy().T).astype(np.float32)
+        assert_fp_parity(out, want, rtol=1e-5, atol_frac=1e-5)
