@@ -69,18 +69,19 @@ static bool valid_desc(const wqaa_matmul_desc* d) {
 // member exists for the dtype pair, else the GEMV family iterates over batch tiles of 8 rows.
 static int dispatch(const wqaa_matmul_desc& d, int m, bool* use_gemm) {
   *use_gemm = false;
+  wqaa_plan p;
+  const int saved = g_last_error;
+  char saved_msg[sizeof(g_last_error_msg)];
+  memcpy(saved_msg, g_last_error_msg, sizeof(saved_msg));
   if (m >= 8) {
-    wqaa_plan p;
-    const int saved = g_last_error;
-    char saved_msg[sizeof(g_last_error_msg)];
-    memcpy(saved_msg, g_last_error_msg, sizeof(saved_msg));
-    if (gemm_plan(d, m, &p) == WQAA_OK) {
-      *use_gemm = true;
-    } else {
-      g_last_error = saved;
-      memcpy(g_last_error_msg, saved_msg, sizeof(saved_msg));
-    }
+    if (gemm_plan(d, m, &p) == WQAA_OK) *use_gemm = true;
+  } else if (gemv_plan(d, m, &p) != WQAA_OK && gemm_plan(d, m, &p) == WQAA_OK) {
+    // the GEMV family refuses this config (e.g. groups smaller than its 16-byte lane chunk) but the
+    // MFMA family's skinny member covers it: correct first, the selector's preference second
+    *use_gemm = true;
   }
+  g_last_error = saved;
+  memcpy(g_last_error_msg, saved_msg, sizeof(saved_msg));
   return WQAA_OK;
 }
 

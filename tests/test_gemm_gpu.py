@@ -252,3 +252,13 @@ def test_bf16_dense():
         out = mm(A.cuda(), W.cuda()).cpu().numpy()
         want = (A.double().numpy() @ W.double().numpy().T).astype(np.float32)
         assert_fp_parity(out, want, rtol=1e-5, atol_frac=1e-5)
+
+
+@pytest.mark.parametrize("M", [1, 5])
+def test_small_groups_fall_through_to_the_mfma_family(M):
+    """uint2 with group_size 32: below the GEMV's 64-element lane chunk, inside the GEMM's 32-element one."""
+    case = make_case(M, 256, 512, W_dtype="uint2", group_size=32, with_scaling=True, with_zeros=True, zeros_mode="original",
+                     scale_mul=0.05, seed=M)
+    got, mm = hip_output(case)
+    assert mm.plans[M]["kernel_family"] == 2
+    assert_fp_parity(got, oracle_output(case))
