@@ -63,7 +63,7 @@ __device__ __forceinline__ int wave_sum(int v) {
 // ------------------------------------------------------------------------------------------
 // policy
 // ------------------------------------------------------------------------------------------
-template <int KIND_, int LAYOUT_, int AT_, int MB_, int MODE_, int FLAGS_, int R_ = 2, int D_ = 2>
+template <int KIND_, int LAYOUT_, int AT_, int MB_, int MODE_, int FLAGS_, int R_ = 2, int D_ = 2, bool AD_ = false>
 struct GemvPolicy {
   static constexpr int KIND = KIND_, LAYOUT = LAYOUT_, AT = AT_, MB = MB_, MODE = MODE_, FLAGS = FLAGS_;
   static constexpr int R = R_;       // weight rows per wave per step
@@ -71,6 +71,13 @@ struct GemvPolicy {
   static constexpr bool STRICT = (FLAGS_ & FL_STRICT) != 0;
   static constexpr bool A8 = (FLAGS_ & FL_A8) != 0;
   static constexpr bool BF = (FLAGS_ & FL_BF16) != 0;   // 16-bit float type is bfloat16
+  // AD ("activations direct") members, M = 1 and K within one step (K <= D * 64 * E): every lane
+  // reads its activation slice straight from global memory (L2-resident) into registers, once, and
+  // keeps it for all the rows its wave visits: no LDS tile, no staging pass, no barrier.  Measured
+  // against the LDS-staged form: 4096x4096 4.25 -> 4.11 us, 1024x1024 3.29 -> 2.81 us.  For longer K
+  // the slice would have to be re-read every step (64 B of A per 32 B of weights through the same
+  // texture path: 8192x28672 29.7 -> 30.5 us), so those and all batch tiles > 1 keep the LDS tile.
+  static constexpr bool AD = AD_ && MB_ == 1 && !A8;
   using T = KindTraits<KIND_, AT_>;
   // words of raw activation data per staging item (one decode unit = G elements)
   static constexpr int AW = (AT_ == AT_I8 || A8) ? T::G / 4 : T::G / 2;
@@ -83,7 +90,55 @@ struct Stage {
   u32x4 w[P::R];
   uint32_t s[P::R];  // scale bits (low 16)
   uint32_t z[P::R];  // zero bits (low 16) / raw qzeros byte
+  uint32_t araw[P::AD ? P::T::UNITS * P::AW : 1];   // AD: the lane's activation slice, natural order
+  bool avalid;
 };
+
+// AD members: activation piece `pp` of unit `u` in the order the unpack produces, built from the raw
+// natural-order words with compile-time v_perm selectors (nothing for layouts whose order is natural)
+template <class P, int PP, int Eo>
+__device__ __forceinline__ uint32_t a_piece_word(const uint32_t* raw /* AW words of the unit */) {
+  using T = typename P::T;
+  if constexpr (P::AT == AT_F16) {
+    constexpr int sa = T::src_elem(P::LAYOUT, PP * T::PE + 2 * Eo), sb = T::src_elem(P::LAYOUT, PP * T::PE + 2 * Eo + 1);
+    if constexpr (sb == sa + 1 && (sa % 2) == 0) {
+      return raw[sa / 2];
+    } else {
+      constexpr uint32_t sel = ((uint32_t)(4 + 2 * (sb % 2) + 1) << 24) | ((uint32_t)(4 + 2 * (sb % 2)) << 16) |
+                               ((uint32_t)(2 * (sa % 2) + 1) << 8) | (uint32_t)(2 * (sa % 2));
+      return __builtin_amdgcn_perm(raw[sb / 2], raw[sa / 2], sel);
+    }
+  } else {
+    constexpr int s0 = T::src_elem(P::LAYOUT, PP * T::PE + 4 * Eo), s1 = T::src_elem(P::LAYOUT, PP * T::PE + 4 * Eo + 1),
+                  s2 = T::src_elem(P::LAYOUT, PP * T::PE + 4 * Eo + 2), s3 = T::src_elem(P::LAYOUT, PP * T::PE + 4 * Eo + 3);
+    if constexpr (s1 == s0 + 1 && s2 == s0 + 2 && s3 == s0 + 3 && (s0 % 4) == 0) {
+      return raw[s0 / 4];
+    } else {
+      constexpr uint32_t selA = 0x0C0C0000u | ((uint32_t)(4 + (s1 % 4)) << 8) | (uint32_t)(s0 % 4);
+      constexpr uint32_t selB = 0x0C0C0000u | ((uint32_t)(4 + (s3 % 4)) << 8) | (uint32_t)(s2 % 4);
+      const uint32_t lo = __builtin_amdgcn_perm(raw[s1 / 4], raw[s0 / 4], selA);
+      const uint32_t hi = __builtin_amdgcn_perm(raw[s3 / 4], raw[s2 / 4], selB);
+      return lo | (hi << 16);
+    }
+  }
+}
+template <class P, int PP>
+__device__ __forceinline__ u32x4 a_piece(const uint32_t* raw, bool valid) {
+  u32x4 v = {a_piece_word<P, PP, 0>(raw), a_piece_word<P, PP, 1>(raw), a_piece_word<P, PP, 2>(raw), a_piece_word<P, PP, 3>(raw)};
+  if (!valid) v = u32x4{0u, 0u, 0u, 0u};
+  return v;
+}
+template <class P>
+__device__ __forceinline__ u32x4 a_piece_rt(const uint32_t* raw, int pp, bool valid) {
+  // pp is a fully unrolled loop index in the callers; the switch folds away
+  switch (pp) {
+    case 0: return a_piece<P, 0>(raw, valid);
+    case 1: if constexpr (P::T::PU > 1) return a_piece<P, 1>(raw, valid); break;
+    case 2: if constexpr (P::T::PU > 2) return a_piece<P, 2>(raw, valid); break;
+    case 3: if constexpr (P::T::PU > 3) return a_piece<P, 3>(raw, valid); break;
+  }
+  return u32x4{0u, 0u, 0u, 0u};
+}
 
 
 __device__ __forceinline__ half_t fp8_to_half(uint8_t v, bool e5m2) {
@@ -289,8 +344,9 @@ __global__ void __launch_bounds__(1024) wq_gemv_kernel(const GemvArgs a) {
   constexpr int ZB = T::SUBBYTE ? T::BITS : 8;   // quantized zeros field width
   constexpr int ZPB = 8 / ZB;
 
-  // ---- activations: tiles larger than NA items/thread go through a plain loop first ----
-  const int total_items = MB * ncp * 64 * UNITS;
+  // ---- activations (batch tiles > 1): tiles larger than NA items/thread go through a plain loop first ----
+  constexpr bool AD = P::AD;
+  const int total_items = AD ? 0 : MB * ncp * 64 * UNITS;
   for (int idx = NA * nthreads + tid; idx < total_items; idx += nthreads) {
     AItem<P> it;
     a_item_load<P>(a, m0, idx, it);
@@ -299,19 +355,34 @@ __global__ void __launch_bounds__(1024) wq_gemv_kernel(const GemvArgs a) {
   // the first NA items per thread: loads now (ahead of the weight stream), LDS writes after the
   // first weight step has been issued
   AItem<P> ahead[NA];
+  if constexpr (!AD) {
 #pragma unroll
-  for (int j = 0; j < NA; ++j) {
-    const int idx = j * nthreads + tid;
-    if (j * nthreads < total_items)   // wave-uniform: whole rounds beyond the tile are skipped
-      a_item_load<P>(a, m0, idx < total_items ? idx : 0, ahead[j]);
+    for (int j = 0; j < NA; ++j) {
+      const int idx = j * nthreads + tid;
+      if (j * nthreads < total_items)   // wave-uniform: whole rounds beyond the tile are skipped
+        a_item_load<P>(a, m0, idx < total_items ? idx : 0, ahead[j]);
+    }
   }
+  const uint8_t* Arow = reinterpret_cast<const uint8_t*>(a.A) + (long)m0 * a.K * (F16 ? 2 : 1);
 
   // one step: D lane chunks x R rows, every load unconditional
-  auto issue = [&](Stage<P> (&st)[D], int rg, int c0) {
+  auto issue = [&](Stage<P> (&st)[D], int rg, int c0, bool load_a) {
 #pragma unroll
     for (int d = 0; d < D; ++d) {
       int chunk = (c0 + d) * 64 + lane;
+      if constexpr (AD) st[d].avalid = chunk < cpr;
       chunk = chunk < cpr ? chunk : 0;       // clamped lanes meet zero activations
+      if (AD && load_a) {
+        // the lane's E activations: UNITS loads of AW words, issued ahead of this chunk's weights
+        constexpr int UB = T::G * (F16 ? 2 : 1);   // bytes per unit
+#pragma unroll
+        for (int u = 0; u < UNITS; ++u) {
+          uint32_t t[P::AW];
+          load_words<P::AW>(Arow + (long)chunk * (UNITS * UB) + u * UB, t);
+#pragma unroll
+          for (int q = 0; q < P::AW; ++q) st[d].araw[u * P::AW + q] = t[q];
+        }
+      }
       // group of this lane chunk: chunk / (g / E), as a shift or a 32x32->hi multiply by ceil(2^32 / d)
       // (exact for chunk, d < 2^16), selected without a branch
       int gi = 0;
@@ -332,12 +403,14 @@ __global__ void __launch_bounds__(1024) wq_gemv_kernel(const GemvArgs a) {
   Stage<P> st[D];
   int rg = wg;
   const bool have_work = rg < n_rg;
-  issue(st, have_work ? rg : n_rg - 1, 0);
+  issue(st, have_work ? rg : n_rg - 1, 0, true);
 
+  if constexpr (!AD) {
 #pragma unroll
-  for (int j = 0; j < NA; ++j) {
-    const int idx = j * nthreads + tid;
-    if (idx < total_items) a_item_store<P>(a, ncp, idx, ahead[j], a_lds);
+    for (int j = 0; j < NA; ++j) {
+      const int idx = j * nthreads + tid;
+      if (idx < total_items) a_item_store<P>(a, ncp, idx, ahead[j], a_lds);
+    }
   }
 
   Lut16 lut;
@@ -348,7 +421,7 @@ __global__ void __launch_bounds__(1024) wq_gemv_kernel(const GemvArgs a) {
       lut = make_lut16(reinterpret_cast<const half_t*>(a.lut));
     }
   }
-  __syncthreads();
+  if constexpr (!AD) __syncthreads();
 
   DecodeCtx cx;
   cx.zf = (F16 && a.is_signed && T::SUBBYTE) ? (half_t)(float)(1 << (T::BITS - 1)) : (half_t)0.0f;
@@ -365,6 +438,7 @@ __global__ void __launch_bounds__(1024) wq_gemv_kernel(const GemvArgs a) {
 #pragma unroll
     for (int mi = 0; mi < MB; ++mi) acc[r][mi] = 0;
 
+  const bool need_mask = ncp * 64 != cpr;    // some lanes of the last step lie beyond K
   auto consume = [&](const Stage<P>& s, int c, int rg_now) {
 #pragma unroll
     for (int u = 0; u < UNITS; ++u) {
@@ -433,7 +507,13 @@ __global__ void __launch_bounds__(1024) wq_gemv_kernel(const GemvArgs a) {
         for (int pp = 0; pp < PU; ++pp) {
 #pragma unroll
           for (int mi = 0; mi < MB; ++mi) {
-            const u32x4 av = a_lds[((long)(mi * ncp + c) * PIECES + u * PU + pp) * 64 + lane];
+            u32x4 av;
+            if constexpr (AD) {
+              av = a_piece_rt<P>(s.araw + u * P::AW, pp, true);
+              if (need_mask && !s.avalid) av = u32x4{0u, 0u, 0u, 0u};   // wave-uniform outer test: free when K has no ragged chunk
+            } else {
+              av = a_lds[((long)(mi * ncp + c) * PIECES + u * PU + pp) * 64 + lane];
+            }
 #pragma unroll
             for (int r = 0; r < R; ++r)
 #pragma unroll
@@ -453,7 +533,13 @@ __global__ void __launch_bounds__(1024) wq_gemv_kernel(const GemvArgs a) {
         for (int pp = 0; pp < PU; ++pp) {
 #pragma unroll
           for (int mi = 0; mi < MB; ++mi) {
-            const u32x4 av = a_lds[((long)(mi * ncp + c) * PIECES + u * PU + pp) * 64 + lane];
+            u32x4 av;
+            if constexpr (AD) {
+              av = a_piece_rt<P>(s.araw + u * P::AW, pp, true);
+              if (need_mask && !s.avalid) av = u32x4{0u, 0u, 0u, 0u};   // wave-uniform outer test: free when K has no ragged chunk
+            } else {
+              av = a_lds[((long)(mi * ncp + c) * PIECES + u * PU + pp) * 64 + lane];
+            }
 #pragma unroll
             for (int r = 0; r < R; ++r)
 #pragma unroll
@@ -506,7 +592,7 @@ __global__ void __launch_bounds__(1024) wq_gemv_kernel(const GemvArgs a) {
       rg += total_waves;
       if (rg >= n_rg) break;
     }
-    issue(st, rg, c0);
+    issue(st, rg, c0, false);   // AD members: K fits one step, the activation registers stay as loaded
   }
 }
 
@@ -515,12 +601,14 @@ __global__ void __launch_bounds__(1024) wq_gemv_kernel(const GemvArgs a) {
 // ------------------------------------------------------------------------------------------
 typedef void (*gemv_fn)(const GemvArgs);
 
-static const int kBatchTiles[] = {1, 2, 4};
+static constexpr int kDirectTile = 101;   // pick_mb code of the M = 1 "activations direct" member
+static const int kBatchTiles[] = {1, kDirectTile, 2, 4};
 
 template <int KIND, int LAYOUT, int AT, int MODE, int FLAGS>
 static gemv_fn pick_mb(int mb) {
   switch (mb) {
     case 1: return wq_gemv_kernel<GemvPolicy<KIND, LAYOUT, AT, 1, MODE, FLAGS>>;
+    case kDirectTile: return wq_gemv_kernel<GemvPolicy<KIND, LAYOUT, AT, 1, MODE, FLAGS, 2, 2, true>>;
     case 2: return wq_gemv_kernel<GemvPolicy<KIND, LAYOUT, AT, 2, MODE, FLAGS>>;
     case 4: return wq_gemv_kernel<GemvPolicy<KIND, LAYOUT, AT, 4, MODE, FLAGS>>;
     default: return nullptr;
@@ -704,16 +792,23 @@ static int choose(const wqaa_matmul_desc& d, int m, GemvChoice* c) {
   c->R = 2;
   c->D = 2;
   c->variant = 0;
-  c->fn = pick_kernel(c->kind, c->layout, c->at, c->mode, c->flags, mb);
+  c->ncp = (c->nc + c->D - 1) / c->D * c->D;
+  // K within one step: the M = 1 member that keeps its activation slice in registers
+  // and few enough waves per CU that the redundant per-wave reads of A stay cheap (same-box A/B, int4:
+  // 1024 rows -4 %, 2048 -3 %, 4096 -2.5 %, 11008 +3 %)
+  const int cus0 = device_info().ok ? device_info().cus : 256;
+  const bool direct = mb == 1 && !(c->flags & FL_A8) && c->ncp == c->D && (d.N + c->R - 1) / c->R <= 10 * cus0 &&
+                      !getenv("WQAA_GEMV_NO_DIRECT");
+  c->fn = pick_kernel(c->kind, c->layout, c->at, c->mode, c->flags, direct ? kDirectTile : mb);
   if (!c->fn) {
     set_error(WQAA_ERR_UNSUPPORTED, "gemv: no kernel for kind=%d layout=%d at=%d mode=%d flags=%d", c->kind,
               c->layout, c->at, c->mode, c->flags);
     return WQAA_ERR_UNSUPPORTED;
   }
   const int cus = device_info().ok ? device_info().cus : 256;
-  c->ncp = (c->nc + c->D - 1) / c->D * c->D;
   const long kpad = (long)c->ncp * 64 * c->E;
   c->lds = (int)(mb * kpad * (c->at == AT_F16 ? 2 : 1));
+  if (direct) { c->lds = 0; c->variant = 1; }
   if (c->lds > 160 * 1024) {
     set_error(WQAA_ERR_UNSUPPORTED, "gemv: activation tile %d B exceeds LDS", c->lds);
     return WQAA_ERR_UNSUPPORTED;
@@ -784,8 +879,8 @@ int gemv_plan(const wqaa_matmul_desc& d, int m, wqaa_plan* plan) {
     plan->lds_bytes = c.lds;
     char wd[24];
     short_wdtype(d, wd, sizeof(wd));
-    snprintf(plan->name, sizeof(plan->name), "matmul_m%dn%dk%d_%sx%s_gemv_b%dr%dd%d", m, d.N, d.K,
-             short_dtype(d.a_dtype), wd, c.mb, c.R, c.D);
+    snprintf(plan->name, sizeof(plan->name), "matmul_m%dn%dk%d_%sx%s_gemv_b%dr%dd%d%s", m, d.N, d.K,
+             short_dtype(d.a_dtype), wd, c.mb, c.R, c.D, c.variant ? "_areg" : "");
   }
   return WQAA_OK;
 }

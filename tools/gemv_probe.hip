@@ -234,9 +234,8 @@ int main(int argc, char** argv) {
   const double alg = wbytes + sbytes + K * 2 + N * 2;
 #define RUN(FLAGS, R, NWAVE) { double us = time_graph([&](int i) { hipLaunchKernelGGL((k_gemv<FLAGS, R, NWAVE>), dim3(N / (R * NWAVE)), dim3(NWAVE * 64), 0, s, (const uint8_t*)W[i], (const half_t*)A, (const uint16_t*)S[i], C, N); }, nbuf, s); \
     printf("flags=%3d (%s%s%s%s%s%s%s) R=%d waves/block=%d grid=%4d : %6.3f us  -> %6.1f GB/s\n", FLAGS, (FLAGS & 1) ? "compute " : "", (FLAGS & 2) ? "lds " : "", (FLAGS & 4) ? "store " : "", (FLAGS & 8) ? "scale " : "", (FLAGS & 16) ? "xcd " : "", (FLAGS & 32) ? "fold " : "", (FLAGS & 64) ? "adirect " : "", R, NWAVE, N / (R * NWAVE), us, alg / us * 1e-3); }
-  RUN(0, 2, 4) RUN(4 + 16, 2, 4) RUN(8, 2, 4) RUN(2, 2, 4) RUN(1, 2, 4) RUN(15 + 16, 2, 4) RUN(15 + 16, 1, 4) RUN(15 + 16, 2, 2) RUN(15 + 16, 1, 2) RUN(15 + 16, 1, 1) RUN(15 + 16, 4, 4) RUN(15 + 16 + 32, 2, 4)
+  RUN(0, 2, 4) RUN(15 + 16, 2, 4) RUN(13 + 16 + 64, 2, 4) RUN(13 + 16 + 64, 1, 4) RUN(13 + 16 + 64, 2, 2) RUN(13 + 16 + 64, 4, 4) RUN(13 + 16 + 64, 2, 8)
 #define RUNP(R, NWAVE, GRID) { double us = time_graph([&](int i) { hipLaunchKernelGGL((k_gemv_pipe<R, NWAVE>), dim3(GRID), dim3(NWAVE * 64), 0, s, (const uint8_t*)W[i], (const half_t*)A, (const uint16_t*)S[i], C, N); }, nbuf, s); \
     printf("pipelined R=%d waves/block=%d grid=%4d : %6.3f us  -> %6.1f GB/s\n", R, NWAVE, GRID, us, alg / us * 1e-3); }
-  RUNP(2, 4, 256) RUNP(2, 4, 512) RUNP(2, 4, 768) RUNP(2, 4, 1024) RUNP(1, 4, 512) RUNP(1, 4, 1024) RUNP(1, 4, 2048) RUNP(2, 2, 1024) RUNP(2, 2, 2048) RUNP(2, 8, 256) RUNP(2, 8, 512) RUNP(4, 4, 256) RUNP(4, 4, 512)
   return 0;
 }
