@@ -230,7 +230,7 @@ int wqaa_pack_weight(const int8_t* codes, int64_t rows, int64_t cols, int bits, 
     set_error(WQAA_ERR_BAD_DESC, "pack_weight: LOP3 layout needs K*bits %% 32 == 0");
     return WQAA_ERR_BAD_DESC;
   }
-  const int S = a_dtype == WQAA_I8 ? 8 : 16;
+  const int S = a_dtype == WQAA_I8 ? 8 : a_dtype == WQAA_I4 ? 4 : 16;
   const int epw = 32 / bits;
   int dst[32];
   for (int o = 0; o < epw; ++o) dst[o] = layout == WQAA_LAYOUT_LOP3 ? dst_bit(bits, S, o) : o * bits;
@@ -267,7 +267,7 @@ int wqaa_unpack_weight(const int8_t* packed, int64_t rows, int64_t cols, int bit
   const int epb = 8 / bits, epw = 32 / bits;
   const int64_t row_bytes = cols / epb;
   const uint32_t mask = (1u << bits) - 1u;
-  const int S = a_dtype == WQAA_I8 ? 8 : 16;
+  const int S = a_dtype == WQAA_I8 ? 8 : a_dtype == WQAA_I4 ? 4 : 16;
   if (layout == WQAA_LAYOUT_LOP3 && row_bytes % 4) {
     set_error(WQAA_ERR_BAD_DESC, "unpack_weight: LOP3 layout needs K*bits %% 32 == 0");
     return WQAA_ERR_BAD_DESC;

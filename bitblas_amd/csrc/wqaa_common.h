@@ -101,6 +101,7 @@ inline const char* short_dtype(int dt) {
   switch (dt) {
     case WQAA_F16: return "f16"; case WQAA_BF16: return "bf16"; case WQAA_F32: return "f32";
     case WQAA_I8: return "i8"; case WQAA_I32: return "i32"; case WQAA_E4M3: return "e4m3"; case WQAA_E5M2: return "e5m2";
+    case WQAA_I4: return "i4";
   }
   return "x";
 }

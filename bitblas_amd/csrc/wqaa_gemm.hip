@@ -57,6 +57,7 @@ static int gemm_choose(const wqaa_matmul_desc& d, int m, GemmChoice* c) {
   if (a == WQAA_F16) c->at = AT_F16;
   else if (a == WQAA_BF16) { c->at = AT_F16; c->flags |= FL_BF16; }   // same machine path, bfloat16 arithmetic
   else if (a == WQAA_I8) c->at = AT_I8;
+  else if (a == WQAA_I4) c->at = AT_I4;
   else if (a == WQAA_E4M3 || a == WQAA_E5M2) {
     c->at = AT_F8;
     if (a == WQAA_E5M2) c->flags |= FL_ABF8;
@@ -82,8 +83,13 @@ static int gemm_choose(const wqaa_matmul_desc& d, int m, GemmChoice* c) {
     case WQAA_W_NATIVE:
       c->kind = a == WQAA_E4M3 ? DK_E4M3 : a == WQAA_E5M2 ? DK_E5M2 : DK_NATIVE;
       c->bits = (a == WQAA_F16 || a == WQAA_BF16) ? 16 : 8;
+      if (a == WQAA_I4) { c->kind = DK_INT4; c->bits = 4; }   // two's-complement nibbles
       break;
     default: c->kind = -1;
+  }
+  if (a == WQAA_I4 && !(c->kind == DK_INT4 && d.w_format == WQAA_W_NATIVE) && c->kind != DK_INT2) {
+    set_error(WQAA_ERR_UNSUPPORTED, "gemm: int4 activations pair with int4 (native) or 2-bit weights only");
+    return WQAA_ERR_UNSUPPORTED;
   }
   if (c->kind < 0) {
     set_error(WQAA_ERR_UNSUPPORTED, "gemm: weight format %d / %d bits not supported", d.w_format, d.w_bits);
@@ -208,6 +214,7 @@ int gemm_launch(const wqaa_matmul_desc& d, const void* A, const void* B, const v
   a.has_bias = d.with_bias;
   a.out_dtype = d.out_dtype;
   a.is_signed = d.w_format == WQAA_W_INT;
+  if (d.a_dtype == WQAA_I4) a.is_signed = c.kind == DK_INT4;   // 2-bit weights are zero-extended (matmul_dequantize_mma.py:742-749)
   a.fp4_table = c.fp4_table;
   a.zq_row_bytes = d.N * (c.bits < 8 ? c.bits : 8) / 8;
   a.tiles_m = c.tiles_m;
@@ -216,7 +223,7 @@ int gemm_launch(const wqaa_matmul_desc& d, const void* A, const void* B, const v
   a.epi_row = nullptr;
   a.epi_tensor = 1.f;
   if (epi) {
-    if (c.at != AT_I8 || d.out_dtype != WQAA_F16) {
+    if (!at_is_int(c.at) || d.out_dtype != WQAA_F16) {
       set_error(WQAA_ERR_UNSUPPORTED, "matmul_ex: the fused epilogue needs int8 activations and float16 output");
       return WQAA_ERR_UNSUPPORTED;
     }
@@ -249,7 +256,7 @@ int gemm_launch(const wqaa_matmul_desc& d, const void* A, const void* B, const v
     const float* er = a.epi_row;
     float et = a.epi_tensor;
     void* rparams[] = {&ws, &C, &Bias, &M_, &N_, &ks_, &od, &hb, &er, &et};
-    const void* rfn = c.at != AT_I8 ? reinterpret_cast<const void*>(wq_splitk_reduce_kernel<true>)
+    const void* rfn = !at_is_int(c.at) ? reinterpret_cast<const void*>(wq_splitk_reduce_kernel<true>)
                                      : reinterpret_cast<const void*>(wq_splitk_reduce_kernel<false>);
     if (start || stop) e = hipExtLaunchKernel(rfn, rgrid, rblock, rparams, 0, stream, nullptr, stop, 0);
     else e = hipLaunchKernel(rfn, rgrid, rblock, rparams, 0, stream);
@@ -265,7 +272,7 @@ void gemm_init() {
   const int kinds[] = {DK_INT4, DK_INT2, DK_INT1, DK_INT8, DK_LUT4, DK_E4M3, DK_E5M2, DK_NATIVE};
   for (int kind : kinds)
     for (int layout = 0; layout < 2; ++layout)
-      for (int at = 0; at < 3; ++at)
+      for (int at = 0; at < 4; ++at)
         for (int mode = 0; mode <= MD_ZQ; ++mode)
           for (int flags : {0, (int)FL_STRICT, (int)FL_ABF8, (int)FL_BF16})
             for (int mf : {1, 2, 4, 8, 16, 101, 102, 104}) {

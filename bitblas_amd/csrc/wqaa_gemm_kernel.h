@@ -87,7 +87,7 @@ struct GemmPolicy {
   static constexpr int BITS = T::BITS;
   static constexpr int EPW = T::EPW;
   // elements of k per lane per MFMA, MFMAs per k-step, k per lane per k-step
-  static constexpr int KPM = AT_ == AT_I8 ? 16 : 8;
+  static constexpr int KPM = at_is_int(AT_) ? 16 : 8;
   // MFMAs per 16-byte activation granule: fp8 operands are 8 bytes, so a granule feeds two
   static constexpr int MPG = AT_ == AT_F8 ? 2 : 1;
   static constexpr int NJ = 4 * MPG;
@@ -320,7 +320,8 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_kernel(const GemmArgs a) {
   constexpr bool F16 = P::AT == AT_F16;
   constexpr bool F8 = P::AT == AT_F8;
   constexpr bool FACC = F16 || F8;                        // fp32 accumulators
-  constexpr int ASZ = F16 ? 2 : 1;                        // bytes per activation element
+  constexpr int ASZ = F16 ? 2 : 1;                        // bytes per activation element (in LDS)
+  constexpr bool A4 = P::AT == AT_I4;                     // packed int4 activations in memory
   using acc_t = typename std::conditional<FACC, f32x4, i32x4>::type;
   constexpr int ZB = T::SUBBYTE ? T::BITS : 8;
   constexpr int ZPB = 8 / ZB;
@@ -366,19 +367,42 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_kernel(const GemmArgs a) {
     const int ns = ((q & 7) >> 1) * 4 + (q & 1) + ((q >> 3) << 1);   // natural granule = kb' * 4 + j'
     int m = m0 + r;
     m = m < a.M ? m : a.M - 1;
-    aptr[it] = Ap + (long)m * a.K * ASZ + ns * 16;
+    aptr[it] = A4 ? Ap + (long)m * (a.K / 2) + ns * 8 : Ap + (long)m * a.K * ASZ + ns * 16;
     const int phys = (((ns & 3) << 2) | (ns >> 2)) ^ (r & 15);
     a_lds_off[it] = r * P::ROW_BYTES + phys * 16;
   }
+  // packed int4 activations: a granule of 16 elements is 8 bytes in memory; widened to int8 on the way
+  // into LDS, so everything downstream is the int8 path
+  auto granule_load = [&](const uint8_t* p) -> u32x4 {
+    if constexpr (A4) {
+      const u32x2 v = *reinterpret_cast<const u32x2*>(p);
+      return u32x4{v[0], v[1], 0u, 0u};
+    } else {
+      return *reinterpret_cast<const u32x4*>(p);
+    }
+  };
+  auto granule_lds = [&](const u32x4 v) -> u32x4 {
+    if constexpr (A4) {
+      u32x4 o;
+      uint32_t x0, x1, x2, x3;
+      widen_nibbles(v[0], x0, x1);
+      widen_nibbles(v[1], x2, x3);
+      o[0] = x0; o[1] = x1; o[2] = x2; o[3] = x3;
+      return o;
+    } else {
+      return v;
+    }
+  };
+  constexpr int ASTEP = A4 ? P::KS / 2 : P::KS * ASZ;     // bytes of one k-step in a row of A
   auto a_load = [&](int t) {
-    const long koff = (long)t * (P::KS * ASZ);
+    const long koff = (long)t * ASTEP;
 #pragma unroll
-    for (int it = 0; it < AG; ++it) areg[it] = *reinterpret_cast<const u32x4*>(aptr[it] + koff);
+    for (int it = 0; it < AG; ++it) areg[it] = granule_load(aptr[it] + koff);
   };
   auto a_store = [&](int buf) {
 #pragma unroll
     for (int it = 0; it < AG; ++it)
-      *reinterpret_cast<u32x4*>(smem_raw + buf * (P::BM * P::ROW_BYTES) + a_lds_off[it]) = areg[it];
+      *reinterpret_cast<u32x4*>(smem_raw + buf * (P::BM * P::ROW_BYTES) + a_lds_off[it]) = granule_lds(areg[it]);
   };
 
   // ---- weight lane loads ----
@@ -409,6 +433,7 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_kernel(const GemmArgs a) {
   cx.flip = 0u;
   if (P::KIND == DK_INT1 && a.is_signed) cx.flip = 0xFFFFFFFFu;
   if (P::KIND == DK_INT8 && a.is_signed) cx.flip = 0x80808080u;
+  if (A4 && P::KIND == DK_INT4 && a.is_signed) cx.flip = 0x88888888u;   // two's-complement weight nibbles
   cx.off8 = (half_t)(a.is_signed ? 1152.0f : 1024.0f);
   make_magic(cx.magic);
   const uint32_t zp4 = (!F16 && a.is_signed && T::SUBBYTE) ? (uint32_t)(1u << (T::BITS - 1)) * 0x01010101u : 0u;
@@ -505,9 +530,9 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_kernel(const GemmArgs a) {
 #pragma unroll
     for (int q = 0; q < S; ++q) {
       const int t = t0 + q < a.nsteps ? t0 + q : a.nsteps - 1;
-      const long koff = (long)t * (P::KS * ASZ);
+      const long koff = (long)t * ASTEP;
 #pragma unroll
-      for (int it = 0; it < AG; ++it) areg_s[q][it] = *reinterpret_cast<const u32x4*>(aptr[it] + koff);
+      for (int it = 0; it < AG; ++it) areg_s[q][it] = granule_load(aptr[it] + koff);
     }
     BLane<P> bs[S];
 #pragma unroll
@@ -516,7 +541,7 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_kernel(const GemmArgs a) {
     for (int q = 0; q < S; ++q)
 #pragma unroll
       for (int it = 0; it < AG; ++it)
-        *reinterpret_cast<u32x4*>(smem_raw + q * (P::BM * P::ROW_BYTES) + a_lds_off[it]) = areg_s[q][it];
+        *reinterpret_cast<u32x4*>(smem_raw + q * (P::BM * P::ROW_BYTES) + a_lds_off[it]) = granule_lds(areg_s[q][it]);
     __syncthreads();
 #pragma unroll
     for (int q = 0; q < S; ++q)

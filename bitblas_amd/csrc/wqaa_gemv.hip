@@ -77,10 +77,11 @@ struct GemvPolicy {
   // against the LDS-staged form: 4096x4096 4.25 -> 4.11 us, 1024x1024 3.29 -> 2.81 us.  For longer K
   // the slice would have to be re-read every step (64 B of A per 32 B of weights through the same
   // texture path: 8192x28672 29.7 -> 30.5 us), so those and all batch tiles > 1 keep the LDS tile.
-  static constexpr bool AD = AD_ && MB_ == 1 && !A8;
+  static constexpr bool A4 = AT_ == AT_I4;              // packed int4 activations, widened while staged
+  static constexpr bool AD = AD_ && MB_ == 1 && !A8 && !A4;
   using T = KindTraits<KIND_, AT_>;
   // words of raw activation data per staging item (one decode unit = G elements)
-  static constexpr int AW = (AT_ == AT_I8 || A8) ? T::G / 4 : T::G / 2;
+  static constexpr int AW = AT_ == AT_I4 ? T::G / 8 : (AT_ == AT_I8 || A8) ? T::G / 4 : T::G / 2;
   // activation items per thread loaded ahead of the weights (<= 32 VGPRs)
   static constexpr int NA = 32 / AW > 8 ? 8 : (32 / AW < 1 ? 1 : 32 / AW);
 };
@@ -185,7 +186,8 @@ __device__ __forceinline__ void a_item_load(const GemvArgs& a, int m0, int idx, 
   it.valid = kb < a.K && (m0 + mi) < a.m;
   const long off = it.valid ? (long)(m0 + mi) * a.K + kb : 0;   // clamped: always a readable address
   constexpr int esz = (P::AT == AT_I8 || P::A8) ? 1 : 2;
-  load_words<P::AW>(reinterpret_cast<const uint8_t*>(a.A) + off * esz, it.w);
+  if constexpr (P::A4) load_words<P::AW>(reinterpret_cast<const uint8_t*>(a.A) + off / 2, it.w);   // two per byte
+  else load_words<P::AW>(reinterpret_cast<const uint8_t*>(a.A) + off * esz, it.w);
 }
 
 template <class P>
@@ -224,8 +226,21 @@ __device__ __forceinline__ void a_item_store(const GemvArgs& a, int ncp, int idx
     }
   } else {
     uint8_t src[G];
+    if constexpr (P::A4) {
 #pragma unroll
-    for (int e = 0; e < G; ++e) src[e] = (uint8_t)(it.w[e / 4] >> (8 * (e % 4)));
+      for (int q = 0; q < G / 8; ++q) {
+        uint32_t lo4, hi4;
+        widen_nibbles(it.w[q], lo4, hi4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          src[8 * q + e] = (uint8_t)(lo4 >> (8 * e));
+          src[8 * q + 4 + e] = (uint8_t)(hi4 >> (8 * e));
+        }
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < G; ++e) src[e] = (uint8_t)(it.w[e / 4] >> (8 * (e % 4)));
+    }
 #pragma unroll
     for (int pp = 0; pp < PU; ++pp) {
       u32x4 out;
@@ -428,6 +443,8 @@ __global__ void __launch_bounds__(1024) wq_gemv_kernel(const GemvArgs a) {
   cx.flip = 0u;
   if (P::KIND == DK_INT1 && a.is_signed) cx.flip = 0xFFFFFFFFu;
   if (P::KIND == DK_INT8 && a.is_signed) cx.flip = 0x80808080u;
+  // int4 x int4: the weight nibbles are two's complement, not offset binary: n ^ 8 is the offset code
+  if (P::A4 && P::KIND == DK_INT4 && a.is_signed) cx.flip = 0x88888888u;
   cx.off8 = (half_t)(a.is_signed ? 1152.0f : 1024.0f);
   make_magic(cx.magic);
   const uint32_t zp4 = (!F16 && a.is_signed && T::SUBBYTE) ? (uint32_t)(1u << (T::BITS - 1)) * 0x01010101u : 0u;
@@ -674,6 +691,11 @@ static gemv_fn pick_kernel(int kind, int layout, int at, int mode, int flags, in
     return nullptr;
   }
   if (mode != MD_NONE) return nullptr;
+  if (at == AT_I4) {   // packed int4 activations: native int4 weights, or 2-bit weights in either layout
+    if (kind == DK_INT4) return layout == LAYOUT_PLAIN ? pick_mb<DK_INT4, LAYOUT_PLAIN, AT_I4, MD_NONE, 0>(mb) : nullptr;
+    if (kind == DK_INT2) return layout == LAYOUT_LOP3 ? pick_mb<DK_INT2, LAYOUT_LOP3, AT_I4, MD_NONE, 0>(mb) : pick_mb<DK_INT2, LAYOUT_PLAIN, AT_I4, MD_NONE, 0>(mb);
+    return nullptr;
+  }
   switch (kind) {
     case DK_INT4: return layout == LAYOUT_LOP3 ? pick_mb<DK_INT4, LAYOUT_LOP3, AT_I8, MD_NONE, 0>(mb) : pick_mb<DK_INT4, LAYOUT_PLAIN, AT_I8, MD_NONE, 0>(mb);
     case DK_INT2: return layout == LAYOUT_LOP3 ? pick_mb<DK_INT2, LAYOUT_LOP3, AT_I8, MD_NONE, 0>(mb) : pick_mb<DK_INT2, LAYOUT_PLAIN, AT_I8, MD_NONE, 0>(mb);
@@ -707,6 +729,8 @@ static int classify(const wqaa_matmul_desc& d, GemvChoice* c) {
     c->flags |= FL_BF16;
   } else if (a == WQAA_I8) {
     c->at = AT_I8;
+  } else if (a == WQAA_I4) {
+    c->at = AT_I4;
   } else if (a == WQAA_E4M3 || a == WQAA_E5M2) {
     c->at = AT_F16;
     c->flags |= FL_A8;
@@ -730,8 +754,13 @@ static int classify(const wqaa_matmul_desc& d, GemvChoice* c) {
       else if (a == WQAA_E5M2) c->kind = DK_E5M2;
       else c->kind = DK_NATIVE;
       c->bits = (a == WQAA_F16 || a == WQAA_BF16) ? 16 : 8;
+      if (a == WQAA_I4) { c->kind = DK_INT4; c->bits = 4; }   // two's-complement nibbles
       break;
     default: c->kind = -1;
+  }
+  if (a == WQAA_I4 && !(c->kind == DK_INT4 && d.w_format == WQAA_W_NATIVE) && c->kind != DK_INT2) {
+    set_error(WQAA_ERR_UNSUPPORTED, "gemv: int4 activations pair with int4 (native) or 2-bit weights only");
+    return WQAA_ERR_UNSUPPORTED;
   }
   if (c->kind < 0) {
     set_error(WQAA_ERR_UNSUPPORTED, "gemv: weight format %d / %d bits not supported", d.w_format, d.w_bits);
@@ -743,7 +772,7 @@ static int classify(const wqaa_matmul_desc& d, GemvChoice* c) {
   }
   if (c->kind == DK_E4M3 && d.strict_reference && !(c->flags & FL_A8)) c->flags |= FL_STRICT;
   if (c->kind != DK_INT4 && c->kind != DK_INT2 && c->kind != DK_INT1) c->layout = LAYOUT_PLAIN;
-  if (c->at == AT_I8 && (d.with_scaling || d.zeros_mode != WQAA_Z_NONE)) {
+  if (at_is_int(c->at) && (d.with_scaling || d.zeros_mode != WQAA_Z_NONE)) {
     set_error(WQAA_ERR_UNSUPPORTED, "gemv: scale/zeros with int8 activations are not defined by the reference");
     return WQAA_ERR_UNSUPPORTED;
   }
@@ -797,7 +826,7 @@ static int choose(const wqaa_matmul_desc& d, int m, GemvChoice* c) {
   // and few enough waves per CU that the redundant per-wave reads of A stay cheap (same-box A/B, int4:
   // 1024 rows -4 %, 2048 -3 %, 4096 -2.5 %, 11008 +3 %)
   const int cus0 = device_info().ok ? device_info().cus : 256;
-  const bool direct = mb == 1 && !(c->flags & FL_A8) && c->ncp == c->D && (d.N + c->R - 1) / c->R <= 10 * cus0 &&
+  const bool direct = mb == 1 && !(c->flags & FL_A8) && c->at != AT_I4 && c->ncp == c->D && (d.N + c->R - 1) / c->R <= 10 * cus0 &&
                       !getenv("WQAA_GEMV_NO_DIRECT");
   c->fn = pick_kernel(c->kind, c->layout, c->at, c->mode, c->flags, direct ? kDirectTile : mb);
   if (!c->fn) {
@@ -854,6 +883,9 @@ static void fill_args(const wqaa_matmul_desc& d, const GemvChoice& c, const void
   a->has_bias = d.with_bias;
   a->out_dtype = d.out_dtype;
   a->is_signed = d.w_format == WQAA_W_INT;
+  // int4 activations: 4-bit weights are native two's complement, 2-bit weights are zero-extended
+  // (matmul_dequantize_mma.py:742-749)
+  if (d.a_dtype == WQAA_I4) a->is_signed = c.kind == DK_INT4;
   a->fp4_table = c.fp4_table;
   a->a_fmt = c.a_fmt;
   a->zq_row_bytes = d.N * (c.bits < 8 ? c.bits : 8) / 8;
@@ -894,7 +926,7 @@ int gemv_launch(const wqaa_matmul_desc& d, const void* A, const void* B, const v
   GemvArgs a;
   fill_args(d, c, A, B, LUT, Scale, Zeros, Bias, C, m, &a);
   if (epi) {
-    if (c.at != AT_I8 || d.out_dtype != WQAA_F16) {
+    if (!at_is_int(c.at) || d.out_dtype != WQAA_F16) {
       set_error(WQAA_ERR_UNSUPPORTED, "matmul_ex: the fused epilogue needs int8 activations and float16 output");
       return WQAA_ERR_UNSUPPORTED;
     }
@@ -921,7 +953,7 @@ void gemv_init() {
   const int kinds[] = {DK_INT4, DK_INT2, DK_INT1, DK_INT8, DK_LUT4, DK_E4M3, DK_E5M2, DK_NATIVE};
   for (int kind : kinds)
     for (int layout = 0; layout < 2; ++layout)
-      for (int at = 0; at < 2; ++at)
+      for (int at : {(int)AT_F16, (int)AT_I8, (int)AT_I4})
         for (int mode = 0; mode <= MD_ZQ; ++mode)
           for (int flags : {0, 1, 2, 3, (int)FL_BF16})
             for (int mb : kBatchTiles) {

@@ -9,7 +9,10 @@ namespace wqaa {
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
-enum : int { AT_F16 = 0, AT_I8 = 1, AT_F8 = 2 };   // activation operand type of the kernel
+// activation operand type of the kernel.  AT_I4: packed int4 activations - the int8 machine path with the
+// nibbles widened to int8 while the tile is staged into LDS; only the LOP3 target width differs (4)
+enum : int { AT_F16 = 0, AT_I8 = 1, AT_F8 = 2, AT_I4 = 3 };
+constexpr bool at_is_int(int at) { return at == AT_I8 || at == AT_I4; }
 // dequant arithmetic (matmul_dequantize_impl.py:435-449)
 enum : int { MD_NONE = 0, MD_S = 1, MD_ZO = 2, MD_ZR = 3, MD_ZQ = 4 };
 enum : int { FL_STRICT = 1, FL_A8 = 2, FL_ABF8 = 4, FL_BF16 = 8 };   // FL_BF16: the 16-bit float type is bfloat16  // e4m3 reference bit trick; activations stored as fp8 (GEMV); fp8 MFMA activations are e5m2
@@ -31,12 +34,12 @@ struct KindTraits {
   static constexpr int PU = G / PE;              // LDS pieces per unit
   static constexpr int UNITS = E / G;            // units per lane chunk
   static constexpr int PIECES = E / PE;          // LDS pieces per lane chunk
-  static constexpr int S = AT == AT_F16 ? 16 : 8;   // LOP3 interleave target width
+  static constexpr int S = AT == AT_F16 ? 16 : AT == AT_I4 ? 4 : 8;   // LOP3 interleave target width
   static constexpr bool SUBBYTE = BITS < 8;
 
   static constexpr int field_of_slot(int xs) {
     if (!SUBBYTE) return xs;
-    if (AT == AT_I8) return I8Unpack<BITS < 8 ? BITS : 4>::field_of_slot(xs);
+    if (at_is_int(AT)) return I8Unpack<BITS < 8 ? BITS : 4>::field_of_slot(xs);
     if (KIND == DK_LUT4) return lut_field_of_slot(xs);
     return F16Unpack<BITS < 8 ? BITS : 4>::field_of_slot(xs);
   }
@@ -104,6 +107,15 @@ __device__ __forceinline__ void store_out_fused(void* C, long idx, int acc, floa
   half_t h = (half_t)v;
   if (has_bias) h = h + reinterpret_cast<const half_t*>(bias)[n];
   reinterpret_cast<half_t*>(C)[idx] = h;
+}
+
+// 8 two's-complement nibbles (element 2i = low nibble of byte i) -> 8 int8 in element order
+__device__ __forceinline__ void widen_nibbles(uint32_t w, uint32_t& lo4, uint32_t& hi4) {
+  const uint32_t even = w & 0x0F0F0F0Fu, odd = (w >> 4) & 0x0F0F0F0Fu;      // elements 0,2,4,6 / 1,3,5,7
+  const uint32_t a = __builtin_amdgcn_perm(odd, even, 0x05010400u);           // e0 e1 e2 e3
+  const uint32_t b = __builtin_amdgcn_perm(odd, even, 0x07030602u);           // e4 e5 e6 e7
+  lo4 = sub_bytes(a ^ 0x08080808u, 0x08080808u);                             // (n ^ 8) - 8: sign extension
+  hi4 = sub_bytes(b ^ 0x08080808u, 0x08080808u);
 }
 
 __device__ __forceinline__ half_t bits_to_half(uint32_t b) { return __builtin_bit_cast(half_t, (uint16_t)(b & 0xFFFFu)); }

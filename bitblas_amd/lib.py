@@ -21,7 +21,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libwqaa_hip.so")
 
 # enums of include/wqaa.h
-F16, BF16, F32, I8, I32, E4M3, E5M2 = range(7)
+F16, BF16, F32, I8, I32, E4M3, E5M2, I4 = range(8)
 W_UINT, W_INT, W_NF, W_FP4, W_E4M3, W_E5M2, W_NATIVE = range(7)
 Z_NONE, Z_ORIGINAL, Z_RESCALE, Z_QUANTIZED = range(4)
 LAYOUT_PLAIN, LAYOUT_LOP3 = 0, 1
@@ -30,6 +30,7 @@ OK, ERR_BAD_DESC, ERR_UNSUPPORTED, ERR_LAUNCH, ERR_NO_DEVICE = range(5)
 DTYPE_CODE = {
     "float16": F16, "bfloat16": BF16, "float32": F32, "int8": I8, "int32": I32,
     "e4m3_float8": E4M3, "e5m2_float8": E5M2,
+    "int4": I4,   # activations only: two's-complement nibbles, two per byte (A is (M, K/2) int8)
 }
 WFORMAT_CODE = {"uint": W_UINT, "int": W_INT, "nf": W_NF, "fp": W_FP4, "fp_e4m3": W_E4M3,
                 "fp_e5m2": W_E5M2}

@@ -280,6 +280,7 @@ _TORCH_DTYPE = {
     "float16": torch.float16, "bfloat16": torch.bfloat16, "float32": torch.float32,
     "float64": torch.float64, "int8": torch.int8, "uint8": torch.uint8, "int32": torch.int32,
     "e4m3_float8": torch.float8_e4m3fn, "e5m2_float8": torch.float8_e5m2,
+    "int4": torch.int8, "uint4": torch.int8,   # sub-byte dtypes travel packed in int8 storage
 }
 
 
@@ -537,8 +538,9 @@ class Matmul:
             (dynamic_symbolic_constraints or {}).get("m", self.config.M[0]))
         dev = self.device or torch.device("cuda")
         a_dt = torch_dtype(self.A_dtype)
-        A = (torch.rand(m, self.K, device=dev) - 0.5).to(a_dt) if a_dt.is_floating_point else \
-            torch.randint(-8, 8, (m, self.K), device=dev, dtype=a_dt)
+        k_cols = self.K // 2 if self.A_dtype == "int4" else self.K      # int4 activations: two per byte
+        A = (torch.rand(m, k_cols, device=dev) - 0.5).to(a_dt) if a_dt.is_floating_point else \
+            torch.randint(-8, 8, (m, k_cols), device=dev, dtype=a_dt)
         W = torch.randint(-128, 127, self.retrieve_weight_shape(), device=dev, dtype=torch.int8)
         if self.W_dtype == self.A_dtype:
             W = A.new_zeros((self.N, self.K))

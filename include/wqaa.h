@@ -41,7 +41,11 @@ enum wqaa_dtype {
   WQAA_I8 = 3,
   WQAA_I32 = 4,
   WQAA_E4M3 = 5, /* OCP float8_e4m3fn */
-  WQAA_E5M2 = 6
+  WQAA_E5M2 = 6,
+  WQAA_I4 = 7    /* A only: two's-complement nibbles, two per byte, low nibble first (A is (M, K/2) int8):
+                  * the reference's W_int4 / W_int2 x A_int4 path (general_matmul/__init__.py:373-378,
+                  * tilelang/dequantize/matmul_dequantize_mma.py:512-790).  W NATIVE 4-bit = two's-complement
+                  * nibbles; 2-bit weights are zero-extended (ibid. :742-749), whatever their signedness */
 };
 
 /* weight source formats: (format, bits) pairs of Matmul.BITBLAS_TRICK_DTYPE_MAP
@@ -62,7 +66,7 @@ enum wqaa_zeros_mode { WQAA_Z_NONE = 0, WQAA_Z_ORIGINAL = 1, WQAA_Z_RESCALE = 2,
  *   PLAIN : general_compress order (bitblas/quantization/utils.py:54-70)
  *   LOP3  : PLAIN followed by the LOP3 interleave that `fast_decoding=True` applies
  *           (bitblas/ops/lop3_permutate/lop3_permutate_impl.py:12-132); target width 16 for
- *           A=float16, 8 for A=int8 */
+ *           A=float16, 8 for A=int8, 4 for A=int4 */
 enum wqaa_layout { WQAA_LAYOUT_PLAIN = 0, WQAA_LAYOUT_LOP3 = 1 };
 
 enum wqaa_status {

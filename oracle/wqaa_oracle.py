@@ -110,8 +110,8 @@ def interleave_weight(qweight: np.ndarray, nbits: int = 4, target_dtype: str = "
     follow="numpy" -> `quantization/utils.py:73-110` verbatim behaviour, including its missing
                       `return` for nbits=1/float16 (the swizzled value is computed and dropped).
     """
-    assert target_dtype in ("float16", "int8")
-    S = 8 if target_dtype == "int8" else 16
+    assert target_dtype in ("float16", "int8", "int4")   # int4: the tir op only (lop3_permutate_impl.py:131-134)
+    S = {"int8": 8, "int4": 4}.get(target_dtype, 16)
     q = np.ascontiguousarray(qweight).view(np.uint32).astype(np.uint64)
     out = np.zeros_like(q)
     mask = (1 << nbits) - 1
@@ -389,6 +389,37 @@ def matmul_dense(A: np.ndarray, W: np.ndarray, *, a_dtype: str, w_dtype: str | N
 # --------------------------------------------------------------------------------------
 # weight preparation as Matmul.transform_weight does it (general_matmul/__init__.py:662-711)
 # --------------------------------------------------------------------------------------
+def unpack_int4_activations(A_packed: np.ndarray) -> np.ndarray:
+    """(M, K/2) int8 -> (M, K) int64: two's-complement nibbles, low nibble = even k.  The packing of the
+    reference's int4 test: `(A[:, ::2] & 0x0F) + ((A[:, 1::2] & 0x0F) << 4)`
+    (testing/python/operators/test_general_matmul_ops_int4.py:49)."""
+    u = _as_u8(A_packed).astype(np.int64)
+    lo, hi = u & 0xF, (u >> 4) & 0xF
+    out = np.empty((u.shape[0], u.shape[1] * 2), dtype=np.int64)
+    out[:, 0::2] = lo
+    out[:, 1::2] = hi
+    return np.where(out >= 8, out - 16, out)
+
+
+def matmul_int4_act(A_packed: np.ndarray, codes: np.ndarray, *, w_bits: int, out_dtype: str = "int32") -> np.ndarray:
+    """W_int4 / W_int2 x A_int4 (BitNet a4.8 family), int32 accumulation.
+
+    A: packed two's-complement nibbles.  `codes`: the (N, K) raw fields of the weight operand.
+    4-bit fields are native two's-complement int4 (the operands of the int4 tensor-core instruction,
+    tilelang/dequantize/matmul_dequantize_mma.py:512-520, dense pair ("int4", "int4") of
+    general_matmul/__init__.py:41).  2-bit fields are ZERO-extended to a nibble, signed or not: both
+    the plain decode (ibid. :742-749: `(x >> 0) & 3`, `(x >> 2) & 3`) and the fast decode
+    (gpu/intrin/lop3.py:1057-1083, whose `isSigned` branch is empty) do exactly that.  The reference
+    test compares with `A.float() @ B.T.float()` on non-negative operands
+    (test_general_matmul_ops_int4.py:141-146), which this restates for the full nibble range."""
+    A = unpack_int4_activations(A_packed)
+    w = np.asarray(codes).astype(np.int64) & ((1 << w_bits) - 1)
+    if w_bits == 4:
+        w = np.where(w >= 8, w - 16, w)
+    acc = A @ w.T
+    return acc.astype({"int32": np.int32, "float32": np.float32}[out_dtype])
+
+
 def weight_to_codes(weight: np.ndarray, source_format: str, bit: int) -> np.ndarray:
     """int formats (<8 bit): clamp(W, -2^(b-1), 2^(b-1)) + 2^(b-1), in int8 arithmetic; others: as int8."""
     w = np.asarray(weight)

@@ -81,6 +81,12 @@ def test_c_packer_against_oracle_and_golden(golden):
             lop3 = wlib.pack_weight(codes, bits, wlib.LAYOUT_LOP3, code)
             assert np.array_equal(lop3, oracle.interleave_weight(plain, bits, tgt))
             assert np.array_equal(wlib.unpack_weight(lop3, 128, bits, wlib.LAYOUT_LOP3, code), codes)
+    # int4 activations: 2-bit weights interleaved for a 4-bit target (lop3_permutate_impl.py:27-35, 131-134)
+    codes = rng.integers(0, 4, size=(9, 128), dtype=np.int8)
+    plain = wlib.pack_weight(codes, 2, wlib.LAYOUT_PLAIN, wlib.I4)
+    lop3 = wlib.pack_weight(codes, 2, wlib.LAYOUT_LOP3, wlib.I4)
+    assert np.array_equal(lop3, oracle.interleave_weight(plain, 2, "int4"))
+    assert np.array_equal(wlib.unpack_weight(lop3, 128, 2, wlib.LAYOUT_LOP3, wlib.I4), codes)
     for key in golden.files:
         if key.startswith("interleave_"):
             _, tgt, tag = key.split("_", 2)
