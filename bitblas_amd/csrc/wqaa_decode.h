@@ -241,4 +241,11 @@ __device__ __forceinline__ uint32_t sub_bytes(uint32_t u4, uint32_t z4) {
   return ((u4 | 0x80808080u) - z4) ^ 0x80808080u;
 }
 
+// per-byte (u - z) mod 256 (SWAR, no inter-byte borrow).  8-bit weights with quantized zero points: the
+// TE expression subtracts in the int8 storage type (quantization.py:208-217), so the difference wraps
+__device__ __forceinline__ uint32_t sub_bytes_mod(uint32_t u, uint32_t z) {
+  constexpr uint32_t H = 0x80808080u;
+  return ((u | H) - (z & ~H)) ^ ((u ^ ~z) & H);
+}
+
 }  // namespace wqaa

@@ -190,8 +190,13 @@ __device__ __forceinline__ void dequant_lane_f16(const uint32_t (&w)[P::WL], hal
     for (int wi = 0; wi < P::WL; ++wi) {
       half2_t q[EPW / 2 > 0 ? EPW / 2 : 1];
       if constexpr (P::KIND == DK_INT8) {
-        const uint32_t x = w[wi] ^ cx.flip;
-        const half2_t off = splat(cx.off8 + zf);
+        uint32_t x = w[wi] ^ cx.flip;
+        half2_t off = splat(cx.off8 + zf);
+        if constexpr (P::MODE == MD_ZQ) {
+          // (w - zero) in the int8 storage type (quantization.py:208-217): wraps mod 256, signed byte
+          x = sub_bytes_mod(w[wi], (uint32_t)(int)(float)zf * 0x01010101u) ^ 0x80808080u;
+          off = splat((half_t)1152.0f);
+        }
         q[0] = as_h2(__builtin_amdgcn_perm(0x64646464u, x, 0x04010400u)) - off;
         q[1] = as_h2(__builtin_amdgcn_perm(0x64646464u, x, 0x04030402u)) - off;
       } else if constexpr (P::KIND == DK_E4M3) {
@@ -246,7 +251,8 @@ __device__ __forceinline__ void dequant_lane_bf16(const uint32_t (&w)[P::WL], fl
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int b8 = (int)((w[wi] >> (8 * e)) & 0xFFu);
-        v[e] = (float)(is_signed ? (int)(int8_t)b8 : b8) - (P::MODE == MD_ZQ ? zf : 0.f);
+        if constexpr (P::MODE == MD_ZQ) v[e] = (float)(int)(int8_t)(b8 - (int)zf);   // int8 storage arithmetic wraps
+        else v[e] = (float)(is_signed ? (int)(int8_t)b8 : b8);
         if (SC) v[e] *= s;
       }
       const int e0 = wi * 4;

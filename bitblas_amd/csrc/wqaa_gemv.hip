@@ -273,10 +273,15 @@ __device__ __forceinline__ void decode_unit_f16(const u32x4& w, int u, half_t zf
   } else if constexpr (P::KIND == DK_INT8) {
 #pragma unroll
     for (int j = 0; j < WPU; ++j) {
-      const uint32_t x = w[u * WPU + j] ^ cx.flip;
+      uint32_t x = w[u * WPU + j] ^ cx.flip;
+      half2_t off = splat(cx.off8 + zf);
+      if constexpr (P::MODE == MD_ZQ) {
+        // (w - zero) in the int8 storage type: wraps mod 256, read back as a signed byte
+        x = sub_bytes_mod(w[u * WPU + j], (uint32_t)(int)(float)zf * 0x01010101u) ^ 0x80808080u;
+        off = splat((half_t)1152.0f);
+      }
       const uint32_t lo = __builtin_amdgcn_perm(0x64646464u, x, 0x04010400u);  // {b0,0x64,b1,0x64}
       const uint32_t hi = __builtin_amdgcn_perm(0x64646464u, x, 0x04030402u);  // {b2,0x64,b3,0x64}
-      const half2_t off = splat(cx.off8 + zf);
       q[2 * j] = as_h2(lo) - off;
       q[2 * j + 1] = as_h2(hi) - off;
     }
@@ -488,7 +493,8 @@ __global__ void __launch_bounds__(1024) wq_gemv_kernel(const GemvArgs a) {
 #pragma unroll
                   for (int e = 0; e < 4; ++e) {
                     const int b8 = (int)((x >> (8 * e)) & 0xFFu);
-                    v[e] = (float)(a.is_signed ? (int)(int8_t)b8 : b8) - (MODE == MD_ZQ ? (float)zf : 0.f);
+                    if constexpr (MODE == MD_ZQ) v[e] = (float)(int)(int8_t)(b8 - (int)(float)zf);   // int8 storage arithmetic wraps
+                    else v[e] = (float)(a.is_signed ? (int)(int8_t)b8 : b8);
                     if (MODE != MD_NONE) v[e] *= sc;
                   }
                   q[r][2 * j] = as_h2(cvt_pk_bf16(v[0], v[1]));

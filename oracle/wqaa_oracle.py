@@ -261,6 +261,17 @@ def bf16_round(x: np.ndarray) -> np.ndarray:
 
 
 
+def _quantized_zero_difference(codes, qzeros, bit: int, gi) -> np.ndarray:
+    """`(w_u - zero_u)` of zeros_mode="quantized", taken in the int8 storage type as the TE expression
+    does (quantization.py:197-217 with storage_dtype int8, matmul_dequantize_impl.py:375-389): exact
+    for sub-byte fields, wraps mod 256 to a signed byte for 8-bit ones."""
+    mask = (1 << bit) - 1
+    zq = general_decompress(np.asarray(qzeros), bit).astype(np.int64) & mask   # (K/g, N) unsigned fields
+    u = np.asarray(codes).astype(np.int64) & mask
+    d = u - zq[gi, :].T
+    return ((d + 128) % 256) - 128
+
+
 def dequantize_weight(codes: np.ndarray, source_format: str, bit: int, *, K: int | None = None,
                       scale=None, zeros=None, zeros_mode: str = "original", group_size: int = -1,
                       a_dtype: str = "float16", strict_reference: bool = True, lut=None) -> np.ndarray:
@@ -285,9 +296,7 @@ def dequantize_weight(codes: np.ndarray, source_format: str, bit: int, *, K: int
     ft = {"float16": np.float16, "float32": np.float32}[a_dtype]
     with_zeros = zeros is not None
     if with_zeros and zeros_mode == "quantized":
-        zq = general_decompress(np.asarray(zeros), bit).astype(np.int64)  # (K/g, N)
-        u = codes.astype(np.int64) & ((1 << bit) - 1)
-        w = (u - zq[gi, :].T).astype(ft)  # integer subtraction, then cast (quantization.py:208-217)
+        w = _quantized_zero_difference(codes, zeros, bit, gi).astype(ft)
     else:
         w = decode_codes(codes, source_format, bit, strict_reference, lut).astype(ft)
     if scale is None:
@@ -311,9 +320,7 @@ def _dequantize_weight_bf16(codes, source_format, bit, K, scale, zeros, zeros_mo
     Scale / Zeros arrive as float32 arrays holding bf16-representable values."""
     with_zeros = zeros is not None
     if with_zeros and zeros_mode == "quantized":
-        zq = general_decompress(np.asarray(zeros), bit).astype(np.int64)
-        u = np.asarray(codes).astype(np.int64) & ((1 << bit) - 1)
-        w = bf16_round((u - zq[gi, :].T).astype(np.float32))
+        w = bf16_round(_quantized_zero_difference(codes, zeros, bit, gi).astype(np.float32))
     else:
         w = bf16_round(decode_codes(codes, source_format, bit, True, lut).astype(np.float32))
     if scale is None:

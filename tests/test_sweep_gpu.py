@@ -1,0 +1,82 @@
+"""Seeded random sweep over the operator's configuration space: every configuration the selector
+accepts must match the oracle (fp paths 1e-3 relative, integer paths bit exact); configurations it
+refuses must be refused loudly at construction - never run and be wrong.
+
+The axes are the MatmulConfig fields of the reference's op tests
+(testing/python/operators/test_general_matmul_ops_backend_tl.py:327-343, ..._ops_backend.py:211-229,
+..._ops_nf4.py, ..._fp8.py) drawn independently instead of as a hand-picked list, with ragged M and N.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import bitblas_amd as bitblas
+from helpers import assert_fp_parity, hip_output, make_case, oracle_output
+
+pytestmark = pytest.mark.gpu
+
+W_F16 = ["uint4", "int4", "uint2", "int2", "uint1", "int1", "uint8", "int8", "nf4", "fp4_e2m1", "e4m3_float8"]
+W_I8 = ["int4", "uint4", "int2", "uint2", "int1", "int8"]
+MS = [1, 2, 3, 5, 7, 8, 13, 16, 17, 33, 64, 100, 128, 200, 257]
+NS = [16, 48, 64, 100, 128, 272, 520]
+KS = [256, 512, 768, 1024, 1536, 2048]
+
+
+def draw(rng):
+    a_int8 = rng.random() < 0.3
+    wd = str(rng.choice(W_I8 if a_int8 else W_F16))
+    M, N, K = int(rng.choice(MS)), int(rng.choice(NS)), int(rng.choice(KS))
+    kw = dict(W_dtype=wd, A_dtype="int8" if a_int8 else "float16")
+    if a_int8:
+        kw["out_dtype"] = str(rng.choice(["int32", "float32"]))
+        kw["fast_decoding"] = [None, False, True][int(rng.integers(3))] if wd not in ("int8",) else None
+        if wd in ("int4", "uint4"):
+            kw["fast_decoding"] = [None, False][int(rng.integers(2))]   # the reference never interleaves int4 for int8
+    else:
+        kw["out_dtype"] = "float16"
+        is_int = wd.startswith(("uint", "int"))
+        kw["fast_decoding"] = [None, False, True][int(rng.integers(3))] if is_int and wd not in ("uint8", "int8") else None
+        if wd != "fp4_e2m1" and rng.random() < 0.7:
+            kw["with_scaling"] = True
+            kw["group_size"] = int(rng.choice([-1, 32, 64, 128, 256]))
+            kw["scale_mul"] = 0.05
+            if is_int and wd.startswith("uint") and rng.random() < 0.6:
+                kw["with_zeros"] = True
+                kw["zeros_mode"] = str(rng.choice(["original", "rescale", "quantized"]))
+        kw["with_bias"] = bool(rng.random() < 0.3)
+    return M, N, K, kw
+
+
+@pytest.mark.parametrize("chunk", range(int(os.environ.get("WQAA_SWEEP_CHUNKS", "8"))))   # 40 draws each
+def test_random_configurations(chunk):
+    rng = np.random.default_rng(1000 + chunk)
+    ran = refused = 0
+    for _ in range(40):
+        M, N, K, kw = draw(rng)
+        g = kw.get("group_size", -1)
+        if g != -1 and K % g:
+            continue
+        bit = bitblas.Matmul.BITBLAS_TRICK_DTYPE_MAP[kw["W_dtype"]][1]
+        if kw.get("zeros_mode") == "quantized" and (N * bit) % 8:
+            continue          # packed zero points need whole bytes per row (QZeros is (K/g, N*bit/8))
+        try:
+            case = make_case(M, N, K, seed=int(rng.integers(1 << 30)), **kw)
+            got, mm = hip_output(case)
+        except (ValueError, RuntimeError, AssertionError) as e:
+            msg = str(e)
+            # a refusal must come from the selector / config legalisation, with a reason
+            assert any(t in msg for t in ("gemv:", "gemm:", "no gfx950 kernel", "not supported", "Unsupported",
+                                          "must", "should be", "scale", "zeros")), (M, N, K, kw, msg)
+            refused += 1
+            continue
+        want = oracle_output(case)
+        if kw["A_dtype"] == "int8":
+            assert np.array_equal(got, want), (M, N, K, kw, mm.plans[M]["name"])
+        else:
+            try:
+                assert_fp_parity(got, want)
+            except AssertionError as e:
+                raise AssertionError(f"{(M, N, K, kw, mm.plans[M]['name'])}: {e}")
+        ran += 1
+    assert ran >= 15, (ran, refused)
