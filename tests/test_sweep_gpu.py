@@ -20,7 +20,7 @@ W_F16 = ["uint4", "int4", "uint2", "int2", "uint1", "int1", "uint8", "int8", "nf
 W_I8 = ["int4", "uint4", "int2", "uint2", "int1", "int8"]
 MS = [1, 2, 3, 5, 7, 8, 13, 16, 17, 33, 64, 100, 128, 200, 257]
 NS = [16, 48, 64, 100, 128, 272, 520]
-KS = [256, 512, 768, 1024, 1536, 2048]
+KS = [int(k) for k in os.environ.get("WQAA_SWEEP_KS", "256,512,768,1024,1536,2048").split(",")]
 
 
 def draw(rng):
@@ -80,3 +80,40 @@ def test_random_configurations(chunk):
                 raise AssertionError(f"{(M, N, K, kw, mm.plans[M]['name'])}: {e}")
         ran += 1
     assert ran >= 15, (ran, refused)
+
+
+def test_random_bf16_configurations():
+    """bfloat16 activations (ref: test_general_matmul_bf16.py): plain layout, none / scale / quantized zeros."""
+    from test_gemm_gpu import _bf16_case
+    rng = np.random.default_rng(77)
+    ran = 0
+    for _ in range(60):
+        wd = str(rng.choice(["uint4", "int4", "uint2", "int2", "uint1", "uint8", "int8"]))
+        M, N, K = int(rng.choice(MS)), int(rng.choice([64, 128, 272, 520])), int(rng.choice(KS))
+        ws = bool(rng.random() < 0.7)
+        g = int(rng.choice([-1, 64, 128, 256])) if ws else -1
+        zm = "quantized" if (ws and wd.startswith("uint") and rng.random() < 0.5) else None
+        if g != -1 and K % g:
+            continue
+        try:
+            out, want, mm = _bf16_case(M, N, K, wd, g, ws, zm, seed=int(rng.integers(1 << 30)))
+        except (ValueError, RuntimeError) as e:
+            assert any(t in str(e) for t in ("gemv:", "gemm:", "not supported", "must")), (M, N, K, wd, g, ws, zm, str(e))
+            continue
+        try:
+            assert_fp_parity(out, want, rtol=1e-5, atol_frac=1e-5)
+        except AssertionError as e:
+            raise AssertionError(f"{(M, N, K, wd, g, ws, zm, mm.plans[M]['name'])}: {e}")
+        ran += 1
+    assert ran >= 30, ran
+
+
+def test_random_int4_activation_configurations():
+    """packed int4 activations x int4 / int2 weights, every M class and layout, bit exact"""
+    from test_int4_act_gpu import run_case
+    rng = np.random.default_rng(78)
+    for _ in range(40):
+        wd = str(rng.choice(["int4", "int2"]))
+        fd = False if wd == "int4" else [None, False, True][int(rng.integers(3))]
+        M, N, K = int(rng.choice(MS)), int(rng.choice([64, 128, 272, 520])), int(rng.choice([256, 512, 1024, 2048]))
+        run_case(M, N, K, wd, fd, seed=int(rng.integers(1 << 30)), out_dtype=str(rng.choice(["int32", "float32"])))
