@@ -73,7 +73,11 @@ static int dispatch(const wqaa_matmul_desc& d, int m, bool* use_gemm) {
   const int saved = g_last_error;
   char saved_msg[sizeof(g_last_error_msg)];
   memcpy(saved_msg, g_last_error_msg, sizeof(saved_msg));
-  if (m >= 8) {
+  // The reference switches families at M = 8 (matmul_dequantize.py:93-102).  Measured here
+  // (uint4 g128 + zeros, N = K = 4096 / 11008 x 4096): the GEMV batch tile holds 4 rows, so M = 5..7
+  // streams the weights twice (10.9-11.8 / 25.5 us) while the skinny MFMA member takes 9.3 / 16.3 us
+  // for any M <= 16; M <= 4 stays on the GEMV family (M = 4: 8.0 / 15.6 us).
+  if (m >= 5) {
     if (gemm_plan(d, m, &p) == WQAA_OK) *use_gemm = true;
   } else if (gemv_plan(d, m, &p) != WQAA_OK && gemm_plan(d, m, &p) == WQAA_OK) {
     // the GEMV family refuses this config (e.g. groups smaller than its 16-byte lane chunk) but the
