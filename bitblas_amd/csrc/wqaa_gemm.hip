@@ -44,7 +44,7 @@ static gemm_fn pick_gemm(int kind, int layout, int at, int mode, int flags, int 
 struct GemmChoice {
   gemm_fn fn;
   int kind, layout, at, mode, flags, bits;
-  int mf, ks, kl, nwaves, bn, ksplit, skinny;
+  int mf, ks, kl, nwaves, bn, ksplit, skinny, decode;
   int tiles_m, tiles_n, lds;
   int fp4_table;
 };
@@ -139,7 +139,32 @@ static int gemm_choose(const wqaa_matmul_desc& d, int m, GemmChoice* c) {
           : m > 128 ? 8 : m > 32 ? 4 : m > 16 ? 2 : 1;
   if (const char* f = getenv("WQAA_GEMM_MF")) c->mf = atoi(f);   // tuning aid
   const int nsteps = d.K / c->ks;
-  // decode batches (M <= 64): the skinny member, unless disabled
+  // small decode batches: one launch with K split across the 8 waves of a workgroup, no partial sums
+  // in memory (WQAA_GEMM_DECODE=0: back to the split-K skinny member + reduce launch).  Every
+  // workgroup reads all M activation rows, so it pays only while M and the number of 16-row weight
+  // fragments are small.  Same-box A/B against the skinny member, uint4 g128 + zeros: 4096^2 M=5
+  // 7.6 vs 9.2 us, M=8 8.2 vs 9.3, M=16 9.5 vs 9.9, M=32 13.2 vs 11.6; 11008x4096 M=8 18.3 vs 16.2;
+  // 4096x11008 M=8 15.2 vs 17.8; int2 x int8 4096^2 M=5 5.7 vs 7.3.
+  c->decode = 0;
+  if (m <= 8 && c->mf == 1 && (d.N + 15) / 16 <= 2 * cus_) {
+    const char* dflag = getenv("WQAA_GEMM_DECODE");
+    if (!dflag || atoi(dflag) != 0) c->decode = 1;
+  }
+  if (c->decode) {
+    c->fn = pick_gemm(c->kind, c->layout, c->at, c->mode, c->flags, 200 + c->mf);
+    if (c->fn) {
+      c->nwaves = 8;
+      c->bn = 16;
+      c->skinny = 0;
+      c->tiles_m = 1;
+      c->tiles_n = (d.N + 15) / 16;
+      c->lds = 8 * c->mf * 64 * 16;
+      c->ksplit = 1;
+      return WQAA_OK;
+    }
+    c->decode = 0;
+  }
+  // otherwise the skinny member, unless disabled
   c->skinny = (m <= 64 && c->mf <= 4 && getenv("WQAA_GEMM_NOSKINNY") == nullptr) ? 4 : 0;
   c->nwaves = c->mf == 16 ? 8 : 4;
   c->bn = c->skinny ? 64 : c->nwaves * 32;
@@ -189,7 +214,7 @@ int gemm_plan(const wqaa_matmul_desc& d, int m, wqaa_plan* plan) {
     char wd[24];
     short_wdtype(d, wd, sizeof(wd));
     snprintf(plan->name, sizeof(plan->name), "matmul_m%dn%dk%d_%sx%s_tcx%dx%dx%d%s%s", m, d.N, d.K, short_dtype(d.a_dtype),
-             wd, 16 * c.mf, c.bn, c.ks, c.ksplit > 1 ? "xr" : "", c.skinny ? "xs" : "");
+             wd, 16 * c.mf, c.bn, c.ks, c.ksplit > 1 ? "xr" : "", c.skinny ? "xs" : c.decode ? "xd" : "");
   }
   return WQAA_OK;
 }
@@ -275,7 +300,7 @@ void gemm_init() {
       for (int at = 0; at < 4; ++at)
         for (int mode = 0; mode <= MD_ZQ; ++mode)
           for (int flags : {0, (int)FL_STRICT, (int)FL_ABF8, (int)FL_BF16})
-            for (int mf : {1, 2, 4, 8, 16, 101, 102, 104}) {
+            for (int mf : {1, 2, 4, 8, 16, 101, 102, 104, 201}) {
               gemm_fn fn = pick_gemm(kind, layout, at, mode, flags, mf);
               if (fn) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             }

@@ -79,7 +79,8 @@ struct GemmPolicy {
   static constexpr int NWAVES = NWAVES_; // waves side by side along N
   static constexpr int THREADS = 64 * NWAVES_;
   static constexpr int AG = (16 * MF_ * 16) / (64 * NWAVES_);   // activation granules per thread per k-step
-  static_assert(AG >= 1 && AG * 64 * NWAVES_ == 16 * MF_ * 16, "tile / workgroup mismatch");
+  static constexpr bool DECODE = NWAVES_ == 8 && NFW_ == 1;   // decode-batch member: no LDS staging at all
+  static_assert(DECODE || (AG >= 1 && AG * 64 * NWAVES_ == 16 * MF_ * 16), "tile / workgroup mismatch");
   static constexpr int BM = 16 * MF, BN = 16 * NFW * NWAVES;
   static constexpr bool STRICT = (FLAGS_ & FL_STRICT) != 0;
   static constexpr bool BF = (FLAGS_ & FL_BF16) != 0;   // 16-bit float type is bfloat16
@@ -306,6 +307,47 @@ __device__ __forceinline__ void load_lane_words(const uint8_t* p, uint32_t (&w)[
   } else {
     static_assert(NW_ == 1, "unsupported lane word count");
     w[0] = *reinterpret_cast<const uint32_t*>(p);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// output of one lane's 4 consecutive columns [nb, nb+4) of row m: cast to out_dtype, then + bias
+// ------------------------------------------------------------------------------------------
+template <class P, class ACC>
+__device__ __forceinline__ void store_quad(const GemmArgs& a, const ACC v, int m, int nb) {
+  constexpr bool F16 = P::AT == AT_F16, F8 = P::AT == AT_F8, FACC = F16 || F8;
+  float bias_f[4] = {0.f, 0.f, 0.f, 0.f};
+  int bias_i[4] = {0, 0, 0, 0};
+  if (a.has_bias) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if constexpr (F16 && P::BF) bias_f[i] = bf16_bits_to_float(reinterpret_cast<const uint16_t*>(a.bias)[nb + i]);
+      else if constexpr (F16) bias_f[i] = (float)reinterpret_cast<const half_t*>(a.bias)[nb + i];
+      else if constexpr (F8) bias_f[i] = 0.f;   // the reference defines no fp8 bias operand
+      else if (!a.epi_row) bias_i[i] = (int)reinterpret_cast<const int8_t*>(a.bias)[nb + i];
+    }
+  }
+  const long base = (long)m * a.N + nb;
+  if constexpr (FACC) {
+    if (a.out_dtype == WQAA_F16) {
+      half_t h[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        h[i] = (half_t)v[i];
+        if (a.has_bias) h[i] = h[i] + (half_t)bias_f[i];
+      }
+      const half2_t lo = {h[0], h[1]}, hi = {h[2], h[3]};
+      *reinterpret_cast<u32x2*>(reinterpret_cast<half_t*>(a.C) + base) = u32x2{as_u32(lo), as_u32(hi)};
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) store_out(a.C, base + i, v[i], a.out_dtype, a.has_bias != 0, bias_f[i]);
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (a.epi_row) store_out_fused(a.C, base + i, v[i], a.epi_row[m], a.epi_tensor, a.has_bias != 0, a.bias, nb + i);
+      else store_out(a.C, base + i, v[i], a.out_dtype, a.has_bias != 0, bias_i[i]);
+    }
   }
 }
 
@@ -634,6 +676,193 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_kernel(const GemmArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------
+// decode-batch member (M <= 16; the selector uses it for M = 5..8): ONE launch, no partial sums in memory.
+// A workgroup owns one 16-row weight fragment and ALL of K; its NW waves take the k-steps round-robin
+// and meet in LDS at the end (fixed summation order: deterministic).  Nothing is shared between waves
+// inside the loop - no LDS staging, no barrier: the lane reads its activation granules (64 contiguous
+// bytes per row and k-step, L2-resident) straight into MFMA operands.  PF k-steps of BOTH streams are
+// in flight per wave; for K = 4096 that is the wave's whole share, issued before anything is consumed:
+// one memory round trip per launch, which is what a latency-bound decode step wants.
+// ------------------------------------------------------------------------------------------
+template <class P>
+__global__ void __launch_bounds__(P::THREADS) wq_gemm_decode_kernel(const GemmArgs a) {
+  using T = typename P::T;
+  constexpr int MF = P::MF, NJ = P::NJ, WL = P::WL, MODE = P::MODE, NW = P::NWAVES;
+  constexpr bool F16 = P::AT == AT_F16, F8 = P::AT == AT_F8, FACC = F16 || F8, A4 = P::AT == AT_I4;
+  constexpr int ASZ = F16 ? 2 : 1;
+  using acc_t = typename std::conditional<FACC, f32x4, i32x4>::type;
+  constexpr int ZB = T::SUBBYTE ? T::BITS : 8;
+  constexpr int ZPB = 8 / ZB;
+  constexpr int PF = 4;                       // k-steps in flight per wave
+  static_assert(P::NFW == 1 && MF <= 2, "decode member: one weight fragment per workgroup, M <= 32");
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 15, kb = lane >> 4;
+  // XCD-aware order: an XCD (block b runs on XCD b % 8) takes a contiguous band of weight rows
+  int blk = blockIdx.x;
+  if ((gridDim.x & 7) == 0) blk = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  const int n0 = blk * 16;
+  int nrow = n0 + fr;
+  nrow = nrow < a.N ? nrow : a.N - 1;
+
+  const uint8_t* Ap = reinterpret_cast<const uint8_t*>(a.A);
+  const uint8_t* Bp = reinterpret_cast<const uint8_t*>(a.B);
+  const uint16_t* Sp = reinterpret_cast<const uint16_t*>(a.scale);
+  const uint16_t* Zp = reinterpret_cast<const uint16_t*>(a.zeros);
+  const uint8_t* Qp = reinterpret_cast<const uint8_t*>(a.zeros);
+  const uint8_t* brow = Bp + (long)nrow * a.row_bytes + (long)kb * (WL * 4);
+  const long srow = (long)nrow * a.kg;
+
+  // the lane's activation rows: fragment mf -> row mf * 16 + fr (clamped: rows >= M are never stored)
+  constexpr int ALB = A4 ? 32 : 64;           // bytes of one lane k-block of A in memory
+  const uint8_t* arow[MF];
+#pragma unroll
+  for (int mf = 0; mf < MF; ++mf) {
+    int m = mf * 16 + fr;
+    m = m < a.M ? m : a.M - 1;
+    arow[mf] = A4 ? Ap + (long)m * (a.K / 2) + kb * ALB : Ap + (long)m * a.K * ASZ + kb * ALB;
+  }
+
+  struct Step {
+    BLane<P> b;
+    u32x4 araw[MF][A4 ? 2 : 4];
+  };
+  auto load_step = [&](int t, Step& st) {
+    const int kidx = t * 4 + kb;
+    int gi = 0;
+    if (MODE != MD_NONE) gi = a.gq_shift >= 0 ? (kidx >> a.gq_shift) : (int)__umulhi((uint32_t)kidx, a.gq_magic);
+    load_lane_words<WL>(brow + (long)t * (4 * WL * 4), st.b.w[0]);
+    if constexpr (MODE != MD_NONE) st.b.s[0] = Sp[srow + gi];
+    if constexpr (MODE == MD_ZO || MODE == MD_ZR) st.b.z[0] = Zp[srow + gi];
+    if constexpr (MODE == MD_ZQ) st.b.z[0] = Qp[(long)gi * a.zq_row_bytes + nrow / ZPB];
+    const long koff = (long)t * (4 * ALB);
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+      for (int g = 0; g < (A4 ? 2 : 4); ++g) st.araw[mf][g] = *reinterpret_cast<const u32x4*>(arow[mf] + koff + g * 16);
+  };
+
+  DecodeCtx cx;
+  cx.zf = (F16 && a.is_signed && T::SUBBYTE) ? (half_t)(float)(1 << (T::BITS - 1)) : (half_t)0.0f;
+  cx.flip = 0u;
+  if (P::KIND == DK_INT1 && a.is_signed) cx.flip = 0xFFFFFFFFu;
+  if (P::KIND == DK_INT8 && a.is_signed) cx.flip = 0x80808080u;
+  if (A4 && P::KIND == DK_INT4 && a.is_signed) cx.flip = 0x88888888u;
+  cx.off8 = (half_t)(a.is_signed ? 1152.0f : 1024.0f);
+  make_magic(cx.magic);
+  const uint32_t zp4 = (!F16 && a.is_signed && T::SUBBYTE) ? (uint32_t)(1u << (T::BITS - 1)) * 0x01010101u : 0u;
+  Lut16 lut;
+  if constexpr (P::KIND == DK_LUT4) {
+    if (a.fp4_table) lut = make_fp4_lut();
+    else lut = make_lut16(reinterpret_cast<const half_t*>(a.lut));
+  }
+
+  acc_t acc[MF];
+#pragma unroll
+  for (int mf = 0; mf < MF; ++mf) acc[mf] = acc_t{0, 0, 0, 0};
+
+  auto compute = [&](const Step& st) {
+    const BLane<P>& bl = st.b;
+    uint32_t bfrag[NJ][4];
+    if constexpr (F16) {
+      half_t zf = cx.zf;
+      if constexpr (MODE == MD_ZQ) {
+        const uint32_t zq = (bl.z[0] >> ((nrow % ZPB) * ZB)) & ((1u << ZB) - 1u);
+        zf = (half_t)(float)zq;
+      }
+      const half2_t s2 = MODE != MD_NONE ? splat(bits_to_half(bl.s[0])) : splat((half_t)1.0f);
+      const half2_t z2 = (MODE == MD_ZO || MODE == MD_ZR) ? splat(bits_to_half(bl.z[0])) : splat((half_t)0.0f);
+      if constexpr (P::BF)
+        dequant_lane_bf16<P>(bl.w[0], (float)zf, MODE != MD_NONE ? bf16_bits_to_float(bl.s[0]) : 1.f, a.is_signed != 0, cx.flip, bfrag);
+      else
+        dequant_lane_f16<P>(bl.w[0], zf, s2, z2, cx, lut, bfrag);
+    } else if constexpr (F8) {
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        bfrag[j][0] = bl.w[0][2 * j];
+        bfrag[j][1] = bl.w[0][2 * j + 1];
+      }
+    } else {
+      dequant_lane_i8<P>(bl.w[0], zp4, cx.flip, bfrag);
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+#pragma unroll
+      for (int mf = 0; mf < MF; ++mf) {
+        u32x4 v;
+        if constexpr (A4) {   // granule g = 8 packed bytes -> 16 int8
+          const u32x4 r = st.araw[mf][g >> 1];
+          uint32_t x0, x1, x2, x3;
+          widen_nibbles(r[2 * (g & 1)], x0, x1);
+          widen_nibbles(r[2 * (g & 1) + 1], x2, x3);
+          v = u32x4{x0, x1, x2, x3};
+        } else {
+          v = st.araw[mf][g];
+        }
+        if constexpr (F16) {
+          const u32x4 bv = {bfrag[g][0], bfrag[g][1], bfrag[g][2], bfrag[g][3]};
+          if constexpr (P::BF)
+            acc[mf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, bv), __builtin_bit_cast(bf16x8_t, v), acc[mf], 0, 0, 0);
+          else
+            acc[mf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8_t, bv), __builtin_bit_cast(half8_t, v), acc[mf], 0, 0, 0);
+        } else if constexpr (F8) {
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const u32x2 b2 = {bfrag[2 * g + h][0], bfrag[2 * g + h][1]};
+            const u32x2 a2 = {v[2 * h], v[2 * h + 1]};
+            const long bl8 = __builtin_bit_cast(long, b2), al8 = __builtin_bit_cast(long, a2);
+            constexpr bool WB = P::KIND == DK_E5M2, AB = (P::FLAGS & FL_ABF8) != 0;
+            if constexpr (!WB && !AB) acc[mf] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(bl8, al8, acc[mf], 0, 0, 0);
+            if constexpr (!WB && AB) acc[mf] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_bf8(bl8, al8, acc[mf], 0, 0, 0);
+            if constexpr (WB && !AB) acc[mf] = __builtin_amdgcn_mfma_f32_16x16x32_bf8_fp8(bl8, al8, acc[mf], 0, 0, 0);
+            if constexpr (WB && AB) acc[mf] = __builtin_amdgcn_mfma_f32_16x16x32_bf8_bf8(bl8, al8, acc[mf], 0, 0, 0);
+          }
+        } else {
+          const u32x4 bv = {bfrag[g][0], bfrag[g][1], bfrag[g][2], bfrag[g][3]};
+          acc[mf] = __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4, bv), __builtin_bit_cast(i32x4, v), acc[mf], 0, 0, 0);
+        }
+      }
+    }
+  };
+
+  // wave w takes k-steps w, w + NW, ...; loads are unconditional (clamped step), compute is guarded
+  const int nsteps = a.nsteps;
+  const int last = nsteps - 1;
+  const int my_steps = (nsteps - wave + NW - 1) / NW;     // wave-uniform
+  Step ring[PF];
+#pragma unroll
+  for (int i = 0; i < PF; ++i) {
+    const int t = wave + i * NW;
+    load_step(t < nsteps ? t : last, ring[i]);
+  }
+  for (int s0 = 0; s0 < my_steps; s0 += PF) {
+#pragma unroll
+    for (int i = 0; i < PF; ++i) {
+      const int s = s0 + i;
+      if (s < my_steps) compute(ring[i]);
+      const int tw = wave + (s + PF) * NW;                 // refill the slot just consumed
+      if (s0 + PF < my_steps) load_step(tw < nsteps ? tw : last, ring[i]);   // wave-uniform: short K issues nothing more
+    }
+  }
+
+  // ---- meet in LDS: slot [wave][mf][lane], summed in wave order by the threads of wave mf ----
+  acc_t* red = reinterpret_cast<acc_t*>(smem_raw);
+#pragma unroll
+  for (int mf = 0; mf < MF; ++mf) red[(wave * MF + mf) * 64 + lane] = acc[mf];
+  __syncthreads();
+  if (wave >= MF) return;
+  acc_t sum = red[wave * 64 + lane];                        // wave 0's share of fragment `wave`
+#pragma unroll
+  for (int w = 1; w < NW; ++w) sum += red[(w * MF + wave) * 64 + lane];
+  const int nb = n0 + kb * 4;
+  const int m = wave * 16 + fr;
+  if (nb < a.N && m < a.M) store_quad<P>(a, sum, m, nb);
+}
+
+// ------------------------------------------------------------------------------------------
 // split-K reduction: C[m][n..n+3] = cast(sum_s ws[s][m][n..n+3]) (+ bias after the cast)
 // ------------------------------------------------------------------------------------------
 template <bool F16>
@@ -688,7 +917,8 @@ gemm_fn pick_gemm_f16_other(int kind, int mode, int flags, int mf);
 gemm_fn pick_gemm_bf16(int kind, int mode, int mf);
 gemm_fn pick_gemm_i8_f8(int kind, int layout, int at, int flags, int mf);
 
-// mf codes: 1, 2, 4, 8 (16*mf x 128, 4 waves), 16 (256 x 256, 8 waves), 101/102/104 (skinny members)
+// mf codes: 1, 2, 4, 8 (16*mf x 128, 4 waves), 16 (256 x 256, 8 waves), 101/102/104 (skinny members),
+// 201 (decode-batch member: one launch, K split across the waves of a workgroup)
 template <int KIND, int LAYOUT, int AT, int MODE, int FLAGS>
 static gemm_fn pick_mf(int mf) {
   switch (mf) {
@@ -700,6 +930,7 @@ static gemm_fn pick_mf(int mf) {
     case 101: return wq_gemm_kernel<GemmPolicy<KIND, LAYOUT, AT, MODE, FLAGS, 1, 4, 1, 4>>;
     case 102: return wq_gemm_kernel<GemmPolicy<KIND, LAYOUT, AT, MODE, FLAGS, 2, 4, 1, 4>>;
     case 104: return wq_gemm_kernel<GemmPolicy<KIND, LAYOUT, AT, MODE, FLAGS, 4, 4, 1, 4>>;
+    case 201: return wq_gemm_decode_kernel<GemmPolicy<KIND, LAYOUT, AT, MODE, FLAGS, 1, 8, 1>>;
   }
   return nullptr;
 }

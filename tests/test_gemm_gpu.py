@@ -262,3 +262,24 @@ def test_small_groups_fall_through_to_the_mfma_family(M):
     got, mm = hip_output(case)
     assert mm.plans[M]["kernel_family"] == 2
     assert_fp_parity(got, oracle_output(case))
+
+
+@pytest.mark.parametrize("M", [5, 8])
+@pytest.mark.parametrize("kw", [dict(W_dtype="uint4", group_size=128, with_scaling=True, with_zeros=True, zeros_mode="original", scale_mul=0.05),
+                                dict(W_dtype="int2", A_dtype="int8", out_dtype="int32")])
+def test_decode_batch_member_against_the_split_k_member(M, kw, monkeypatch):
+    """M = 5..8 runs the one-launch member (K split across the waves of a workgroup, summed in LDS);
+    the split-K skinny member + reduce launch must agree: bit exact for integers, within the fp16
+    bound for floats (different summation order)."""
+    case = make_case(M, 1024, 4096, seed=M, **kw)
+    got, mm = hip_output(case)
+    assert mm.plans[M]["name"].endswith("xd")
+    monkeypatch.setenv("WQAA_GEMM_DECODE", "0")
+    got2, mm2 = hip_output(case)
+    assert mm2.plans[M]["name"].endswith("xs")
+    want = oracle_output(case)
+    if kw.get("A_dtype") == "int8":
+        assert np.array_equal(got, got2) and np.array_equal(got, want)
+    else:
+        assert_fp_parity(got, want)
+        assert_fp_parity(got2, want)
