@@ -146,6 +146,12 @@ class Linear(nn.Module):
         self.q_params = [ctypes.c_void_p(p.data_ptr()) for p in params]
         self._q_param_keys = tuple(p.data_ptr() for p in params)
         self._q_param_tensors = params
+        # raw pointers in `BoundLib.run` order (B, scale, zeros, bias) for the forward fast path
+        it = iter(self._q_param_keys[1:])
+        self._q_run = (self._q_param_keys[0],
+                       next(it) if (not self.consistent and cfg.with_scaling) else None,
+                       next(it) if (not self.consistent and cfg.with_zeros) else None,
+                       next(it) if cfg.with_bias else None)
 
     def _params_current(self):
         if self.q_params is None:
@@ -161,13 +167,14 @@ class Linear(nn.Module):
             # upstream uses torch.zeros here; every element is written by the kernel
             output = torch.empty(A.shape[:-1] + (self.out_features,),
                                  dtype=torch_dtype(self.bitblas_matmul.out_dtype), device=A.device)
-        args = [ctypes.c_void_p(A.data_ptr()), *self.q_params, ctypes.c_void_p(output.data_ptr())]
-        if self.bitblas_matmul.dynamic_range is not None:
-            args.append(reduce(operator.mul, A.shape[:-1], 1))
-        args.append(ctypes.c_void_p(torch.cuda.current_stream(A.device).cuda_stream))
-        if self.source_format == "nf":
-            self.bitblas_matmul._ensure_lut(A.device)
-        self.bitblas_matmul.lib.call(*args)
+        # upstream rebuilds a ctypes argument list and goes through the positional `lib.call` here
+        # (:271-287); same pointers, same order, without the per-call wrapping
+        mm = self.bitblas_matmul
+        m = A.numel() // A.shape[-1] if mm.dynamic_range is not None else mm.lib.static_m
+        lut = mm._ensure_lut(A.device) if self.source_format == "nf" else None
+        B, scale, zeros, bias = self._q_run
+        mm.lib.run(A.data_ptr(), B, lut.data_ptr() if lut is not None else None, scale, zeros, bias,
+                   output.data_ptr(), m, torch.cuda.current_stream(A.device).cuda_stream)
         return output
 
     def load_and_transform_weight(self, weight: torch.Tensor, scales: torch.Tensor = None,
