@@ -58,6 +58,7 @@ struct GemmArgs {
   int zq_row_bytes;
   int tiles_m, tiles_n;
   int nsteps;         // K / KS
+  int group_m;        // M-tiles per group of the tile order (1 = row-major)
   const float* epi_row;   // fused caller epilogue (wqaa_matmul_ex): out = half(acc / epi_row[m] / epi_tensor)
   float epi_tensor;
   int ksplit;         // > 1: workgroup (tile, s) covers k-steps [s*nsteps/ksplit, (s+1)*nsteps/ksplit) and
@@ -390,7 +391,13 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_kernel(const GemmArgs a) {
   const int ntiles = a.tiles_m * a.tiles_n;
   const int split = blk / ntiles;        // k-slice of this workgroup (0 when ksplit == 1)
   blk -= split * ntiles;
-  const int tile_m = blk / a.tiles_n, tile_n = blk % a.tiles_n;
+  // grouped order: consecutive tile ids sweep `group_m` M-tiles x all N-tiles column by column, so the
+  // ~32 tiles an XCD has in flight form a compact 2-D block and share both operand bands in its L2
+  // (row-major order shares one activation band and streams 32 different weight bands)
+  const int per_group = a.group_m * a.tiles_n;
+  const int first_m = (blk / per_group) * a.group_m;
+  const int gsz = a.tiles_m - first_m < a.group_m ? a.tiles_m - first_m : a.group_m;
+  const int tile_m = first_m + (blk % per_group) % gsz, tile_n = (blk % per_group) / gsz;
   const int m0 = tile_m * P::BM;
   const int n0 = tile_n * P::BN + wave * (NFW * 16);
 
