@@ -3,7 +3,7 @@
 // Replaces the reference's generated per-config wrapper (`init()` + `call()`,
 // bitblas/builder/wrapper/tl.py:90-166 and :200-305) and its host-side kernel choice
 // (`MatmulDequantizeScheduler.dispatch_*`, tilelang/dequantize/matmul_dequantize.py:65-155:
-// M < 8 -> GEMV, otherwise the tensor-core GEMM).
+// M < 8 -> GEMV, otherwise the tensor-core GEMM; here the switch sits at M = 5, see dispatch()).
 #include <hip/hip_ext.h>
 #include <stdarg.h>
 #include <stdio.h>
@@ -65,8 +65,8 @@ static bool valid_desc(const wqaa_matmul_desc* d) {
   return true;
 }
 
-// M < 8 -> GEMV (reference threshold, matmul_dequantize.py:93-102); larger m -> MFMA GEMM when a
-// member exists for the dtype pair, else the GEMV family iterates over batch tiles of 8 rows.
+// M <= 4 -> GEMV family; larger m -> MFMA GEMM when a member exists for the dtype pair and shape, else the
+// GEMV family iterates over batch tiles of 4 rows.
 static int dispatch(const wqaa_matmul_desc& d, int m, bool* use_gemm) {
   *use_gemm = false;
   wqaa_plan p;
