@@ -632,6 +632,7 @@ static gemv_fn pick_mb(int mb) {
   switch (mb) {
     case 1: return wq_gemv_kernel<GemvPolicy<KIND, LAYOUT, AT, 1, MODE, FLAGS>>;
     case kDirectTile: return wq_gemv_kernel<GemvPolicy<KIND, LAYOUT, AT, 1, MODE, FLAGS, 2, 2, true>>;
+    case kDirectTile + 1: return wq_gemv_kernel<GemvPolicy<KIND, LAYOUT, AT, 1, MODE, FLAGS, 1, 2, true>>;
     case 2: return wq_gemv_kernel<GemvPolicy<KIND, LAYOUT, AT, 2, MODE, FLAGS>>;
     case 4: return wq_gemv_kernel<GemvPolicy<KIND, LAYOUT, AT, 4, MODE, FLAGS>>;
     default: return nullptr;
@@ -834,7 +835,11 @@ static int choose(const wqaa_matmul_desc& d, int m, GemvChoice* c) {
   const int cus0 = device_info().ok ? device_info().cus : 256;
   const bool direct = mb == 1 && !(c->flags & FL_A8) && c->at != AT_I4 && c->ncp == c->D && (d.N + c->R - 1) / c->R <= 10 * cus0 &&
                       !getenv("WQAA_GEMV_NO_DIRECT");
-  c->fn = pick_kernel(c->kind, c->layout, c->at, c->mode, c->flags, direct ? kDirectTile : mb);
+  // small matrices: one row per wave doubles the waves in flight (same-box A/B: 1024 x 1024 2.87 -> 2.45 us,
+  // 2048 x 4096 equal, 4096 x 4096 4.18 -> 4.43 us)
+  const bool r1 = direct && (d.N + 1) / 2 < 3 * cus0;
+  if (r1) c->R = 1;
+  c->fn = pick_kernel(c->kind, c->layout, c->at, c->mode, c->flags, direct ? (r1 ? kDirectTile + 1 : kDirectTile) : mb);
   if (!c->fn) {
     set_error(WQAA_ERR_UNSUPPORTED, "gemv: no kernel for kind=%d layout=%d at=%d mode=%d flags=%d", c->kind,
               c->layout, c->at, c->mode, c->flags);
