@@ -513,6 +513,10 @@ class Matmul:
             output = torch.empty(A.shape[:-1] + (self.N,), dtype=self.torch_output_dtype, device=A.device)
         if not A.is_cuda:
             raise RuntimeError("bitblas_amd.Matmul runs on the GPU only (no CPU fallback)")
+        if not A.is_contiguous():
+            A = A.contiguous()   # the kernels read raw row-major memory (upstream passes data_ptr() unchecked)
+        if not output.is_contiguous():
+            raise ValueError("output must be a contiguous tensor")
         m = reduce(_operator.mul, A.shape[:-1], 1)
         if self.dynamic_range is None and m != self.config.M:
             raise ValueError(f"operator was built for M={self.config.M}, got {m} rows")

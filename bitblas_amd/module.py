@@ -161,6 +161,8 @@ class Linear(nn.Module):
 
     def forward(self, A, output=None):
         A = self.bitblas_matmul.transform_input(A)
+        if not A.is_contiguous():
+            A = A.contiguous()   # the kernels read raw row-major memory
         if not self._params_current():
             self.init_params()
         if output is None:

@@ -172,3 +172,21 @@ def test_register_and_lds_activation_members_agree(wd, g, ws, wz, zm, monkeypatc
     assert not mm2.plans[1]["name"].endswith("_areg")
     assert np.array_equal(got, got_lds)
     assert_fp_parity(got, oracle_output(case))
+
+
+def test_non_contiguous_activations_are_read_correctly():
+    """A strided view (every other row of a taller matrix, and a 3-d batch) must not be read as raw memory."""
+    import bitblas_amd as bitblas
+    case = make_case(4, 256, 512, W_dtype="int4")
+    mm = bitblas.Matmul(bitblas.MatmulConfig(M=[1, 4, 16], N=256, K=512, A_dtype="float16", W_dtype="int4"), enable_tuning=False)
+    W = mm.transform_weight(torch.from_numpy(case["w_user"]).cuda())
+    tall = torch.zeros((8, 512), dtype=torch.float16, device="cuda")
+    tall[0::2] = torch.from_numpy(case["A"]).cuda()
+    tall[1::2] = 123.0
+    out = mm(tall[0::2], W)
+    assert_fp_parity(out.cpu().numpy(), oracle_output(case))
+    out3 = mm(tall[0::2].reshape(2, 2, 512), W)
+    assert out3.shape == (2, 2, 256)
+    assert_fp_parity(out3.reshape(4, 256).cpu().numpy(), oracle_output(case))
+    with pytest.raises(ValueError):
+        mm(tall[0::2], W, output=torch.empty((4, 512), dtype=torch.float16, device="cuda")[:, ::2])
