@@ -412,6 +412,9 @@ class Matmul:
         probe_m = list(config.M) if isinstance(config.M, tuple) else [config.M]
         self.plans = {m: self.lib.plan(m) for m in probe_m}
 
+        # operand sizes the kernels will read (checked on every forward: a short buffer is an out-of-bounds read)
+        self._a_cols = config.K // 2 if config.A_dtype in ("int4", "uint4") else config.K
+        self._w_bytes = config.N * config.K * self.bit // 8
         self.weight_compress = _QuantCompress(self.bit, a_code) if self.bit in (1, 2, 4) else None
         self.lop3_permutate = None
         if config.fast_decoding and not native:
@@ -513,6 +516,11 @@ class Matmul:
             output = torch.empty(A.shape[:-1] + (self.N,), dtype=self.torch_output_dtype, device=A.device)
         if not A.is_cuda:
             raise RuntimeError("bitblas_amd.Matmul runs on the GPU only (no CPU fallback)")
+        if A.shape[-1] != self._a_cols:
+            raise ValueError(f"A has {A.shape[-1]} columns, the operator was built for {self._a_cols} (K={self.K})")
+        if W.numel() * W.element_size() != self._w_bytes:
+            raise ValueError(f"W holds {W.numel() * W.element_size()} bytes, the operator expects {self._w_bytes} "
+                             f"(shape {self.retrieve_weight_shape()}: run transform_weight first)")
         if not A.is_contiguous():
             A = A.contiguous()   # the kernels read raw row-major memory (upstream passes data_ptr() unchecked)
         if not output.is_contiguous():
