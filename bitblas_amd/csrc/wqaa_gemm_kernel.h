@@ -100,8 +100,10 @@ struct GemmPolicy {
   static constexpr int LDS_BYTES = (SK_ > 0 ? SK_ : 2) * BM * ROW_BYTES;
   // LDS read prefetch distance in MFMA slots (0: leave the order to the compiler).  Same-box A/B of the
   // 4-wave members, N = K = 4096: int2 x int8 M=512 30.4 -> 26.5 us, M=1024 43.9 -> 35.1 us; uint4 x fp16
-  // within +-2 % (M=2048 and 11008 x 4096 M=512 slower): on for the integer members only
-  static constexpr int PD = (NWAVES_ == 4 && SK_ == 0 && at_is_int(AT_)) ? 6 : 0;
+  // within +-2 % (M=2048 and 11008 x 4096 M=512 slower): on for the integer members only.
+  // 256 x 256 / 8 waves: 4 slots ahead pays for sub-byte integer weights (int2 x int8 4096^3 82.9 -> 79.5 us,
+  // 8192^3 530 -> 499 us) and costs 50 % with 8-bit weights (256 registers, no room to schedule)
+  static constexpr int PD = (SK_ == 0 && at_is_int(AT_)) ? (NWAVES_ == 4 ? 6 : (T::SUBBYTE ? 4 : 0)) : 0;
 };
 
 // ------------------------------------------------------------------------------------------
