@@ -419,18 +419,25 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_kernel(const GemmArgs a) {
   // {2,3,6,7,...}: their physical slots (j*4+kb)^r are then distinct mod 8 - no write conflicts.
   constexpr int AG = P::AG;
   u32x4 areg[AG];
-  const uint8_t* aptr[AG];
-  int a_lds_off[AG];
-#pragma unroll
-  for (int it = 0; it < AG; ++it) {
-    const int gid = it * P::THREADS + tid;
-    const int r = gid >> 4, q = gid & 15;
+  // addresses cost registers here: a wave-uniform base (SGPRs) + one 32-bit byte offset per granule in
+  // memory, and ONE LDS offset - rows of successive granules are THREADS / 16 apart, a multiple of 16,
+  // so the swizzle term is the same and the rest is a compile-time stride
+  const long a_row_bytes = A4 ? (long)(a.K / 2) : (long)a.K * ASZ;
+  const uint8_t* a_tile = Ap + (long)m0 * a_row_bytes;
+  uint32_t aoff[AG];
+  constexpr int LDS_IT_STRIDE = (P::THREADS / 16) * P::ROW_BYTES;
+  int a_lds_off0;
+  {
+    const int r0 = tid >> 4, q = tid & 15;
     const int ns = ((q & 7) >> 1) * 4 + (q & 1) + ((q >> 3) << 1);   // natural granule = kb' * 4 + j'
-    int m = m0 + r;
-    m = m < a.M ? m : a.M - 1;
-    aptr[it] = A4 ? Ap + (long)m * (a.K / 2) + ns * 8 : Ap + (long)m * a.K * ASZ + ns * 16;
-    const int phys = (((ns & 3) << 2) | (ns >> 2)) ^ (r & 15);
-    a_lds_off[it] = r * P::ROW_BYTES + phys * 16;
+    const int phys = (((ns & 3) << 2) | (ns >> 2)) ^ (r0 & 15);
+    a_lds_off0 = r0 * P::ROW_BYTES + phys * 16;
+#pragma unroll
+    for (int it = 0; it < AG; ++it) {
+      int r = it * (P::THREADS / 16) + r0;
+      r = m0 + r < a.M ? r : a.M - 1 - m0;                         // clamped rows are never stored
+      aoff[it] = (uint32_t)(r * (int)a_row_bytes) + (uint32_t)(ns * (A4 ? 8 : 16));
+    }
   }
   // packed int4 activations: a granule of 16 elements is 8 bytes in memory; widened to int8 on the way
   // into LDS, so everything downstream is the int8 path
@@ -458,12 +465,12 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_kernel(const GemmArgs a) {
   auto a_load = [&](int t) {
     const long koff = (long)t * ASTEP;
 #pragma unroll
-    for (int it = 0; it < AG; ++it) areg[it] = granule_load(aptr[it] + koff);
+    for (int it = 0; it < AG; ++it) areg[it] = granule_load(a_tile + koff + aoff[it]);
   };
   auto a_store = [&](int buf) {
 #pragma unroll
     for (int it = 0; it < AG; ++it)
-      *reinterpret_cast<u32x4*>(smem_raw + buf * (P::BM * P::ROW_BYTES) + a_lds_off[it]) = granule_lds(areg[it]);
+      *reinterpret_cast<u32x4*>(smem_raw + buf * (P::BM * P::ROW_BYTES) + a_lds_off0 + it * LDS_IT_STRIDE) = granule_lds(areg[it]);
   };
 
   // ---- weight lane loads ----
@@ -659,7 +666,7 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_kernel(const GemmArgs a) {
       const int t = t0 + q < a.nsteps ? t0 + q : a.nsteps - 1;
       const long koff = (long)t * ASTEP;
 #pragma unroll
-      for (int it = 0; it < AG; ++it) areg_s[q][it] = granule_load(aptr[it] + koff);
+      for (int it = 0; it < AG; ++it) areg_s[q][it] = granule_load(a_tile + koff + aoff[it]);
     }
     BLane<P> bs[S];
 #pragma unroll
@@ -668,7 +675,7 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_kernel(const GemmArgs a) {
     for (int q = 0; q < S; ++q)
 #pragma unroll
       for (int it = 0; it < AG; ++it)
-        *reinterpret_cast<u32x4*>(smem_raw + q * (P::BM * P::ROW_BYTES) + a_lds_off[it]) = granule_lds(areg_s[q][it]);
+        *reinterpret_cast<u32x4*>(smem_raw + q * (P::BM * P::ROW_BYTES) + a_lds_off0 + it * LDS_IT_STRIDE) = granule_lds(areg_s[q][it]);
     __syncthreads();
 #pragma unroll
     for (int q = 0; q < S; ++q)
