@@ -175,13 +175,15 @@ __device__ __forceinline__ void lut16_word(const Lut16& t, uint32_t w, half2_t (
 
 // the reference's fp4 decode table: s = q>>3, e = q&7, e==0 -> 0 else (-1)^s 2^(e-7)
 // (quantization.py:141-156)
-__device__ __forceinline__ Lut16 make_fp4_lut() {
+__device__ __forceinline__ Lut16 make_fp4_lut(bool bf16 = false) {
   half_t tbl[16];
 #pragma unroll
   for (int q = 0; q < 16; ++q) {
     const int e = q & 7;
-    const uint16_t bits = e == 0 ? (uint16_t)0 : (uint16_t)((((q >> 3) << 5) | (e | 8)) << 10);
-    tbl[q] = __builtin_bit_cast(half_t, bits);
+    // half: sign | (e + 8) << 10 (= 2^(e-7)); bfloat16: sign | (e - 7 + 127) << 7 - both exact
+    const uint16_t hbits = e == 0 ? (uint16_t)0 : (uint16_t)((((q >> 3) << 5) | (e | 8)) << 10);
+    const uint16_t bbits = e == 0 ? (uint16_t)0 : (uint16_t)(((q >> 3) << 15) | ((e + 120) << 7));
+    tbl[q] = __builtin_bit_cast(half_t, bf16 ? bbits : hbits);
   }
   return make_lut16(tbl);
 }

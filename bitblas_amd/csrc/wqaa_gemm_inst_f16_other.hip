@@ -27,6 +27,9 @@ gemm_fn pick_gemm_bf16(int kind, int mode, int mf) {
     case DK_INT4: return pick_bf_modes<DK_INT4>(mode, mf);
     case DK_INT2: return pick_bf_modes<DK_INT2>(mode, mf);
     case DK_INT8: return pick_bf_modes<DK_INT8>(mode, mf);
+    case DK_INT1: return pick_bf_modes<DK_INT1>(mode, mf);
+    case DK_LUT4: return mode == MD_ZQ ? nullptr : pick_bf_modes<DK_LUT4>(mode, mf);
+    case DK_E4M3: return mode == MD_ZQ ? nullptr : pick_bf_modes<DK_E4M3>(mode, mf);
     case DK_NATIVE: return mode == MD_NONE ? pick_mf<DK_NATIVE, LAYOUT_PLAIN, AT_F16, MD_NONE, FL_BF16>(mf) : nullptr;
   }
   return nullptr;

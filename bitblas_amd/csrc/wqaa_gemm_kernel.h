@@ -237,11 +237,40 @@ __device__ __forceinline__ void dequant_lane_f16(const uint32_t (&w)[P::WL], hal
 // bfloat16 flavour: natural order straight away (plain layout), one rounding per element
 template <class P>
 __device__ __forceinline__ void dequant_lane_bf16(const uint32_t (&w)[P::WL], float zf, float s, bool is_signed,
-                                                  uint32_t flip, uint32_t (&frag)[P::NJ][4]) {
+                                                  uint32_t flip, const Lut16& lut, uint32_t (&frag)[P::NJ][4]) {
   using T = typename P::T;
   constexpr int EPW = P::EPW;
   constexpr bool SC = P::MODE != MD_NONE;
-  if constexpr (T::SUBBYTE) {
+  if constexpr (P::KIND == DK_LUT4) {
+    // nf4 / fp4: table entries are bfloat16 bit patterns; scale with one rounding, then natural order
+#pragma unroll
+    for (int wi = 0; wi < P::WL; ++wi) {
+      half2_t q[EPW / 2];
+      lut16_word(lut, w[wi], q);
+      if constexpr (SC) {
+#pragma unroll
+        for (int i = 0; i < EPW / 2; ++i) q[i] = as_h2(bf16x2_scale(as_u32(q[i]), s));
+      }
+      uint32_t nat[EPW / 2];
+      to_natural_f16<T, P::LAYOUT>(q, nat, std::make_integer_sequence<int, EPW / 2>{});
+#pragma unroll
+      for (int i = 0; i < EPW / 2; ++i) {
+        const int e = wi * EPW + 2 * i;
+        frag[e / 8][(e % 8) / 2] = nat[i];
+      }
+    }
+  } else if constexpr (P::KIND == DK_E4M3) {
+    // exact e4m3 -> fp16 -> float, then the scale and one bfloat16 rounding
+#pragma unroll
+    for (int wi = 0; wi < P::WL; ++wi) {
+      half2_t t[2];
+      unpack_e4m3_f16<false>(w[wi], t);
+      const float sc = SC ? s : 1.f;
+      const int e0 = wi * 4;
+      frag[e0 / 8][(e0 % 8) / 2] = cvt_pk_bf16((float)t[0][0] * sc, (float)t[0][1] * sc);
+      frag[e0 / 8][(e0 % 8) / 2 + 1] = cvt_pk_bf16((float)t[1][0] * sc, (float)t[1][1] * sc);
+    }
+  } else if constexpr (T::SUBBYTE) {
 #pragma unroll
     for (int wi = 0; wi < P::WL; ++wi) {
       uint32_t pk[EPW / 2];
@@ -508,7 +537,7 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_kernel(const GemmArgs a) {
   Lut16 lut;
   if constexpr (P::KIND == DK_LUT4) {
     if (a.fp4_table) {
-      lut = make_fp4_lut();
+      lut = make_fp4_lut(P::BF);
     } else {
       lut = make_lut16(reinterpret_cast<const half_t*>(a.lut));
     }
@@ -537,7 +566,7 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_kernel(const GemmArgs a) {
         const half2_t z2 = (MODE == MD_ZO || MODE == MD_ZR) ? splat(bits_to_half(bl.z[nf])) : splat((half_t)0.0f);
         if constexpr (P::BF)
           dequant_lane_bf16<P>(bl.w[nf], (float)zf, MODE != MD_NONE ? bf16_bits_to_float(bl.s[nf]) : 1.f, a.is_signed != 0,
-                               cx.flip, bfrag[nf]);
+                               cx.flip, lut, bfrag[nf]);
         else
           dequant_lane_f16<P>(bl.w[nf], zf, s2, z2, cx, lut, bfrag[nf]);
       } else if constexpr (F8) {
@@ -842,7 +871,7 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_decode_kernel(const GemmAr
   const uint32_t zp4 = (!F16 && a.is_signed && T::SUBBYTE) ? (uint32_t)(1u << (T::BITS - 1)) * 0x01010101u : 0u;
   Lut16 lut;
   if constexpr (P::KIND == DK_LUT4) {
-    if (a.fp4_table) lut = make_fp4_lut();
+    if (a.fp4_table) lut = make_fp4_lut(P::BF);
     else lut = make_lut16(reinterpret_cast<const half_t*>(a.lut));
   }
 
@@ -862,7 +891,7 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_decode_kernel(const GemmAr
       const half2_t s2 = MODE != MD_NONE ? splat(bits_to_half(bl.s[0])) : splat((half_t)1.0f);
       const half2_t z2 = (MODE == MD_ZO || MODE == MD_ZR) ? splat(bits_to_half(bl.z[0])) : splat((half_t)0.0f);
       if constexpr (P::BF)
-        dequant_lane_bf16<P>(bl.w[0], (float)zf, MODE != MD_NONE ? bf16_bits_to_float(bl.s[0]) : 1.f, a.is_signed != 0, cx.flip, bfrag);
+        dequant_lane_bf16<P>(bl.w[0], (float)zf, MODE != MD_NONE ? bf16_bits_to_float(bl.s[0]) : 1.f, a.is_signed != 0, cx.flip, lut, bfrag);
       else
         dequant_lane_f16<P>(bl.w[0], zf, s2, z2, cx, lut, bfrag);
     } else if constexpr (F8) {

@@ -436,7 +436,7 @@ __global__ void __launch_bounds__(1024) wq_gemv_kernel(const GemvArgs a) {
   Lut16 lut;
   if constexpr (P::KIND == DK_LUT4) {
     if (a.fp4_table) {
-      lut = make_fp4_lut();
+      lut = make_fp4_lut(P::BF);
     } else {
       lut = make_lut16(reinterpret_cast<const half_t*>(a.lut));
     }
@@ -477,7 +477,14 @@ __global__ void __launch_bounds__(1024) wq_gemv_kernel(const GemvArgs a) {
           }
           if constexpr (P::BF) {
             // bf16: integer fields (minus the integer zero point) times the scale, one rounding
-            if constexpr (T::SUBBYTE) {
+            if constexpr (P::KIND == DK_LUT4) {
+              // nf4 / fp4: 16-bit table entries (bfloat16 bit patterns), then one rounding for the scale
+              half2_t t[4];
+              lut16_word(lut, s.w[r][u], t);
+#pragma unroll
+              for (int i = 0; i < 4; ++i)
+                q[r][i] = MODE == MD_NONE ? t[i] : as_h2(bf16x2_scale(as_u32(t[i]), bf16_bits_to_float(s.s[r])));
+            } else if constexpr (T::SUBBYTE) {
               uint32_t pk[G / 2];
               unpack_word_bf16<T::BITS, 0>(s.w[r][u] ^ (P::KIND == DK_INT1 ? cx.flip : 0u), (float)zf,
                                            bf16_bits_to_float(s.s[r]), MODE != MD_NONE, pk);
@@ -499,6 +506,14 @@ __global__ void __launch_bounds__(1024) wq_gemv_kernel(const GemvArgs a) {
                   }
                   q[r][2 * j] = as_h2(cvt_pk_bf16(v[0], v[1]));
                   q[r][2 * j + 1] = as_h2(cvt_pk_bf16(v[2], v[3]));
+                } else if constexpr (P::KIND == DK_E4M3) {
+                  // e4m3 -> fp16 is exact (IEEE decode: the reference has no bfloat16 variant of its bit
+                  // trick, quantization.py:169-176 asserts float16), fp16 -> bf16 of an e4m3 value too
+                  half2_t t[2];
+                  unpack_e4m3_f16<false>(x, t);
+                  const float sc = MODE != MD_NONE ? bf16_bits_to_float(s.s[r]) : 1.f;
+                  q[r][2 * j] = as_h2(cvt_pk_bf16((float)t[0][0] * sc, (float)t[0][1] * sc));
+                  q[r][2 * j + 1] = as_h2(cvt_pk_bf16((float)t[1][0] * sc, (float)t[1][1] * sc));
                 } else {
                   q[r][j] = as_h2(x);   // native bf16 weights
                 }
@@ -673,6 +688,8 @@ static gemv_fn pick_kernel(int kind, int layout, int at, int mode, int flags, in
       case DK_INT2: return WQAA_BF_PICK(DK_INT2);
       case DK_INT1: return WQAA_BF_PICK(DK_INT1);
       case DK_INT8: return WQAA_BF_PICK(DK_INT8);
+      case DK_LUT4: return mode == MD_ZQ ? nullptr : WQAA_BF_PICK(DK_LUT4);
+      case DK_E4M3: return mode == MD_ZQ ? nullptr : WQAA_BF_PICK(DK_E4M3);
       case DK_NATIVE: return mode == MD_NONE ? pick_mb<DK_NATIVE, LAYOUT_PLAIN, AT_F16, MD_NONE, FL_BF16>(mb) : nullptr;
     }
 #undef WQAA_BF_PICK
@@ -777,14 +794,15 @@ static int classify(const wqaa_matmul_desc& d, GemvChoice* c) {
     set_error(WQAA_ERR_UNSUPPORTED, "gemv: fp8 activations need fp8 weights");
     return WQAA_ERR_UNSUPPORTED;
   }
-  if (c->kind == DK_E4M3 && d.strict_reference && !(c->flags & FL_A8)) c->flags |= FL_STRICT;
+  if (c->kind == DK_E4M3 && d.strict_reference && !(c->flags & (FL_A8 | FL_BF16))) c->flags |= FL_STRICT;
   if (c->kind != DK_INT4 && c->kind != DK_INT2 && c->kind != DK_INT1) c->layout = LAYOUT_PLAIN;
   if (at_is_int(c->at) && (d.with_scaling || d.zeros_mode != WQAA_Z_NONE)) {
     set_error(WQAA_ERR_UNSUPPORTED, "gemv: scale/zeros with int8 activations are not defined by the reference");
     return WQAA_ERR_UNSUPPORTED;
   }
   if (c->flags & FL_BF16) {
-    const bool kind_ok = c->kind == DK_INT4 || c->kind == DK_INT2 || c->kind == DK_INT1 || c->kind == DK_INT8 || c->kind == DK_NATIVE;
+    const bool kind_ok = c->kind == DK_INT4 || c->kind == DK_INT2 || c->kind == DK_INT1 || c->kind == DK_INT8 || c->kind == DK_NATIVE ||
+                         c->kind == DK_LUT4 || c->kind == DK_E4M3;
     const bool zeros_ok = d.zeros_mode == WQAA_Z_NONE || d.zeros_mode == WQAA_Z_QUANTIZED || !d.with_scaling;
     if (!kind_ok || !zeros_ok || c->layout != LAYOUT_PLAIN) {
       set_error(WQAA_ERR_UNSUPPORTED, "gemv: bfloat16 activations support plain-layout integer / bf16 weights with "

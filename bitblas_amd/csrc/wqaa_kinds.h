@@ -132,6 +132,12 @@ __device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {
   asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
   return r;
 }
+// two bfloat16 values (one register) times a float, rounded back to bfloat16
+__device__ __forceinline__ uint32_t bf16x2_scale(uint32_t bits, float sc) {
+  const float lo = __builtin_bit_cast(float, bits << 16), hi = __builtin_bit_cast(float, bits & 0xFFFF0000u);
+  return cvt_pk_bf16(lo * sc, hi * sc);
+}
+
 __device__ __forceinline__ float bf16_bits_to_float(uint32_t b) { return __builtin_bit_cast(float, (b & 0xFFFFu) << 16); }
 
 // fields of one 32-bit word -> EPW/2 packed bf16 pairs.  PAIR_ORDER selects which two fields share a

@@ -322,7 +322,9 @@ def _dequantize_weight_bf16(codes, source_format, bit, K, scale, zeros, zeros_mo
     if with_zeros and zeros_mode == "quantized":
         w = bf16_round(_quantized_zero_difference(codes, zeros, bit, gi).astype(np.float32))
     else:
-        w = bf16_round(decode_codes(codes, source_format, bit, True, lut).astype(np.float32))
+        # e4m3: exact IEEE decode - the reference's bit trick exists for float16 only
+        # (quantization.py:169-176 asserts dtype == "float16")
+        w = bf16_round(decode_codes(codes, source_format, bit, source_format != "fp_e4m3", lut).astype(np.float32))
     if scale is None:
         return w
     sc = bf16_round(np.asarray(scale, dtype=np.float32))[:, gi]

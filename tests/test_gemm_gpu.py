@@ -204,6 +204,11 @@ def _bf16_case(M, N, K, W_dtype, g, with_scaling, zeros_mode=None, seed=0):
     if src == "uint":
         w_user = rng.integers(0, 1 << bit, size=(N, K)).astype(np.int8) if bit < 8 else rng.integers(0, 128, size=(N, K)).astype(np.int8)
         codes = w_user
+    elif src in ("nf", "fp"):
+        codes = w_user = rng.integers(0, 16, size=(N, K)).astype(np.int8)
+    elif src == "fp_e4m3":
+        w8 = torch.from_numpy((rng.random((N, K), dtype=np.float32) * 2 - 1)).to(torch.float8_e4m3fn)
+        codes = w_user = w8.view(torch.int8).numpy()
     else:
         maxq = 1 << (bit - 1)
         w_user = rng.integers(-maxq, maxq, size=(N, K)).astype(np.int8)
@@ -283,3 +288,13 @@ def test_decode_batch_member_against_the_split_k_member(M, kw, monkeypatch):
     else:
         assert_fp_parity(got, want)
         assert_fp_parity(got2, want)
+
+
+@pytest.mark.parametrize("M", [1, 4, 64, 300])
+@pytest.mark.parametrize("W_dtype,g,ws", [("nf4", -1, False), ("nf4", 128, True), ("fp4_e2m1", -1, False), ("fp4_e2m1", 64, True),
+                                          ("e4m3_float8", -1, False), ("e4m3_float8", 128, True), ("uint1", 128, True)])
+def test_bf16_activations_other_weight_formats(M, W_dtype, g, ws):
+    """the BF16 rows of the reference's support matrix (README.md:63-70) beyond the integer formats: NF4 (table
+    in bfloat16, general_matmul/__init__.py:413-434), FP4_E2M1, FP8_E4M3 (exact decode) and UINT1 on the MFMA path"""
+    out, want, mm = _bf16_case(M, 512, 1024, W_dtype, g, ws, None, seed=M)
+    assert_fp_parity(out, want, rtol=1e-5, atol_frac=1e-5)

@@ -88,7 +88,7 @@ def test_random_bf16_configurations():
     rng = np.random.default_rng(77)
     ran = 0
     for _ in range(60):
-        wd = str(rng.choice(["uint4", "int4", "uint2", "int2", "uint1", "uint8", "int8"]))
+        wd = str(rng.choice(["uint4", "int4", "uint2", "int2", "uint1", "uint8", "int8", "nf4", "fp4_e2m1", "e4m3_float8"]))
         M, N, K = int(rng.choice(MS)), int(rng.choice([64, 128, 272, 520])), int(rng.choice(KS))
         ws = bool(rng.random() < 0.7)
         g = int(rng.choice([-1, 64, 128, 256])) if ws else -1
