@@ -29,7 +29,7 @@ def draw(rng):
     M, N, K = int(rng.choice(MS)), int(rng.choice(NS)), int(rng.choice(KS))
     kw = dict(W_dtype=wd, A_dtype="int8" if a_int8 else "float16")
     if a_int8:
-        kw["out_dtype"] = str(rng.choice(["int32", "float32"]))
+        kw["out_dtype"] = str(rng.choice(["int32", "float32", "float16", "int8"]))   # README.md:79-82
         kw["fast_decoding"] = [None, False, True][int(rng.integers(3))] if wd not in ("int8",) else None
         if wd in ("int4", "uint4"):
             kw["fast_decoding"] = [None, False][int(rng.integers(2))]   # the reference never interleaves int4 for int8
@@ -60,6 +60,8 @@ def test_random_configurations(chunk):
         bit = bitblas.Matmul.BITBLAS_TRICK_DTYPE_MAP[kw["W_dtype"]][1]
         if kw.get("zeros_mode") == "quantized" and (N * bit) % 8:
             continue          # packed zero points need whole bytes per row (QZeros is (K/g, N*bit/8))
+        if os.environ.get("WQAA_SWEEP_VERBOSE"):
+            print("draw", M, N, K, kw, flush=True)
         try:
             case = make_case(M, N, K, seed=int(rng.integers(1 << 30)), **kw)
             got, mm = hip_output(case)
