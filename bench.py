@@ -161,6 +161,47 @@ def time_member_gemm(device, gen, M=4096, N=4096, K=4096, W_dtype="uint4", A_dty
             "frac_of_mfma_peak": tf / peak, "mfma_peak": peak}
 
 
+def time_member_dense(device, gen, M, N, K, kind="fp8", n_buf=4):
+    """Dense members: e4m3 x e4m3 MFMA GEMM on Llama-3-70B shapes (BASELINE config c5, one GPU's unsharded
+    matrix) and the M = 1 W_int2 A_int8 GEMV (c4)."""
+    import bitblas_amd as bitblas
+    try:
+        if kind == "fp8":
+            cfg = bitblas.MatmulConfig(M=M, N=N, K=K, A_dtype="e4m3_float8", W_dtype="e4m3_float8", accum_dtype="float32",
+                                       out_dtype="float16")
+        else:
+            cfg = bitblas.MatmulConfig(M=M, N=N, K=K, A_dtype="int8", W_dtype="int2", accum_dtype="int32", out_dtype="int32")
+        op = bitblas.Matmul(cfg, enable_tuning=False)
+    except Exception as exc:  # member not built: report, never fake
+        return {"error": str(exc)}
+    if kind == "fp8":
+        A = (torch.rand((M, K), device=device, generator=gen) * 2 - 1).to(torch.float8_e4m3fn)
+        Ws = [(torch.rand((N, K), device=device, generator=gen) * 2 - 1).to(torch.float8_e4m3fn) for _ in range(n_buf)]
+        out = torch.empty((M, N), dtype=torch.float16, device=device)
+        wbytes = N * K
+    else:
+        A = torch.randint(-128, 128, (M, K), device=device, dtype=torch.int8, generator=gen)
+        Ws = [torch.randint(-128, 128, (N, K // 4), dtype=torch.int8, device=device, generator=gen) for _ in range(n_buf)]
+        out = torch.empty((M, N), dtype=torch.int32, device=device)
+        wbytes = N * K // 4
+
+    def launch_all():
+        stream = torch.cuda.current_stream(device).cuda_stream
+        for W in Ws:
+            op.lib.run(A.data_ptr(), W.data_ptr(), None, None, None, None, out.data_ptr(), M, stream)
+
+    t = graph_time(device, launch_all, n_buf)
+    res = {"workload": f"{'e4m3 x e4m3' if kind == 'fp8' else 'W_int2 A_int8'} M={M} N={N} K={K}",
+           "kernel": op.plans[M]["name"], "us_per_launch": t * 1e6}
+    if M == 1:
+        nbytes = M * K + wbytes + M * N * out.element_size()
+        res.update(bytes_per_launch=nbytes, GBps=nbytes / t / 1e9, frac_of_hbm_peak=nbytes / t / 1e9 / HBM_PEAK_GBS)
+    else:
+        tf = 2.0 * M * N * K / t / 1e12
+        res.update(TFLOPs=tf, frac_of_mfma_peak=tf / MFMA_I8_PEAK_TOPS, mfma_peak=MFMA_I8_PEAK_TOPS)
+    return res
+
+
 def cpu_baseline(max_seconds=20.0):
     """The CPU oracle (numpy/torch restatement of the reference's TE definition) timed on the host
     cores: dequantise (fp16) + fp32 matmul for the M=1, N=K=4096 member.  Bounded sample."""
@@ -335,6 +376,10 @@ def main():
             members["gemm_uint4_m128"] = time_member_gemm(device, gen, 128)
             members["gemm_uint4_m16"] = time_member_gemm(device, gen, 16)
             members["gemm_int2_int8_m4096"] = time_member_gemm(device, gen, 4096, W_dtype="int2", A_dtype="int8")
+            members["gemv_int2_int8_m1"] = time_member_dense(device, gen, 1, 4096, 4096, kind="int2", n_buf=64)
+            # Llama-3-70B linears, dense fp8 (c5): o_proj and down_proj of one (unsharded) GPU
+            members["gemm_fp8_m4096_n8192_k8192"] = time_member_dense(device, gen, 4096, 8192, 8192)
+            members["gemm_fp8_m4096_n8192_k28672"] = time_member_dense(device, gen, 4096, 8192, 28672, n_buf=2)
             result["members"] = members
         if not args.no_cpu_baseline and world == 1:
             result["cpu_baseline"] = cpu_baseline()
