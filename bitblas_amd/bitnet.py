@@ -26,6 +26,7 @@ class BitLinear(nn.Module):
                               out_dtype="float16", accum_dtype="int32", with_bias=bias, with_scaling=False,
                               with_zeros=False, zeros_mode=None)
         self.bitblas_matmul = Matmul(config, enable_tuning=False)
+        self.fuse_activation_quant = True      # batches of <= 4 rows: quantise inside the matmul launch
         self.register_buffer("qweight", torch.zeros(self.bitblas_matmul.retrieve_weight_shape(), dtype=torch.int8))
         self.register_buffer("sw", torch.ones((), dtype=torch.float32))
         if bias:
@@ -62,12 +63,19 @@ class BitLinear(nn.Module):
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         if not x.is_cuda:
             raise RuntimeError("bitblas_amd.bitnet.BitLinear runs on the GPU only")
-        q, si = self.activation_quant(x)
-        m = q.numel() // self.in_features
+        m = x.numel() // self.in_features
         out = torch.empty(x.shape[:-1] + (self.out_features,), dtype=torch.float16, device=x.device)
         sw = getattr(self, "_sw_host", None)
         if sw is None:
             sw = self._sw_host = float(self.sw)
+        if m <= 4 and x.dtype == torch.float16 and self.fuse_activation_quant:
+            # decode steps: quantise + matmul + rescale in ONE launch (the GEMV workgroup quantises the row itself)
+            xc = x if x.is_contiguous() else x.contiguous()
+            self.bitblas_matmul.lib.run_fused_quant(xc.data_ptr(), self.qweight.data_ptr(),
+                                                    None if self.bias is None else self.bias.data_ptr(), out.data_ptr(), m,
+                                                    torch.cuda.current_stream(x.device).cuda_stream, sw)
+            return out
+        q, si = self.activation_quant(x)
         self.bitblas_matmul.lib.run_fused(q.data_ptr(), self.qweight.data_ptr(),
                                           None if self.bias is None else self.bias.data_ptr(), out.data_ptr(), m,
                                           torch.cuda.current_stream(x.device).cuda_stream, si.data_ptr(), sw)

@@ -122,9 +122,17 @@ static int matmul_impl(const wqaa_matmul_desc* desc, const void* A, const void* 
   dispatch(*desc, m, &use_gemm);
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   hipEvent_t e0 = reinterpret_cast<hipEvent_t>(ev0), e1 = reinterpret_cast<hipEvent_t>(ev1);
-  if (epi && (epi->struct_size != (int32_t)sizeof(wqaa_epilogue) || !epi->row_scale)) {
+  const bool quant_in = epi && (epi->flags & WQAA_EPI_QUANTIZE_INPUT);
+  if (epi && (epi->struct_size != (int32_t)sizeof(wqaa_epilogue) || (!epi->row_scale && !quant_in))) {
     set_error(WQAA_ERR_BAD_DESC, "matmul_ex: malformed epilogue descriptor");
     return WQAA_ERR_BAD_DESC;
+  }
+  if (quant_in) {
+    if (m > 4) {
+      set_error(WQAA_ERR_UNSUPPORTED, "matmul_ex: in-kernel activation quantisation covers m <= 4 (got %d)", m);
+      return WQAA_ERR_UNSUPPORTED;
+    }
+    use_gemm = false;   // a GEMV-family member; refuses loudly if the config has none
   }
   int st = use_gemm ? gemm_launch(*desc, A, B, LUT, Scale, Zeros, Bias, C, m, s, e0, e1, epi)
                     : gemv_launch(*desc, A, B, LUT, Scale, Zeros, Bias, C, m, s, e0, e1, epi);

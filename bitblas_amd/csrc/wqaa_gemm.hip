@@ -308,6 +308,7 @@ void gemm_init() {
               gemm_fn fn = pick_gemm(kind, layout, at, mode, flags, mf);
               if (fn) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             }
+  (void)hipGetLastError();   // a refused attribute must not linger as this thread's "last error"
 }
 
 }  // namespace wqaa

@@ -78,10 +78,14 @@ struct GemvPolicy {
   // the slice would have to be re-read every step (64 B of A per 32 B of weights through the same
   // texture path: 8192x28672 29.7 -> 30.5 us), so those and all batch tiles > 1 keep the LDS tile.
   static constexpr bool A4 = AT_ == AT_I4;              // packed int4 activations, widened while staged
-  static constexpr bool AD = AD_ && MB_ == 1 && !A8 && !A4;
+  // BitNet layers (integration/BitNet/utils_quant.py:161-168, 205-216): the activations arrive as fp16 and
+  // the workgroup applies the per-token absmax int8 quantiser itself while it stages them - the
+  // caller's quantise -> matmul -> rescale chain is one launch
+  static constexpr bool AQ = (FLAGS_ & FL_AQ) != 0 && AT_ == AT_I8;
+  static constexpr bool AD = AD_ && MB_ == 1 && !A8 && !A4 && !AQ;
   using T = KindTraits<KIND_, AT_>;
   // words of raw activation data per staging item (one decode unit = G elements)
-  static constexpr int AW = AT_ == AT_I4 ? T::G / 8 : (AT_ == AT_I8 || A8) ? T::G / 4 : T::G / 2;
+  static constexpr int AW = AT_ == AT_I4 ? T::G / 8 : AQ ? T::G / 2 : (AT_ == AT_I8 || A8) ? T::G / 4 : T::G / 2;
   // activation items per thread loaded ahead of the weights (<= 32 VGPRs)
   static constexpr int NA = 32 / AW > 8 ? 8 : (32 / AW < 1 ? 1 : 32 / AW);
 };
@@ -185,13 +189,14 @@ __device__ __forceinline__ void a_item_load(const GemvArgs& a, int m0, int idx, 
   const int kb = (c * 64 + l) * T::E + u * T::G;
   it.valid = kb < a.K && (m0 + mi) < a.m;
   const long off = it.valid ? (long)(m0 + mi) * a.K + kb : 0;   // clamped: always a readable address
-  constexpr int esz = (P::AT == AT_I8 || P::A8) ? 1 : 2;
+  constexpr int esz = ((P::AT == AT_I8 && !P::AQ) || P::A8) ? 1 : 2;
   if constexpr (P::A4) load_words<P::AW>(reinterpret_cast<const uint8_t*>(a.A) + off / 2, it.w);   // two per byte
   else load_words<P::AW>(reinterpret_cast<const uint8_t*>(a.A) + off * esz, it.w);
 }
 
 template <class P>
-__device__ __forceinline__ void a_item_store(const GemvArgs& a, int ncp, int idx, const AItem<P>& it, u32x4* a_lds) {
+__device__ __forceinline__ void a_item_store(const GemvArgs& a, int ncp, int idx, const AItem<P>& it, u32x4* a_lds,
+                                             float aq_s = 0.f) {
   using T = typename P::T;
   constexpr int G = T::G, PE = T::PE, PU = T::PU, UNITS = T::UNITS, PIECES = T::PIECES;
   const int mi = idx % P::MB;
@@ -226,7 +231,16 @@ __device__ __forceinline__ void a_item_store(const GemvArgs& a, int ncp, int idx
     }
   } else {
     uint8_t src[G];
-    if constexpr (P::A4) {
+    if constexpr (P::AQ) {
+      // q = clamp(round(x * s), -128, 127), round half to even (torch.round), utils_quant.py:165-167
+#pragma unroll
+      for (int e = 0; e < G; ++e) {
+        const half2_t h = as_h2(it.w[e / 2]);
+        float q = rintf((float)h[e & 1] * aq_s);
+        q = fminf(fmaxf(q, -128.f), 127.f);
+        src[e] = (uint8_t)(int)q;
+      }
+    } else if constexpr (P::A4) {
 #pragma unroll
       for (int q = 0; q < G / 8; ++q) {
         uint32_t lo4, hi4;
@@ -367,10 +381,21 @@ __global__ void __launch_bounds__(1024) wq_gemv_kernel(const GemvArgs a) {
   // ---- activations (batch tiles > 1): tiles larger than NA items/thread go through a plain loop first ----
   constexpr bool AD = P::AD;
   const int total_items = AD ? 0 : MB * ncp * 64 * UNITS;
+  constexpr bool AQ = P::AQ;
+  float aq_mx = 0.f;                      // AQ: max |x| over this thread's items (all of row tid % MB)
+  auto item_absmax = [&](const AItem<P>& it) {
+    if (!it.valid) return;
+#pragma unroll
+    for (int e = 0; e < P::AW; ++e) {
+      const half2_t h = as_h2(it.w[e]);
+      aq_mx = fmaxf(aq_mx, fmaxf(fabsf((float)h[0]), fabsf((float)h[1])));
+    }
+  };
   for (int idx = NA * nthreads + tid; idx < total_items; idx += nthreads) {
     AItem<P> it;
     a_item_load<P>(a, m0, idx, it);
-    a_item_store<P>(a, ncp, idx, it, a_lds);
+    if constexpr (AQ) item_absmax(it);     // first pass: the scale needs the whole row; stored in the second pass
+    else a_item_store<P>(a, ncp, idx, it, a_lds);
   }
   // the first NA items per thread: loads now (ahead of the weight stream), LDS writes after the
   // first weight step has been issued
@@ -425,7 +450,42 @@ __global__ void __launch_bounds__(1024) wq_gemv_kernel(const GemvArgs a) {
   const bool have_work = rg < n_rg;
   issue(st, have_work ? rg : n_rg - 1, 0, true);
 
-  if constexpr (!AD) {
+  float aq_s[MB];                         // AQ: 127 / clamp(max |row|, 1e-5) of every row of the batch tile
+#pragma unroll
+  for (int mi = 0; mi < MB; ++mi) aq_s[mi] = 1.f;
+  if constexpr (AQ) {
+    // per-wave row maxima live behind the activation tile in the dynamic LDS block (the host adds 256 B)
+    float* aq_wmax = reinterpret_cast<float*>(a_lds + (long)MB * ncp * T::PIECES * 64);
+#pragma unroll
+    for (int j = 0; j < NA; ++j)
+      if (j * nthreads + tid < total_items) item_absmax(ahead[j]);
+    // a thread's items all sit in row tid % MB (item strides are multiples of MB): butterfly over the
+    // lanes of the same row, then across the waves through LDS
+#pragma unroll
+    for (int off = 32; off >= MB; off >>= 1) aq_mx = fmaxf(aq_mx, __shfl_xor(aq_mx, off));
+    if (lane < MB) aq_wmax[wave * 4 + lane] = aq_mx;
+    __syncthreads();
+#pragma unroll
+    for (int mi = 0; mi < MB; ++mi) {
+      float mx = 0.f;
+      for (int w = 0; w < NW; ++w) mx = fmaxf(mx, aq_wmax[w * 4 + mi]);
+      // IEEE-exact quotient (fp64 divide, one rounding): the default fp32 division is not correctly rounded
+      aq_s[mi] = (float)(127.0 / (double)fmaxf(mx, 1e-5f));
+    }
+    float my_s = aq_s[0];
+#pragma unroll
+    for (int mi = 1; mi < MB; ++mi) my_s = (tid % MB) == mi ? aq_s[mi] : my_s;
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+      const int idx = j * nthreads + tid;
+      if (idx < total_items) a_item_store<P>(a, ncp, idx, ahead[j], a_lds, my_s);
+    }
+    for (int idx = NA * nthreads + tid; idx < total_items; idx += nthreads) {   // second pass over the tail (L2 hits)
+      AItem<P> it;
+      a_item_load<P>(a, m0, idx, it);
+      a_item_store<P>(a, ncp, idx, it, a_lds, my_s);
+    }
+  } else if constexpr (!AD) {
 #pragma unroll
     for (int j = 0; j < NA; ++j) {
       const int idx = j * nthreads + tid;
@@ -604,7 +664,9 @@ __global__ void __launch_bounds__(1024) wq_gemv_kernel(const GemvArgs a) {
                                      : (float)reinterpret_cast<const half_t*>(a.bias)[n];
             store_out(a.C, (long)(m0 + mi) * a.N + n, tot, a.out_dtype, a.has_bias != 0, b);
           } else {
-            if (a.epi_row) {
+            if constexpr (AQ) {
+              store_out_fused(a.C, (long)(m0 + mi) * a.N + n, tot, aq_s[mi], a.epi_tensor, a.has_bias != 0, a.bias, n);
+            } else if (a.epi_row) {
               store_out_fused(a.C, (long)(m0 + mi) * a.N + n, tot, a.epi_row[m0 + mi], a.epi_tensor, a.has_bias != 0, a.bias, n);
             } else {
               const int b = a.has_bias ? (int)reinterpret_cast<const int8_t*>(a.bias)[n] : 0;
@@ -715,6 +777,14 @@ static gemv_fn pick_kernel(int kind, int layout, int at, int mode, int flags, in
     return nullptr;
   }
   if (mode != MD_NONE) return nullptr;
+  if (at == AT_I8 && (flags & FL_AQ)) {   // BitNet layers: fp16 activations quantised in the kernel (sub-byte weights)
+    switch (kind) {
+      case DK_INT4: return layout == LAYOUT_LOP3 ? pick_mb<DK_INT4, LAYOUT_LOP3, AT_I8, MD_NONE, FL_AQ>(mb) : pick_mb<DK_INT4, LAYOUT_PLAIN, AT_I8, MD_NONE, FL_AQ>(mb);
+      case DK_INT2: return layout == LAYOUT_LOP3 ? pick_mb<DK_INT2, LAYOUT_LOP3, AT_I8, MD_NONE, FL_AQ>(mb) : pick_mb<DK_INT2, LAYOUT_PLAIN, AT_I8, MD_NONE, FL_AQ>(mb);
+      case DK_INT1: return layout == LAYOUT_LOP3 ? pick_mb<DK_INT1, LAYOUT_LOP3, AT_I8, MD_NONE, FL_AQ>(mb) : pick_mb<DK_INT1, LAYOUT_PLAIN, AT_I8, MD_NONE, FL_AQ>(mb);
+    }
+    return nullptr;
+  }
   if (at == AT_I4) {   // packed int4 activations: native int4 weights, or 2-bit weights in either layout
     if (kind == DK_INT4) return layout == LAYOUT_PLAIN ? pick_mb<DK_INT4, LAYOUT_PLAIN, AT_I4, MD_NONE, 0>(mb) : nullptr;
     if (kind == DK_INT2) return layout == LAYOUT_LOP3 ? pick_mb<DK_INT2, LAYOUT_LOP3, AT_I4, MD_NONE, 0>(mb) : pick_mb<DK_INT2, LAYOUT_PLAIN, AT_I4, MD_NONE, 0>(mb);
@@ -838,7 +908,7 @@ static int classify(const wqaa_matmul_desc& d, GemvChoice* c) {
 // nine (R, D) shapes tried on 4096x4096 ... 8192x28672.  What the selector has to get right is
 // residency: the activation tile lives in LDS once per workgroup, so for long K the workgroup is
 // widened (up to 16 waves) until the CU holds ~32 waves, i.e. >= 64 KiB of weight loads in flight.
-static int choose(const wqaa_matmul_desc& d, int m, GemvChoice* c) {
+static int choose(const wqaa_matmul_desc& d, int m, GemvChoice* c, bool quant_in = false) {
   int st = classify(d, c);
   if (st != WQAA_OK) return st;
   const int mb = m <= 1 ? 1 : m <= 2 ? 2 : 4;
@@ -851,7 +921,14 @@ static int choose(const wqaa_matmul_desc& d, int m, GemvChoice* c) {
   // and few enough waves per CU that the redundant per-wave reads of A stay cheap (same-box A/B, int4:
   // 1024 rows -4 %, 2048 -3 %, 4096 -2.5 %, 11008 +3 %)
   const int cus0 = device_info().ok ? device_info().cus : 256;
-  const bool direct = mb == 1 && !(c->flags & FL_A8) && c->at != AT_I4 && c->ncp == c->D && (d.N + c->R - 1) / c->R <= 10 * cus0 &&
+  if (quant_in) {
+    if (c->at != AT_I8 || d.a_dtype != WQAA_I8) {
+      set_error(WQAA_ERR_UNSUPPORTED, "gemv: in-kernel activation quantisation needs an int8-activation operator");
+      return WQAA_ERR_UNSUPPORTED;
+    }
+    c->flags |= FL_AQ;
+  }
+  const bool direct = mb == 1 && !(c->flags & (FL_A8 | FL_AQ)) && c->at != AT_I4 && c->ncp == c->D && (d.N + c->R - 1) / c->R <= 10 * cus0 &&
                       !getenv("WQAA_GEMV_NO_DIRECT");
   // small matrices: one row per wave doubles the waves in flight (same-box A/B: 1024 x 1024 2.87 -> 2.45 us,
   // 2048 x 4096 equal, 4096 x 4096 4.18 -> 4.43 us)
@@ -867,6 +944,7 @@ static int choose(const wqaa_matmul_desc& d, int m, GemvChoice* c) {
   const long kpad = (long)c->ncp * 64 * c->E;
   c->lds = (int)(mb * kpad * (c->at == AT_F16 ? 2 : 1));
   if (direct) { c->lds = 0; c->variant = 1; }
+  if (c->flags & FL_AQ) c->lds += 256;   // per-wave row maxima of the in-kernel quantiser
   if (c->lds > 160 * 1024) {
     set_error(WQAA_ERR_UNSUPPORTED, "gemv: activation tile %d B exceeds LDS", c->lds);
     return WQAA_ERR_UNSUPPORTED;
@@ -950,7 +1028,7 @@ int gemv_launch(const wqaa_matmul_desc& d, const void* A, const void* B, const v
                 const void* Scale, const void* Zeros, const void* Bias, void* C, int m,
                 hipStream_t stream, hipEvent_t start, hipEvent_t stop, const wqaa_epilogue* epi) {
   GemvChoice c;
-  int st = choose(d, m, &c);
+  int st = choose(d, m, &c, epi && (epi->flags & WQAA_EPI_QUANTIZE_INPUT));
   if (st != WQAA_OK) return st;
   GemvArgs a;
   fill_args(d, c, A, B, LUT, Scale, Zeros, Bias, C, m, &a);
@@ -984,12 +1062,13 @@ void gemv_init() {
     for (int layout = 0; layout < 2; ++layout)
       for (int at : {(int)AT_F16, (int)AT_I8, (int)AT_I4})
         for (int mode = 0; mode <= MD_ZQ; ++mode)
-          for (int flags : {0, 1, 2, 3, (int)FL_BF16})
+          for (int flags : {0, 1, 2, 3, (int)FL_BF16, (int)FL_AQ})
             for (int mb : kBatchTiles) {
               gemv_fn fn = pick_kernel(kind, layout, at, mode, flags, mb);
               if (fn) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 
             }
+  (void)hipGetLastError();   // a refused attribute must not linger as this thread's "last error"
 }
 
 

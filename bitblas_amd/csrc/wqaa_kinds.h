@@ -15,7 +15,7 @@ enum : int { AT_F16 = 0, AT_I8 = 1, AT_F8 = 2, AT_I4 = 3 };
 constexpr bool at_is_int(int at) { return at == AT_I8 || at == AT_I4; }
 // dequant arithmetic (matmul_dequantize_impl.py:435-449)
 enum : int { MD_NONE = 0, MD_S = 1, MD_ZO = 2, MD_ZR = 3, MD_ZQ = 4 };
-enum : int { FL_STRICT = 1, FL_A8 = 2, FL_ABF8 = 4, FL_BF16 = 8 };   // FL_BF16: the 16-bit float type is bfloat16  // e4m3 reference bit trick; activations stored as fp8 (GEMV); fp8 MFMA activations are e5m2
+enum : int { FL_STRICT = 1, FL_A8 = 2, FL_ABF8 = 4, FL_BF16 = 8, FL_AQ = 16 };   // FL_AQ: int8 GEMV quantises fp16 activations itself   // FL_BF16: the 16-bit float type is bfloat16  // e4m3 reference bit trick; activations stored as fp8 (GEMV); fp8 MFMA activations are e5m2
 
 constexpr int cmax(int a, int b) { return a > b ? a : b; }
 

@@ -26,6 +26,7 @@ W_UINT, W_INT, W_NF, W_FP4, W_E4M3, W_E5M2, W_NATIVE = range(7)
 Z_NONE, Z_ORIGINAL, Z_RESCALE, Z_QUANTIZED = range(4)
 LAYOUT_PLAIN, LAYOUT_LOP3 = 0, 1
 OK, ERR_BAD_DESC, ERR_UNSUPPORTED, ERR_LAUNCH, ERR_NO_DEVICE = range(5)
+EPI_QUANTIZE_INPUT = 1
 
 DTYPE_CODE = {
     "float16": F16, "bfloat16": BF16, "float32": F32, "int8": I8, "int32": I32,
@@ -73,7 +74,7 @@ class Plan(ctypes.Structure):
 
 class Epilogue(ctypes.Structure):
     """struct wqaa_epilogue (include/wqaa.h): fused `out / si / sw -> half` of BitNet-style callers."""
-    _fields_ = [("struct_size", ctypes.c_int32), ("reserved", ctypes.c_int32),
+    _fields_ = [("struct_size", ctypes.c_int32), ("flags", ctypes.c_int32),
                 ("row_scale", ctypes.c_void_p), ("tensor_scale", ctypes.c_float),
                 ("reserved2", ctypes.c_int32)]
 
@@ -246,6 +247,19 @@ class BoundLib:
         epi.row_scale = row_scale_ptr
         epi.tensor_scale = float(tensor_scale)
         status = self._lib.wqaa_matmul_ex(self._desc_ref, A, B, None, None, None, bias, C, m, stream,
+                                          ctypes.byref(epi))
+        if status != OK:
+            check(status)
+
+    def run_fused_quant(self, X, B, bias, C, m, stream, tensor_scale):
+        """BitNet layer in one launch (m <= 4): X is the float16 input; the kernel applies activation_quant
+        itself (WQAA_EPI_QUANTIZE_INPUT) and folds `out / si / sw -> half (+bias)` into its epilogue."""
+        epi = Epilogue()
+        epi.struct_size = ctypes.sizeof(Epilogue)
+        epi.flags = EPI_QUANTIZE_INPUT
+        epi.row_scale = None
+        epi.tensor_scale = float(tensor_scale)
+        status = self._lib.wqaa_matmul_ex(self._desc_ref, X, B, None, None, None, bias, C, m, stream,
                                           ctypes.byref(epi))
         if status != OK:
             check(status)

@@ -141,9 +141,13 @@ int wqaa_matmul_timed(const wqaa_matmul_desc* desc, const void* A, const void* B
  * after it.  `wqaa_act_quant_int8` is the first; `wqaa_matmul_ex` folds the second into the matmul's
  * epilogue:  C[m, n] = half( (float(acc[m, n]) / row_scale[m]) / tensor_scale ) (+ half Bias[n]).
  * Only for int8 activations with out_dtype float16; desc.with_bias then means a float16 bias. */
+#define WQAA_EPI_QUANTIZE_INPUT 1   /* A is the layer's float16 input (m, K): the kernel applies activation_quant
+                                     * itself (per-token absmax -> int8) and uses its own si; row_scale is ignored
+                                     * and may be NULL.  One launch for quantise + matmul + rescale; m <= 4 only
+                                     * (WQAA_ERR_UNSUPPORTED otherwise: quantise with wqaa_act_quant_int8 first) */
 typedef struct wqaa_epilogue {
   int32_t struct_size;      /* = sizeof(wqaa_epilogue) */
-  int32_t reserved;
+  int32_t flags;            /* 0 or WQAA_EPI_QUANTIZE_INPUT */
   const float* row_scale;   /* (m,) si of activation_quant, device pointer */
   float tensor_scale;       /* sw = 1 / mean|W| */
   int32_t reserved2;
