@@ -11,6 +11,15 @@ from bitblas_amd.bitnet import BitLinear
 pytestmark = pytest.mark.gpu
 
 
+def module_codes(lin):
+    """ternary weights as the module holds them (read back from the packed operand): mean|W| reduced on the GPU can
+    differ from a CPU reduction in the last bit, which flips a few borderline weights - not what is under test"""
+    cfg = lin.bitblas_matmul.config
+    layout = wlib.LAYOUT_LOP3 if cfg.fast_decoding else wlib.LAYOUT_PLAIN
+    codes = wlib.unpack_weight(lin.qweight.cpu().numpy(), lin.in_features, 2, layout, wlib.I8)
+    return codes.astype(np.int8) - 2
+
+
 @pytest.mark.parametrize("rows,K", [(1, 4096), (7, 1024), (300, 2560)])
 def test_activation_quant_matches_reference_math(rows, K):
     rng = np.random.default_rng(rows)
@@ -35,9 +44,8 @@ def test_bitlinear_forward(m, bias, seed):
     lin.load_float_weight(torch.from_numpy(w).cuda(), None if b is None else torch.from_numpy(b).cuda())
     x = (rng.standard_normal((m, K))).astype(np.float16)
     got = lin(torch.from_numpy(x).cuda()).cpu().numpy()
-    # sw / the ternary codes come from the module (torch's reduction order for mean|W| differs from
-    # numpy's in the last bit); what is under test is quantiser + matmul + fused epilogue
-    wq = BitLinear.weight_quant(torch.from_numpy(w)).numpy()
+    # sw / the ternary codes come from the module; what is under test is quantiser + matmul + fused epilogue
+    wq = module_codes(lin)
     want = oracle.bitnet_forward(x, wq, np.float32(lin.sw.item()), b)
     # same integer accumulators, same two fp32 divisions, same half rounding: bit exact
     assert np.array_equal(got.view(np.uint16), want.view(np.uint16))
@@ -51,10 +59,13 @@ def test_bitlinear_llama_shape_exact():
     lin.load_float_weight(torch.from_numpy(w).cuda())
     x = rng.standard_normal((2, K)).astype(np.float16)
     got = lin(torch.from_numpy(x).cuda()).cpu().numpy()
-    wq = BitLinear.weight_quant(torch.from_numpy(w)).numpy()
+    wq = module_codes(lin)
     assert np.array_equal(got.view(np.uint16), oracle.bitnet_forward(x, wq, np.float32(lin.sw.item())).view(np.uint16))
+    # the weight quantiser against the oracle's: same scale up to the reduction order, same codes except where
+    # |w * s| sits on a rounding boundary
     wq_np, sw_np = oracle.bitnet_weight_quant(w)
-    assert np.array_equal(wq_np, wq) and abs(float(sw_np) - lin.sw.item()) <= 1e-6 * float(sw_np)
+    assert abs(float(sw_np) - lin.sw.item()) <= 1e-6 * float(sw_np)
+    assert np.count_nonzero(wq_np != wq) <= 1e-6 * wq.size + 4
 
 
 @pytest.mark.parametrize("m", [1, 2, 3, 4])
@@ -76,10 +87,6 @@ def test_single_launch_layer_for_decode_batches(m, bias, N, K):
     lin.fuse_activation_quant = False
     two = lin(xd).cpu().numpy()
     assert np.array_equal(one, two)
-    # the ternary codes are read back from the module: mean|W| reduced on the GPU can differ from the CPU value
-    # in the last bit, which flips a few of 16M borderline weights - not what is under test here
-    cfg = lin.bitblas_matmul.config
-    codes = wlib.unpack_weight(lin.qweight.cpu().numpy(), K, 2, wlib.LAYOUT_LOP3 if cfg.fast_decoding else wlib.LAYOUT_PLAIN, wlib.I8)
-    wq = codes.astype(np.int8) - 2
+    wq = module_codes(lin)
     want = oracle.bitnet_forward(x, wq, np.float32(lin.sw.item()), b)
     assert np.array_equal(one, want)
