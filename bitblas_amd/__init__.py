@@ -16,8 +16,8 @@ __version__ = "0.1.0"
 
 from .target import auto_detect_nvidia_target, auto_detect_target, get_arch  # noqa: F401
 from .matmul import (  # noqa: F401
-    Matmul, MatmulConfig, MatmulKernelNameGenerator, OperatorConfig, OptimizeStrategy,
-    TransformKind, is_native_compute,
+    Matmul, MatmulConfig, MatmulConfigWithSplitK, MatmulKernelNameGenerator, MatmulWithSplitK, OperatorConfig,
+    OptimizeStrategy, TransformKind, is_native_compute,
 )
 from .module import Linear  # noqa: F401
 from .cache import (  # noqa: F401

@@ -612,3 +612,23 @@ class Matmul:
     @property
     def weight_transform(self):
         return self.weight_executors if self.weight_executors.size else None
+
+
+@dataclass(frozen=True)
+class MatmulConfigWithSplitK(MatmulConfig):
+    """`bitblas.MatmulConfigWithSplitK` (ops/general_matmul_splitk.py:21-23)."""
+    k_split: int = 1  # split K dimension
+
+
+class MatmulWithSplitK(Matmul):
+    """`bitblas.MatmulWithSplitK` (ops/general_matmul_splitk.py:26-199).
+
+    Upstream launches a kernel that writes `k_split` partial products in out_dtype and reduces them with
+    `torch.sum` (:168-186).  Here split-K is the tile selector's own decision per (M, N, K) - fp32 / int32
+    partial sums in a library-owned scratch, one rounding at the end - so `k_split` is accepted as a
+    hint and the result is at least as accurate as upstream's sum of rounded partials.  Weight layout,
+    arguments and return value are those of `Matmul`."""
+
+    @property
+    def k_split(self):
+        return getattr(self.config, "k_split", 1)

@@ -298,3 +298,17 @@ def test_bf16_activations_other_weight_formats(M, W_dtype, g, ws):
     in bfloat16, general_matmul/__init__.py:413-434), FP4_E2M1, FP8_E4M3 (exact decode) and UINT1 on the MFMA path"""
     out, want, mm = _bf16_case(M, 512, 1024, W_dtype, g, ws, None, seed=M)
     assert_fp_parity(out, want, rtol=1e-5, atol_frac=1e-5)
+
+
+def test_split_k_operator_matches_matmul():
+    """`MatmulWithSplitK` (ref: bitblas/ops/general_matmul_splitk.py:26-199): same result as
+    `Matmul` on the same operands - split-K is the selector's decision here, k_split a hint"""
+    import bitblas_amd as bitblas
+    case = make_case(16, 1024, 4096, W_dtype="uint4", group_size=128, with_scaling=True, with_zeros=True, scale_mul=0.05)
+    got, mm = hip_output(case)
+    c = case["config"]
+    cfg = bitblas.MatmulConfigWithSplitK(M=16, N=1024, K=4096, A_dtype="float16", W_dtype="uint4", group_size=128,
+                                         with_scaling=True, with_zeros=True, zeros_mode=c.zeros_mode, k_split=4)
+    got_sk, mm_sk = hip_output(case, matmul=bitblas.MatmulWithSplitK(cfg, enable_tuning=False))
+    assert np.array_equal(got, got_sk)
+    assert_fp_parity(got_sk, oracle_output(case))

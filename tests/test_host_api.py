@@ -141,9 +141,18 @@ def test_linear_buffers_and_validation():
 
 
 def test_public_names():
-    for name in ("Matmul", "MatmulConfig", "Linear", "set_log_level", "auto_detect_nvidia_target",
-                 "global_operator_cache", "general_compress", "interleave_weight"):
+    for name in ("Matmul", "MatmulConfig", "MatmulWithSplitK", "MatmulConfigWithSplitK", "Linear", "set_log_level",
+                 "auto_detect_nvidia_target", "global_operator_cache", "general_compress", "interleave_weight"):
         assert hasattr(bitblas, name)
     assert bitblas.auto_detect_nvidia_target().startswith("hip")
     bitblas.set_log_level("DEBUG")
     bitblas.set_log_level("WARNING")
+
+
+def test_split_k_operator_mirror():
+    """`MatmulWithSplitK` (ops/general_matmul_splitk.py): same construction surface, k_split kept as a hint"""
+    cfg = bitblas.MatmulConfigWithSplitK(M=16, N=1024, K=4096, A_dtype="float16", W_dtype="int4", k_split=4)
+    assert cfg.k_split == 4 and "k_split=4" in repr(cfg) and cfg.fast_decoding is True
+    op = bitblas.MatmulWithSplitK(cfg, enable_tuning=False)
+    assert op.k_split == 4 and op.plans[16]["kernel_family"] == 2
+    assert op.retrieve_weight_shape() == [1024, 2048]
