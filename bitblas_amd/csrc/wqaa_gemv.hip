@@ -82,7 +82,7 @@ struct GemvPolicy {
   // the workgroup applies the per-token absmax int8 quantiser itself while it stages them - the
   // caller's quantise -> matmul -> rescale chain is one launch
   static constexpr bool AQ = (FLAGS_ & FL_AQ) != 0 && AT_ == AT_I8;
-  static constexpr bool AD = AD_ && MB_ == 1 && !A8 && !A4 && !AQ;
+  static constexpr bool AD = AD_ && MB_ <= 2 && !A8 && !A4 && !AQ;
   using T = KindTraits<KIND_, AT_>;
   // words of raw activation data per staging item (one decode unit = G elements)
   static constexpr int AW = AT_ == AT_I4 ? T::G / 8 : AQ ? T::G / 2 : (AT_ == AT_I8 || A8) ? T::G / 4 : T::G / 2;
@@ -95,7 +95,7 @@ struct Stage {
   u32x4 w[P::R];
   uint32_t s[P::R];  // scale bits (low 16)
   uint32_t z[P::R];  // zero bits (low 16) / raw qzeros byte
-  uint32_t araw[P::AD ? P::T::UNITS * P::AW : 1];   // AD: the lane's activation slice, natural order
+  uint32_t araw[P::AD ? P::MB : 1][P::AD ? P::T::UNITS * P::AW : 1];   // AD: the lane's activation slices (one per batch row), natural order
   bool avalid;
 };
 
@@ -421,11 +421,16 @@ __global__ void __launch_bounds__(1024) wq_gemv_kernel(const GemvArgs a) {
         // the lane's E activations: UNITS loads of AW words, issued ahead of this chunk's weights
         constexpr int UB = T::G * (F16 ? 2 : 1);   // bytes per unit
 #pragma unroll
-        for (int u = 0; u < UNITS; ++u) {
-          uint32_t t[P::AW];
-          load_words<P::AW>(Arow + (long)chunk * (UNITS * UB) + u * UB, t);
+        for (int mi = 0; mi < MB; ++mi) {
+          // batch rows beyond m (a 2-row tile of a 1-row call never happens: MB follows m) are real rows
+          const uint8_t* arow_mi = Arow + (long)mi * a.K * (F16 ? 2 : 1);
 #pragma unroll
-          for (int q = 0; q < P::AW; ++q) st[d].araw[u * P::AW + q] = t[q];
+          for (int u = 0; u < UNITS; ++u) {
+            uint32_t t[P::AW];
+            load_words<P::AW>(arow_mi + (long)chunk * (UNITS * UB) + u * UB, t);
+#pragma unroll
+            for (int q = 0; q < P::AW; ++q) st[d].araw[mi][u * P::AW + q] = t[q];
+          }
         }
       }
       // group of this lane chunk: chunk / (g / E), as a shift or a 32x32->hi multiply by ceil(2^32 / d)
@@ -607,7 +612,7 @@ __global__ void __launch_bounds__(1024) wq_gemv_kernel(const GemvArgs a) {
           for (int mi = 0; mi < MB; ++mi) {
             u32x4 av;
             if constexpr (AD) {
-              av = a_piece_rt<P>(s.araw + u * P::AW, pp, true);
+              av = a_piece_rt<P>(s.araw[mi] + u * P::AW, pp, true);
               if (need_mask && !s.avalid) av = u32x4{0u, 0u, 0u, 0u};   // wave-uniform outer test: free when K has no ragged chunk
             } else {
               av = a_lds[((long)(mi * ncp + c) * PIECES + u * PU + pp) * 64 + lane];
@@ -633,7 +638,7 @@ __global__ void __launch_bounds__(1024) wq_gemv_kernel(const GemvArgs a) {
           for (int mi = 0; mi < MB; ++mi) {
             u32x4 av;
             if constexpr (AD) {
-              av = a_piece_rt<P>(s.araw + u * P::AW, pp, true);
+              av = a_piece_rt<P>(s.araw[mi] + u * P::AW, pp, true);
               if (need_mask && !s.avalid) av = u32x4{0u, 0u, 0u, 0u};   // wave-uniform outer test: free when K has no ragged chunk
             } else {
               av = a_lds[((long)(mi * ncp + c) * PIECES + u * PU + pp) * 64 + lane];
@@ -702,7 +707,7 @@ __global__ void __launch_bounds__(1024) wq_gemv_kernel(const GemvArgs a) {
 typedef void (*gemv_fn)(const GemvArgs);
 
 static constexpr int kDirectTile = 101;   // pick_mb code of the M = 1 "activations direct" member
-static const int kBatchTiles[] = {1, kDirectTile, 2, 4};
+static const int kBatchTiles[] = {1, kDirectTile, kDirectTile + 1, kDirectTile + 2, 2, 4};
 
 template <int KIND, int LAYOUT, int AT, int MODE, int FLAGS>
 static gemv_fn pick_mb(int mb) {
@@ -710,6 +715,7 @@ static gemv_fn pick_mb(int mb) {
     case 1: return wq_gemv_kernel<GemvPolicy<KIND, LAYOUT, AT, 1, MODE, FLAGS>>;
     case kDirectTile: return wq_gemv_kernel<GemvPolicy<KIND, LAYOUT, AT, 1, MODE, FLAGS, 2, 2, true>>;
     case kDirectTile + 1: return wq_gemv_kernel<GemvPolicy<KIND, LAYOUT, AT, 1, MODE, FLAGS, 1, 2, true>>;
+    case kDirectTile + 2: return wq_gemv_kernel<GemvPolicy<KIND, LAYOUT, AT, 2, MODE, FLAGS, 2, 2, true>>;
     case 2: return wq_gemv_kernel<GemvPolicy<KIND, LAYOUT, AT, 2, MODE, FLAGS>>;
     case 4: return wq_gemv_kernel<GemvPolicy<KIND, LAYOUT, AT, 4, MODE, FLAGS>>;
     default: return nullptr;
@@ -928,13 +934,14 @@ static int choose(const wqaa_matmul_desc& d, int m, GemvChoice* c, bool quant_in
     }
     c->flags |= FL_AQ;
   }
-  const bool direct = mb == 1 && !(c->flags & (FL_A8 | FL_AQ)) && c->at != AT_I4 && c->ncp == c->D && (d.N + c->R - 1) / c->R <= 10 * cus0 &&
+  const bool direct = mb <= 2 && m == mb && !(c->flags & (FL_A8 | FL_AQ)) && c->at != AT_I4 && c->ncp == c->D && (d.N + c->R - 1) / c->R <= 10 * cus0 &&
                       !getenv("WQAA_GEMV_NO_DIRECT");
   // small matrices: one row per wave doubles the waves in flight (same-box A/B: 1024 x 1024 2.87 -> 2.45 us,
   // 2048 x 4096 equal, 4096 x 4096 4.18 -> 4.43 us)
-  const bool r1 = direct && (d.N + 1) / 2 < 3 * cus0;
+  const bool r1 = direct && mb == 1 && (d.N + 1) / 2 < 3 * cus0;
   if (r1) c->R = 1;
-  c->fn = pick_kernel(c->kind, c->layout, c->at, c->mode, c->flags, direct ? (r1 ? kDirectTile + 1 : kDirectTile) : mb);
+  c->fn = pick_kernel(c->kind, c->layout, c->at, c->mode, c->flags,
+                      direct ? (mb == 2 ? kDirectTile + 2 : r1 ? kDirectTile + 1 : kDirectTile) : mb);
   if (!c->fn) {
     set_error(WQAA_ERR_UNSUPPORTED, "gemv: no kernel for kind=%d layout=%d at=%d mode=%d flags=%d", c->kind,
               c->layout, c->at, c->mode, c->flags);

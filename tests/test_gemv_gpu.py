@@ -160,16 +160,17 @@ def test_output_buffer_and_stream_semantics():
                                             ("uint4", 128, True, True, "original"),
                                             ("uint2", 64, True, True, "quantized"),
                                             ("e4m3_float8", -1, False, False, "original")])
-def test_register_and_lds_activation_members_agree(wd, g, ws, wz, zm, monkeypatch):
-    """M = 1, K within one step runs the member that keeps its activation slice in registers; the
+@pytest.mark.parametrize("M", [1, 2])
+def test_register_and_lds_activation_members_agree(wd, g, ws, wz, zm, M, monkeypatch):
+    """M <= 2, K within one step runs the member that keeps its activation slices in registers; the
     LDS-staged member (forced through the selector's tuning switch) must give the same bits."""
-    case = make_case(1, 512, 2048 if wd != "uint2" else 4096, W_dtype=wd, group_size=g, with_scaling=ws,
+    case = make_case(M, 512, 2048 if wd != "uint2" else 4096, W_dtype=wd, group_size=g, with_scaling=ws,
                      with_zeros=wz, zeros_mode=zm)
     got, mm = hip_output(case)
-    assert mm.plans[1]["name"].endswith("_areg")
+    assert mm.plans[M]["name"].endswith("_areg")
     monkeypatch.setenv("WQAA_GEMV_NO_DIRECT", "1")
     got_lds, mm2 = hip_output(case)
-    assert not mm2.plans[1]["name"].endswith("_areg")
+    assert not mm2.plans[M]["name"].endswith("_areg")
     assert np.array_equal(got, got_lds)
     assert_fp_parity(got, oracle_output(case))
 
