@@ -3,10 +3,11 @@
 // Replaces the reference's generated per-config wrapper (`init()` + `call()`,
 // bitblas/builder/wrapper/tl.py:90-166 and :200-305) and its host-side kernel choice
 // (`MatmulDequantizeScheduler.dispatch_*`, tilelang/dequantize/matmul_dequantize.py:65-155:
-// M < 8 -> GEMV, otherwise the tensor-core GEMM; here the switch sits at M = 5, see dispatch()).
+// M < 8 -> GEMV, otherwise the tensor-core GEMM; here the switch sits at M = 3, see dispatch()).
 #include <hip/hip_ext.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <mutex>
@@ -65,7 +66,7 @@ static bool valid_desc(const wqaa_matmul_desc* d) {
   return true;
 }
 
-// M <= 4 -> GEMV family; larger m -> MFMA GEMM when a member exists for the dtype pair and shape, else the
+// M <= 2 -> GEMV family; larger m -> MFMA GEMM when a member exists for the dtype pair and shape, else the
 // GEMV family iterates over batch tiles of 4 rows.
 static int dispatch(const wqaa_matmul_desc& d, int m, bool* use_gemm) {
   *use_gemm = false;
@@ -73,11 +74,16 @@ static int dispatch(const wqaa_matmul_desc& d, int m, bool* use_gemm) {
   const int saved = g_last_error;
   char saved_msg[sizeof(g_last_error_msg)];
   memcpy(saved_msg, g_last_error_msg, sizeof(saved_msg));
-  // The reference switches families at M = 8 (matmul_dequantize.py:93-102).  Measured here
-  // (uint4 g128 + zeros, N = K = 4096 / 11008 x 4096): the GEMV batch tile holds 4 rows, so M = 5..7
-  // streams the weights twice (10.9-11.8 / 25.5 us) while the skinny MFMA member takes 9.3 / 16.3 us
-  // for any M <= 16; M <= 4 stays on the GEMV family (M = 4: 8.0 / 15.6 us).
-  if (m >= 5) {
+  // The reference switches families at M = 8 (matmul_dequantize.py:93-102).  Measured here (same box,
+  // int4 g128, N x K): the 4-row GEMV batch tile pays 4 LDS reads + 16 dot2 per weight word and, for
+  // M = 5..7, streams the weights twice, while one MFMA covers 16 rows:
+  //   M = 3   4096^2 7.5 vs 6.4 us (decode-batch MFMA member), 4096 x 11008 21.4 vs 11.7, int2 x int8 6.7 vs 5.5
+  //   M = 4   4096^2 7.8 vs 6.6,  11008 x 4096 14.4 vs 13.2 (skinny member + reduce launch)
+  //   M = 5-7 4096^2 10.9-11.8 vs 7.6-8.2
+  // M <= 2 stays on the GEMV family (M = 2: 5.2 us at 4096^2, the MFMA members take ~6.2).
+  int min_m = 3;
+  if (const char* f = getenv("WQAA_GEMM_MIN_M")) min_m = atoi(f);   // tuning aid
+  if (m >= min_m) {
     if (gemm_plan(d, m, &p) == WQAA_OK) *use_gemm = true;
   } else if (gemv_plan(d, m, &p) != WQAA_OK && gemm_plan(d, m, &p) == WQAA_OK) {
     // the GEMV family refuses this config (e.g. groups smaller than its 16-byte lane chunk) but the
