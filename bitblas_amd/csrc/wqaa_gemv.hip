@@ -961,6 +961,12 @@ static int choose(const wqaa_matmul_desc& d, int m, GemvChoice* c, bool quant_in
   if (blocks_per_cu < 1) blocks_per_cu = 1;
   int nw = 4;
   while (nw < 16 && blocks_per_cu * nw < 32) nw *= 2;
+  // ... but never so wide that some CUs get no workgroup at all (N = 4096, K = 11008, M = 2: 16 waves
+  // gave 128 workgroups for 256 CUs - 14.8 us; 8 waves, one workgroup per CU - see DESIGN 3.4)
+  {
+    const int n_rg0 = (d.N + c->R - 1) / c->R;
+    while (nw > 4 && (n_rg0 + nw - 1) / nw < cus) nw /= 2;
+  }
   const char* force = getenv("WQAA_GEMV_THREADS");   // tuning aid
   if (force && atoi(force) >= 64) nw = atoi(force) / 64;
   if (blocks_per_cu * nw > 32) blocks_per_cu = 32 / nw;
