@@ -698,8 +698,32 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_kernel(const GemmArgs a) {
       for (int it = 0; it < AG; ++it) areg_s[q][it] = granule_load(a_tile + koff + aoff[it]);
     }
     BLane<P> bs[S];
+    // Scale / Zeros: with one group per k-step (g = 128 for fp16) the S = 4 steps of this workgroup use 4
+    // consecutive groups - ONE 8-byte load per row instead of four 2-byte loads.  A 2-byte load per lane
+    // touches 16 cache lines per wave instruction (16 rows), exactly like the 16-byte weight load, so
+    // the per-step form spends two thirds of its memory transactions on 64 bytes of metadata.
+    constexpr bool WIDE_OK = S == 4 && (MODE == MD_S || MODE == MD_ZO || MODE == MD_ZR);
+    const bool wide = WIDE_OK && a.gq_shift == 2 && (a.kg & 3) == 0 && t0 + S <= a.nsteps;   // wave-uniform
+    if (wide) {
 #pragma unroll
-    for (int q = 0; q < S; ++q) b_load(t0 + q < a.nsteps ? t0 + q : a.nsteps - 1, bs[q]);
+      for (int q = 0; q < S; ++q)
+#pragma unroll
+        for (int nf = 0; nf < NFW; ++nf) load_lane_words<WL>(bptr[nf] + (long)(t0 + q) * (4 * WL * 4), bs[q].w[nf]);
+#pragma unroll
+      for (int nf = 0; nf < NFW; ++nf) {
+        const u32x2 sv = *reinterpret_cast<const u32x2*>(Sp + (long)nrow[nf] * a.kg + t0);
+        u32x2 zv = {0u, 0u};
+        if constexpr (MODE == MD_ZO || MODE == MD_ZR) zv = *reinterpret_cast<const u32x2*>(Zp + (long)nrow[nf] * a.kg + t0);
+#pragma unroll
+        for (int q = 0; q < S; ++q) {
+          bs[q].s[nf] = (sv[q >> 1] >> (16 * (q & 1))) & 0xFFFFu;
+          bs[q].z[nf] = (zv[q >> 1] >> (16 * (q & 1))) & 0xFFFFu;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < S; ++q) b_load(t0 + q < a.nsteps ? t0 + q : a.nsteps - 1, bs[q]);
+    }
 #pragma unroll
     for (int q = 0; q < S; ++q)
 #pragma unroll
