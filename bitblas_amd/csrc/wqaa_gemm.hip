@@ -146,7 +146,9 @@ static int gemm_choose(const wqaa_matmul_desc& d, int m, GemmChoice* c) {
   // 7.6 vs 9.2 us, M=8 8.2 vs 9.3, M=16 9.5 vs 9.9, M=32 13.2 vs 11.6; 11008x4096 M=8 18.3 vs 16.2;
   // 4096x11008 M=8 15.2 vs 17.8; int2 x int8 4096^2 M=5 5.7 vs 7.3.
   c->decode = 0;
-  if (m <= 8 && c->mf == 1 && (d.N + 15) / 16 <= 2 * cus_) {   // (the dispatcher sends M >= 3 here)
+  // (with the 8-byte metadata loads in both members: 4096^2 M=3 6.3 vs 9.1 us, M=8 7.2 vs 9.1; 8192^2 M=3 18.0 vs
+  // 17.1, M=8 22.4 vs 17.7 - beyond ~1.5 fragments per CU the skinny member takes over)
+  if (m <= 8 && c->mf == 1 && (d.N + 15) / 16 <= cus_ + cus_ / 2) {   // (the dispatcher sends M >= 3 here)
     const char* dflag = getenv("WQAA_GEMM_DECODE");
     if (!dflag || atoi(dflag) != 0) c->decode = 1;
   }

@@ -869,13 +869,20 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_decode_kernel(const GemmAr
     BLane<P> b;
     u32x4 araw[MF][A4 ? 2 : 4];
   };
+  // Scale / Zeros: a 2-byte load per lane touches 16 cache lines per wave instruction, as many as the
+  // 16-byte weight load.  With one group per k-step (g = 128 for fp16) four consecutive steps use four
+  // consecutive groups: ONE 8-byte load per row and block of 4 steps (wide = true) instead of four.
+  constexpr bool WIDE_OK = MODE == MD_S || MODE == MD_ZO || MODE == MD_ZR;
+  const bool wide = WIDE_OK && a.gq_shift == 2 && (a.kg & 3) == 0;   // wave-uniform
   auto load_step = [&](int t, Step& st) {
     const int kidx = t * 4 + kb;
     int gi = 0;
     if (MODE != MD_NONE) gi = a.gq_shift >= 0 ? (kidx >> a.gq_shift) : (int)__umulhi((uint32_t)kidx, a.gq_magic);
     load_lane_words<WL>(brow + (long)t * (4 * WL * 4), st.b.w[0]);
-    if constexpr (MODE != MD_NONE) st.b.s[0] = Sp[srow + gi];
-    if constexpr (MODE == MD_ZO || MODE == MD_ZR) st.b.z[0] = Zp[srow + gi];
+    if (!wide) {
+      if constexpr (MODE != MD_NONE) st.b.s[0] = Sp[srow + gi];
+      if constexpr (MODE == MD_ZO || MODE == MD_ZR) st.b.z[0] = Zp[srow + gi];
+    }
     if constexpr (MODE == MD_ZQ) st.b.z[0] = Qp[(long)gi * a.zq_row_bytes + nrow / ZPB];
     const long koff = (long)t * (4 * ALB);
 #pragma unroll
@@ -967,24 +974,45 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_decode_kernel(const GemmAr
     }
   };
 
-  // wave w takes k-steps w, w + NW, ...; loads are unconditional (clamped step), compute is guarded
+  // wave w takes a contiguous run of k-steps (a multiple of 4 long, so its blocks of 4 steps line up with
+  // the 8-byte metadata loads); loads are unconditional (clamped step), compute is guarded
   const int nsteps = a.nsteps;
   const int last = nsteps - 1;
-  const int my_steps = (nsteps - wave + NW - 1) / NW;     // wave-uniform
+  const int run = (((nsteps + NW - 1) / NW) + 3) & ~3;
+  const int t_lo = wave * run;
+  const int my_steps = t_lo >= nsteps ? 0 : (nsteps - t_lo < run ? nsteps - t_lo : run);   // wave-uniform
+  auto meta_load = [&](int block_first_step, u32x2& gs, u32x2& gz) {
+    int base = block_first_step < a.kg - 4 ? block_first_step : a.kg - 4;   // group index = step when wide
+    base = base < 0 ? 0 : base;
+    gs = *reinterpret_cast<const u32x2*>(Sp + srow + base);
+    if constexpr (MODE == MD_ZO || MODE == MD_ZR) gz = *reinterpret_cast<const u32x2*>(Zp + srow + base);
+    else gz = u32x2{0u, 0u};
+  };
   Step ring[PF];
+  static_assert(PF == 4, "blocks of four steps");
 #pragma unroll
   for (int i = 0; i < PF; ++i) {
-    const int t = wave + i * NW;
+    const int t = t_lo + i;
     load_step(t < nsteps ? t : last, ring[i]);
   }
+  u32x2 gs_cur = {0u, 0u}, gz_cur = {0u, 0u}, gs_nxt = {0u, 0u}, gz_nxt = {0u, 0u};
+  if (wide) meta_load(t_lo < nsteps ? t_lo : 0, gs_cur, gz_cur);
   for (int s0 = 0; s0 < my_steps; s0 += PF) {
+    const bool more = s0 + PF < my_steps;                    // wave-uniform: short K issues nothing more
+    if (wide && more) meta_load(t_lo + s0 + PF, gs_nxt, gz_nxt);
 #pragma unroll
     for (int i = 0; i < PF; ++i) {
       const int s = s0 + i;
+      if (wide) {                                            // step i of the block: half i of the 8 bytes
+        ring[i].b.s[0] = (gs_cur[i >> 1] >> (16 * (i & 1))) & 0xFFFFu;
+        ring[i].b.z[0] = (gz_cur[i >> 1] >> (16 * (i & 1))) & 0xFFFFu;
+      }
       if (s < my_steps) compute(ring[i]);
-      const int tw = wave + (s + PF) * NW;                 // refill the slot just consumed
-      if (s0 + PF < my_steps) load_step(tw < nsteps ? tw : last, ring[i]);   // wave-uniform: short K issues nothing more
+      const int tw = t_lo + s + PF;                          // refill the slot just consumed
+      if (more) load_step(tw < nsteps ? tw : last, ring[i]);
     }
+    gs_cur = gs_nxt;
+    gz_cur = gz_nxt;
   }
 
   // ---- meet in LDS: slot [wave][mf][lane], summed in wave order by the threads of wave mf ----
