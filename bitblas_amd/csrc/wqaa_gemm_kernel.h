@@ -704,7 +704,40 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_kernel(const GemmArgs a) {
     // the per-step form spends two thirds of its memory transactions on 64 bytes of metadata.
     constexpr bool WIDE_OK = S == 4 && (MODE == MD_S || MODE == MD_ZO || MODE == MD_ZR);
     const bool wide = WIDE_OK && a.gq_shift == 2 && (a.kg & 3) == 0 && t0 + S <= a.nsteps;   // wave-uniform
-    if (wide) {
+    // groups of 512 and more (and per-channel scales): the four steps share ONE group - one 2-byte load
+    const bool uni = WIDE_OK && a.gq_shift >= 4 && t0 + S <= a.nsteps;
+    if (uni) {
+#pragma unroll
+      for (int q = 0; q < S; ++q)
+#pragma unroll
+        for (int nf = 0; nf < NFW; ++nf) load_lane_words<WL>(bptr[nf] + (long)(t0 + q) * (4 * WL * 4), bs[q].w[nf]);
+      const int gi = (t0 * 4) >> a.gq_shift;
+#pragma unroll
+      for (int nf = 0; nf < NFW; ++nf) {
+        const uint32_t sv = Sp[(long)nrow[nf] * a.kg + gi];
+        uint32_t zv = 0;
+        if constexpr (MODE == MD_ZO || MODE == MD_ZR) zv = Zp[(long)nrow[nf] * a.kg + gi];
+#pragma unroll
+        for (int q = 0; q < S; ++q) { bs[q].s[nf] = sv; bs[q].z[nf] = zv; }
+      }
+    } else if (WIDE_OK && a.gq_shift == 3 && (a.kg & 1) == 0 && t0 + S <= a.nsteps) {
+      // g = 256: two groups per four steps - one 4-byte load
+#pragma unroll
+      for (int q = 0; q < S; ++q)
+#pragma unroll
+        for (int nf = 0; nf < NFW; ++nf) load_lane_words<WL>(bptr[nf] + (long)(t0 + q) * (4 * WL * 4), bs[q].w[nf]);
+#pragma unroll
+      for (int nf = 0; nf < NFW; ++nf) {
+        const uint32_t sv = *reinterpret_cast<const uint32_t*>(Sp + (long)nrow[nf] * a.kg + (t0 >> 1));
+        uint32_t zv = 0;
+        if constexpr (MODE == MD_ZO || MODE == MD_ZR) zv = *reinterpret_cast<const uint32_t*>(Zp + (long)nrow[nf] * a.kg + (t0 >> 1));
+#pragma unroll
+        for (int q = 0; q < S; ++q) {
+          bs[q].s[nf] = (sv >> (16 * (q >> 1))) & 0xFFFFu;
+          bs[q].z[nf] = (zv >> (16 * (q >> 1))) & 0xFFFFu;
+        }
+      }
+    } else if (wide) {
 #pragma unroll
       for (int q = 0; q < S; ++q)
 #pragma unroll
