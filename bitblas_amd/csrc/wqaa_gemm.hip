@@ -44,7 +44,7 @@ static gemm_fn pick_gemm(int kind, int layout, int at, int mode, int flags, int 
 struct GemmChoice {
   gemm_fn fn;
   int kind, layout, at, mode, flags, bits;
-  int mf, ks, kl, nwaves, bn, ksplit, skinny, decode;
+  int mf, ks, kl, nwaves, bn, ksplit, skinny, decode, wide;
   int tiles_m, tiles_n, lds;
   int fp4_table;
 };
@@ -170,7 +170,20 @@ static int gemm_choose(const wqaa_matmul_desc& d, int m, GemmChoice* c) {
   c->skinny = (m <= 64 && c->mf <= 4 && getenv("WQAA_GEMM_NOSKINNY") == nullptr) ? 4 : 0;
   c->nwaves = c->mf == 16 ? 8 : 4;
   c->bn = c->skinny ? 64 : c->nwaves * 32;
-  c->fn = pick_gemm(c->kind, c->layout, c->at, c->mode, c->flags, c->skinny ? 100 + c->mf : c->mf);
+  int code = c->skinny ? 100 + c->mf : c->mf;
+  // the 64-row member with Scale AND Zeros, one group per k-step, K / g a multiple of 4: the variant with 8-byte
+  // metadata loads (two 2-byte loads per lane and step are as many cache-line touches as the weight load itself;
+  // measured same-call: 28672x8192 M=128 143 -> 124 us, 8192^2 51 -> 48 us.  The taller members and the
+  // scale-only case LOSE 3-10 % to the four-step unrolled loop, so they keep the per-step form)
+  {
+    const int dq = g / c->kl;
+    const char* wflag = getenv("WQAA_GEMM_WIDE");
+    if (!c->skinny && c->mf == 4 && (c->mode == MD_ZO || c->mode == MD_ZR) && dq == 4 && ((d.K / g) & 3) == 0 &&
+        (!wflag || atoi(wflag) != 0) && pick_gemm(c->kind, c->layout, c->at, c->mode, c->flags, 404))
+      code = 404;
+  }
+  c->wide = code >= 400;
+  c->fn = pick_gemm(c->kind, c->layout, c->at, c->mode, c->flags, code);
   if (!c->fn) {
     set_error(WQAA_ERR_UNSUPPORTED, "gemm: no kernel for kind=%d layout=%d at=%d mode=%d", c->kind, c->layout, c->at, c->mode);
     return WQAA_ERR_UNSUPPORTED;
@@ -216,7 +229,7 @@ int gemm_plan(const wqaa_matmul_desc& d, int m, wqaa_plan* plan) {
     char wd[24];
     short_wdtype(d, wd, sizeof(wd));
     snprintf(plan->name, sizeof(plan->name), "matmul_m%dn%dk%d_%sx%s_tcx%dx%dx%d%s%s", m, d.N, d.K, short_dtype(d.a_dtype),
-             wd, 16 * c.mf, c.bn, c.ks, c.ksplit > 1 ? "xr" : "", c.skinny ? "xs" : c.decode ? "xd" : "");
+             wd, 16 * c.mf, c.bn, c.ks, c.ksplit > 1 ? "xr" : "", c.skinny ? "xs" : c.decode ? "xd" : c.wide ? "xw" : "");
   }
   return WQAA_OK;
 }
@@ -306,7 +319,7 @@ void gemm_init() {
       for (int at = 0; at < 4; ++at)
         for (int mode = 0; mode <= MD_ZQ; ++mode)
           for (int flags : {0, (int)FL_STRICT, (int)FL_ABF8, (int)FL_BF16})
-            for (int mf : {1, 2, 4, 8, 16, 101, 102, 104, 201}) {
+            for (int mf : {1, 2, 4, 8, 16, 101, 102, 104, 201, 404}) {
               gemm_fn fn = pick_gemm(kind, layout, at, mode, flags, mf);
               if (fn) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             }

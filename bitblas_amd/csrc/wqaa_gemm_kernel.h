@@ -68,8 +68,11 @@ struct GemmArgs {
 // ------------------------------------------------------------------------------------------
 // policy: one k-step is KS = 4 * KL deep; a lane owns KL consecutive k of one weight row
 // ------------------------------------------------------------------------------------------
-template <int KIND_, int LAYOUT_, int AT_, int MODE_, int FLAGS_, int MF_, int NWAVES_ = 4, int NFW_ = 2, int SK_ = 0>
+template <int KIND_, int LAYOUT_, int AT_, int MODE_, int FLAGS_, int MF_, int NWAVES_ = 4, int NFW_ = 2, int SK_ = 0, bool WIDE_ = false>
 struct GemmPolicy {
+  // WIDE: Scale / Zeros of four consecutive groups per 8-byte load (the host picks these members when a k-step is
+  // exactly one group and K / g is a multiple of 4)
+  static constexpr bool WIDE = WIDE_ && (MODE_ == MD_S || MODE_ == MD_ZO || MODE_ == MD_ZR) && SK_ == 0;
   // SK > 0: "skinny" member for decode batches - a workgroup owns SK consecutive k-steps of its tile,
   // issues ALL their weight loads before anything is consumed and stages all SK activation tiles behind
   // one barrier (the pipelined member is latency-bound when M is small: one HBM round trip per k-step)
@@ -770,6 +773,52 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_kernel(const GemmArgs a) {
     const int t_begin = (int)((long)split * a.nsteps / a.ksplit);
     const int nsteps = (int)((long)(split + 1) * a.nsteps / a.ksplit);   // end of this workgroup's k range
     BLane<P> bcur, bnext;
+    if constexpr (P::WIDE) {
+      // one group per k-step: the groups of four consecutive steps come with ONE 8-byte load per row, a
+      // block ahead; the loop is unrolled by four so each step's half is a compile-time pick
+      u32x2 gs_cur[NFW], gz_cur[NFW], gs_nxt[NFW], gz_nxt[NFW];
+      auto g_load = [&](int first, u32x2 (&gs)[NFW], u32x2 (&gz)[NFW]) {
+#pragma unroll
+        for (int nf = 0; nf < NFW; ++nf) {
+          gs[nf] = *reinterpret_cast<const u32x2*>(Sp + (long)nrow[nf] * a.kg + first);
+          if constexpr (MODE == MD_ZO || MODE == MD_ZR) gz[nf] = *reinterpret_cast<const u32x2*>(Zp + (long)nrow[nf] * a.kg + first);
+          else gz[nf] = u32x2{0u, 0u};
+        }
+      };
+      auto w_load = [&](int t, BLane<P>& b) {
+#pragma unroll
+        for (int nf = 0; nf < NFW; ++nf) load_lane_words<WL>(bptr[nf] + (long)t * (4 * WL * 4), b.w[nf]);
+      };
+      const int tb4 = t_begin & ~3;               // blocks are aligned to 4 steps (the host keeps split ranges aligned)
+      a_load(t_begin);
+      w_load(t_begin, bcur);
+      g_load(tb4, gs_cur, gz_cur);
+      a_store(t_begin & 1);
+      __syncthreads();
+      for (int t4 = tb4; t4 < nsteps; t4 += 4) {
+        const int nb = t4 + 4 < nsteps ? t4 + 4 : t4;      // next block (the last one reloads itself)
+        g_load(nb, gs_nxt, gz_nxt);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int t = t4 + q;
+          if (t < t_begin || t >= nsteps) continue;         // wave-uniform
+          const int tn = t + 1 < nsteps ? t + 1 : t;
+          a_load(tn);
+          w_load(tn, bnext);
+#pragma unroll
+          for (int nf = 0; nf < NFW; ++nf) {
+            bcur.s[nf] = (gs_cur[nf][q >> 1] >> (16 * (q & 1))) & 0xFFFFu;
+            bcur.z[nf] = (gz_cur[nf][q >> 1] >> (16 * (q & 1))) & 0xFFFFu;
+          }
+          compute_step(bcur, smem_raw + (t & 1) * (P::BM * P::ROW_BYTES));
+          a_store((t + 1) & 1);
+          __syncthreads();
+          bcur = bnext;
+        }
+#pragma unroll
+        for (int nf = 0; nf < NFW; ++nf) { gs_cur[nf] = gs_nxt[nf]; gz_cur[nf] = gz_nxt[nf]; }
+      }
+    } else {
     a_load(t_begin);
     b_load(t_begin, bcur);
     a_store(t_begin & 1);
@@ -783,6 +832,7 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_kernel(const GemmArgs a) {
       a_store((t + 1) & 1);
       __syncthreads();
       bcur = bnext;
+    }
     }
   }
 
@@ -1131,6 +1181,7 @@ static gemm_fn pick_mf(int mf) {
     case 102: return wq_gemm_kernel<GemmPolicy<KIND, LAYOUT, AT, MODE, FLAGS, 2, 4, 1, 4>>;
     case 104: return wq_gemm_kernel<GemmPolicy<KIND, LAYOUT, AT, MODE, FLAGS, 4, 4, 1, 4>>;
     case 201: return wq_gemm_decode_kernel<GemmPolicy<KIND, LAYOUT, AT, MODE, FLAGS, 1, 8, 1>>;
+    case 404: if constexpr (KIND == DK_INT4 && AT == AT_F16 && FLAGS == 0 && (MODE == MD_ZO || MODE == MD_ZR)) return wq_gemm_kernel<GemmPolicy<KIND, LAYOUT, AT, MODE, FLAGS, 4, 4, 2, 0, true>>; else return nullptr;
   }
   return nullptr;
 }

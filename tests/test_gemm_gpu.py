@@ -290,6 +290,31 @@ def test_decode_batch_member_against_the_split_k_member(M, kw, monkeypatch):
         assert_fp_parity(got2, want)
 
 
+@pytest.mark.parametrize("M", [65, 100, 128])
+@pytest.mark.parametrize("kw", [dict(W_dtype="uint4", with_zeros=True, zeros_mode="original"),
+                                dict(W_dtype="uint4", with_zeros=True, zeros_mode="rescale"),
+                                dict(W_dtype="int4", with_zeros=True, zeros_mode="original")])
+@pytest.mark.parametrize("N,K", [(512, 1024), (200, 2048)])
+def test_block_metadata_member_is_bit_identical(M, kw, N, K, monkeypatch):
+    """g = 128 with K / g a multiple of 4: the 64-row member fetches Scale / Zeros of four k-steps with one
+    8-byte load each (plan suffix xw).  Same arithmetic in the same order as the per-step form: bit identical,
+    also under split-K (a slice may start inside a block of four)."""
+    case = make_case(M, N, K, seed=M + N, group_size=128, with_scaling=True, scale_mul=0.05, **kw)
+    got, mm = hip_output(case)
+    assert mm.plans[M]["name"].endswith("xw")
+    monkeypatch.setenv("WQAA_GEMM_WIDE", "0")
+    got2, mm2 = hip_output(case)
+    assert not mm2.plans[M]["name"].endswith("xw")
+    assert np.array_equal(got.view(np.uint16), got2.view(np.uint16))
+    assert_fp_parity(got, oracle_output(case))
+    monkeypatch.delenv("WQAA_GEMM_WIDE")
+    for ks in (3, 5):
+        monkeypatch.setenv("WQAA_GEMM_KSPLIT", str(ks))
+        got3, mm3 = hip_output(case)
+        assert mm3.plans[M]["name"].endswith("xw")
+        assert_fp_parity(got3, oracle_output(case))
+
+
 @pytest.mark.parametrize("M", [1, 4, 64, 300])
 @pytest.mark.parametrize("W_dtype,g,ws", [("nf4", -1, False), ("nf4", 128, True), ("fp4_e2m1", -1, False), ("fp4_e2m1", 64, True),
                                           ("e4m3_float8", -1, False), ("e4m3_float8", 128, True), ("uint1", 128, True)])
