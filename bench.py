@@ -261,7 +261,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    dist_on = world > 1
+    # WQAA_BENCH_FORCE_DIST=1: run the N>1 code path (RCCL init, per-step all-gather) with one rank - the only way to
+    # exercise it on a 1-GPU box
+    dist_on = world > 1 or os.environ.get("WQAA_BENCH_FORCE_DIST") == "1"
     if dist_on:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -282,39 +284,112 @@ def main():
     step_bytes = args.layers * sum(algorithmic_bytes(1, N, K) for (_, N, K) in LLAMA2_7B_LINEARS)
     launches_per_step = args.layers * len(LLAMA2_7B_LINEARS)
 
+    # N > 1: every rank writes its column slice of a step into one of TWO staging buffers and the RCCL all-gather
+    # of step i runs on RCCL's stream while step i+1 computes into the other buffer (a buffer is reused only after
+    # its gather has been waited for) - throughput is max(compute, gather) per step, not the sum
     gathered = local_out = None
+    n_slots = 2 if dist_on else 1
     if dist_on:
         flat_n = sum(N for (_, N, _) in LLAMA2_7B_LINEARS)
-        local_out = torch.empty((args.layers, flat_n), dtype=torch.float16, device=device)
-        gathered = torch.empty((world * args.layers, flat_n), dtype=torch.float16, device=device)
+        local_out = [torch.empty((args.layers, flat_n), dtype=torch.float16, device=device) for _ in range(n_slots)]
+        gathered = [torch.empty((world * args.layers, flat_n), dtype=torch.float16, device=device) for _ in range(n_slots)]
 
-    def launch_layers():
+    def launch_layers(slot):
         stream = torch.cuda.current_stream(device).cuda_stream
         for li, layer in enumerate(layers):
             off = 0
             for (op, qw, sc, out) in layer:
                 A = acts[op.K]
-                dst = out if not dist_on else local_out[li:li + 1, off:off + op.N]
+                dst = out if not dist_on else local_out[slot][li:li + 1, off:off + op.N]
                 op.lib.run(A.data_ptr(), qw.data_ptr(), None, sc.data_ptr(), None, None,
                            dst.data_ptr(), 1, stream)
                 off += op.N
 
-    graph = None
+    # The collective rides in the hipGraph: the graph of a step forks a side stream that all-gathers the PREVIOUS
+    # step's staging buffer while the main branch runs this step's GEMVs into the other one, then joins.  One graph
+    # replay per step, no per-step host call into RCCL (an eager all_gather_into_tensor costs ~50 us of host time
+    # against a 160 us step).  If RCCL refuses capture the eager double-buffered scheme below takes over.
+    graphs = None
+    gather_in_graph = False
+    pending = [None] * n_slots
+    step_no = [0]
+
+    # WQAA_BENCH_GATHER: "serial" (default) = the step's graph ends with the all-gather of its own staging buffer, one
+    # linear graph; "overlap" = the graph forks a side stream that gathers the PREVIOUS step's buffer while this
+    # step's GEMVs run (measured slower at one rank: a forked hipGraph loses 70 us per replay); "eager" = no capture
+    gather_mode = os.environ.get("WQAA_BENCH_GATHER", "serial") if dist_on else "none"
+    if dist_on and args.eager:
+        gather_mode = "eager"
+
+    def capture(mode):
+        out = []
+        if mode in ("serial", "overlap"):
+            import torch.distributed as dist
+            for slot in range(n_slots):   # communicator set-up and buffer registration happen outside capture
+                dist.all_gather_into_tensor(gathered[slot], local_out[slot])
+            torch.cuda.synchronize(device)
+        side = torch.cuda.Stream(device=device) if mode == "overlap" else None
+        for slot in range(n_slots):
+            launch_layers(slot)
+            torch.cuda.synchronize(device)
+            g = torch.cuda.CUDAGraph()
+            # thread_local: RCCL's watchdog thread may query events while this thread captures
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                if mode == "overlap":
+                    main = torch.cuda.current_stream(device)
+                    side.wait_stream(main)
+                    with torch.cuda.stream(side):
+                        dist.all_gather_into_tensor(gathered[1 - slot], local_out[1 - slot])
+                launch_layers(slot)
+                if mode == "overlap":
+                    main.wait_stream(side)
+                if mode == "serial":
+                    dist.all_gather_into_tensor(gathered[slot], local_out[slot])
+            out.append(g)
+        return out
+
     if not args.eager:
-        launch_layers()
-        torch.cuda.synchronize(device)
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            launch_layers()
+        if gather_mode in ("serial", "overlap"):
+            try:
+                graphs = capture(gather_mode)
+                gather_in_graph = True
+            except Exception as e:  # noqa: BLE001 - any capture failure: fall back, say so
+                print(f"[bench] rank {rank}: RCCL all-gather not capturable ({type(e).__name__}: {e}); eager gather",
+                      file=sys.stderr)
+                torch.cuda.synchronize(device)
+                graphs = None
+                gather_mode = "eager"
+        if graphs is None:
+            graphs = capture("none")
+    graph = graphs[0] if graphs else None
 
     def one_step():
-        if graph is not None:
-            graph.replay()
+        slot = step_no[0] % n_slots
+        step_no[0] += 1
+        if pending[slot] is not None:
+            pending[slot].wait()          # stream-side wait: the staging buffer is free again
+            pending[slot] = None
+        if graphs is not None:
+            graphs[slot].replay()
         else:
-            launch_layers()
-        if dist_on:
+            launch_layers(slot)
+        if dist_on and not gather_in_graph:
             import torch.distributed as dist
-            dist.all_gather_into_tensor(gathered, local_out)
+            pending[slot] = dist.all_gather_into_tensor(gathered[slot], local_out[slot], async_op=True)
+
+    def drain():
+        if gather_in_graph and gather_mode == "serial":
+            return
+        if gather_in_graph:
+            # the last step's slice has not been gathered by a following replay yet
+            import torch.distributed as dist
+            last = (step_no[0] - 1) % n_slots
+            dist.all_gather_into_tensor(gathered[last], local_out[last])
+            return
+        for slot in range(n_slots):
+            if pending[slot] is not None:
+                pending[slot].wait()
+                pending[slot] = None
 
     def barrier():
         if dist_on:
@@ -323,6 +398,7 @@ def main():
 
     for _ in range(args.warmup):
         one_step()
+    drain()
     barrier()
     torch.cuda.synchronize(device)
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -330,6 +406,7 @@ def main():
     ev0.record()
     for _ in range(args.steps):
         one_step()
+    drain()                               # every step's gather is inside the timed region
     ev1.record()
     torch.cuda.synchronize(device)
     barrier()
@@ -360,7 +437,12 @@ def main():
                                    f"{args.layers} layers x 7 GEMV per step per GPU, "
                                    f"{'one hipGraph replay per step' if graph is not None else 'eager launches'}",
                        "launches_per_step": launches_per_step, "bytes_per_step_per_gpu": step_bytes,
-                       "sharding": "column (N) shard per rank + 1 RCCL all-gather per step" if dist_on else "none"},
+                       "sharding": (f"column (N) shard per rank + 1 RCCL all-gather per step ({gather_mode}: " +
+                                    {"serial": "captured at the end of the step's hipGraph",
+                                     "overlap": "captured on a forked branch of the next step's hipGraph",
+                                     "eager": "eager async call, overlapped with the next step, two staging buffers"
+                                     }.get(gather_mode, "") + ")")
+                       if dist_on else "none"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(),
                          "kernel": "wq_gemv_kernel<int4, lop3, f16, mb1, scale> (" + kernel_name + ")",
