@@ -148,7 +148,14 @@ static int gemm_choose(const wqaa_matmul_desc& d, int m, GemmChoice* c) {
   c->decode = 0;
   // (with the 8-byte metadata loads in both members: 4096^2 M=3 6.3 vs 9.1 us, M=8 7.2 vs 9.1; 8192^2 M=3 18.0 vs
   // 17.1, M=8 22.4 vs 17.7 - beyond ~1.5 fragments per CU the skinny member takes over)
-  if (m <= 8 && c->mf == 1 && (d.N + 15) / 16 <= cus_ + cus_ / 2) {   // (the dispatcher sends M >= 3 here)
+  // M = 9...16 still fits the one 16-row MFMA fragment; there the member pays only when the grid is close to one
+  // fragment per CU (same-call A/B, 4096^2 uint4+zeros: M=10 9.2 -> 7.4 us, M=12 9.3 -> 7.8, M=16 9.6 -> 8.5;
+  // int2 x int8 M=16 7.3 -> 5.7; but N=5120: 12.7 -> 21.6 and N=2048, K=8192: 10.3 -> 13.8, so it is fenced)
+  const int frags = (d.N + 15) / 16;
+  int decode_max_m = 16;
+  if (const char* f = getenv("WQAA_GEMM_DECODE_MAXM")) decode_max_m = atoi(f);   // tuning aid
+  const bool decode_fits = m <= 8 ? frags <= cus_ + cus_ / 2 : (frags <= cus_ && 4 * frags >= 3 * cus_);
+  if (m <= decode_max_m && m <= 16 && c->mf == 1 && decode_fits) {
     const char* dflag = getenv("WQAA_GEMM_DECODE");
     if (!dflag || atoi(dflag) != 0) c->decode = 1;
   }

@@ -269,14 +269,14 @@ def test_small_groups_fall_through_to_the_mfma_family(M):
     assert_fp_parity(got, oracle_output(case))
 
 
-@pytest.mark.parametrize("M", [5, 8])
+@pytest.mark.parametrize("M,N", [(5, 1024), (8, 1024), (9, 3584), (13, 4096), (16, 4096)])
 @pytest.mark.parametrize("kw", [dict(W_dtype="uint4", group_size=128, with_scaling=True, with_zeros=True, zeros_mode="original", scale_mul=0.05),
                                 dict(W_dtype="int2", A_dtype="int8", out_dtype="int32")])
-def test_decode_batch_member_against_the_split_k_member(M, kw, monkeypatch):
-    """M = 5..8 runs the one-launch member (K split across the waves of a workgroup, summed in LDS);
-    the split-K skinny member + reduce launch must agree: bit exact for integers, within the fp16
-    bound for floats (different summation order)."""
-    case = make_case(M, 1024, 4096, seed=M, **kw)
+def test_decode_batch_member_against_the_split_k_member(M, N, kw, monkeypatch):
+    """M = 3..8 (and 9..16 when the grid is about one weight fragment per CU) runs the one-launch member (K split
+    across the waves of a workgroup, summed in LDS); the split-K skinny member + reduce launch must agree: bit
+    exact for integers, within the fp16 bound for floats (different summation order)."""
+    case = make_case(M, N, 4096 if N <= 1024 else 2048, seed=M, **kw)
     got, mm = hip_output(case)
     assert mm.plans[M]["name"].endswith("xd")
     monkeypatch.setenv("WQAA_GEMM_DECODE", "0")
