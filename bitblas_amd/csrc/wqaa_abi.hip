@@ -16,6 +16,7 @@
 
 namespace wqaa {
 
+std::atomic<unsigned> g_plan_epoch{1};
 static thread_local int g_last_error = WQAA_OK;
 static thread_local char g_last_error_msg[512] = "";
 
@@ -125,7 +126,15 @@ static int matmul_impl(const wqaa_matmul_desc* desc, const void* A, const void* 
     return WQAA_ERR_NO_DEVICE;
   }
   bool use_gemm = false;
-  dispatch(*desc, m, &use_gemm);
+  {
+    static thread_local ChoiceMemo<int> memo;   // family per (desc, m), see ChoiceMemo
+    if (const int* hit = memo.find(*desc, m, 0)) {
+      use_gemm = *hit != 0;
+    } else {
+      dispatch(*desc, m, &use_gemm);
+      memo.put(*desc, m, 0, use_gemm ? 1 : 0);
+    }
+  }
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   hipEvent_t e0 = reinterpret_cast<hipEvent_t>(ev0), e1 = reinterpret_cast<hipEvent_t>(ev1);
   const bool quant_in = epi && (epi->flags & WQAA_EPI_QUANTIZE_INPUT);
@@ -222,6 +231,7 @@ int wqaa_select(const wqaa_matmul_desc* desc, int m, wqaa_plan* plan) {
   if (!valid_desc(desc)) return WQAA_ERR_BAD_DESC;
   if (plan) memset(plan, 0, sizeof(*plan));
   if (m <= 0) m = 1;
+  g_plan_epoch.fetch_add(1, std::memory_order_relaxed);   // planning re-reads the tuning environment (ChoiceMemo)
   bool use_gemm = false;
   dispatch(*desc, m, &use_gemm);
   return use_gemm ? gemm_plan(*desc, m, plan) : gemv_plan(*desc, m, plan);

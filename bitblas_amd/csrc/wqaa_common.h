@@ -2,6 +2,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
+#include <cstring>
 #include <stdio.h>
 
 #include "../../include/wqaa.h"
@@ -75,6 +77,39 @@ void gemm_init();
 
 int debug_decode_launch(const void* packed, int64_t nwords, int w_format, int bits, int layout,
                         int a_dtype, int strict, const void* lut, void* out, hipStream_t stream);
+
+// Tile choices are memoised per thread: a selector reads tuning environment variables and walks its rules, ~1 us
+// per call against a 4 us kernel (twice per wqaa_matmul: family dispatch + launch).  wqaa_select() - operator
+// planning - bumps the epoch, so the tuning variables are PLAN-time switches: a change takes effect at the next
+// wqaa_select() of any operator, not in the middle of a stream of calls.
+extern std::atomic<unsigned> g_plan_epoch;
+template <class Choice, int WAYS = 16>
+struct ChoiceMemo {
+  struct Entry {
+    wqaa_matmul_desc d;
+    int m, q, valid;
+    unsigned epoch;
+    Choice c;
+  };
+  Entry e[WAYS] = {};
+  static unsigned slot(const wqaa_matmul_desc& d, int m, int q) {
+    return ((unsigned)d.N * 2654435761u ^ (unsigned)d.K * 40503u ^ (unsigned)m * 97u ^ (unsigned)q ^
+            ((unsigned)d.w_bits << 3) ^ ((unsigned)d.zeros_mode << 7) ^ ((unsigned)d.a_dtype << 11)) % WAYS;
+  }
+  const Choice* find(const wqaa_matmul_desc& d, int m, int q) const {
+    const Entry& en = e[slot(d, m, q)];
+    if (en.valid && en.m == m && en.q == q && en.epoch == g_plan_epoch.load(std::memory_order_relaxed) &&
+        memcmp(&en.d, &d, sizeof(d)) == 0)
+      return &en.c;
+    return nullptr;
+  }
+  void put(const wqaa_matmul_desc& d, int m, int q, const Choice& c) {
+    Entry& en = e[slot(d, m, q)];
+    en.d = d; en.m = m; en.q = q; en.c = c;
+    en.epoch = g_plan_epoch.load(std::memory_order_relaxed);
+    en.valid = 1;
+  }
+};
 
 struct DeviceInfo {
   int ok;

@@ -245,8 +245,16 @@ int gemm_launch(const wqaa_matmul_desc& d, const void* A, const void* B, const v
                 const void* Scale, const void* Zeros, const void* Bias, void* C, int m,
                 hipStream_t stream, hipEvent_t start, hipEvent_t stop, const wqaa_epilogue* epi) {
   GemmChoice c;
-  int st = gemm_choose(d, m, &c);
-  if (st != WQAA_OK) return st;
+  {
+    static thread_local ChoiceMemo<GemmChoice> memo;
+    if (const GemmChoice* hit = memo.find(d, m, 0)) {
+      c = *hit;
+    } else {
+      int st = gemm_choose(d, m, &c);
+      if (st != WQAA_OK) return st;
+      memo.put(d, m, 0, c);
+    }
+  }
   const int g = d.group_size <= 0 ? d.K : d.group_size;
   GemmArgs a;
   a.A = A; a.B = B; a.lut = LUT; a.scale = Scale; a.zeros = Zeros; a.bias = Bias; a.C = C;

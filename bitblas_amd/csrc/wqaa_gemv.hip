@@ -1041,8 +1041,17 @@ int gemv_launch(const wqaa_matmul_desc& d, const void* A, const void* B, const v
                 const void* Scale, const void* Zeros, const void* Bias, void* C, int m,
                 hipStream_t stream, hipEvent_t start, hipEvent_t stop, const wqaa_epilogue* epi) {
   GemvChoice c;
-  int st = choose(d, m, &c, epi && (epi->flags & WQAA_EPI_QUANTIZE_INPUT));
-  if (st != WQAA_OK) return st;
+  {
+    static thread_local ChoiceMemo<GemvChoice> memo;
+    const int q = (epi && (epi->flags & WQAA_EPI_QUANTIZE_INPUT)) ? 1 : 0;
+    if (const GemvChoice* hit = memo.find(d, m, q)) {
+      c = *hit;
+    } else {
+      int st = choose(d, m, &c, q != 0);
+      if (st != WQAA_OK) return st;
+      memo.put(d, m, q, c);
+    }
+  }
   GemvArgs a;
   fill_args(d, c, A, B, LUT, Scale, Zeros, Bias, C, m, &a);
   if (epi) {
