@@ -174,7 +174,9 @@ static int gemm_choose(const wqaa_matmul_desc& d, int m, GemmChoice* c) {
     c->decode = 0;
   }
   // otherwise the skinny member, unless disabled
-  c->skinny = (m <= 64 && c->mf <= 4 && getenv("WQAA_GEMM_NOSKINNY") == nullptr) ? 4 : 0;
+  int skinny_max_m = 64;
+  if (const char* f = getenv("WQAA_GEMM_SKINNY_MAXM")) skinny_max_m = atoi(f);   // tuning aid
+  c->skinny = (m <= skinny_max_m && c->mf <= 4 && getenv("WQAA_GEMM_NOSKINNY") == nullptr) ? 4 : 0;
   c->nwaves = c->mf == 16 ? 8 : 4;
   c->bn = c->skinny ? 64 : c->nwaves * 32;
   int code = c->skinny ? 100 + c->mf : c->mf;
