@@ -63,6 +63,16 @@ __device__ __forceinline__ int wave_sum(int v) {
 // ------------------------------------------------------------------------------------------
 // policy
 // ------------------------------------------------------------------------------------------
+// The reference computes `s = Qp / x.abs().max(...).clamp(min=1e-5)` with a Python int on the left
+// (integration/BitNet/utils_quant.py:166): torch evaluates that as `reciprocal(t) * 127` - TWO fp32 roundings, which
+// differs from the single quotient 127 / t in the last bit for about half of all inputs (pinned by
+// tests/golden/bitnet_golden.npz, produced by running the reference function).  The reciprocal is taken in fp64 and
+// rounded once: identical to a correctly rounded fp32 division (53 >= 2 * 24 + 2 bits).
+__device__ inline float act_quant_scale(float absmax) {
+  const float r = (float)(1.0 / (double)fmaxf(absmax, 1e-5f));
+  return __fmul_rn(r, 127.0f);
+}
+
 template <int KIND_, int LAYOUT_, int AT_, int MB_, int MODE_, int FLAGS_, int R_ = 2, int D_ = 2, bool AD_ = false>
 struct GemvPolicy {
   static constexpr int KIND = KIND_, LAYOUT = LAYOUT_, AT = AT_, MB = MB_, MODE = MODE_, FLAGS = FLAGS_;
@@ -455,7 +465,7 @@ __global__ void __launch_bounds__(1024) wq_gemv_kernel(const GemvArgs a) {
   const bool have_work = rg < n_rg;
   issue(st, have_work ? rg : n_rg - 1, 0, true);
 
-  float aq_s[MB];                         // AQ: 127 / clamp(max |row|, 1e-5) of every row of the batch tile
+  float aq_s[MB];                         // AQ: act_quant_scale(max |row|) of every row of the batch tile
 #pragma unroll
   for (int mi = 0; mi < MB; ++mi) aq_s[mi] = 1.f;
   if constexpr (AQ) {
@@ -474,8 +484,7 @@ __global__ void __launch_bounds__(1024) wq_gemv_kernel(const GemvArgs a) {
     for (int mi = 0; mi < MB; ++mi) {
       float mx = 0.f;
       for (int w = 0; w < NW; ++w) mx = fmaxf(mx, aq_wmax[w * 4 + mi]);
-      // IEEE-exact quotient (fp64 divide, one rounding): the default fp32 division is not correctly rounded
-      aq_s[mi] = (float)(127.0 / (double)fmaxf(mx, 1e-5f));
+      aq_s[mi] = act_quant_scale(mx);
     }
     float my_s = aq_s[0];
 #pragma unroll
@@ -1096,7 +1105,7 @@ void gemv_init() {
 
 // ------------------------------------------------------------------------------------------
 // per-row absmax int8 quantiser - the pre-op of BitNet-style callers (integration/BitNet/
-// utils_quant.py:161-168): s = 127 / clamp(max|x|, 1e-5), q = clamp(round(x * s), -128, 127).
+// utils_quant.py:161-168): s = (1 / clamp(max|x|, 1e-5)) * 127 (see act_quant_scale), q = clamp(round(x * s), -128, 127).
 // One workgroup per row, 16-byte loads, wave DPP max + LDS across waves.  HBM-bound: 3 B per element.
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) wq_act_quant_kernel(const half_t* __restrict__ X, int K, int8_t* __restrict__ Q,
@@ -1119,8 +1128,7 @@ __global__ void __launch_bounds__(256) wq_act_quant_kernel(const half_t* __restr
   if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = mx;
   __syncthreads();
   mx = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
-  // IEEE-exact quotient (fp64 divide, one rounding): the default fp32 division is not correctly rounded
-  const float s = (float)(127.0 / (double)fmaxf(mx, 1e-5f));
+  const float s = act_quant_scale(mx);
   if (threadIdx.x == 0) S[row] = s;
   u32x2* qr = reinterpret_cast<u32x2*>(Q + row * K);
   for (int i = threadIdx.x; i < nvec; i += 256) {

@@ -492,9 +492,13 @@ def bitnet_weight_quant(weight: np.ndarray):
 
 
 def bitnet_activation_quant(x: np.ndarray):
-    """per-token int8: s = 127 / clamp(max|x|, 1e-5); round(x * s) clamped to [-128, 127] (:157-164)."""
+    """per-token int8: s = Qp / clamp(max|x|, 1e-5); round(x * s) clamped to [-128, 127] (:162-169).
+
+    `Qp / tensor` with a Python int on the left is `tensor.reciprocal() * Qp` in torch (Tensor.__rtruediv__):
+    two fp32 roundings, not one quotient - pinned by tests/golden/bitnet_golden.npz (reference-run)."""
     xf = np.asarray(x).astype(np.float32)
-    s = np.float32(127.0) / np.maximum(np.abs(xf).max(axis=-1, keepdims=True), np.float32(1e-5))
+    m = np.maximum(np.abs(xf).max(axis=-1, keepdims=True), np.float32(1e-5))
+    s = ((np.float32(1.0) / m).astype(np.float32) * np.float32(127.0)).astype(np.float32)
     q = np.clip(np.rint(xf * s), -128, 127).astype(np.int8)
     return q, s.astype(np.float32)
 

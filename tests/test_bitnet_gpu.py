@@ -90,3 +90,18 @@ def test_single_launch_layer_for_decode_batches(m, bias, N, K):
     wq = module_codes(lin)
     want = oracle.bitnet_forward(x, wq, np.float32(lin.sw.item()), b)
     assert np.array_equal(one, want)
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_quantiser_and_layer_against_reference_run_vectors(tag):
+    """tests/golden/bitnet_golden.npz holds what the reference's own activation_quant / post_quant_process
+    (integration/BitNet/utils_quant.py:162-176) return on seeded inputs (oracle/gen_bitnet_golden.py runs them):
+    the HIP quantiser must reproduce q and s bit for bit - including torch's `127 / t` = `reciprocal(t) * 127`."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "bitnet_golden.npz"))
+    x = g[f"{tag}_x"]
+    K = x.shape[1]
+    lin = BitLinear(K, 256).cuda()
+    q, s = lin.activation_quant(torch.from_numpy(x).cuda())
+    assert np.array_equal(q.cpu().numpy(), g[f"{tag}_q"])
+    assert np.array_equal(s.cpu().numpy(), g[f"{tag}_si"][:, 0])

@@ -1,7 +1,12 @@
 """The oracle against vectors produced by the reference's own numpy helpers (oracle/gen_golden.py)."""
+import os
+
 import numpy as np
+import pytest
 
 import wqaa_oracle as oracle
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
 def test_compress_matches_reference(golden):
@@ -104,3 +109,21 @@ def test_gptq_unpack_helpers():
     q = packed.astype(np.uint32).view(np.int32)
     assert np.array_equal(oracle.unpack_qzeros(q, 4), (z + 1) & 15)
     assert np.array_equal(oracle.unpack_qzeros(q, 4, v2=True), z)
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_bitnet_caller_ops_against_reference_run_vectors(tag):
+    """oracle/gen_bitnet_golden.py RUNS the reference's BitLinearBitBLAS.weight_quant / activation_quant /
+    post_quant_process (integration/BitNet/utils_quant.py:155-176) on seeded inputs; the oracle's restatement
+    must reproduce every intermediate and the final half output bit for bit."""
+    g = np.load(os.path.join(GOLDEN_DIR, "bitnet_golden.npz"))
+    W, x = g[f"{tag}_W"], g[f"{tag}_x"]
+    wq, sw = oracle.bitnet_weight_quant(W)
+    assert np.array_equal(wq, g[f"{tag}_wq"])
+    assert np.float32(sw) == g[f"{tag}_sw"]
+    q, si = oracle.bitnet_activation_quant(x)
+    assert np.array_equal(q, g[f"{tag}_q"])
+    assert np.array_equal(si, g[f"{tag}_si"])
+    bias = g[f"{tag}_bias"] if f"{tag}_bias" in g.files else None
+    y = oracle.bitnet_forward(x, wq, sw, bias)
+    assert np.array_equal(y.view(np.uint16), g[f"{tag}_y"].view(np.uint16))
