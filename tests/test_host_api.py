@@ -10,6 +10,7 @@ import json
 import os
 import threading
 
+import numpy as np
 import pytest
 import torch
 
@@ -156,3 +157,42 @@ def test_split_k_operator_mirror():
     op = bitblas.MatmulWithSplitK(cfg, enable_tuning=False)
     assert op.k_split == 4 and op.plans[16]["kernel_family"] == 2
     assert op.retrieve_weight_shape() == [1024, 2048]
+
+
+@pytest.mark.parametrize("bits", [4, 2])
+def test_gptq_repack_against_reference_run_vectors(bits):
+    """tests/golden/gptq_golden.npz: what the reference's own unpack_qweight / unpack_qzeros[_v2] and
+    Linear.repack_from_gptq[_v2] (bitblas/module/__init__.py:24-74, 315-363) produce on seeded AutoGPTQ-shaped
+    tensors (oracle/gen_gptq_golden.py runs them).  The mirror must produce the same buffers - including the
+    int8 wrap of `stored zero + 1` at the top of the code range."""
+    import types
+    import wqaa_oracle as oracle
+    from bitblas_amd import lib as wlib
+    from bitblas_amd import module as wmod
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "gptq_golden.npz"))
+    tag = f"b{bits}"
+    qweight, qzeros, scales = (torch.from_numpy(g[f"{tag}_{k}"]) for k in ("qweight", "qzeros", "scales"))
+    K, N = qweight.shape[0] * 32 // bits, qweight.shape[1]
+    gsz = K // qzeros.shape[0]
+    codes_ref = g[f"{tag}_unpack_qweight"]                       # (N, K) integer codes
+    # helpers: product mirror and oracle
+    assert np.array_equal(wmod.unpack_qweight(qweight.T.contiguous().view(torch.int8), bits).numpy(), codes_ref)
+    assert np.array_equal(wmod.unpack_qzeros(qzeros, bits).numpy(), g[f"{tag}_unpack_qzeros"])
+    assert np.array_equal(wmod.unpack_qzeros_v2(qzeros, bits).numpy(), g[f"{tag}_unpack_qzeros_v2"])
+    assert np.array_equal(oracle.unpack_qweight(qweight.T.contiguous().view(torch.int8).numpy(), bits), codes_ref)
+    assert np.array_equal(oracle.unpack_qzeros(qzeros.numpy(), bits), g[f"{tag}_unpack_qzeros"])
+    assert np.array_equal(oracle.unpack_qzeros(qzeros.numpy(), bits, v2=True), g[f"{tag}_unpack_qzeros_v2"])
+    fake = types.SimpleNamespace(qweight=qweight, qzeros=qzeros, scales=scales, bias=None)
+    for v2 in (False, True):
+        for mode in ("original", "rescale", "quantized"):
+            lin = bitblas.Linear(K, N, bias=False, A_dtype="float16", W_dtype=f"uint{bits}", accum_dtype="float16",
+                                 out_dtype="float16", group_size=gsz, with_scaling=True, with_zeros=True,
+                                 zeros_mode=mode, opt_M=[1, 16])
+            (lin.repack_from_gptq_v2 if v2 else lin.repack_from_gptq)(fake, device="cpu")
+            key = f"{tag}_{'v2' if v2 else 'v1'}_{mode}"
+            assert np.array_equal(lin.scales.numpy(), g[f"{key}_scales"])
+            assert np.array_equal(lin.zeros.numpy(), g[f"{key}_zeros"]), key
+            cfg = lin.bitblas_matmul.config
+            layout = wlib.LAYOUT_LOP3 if cfg.fast_decoding else wlib.LAYOUT_PLAIN
+            back = wlib.unpack_weight(lin.qweight.numpy(), K, bits, layout, wlib.F16)
+            assert np.array_equal(back, codes_ref)
