@@ -20,6 +20,7 @@ W[:c]) so the fixtures stay small.  Output: tests/golden/optest_golden.npz + opt
 
 Runs only where /root/reference exists.  Test infrastructure - never imported by the product.
 Sources executed: testing/python/operators/test_general_matmul_ops_backend_tl.py (:327-343, 13 cases),
+test_general_matmul_ops_backend.py (:211-229, 9 cases, the ones with bias),
 test_general_matmul_fp8.py (:150-158), test_general_matmul_ops_nf4.py (:64-66), test_general_matmul_bf16.py
 (:170-178).
 """
@@ -142,7 +143,15 @@ def install_stub(rec, trick, lut, ref_utils):
     quant = types.ModuleType("bitblas.quantization")
     quant.general_compress = ref_utils.general_compress
     bb.testing, bb.quantization = testing, quant
-    sys.modules["bitblas"], sys.modules["bitblas.testing"], sys.modules["bitblas.quantization"] = bb, testing, quant
+    bb.__path__ = []                                    # a package, so `from bitblas.tl.lower import ...` resolves
+    tl = types.ModuleType("bitblas.tl")
+    tl.__path__ = []
+    lower = types.ModuleType("bitblas.tl.lower")
+    lower.tl_lower = None                                # imported by a test module, used by its codegen tests only
+    tl.lower = lower
+    bb.tl = tl
+    sys.modules.update({"bitblas": bb, "bitblas.testing": testing, "bitblas.quantization": quant,
+                        "bitblas.tl": tl, "bitblas.tl.lower": lower})
     torch.Tensor.cuda = lambda self, *a, **k: self
     torch.testing.assert_close = lambda a, b, **k: rec.expected(a, b)
 
@@ -175,6 +184,7 @@ def main():
     rec = Recorder()
     install_stub(rec, trick, lut, ref_utils)
     plan = [("test_general_matmul_ops_backend_tl.py", "test_matmul_torch_dequant_forward"),
+            ("test_general_matmul_ops_backend.py", "test_matmul_torch_forward"),
             ("test_general_matmul_fp8.py", "test_matmul_torch_forward_weight_dequantize"),
             ("test_general_matmul_ops_nf4.py", "test_matmul_torch_forward"),
             ("test_general_matmul_bf16.py", "test_matmul_torch_forward_weight_dequantize")]

@@ -33,7 +33,8 @@ matmul.  What *is* importable is `bitblas/quantization/utils.py`; `oracle/gen_go
    `oracle/gen_optest_golden.py` RUNS those test functions from the files where they lie (a recorder stands in
    for the un-importable `bitblas` package) and commits their seeded operands + the expected result of their
    in-test `ref_program` (tests/golden/optest_golden.*): 13 cases of test_general_matmul_ops_backend_tl.py
-   (uint4 / int4, g = -1 / 32, zeros original / rescale / quantized, M = 1 / 256), 4 of test_general_matmul_fp8.py
+   (uint4 / int4, g = -1 / 32, zeros original / rescale / quantized, M = 1 / 256), 9 of
+   test_general_matmul_ops_backend.py (bias, M = 1 / 768), 4 of test_general_matmul_fp8.py
    (W e4m3 x A fp16, +-scale g = 32), 2 of test_general_matmul_ops_nf4.py, 4 of test_general_matmul_bf16.py.
    `tests/test_optest_golden.py`: this module is bit-identical to those expectations on >= 99.8 % of the fp16
    outputs and one fp16 ulp away on the rest (fp32 summation order inside torch.matmul); the bf16 expectations

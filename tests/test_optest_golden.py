@@ -1,6 +1,7 @@
 """The reference's own operator tests as fixtures: seeded operands and the expected result of their in-test
 `ref_program`, produced by RUNNING those test functions (oracle/gen_optest_golden.py; sources
-testing/python/operators/test_general_matmul_ops_backend_tl.py:327-343, test_general_matmul_fp8.py:150-158,
+testing/python/operators/test_general_matmul_ops_backend_tl.py:327-343, test_general_matmul_ops_backend.py:211-229,
+test_general_matmul_fp8.py:150-158,
 test_general_matmul_ops_nf4.py:64-66, test_general_matmul_bf16.py:170-178).
 
 CPU: pins the oracle's decode + matmul semantics against those expectations.
@@ -55,6 +56,7 @@ def tolerance(c, slack=1.0):
 def test_fixture_inventory():
     srcs = [c["source"] for c in META]
     assert srcs.count("test_general_matmul_ops_backend_tl.py") == 13
+    assert srcs.count("test_general_matmul_ops_backend.py") == 9
     assert srcs.count("test_general_matmul_fp8.py") == 4
     assert srcs.count("test_general_matmul_ops_nf4.py") == 2
     assert srcs.count("test_general_matmul_bf16.py") == 4
@@ -68,8 +70,8 @@ def test_oracle_reproduces_the_reference_tests_expectation(i):
     # (quantization.py:169-176: zero -> 2^-7, subnormals wrong; ~1.5 % of uniform(-1,1) weights are subnormal)
     want = oracle.matmul_dequant(
         c["A"], c["W"], source_format=c["src"], bit=c["bit"], scale=c.get("scale"), zeros=c.get("zeros"),
-        zeros_mode=c["zeros_mode"], group_size=c["g"], a_dtype=cfg["A_dtype"], out_dtype=cfg["out_dtype"],
-        strict_reference=c["src"] != "fp_e4m3")
+        zeros_mode=c["zeros_mode"], group_size=c["g"], bias=c.get("bias"), a_dtype=cfg["A_dtype"],
+        out_dtype=cfg["out_dtype"], strict_reference=c["src"] != "fp_e4m3")
     assert_fp_parity(want, c["expected"], **tolerance(c))
 
 
@@ -90,13 +92,15 @@ def test_hip_path_reproduces_the_reference_tests_expectation(i):
         W = mm.transform_weight(W.view(torch.float8_e4m3fn).cuda())
     else:   # integer codes / table indices, as the reference tests hand them to weight_transform
         W = mm.weight_transform(W).cuda() if mm.weight_transform is not None else W.cuda()
-    scale = zeros = None
+    scale = zeros = bias = None
+    if "bias" in c:
+        bias = torch.from_numpy(np.ascontiguousarray(c["bias"])).to(tdt).cuda()
     if "scale" in c:
         scale = torch.from_numpy(np.ascontiguousarray(c["scale"])).to(tdt).cuda()
     if "zeros" in c:
         z = torch.from_numpy(np.ascontiguousarray(c["zeros"]))
         zeros = z.cuda() if c["zeros_mode"] == "quantized" else z.to(tdt).cuda()
-    out = mm(A, W, scale=scale, zeros=zeros)
+    out = mm(A, W, scale=scale, zeros=zeros, bias=bias)
     torch.cuda.synchronize()
     # two summation orders stack here (kernel vs oracle vs torch): twice the oracle's bound - still 5x tighter than
     # the reference test's own rtol = atol = 1e-2 with 5 % mismatches allowed (backend_tl.py:275)
