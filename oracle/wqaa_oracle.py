@@ -39,8 +39,12 @@ matmul.  What *is* importable is `bitblas/quantization/utils.py`; `oracle/gen_go
    `tests/test_optest_golden.py`: this module is bit-identical to those expectations on >= 99.8 % of the fp16
    outputs and one fp16 ulp away on the rest (fp32 summation order inside torch.matmul); the bf16 expectations
    are themselves rounded to bfloat16 and are met within 2^-7.
-=> STILL UNPINNED ("parity unpinned"): W_int2 x A_int8, fp4_e2m1 and dense fp8 x fp8 - the
-   reference never asserts on them - and the kernels' e4m3 bit trick (zero -> 2^-7, wrong subnormals): the fp8
+   Dense fp8 x fp8 (e4m3, e5m2): the reference test (test_general_matmul_fp8.py:11-71) PRINTS its expectation and
+   asserts nothing; the printed tensor is recorded by the same script and `matmul_dense` reproduces it to 1e-5.
+   The BitNet caller ops and the GPTQ repack are pinned by gen_bitnet_golden.py / gen_gptq_golden.py (the W_int2 x
+   A_int8 path is thereby pinned at the layer level: quantisers, exact integer product, post-process).
+=> STILL UNPINNED ("parity unpinned"): the operator-level W_int2 x A_int8 decode convention
+   (u - 2, TE spec) and fp4_e2m1 - the reference never asserts on them - and the kernels' e4m3 bit trick (zero -> 2^-7, wrong subnormals): the fp8
    test's expectation decodes per IEEE and hides the difference behind rtol = 1e-1, so `strict_reference=True`
    for e4m3 follows `quantization.py:169-176` as read, not as run.
 """
