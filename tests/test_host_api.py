@@ -196,3 +196,18 @@ def test_gptq_repack_against_reference_run_vectors(bits):
             layout = wlib.LAYOUT_LOP3 if cfg.fast_decoding else wlib.LAYOUT_PLAIN
             back = wlib.unpack_weight(lin.qweight.numpy(), K, bits, layout, wlib.F16)
             assert np.array_equal(back, codes_ref)
+
+
+def test_bench_algorithmic_bytes_are_the_survey_figures():
+    """bench.py prices `roofline.achieved` with SURVEY.md section 8(d)'s per-launch byte counts."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    assert bench.algorithmic_bytes(1, 4096, 4096) == 8_667_136                      # c2, scale only
+    assert bench.algorithmic_bytes(1, 4096, 4096, zeros=True) == 8_667_136 + 262_144
+    assert bench.algorithmic_bytes(1, 11008, 4096) == 8192 + 22_544_384 + 704_512 + 22_016
+    assert bench.algorithmic_bytes(1, 1024, 1024, g=1024) == 2048 + 524_288 + 2048 + 2048          # c1, g = -1
+    names = [n for (n, _, _) in bench.LLAMA2_7B_LINEARS]
+    assert len(names) == 7 and bench.HBM_PEAK_GBS == 8000.0
