@@ -97,3 +97,52 @@ def test_c_packer_against_oracle_and_golden(golden):
             tag = key[len("compress_"):]
             bits = int(tag[1])
             assert np.array_equal(wlib.pack_weight(golden["codes_" + tag], bits, wlib.LAYOUT_PLAIN, wlib.F16), golden[key])
+
+
+def test_selector_invariants_over_a_random_configuration_sweep():
+    """Host logic only (wqaa_select needs no GPU): whatever the selector answers must be launchable - workgroup
+    size a multiple of 64 and <= 1024, LDS within the 160 KB of a CU, non-empty grid, a name in the reference's
+    kernel-name style (general_matmul/__init__.py:240-318) - and a refusal must carry a message."""
+    import re
+    rng = np.random.default_rng(7)
+    name_re = re.compile(r"^matmul_m\d+n\d+k\d+_[a-z0-9]+x[a-z0-9_]+_(gemv_b\d+r\d+d\d+(_areg)?|tcx\d+x\d+x\d+(xr)?(xs|xd|xw)?)$")
+    pairs = [(wlib.F16, wlib.W_UINT, b) for b in (1, 2, 4, 8)] + [(wlib.F16, wlib.W_INT, b) for b in (1, 2, 4, 8)] + \
+            [(wlib.F16, wlib.W_NF, 4), (wlib.F16, wlib.W_FP4, 4), (wlib.F16, wlib.W_E4M3, 8),
+             (wlib.BF16, wlib.W_UINT, 4), (wlib.BF16, wlib.W_NF, 4),
+             (wlib.I8, wlib.W_INT, 2), (wlib.I8, wlib.W_INT, 4), (wlib.I8, wlib.W_NATIVE, 8),
+             (wlib.I4, wlib.W_NATIVE, 4), (wlib.I4, wlib.W_INT, 2),
+             (wlib.E4M3, wlib.W_E4M3, 8), (wlib.E5M2, wlib.W_E5M2, 8), (wlib.F16, wlib.W_NATIVE, 16)]
+    ok = refused = 0
+    for _ in range(3000):
+        a, wf, bits = pairs[rng.integers(len(pairs))]
+        N = int(rng.choice([16, 48, 200, 256, 1000, 1024, 4096, 5120, 11008, 28672]))
+        K = int(rng.choice([256, 512, 768, 1024, 2048, 4096, 8192, 11008, 28672]))
+        M = int(rng.choice([1, 2, 3, 5, 8, 9, 16, 17, 33, 64, 65, 100, 128, 256, 777, 1024, 4096]))
+        fp_act = a in (wlib.F16, wlib.BF16)
+        quant = wf in (wlib.W_UINT, wlib.W_INT, wlib.W_NF, wlib.W_FP4, wlib.W_E4M3) and fp_act
+        g = int(rng.choice([-1, 32, 64, 128, 256])) if quant else -1
+        scaling = bool(rng.integers(2)) if quant else False
+        zmode = int(rng.choice([wlib.Z_NONE, wlib.Z_ORIGINAL, wlib.Z_RESCALE, wlib.Z_QUANTIZED])) \
+            if (scaling and wf in (wlib.W_UINT, wlib.W_INT)) else wlib.Z_NONE
+        out = {wlib.I8: wlib.I32, wlib.I4: wlib.I32, wlib.BF16: wlib.F32, wlib.E4M3: wlib.F32, wlib.E5M2: wlib.F32}.get(a, wlib.F16)
+        layout = int(rng.integers(2)) if (wf in (wlib.W_UINT, wlib.W_INT) and bits < 8 and a != wlib.BF16) else wlib.LAYOUT_PLAIN
+        desc = wlib.make_desc(N=N, K=K, a_dtype=a, w_format=wf, w_bits=bits, out_dtype=out, group_size=g,
+                              with_scaling=scaling, zeros_mode=zmode, with_bias=bool(rng.integers(2)), w_layout=layout)
+        try:
+            p = wlib.select(desc, M)
+        except wlib.WqaaError as e:
+            assert e.code in (wlib.ERR_UNSUPPORTED, wlib.ERR_BAD_DESC) and str(e), (N, K, M, a, wf, bits)
+            refused += 1
+            continue
+        ok += 1
+        ctx = (N, K, M, a, wf, bits, g, scaling, zmode, layout, p)
+        assert p["kernel_family"] in (1, 2), ctx
+        assert p["threads"] % 64 == 0 and 64 <= p["threads"] <= 1024, ctx
+        assert 0 <= p["lds_bytes"] <= 160 * 1024, ctx
+        assert p["grid"] >= 1, ctx
+        assert name_re.match(p["name"]), ctx
+        assert f"m{M}n{N}k{K}_" in p["name"], ctx
+        if M <= 2 and p["kernel_family"] == 2:
+            # only when the GEMV family has no member for the configuration (groups below its lane chunk)
+            assert g != -1 and g < 128, ctx
+    assert ok > 1500 and refused > 0
