@@ -23,7 +23,8 @@ Sources executed: testing/python/operators/test_general_matmul_ops_backend_tl.py
 test_general_matmul_ops_backend.py (:211-229, 9 cases, the ones with bias),
 test_general_matmul_fp8.py (:150-158; :63-71 dense e4m3 / e5m2 - that test PRINTS its expectation and asserts
 nothing, the printed tensor is recorded), test_general_matmul_ops_nf4.py (:64-66), test_general_matmul_bf16.py
-(:170-178).
+(:170-178); testing/python/module/test_bitblas_linear.py (:45-49 dense fp16 Linear vs torch.nn.Linear, :169-176
+uint4 / uint2 weight-only, with bias) through a recorder `bitblas.Linear`.
 """
 from __future__ import annotations
 
@@ -150,8 +151,47 @@ def install_stub(rec, trick, lut, ref_utils):
             rec.operands(args, output, placeholder)
             return placeholder
 
+    class Linear(torch.nn.Module):
+        """recorder for `bitblas.Linear` (testing/python/module/test_bitblas_linear.py): holds the buffers the test
+        assigns, records them with the input at call time, computes nothing"""
+
+        def __init__(self, in_features, out_features, bias=False, A_dtype="float16", W_dtype="float16",
+                     accum_dtype="float16", out_dtype="float16", group_size=-1, with_scaling=False,
+                     with_zeros=False, zeros_mode=None, opt_M=None, **_):
+            super().__init__()
+            self.kw = dict(N=out_features, K=in_features, A_dtype=A_dtype, W_dtype=W_dtype, accum_dtype=accum_dtype,
+                           out_dtype=out_dtype, group_size=group_size, with_scaling=with_scaling,
+                           with_zeros=with_zeros, zeros_mode=zeros_mode, with_bias=bool(bias))
+            src, bit = trick[W_dtype]
+            self.bitblas_matmul = types.SimpleNamespace(source_format=src, bit=bit, weight_transform=lambda w: w)
+            holder = lambda: torch.nn.Parameter(torch.zeros(1), requires_grad=False)   # `.data = ...` targets
+            self.qweight, self.scales, self.zeros = holder(), holder(), holder()
+            self.bias = holder() if bias else None
+            self.weight = None
+
+        def cuda(self, *a, **k):
+            return self
+
+        def load_and_transform_weight(self, weight, *a, **k):
+            self.weight = weight
+
+        def forward(self, x):
+            kw = dict(self.kw, M=x.shape[0])
+            rec.begin(kw)
+            dense = self.weight is not None
+            ops = [x, self.weight if dense else self.qweight.data]
+            if kw["with_scaling"]:
+                ops.append(self.scales.data)
+            if kw["with_zeros"]:
+                ops.append(self.zeros.data)
+            if kw["with_bias"]:
+                ops.append(self.bias.data)
+            placeholder = torch.zeros((x.shape[0], kw["N"]), dtype=torch.float16)
+            rec.operands(ops, None, placeholder)
+            return placeholder
+
     bb = types.ModuleType("bitblas")
-    bb.MatmulConfig, bb.Matmul = MatmulConfig, Matmul
+    bb.MatmulConfig, bb.Matmul, bb.Linear = MatmulConfig, Matmul, Linear
     bb.set_log_level = lambda *a, **k: None
     testing = types.ModuleType("bitblas.testing")
     testing.torch_assert_close = lambda a, b, **k: rec.expected(a, b)
@@ -161,6 +201,14 @@ def install_stub(rec, trick, lut, ref_utils):
     quant.general_compress = ref_utils.general_compress
     bb.testing, bb.quantization = testing, quant
     bb.__path__ = []                                    # a package, so `from bitblas.tl.lower import ...` resolves
+    cache = types.ModuleType("bitblas.cache")
+    cache.global_operator_cache = types.SimpleNamespace(clear=lambda: None)
+    qutils = types.ModuleType("bitblas.quantization.utils")
+    qutils.general_compress = ref_utils.general_compress
+    quant.__path__ = []
+    quant.utils = qutils
+    bb.cache = cache
+    sys.modules.update({"bitblas.cache": cache, "bitblas.quantization.utils": qutils})
     tl = types.ModuleType("bitblas.tl")
     tl.__path__ = []
     lower = types.ModuleType("bitblas.tl.lower")
@@ -174,7 +222,7 @@ def install_stub(rec, trick, lut, ref_utils):
 
 
 def run_reference_test(filename, func, print_hook=None):
-    path = os.path.join(OPTESTS, filename)
+    path = os.path.join(OPTESTS if not filename.startswith("module/") else os.path.join(REF, "testing", "python"), filename)
     ns = {"__name__": "ref_optest", "__file__": path}
     if print_hook is not None:
         ns["print"] = print_hook                         # module-global shadow of the builtin, this module only
@@ -207,7 +255,9 @@ def main():
             ("test_general_matmul_fp8.py", "test_matmul_torch_forward_weight_dequantize"),
             ("test_general_matmul_fp8.py", "test_matmul_torch_forward"),
             ("test_general_matmul_ops_nf4.py", "test_matmul_torch_forward"),
-            ("test_general_matmul_bf16.py", "test_matmul_torch_forward_weight_dequantize")]
+            ("test_general_matmul_bf16.py", "test_matmul_torch_forward_weight_dequantize"),
+            ("module/test_bitblas_linear.py", "test_correctness_consistent"),
+            ("module/test_bitblas_linear.py", "test_correctness_weight_only_dequantize")]
     origin = []
     for fn, func in plan:
         n0 = len(rec.cases)
@@ -219,7 +269,7 @@ def main():
     for i, (case, src) in enumerate(zip(rec.cases, origin)):
         cfg = {k: v for k, v in case["config"].items() if v is not None}
         M, N, K = cfg["M"], cfg["N"], cfg["K"]
-        r, c = min(M, MAX_ROWS), min(N, MAX_COLS)
+        r, c = min(M, MAX_ROWS), min(N, MAX_COLS if not src.startswith("module/") else 32)
         ops = list(case["operands"])
         names = ["A", "W"]
         if cfg.get("with_scaling"):

@@ -2,7 +2,7 @@
 `ref_program`, produced by RUNNING those test functions (oracle/gen_optest_golden.py; sources
 testing/python/operators/test_general_matmul_ops_backend_tl.py:327-343, test_general_matmul_ops_backend.py:211-229,
 test_general_matmul_fp8.py:150-158,
-test_general_matmul_ops_nf4.py:64-66, test_general_matmul_bf16.py:170-178).
+test_general_matmul_ops_nf4.py:64-66, test_general_matmul_bf16.py:170-178, module/test_bitblas_linear.py:45-49, 169-176).
 
 CPU: pins the oracle's decode + matmul semantics against those expectations.
 GPU: the HIP path through the C ABI on the same operands against the same expectations."""
@@ -20,9 +20,9 @@ from helpers import assert_fp_parity
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 META = json.load(open(os.path.join(GOLD, "optest_golden.json")))["cases"]
 ARR = np.load(os.path.join(GOLD, "optest_golden.npz"))
-IDS = [f"{i}-{c['source'].replace('test_general_matmul_', '').replace('.py', '')}-{c['config']['W_dtype']}-m{c['rows']}"
+IDS = [f"{i}-{c['source'].replace('test_general_matmul_', '').replace('.py', '').replace('module/test_bitblas_', '')}-{c['config']['W_dtype']}-m{c['rows']}"
        f"{'-g%d' % c['config']['group_size'] if c['config'].get('group_size') else ''}"
-       f"{'-' + c['config']['zeros_mode'] if c['config'].get('with_zeros') else ''}" for i, c in enumerate(META)]
+       f"{'-' + (c['config'].get('zeros_mode') or 'original') if c['config'].get('with_zeros') else ''}" for i, c in enumerate(META)]
 
 
 def _bf16_bits_to_f32(a):
@@ -61,12 +61,18 @@ def test_fixture_inventory():
     assert len(GPU_CASES) == 32
     assert srcs.count("test_general_matmul_ops_nf4.py") == 2
     assert srcs.count("test_general_matmul_bf16.py") == 4
+    assert srcs.count("module/test_bitblas_linear.py") == 11
 
 
 @pytest.mark.parametrize("i", range(len(META)), ids=IDS)
 def test_oracle_reproduces_the_reference_tests_expectation(i):
     c = load(i)
     cfg = c["cfg"]
+    if cfg["W_dtype"] == "float16":
+        # dense fp16 Linear against torch.nn.Linear (module/test_bitblas_linear.py:14-49)
+        want = oracle.matmul_dense(c["A"], c["W"], a_dtype="float16", out_dtype="float16", bias=c.get("bias"))
+        assert_fp_parity(want, c["expected"], **tolerance(c))
+        return
     if cfg["A_dtype"].endswith("float8"):
         # dense fp8 x fp8 (test_general_matmul_fp8.py:11-71): exact products of exactly decoded operands, fp32 sum
         want = oracle.matmul_dense(c["A"], c["W"], a_dtype=cfg["A_dtype"], w_dtype=cfg["W_dtype"], out_dtype=cfg["out_dtype"])
@@ -82,7 +88,9 @@ def test_oracle_reproduces_the_reference_tests_expectation(i):
 
 
 # dense fp8 x fp8 cases pin the oracle only (the HIP dense members are compared with the oracle in test_gemm_gpu.py)
-GPU_CASES = [i for i, c in enumerate(META) if c["config"]["A_dtype"] in ("float16", "bfloat16")]
+# (so do the Linear-test fixtures: Linear itself is compared with the oracle in test_linear_gpu.py)
+GPU_CASES = [i for i, c in enumerate(META)
+             if c["config"]["A_dtype"] in ("float16", "bfloat16") and not c["source"].startswith("module/")]
 
 
 @pytest.mark.gpu
