@@ -127,3 +127,18 @@ def test_bitnet_caller_ops_against_reference_run_vectors(tag):
     bias = g[f"{tag}_bias"] if f"{tag}_bias" in g.files else None
     y = oracle.bitnet_forward(x, wq, sw, bias)
     assert np.array_equal(y.view(np.uint16), g[f"{tag}_y"].view(np.uint16))
+
+
+def test_int4_activations_against_the_reference_tests_expectation():
+    """oracle/gen_int4_golden.py RUNS testing/python/operators/test_general_matmul_ops_int4.py's
+    matmul_int4_torch_forward (int4 x int4, int4 x int2): the packed operands exactly as that test hands them to
+    the operator, and its expected `A.float() @ B.T.float()`.  Pins nibble / field order of both operands."""
+    g = np.load(os.path.join(GOLDEN_DIR, "int4_golden.npz"))
+    seen = set()
+    for i in range(2):
+        w_bits = {"int4": 4, "int2": 2}[str(g[f"c{i}_W_dtype"])]
+        seen.add(w_bits)
+        codes = oracle.general_decompress(g[f"c{i}_B"], w_bits)
+        got = oracle.matmul_int4_act(g[f"c{i}_A"], codes, w_bits=w_bits)
+        assert np.array_equal(got, g[f"c{i}_expected"])
+    assert seen == {2, 4}
