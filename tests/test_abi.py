@@ -146,3 +146,18 @@ def test_selector_invariants_over_a_random_configuration_sweep():
             # only when the GEMV family has no member for the configuration (groups below its lane chunk)
             assert g != -1 and g < 128, ctx
     assert ok > 1500 and refused > 0
+
+
+def test_c_packer_reproduces_the_reference_int4_tests_operands():
+    """tests/golden/int4_golden.npz holds the weight operand exactly as the reference's int4 test packs it by hand
+    (test_general_matmul_ops_int4.py:49-57, produced by running that test): the C packer must emit the same bytes
+    from the unpacked fields."""
+    import os
+    import wqaa_oracle as oracle
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "int4_golden.npz"))
+    for i in range(2):
+        bits = {"int4": 4, "int2": 2}[str(g[f"c{i}_W_dtype"])]
+        packed = g[f"c{i}_B"]
+        codes = oracle.general_decompress(packed, bits).astype(np.int8)
+        assert np.array_equal(wlib.pack_weight(codes, bits, wlib.LAYOUT_PLAIN, wlib.I4), packed)
+        assert np.array_equal(wlib.unpack_weight(packed, codes.shape[1], bits, wlib.LAYOUT_PLAIN, wlib.I4), codes)
