@@ -30,11 +30,24 @@ def load_reference_utils():
     return mod
 
 
+def load_test_suite_interleave():
+    """`interleave_weight` as copied into the reference's own type-conversion test (numpy only); the file itself
+    needs tvm, so the function's source text is sliced out at run time and executed - nothing is copied here."""
+    path = "/root/reference/testing/python/type_conversion/test_int4b_fp16_convert.py"
+    src = open(path).read()
+    start = src.index("def interleave_weight(")
+    end = src.index("def tir_interleave_weight(")
+    ns = {"np": np}
+    exec(compile(src[start:end], path, "exec"), ns)
+    return ns["interleave_weight"]
+
+
 def main():
     if not os.path.exists(REF_UTILS):
         print("reference not present; golden vectors are already committed", file=sys.stderr)
         return 0
     ref = load_reference_utils()
+    test_copy = load_test_suite_interleave()
     rng = np.random.default_rng(20250704)
     out = {}
     skipped = set()
@@ -51,8 +64,15 @@ def main():
                         inter = ref.interleave_weight(comp.copy(), nbits=bits, target_dtype=tgt)
                     except OverflowError as exc:
                         # numpy >= 2 rejects the helper's np.int32(0xF0F00F0F)-style masks (1b/int8,
-                        # 2b/f16, 1b/f16 branches): the reference cannot produce these vectors here.
+                        # 2b/f16, 1b/f16 branches).  The reference's test suite carries its own copy of the
+                        # helper with the masks wrapped in np.uint32 (testing/python/type_conversion/
+                        # test_int4b_fp16_convert.py:29-65): run THAT for these branches.  1b/f16 is left out:
+                        # both copies compute the byte swizzle and then return the unswizzled word, while the
+                        # TIR op transform_weight really runs (lop3_permutate_impl.py:12-132) applies it.
                         skipped.add(f"{bits}b/{tgt}: {type(exc).__name__}")
+                        if (bits, tgt) in ((1, "int8"), (2, "float16")):
+                            inter = test_copy(comp.copy(), nbits=bits, target_dtype=tgt)
+                            out[f"interleave_{tgt}_{tag}"] = np.asarray(inter).view(np.int8).reshape(comp.shape)
                         continue
                     out[f"interleave_{tgt}_{tag}"] = np.asarray(inter).view(np.int8).reshape(comp.shape)
     # signed sources as transform_weight feeds them (codes already offset to unsigned)

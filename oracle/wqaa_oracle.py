@@ -28,7 +28,8 @@ The reference cannot be imported here (its tvm / tilelang submodules are empty) 
 matmul.  What *is* importable is `bitblas/quantization/utils.py`; `oracle/gen_golden.py` runs
 `general_compress` / `interleave_weight` from that file and commits the vectors under
 `tests/golden/`; `tests/test_oracle_golden.py` checks this module against them bit for bit.
-=> packing + interleave: PINNED by reference-generated fixtures.
+=> packing + interleave: PINNED by reference-generated fixtures (4b and 2b for both targets, 1b for int8; the
+   1b/float16 interleave follows the TIR op, which neither numpy copy of the helper reproduces - see above).
 => decode + matmul semantics: PINNED for the configurations the reference's own operator tests assert on.
    `oracle/gen_optest_golden.py` RUNS those test functions from the files where they lie (a recorder stands in
    for the un-importable `bitblas` package) and commits their seeded operands + the expected result of their

@@ -31,7 +31,9 @@ def test_interleave_matches_reference(golden):
             mine = oracle.interleave_weight(golden["compress_" + tag], bits, tgt, follow="numpy")
             assert np.array_equal(mine, golden[key]), key
             n += 1
-    assert n >= 9  # 4b/f16, 4b/i8, 2b/i8 (the other variants crash upstream under numpy 2)
+    # 4b/f16, 4b/i8, 2b/i8 from quantization/utils.py; 2b/f16 and 1b/i8 from the reference test suite's own copy of
+    # the helper (the library copy crashes under numpy 2), see oracle/gen_golden.py
+    assert n >= 15
 
 
 def test_signed_source_offset(golden):
