@@ -157,11 +157,14 @@ int wqaa_matmul_ex(const wqaa_matmul_desc* desc, const void* A, const void* B, c
                    const void* Scale, const void* Zeros, const void* Bias, void* C, int m, void* stream,
                    const wqaa_epilogue* epilogue);
 
-/* per-row absmax quantiser (utils_quant.py:161-168): s = 127 / max(|x|, 1e-5), q = clamp(rint(x * s)).
+/* per-row absmax quantiser (utils_quant.py:161-168): s = (1 / max(|x|, 1e-5)) * 127 - two fp32 roundings, what torch
+ * evaluates for the reference's `Qp / tensor` (Tensor.__rtruediv__) -, q = clamp(rint(x * s)).
  * X: (rows, K) float16; Q: (rows, K) int8; S: (rows,) float32.  K % 8 == 0. */
 int wqaa_act_quant_int8(const void* X, int64_t rows, int K, void* Q, float* S, void* stream);
 
-/* tile-config selector: replaces roller + tuner (bitblas/base/roller, bitblas/base/tuner.py) */
+/* tile-config selector: replaces roller + tuner (bitblas/base/roller, bitblas/base/tuner.py).  Needs no device.
+ * The WQAA_GEMM_* / WQAA_GEMV_* tuning environment variables are read here and at the first wqaa_matmul of a
+ * (desc, m) pair per thread; a later change takes effect at the next wqaa_select call. */
 int wqaa_select(const wqaa_matmul_desc* desc, int m, wqaa_plan* plan);
 
 /* ---- weight pre-processing (CPU; replaces the TVM-llvm ops of Matmul.transform_weight,
