@@ -144,3 +144,31 @@ def test_int4_activations_against_the_reference_tests_expectation():
         got = oracle.matmul_int4_act(g[f"c{i}_A"], codes, w_bits=w_bits)
         assert np.array_equal(got, g[f"c{i}_expected"])
     assert seen == {2, 4}
+
+
+def test_oracle_properties_exact():
+    """size-independent properties of the restated semantics that hold bit for bit: doubling every scale doubles the
+    output (power-of-two factors commute with every fp16 / fp32 rounding short of overflow), integer activations are
+    linear, all-zero-point weights give the bias."""
+    rng = np.random.default_rng(5)
+    N, K, g = 48, 256, 64
+    A = (rng.random((5, K), dtype=np.float32) - 0.5).astype(np.float16)
+    codes = rng.integers(0, 16, size=(N, K)).astype(np.int8)
+    scale = (rng.random((N, K // g), dtype=np.float32) * 0.05 + 0.01).astype(np.float16)
+    zeros = rng.integers(6, 10, size=(N, K // g)).astype(np.float16)
+    kw = dict(source_format="uint", bit=4, zeros=zeros, zeros_mode="original", group_size=g, out_dtype="float32")
+    y1 = oracle.matmul_dequant(A, codes, scale=scale, **kw)
+    y2 = oracle.matmul_dequant(A, codes, scale=(scale * np.float16(2)).astype(np.float16), **kw)
+    assert np.array_equal(y2, y1 * np.float32(2))
+    # integer path: exact linearity in the activations
+    A1 = rng.integers(-60, 60, size=(3, K), dtype=np.int8)
+    A2 = rng.integers(-60, 60, size=(3, K), dtype=np.int8)
+    c2 = rng.integers(0, 4, size=(N, K)).astype(np.int8)
+    f = lambda a: oracle.matmul_dequant(a, c2, source_format="int", bit=2, a_dtype="int8", out_dtype="int32")
+    assert np.array_equal(f((A1 + A2).astype(np.int8)), f(A1) + f(A2))
+    # weights sitting on their zero point contribute nothing: the output is the bias (added after the cast)
+    bias = rng.random(N, dtype=np.float32).astype(np.float16)
+    flat = np.full((N, K), 8, dtype=np.int8)
+    y0 = oracle.matmul_dequant(A, flat, source_format="uint", bit=4, scale=scale, zeros=np.full((N, K // g), 8, np.float16),
+                               zeros_mode="original", group_size=g, bias=bias, out_dtype="float16")
+    assert np.array_equal(y0, np.broadcast_to(bias, y0.shape))
