@@ -23,7 +23,9 @@ fp16 MFMA peak) are timed the same way and reported under `members`.
 
 N > 1: the weight matrices are column(N)-sharded: every rank owns an equal slice of every layer
 (weak scaling: per-GPU work fixed, i.e. the model is N_gpus x wider) and the per-layer output slices
-are all-gathered with one RCCL all-gather per step.
+are all-gathered with one RCCL all-gather per step, captured at the end of the step's hipGraph (one replay per
+step, no per-step host call into RCCL; WQAA_BENCH_GATHER=eager|overlap select the measured alternatives, DESIGN.md
+section 6).  WQAA_BENCH_FORCE_DIST=1 runs that code path with a single rank (1-GPU boxes).
 """
 from __future__ import annotations
 
