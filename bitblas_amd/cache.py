@@ -102,12 +102,14 @@ class OperatorCache:
                     config = json.load(f)
         if not (mapping and config):
             return
-        config_cls = getattr(bitblas_amd, mapping["config_type"])
-        operator_cls = getattr(bitblas_amd, mapping["operator_type"])
-        if isinstance(config.get("M"), list):
-            config["M"] = tuple(config["M"])
-        cfg = config_cls(**config)
+        # the default database path (~/.cache/bitblas) is shared with upstream BitBLAS: an entry of an operator
+        # or config type this build does not have, or with fields it does not know, is skipped, never fatal
         try:
+            config_cls = getattr(bitblas_amd, mapping["config_type"])
+            operator_cls = getattr(bitblas_amd, mapping["operator_type"])
+            if isinstance(config.get("M"), list):
+                config["M"] = tuple(config["M"])
+            cfg = config_cls(**config)
             op = operator_cls(config=cfg, target=target, enable_tuning=False, from_database=True)
         except Exception as exc:  # an entry written by another build that we cannot serve
             logger.warning("skipping database entry %s: %s", config_path, exc)

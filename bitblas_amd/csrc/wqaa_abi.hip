@@ -28,28 +28,91 @@ void set_error(int code, const char* fmt, ...) {
   va_end(ap);
 }
 
-static DeviceInfo g_dev = {0, 256, 160 * 1024, "gfx950"};
-static std::once_flag g_dev_once;
+// ---- devices ---------------------------------------------------------------------------------
+// Everything device-specific is per device and lazy: the CU count the selector sizes grids with, and the
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) calls of gemv_init / gemm_init (function attributes are per
+// device).  A launch runs on the device that OWNS ITS STREAM (hipStreamGetDevice), made current for the duration of
+// the call when it is not - so `A` on cuda:1 with cuda:0 current works without a device guard in the caller
+// (the reference leaves this to torch's current device; upstream wrapper: bitblas/builder/wrapper/tl.py:104-120).
+static constexpr int kMaxDevices = 32;
+static DeviceInfo g_dev[kMaxDevices];
+static std::once_flag g_dev_once[kMaxDevices];
+static const DeviceInfo g_no_dev = {0, 256, 160 * 1024, "gfx950"};
+static int g_ndev = -1;
+static std::once_flag g_ndev_once;
 
-const DeviceInfo& device_info() {
-  std::call_once(g_dev_once, [] {
+static int device_count_cached() {
+  std::call_once(g_ndev_once, [] {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
       (void)hipGetLastError();
-      return;
+      n = 0;
     }
-    int dev = 0;
-    (void)hipGetDevice(&dev);
+    g_ndev = n < kMaxDevices ? n : kMaxDevices;
+  });
+  return g_ndev;
+}
+
+// properties of device `dev` + the per-device kernel attributes, once (the device must be current)
+static void ensure_device(int dev) {
+  if (dev < 0 || dev >= device_count_cached()) return;
+  std::call_once(g_dev_once[dev], [dev] {
+    DeviceInfo& di = g_dev[dev];
+    di = g_no_dev;
     hipDeviceProp_t p;
     if (hipGetDeviceProperties(&p, dev) == hipSuccess) {
-      g_dev.ok = 1;
-      g_dev.cus = p.multiProcessorCount;
-      g_dev.lds_per_block = (int)p.maxSharedMemoryPerMultiProcessor;
-      snprintf(g_dev.arch, sizeof(g_dev.arch), "%s", p.gcnArchName);
+      di.cus = p.multiProcessorCount;
+      di.lds_per_block = (int)p.maxSharedMemoryPerMultiProcessor;
+      snprintf(di.arch, sizeof(di.arch), "%s", p.gcnArchName);
+      di.ok = 1;
+      gemv_init();
+      gemm_init();
+    } else {
+      (void)hipGetLastError();
     }
   });
-  return g_dev;
 }
+
+const DeviceInfo& device_info() {
+  if (device_count_cached() <= 0) return g_no_dev;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= g_ndev) {
+    (void)hipGetLastError();
+    return g_no_dev;
+  }
+  ensure_device(dev);
+  return g_dev[dev];
+}
+
+int current_device() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) {
+    (void)hipGetLastError();
+    return -1;
+  }
+  return dev;
+}
+
+// RAII: make the stream's device current (and initialised) for one call
+struct StreamDeviceScope {
+  int prev = -1, dev = -1;
+  bool switched = false;
+  explicit StreamDeviceScope(hipStream_t s) {
+    if (device_count_cached() <= 0) return;
+    (void)hipGetDevice(&prev);
+    dev = prev;
+    if (s != nullptr && g_ndev > 1) {
+      hipDevice_t sd = 0;
+      if (hipStreamGetDevice(s, &sd) == hipSuccess) dev = (int)sd;
+      else (void)hipGetLastError();
+    }
+    if (dev != prev) switched = hipSetDevice(dev) == hipSuccess;
+    ensure_device(dev);
+  }
+  ~StreamDeviceScope() {
+    if (switched) (void)hipSetDevice(prev);
+  }
+};
 
 static bool valid_desc(const wqaa_matmul_desc* d) {
   if (!d) {
@@ -98,7 +161,8 @@ static int dispatch(const wqaa_matmul_desc& d, int m, bool* use_gemm) {
 
 static int matmul_impl(const wqaa_matmul_desc* desc, const void* A, const void* B, const void* LUT,
                        const void* Scale, const void* Zeros, const void* Bias, void* C, int m,
-                       void* stream, void* ev0, void* ev1, const wqaa_epilogue* epi = nullptr) {
+                       void* stream, void* ev0, void* ev1, const wqaa_epilogue* epi = nullptr,
+                       const wqaa_call_opts* opts = nullptr) {
   if (!valid_desc(desc)) return WQAA_ERR_BAD_DESC;
   if (m == 0) return WQAA_OK;  // wrapper/tl.py:277
   if (m < 0 || !A || !B || !C) {
@@ -121,6 +185,8 @@ static int matmul_impl(const wqaa_matmul_desc* desc, const void* A, const void* 
     set_error(WQAA_ERR_BAD_DESC, "nf weights need the LUT pointer");
     return WQAA_ERR_BAD_DESC;
   }
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  StreamDeviceScope scope(s);
   if (!device_info().ok) {
     set_error(WQAA_ERR_NO_DEVICE, "no HIP device visible");
     return WQAA_ERR_NO_DEVICE;
@@ -135,7 +201,6 @@ static int matmul_impl(const wqaa_matmul_desc* desc, const void* A, const void* 
       memo.put(*desc, m, 0, use_gemm ? 1 : 0);
     }
   }
-  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   hipEvent_t e0 = reinterpret_cast<hipEvent_t>(ev0), e1 = reinterpret_cast<hipEvent_t>(ev1);
   const bool quant_in = epi && (epi->flags & WQAA_EPI_QUANTIZE_INPUT);
   if (epi && (epi->struct_size != (int32_t)sizeof(wqaa_epilogue) || (!epi->row_scale && !quant_in))) {
@@ -149,7 +214,7 @@ static int matmul_impl(const wqaa_matmul_desc* desc, const void* A, const void* 
     }
     use_gemm = false;   // a GEMV-family member; refuses loudly if the config has none
   }
-  int st = use_gemm ? gemm_launch(*desc, A, B, LUT, Scale, Zeros, Bias, C, m, s, e0, e1, epi)
+  int st = use_gemm ? gemm_launch(*desc, A, B, LUT, Scale, Zeros, Bias, C, m, s, e0, e1, epi, opts)
                     : gemv_launch(*desc, A, B, LUT, Scale, Zeros, Bias, C, m, s, e0, e1, epi);
   if (st == WQAA_OK) g_last_error = WQAA_OK;
   return st;
@@ -184,11 +249,7 @@ extern "C" {
 
 void init(void) {
   static std::once_flag once;
-  std::call_once(once, [] {
-    if (!device_info().ok) return;
-    gemv_init();
-    gemm_init();
-  });
+  std::call_once(once, [] { (void)device_info(); });   // current device now; any other device at its first launch
 }
 
 int wqaa_abi_version(void) { return WQAA_ABI_VERSION; }
@@ -219,7 +280,25 @@ int wqaa_matmul_ex(const wqaa_matmul_desc* desc, const void* A, const void* B, c
   return matmul_impl(desc, A, B, LUT, Scale, Zeros, Bias, C, m, stream, nullptr, nullptr, epilogue);
 }
 
+uint64_t wqaa_workspace_bytes(const wqaa_matmul_desc* desc, int m) {
+  if (!valid_desc(desc) || m <= 0) return 0;
+  bool use_gemm = false;
+  dispatch(*desc, m, &use_gemm);
+  return use_gemm ? (uint64_t)gemm_workspace_bytes(*desc, m) : 0;
+}
+
+int wqaa_matmul_opts(const wqaa_matmul_desc* desc, const void* A, const void* B, const void* LUT,
+                     const void* Scale, const void* Zeros, const void* Bias, void* C, int m, void* stream,
+                     const wqaa_call_opts* opts) {
+  if (opts && opts->struct_size != (int32_t)sizeof(wqaa_call_opts)) {
+    set_error(WQAA_ERR_BAD_DESC, "call options size %d != %zu (ABI mismatch)", opts->struct_size, sizeof(wqaa_call_opts));
+    return WQAA_ERR_BAD_DESC;
+  }
+  return matmul_impl(desc, A, B, LUT, Scale, Zeros, Bias, C, m, stream, nullptr, nullptr, opts ? opts->epilogue : nullptr, opts);
+}
+
 int wqaa_act_quant_int8(const void* X, int64_t rows, int K, void* Q, float* S, void* stream) {
+  StreamDeviceScope scope(reinterpret_cast<hipStream_t>(stream));
   if (!device_info().ok) {
     set_error(WQAA_ERR_NO_DEVICE, "no HIP device visible");
     return WQAA_ERR_NO_DEVICE;
@@ -319,6 +398,7 @@ int wqaa_unpack_weight(const int8_t* packed, int64_t rows, int64_t cols, int bit
 int wqaa_debug_decode(const void* packed_dev, int64_t nwords, int w_format, int bits, int layout,
                       int a_dtype, int strict_reference, const void* lut_dev, void* out_dev,
                       void* stream) {
+  StreamDeviceScope scope(reinterpret_cast<hipStream_t>(stream));
   if (!device_info().ok) {
     set_error(WQAA_ERR_NO_DEVICE, "no HIP device visible");
     return WQAA_ERR_NO_DEVICE;

@@ -71,7 +71,9 @@ void gemv_init();
 int gemm_plan(const wqaa_matmul_desc& d, int m, wqaa_plan* plan);
 int gemm_launch(const wqaa_matmul_desc& d, const void* A, const void* B, const void* LUT,
                 const void* Scale, const void* Zeros, const void* Bias, void* C, int m,
-                hipStream_t stream, hipEvent_t start, hipEvent_t stop, const wqaa_epilogue* epi = nullptr);
+                hipStream_t stream, hipEvent_t start, hipEvent_t stop, const wqaa_epilogue* epi = nullptr,
+                const wqaa_call_opts* opts = nullptr);
+size_t gemm_workspace_bytes(const wqaa_matmul_desc& d, int m);
 int act_quant_launch(const void* X, int64_t rows, int K, void* Q, float* S, hipStream_t stream);
 void gemm_init();
 
@@ -117,7 +119,8 @@ struct DeviceInfo {
   int lds_per_block;
   char arch[64];
 };
-const DeviceInfo& device_info();
+const DeviceInfo& device_info();   // of the CURRENT device, lazily initialised (kernel attributes included)
+int current_device();
 
 template <typename K>
 inline hipError_t launch_kernel(K kernel, const LaunchCfg& cfg, void* args_struct) {

@@ -2,29 +2,57 @@
 // The kernels live in wqaa_gemm_kernel.h; the member tables are instantiated in wqaa_gemm_inst_*.hip.
 #include "wqaa_gemm_kernel.h"
 
+#include <vector>
+
 namespace wqaa {
 
-// library-owned scratch for the partial sums (one per device, grown on demand, never shrunk).
-// Growing calls hipMalloc: do the first call of a new shape outside stream capture.
-static void* g_ws[16] = {nullptr};
-static size_t g_ws_bytes[16] = {0};
+// Scratch for the fp32 / int32 partial sums of the split-K members.  Ownership (the reference leaves workspace
+// ownership with the caller: bitblas/ops/general_matmul/__init__.py:29, 456-457, 482):
+//   * caller-owned: wqaa_matmul_opts(..., workspace, workspace_bytes) - the library allocates nothing;
+//   * otherwise a library pool with ONE slab per (device, stream): two streams never share partial sums, and a slab
+//     that has to grow is RETIRED, never freed - a hipGraph captured earlier keeps replaying into memory that is
+//     still allocated.  Growing calls hipMalloc, which is illegal during stream capture: that case is refused with
+//     an error telling the caller to run the shape once outside capture (or to pass its own workspace).
+struct WsSlab {
+  int dev;
+  hipStream_t stream;
+  void* ptr;
+  size_t bytes;
+};
+static std::vector<WsSlab> g_ws;
+static std::vector<void*> g_ws_retired;
 static std::mutex g_ws_mu;
-static void* workspace(size_t bytes) {
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+static void* workspace(hipStream_t stream, size_t bytes) {
+  const int dev = current_device();
+  if (dev < 0) return nullptr;
   std::lock_guard<std::mutex> lk(g_ws_mu);
-  if (g_ws_bytes[dev] < bytes) {
-    if (g_ws[dev]) (void)hipFree(g_ws[dev]);
-    size_t want = bytes < (32u << 20) ? (32u << 20) : bytes;
-    if (hipMalloc(&g_ws[dev], want) != hipSuccess) {
-      g_ws[dev] = nullptr;
-      g_ws_bytes[dev] = 0;
-      (void)hipGetLastError();
-      return nullptr;
-    }
-    g_ws_bytes[dev] = want;
+  WsSlab* slab = nullptr;
+  for (auto& w : g_ws)
+    if (w.dev == dev && w.stream == stream) { slab = &w; break; }
+  if (slab && slab->bytes >= bytes) return slab->ptr;
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(stream, &cs) != hipSuccess) (void)hipGetLastError();
+  if (cs != hipStreamCaptureStatusNone) {
+    set_error(WQAA_ERR_LAUNCH, "gemm: the split-K scratch of this stream has to grow to %zu B, which cannot happen during stream "
+              "capture: run this shape once outside capture, or pass a workspace (wqaa_matmul_opts)", bytes);
+    return nullptr;
   }
-  return g_ws[dev];
+  size_t want = bytes < (8u << 20) ? (8u << 20) : bytes;
+  if (slab && want < 2 * slab->bytes) want = 2 * slab->bytes;     // geometric growth bounds the retired total
+  void* p = nullptr;
+  if (hipMalloc(&p, want) != hipSuccess) {
+    (void)hipGetLastError();
+    set_error(WQAA_ERR_LAUNCH, "gemm: cannot allocate %zu B of split-K scratch", want);
+    return nullptr;
+  }
+  if (slab) {
+    g_ws_retired.push_back(slab->ptr);
+    slab->ptr = p;
+    slab->bytes = want;
+  } else {
+    g_ws.push_back(WsSlab{dev, stream, p, want});
+  }
+  return p;
 }
 
 static gemm_fn pick_gemm(int kind, int layout, int at, int mode, int flags, int mf) {
@@ -243,9 +271,15 @@ int gemm_plan(const wqaa_matmul_desc& d, int m, wqaa_plan* plan) {
   return WQAA_OK;
 }
 
+size_t gemm_workspace_bytes(const wqaa_matmul_desc& d, int m) {
+  GemmChoice c;
+  if (gemm_choose(d, m, &c) != WQAA_OK) return 0;
+  return c.ksplit > 1 ? (size_t)c.ksplit * m * d.N * 4 : 0;
+}
+
 int gemm_launch(const wqaa_matmul_desc& d, const void* A, const void* B, const void* LUT,
                 const void* Scale, const void* Zeros, const void* Bias, void* C, int m,
-                hipStream_t stream, hipEvent_t start, hipEvent_t stop, const wqaa_epilogue* epi) {
+                hipStream_t stream, hipEvent_t start, hipEvent_t stop, const wqaa_epilogue* epi, const wqaa_call_opts* opts) {
   GemmChoice c;
   {
     static thread_local ChoiceMemo<GemmChoice> memo;
@@ -270,7 +304,8 @@ int gemm_launch(const wqaa_matmul_desc& d, const void* A, const void* B, const v
   a.row_bytes = (long)d.K * c.bits / 8;
   a.has_bias = d.with_bias;
   a.out_dtype = d.out_dtype;
-  a.is_signed = d.w_format == WQAA_W_INT;
+  // "uint8" weights under strict_reference are read as SIGNED storage bytes (see gemv fill_args)
+  a.is_signed = d.w_format == WQAA_W_INT || (d.w_format == WQAA_W_UINT && d.w_bits == 8 && d.strict_reference);
   if (d.a_dtype == WQAA_I4) a.is_signed = c.kind == DK_INT4;   // 2-bit weights are zero-extended (matmul_dequantize_mma.py:742-749)
   a.fp4_table = c.fp4_table;
   a.zq_row_bytes = d.N * (c.bits < 8 ? c.bits : 8) / 8;
@@ -294,10 +329,17 @@ int gemm_launch(const wqaa_matmul_desc& d, const void* A, const void* B, const v
   a.ksplit = c.ksplit;
   a.ws = nullptr;
   if (c.ksplit > 1) {
-    a.ws = workspace((size_t)c.ksplit * m * d.N * 4);
-    if (!a.ws) {
-      set_error(WQAA_ERR_LAUNCH, "gemm: cannot allocate %zu B of split-K scratch", (size_t)c.ksplit * m * d.N * 4);
-      return WQAA_ERR_LAUNCH;
+    const size_t need = (size_t)c.ksplit * m * d.N * 4;
+    if (opts && opts->workspace) {
+      if (opts->workspace_bytes < need || (reinterpret_cast<uintptr_t>(opts->workspace) & 15)) {
+        set_error(WQAA_ERR_BAD_DESC, "gemm: workspace of %zu B (16-byte aligned) needed, got %zu B at %p", need,
+                  (size_t)opts->workspace_bytes, opts->workspace);
+        return WQAA_ERR_BAD_DESC;
+      }
+      a.ws = opts->workspace;
+    } else {
+      a.ws = workspace(stream, need);
+      if (!a.ws) return WQAA_ERR_LAUNCH;
     }
   }
   void* params[] = {&a};

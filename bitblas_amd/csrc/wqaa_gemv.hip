@@ -1011,7 +1011,9 @@ static void fill_args(const wqaa_matmul_desc& d, const GemvChoice& c, const void
   a->row_bytes = (long)d.K * c.bits / 8;
   a->has_bias = d.with_bias;
   a->out_dtype = d.out_dtype;
-  a->is_signed = d.w_format == WQAA_W_INT;
+  // "uint8" weights under strict_reference: the TE graph reads the int8 storage buffer with `.astype(A_dtype)`
+  // (matmul_dequantize_impl.py:404-406), i.e. SIGNED bytes - pinned by tests/golden/te_golden.npz (f16_uint8_scale)
+  a->is_signed = d.w_format == WQAA_W_INT || (d.w_format == WQAA_W_UINT && d.w_bits == 8 && d.strict_reference);
   // int4 activations: 4-bit weights are native two's complement, 2-bit weights are zero-extended
   // (matmul_dequantize_mma.py:742-749)
   if (d.a_dtype == WQAA_I4) a->is_signed = c.kind == DK_INT4;

@@ -39,7 +39,7 @@ ZEROS_CODE = {"original": Z_ORIGINAL, "rescale": Z_RESCALE, "quantized": Z_QUANT
 
 EXPORTED_SYMBOLS = (
     "init", "wqaa_abi_version", "wqaa_device_count", "wqaa_matmul", "wqaa_matmul_timed",
-    "wqaa_matmul_ex", "wqaa_act_quant_int8", "wqaa_select", "wqaa_pack_weight", "wqaa_unpack_weight", "wqaa_debug_decode",
+    "wqaa_matmul_ex", "wqaa_matmul_opts", "wqaa_workspace_bytes", "wqaa_act_quant_int8", "wqaa_select", "wqaa_pack_weight", "wqaa_unpack_weight", "wqaa_debug_decode",
     "wqaa_last_error", "wqaa_last_error_string",
 )
 
@@ -79,6 +79,12 @@ class Epilogue(ctypes.Structure):
                 ("reserved2", ctypes.c_int32)]
 
 
+class CallOpts(ctypes.Structure):
+    """struct wqaa_call_opts (include/wqaa.h): caller-owned split-K workspace (+ optional fused epilogue)."""
+    _fields_ = [("struct_size", ctypes.c_int32), ("flags", ctypes.c_int32), ("workspace", ctypes.c_void_p),
+                ("workspace_bytes", ctypes.c_uint64), ("epilogue", ctypes.POINTER(Epilogue))]
+
+
 class WqaaError(RuntimeError):
     def __init__(self, code: int, message: str):
         super().__init__(f"libwqaa_hip error {code}: {message}")
@@ -115,6 +121,10 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
         lib.wqaa_matmul_timed.argtypes = [dp, vp, vp, vp, vp, vp, vp, vp, ci, vp, vp, vp]
         lib.wqaa_matmul_ex.restype = ci
         lib.wqaa_matmul_ex.argtypes = [dp, vp, vp, vp, vp, vp, vp, vp, ci, vp, ctypes.POINTER(Epilogue)]
+        lib.wqaa_matmul_opts.restype = ci
+        lib.wqaa_matmul_opts.argtypes = [dp, vp, vp, vp, vp, vp, vp, vp, ci, vp, ctypes.POINTER(CallOpts)]
+        lib.wqaa_workspace_bytes.restype = ctypes.c_uint64
+        lib.wqaa_workspace_bytes.argtypes = [dp, ci]
         lib.wqaa_act_quant_int8.restype = ci
         lib.wqaa_act_quant_int8.argtypes = [vp, i64, ci, vp, vp, vp]
         lib.wqaa_select.restype = ci
@@ -127,8 +137,8 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
         lib.wqaa_debug_decode.argtypes = [vp, i64, ci, ci, ci, ci, ci, vp, vp, vp]
         lib.wqaa_last_error.restype = ci
         lib.wqaa_last_error_string.restype = ctypes.c_char_p
-        if lib.wqaa_abi_version() != 1:
-            raise ImportError(f"{p}: ABI version {lib.wqaa_abi_version()} != 1")
+        if lib.wqaa_abi_version() != 2:
+            raise ImportError(f"{p}: ABI version {lib.wqaa_abi_version()} != 2 (rebuild: python -m bitblas_amd.build)")
         lib.init()
         if path is None:
             _lib = lib
@@ -233,6 +243,19 @@ class BoundLib:
         status = self._fn(self._desc_ref, A, B, lut, scale, zeros, bias, C, m, stream)
         if status != OK:
             check(status)
+
+    def run_ws(self, A, B, lut, scale, zeros, bias, C, m, stream, workspace_ptr, workspace_bytes):
+        """as `run`, with a caller-owned split-K workspace (wqaa_matmul_opts)"""
+        opts = CallOpts()
+        opts.struct_size = ctypes.sizeof(CallOpts)
+        opts.workspace = workspace_ptr
+        opts.workspace_bytes = int(workspace_bytes)
+        status = self._lib.wqaa_matmul_opts(self._desc_ref, A, B, lut, scale, zeros, bias, C, m, stream, ctypes.byref(opts))
+        if status != OK:
+            check(status)
+
+    def workspace_bytes(self, m: int) -> int:
+        return int(self._lib.wqaa_workspace_bytes(self._desc_ref, int(m)))
 
     def run_timed(self, A, B, lut, scale, zeros, bias, C, m, stream, ev_start, ev_stop):
         status = self._lib.wqaa_matmul_timed(self._desc_ref, A, B, lut, scale, zeros, bias, C, m,

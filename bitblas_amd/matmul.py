@@ -414,6 +414,7 @@ class Matmul:
 
         # operand sizes the kernels will read (checked on every forward: a short buffer is an out-of-bounds read)
         self._a_cols = config.K // 2 if config.A_dtype in ("int4", "uint4") else config.K
+        self._a_torch_dtype = torch_dtype(config.A_dtype)
         self._w_bytes = config.N * config.K * self.bit // 8
         self.weight_compress = _QuantCompress(self.bit, a_code) if self.bit in (1, 2, 4) else None
         self.lop3_permutate = None
@@ -509,15 +510,27 @@ class Matmul:
     def transform_input(self, input_tensor):
         return input_tensor  # propagate_a is always NonTransform on CDNA (see propagate_a)
 
-    def forward(self, A, W, scale=None, zeros=None, bias=None, output=None) -> Any:
-        """`matmul(A, W, scale, zeros, bias, output)` (:724-753).  Launches on the current stream
-        of A's device; returns immediately (asynchronous)."""
-        if output is None:
-            output = torch.empty(A.shape[:-1] + (self.N,), dtype=self.torch_output_dtype, device=A.device)
+    def check_activation(self, A) -> int:
+        """What the kernels assume about A and the reference never checks (it passes `data_ptr()` on,
+        ops/operator.py:458-463): device memory, K columns, the operator's A_dtype, and for a static-M operator
+        exactly M rows - a short A would be read out of bounds.  Returns the row count m."""
         if not A.is_cuda:
             raise RuntimeError("bitblas_amd.Matmul runs on the GPU only (no CPU fallback)")
         if A.shape[-1] != self._a_cols:
             raise ValueError(f"A has {A.shape[-1]} columns, the operator was built for {self._a_cols} (K={self.K})")
+        if A.dtype != self._a_torch_dtype:
+            raise TypeError(f"A is {A.dtype}, the operator was built for A_dtype={self.A_dtype} ({self._a_torch_dtype})")
+        m = A.numel() // self._a_cols
+        if self.dynamic_range is None and m != self.config.M:
+            raise ValueError(f"operator was built for M={self.config.M}, got {m} rows")
+        return m
+
+    def forward(self, A, W, scale=None, zeros=None, bias=None, output=None) -> Any:
+        """`matmul(A, W, scale, zeros, bias, output)` (:724-753).  Launches on the current stream
+        of A's device; returns immediately (asynchronous)."""
+        m = self.check_activation(A)
+        if output is None:
+            output = torch.empty(A.shape[:-1] + (self.N,), dtype=self.torch_output_dtype, device=A.device)
         if W.numel() * W.element_size() != self._w_bytes:
             raise ValueError(f"W holds {W.numel() * W.element_size()} bytes, the operator expects {self._w_bytes} "
                              f"(shape {self.retrieve_weight_shape()}: run transform_weight first)")
@@ -525,9 +538,6 @@ class Matmul:
             A = A.contiguous()   # the kernels read raw row-major memory (upstream passes data_ptr() unchecked)
         if not output.is_contiguous():
             raise ValueError("output must be a contiguous tensor")
-        m = reduce(_operator.mul, A.shape[:-1], 1)
-        if self.dynamic_range is None and m != self.config.M:
-            raise ValueError(f"operator was built for M={self.config.M}, got {m} rows")
         lut = self._ensure_lut(A.device)
         stream = torch.cuda.current_stream(A.device).cuda_stream
         self.lib.run(
@@ -554,8 +564,8 @@ class Matmul:
         A = (torch.rand(m, k_cols, device=dev) - 0.5).to(a_dt) if a_dt.is_floating_point else \
             torch.randint(-8, 8, (m, k_cols), device=dev, dtype=a_dt)
         W = torch.randint(-128, 127, self.retrieve_weight_shape(), device=dev, dtype=torch.int8)
-        if self.W_dtype == self.A_dtype:
-            W = A.new_zeros((self.N, self.K))
+        if self.W_dtype == self.A_dtype and self.bit >= 8:
+            W = A.new_zeros((self.N, self.K))      # dense pair; sub-byte native pairs (int4 x int4) keep the packed shape
         g = self.K if self.group_size in (-1, None) else self.group_size
         scale = torch.rand(self.N, self.K // g, device=dev).to(a_dt) if self.with_scaling else None
         zeros = None

@@ -130,8 +130,8 @@ class Linear(nn.Module):
     def warmup(self, topk=20):
         self.bitblas_matmul.hardware_aware_finetune(topk=topk)
 
-    def init_params(self):
-        """Pre-wrap the parameter pointers (upstream redoes this on every forward, :138-153)."""
+    def _live_params(self):
+        """the buffers the kernel reads, in `lib.call` order (B, scale, zeros, bias)"""
         cfg = self.bitblas_matmul.config
         if self.consistent:
             params = [self.weight]
@@ -143,9 +143,14 @@ class Linear(nn.Module):
                 params.append(self.zeros)
         if cfg.with_bias:
             params.append(self.bias)
+        return params
+
+    def init_params(self):
+        """Pre-wrap the parameter pointers (upstream redoes this on every forward, :138-153)."""
+        cfg = self.bitblas_matmul.config
+        params = self._live_params()
         self.q_params = [ctypes.c_void_p(p.data_ptr()) for p in params]
         self._q_param_keys = tuple(p.data_ptr() for p in params)
-        self._q_param_tensors = params
         # raw pointers in `BoundLib.run` order (B, scale, zeros, bias) for the forward fast path
         it = iter(self._q_param_keys[1:])
         self._q_run = (self._q_param_keys[0],
@@ -154,13 +159,17 @@ class Linear(nn.Module):
                        next(it) if cfg.with_bias else None)
 
     def _params_current(self):
+        """the cached pointers still are the LIVE buffers' (`layer.scales = t`, `.to(device)`, `load_state_dict`
+        all replace tensors; upstream re-reads every pointer on every forward)"""
         if self.q_params is None:
             return False
-        return all(t.data_ptr() == k for t, k in zip(self._q_param_tensors, self._q_param_keys)) and \
-            self._q_param_tensors[0] is (self.weight if self.consistent else self.qweight)
+        live = self._live_params()
+        return len(live) == len(self._q_param_keys) and all(t.data_ptr() == k for t, k in zip(live, self._q_param_keys))
 
     def forward(self, A, output=None):
-        A = self.bitblas_matmul.transform_input(A)
+        mm = self.bitblas_matmul
+        A = mm.transform_input(A)
+        m = mm.check_activation(A)           # cuda, K columns, A_dtype, and M rows for a static-M operator
         if not A.is_contiguous():
             A = A.contiguous()   # the kernels read raw row-major memory
         if not self._params_current():
@@ -168,11 +177,11 @@ class Linear(nn.Module):
         if output is None:
             # upstream uses torch.zeros here; every element is written by the kernel
             output = torch.empty(A.shape[:-1] + (self.out_features,),
-                                 dtype=torch_dtype(self.bitblas_matmul.out_dtype), device=A.device)
+                                 dtype=torch_dtype(mm.out_dtype), device=A.device)
+        elif not output.is_contiguous() or output.device != A.device:
+            raise ValueError("output must be a contiguous tensor on A's device")
         # upstream rebuilds a ctypes argument list and goes through the positional `lib.call` here
         # (:271-287); same pointers, same order, without the per-call wrapping
-        mm = self.bitblas_matmul
-        m = A.numel() // A.shape[-1] if mm.dynamic_range is not None else mm.lib.static_m
         lut = mm._ensure_lut(A.device) if self.source_format == "nf" else None
         B, scale, zeros, bias = self._q_run
         mm.lib.run(A.data_ptr(), B, lut.data_ptr() if lut is not None else None, scale, zeros, bias,

@@ -15,9 +15,12 @@
  * Here nothing is JIT-compiled: ONE prebuilt library holds the static kernel set, and the per-config
  * `call` becomes `wqaa_matmul(desc, ...)` with the config passed as a plain struct.  Pointer order is
  * the reference's prim_func order (tirscript/matmul_dequantize_impl.py:465-478).  All pointers are
- * device pointers owned by the caller; the library never frees or synchronises, and allocates only one
- * internal scratch buffer per device (fp32 partial sums of the split-K GEMM members, grown on demand:
- * make the first call of a new skinny shape outside stream capture).
+ * device pointers owned by the caller; the library never synchronises.  A launch runs on the device that owns
+ * `stream` (made current for the duration of the call when it is not).  The split-K GEMM members need scratch for
+ * their fp32 partial sums (wqaa_workspace_bytes): pass it with wqaa_matmul_opts (caller-owned, the reference's
+ * model: general_matmul/__init__.py:29, 456-457, 482), or let the library keep one slab per (device, stream) -
+ * never shared between streams, retired instead of freed when it has to grow (a captured hipGraph stays valid),
+ * and refused with WQAA_ERR_LAUNCH when it would have to grow during stream capture.
  *
  * Plain C: no torch, no HIP types in signatures (hipStream_t is passed as void*).
  */
@@ -31,7 +34,7 @@
 extern "C" {
 #endif
 
-#define WQAA_ABI_VERSION 1
+#define WQAA_ABI_VERSION 2   /* 2: wqaa_matmul_opts, wqaa_workspace_bytes */
 
 /* element types of A / C / Scale / Bias */
 enum wqaa_dtype {
@@ -156,6 +159,24 @@ typedef struct wqaa_epilogue {
 int wqaa_matmul_ex(const wqaa_matmul_desc* desc, const void* A, const void* B, const void* LUT,
                    const void* Scale, const void* Zeros, const void* Bias, void* C, int m, void* stream,
                    const wqaa_epilogue* epilogue);
+
+/* ---- call options: caller-owned workspace and/or the fused epilogue above ------------------------
+ * wqaa_workspace_bytes(desc, m): bytes of scratch the member selected for (desc, m) needs (0 for most members;
+ * ksplit * m * N * 4 for the split-K GEMM members).  Needs no device.
+ * wqaa_matmul_opts: as wqaa_matmul / wqaa_matmul_ex; `workspace` (16-byte aligned device memory of at least
+ * wqaa_workspace_bytes, or NULL = library pool) must not be used by another stream at the same time. */
+typedef struct wqaa_call_opts {
+  int32_t struct_size;              /* = sizeof(wqaa_call_opts) */
+  int32_t flags;                    /* reserved, 0 */
+  void* workspace;
+  uint64_t workspace_bytes;
+  const wqaa_epilogue* epilogue;    /* NULL: plain matmul */
+} wqaa_call_opts;
+
+uint64_t wqaa_workspace_bytes(const wqaa_matmul_desc* desc, int m);
+int wqaa_matmul_opts(const wqaa_matmul_desc* desc, const void* A, const void* B, const void* LUT,
+                     const void* Scale, const void* Zeros, const void* Bias, void* C, int m, void* stream,
+                     const wqaa_call_opts* opts);
 
 /* per-row absmax quantiser (utils_quant.py:161-168): s = (1 / max(|x|, 1e-5)) * 127 - two fp32 roundings, what torch
  * evaluates for the reference's `Qp / tensor` (Tensor.__rtruediv__) -, q = clamp(rint(x * s)).

@@ -244,6 +244,12 @@ def decode_codes(codes: np.ndarray, source_format: str, bit: int, strict_referen
     c = np.asarray(codes)
     u = c.astype(np.int64) & ((1 << bit) - 1)
     if source_format == "uint":
+        if bit == 8 and strict_reference:
+            # 8-bit weights are not unpacked: the TE graph reads `B[n, k].astype(in_dtype)` from the int8 STORAGE buffer
+            # (matmul_dequantize_impl.py:404-406, storage_dtype "int8"), so a "uint8" byte >= 128 decodes as a NEGATIVE
+            # value.  Pinned by executing the definition (tests/golden/te_golden.npz, f16_uint8_scale); the reference's
+            # own tests never notice because they draw uint8 weights below 128.  strict_reference=False: true unsigned
+            return _as_u8(c).view(np.int8).astype(np.float64)
         return u.astype(np.float64)
     if source_format == "int":
         if bit == 8:
