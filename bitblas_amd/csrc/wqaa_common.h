@@ -68,6 +68,13 @@ int gemv_launch(const wqaa_matmul_desc& d, const void* A, const void* B, const v
                 hipStream_t stream, hipEvent_t start, hipEvent_t stop, const wqaa_epilogue* epi = nullptr);
 void gemv_init();
 
+// exact-product GEMV members (strict_reference = 0, sub-byte integer weights x float16, M <= 2)
+bool gemvx_eligible(const wqaa_matmul_desc& d, int m);
+int gemvx_plan(const wqaa_matmul_desc& d, int m, wqaa_plan* plan);
+int gemvx_launch(const wqaa_matmul_desc& d, const void* A, const void* B, const void* Scale, const void* Zeros,
+                 const void* Bias, void* C, int m, hipStream_t stream, hipEvent_t start, hipEvent_t stop);
+void gemvx_init();
+
 int gemm_plan(const wqaa_matmul_desc& d, int m, wqaa_plan* plan);
 int gemm_launch(const wqaa_matmul_desc& d, const void* A, const void* B, const void* LUT,
                 const void* Scale, const void* Zeros, const void* Bias, void* C, int m,

@@ -1,0 +1,209 @@
+// wqaa_gemvx.hip - host side of the exact-product GEMV members (wqaa_gemvx_kernel.h): eligibility, tile-config
+// selection (rows per wave, K split across the waves of a workgroup, workgroup width, grid) and launch.
+#include "wqaa_gemvx_kernel.h"
+
+namespace wqaa {
+
+struct GemvxChoice {
+  gemvx_fn fn;
+  int bits, layout, mode, mb, R, D, kw, nw;
+  int E, cpr, nc, nsteps, n_rgb;
+  int grid, lds;
+};
+
+// sub-byte integer weights x float16 activations, M <= 2, and the caller did not ask for the TE definition's
+// per-element rounding (strict_reference).  WQAA_GEMVX=0 disables the family (A/B aid).
+bool gemvx_eligible(const wqaa_matmul_desc& d, int m) {
+  if (d.strict_reference || m < 1 || m > 2 || d.a_dtype != WQAA_F16) return false;
+  if (d.w_format != WQAA_W_UINT && d.w_format != WQAA_W_INT) return false;
+  if (d.w_bits != 4 && d.w_bits != 2 && d.w_bits != 1) return false;
+  const int E = 128 / d.w_bits;
+  if (d.K % E != 0) return false;
+  const int g = d.group_size <= 0 ? d.K : d.group_size;
+  if (d.K % g != 0 || (d.with_scaling && g % E != 0)) return false;
+  // the switch is a plan-time one like every tuning variable (ChoiceMemo): re-read when wqaa_select bumps the epoch
+  static thread_local unsigned seen_epoch = 0;
+  static thread_local bool enabled = true;
+  const unsigned ep = g_plan_epoch.load(std::memory_order_relaxed);
+  if (ep != seen_epoch) {
+    const char* f = getenv("WQAA_GEMVX");
+    enabled = !(f && atoi(f) == 0);
+    seen_epoch = ep;
+  }
+  return enabled;
+}
+
+// Tile-config selection.  Many small workgroups (the hardware dispatcher balances them; a persistent workgroup per CU
+// measured 15-40 % slower): a workgroup works on `slots` row groups at a time, each by `kw` waves that split K.
+// For R in {2, 1}: the K split that brings the waves per CU towards 16 (never more parts than steps, and only splits
+// that leave the parts evenly loaded); the candidate with more busy waves wins, two rows per wave (half the LDS reads
+// per weight byte) on a tie.
+static void gemvx_candidate(int N, int nsteps, int cus, int R, int* kw, double* score) {
+  const int n_rg = (N + R - 1) / R;
+  const double base = (double)n_rg / cus;            // waves per CU without a split
+  int want = 1;
+  while (want < 8 && base * want < 16.0) ++want;
+  if (want > nsteps) want = nsteps;
+  int best = 1;
+  for (int k = want; k >= 1; --k) {
+    const double eff = (double)nsteps / (k * ((nsteps + k - 1) / k));
+    if (eff >= 0.85) { best = k; break; }
+  }
+  *kw = best;
+  const double eff = (double)nsteps / (best * ((nsteps + best - 1) / best));
+  double waves = base * best;
+  if (waves > 16.0) waves = 16.0;
+  *score = waves * eff;
+}
+
+static int gemvx_choose(const wqaa_matmul_desc& d, int m, GemvxChoice* c) {
+  c->bits = d.w_bits;
+  c->layout = d.w_layout == WQAA_LAYOUT_LOP3 ? LAYOUT_LOP3 : LAYOUT_PLAIN;
+  c->mode = !d.with_scaling ? MD_NONE
+            : d.zeros_mode == WQAA_Z_ORIGINAL ? MD_ZO
+            : d.zeros_mode == WQAA_Z_RESCALE  ? MD_ZR
+            : d.zeros_mode == WQAA_Z_QUANTIZED ? MD_ZQ
+                                               : MD_S;
+  c->mb = m;
+  c->E = 128 / c->bits;
+  c->cpr = d.K / c->E;
+  c->nc = (c->cpr + 63) / 64;
+  c->D = 2;
+  c->nsteps = (c->nc + c->D - 1) / c->D;
+  const int cus = device_info().ok ? device_info().cus : 256;
+  int k2, k1;
+  double sc2, sc1;
+  gemvx_candidate(d.N, c->nsteps, cus, 2, &k2, &sc2);
+  gemvx_candidate(d.N, c->nsteps, cus, 1, &k1, &sc1);
+  c->R = sc2 >= 0.9 * sc1 ? 2 : 1;
+  if (const char* f = getenv("WQAA_GEMVX_R")) c->R = atoi(f) == 1 ? 1 : 2;
+  int kw = c->R == 2 ? k2 : k1;
+  if (const char* f = getenv("WQAA_GEMVX_KW")) kw = atoi(f) > 0 ? atoi(f) : 1;          // tuning aid
+  if (kw > c->nsteps) kw = c->nsteps;
+  if (kw > 16) kw = 16;
+  c->kw = kw;
+  const int n_rg = (d.N + c->R - 1) / c->R;
+  // workgroup: ~8 waves (a multiple of kw); the activation tile is staged once per workgroup.  Same-call A/B, int4 g128
+  // (tools/ab_gemvx_quick.sh): 8 waves beat 4 on 4096^2 (4.27 vs 4.63 us), 11008x4096 (6.92 vs 7.56) and 4096x11008
+  // (8.5 vs 10.4); on streams far beyond the caches 4 waves win (28672x8192: 24.7 vs 27.4 us)
+  const long wbytes = (long)d.N * d.K * c->bits / 8;
+  int slots = (wbytes >= (48l << 20) ? 4 : 8) / kw;
+  if (slots < 1) slots = 1;
+  // ... but never so wide that CUs are left without a workgroup
+  while (slots > 1 && (n_rg + slots - 1) / slots < cus) slots /= 2;
+  if (const char* f = getenv("WQAA_GEMVX_SLOTS")) slots = atoi(f) > 0 ? atoi(f) : 1;
+  if (slots * kw > 16) slots = 16 / kw;
+  if (slots < 1) slots = 1;
+  c->nw = slots * kw;
+  c->n_rgb = (n_rg + slots - 1) / slots;
+  const long ncp = (long)c->nsteps * c->D;
+  c->lds = (int)(c->mb * ncp * 64 * (c->E * 2 + 16)) + 2 * c->nw * c->R * c->mb * 4 + 64;
+  if (c->lds > 160 * 1024) {
+    set_error(WQAA_ERR_UNSUPPORTED, "gemvx: activation tile %d B exceeds LDS", c->lds);
+    return WQAA_ERR_UNSUPPORTED;
+  }
+  int blocks_per_cu = 160 * 1024 / c->lds;
+  if (blocks_per_cu > 32 / c->nw) blocks_per_cu = 32 / c->nw;
+  if (blocks_per_cu < 1) blocks_per_cu = 1;
+  int blocks = c->n_rgb;
+  if (blocks > cus * blocks_per_cu) blocks = cus * blocks_per_cu;
+  if (blocks >= 8) blocks = (blocks + 7) / 8 * 8;       // whole XCD rounds keep the block swizzle on
+  if (const char* f = getenv("WQAA_GEMVX_GRID")) blocks = atoi(f) > 0 ? atoi(f) : 1;
+  c->grid = blocks;
+  const int rd = c->R * 10 + c->D;
+  c->fn = c->bits == 4 ? pick_gemvx_int4(c->layout, c->mode, c->mb, rd)
+          : c->bits == 2 ? pick_gemvx_int2(c->layout, c->mode, c->mb, rd)
+                         : pick_gemvx_int1(c->layout, c->mode, c->mb, rd);
+  if (const char* f = getenv("WQAA_GEMVX_ABL")) {      // ablation members (tools only): wrong results by construction
+    if (atoi(f) > 0 && c->bits == 4 && c->layout == LAYOUT_LOP3 && c->mode == MD_S && c->mb == 1 && c->R == 2 && pick_gemvx_lab(atoi(f)))
+      c->fn = pick_gemvx_lab(atoi(f));
+  }
+  if (!c->fn) {
+    set_error(WQAA_ERR_UNSUPPORTED, "gemvx: no member for bits=%d layout=%d mode=%d mb=%d rd=%d", c->bits, c->layout, c->mode, c->mb, rd);
+    return WQAA_ERR_UNSUPPORTED;
+  }
+  return WQAA_OK;
+}
+
+int gemvx_plan(const wqaa_matmul_desc& d, int m, wqaa_plan* plan) {
+  GemvxChoice c;
+  int st = gemvx_choose(d, m, &c);
+  if (st != WQAA_OK) return st;
+  if (plan) {
+    plan->kernel_family = 1;
+    plan->block_m = c.mb;
+    plan->block_n = c.R * (c.nw / c.kw);   // rows a workgroup works on at a time
+    plan->block_k = 64 * c.E * c.D;
+    plan->threads = c.nw * 64;
+    plan->grid = c.grid;
+    plan->rows_per_wave = c.R;
+    plan->batch_tile = c.mb;
+    plan->pipeline_depth = c.D;
+    plan->split_k = c.kw;
+    plan->lds_bytes = c.lds;
+    char wd[24];
+    short_wdtype(d, wd, sizeof(wd));
+    snprintf(plan->name, sizeof(plan->name), "matmul_m%dn%dk%d_%sx%s_gemvx_b%dr%dd%dk%d", m, d.N, d.K, short_dtype(d.a_dtype), wd,
+             c.mb, c.R, c.D, c.kw);
+  }
+  return WQAA_OK;
+}
+
+int gemvx_launch(const wqaa_matmul_desc& d, const void* A, const void* B, const void* Scale, const void* Zeros,
+                 const void* Bias, void* C, int m, hipStream_t stream, hipEvent_t start, hipEvent_t stop) {
+  GemvxChoice c;
+  {
+    static thread_local ChoiceMemo<GemvxChoice> memo;
+    if (const GemvxChoice* hit = memo.find(d, m, 7)) {
+      c = *hit;
+    } else {
+      int st = gemvx_choose(d, m, &c);
+      if (st != WQAA_OK) return st;
+      memo.put(d, m, 7, c);
+    }
+  }
+  const int g = d.group_size <= 0 ? d.K : d.group_size;
+  GemvxArgs a;
+  a.A = A; a.B = B; a.scale = Scale; a.zeros = Zeros; a.bias = Bias; a.C = C;
+  a.m = m; a.N = d.N; a.K = d.K;
+  a.kg = d.K / g;
+  {
+    const int dq = g / c.E > 0 ? g / c.E : 1;
+    a.gq_shift = ilog2_exact(dq);
+    a.gq_magic = a.gq_shift >= 0 ? 0u : (uint32_t)(((1ull << 32) + dq - 1) / dq);
+  }
+  a.nc = c.nc; a.cpr = c.cpr; a.nsteps = c.nsteps; a.kw = c.kw;
+  a.row_bytes = (long)d.K * c.bits / 8;
+  a.has_bias = d.with_bias;
+  a.out_dtype = d.out_dtype;
+  const bool is_signed = d.w_format == WQAA_W_INT;
+  a.zint = is_signed ? (c.bits == 1 ? 1 : (1 << (c.bits - 1))) : 0;
+  a.flip = (is_signed && c.bits == 1) ? 0xFFFFFFFFu : 0u;
+  a.zq_row_bytes = d.N * c.bits / 8;
+  a.n_rgb = c.n_rgb;
+  void* params[] = {&a};
+  dim3 grid(c.grid, 1, 1), block(c.nw * 64, 1, 1);
+  hipError_t e;
+  if (start || stop) e = hipExtLaunchKernel(reinterpret_cast<const void*>(c.fn), grid, block, params, c.lds, stream, start, stop, 0);
+  else e = hipLaunchKernel(reinterpret_cast<const void*>(c.fn), grid, block, params, c.lds, stream);
+  if (e != hipSuccess) {
+    set_error(WQAA_ERR_LAUNCH, "gemvx launch failed: %s", hipGetErrorString(e));
+    return WQAA_ERR_LAUNCH;
+  }
+  return WQAA_OK;
+}
+
+void gemvx_init() {
+  for (int bits : {4, 2, 1})
+    for (int layout = 0; layout < 2; ++layout)
+      for (int mode = 0; mode <= MD_ZQ; ++mode)
+        for (int mb = 1; mb <= 2; ++mb)
+          for (int rd : {12, 22}) {
+            gemvx_fn fn = bits == 4 ? pick_gemvx_int4(layout, mode, mb, rd) : bits == 2 ? pick_gemvx_int2(layout, mode, mb, rd)
+                                                                                       : pick_gemvx_int1(layout, mode, mb, rd);
+            if (fn) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+          }
+  (void)hipGetLastError();
+}
+
+}  // namespace wqaa

@@ -207,6 +207,8 @@ class BoundLib:
         self.default_lut = default_lut
         self._n_opt = int(self.has_scale) + int(self.has_zeros) + int(self.has_bias)
         self._fn = self._lib.wqaa_matmul
+        self._ws_need = {}     # m -> bytes of scratch the selected member needs
+        self._ws = {}          # (stream, device) -> torch uint8 tensor
 
     def init(self):
         self._lib.init()
@@ -234,12 +236,26 @@ class BoundLib:
         zeros = next(it) if self.has_zeros else None
         bias = next(it) if self.has_bias else None
         C = next(it)
-        status = self._fn(self._desc_ref, A, B, lut, scale, zeros, bias, C, m, stream)
-        if status != OK:
-            check(status)
+        self.run(A, B, lut, scale, zeros, bias, C, m, stream)
 
-    def run(self, A, B, lut, scale, zeros, bias, C, m, stream):
-        """Fast path used by Matmul.forward: raw integer pointers, no list juggling."""
+    def run(self, A, B, lut, scale, zeros, bias, C, m, stream, device=None):
+        """Fast path used by Matmul.forward: raw integer pointers, no list juggling.
+
+        Members that need scratch (split-K partial sums, `wqaa_workspace_bytes`) get a CALLER-OWNED workspace here, the
+        reference's ownership model (general_matmul/__init__.py:29, 456-457, 482): one torch tensor per (operator,
+        stream), allocated by torch's caching allocator - which also works while the stream is being captured into a
+        graph (the block then lives in the graph's private pool for the graph's lifetime; `torch.cuda.graph` captures
+        on a side stream the library's own per-stream slab has never seen).  Two streams never share a workspace."""
+        need = self._ws_need.get(m)
+        if need is None:
+            need = self._ws_need[m] = self.workspace_bytes(m)
+        if need:
+            key = (stream, device)
+            ws = self._ws.get(key)
+            if ws is None or ws.numel() < need:
+                import torch
+                ws = self._ws[key] = torch.empty(need, dtype=torch.uint8, device=device if device is not None else "cuda")
+            return self.run_ws(A, B, lut, scale, zeros, bias, C, m, stream, ws.data_ptr(), need)
         status = self._fn(self._desc_ref, A, B, lut, scale, zeros, bias, C, m, stream)
         if status != OK:
             check(status)

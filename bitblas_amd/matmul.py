@@ -545,7 +545,7 @@ class Matmul:
             scale.data_ptr() if scale is not None else None,
             zeros.data_ptr() if zeros is not None else None,
             bias.data_ptr() if bias is not None else None,
-            output.data_ptr(), m, stream)
+            output.data_ptr(), m, stream, A.device)
         return output
 
     __call__ = forward

@@ -185,7 +185,7 @@ class Linear(nn.Module):
         lut = mm._ensure_lut(A.device) if self.source_format == "nf" else None
         B, scale, zeros, bias = self._q_run
         mm.lib.run(A.data_ptr(), B, lut.data_ptr() if lut is not None else None, scale, zeros, bias,
-                   output.data_ptr(), m, torch.cuda.current_stream(A.device).cuda_stream)
+                   output.data_ptr(), m, torch.cuda.current_stream(A.device).cuda_stream, A.device)
         return output
 
     def load_and_transform_weight(self, weight: torch.Tensor, scales: torch.Tensor = None,

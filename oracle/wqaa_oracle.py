@@ -294,6 +294,47 @@ def _quantized_zero_difference(codes, qzeros, bit: int, gi) -> np.ndarray:
     return ((d + 128) % 256) - 128
 
 
+def dequantize_weight_exact(codes: np.ndarray, source_format: str, bit: int, *, K: int | None = None,
+                            scale=None, zeros=None, zeros_mode: str = "original", group_size: int = -1, lut=None) -> np.ndarray:
+    """The real-valued dequantised weight, float64, NO rounding to A_dtype between the steps: what the
+    `strict_reference=False` exact-product members compute with (csrc/wqaa_gemvx_kernel.h).  NOT the reference's
+    definition - that is `dequantize_weight`, which rounds every step to A_dtype - but the value both approximate."""
+    codes = np.asarray(codes)
+    N, Kc = codes.shape
+    K = Kc if K is None else K
+    g = K if group_size in (-1, None) else group_size
+    gi = np.arange(K) // g
+    if zeros is not None and zeros_mode == "quantized":
+        w = _quantized_zero_difference(codes, zeros, bit, gi).astype(np.float64)
+    else:
+        w = decode_codes(codes, source_format, bit, False, lut).astype(np.float64)
+    if scale is None:
+        return w
+    s = np.asarray(scale).astype(np.float64)[:, gi]
+    if zeros is None or zeros_mode == "quantized":
+        return w * s
+    z = np.asarray(zeros).astype(np.float64)[:, gi]
+    if zeros_mode == "original":
+        return (w - z) * s
+    if zeros_mode == "rescale":
+        return w * s - z
+    raise ValueError(zeros_mode)
+
+
+def matmul_dequant_exact(A: np.ndarray, codes: np.ndarray, *, source_format: str, bit: int, scale=None, zeros=None,
+                         zeros_mode="original", group_size=-1, bias=None, out_dtype="float16", lut=None) -> np.ndarray:
+    """C = cast_out(sum_k A[m,k] * w[n,k]) (+ bias after the cast) with the unrounded w of dequantize_weight_exact."""
+    A = np.asarray(A)
+    K = A.shape[-1]
+    Wd = dequantize_weight_exact(codes, source_format, bit, K=K, scale=scale, zeros=zeros, zeros_mode=zeros_mode,
+                                 group_size=group_size, lut=lut)
+    acc = A.reshape(-1, K).astype(np.float64) @ Wd.T
+    out = acc.astype(np.float32).astype(_OUT_NP[out_dtype])
+    if bias is not None:
+        out = (out + np.asarray(bias).astype(out.dtype)).astype(out.dtype)
+    return out.reshape(*A.shape[:-1], Wd.shape[0])
+
+
 def dequantize_weight(codes: np.ndarray, source_format: str, bit: int, *, K: int | None = None,
                       scale=None, zeros=None, zeros_mode: str = "original", group_size: int = -1,
                       a_dtype: str = "float16", strict_reference: bool = True, lut=None) -> np.ndarray:

@@ -30,8 +30,41 @@ def _prepared(M, N, K, seed):
 
 
 def _run(mm, ops, out, stream, m):
-    mm.lib.run(ops["A"].data_ptr(), ops["W"].data_ptr(), None, ops["scale"].data_ptr(), ops["zeros"].data_ptr(), None,
-               out.data_ptr(), m, stream.cuda_stream)
+    """the plain C entry (wqaa_matmul): scratch from the LIBRARY's per-(device, stream) pool"""
+    import ctypes
+    lib = wl.load_library()
+    st = lib.wqaa_matmul(ctypes.byref(mm.lib.desc), ops["A"].data_ptr(), ops["W"].data_ptr(), None, ops["scale"].data_ptr(),
+                         ops["zeros"].data_ptr(), None, out.data_ptr(), m, stream.cuda_stream)
+    wl.check(st)
+
+
+def test_python_operator_owns_its_workspace_and_captures_on_a_fresh_stream():
+    """`Matmul.forward` / `lib.run`: caller-owned workspace from torch's allocator, one per (operator, stream) -
+    `torch.cuda.graph` captures on a side stream no call has run on before, and that has to work"""
+    case, mm, ops = _prepared(48, 1024, 8192, 6)
+    assert mm.lib.workspace_bytes(48) > 0
+    A, W = ops["A"], ops["W"]
+    g = torch.cuda.CUDAGraph()
+    out = torch.empty((48, 1024), dtype=torch.float16, device="cuda")
+    with torch.cuda.graph(g):
+        mm(A, W, scale=ops["scale"], zeros=ops["zeros"], output=out)
+    out.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    want = oracle_output(case)
+    assert_fp_parity(out.cpu().numpy(), want)
+    # two streams through the Python operator: each gets its own workspace tensor
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    o1, o2 = torch.empty_like(out), torch.empty_like(out)
+    for _ in range(16):
+        with torch.cuda.stream(s1):
+            mm(A, W, scale=ops["scale"], zeros=ops["zeros"], output=o1)
+        with torch.cuda.stream(s2):
+            mm(A, W, scale=ops["scale"], zeros=ops["zeros"], output=o2)
+    torch.cuda.synchronize()
+    assert_fp_parity(o1.cpu().numpy(), want)
+    assert torch.equal(o1, o2)
+    assert len(mm.lib._ws) >= 3
 
 
 def test_workspace_bytes_query():

@@ -31,7 +31,7 @@ int main(int argc, char** argv) {
   d.struct_size = sizeof d; d.N = N; d.K = K; d.a_dtype = adt; d.w_format = wfmt; d.w_bits = bits;
   d.out_dtype = odt; d.group_size = group; d.with_scaling = (adt == WQAA_F16 && wfmt != WQAA_W_NATIVE && getenv("WQ_NOSCALE") == nullptr) ? 1 : 0;
   d.zeros_mode = zmode; d.with_bias = 0; d.w_layout = (wfmt <= WQAA_W_INT && bits < 8 && getenv("WQ_PLAIN") == nullptr) ? WQAA_LAYOUT_LOP3 : WQAA_LAYOUT_PLAIN;
-  d.strict_reference = 1;
+  d.strict_reference = getenv("WQ_STRICT") ? atoi(getenv("WQ_STRICT")) : 1;
   wqaa_plan plan;
   if (wqaa_select(&d, M, &plan) != WQAA_OK) { printf("select failed: %s\n", wqaa_last_error_string()); return 2; }
   const int g = group <= 0 ? K : group;
