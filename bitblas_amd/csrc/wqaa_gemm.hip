@@ -128,10 +128,6 @@ static int gemm_choose(const wqaa_matmul_desc& d, int m, GemmChoice* c) {
     return WQAA_ERR_UNSUPPORTED;
   }
   if (c->kind == DK_E4M3 && d.strict_reference && c->at == AT_F16 && !(c->flags & FL_BF16)) c->flags |= FL_STRICT;
-  if ((c->flags & FL_BF16) && d.with_scaling && d.zeros_mode != WQAA_Z_NONE && d.zeros_mode != WQAA_Z_QUANTIZED) {
-    set_error(WQAA_ERR_UNSUPPORTED, "gemm: bfloat16 activations support scale and quantized zeros only");
-    return WQAA_ERR_UNSUPPORTED;
-  }
   if (c->kind != DK_INT4 && c->kind != DK_INT2 && c->kind != DK_INT1) c->layout = LAYOUT_PLAIN;
   if (c->at != AT_F16 && (d.with_scaling || d.zeros_mode != WQAA_Z_NONE)) {
     set_error(WQAA_ERR_UNSUPPORTED, "gemm: scale/zeros with int8 / fp8 activations are not defined by the reference");

@@ -240,7 +240,8 @@ __device__ __forceinline__ void dequant_lane_f16(const uint32_t (&w)[P::WL], hal
 // bfloat16 flavour: natural order straight away (plain layout), one rounding per element
 template <class P>
 __device__ __forceinline__ void dequant_lane_bf16(const uint32_t (&w)[P::WL], float zf, float s, bool is_signed,
-                                                  uint32_t flip, const Lut16& lut, uint32_t (&frag)[P::NJ][4]) {
+                                                  uint32_t flip, const Lut16& lut, uint32_t (&frag)[P::NJ][4], float z = 0.f) {
+  constexpr int ZM = P::MODE == MD_ZO ? 1 : P::MODE == MD_ZR ? 2 : 0;      // bfloat16 zero-point modes: one more rounding
   using T = typename P::T;
   constexpr int EPW = P::EPW;
   constexpr bool SC = P::MODE != MD_NONE;
@@ -277,7 +278,7 @@ __device__ __forceinline__ void dequant_lane_bf16(const uint32_t (&w)[P::WL], fl
 #pragma unroll
     for (int wi = 0; wi < P::WL; ++wi) {
       uint32_t pk[EPW / 2];
-      unpack_word_bf16<T::BITS, 1>(w[wi] ^ (P::KIND == DK_INT1 ? flip : 0u), zf, s, SC, pk);
+      unpack_word_bf16<T::BITS, 1, ZM>(w[wi] ^ (P::KIND == DK_INT1 ? flip : 0u), zf, s, SC, pk, z);
 #pragma unroll
       for (int i = 0; i < EPW / 2; ++i) {
         const int e = wi * EPW + 2 * i;
@@ -293,8 +294,9 @@ __device__ __forceinline__ void dequant_lane_bf16(const uint32_t (&w)[P::WL], fl
         const int b8 = (int)((w[wi] >> (8 * e)) & 0xFFu);
         if constexpr (P::MODE == MD_ZQ) v[e] = (float)(int)(int8_t)(b8 - (int)zf);   // int8 storage arithmetic wraps
         else v[e] = (float)(is_signed ? (int)(int8_t)b8 : b8);
-        if (SC) v[e] *= s;
       }
+      dequant_pair_bf16<ZM>(v[0], v[1], 0.f, s, z, SC);
+      dequant_pair_bf16<ZM>(v[2], v[3], 0.f, s, z, SC);
       const int e0 = wi * 4;
       frag[e0 / 8][(e0 % 8) / 2] = cvt_pk_bf16(v[0], v[1]);
       frag[e0 / 8][(e0 % 8) / 2 + 1] = cvt_pk_bf16(v[2], v[3]);
@@ -569,7 +571,7 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_kernel(const GemmArgs a) {
         const half2_t z2 = (MODE == MD_ZO || MODE == MD_ZR) ? splat(bits_to_half(bl.z[nf])) : splat((half_t)0.0f);
         if constexpr (P::BF)
           dequant_lane_bf16<P>(bl.w[nf], (float)zf, MODE != MD_NONE ? bf16_bits_to_float(bl.s[nf]) : 1.f, a.is_signed != 0,
-                               cx.flip, lut, bfrag[nf]);
+                               cx.flip, lut, bfrag[nf], (MODE == MD_ZO || MODE == MD_ZR) ? bf16_bits_to_float(bl.z[nf]) : 0.f);
         else
           dequant_lane_f16<P>(bl.w[nf], zf, s2, z2, cx, lut, bfrag[nf]);
       } else if constexpr (F8) {
@@ -1005,7 +1007,8 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_decode_kernel(const GemmAr
       const half2_t s2 = MODE != MD_NONE ? splat(bits_to_half(bl.s[0])) : splat((half_t)1.0f);
       const half2_t z2 = (MODE == MD_ZO || MODE == MD_ZR) ? splat(bits_to_half(bl.z[0])) : splat((half_t)0.0f);
       if constexpr (P::BF)
-        dequant_lane_bf16<P>(bl.w[0], (float)zf, MODE != MD_NONE ? bf16_bits_to_float(bl.s[0]) : 1.f, a.is_signed != 0, cx.flip, lut, bfrag);
+        dequant_lane_bf16<P>(bl.w[0], (float)zf, MODE != MD_NONE ? bf16_bits_to_float(bl.s[0]) : 1.f, a.is_signed != 0, cx.flip, lut, bfrag,
+                             (MODE == MD_ZO || MODE == MD_ZR) ? bf16_bits_to_float(bl.z[0]) : 0.f);
       else
         dequant_lane_f16<P>(bl.w[0], zf, s2, z2, cx, lut, bfrag);
     } else if constexpr (F8) {

@@ -95,10 +95,8 @@ static int classify(const wqaa_matmul_desc& d, GemvChoice* c) {
   if (c->flags & FL_BF16) {
     const bool kind_ok = c->kind == DK_INT4 || c->kind == DK_INT2 || c->kind == DK_INT1 || c->kind == DK_INT8 || c->kind == DK_NATIVE ||
                          c->kind == DK_LUT4 || c->kind == DK_E4M3;
-    const bool zeros_ok = d.zeros_mode == WQAA_Z_NONE || d.zeros_mode == WQAA_Z_QUANTIZED || !d.with_scaling;
-    if (!kind_ok || !zeros_ok || c->layout != LAYOUT_PLAIN) {
-      set_error(WQAA_ERR_UNSUPPORTED, "gemv: bfloat16 activations support plain-layout integer / bf16 weights with "
-                "scale and quantized zeros only");
+    if (!kind_ok || c->layout != LAYOUT_PLAIN) {
+      set_error(WQAA_ERR_UNSUPPORTED, "gemv: bfloat16 activations support plain-layout integer / nf4 / fp4 / e4m3 / bf16 weights");
       return WQAA_ERR_UNSUPPORTED;
     }
   }

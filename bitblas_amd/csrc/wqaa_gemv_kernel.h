@@ -561,8 +561,10 @@ __global__ void __launch_bounds__(1024) wq_gemv_kernel(const GemvArgs a) {
                 q[r][i] = MODE == MD_NONE ? t[i] : as_h2(bf16x2_scale(as_u32(t[i]), bf16_bits_to_float(s.s[r])));
             } else if constexpr (T::SUBBYTE) {
               uint32_t pk[G / 2];
-              unpack_word_bf16<T::BITS, 0>(s.w[r][u] ^ (P::KIND == DK_INT1 ? cx.flip : 0u), (float)zf,
-                                           bf16_bits_to_float(s.s[r]), MODE != MD_NONE, pk);
+              constexpr int ZM = MODE == MD_ZO ? 1 : MODE == MD_ZR ? 2 : 0;
+              unpack_word_bf16<T::BITS, 0, ZM>(s.w[r][u] ^ (P::KIND == DK_INT1 ? cx.flip : 0u), (float)zf,
+                                               bf16_bits_to_float(s.s[r]), MODE != MD_NONE, pk,
+                                               ZM ? bf16_bits_to_float(s.z[r]) : 0.f);
 #pragma unroll
               for (int i = 0; i < G / 2; ++i) q[r][i] = as_h2(pk[i]);
             } else {
@@ -577,7 +579,12 @@ __global__ void __launch_bounds__(1024) wq_gemv_kernel(const GemvArgs a) {
                     const int b8 = (int)((x >> (8 * e)) & 0xFFu);
                     if constexpr (MODE == MD_ZQ) v[e] = (float)(int)(int8_t)(b8 - (int)(float)zf);   // int8 storage arithmetic wraps
                     else v[e] = (float)(a.is_signed ? (int)(int8_t)b8 : b8);
-                    if (MODE != MD_NONE) v[e] *= sc;
+                  }
+                  {
+                    constexpr int ZM = MODE == MD_ZO ? 1 : MODE == MD_ZR ? 2 : 0;
+                    const float zv = ZM ? bf16_bits_to_float(s.z[r]) : 0.f;
+                    dequant_pair_bf16<ZM>(v[0], v[1], 0.f, sc, zv, MODE != MD_NONE);
+                    dequant_pair_bf16<ZM>(v[2], v[3], 0.f, sc, zv, MODE != MD_NONE);
                   }
                   q[r][2 * j] = as_h2(cvt_pk_bf16(v[0], v[1]));
                   q[r][2 * j + 1] = as_h2(cvt_pk_bf16(v[2], v[3]));

@@ -143,15 +143,39 @@ __device__ __forceinline__ float bf16_bits_to_float(uint32_t b) { return __built
 // fields of one 32-bit word -> EPW/2 packed bf16 pairs.  PAIR_ORDER selects which two fields share a
 // register: 0 = F16Unpack's extraction order (field i, field i + EPW/2) used by the GEMV's permuted LDS
 // tile, 1 = natural order (2i, 2i+1) used by the MFMA fragments.  Plain layout only (bf16 has no LOP3).
-template <int BITS, int PAIR_ORDER>
-__device__ __forceinline__ void unpack_word_bf16(uint32_t w, float zf, float s, bool scale, uint32_t (&out)[32 / BITS / 2]) {
+// One more bfloat16 rounding between the two steps of the zero-point modes, as the TE expression has it
+// (matmul_dequantize_impl.py:441-444 in bfloat16 arithmetic): original (w - z) * s, rescale w * s - z.
+__device__ __forceinline__ void bf16x2_round(float& a, float& b) {
+  const uint32_t r = cvt_pk_bf16(a, b);
+  a = __builtin_bit_cast(float, r << 16);
+  b = __builtin_bit_cast(float, r & 0xFFFF0000u);
+}
+// one dequantised value in bfloat16 arithmetic: ZM 0 = (w - zf) * s with an integer zf (w - zf exact: one rounding),
+// 1 = original: bf16(bf16(w - z) * s), 2 = rescale: bf16(bf16(w * s) - z)
+template <int ZM>
+__device__ __forceinline__ void dequant_pair_bf16(float& a, float& b, float zf, float s, float z, bool scale) {
+  if constexpr (ZM == 1) {
+    a -= z; b -= z;
+    bf16x2_round(a, b);
+    a *= s; b *= s;
+  } else if constexpr (ZM == 2) {
+    a *= s; b *= s;
+    bf16x2_round(a, b);
+    a -= z; b -= z;
+  } else {
+    a -= zf; b -= zf;
+    if (scale) { a *= s; b *= s; }
+  }
+}
+template <int BITS, int PAIR_ORDER, int ZM = 0>
+__device__ __forceinline__ void unpack_word_bf16(uint32_t w, float zf, float s, bool scale, uint32_t (&out)[32 / BITS / 2], float z = 0.f) {
   constexpr int EPW = 32 / BITS, NPAIR = EPW / 2;
 #pragma unroll
   for (int i = 0; i < NPAIR; ++i) {
     const int f0 = PAIR_ORDER ? 2 * i : i, f1 = PAIR_ORDER ? 2 * i + 1 : i + NPAIR;
-    float a = (float)__builtin_amdgcn_ubfe(w, f0 * BITS, BITS) - zf;
-    float b = (float)__builtin_amdgcn_ubfe(w, f1 * BITS, BITS) - zf;
-    if (scale) { a *= s; b *= s; }
+    float a = (float)__builtin_amdgcn_ubfe(w, f0 * BITS, BITS);
+    float b = (float)__builtin_amdgcn_ubfe(w, f1 * BITS, BITS);
+    dequant_pair_bf16<ZM>(a, b, zf, s, z, scale);
     out[i] = cvt_pk_bf16(a, b);
   }
 }

@@ -220,23 +220,34 @@ def _bf16_case(M, N, K, W_dtype, g, with_scaling, zeros_mode=None, seed=0):
     if zeros_mode == "quantized":
         zint = np.clip((1 << (bit - 1)) + rng.integers(-2, 2, size=(K // gg, N)), 0, (1 << bit) - 1).astype(np.int8)
         zeros = oracle.general_compress(zint, bit)
+    elif zeros_mode in ("original", "rescale"):
+        # bfloat16 zero points: integers as GPTQ gives them, some with a fraction (then `w - z` itself rounds to bfloat16)
+        z = ((1 << (bit - 1)) + rng.integers(-2, 3, size=(N, K // gg))).astype(np.float32)
+        z[::3, 0] += 0.3125
+        zt = torch.from_numpy(z).to(torch.bfloat16)
+        if zeros_mode == "rescale":
+            zt = (zt.float() * scale.float()).to(torch.bfloat16)
+        zeros = zt
     cfg = bitblas.MatmulConfig(M=M, N=N, K=K, A_dtype="bfloat16", W_dtype=W_dtype, accum_dtype="float32", out_dtype="float32",
                                group_size=g, with_scaling=with_scaling, with_zeros=zeros is not None,
                                zeros_mode=zeros_mode or "original")
     mm = bitblas.Matmul(cfg, enable_tuning=False)
     assert cfg.fast_decoding is False                 # the reference's legalisation: no LOP3 layout for bf16
     Wt = mm.weight_transform(torch.from_numpy(codes)).cuda() if mm.weight_transform is not None else torch.from_numpy(codes).cuda()
-    out = mm(A.cuda(), Wt, scale=None if scale is None else scale.cuda(),
-             zeros=None if zeros is None else torch.from_numpy(zeros).cuda()).cpu().numpy()
+    zdev = None if zeros is None else (zeros.cuda() if isinstance(zeros, torch.Tensor) else torch.from_numpy(zeros).cuda())
+    out = mm(A.cuda(), Wt, scale=None if scale is None else scale.cuda(), zeros=zdev).cpu().numpy()
     want = oracle.matmul_dequant(A.float().numpy(), codes, source_format=src, bit=bit,
-                                 scale=None if scale is None else scale.float().numpy(), zeros=zeros,
+                                 scale=None if scale is None else scale.float().numpy(),
+                                 zeros=zeros.float().numpy() if isinstance(zeros, torch.Tensor) else zeros,
                                  zeros_mode=zeros_mode or "original", group_size=gg, a_dtype="bfloat16", out_dtype="float32")
     return out, want, mm
 
 
 @pytest.mark.parametrize("M", [1, 3, 64, 1024])
 @pytest.mark.parametrize("W_dtype,g,ws,zm", [("uint4", -1, False, None), ("uint4", 32, True, None), ("int4", 128, True, None),
-                                             ("uint4", 128, True, "quantized"), ("uint2", 128, True, None), ("int8", 128, True, None)])
+                                             ("uint4", 128, True, "quantized"), ("uint2", 128, True, None), ("int8", 128, True, None),
+                                             ("uint4", 128, True, "original"), ("uint4", 128, True, "rescale"),
+                                             ("uint2", 64, True, "original"), ("uint8", 128, True, "rescale"), ("uint1", 128, True, "original")])
 def test_bf16_activations(M, W_dtype, g, ws, zm):
     """reference cases test_general_matmul_bf16.py:170-178 (M in {1, 1024}, uint4, +-scale g=32) and neighbours."""
     if W_dtype == "uint4" and g == 32 and M >= 8:

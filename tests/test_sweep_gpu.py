@@ -85,7 +85,8 @@ def test_random_configurations(chunk):
 
 
 def test_random_bf16_configurations():
-    """bfloat16 activations (ref: test_general_matmul_bf16.py): plain layout, none / scale / quantized zeros."""
+    """bfloat16 activations (ref: test_general_matmul_bf16.py; the TE zero modes apply to any A_dtype,
+    matmul_dequantize_impl.py:435-449): plain layout, none / scale / the three zeros modes."""
     from test_gemm_gpu import _bf16_case
     rng = np.random.default_rng(77)
     ran = 0
@@ -94,7 +95,7 @@ def test_random_bf16_configurations():
         M, N, K = int(rng.choice(MS)), int(rng.choice([64, 128, 272, 520])), int(rng.choice(KS))
         ws = bool(rng.random() < 0.7)
         g = int(rng.choice([-1, 64, 128, 256])) if ws else -1
-        zm = "quantized" if (ws and wd.startswith("uint") and rng.random() < 0.5) else None
+        zm = str(rng.choice(["quantized", "original", "rescale"])) if (ws and wd.startswith("uint") and rng.random() < 0.6) else None
         if g != -1 and K % g:
             continue
         try:
