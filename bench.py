@@ -221,6 +221,50 @@ def time_member_dense(device, gen, M, N, K, kind="fp8", n_buf=4):
     return res
 
 
+def time_c5_sharded(device, gen, world, rank, steps=5, warmup=2):
+    """BASELINE config c5 as the multi-GPU workload: dense e4m3 x e4m3, M = 4096, the four Llama-3-70B linears, N column-
+    sharded over the ranks (rank p owns rows [p N/P, (p+1) N/P) of W), output slices all-gathered over RCCL in row blocks
+    (ColumnParallelMatmul.auto_row_block) under the next block's GEMM (bitblas_amd/parallel.py).  Strong scaling: the total work is fixed."""
+    import torch.distributed as dist
+    from bitblas_amd.parallel import ColumnParallelMatmul
+    M = 4096
+    shapes = [("o_proj", 8192, 8192), ("down_proj", 8192, 28672), ("qkv_proj", 10240, 8192), ("gate_proj", 28672, 8192)]
+    ops = []
+    for (_, N, K) in shapes:
+        cfg = bitblas.MatmulConfig(M=M, N=N, K=K, A_dtype="e4m3_float8", W_dtype="e4m3_float8", accum_dtype="float32", out_dtype="float16")
+        op = ColumnParallelMatmul(cfg)
+        A = (torch.rand((M, K), device=device, generator=gen) * 2 - 1).to(torch.float8_e4m3fn)
+        W = (torch.rand((N // world, K), device=device, generator=gen) * 2 - 1).to(torch.float8_e4m3fn)
+        out = torch.empty((M, N), dtype=torch.float16, device=device)
+        ops.append((op, A, W, out))
+
+    def step():
+        for (op, A, W, out) in ops:
+            op(A, W, out=out)
+
+    for _ in range(warmup):
+        step()
+    dist.barrier()
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize(device)
+    dist.barrier()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    flops = sum(2.0 * M * N * K for (_, N, K) in shapes)
+    return {"workload": "e4m3 x e4m3 GEMM M=4096, Llama-3-70B o/down/qkv/gate, N column-sharded over the ranks, all-gather of the "
+                        "[4096, N/P] float16 slices in row blocks under the next block's GEMM",
+            "row_blocks": [op.row_block for (op, _, _, _) in ops],
+            "scaling": "strong", "n_gpus": world, "steps": steps, "ms_per_step": elapsed / steps * 1e3,
+            "TFLOPs_whole_job": flops * steps / elapsed / 1e12,
+            "gathered_bytes_per_step_per_rank": sum(M * N * 2 for (_, N, _) in shapes) * (world - 1) // max(world, 1),
+            "kernels": [op.op.plans[M]["name"] if M in op.op.plans else None for (op, _, _, _) in ops]}
+
+
 def cpu_baseline(max_seconds=20.0):
     """The reference's CPU path restated: dequantise the int4 weights to float16 values and take
     the fp32 matmul, timed on ALL host cores - both stages in torch (threaded); the first pass is checked against the
@@ -503,6 +547,11 @@ def main():
             result["members"] = members
         if not args.no_cpu_baseline and world == 1:
             result["cpu_baseline"] = cpu_baseline()
+    if dist_on and not args.no_members:
+        c5 = time_c5_sharded(device, gen, world, rank)          # every rank takes part; rank 0 reports
+        if rank == 0:
+            result["multi_gpu_c5"] = c5
+            result["config"]["workload"] += "; + BASELINE c5 (e4m3 x e4m3 M=4096, N column-sharded, RCCL all-gather) under `multi_gpu_c5`"
     if dist_on:
         import torch.distributed as dist
         dist.barrier()

@@ -65,6 +65,59 @@ def _worker(rank, world, port, zeros_mode, M, ret):
         dist.destroy_process_group()
 
 
+def _worker_dense_blocked(rank, world, port, M, row_block, ret):
+    """BASELINE c5 shape family on CPU: dense e4m3 x e4m3, M rows streamed in row blocks, every block gathered +
+    interleaved into the [M, N] output; the kernel launch is replaced by the oracle"""
+    for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import wqaa_oracle as oracle
+        from bitblas_amd import MatmulConfig
+        from bitblas_amd.parallel import ColumnParallelMatmul, gather_columns
+        rng = np.random.default_rng(11)
+        N, K = 96, 128
+        A8 = torch.from_numpy(rng.random((M, K), dtype=np.float32) * 2 - 1).to(torch.float8_e4m3fn)
+        W8 = torch.from_numpy(rng.random((N, K), dtype=np.float32) * 2 - 1).to(torch.float8_e4m3fn)
+        want = oracle.matmul_dense(A8.view(torch.int8).numpy(), W8.view(torch.int8).numpy(), a_dtype="e4m3_float8", out_dtype="float16")
+        cfg = MatmulConfig(M=M, N=N, K=K, A_dtype="e4m3_float8", W_dtype="e4m3_float8", accum_dtype="float32", out_dtype="float16")
+
+        def compute(A_t, W_t, s, z, b):
+            return torch.from_numpy(oracle.matmul_dense(A_t.view(torch.int8).numpy(), W_t.view(torch.int8).numpy(),
+                                                        a_dtype="e4m3_float8", out_dtype="float16"))
+
+        op = ColumnParallelMatmul(cfg, compute=compute, row_block=row_block)
+        lo, hi = op.lo, op.hi
+        got = op(A8, W8.view(torch.int8)[lo:hi].contiguous().view(torch.float8_e4m3fn))
+        ok = got.shape == (M, N) and got.is_contiguous() and bool(np.array_equal(got.numpy(), want))
+        # M = 1 / pre-allocated output: the collective writes straight into `out`, which is returned as is
+        one = torch.from_numpy(want[:1, lo:hi].copy())
+        dst = torch.empty((1, N), dtype=torch.float16)
+        res = gather_columns(one, out=dst)
+        ok = ok and res.data_ptr() == dst.data_ptr() and bool(np.array_equal(dst.numpy(), want[:1]))
+        ret[rank] = ok
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("M,row_block", [(7, 512), (40, 16), (33, 8)])
+def test_dense_fp8_row_blocked_gather(M, row_block):
+    world = 2
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_dense_blocked, args=(r, world, port, M, row_block, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    assert all(ret.get(r) for r in range(world)), dict(ret)
+
+
 @pytest.mark.parametrize("zeros_mode", ["original", "quantized"])
 @pytest.mark.parametrize("M", [1, 5])
 def test_column_shard_all_gather_matches_unsharded(zeros_mode, M):
