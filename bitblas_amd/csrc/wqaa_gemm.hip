@@ -184,15 +184,21 @@ static int gemm_choose(const wqaa_matmul_desc& d, int m, GemmChoice* c) {
     if (!dflag || atoi(dflag) != 0) c->decode = 1;
   }
   if (c->decode) {
-    c->fn = pick_gemm(c->kind, c->layout, c->at, c->mode, c->flags, 200 + c->mf);
+    // activations through LDS-DMA (member 211) unless disabled (WQAA_GEMM_DECODE_LDS=0: the direct-load member 201)
+    const char* lflag = getenv("WQAA_GEMM_DECODE_LDS");
+    const bool want_lds = c->mf == 1 && c->at != AT_I4 && (!lflag || atoi(lflag) != 0);
+    c->fn = want_lds ? pick_gemm(c->kind, c->layout, c->at, c->mode, c->flags, 211) : nullptr;
+    const bool lds_member = c->fn != nullptr;
+    if (!c->fn) c->fn = pick_gemm(c->kind, c->layout, c->at, c->mode, c->flags, 200 + c->mf);
     if (c->fn) {
       c->nwaves = 8;
       c->bn = 16;
       c->skinny = 0;
       c->tiles_m = 1;
       c->tiles_n = (d.N + 15) / 16;
-      c->lds = 8 * c->mf * 64 * 16;
+      c->lds = lds_member ? 8 * 4 * 16 * 256 + 8 * 64 * 16 : 8 * c->mf * 64 * 16;
       c->ksplit = 1;
+      c->decode = lds_member ? 2 : 1;
       return WQAA_OK;
     }
     c->decode = 0;
@@ -262,7 +268,7 @@ int gemm_plan(const wqaa_matmul_desc& d, int m, wqaa_plan* plan) {
     char wd[24];
     short_wdtype(d, wd, sizeof(wd));
     snprintf(plan->name, sizeof(plan->name), "matmul_m%dn%dk%d_%sx%s_tcx%dx%dx%d%s%s", m, d.N, d.K, short_dtype(d.a_dtype),
-             wd, 16 * c.mf, c.bn, c.ks, c.ksplit > 1 ? "xr" : "", c.skinny ? "xs" : c.decode ? "xd" : c.wide ? "xw" : "");
+             wd, 16 * c.mf, c.bn, c.ks, c.ksplit > 1 ? "xr" : "", c.skinny ? "xs" : c.decode == 2 ? "xdl" : c.decode ? "xd" : c.wide ? "xw" : "");
   }
   return WQAA_OK;
 }
@@ -374,7 +380,7 @@ void gemm_init() {
       for (int at = 0; at < 4; ++at)
         for (int mode = 0; mode <= MD_ZQ; ++mode)
           for (int flags : {0, (int)FL_STRICT, (int)FL_ABF8, (int)FL_BF16})
-            for (int mf : {1, 2, 4, 8, 16, 101, 102, 104, 201, 404}) {
+            for (int mf : {1, 2, 4, 8, 16, 101, 102, 104, 201, 211, 404}) {
               gemm_fn fn = pick_gemm(kind, layout, at, mode, flags, mf);
               if (fn) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             }

@@ -1116,6 +1116,214 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_decode_kernel(const GemmAr
 }
 
 // ------------------------------------------------------------------------------------------
+// decode-batch member, activations through LDS (M <= 16, 2-byte or 1-byte activations).  Same decomposition as
+// wq_gemm_decode_kernel - a workgroup per 16-row weight fragment owning all of K, its 8 waves taking contiguous
+// k ranges, one launch, deterministic - but the activation operand no longer comes as fragment-shaped global loads
+// (16 rows x 64 B per wave instruction: 16 cache-line halves, twice the texture-path work per byte, PMC:
+// profiles/r02_pmc_before.json m16, TA busy 3.5x the GEMV's).  Each wave copies exactly the activation columns IT
+// multiplies - 16 rows x its k range - into its own LDS region with global_load_lds (LDS-DMA: 1 KiB of contiguous
+// row segments per instruction, no VGPRs, no ds_write), XOR-swizzled through the SOURCE address so that the MFMA
+// operand reads (ds_read_b128) are conflict free; nothing is shared between waves, so the only synchronisation is
+// the issuing wave's own vmcnt.  Blocks of 4 k-steps: the block's activations (only the row groups below M), then its
+// metadata and weights, all in flight before any is used.
+// Same-call A/B against the direct-load member, uint4 g128 + zeros, 4096^2 (profiles/r02_ab_decode_lds.txt):
+// M=16 8.43 -> 6.66 us, M=12 7.8 -> 6.2, M=8 7.1 -> 5.95, M=3 6.2 -> 5.76; 3584x8192 M=16 14.4 -> 10.5; int2 x int8 M=16 5.68 -> 5.08.
+// ------------------------------------------------------------------------------------------
+template <class P>
+__global__ void __launch_bounds__(P::THREADS) wq_gemm_decode_lds_kernel(const GemmArgs a) {
+  using T = typename P::T;
+  constexpr int NJ = P::NJ, WL = P::WL, MODE = P::MODE, NW = P::NWAVES;
+  constexpr bool F16 = P::AT == AT_F16, F8 = P::AT == AT_F8, FACC = F16 || F8;
+  constexpr int ASZ = F16 ? 2 : 1;
+  using acc_t = typename std::conditional<FACC, f32x4, i32x4>::type;
+  constexpr int ZB = T::SUBBYTE ? T::BITS : 8;
+  constexpr int ZPB = 8 / ZB;
+  constexpr int PF = 4;                       // k-steps per block
+  static_assert(P::NFW == 1 && P::MF == 1 && P::AT != AT_I4, "decode-LDS member: one weight fragment, M <= 16, unpacked activations");
+  constexpr int STEP_BYTES = 16 * P::ROW_BYTES;          // one k-step of the 16-row activation fragment in LDS: 4 KiB
+  constexpr int REGION = PF * STEP_BYTES;                // per wave: 16 KiB
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 15, kb = lane >> 4;
+  int blk = blockIdx.x;
+  if ((gridDim.x & 7) == 0) blk = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  const int n0 = blk * 16;
+  int nrow = n0 + fr;
+  nrow = nrow < a.N ? nrow : a.N - 1;
+
+  const uint8_t* Ap = reinterpret_cast<const uint8_t*>(a.A);
+  const uint8_t* Bp = reinterpret_cast<const uint8_t*>(a.B);
+  const uint16_t* Sp = reinterpret_cast<const uint16_t*>(a.scale);
+  const uint16_t* Zp = reinterpret_cast<const uint16_t*>(a.zeros);
+  const uint8_t* Qp = reinterpret_cast<const uint8_t*>(a.zeros);
+  const uint8_t* brow = Bp + (long)nrow * a.row_bytes + (long)kb * (WL * 4);
+  const long srow = (long)nrow * a.kg;
+  unsigned char* region = smem_raw + wave * REGION;
+
+  // LDS-DMA source of this lane for instruction q (rows 4q .. 4q+3) of a k-step: the slot it fills is (row, p = lane & 15);
+  // slot p of row r holds the granule whose (j, kb) index is p ^ (r & 15)  [granule order (j << 2) | kb, see wq_gemm_kernel]
+  uint32_t dsrc[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    int r = 4 * q + (lane >> 4);
+    const int x = (lane & 15) ^ (r & 15);
+    const int ns = (x & 3) * 4 + (x >> 2);                     // natural granule (kb' * 4 + j') inside the k-step
+    r = r < a.M ? r : a.M - 1;                                  // rows >= M are never stored
+    dsrc[q] = (uint32_t)r * (uint32_t)(a.K * ASZ) + (uint32_t)(ns * 16);
+  }
+  constexpr int ASTEP = P::KS * ASZ;                            // bytes of one k-step in a row of A (= 256)
+  const int nq = (a.M + 3) >> 2;                                // row groups that hold real rows (the rest of the fragment is never stored)
+  auto dma_step = [&](int t, int s) {                           // k-step t -> block slot s
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (q < nq)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Ap + (long)t * ASTEP + dsrc[q]),
+                                         (__attribute__((address_space(3))) void*)(region + s * STEP_BYTES + q * 1024), 16, 0, 0);
+  };
+
+  constexpr bool WIDE_OK = MODE == MD_S || MODE == MD_ZO || MODE == MD_ZR;
+  const bool wide = WIDE_OK && a.gq_shift == 2 && (a.kg & 3) == 0;   // one group per k-step: 8-byte metadata loads per block
+  auto w_load = [&](int t, BLane<P>& b) {
+    const int kidx = t * 4 + kb;
+    int gi = 0;
+    if (MODE != MD_NONE) gi = a.gq_shift >= 0 ? (kidx >> a.gq_shift) : (int)__umulhi((uint32_t)kidx, a.gq_magic);
+    load_lane_words<WL>(brow + (long)t * (4 * WL * 4), b.w[0]);
+    if (!wide) {
+      if constexpr (MODE != MD_NONE) b.s[0] = Sp[srow + gi];
+      if constexpr (MODE == MD_ZO || MODE == MD_ZR) b.z[0] = Zp[srow + gi];
+    }
+    if constexpr (MODE == MD_ZQ) b.z[0] = Qp[(long)gi * a.zq_row_bytes + nrow / ZPB];
+  };
+
+  DecodeCtx cx;
+  cx.zf = (F16 && a.is_signed && T::SUBBYTE) ? (half_t)(float)(1 << (T::BITS - 1)) : (half_t)0.0f;
+  cx.flip = 0u;
+  if (P::KIND == DK_INT1 && a.is_signed) cx.flip = 0xFFFFFFFFu;
+  if (P::KIND == DK_INT8 && a.is_signed) cx.flip = 0x80808080u;
+  cx.off8 = (half_t)(a.is_signed ? 1152.0f : 1024.0f);
+  make_magic(cx.magic);
+  const uint32_t zp4 = (!F16 && a.is_signed && T::SUBBYTE) ? (uint32_t)(1u << (T::BITS - 1)) * 0x01010101u : 0u;
+  Lut16 lut;
+  if constexpr (P::KIND == DK_LUT4) {
+    if (a.fp4_table) lut = make_fp4_lut(P::BF);
+    else lut = make_lut16(reinterpret_cast<const half_t*>(a.lut));
+  }
+
+  acc_t acc = acc_t{0, 0, 0, 0};
+  auto compute = [&](const BLane<P>& bl, int s) {
+    uint32_t bfrag[NJ][4];
+    if constexpr (F16) {
+      half_t zf = cx.zf;
+      if constexpr (MODE == MD_ZQ) {
+        const uint32_t zq = (bl.z[0] >> ((nrow % ZPB) * ZB)) & ((1u << ZB) - 1u);
+        zf = (half_t)(float)zq;
+      }
+      const half2_t s2 = MODE != MD_NONE ? splat(bits_to_half(bl.s[0])) : splat((half_t)1.0f);
+      const half2_t z2 = (MODE == MD_ZO || MODE == MD_ZR) ? splat(bits_to_half(bl.z[0])) : splat((half_t)0.0f);
+      if constexpr (P::BF)
+        dequant_lane_bf16<P>(bl.w[0], (float)zf, MODE != MD_NONE ? bf16_bits_to_float(bl.s[0]) : 1.f, a.is_signed != 0, cx.flip, lut, bfrag,
+                             (MODE == MD_ZO || MODE == MD_ZR) ? bf16_bits_to_float(bl.z[0]) : 0.f);
+      else
+        dequant_lane_f16<P>(bl.w[0], zf, s2, z2, cx, lut, bfrag);
+    } else if constexpr (F8) {
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        bfrag[j][0] = bl.w[0][2 * j];
+        bfrag[j][1] = bl.w[0][2 * j + 1];
+      }
+    } else {
+      dequant_lane_i8<P>(bl.w[0], zp4, cx.flip, bfrag);
+    }
+    // The LDS-DMA writes of this block were issued BEFORE its weight loads and loads return in order, so once the
+    // weight word is here the activations are too.  The compiler does not know the ds_reads depend on the DMA: tie
+    // their address to the weight word (an empty asm that "rewrites" the offset after reading the word), so the
+    // reads are ordered after the vmcnt wait it inserts for the weights.
+    uint32_t roff = (uint32_t)(s * STEP_BYTES + fr * P::ROW_BYTES);
+    asm volatile("" : "+v"(roff) : "v"(bl.w[0][0]));
+    const unsigned char* rowp = region + roff;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const u32x4 v = *reinterpret_cast<const u32x4*>(rowp + ((((g << 2) | kb) ^ fr) * 16));
+      if constexpr (F16) {
+        const u32x4 bv = {bfrag[g][0], bfrag[g][1], bfrag[g][2], bfrag[g][3]};
+        if constexpr (P::BF)
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, bv), __builtin_bit_cast(bf16x8_t, v), acc, 0, 0, 0);
+        else
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8_t, bv), __builtin_bit_cast(half8_t, v), acc, 0, 0, 0);
+      } else if constexpr (F8) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const u32x2 b2 = {bfrag[2 * g + h][0], bfrag[2 * g + h][1]};
+          const u32x2 a2 = {v[2 * h], v[2 * h + 1]};
+          const long bl8 = __builtin_bit_cast(long, b2), al8 = __builtin_bit_cast(long, a2);
+          constexpr bool WB = P::KIND == DK_E5M2, AB = (P::FLAGS & FL_ABF8) != 0;
+          if constexpr (!WB && !AB) acc = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(bl8, al8, acc, 0, 0, 0);
+          if constexpr (!WB && AB) acc = __builtin_amdgcn_mfma_f32_16x16x32_fp8_bf8(bl8, al8, acc, 0, 0, 0);
+          if constexpr (WB && !AB) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf8_fp8(bl8, al8, acc, 0, 0, 0);
+          if constexpr (WB && AB) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf8_bf8(bl8, al8, acc, 0, 0, 0);
+        }
+      } else {
+        const u32x4 bv = {bfrag[g][0], bfrag[g][1], bfrag[g][2], bfrag[g][3]};
+        acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4, bv), __builtin_bit_cast(i32x4, v), acc, 0, 0, 0);
+      }
+    }
+  };
+
+  // wave w takes a contiguous run of k-steps, a multiple of 4 long (blocks line up with the 8-byte metadata loads)
+  const int nsteps = a.nsteps;
+  const int last = nsteps - 1;
+  const int run = (((nsteps + NW - 1) / NW) + 3) & ~3;
+  const int t_lo = wave * run;
+  const int my_steps = t_lo >= nsteps ? 0 : (nsteps - t_lo < run ? nsteps - t_lo : run);   // wave-uniform
+  acc_t* red = reinterpret_cast<acc_t*>(smem_raw + NW * REGION);
+  for (int s0 = 0; s0 < my_steps; s0 += PF) {
+    BLane<P> bs[PF];
+    u32x2 gs = {0u, 0u}, gz = {0u, 0u};
+    // activations first (L2 resident after the first workgroups, and loads return in order), then the weights
+#pragma unroll
+    for (int i = 0; i < PF; ++i) {
+      const int t = t_lo + s0 + i;
+      dma_step(t < nsteps ? t : last, i);                      // clamped: loads unconditional, compute guarded
+    }
+    asm volatile("" ::: "memory");
+    if (wide) {
+      int base = t_lo + s0 < a.kg - 4 ? t_lo + s0 : a.kg - 4;
+      base = base < 0 ? 0 : base;
+      gs = *reinterpret_cast<const u32x2*>(Sp + srow + base);
+      if constexpr (MODE == MD_ZO || MODE == MD_ZR) gz = *reinterpret_cast<const u32x2*>(Zp + srow + base);
+    }
+#pragma unroll
+    for (int i = 0; i < PF; ++i) {
+      const int t = t_lo + s0 + i;
+      w_load(t < nsteps ? t : last, bs[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < PF; ++i) {
+      if (wide) {
+        bs[i].s[0] = (gs[i >> 1] >> (16 * (i & 1))) & 0xFFFFu;
+        bs[i].z[0] = (gz[i >> 1] >> (16 * (i & 1))) & 0xFFFFu;
+      }
+      if (s0 + i < my_steps) compute(bs[i], i);
+    }
+    // the region is rewritten by the next block's DMA: every ds_read of this block must have returned
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+
+  // ---- meet in LDS: slot [wave][lane] (its own region, after the activation ones), summed in wave order by wave 0 ----
+  red[wave * 64 + lane] = acc;
+  __syncthreads();
+  if (wave != 0) return;
+  acc_t sum = red[lane];
+#pragma unroll
+  for (int w = 1; w < NW; ++w) sum += red[w * 64 + lane];
+  const int nb = n0 + kb * 4;
+  if (nb < a.N && fr < a.M) store_quad<P>(a, sum, fr, nb);
+}
+
+// ------------------------------------------------------------------------------------------
 // split-K reduction: C[m][n..n+3] = cast(sum_s ws[s][m][n..n+3]) (+ bias after the cast)
 // ------------------------------------------------------------------------------------------
 template <bool F16>
@@ -1171,7 +1379,7 @@ gemm_fn pick_gemm_bf16(int kind, int mode, int mf);
 gemm_fn pick_gemm_i8_f8(int kind, int layout, int at, int flags, int mf);
 
 // mf codes: 1, 2, 4, 8 (16*mf x 128, 4 waves), 16 (256 x 256, 8 waves), 101/102/104 (skinny members),
-// 201 (decode-batch member: one launch, K split across the waves of a workgroup)
+// 201 (decode-batch member: one launch, K split across the waves of a workgroup), 211 (the same with the activations through LDS-DMA)
 template <int KIND, int LAYOUT, int AT, int MODE, int FLAGS>
 static gemm_fn pick_mf(int mf) {
   switch (mf) {
@@ -1183,7 +1391,9 @@ static gemm_fn pick_mf(int mf) {
     case 101: return wq_gemm_kernel<GemmPolicy<KIND, LAYOUT, AT, MODE, FLAGS, 1, 4, 1, 4>>;
     case 102: return wq_gemm_kernel<GemmPolicy<KIND, LAYOUT, AT, MODE, FLAGS, 2, 4, 1, 4>>;
     case 104: return wq_gemm_kernel<GemmPolicy<KIND, LAYOUT, AT, MODE, FLAGS, 4, 4, 1, 4>>;
+    // 128-row skinny member: 8 waves x one weight fragment each (BN = 128), 4 k-steps per workgroup, every load first
     case 201: return wq_gemm_decode_kernel<GemmPolicy<KIND, LAYOUT, AT, MODE, FLAGS, 1, 8, 1>>;
+    case 211: if constexpr (AT != AT_I4) return wq_gemm_decode_lds_kernel<GemmPolicy<KIND, LAYOUT, AT, MODE, FLAGS, 1, 8, 1>>; else return nullptr;
     case 404: if constexpr (KIND == DK_INT4 && AT == AT_F16 && FLAGS == 0 && (MODE == MD_ZO || MODE == MD_ZR)) return wq_gemm_kernel<GemmPolicy<KIND, LAYOUT, AT, MODE, FLAGS, 4, 4, 2, 0, true>>; else return nullptr;
   }
   return nullptr;
