@@ -334,20 +334,20 @@ __device__ __forceinline__ void dequant_lane_i8(const uint32_t (&w)[P::WL], uint
   }
 }
 
-template <int NW_>
+template <int NW_, bool NT = false>   // NT: non-temporal (weights one CU reads once: landed ~18 % sooner, MI355X_MICROARCH "nt-weights")
 __device__ __forceinline__ void load_lane_words(const uint8_t* p, uint32_t (&w)[NW_]) {
   if constexpr (NW_ % 4 == 0) {
 #pragma unroll
     for (int q = 0; q < NW_ / 4; ++q) {
-      const u32x4 v = reinterpret_cast<const u32x4*>(p)[q];
+      const u32x4 v = NT ? __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p) + q) : reinterpret_cast<const u32x4*>(p)[q];
       w[4 * q] = v[0]; w[4 * q + 1] = v[1]; w[4 * q + 2] = v[2]; w[4 * q + 3] = v[3];
     }
   } else if constexpr (NW_ == 2) {
-    const u32x2 v = *reinterpret_cast<const u32x2*>(p);
+    const u32x2 v = NT ? __builtin_nontemporal_load(reinterpret_cast<const u32x2*>(p)) : *reinterpret_cast<const u32x2*>(p);
     w[0] = v[0]; w[1] = v[1];
   } else {
     static_assert(NW_ == 1, "unsupported lane word count");
-    w[0] = *reinterpret_cast<const uint32_t*>(p);
+    w[0] = NT ? __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(p)) : *reinterpret_cast<const uint32_t*>(p);
   }
 }
 
@@ -715,7 +715,7 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_kernel(const GemmArgs a) {
 #pragma unroll
       for (int q = 0; q < S; ++q)
 #pragma unroll
-        for (int nf = 0; nf < NFW; ++nf) load_lane_words<WL>(bptr[nf] + (long)(t0 + q) * (4 * WL * 4), bs[q].w[nf]);
+        for (int nf = 0; nf < NFW; ++nf) load_lane_words<WL, true>(bptr[nf] + (long)(t0 + q) * (4 * WL * 4), bs[q].w[nf]);
       const int gi = (t0 * 4) >> a.gq_shift;
 #pragma unroll
       for (int nf = 0; nf < NFW; ++nf) {
@@ -730,7 +730,7 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_kernel(const GemmArgs a) {
 #pragma unroll
       for (int q = 0; q < S; ++q)
 #pragma unroll
-        for (int nf = 0; nf < NFW; ++nf) load_lane_words<WL>(bptr[nf] + (long)(t0 + q) * (4 * WL * 4), bs[q].w[nf]);
+        for (int nf = 0; nf < NFW; ++nf) load_lane_words<WL, true>(bptr[nf] + (long)(t0 + q) * (4 * WL * 4), bs[q].w[nf]);
 #pragma unroll
       for (int nf = 0; nf < NFW; ++nf) {
         const uint32_t sv = *reinterpret_cast<const uint32_t*>(Sp + (long)nrow[nf] * a.kg + (t0 >> 1));
@@ -746,7 +746,7 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_kernel(const GemmArgs a) {
 #pragma unroll
       for (int q = 0; q < S; ++q)
 #pragma unroll
-        for (int nf = 0; nf < NFW; ++nf) load_lane_words<WL>(bptr[nf] + (long)(t0 + q) * (4 * WL * 4), bs[q].w[nf]);
+        for (int nf = 0; nf < NFW; ++nf) load_lane_words<WL, true>(bptr[nf] + (long)(t0 + q) * (4 * WL * 4), bs[q].w[nf]);
 #pragma unroll
       for (int nf = 0; nf < NFW; ++nf) {
         const u32x2 sv = *reinterpret_cast<const u32x2*>(Sp + (long)nrow[nf] * a.kg + t0);
@@ -963,7 +963,7 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_decode_kernel(const GemmAr
     const int kidx = t * 4 + kb;
     int gi = 0;
     if (MODE != MD_NONE) gi = a.gq_shift >= 0 ? (kidx >> a.gq_shift) : (int)__umulhi((uint32_t)kidx, a.gq_magic);
-    load_lane_words<WL>(brow + (long)t * (4 * WL * 4), st.b.w[0]);
+    load_lane_words<WL, true>(brow + (long)t * (4 * WL * 4), st.b.w[0]);
     if (!wide) {
       if constexpr (MODE != MD_NONE) st.b.s[0] = Sp[srow + gi];
       if constexpr (MODE == MD_ZO || MODE == MD_ZR) st.b.z[0] = Zp[srow + gi];
@@ -1127,8 +1127,33 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_decode_kernel(const GemmAr
 // the issuing wave's own vmcnt.  Blocks of 4 k-steps: the block's activations (only the row groups below M), then its
 // metadata and weights, all in flight before any is used.
 // Same-call A/B against the direct-load member, uint4 g128 + zeros, 4096^2 (profiles/r02_ab_decode_lds.txt):
-// M=16 8.43 -> 6.66 us, M=12 7.8 -> 6.2, M=8 7.1 -> 5.95, M=3 6.2 -> 5.76; 3584x8192 M=16 14.4 -> 10.5; int2 x int8 M=16 5.68 -> 5.08.
+// M=16 8.43 -> 6.66 us, M=12 7.8 -> 6.2, M=8 7.1 -> 5.95, M=3 6.2 -> 5.76; 3584x8192 M=16 14.4 -> 10.5; int2 x int8 M=16 5.68 -> 5.08;
+// with non-temporal weight loads on top M=16 6.45, M=12 6.08, int2 x int8 4.87.
+// What bounds it (tools/decode_trace.hip, profiles/r02_decode_trace.txt): every workgroup reads ALL of A - 256 x 128 KiB
+// = 32 MiB through the L2s at M = 16 - and the LDS-DMA issue stalls for ~2.5 us on that; weights-first issue order
+// and hand-kept per-k-step vmcnt waits were tried and measured no better (the wave is through its DMA queue only
+// when everything else has long arrived).
 // ------------------------------------------------------------------------------------------
+// lab builds only (tools/decode_trace.hip, -DWQAA_TRACE): per-wave timestamps kept in registers, written through a.ws
+// after the last phase
+#ifdef WQAA_TRACE
+#define WQ_TRACE_DECL unsigned long long tr_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; const unsigned long long tr_real0_ = __builtin_amdgcn_s_memrealtime()
+#define WQ_TRACE(i) tr_[i] = __builtin_readcyclecounter()
+#define WQ_TRACE_IF(c, i) if (c) tr_[i] = __builtin_readcyclecounter()
+#define WQ_TRACE_DUMP(nw)                                                                                             \
+  if (lane == 0 && a.ws) {                                                                                             \
+    unsigned long long* d_ = reinterpret_cast<unsigned long long*>(a.ws) + ((long)blockIdx.x * (nw) + wave) * 16;      \
+    for (int i_ = 0; i_ < 8; ++i_) d_[i_] = tr_[i_];                                                                   \
+    d_[8] = tr_real0_;                                                                                                 \
+    d_[9] = __builtin_amdgcn_s_memrealtime();                                                                          \
+  }
+#else
+#define WQ_TRACE_DECL
+#define WQ_TRACE(i)
+#define WQ_TRACE_IF(c, i)
+#define WQ_TRACE_DUMP(nw)
+#endif
+
 template <class P>
 __global__ void __launch_bounds__(P::THREADS) wq_gemm_decode_lds_kernel(const GemmArgs a) {
   using T = typename P::T;
@@ -1147,6 +1172,8 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_decode_lds_kernel(const Ge
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  WQ_TRACE_DECL;
+  WQ_TRACE(0);
   const int fr = lane & 15, kb = lane >> 4;
   int blk = blockIdx.x;
   if ((gridDim.x & 7) == 0) blk = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
@@ -1190,7 +1217,7 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_decode_lds_kernel(const Ge
     const int kidx = t * 4 + kb;
     int gi = 0;
     if (MODE != MD_NONE) gi = a.gq_shift >= 0 ? (kidx >> a.gq_shift) : (int)__umulhi((uint32_t)kidx, a.gq_magic);
-    load_lane_words<WL>(brow + (long)t * (4 * WL * 4), b.w[0]);
+    load_lane_words<WL, true>(brow + (long)t * (4 * WL * 4), b.w[0]);
     if (!wide) {
       if constexpr (MODE != MD_NONE) b.s[0] = Sp[srow + gi];
       if constexpr (MODE == MD_ZO || MODE == MD_ZR) b.z[0] = Zp[srow + gi];
@@ -1300,6 +1327,7 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_decode_lds_kernel(const Ge
       const int t = t_lo + s0 + i;
       w_load(t < nsteps ? t : last, bs[i]);
     }
+    WQ_TRACE_IF(s0 == 0, 1);
 #pragma unroll
     for (int i = 0; i < PF; ++i) {
       if (wide) {
@@ -1307,20 +1335,29 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_decode_lds_kernel(const Ge
         bs[i].z[0] = (gz[i >> 1] >> (16 * (i & 1))) & 0xFFFFu;
       }
       if (s0 + i < my_steps) compute(bs[i], i);
+      WQ_TRACE_IF(s0 == 0 && i == 0, 2);
+      WQ_TRACE_IF(s0 == 0 && i == PF - 2, 3);
     }
     // the region is rewritten by the next block's DMA: every ds_read of this block must have returned
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   }
 
   // ---- meet in LDS: slot [wave][lane] (its own region, after the activation ones), summed in wave order by wave 0 ----
+  WQ_TRACE(4);
   red[wave * 64 + lane] = acc;
   __syncthreads();
-  if (wave != 0) return;
+  WQ_TRACE(5);
+  if (wave != 0) {
+    WQ_TRACE_DUMP(NW);
+    return;
+  }
   acc_t sum = red[lane];
 #pragma unroll
   for (int w = 1; w < NW; ++w) sum += red[w * 64 + lane];
   const int nb = n0 + kb * 4;
   if (nb < a.N && fr < a.M) store_quad<P>(a, sum, fr, nb);
+  WQ_TRACE(6);
+  WQ_TRACE_DUMP(NW);
 }
 
 // ------------------------------------------------------------------------------------------

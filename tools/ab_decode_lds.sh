@@ -1,7 +1,7 @@
 #!/bin/bash
 # A/B in ONE call: M <= 16 decode-batch member, activations as fragment-shaped global loads (201) vs through LDS-DMA (211)
 cd ${GRAFT_REPO_ROOT:-.}
-timeout 900 python -m pytest tests/test_gemm_gpu.py -q -x -k "decode" 2>&1 | tail -5
+timeout 900 python -m pytest tests/test_gemm_gpu.py tests/test_te_golden.py tests/test_sweep_gpu.py -q -x 2>&1 | tail -5
 for shape in "16 4096 4096" "12 4096 4096" "8 4096 4096" "3 4096 4096" "16 3584 8192"; do
   for rep in 1 2; do
     for v in 0 1; do
