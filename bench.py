@@ -317,7 +317,9 @@ def pmc_traffic():
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc*.json")), reverse=True):
         try:
             with open(path) as f:
-                return json.load(f).get("gemv_hbm_bytes_per_launch")
+                v = json.load(f).get("gemv_hbm_bytes_per_launch")
+            if v is not None:
+                return v
         except Exception:
             continue
     return None

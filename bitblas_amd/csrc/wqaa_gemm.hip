@@ -170,15 +170,21 @@ static int gemm_choose(const wqaa_matmul_desc& d, int m, GemmChoice* c) {
   // 7.6 vs 9.2 us, M=8 8.2 vs 9.3, M=16 9.5 vs 9.9, M=32 13.2 vs 11.6; 11008x4096 M=8 18.3 vs 16.2;
   // 4096x11008 M=8 15.2 vs 17.8; int2 x int8 4096^2 M=5 5.7 vs 7.3.
   c->decode = 0;
-  // (with the 8-byte metadata loads in both members: 4096^2 M=3 6.3 vs 9.1 us, M=8 7.2 vs 9.1; 8192^2 M=3 18.0 vs
-  // 17.1, M=8 22.4 vs 17.7 - beyond ~1.5 fragments per CU the skinny member takes over)
-  // M = 9...16 still fits the one 16-row MFMA fragment; there the member pays only when the grid is close to one
-  // fragment per CU (same-call A/B, 4096^2 uint4+zeros: M=10 9.2 -> 7.4 us, M=12 9.3 -> 7.8, M=16 9.6 -> 8.5;
-  // int2 x int8 M=16 7.3 -> 5.7; but N=5120: 12.7 -> 21.6 and N=2048, K=8192: 10.3 -> 13.8, so it is fenced)
+  // With the activations through LDS-DMA (member 211) the one-launch member wins whenever the 16-row weight fragments
+  // fill whole rounds of the chip - one 136 KiB workgroup per CU - and loses the tail of a partial round to the
+  // skinny member, whose small workgroups overlap.  Same-call A/B, uint4 g128 + zeros, member vs skinny + reduce
+  // (profiles/r02_ab_decode_fence.txt): M=16 N=2048 6.0 vs 7.4 us, N=3072 6.3 vs 8.7, N=4096 6.4 vs 9.0, N=5120 (1.25
+  // rounds) 11.0 vs 10.4, N=8192 (2 rounds) 11.6 vs 12.6, N=11008 (2.7 rounds) 16.7 vs 15.1; 4096x11008 16.5 vs 19.7;
+  // M=8 N=6144 (1.5 rounds) 9.8 vs 10.2, N=8192 10.4 vs 11.3, N=11008 14.5 vs 13.5, 4096x11008 12.1 vs 18.8;
+  // M=4 8192^2 15.9 vs 17.3.
   const int frags = (d.N + 15) / 16;
   int decode_max_m = 16;
   if (const char* f = getenv("WQAA_GEMM_DECODE_MAXM")) decode_max_m = atoi(f);   // tuning aid
-  const bool decode_fits = m <= 8 ? frags <= cus_ + cus_ / 2 : (frags <= cus_ && 4 * frags >= 3 * cus_);
+  // (the direct-load member, which only packed-int4 activations still use: M <= 8 up to 1.5 rounds, M = 9..16 between
+  // 0.75 and 1 round - the round-1 table above)
+  bool decode_fits = c->at != AT_I4 ? (frags <= cus_ || frags == 2 * cus_ || (m <= 8 && frags <= 2 * cus_))
+                                    : (m <= 8 ? frags <= cus_ + cus_ / 2 : (frags <= cus_ && 4 * frags >= 3 * cus_));
+  if (const char* f = getenv("WQAA_GEMM_DECODE_FORCE")) decode_fits = atoi(f) != 0;   // tuning aid
   if (m <= decode_max_m && m <= 16 && c->mf == 1 && decode_fits) {
     const char* dflag = getenv("WQAA_GEMM_DECODE");
     if (!dflag || atoi(dflag) != 0) c->decode = 1;

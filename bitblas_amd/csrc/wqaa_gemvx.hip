@@ -21,6 +21,15 @@ bool gemvx_eligible(const wqaa_matmul_desc& d, int m) {
   if (d.K % E != 0) return false;
   const int g = d.group_size <= 0 ? d.K : d.group_size;
   if (d.K % g != 0 || (d.with_scaling && g % E != 0)) return false;
+  // Long K with enough rows to fill the chip unsplit: the rounding members win (4096x11008 int4: 8.15 vs 8.5-8.8 us,
+  // same-call A/B profiles/r02_ab_gemvx.txt - staging the 22 KB activation row and its chunk sums before the first dot
+  // costs 1.2 us of the launch there, profiles/r02_abl_gemvx.txt).  Either numerics meets the contract when
+  // strict_reference = 0, so the faster member is taken.
+  {
+    const int cus = device_info().ok ? device_info().cus : 256;
+    const long wbytes = (long)d.N * d.K * d.w_bits / 8;
+    if (d.K > 8192 && wbytes < (48l << 20) && (d.N + 1) / 2 >= 8 * cus) return false;
+  }
   // the switch is a plan-time one like every tuning variable (ChoiceMemo): re-read when wqaa_select bumps the epoch
   static thread_local unsigned seen_epoch = 0;
   static thread_local bool enabled = true;

@@ -105,18 +105,18 @@ def test_two_streams_do_not_share_partial_sums():
 
 
 def test_graph_captured_before_the_scratch_grew_still_replays():
-    small_case, mm_s, ops_s = _prepared(16, 256, 4096, 2)
+    small_case, mm_s, ops_s = _prepared(24, 256, 4096, 2)   # M = 24: the skinny split-K member (M <= 16 is the one-launch decode member)
     big_case, mm_b, ops_b = _prepared(64, 8192, 8192, 3)
-    assert mm_s.plans[16]["split_k"] > 1, mm_s.plans[16]
+    assert mm_s.plans[24]["split_k"] > 1, mm_s.plans[24]
     s = torch.cuda.Stream()
-    out_s = torch.empty((16, 256), dtype=torch.float16, device="cuda")
+    out_s = torch.empty((24, 256), dtype=torch.float16, device="cuda")
     out_b = torch.empty((64, 8192), dtype=torch.float16, device="cuda")
     with torch.cuda.stream(s):
-        _run(mm_s, ops_s, out_s, s, 16)          # first call outside capture: the stream's slab exists
+        _run(mm_s, ops_s, out_s, s, 24)          # first call outside capture: the stream's slab exists
         s.synchronize()
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g, stream=s):
-            _run(mm_s, ops_s, out_s, s, 16)
+            _run(mm_s, ops_s, out_s, s, 24)
         g.replay()
         s.synchronize()
         want_s = oracle_output(small_case)

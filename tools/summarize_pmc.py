@@ -21,7 +21,7 @@ for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
             if row.get("Counter_Name") != ctr:
                 continue
             name = row.get("Kernel_Name", "")
-            if "wq_gemv_kernel" not in name:
+            if "wq_gemv_kernel" not in name and "wq_gemvx_kernel" not in name:
                 continue
             key = (row.get("Grid_Size"), row.get("LDS_Block_Size"))
             vals.setdefault(key, []).append(float(row["Counter_Value"]))
