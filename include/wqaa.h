@@ -93,7 +93,11 @@ typedef struct wqaa_matmul_desc {
   int32_t zeros_mode;    /* wqaa_zeros_mode; Zeros (N,K/g) A_dtype, or QZeros (K/g, N*bits/8) int8 */
   int32_t with_bias;     /* Bias (N,) added after the cast to out_dtype */
   int32_t w_layout;      /* wqaa_layout   */
-  int32_t strict_reference; /* 1: reproduce the reference's e4m3->f16 bit trick (0 -> 2^-7); 0: IEEE */
+  int32_t strict_reference; /* 1: the reference's definition to the letter - dequantised weight rounded to A_dtype
+                               per element (TE graph, matmul_dequantize_impl.py:391-459), e4m3->f16 bit trick
+                               (0 -> 2^-7, quantization.py:169-176), "uint8" weights read through the signed storage
+                               type; 0: members that skip the intermediate rounding (M <= 2 exact-product GEMV) and
+                               decode e4m3 per IEEE may be taken - within the 1e-3 contract, closer to the real product */
   int32_t reserved[3];
 } wqaa_matmul_desc;
 
