@@ -247,7 +247,9 @@ static int gemm_choose(const wqaa_matmul_desc& d, int m, GemmChoice* c) {
   const int tiles = c->tiles_m * c->tiles_n;
   int ks = 1;
   while (tiles * ks < cus && ks * 2 <= 16 && nsteps / (ks * 2) >= 1) ks *= 2;
+  if (d.k_split_hint > 1) ks = d.k_split_hint;             // the caller's MatmulConfigWithSplitK.k_split
   if (const char* f = getenv("WQAA_GEMM_KSPLIT")) ks = atoi(f);
+  if (ks > 16) ks = 16;                                     // partial sums cost 4 B per output element per slice
   if (ks > nsteps) ks = nsteps;
   if (ks < 1) ks = 1;
   c->ksplit = ks;

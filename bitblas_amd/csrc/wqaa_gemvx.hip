@@ -87,6 +87,7 @@ static int gemvx_choose(const wqaa_matmul_desc& d, int m, GemvxChoice* c) {
   c->R = sc2 >= 0.9 * sc1 ? 2 : 1;
   if (const char* f = getenv("WQAA_GEMVX_R")) c->R = atoi(f) == 1 ? 1 : 2;
   int kw = c->R == 2 ? k2 : k1;
+  if (d.k_split_hint > 1) kw = d.k_split_hint;                                          // the caller's k_split
   if (const char* f = getenv("WQAA_GEMVX_KW")) kw = atoi(f) > 0 ? atoi(f) : 1;          // tuning aid
   if (kw > c->nsteps) kw = c->nsteps;
   if (kw > 16) kw = 16;

@@ -52,7 +52,7 @@ class MatmulDesc(ctypes.Structure):
         ("out_dtype", ctypes.c_int32), ("group_size", ctypes.c_int32),
         ("with_scaling", ctypes.c_int32), ("zeros_mode", ctypes.c_int32),
         ("with_bias", ctypes.c_int32), ("w_layout", ctypes.c_int32),
-        ("strict_reference", ctypes.c_int32), ("reserved", ctypes.c_int32 * 3),
+        ("strict_reference", ctypes.c_int32), ("k_split_hint", ctypes.c_int32), ("reserved", ctypes.c_int32 * 2),
     ]
 
 
@@ -152,7 +152,7 @@ def check(status: int) -> None:
 
 
 def make_desc(*, N, K, a_dtype, w_format, w_bits, out_dtype, group_size=-1, with_scaling=False,
-              zeros_mode=Z_NONE, with_bias=False, w_layout=LAYOUT_PLAIN, strict_reference=True) -> MatmulDesc:
+              zeros_mode=Z_NONE, with_bias=False, w_layout=LAYOUT_PLAIN, strict_reference=True, k_split_hint=0) -> MatmulDesc:
     d = MatmulDesc()
     d.struct_size = ctypes.sizeof(MatmulDesc)
     d.N, d.K = int(N), int(K)
@@ -163,6 +163,7 @@ def make_desc(*, N, K, a_dtype, w_format, w_bits, out_dtype, group_size=-1, with
     d.with_bias = int(bool(with_bias))
     d.w_layout = int(w_layout)
     d.strict_reference = int(bool(strict_reference))
+    d.k_split_hint = max(0, int(k_split_hint or 0))
     return d
 
 

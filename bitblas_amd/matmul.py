@@ -404,7 +404,7 @@ class Matmul:
             out_dtype=out_code, group_size=config.group_size, with_scaling=config.with_scaling,
             zeros_mode=zeros_mode, with_bias=config.with_bias,
             w_layout=_lib.LAYOUT_LOP3 if (config.fast_decoding and not native) else _lib.LAYOUT_PLAIN,
-            strict_reference=strict_reference)
+            strict_reference=strict_reference, k_split_hint=getattr(config, "k_split", 0))
         static_m = config.M if isinstance(config.M, int) else 1
         self.lib = _lib.BoundLib(self._desc, has_lut=self.source_format == "nf",
                                  dynamic_m=self.dynamic_range is not None, static_m=static_m)
@@ -634,10 +634,12 @@ class MatmulWithSplitK(Matmul):
     """`bitblas.MatmulWithSplitK` (ops/general_matmul_splitk.py:26-199).
 
     Upstream launches a kernel that writes `k_split` partial products in out_dtype and reduces them with
-    `torch.sum` (:168-186).  Here split-K is the tile selector's own decision per (M, N, K) - fp32 / int32
-    partial sums in a library-owned scratch, one rounding at the end - so `k_split` is accepted as a
-    hint and the result is at least as accurate as upstream's sum of rounded partials.  Weight layout,
-    arguments and return value are those of `Matmul`."""
+    `torch.sum` (:168-186).  Here `k_split` travels to the tile selector as `wqaa_matmul_desc.k_split_hint`: it sets
+    the K split across the waves of a workgroup of the M <= 2 exact-product GEMV (`strict_reference=False`) and the
+    split-K count of the pipelined MFMA members; the one-launch decode member (M <= 16) and the skinny member
+    (M <= 64) split K structurally and keep their own count - `plans[m]["split_k"]` says what was taken.  Partial
+    sums are fp32 / int32 with one rounding at the end, so the result is at least as accurate as upstream's sum of
+    rounded partials.  Weight layout, arguments and return value are those of `Matmul`."""
 
     @property
     def k_split(self):

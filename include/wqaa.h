@@ -98,7 +98,13 @@ typedef struct wqaa_matmul_desc {
                                (0 -> 2^-7, quantization.py:169-176), "uint8" weights read through the signed storage
                                type; 0: members that skip the intermediate rounding (M <= 2 exact-product GEMV) and
                                decode e4m3 per IEEE may be taken - within the 1e-3 contract, closer to the real product */
-  int32_t reserved[3];
+  int32_t k_split_hint;  /* 0 / 1: the selector decides.  > 1: the caller's split-K request, as `MatmulConfigWithSplitK.k_split`
+                            (ops/general_matmul_splitk.py:21-23).  Honoured where K is split by a free parameter: the
+                            K split across the waves of a workgroup of the M <= 2 exact-product GEMV, and the split-K
+                            count of the pipelined MFMA members (clamped to the k-steps available).  Members whose split is
+                            structural (one-launch decode member: 8 waves; skinny member: 4 k-steps per workgroup) keep it;
+                            wqaa_plan.split_k reports what was taken.  (was reserved[0], must-be-zero: ABI compatible) */
+  int32_t reserved[2];
 } wqaa_matmul_desc;
 
 /* what the selector chose for (desc, m): reported for tests, rocprof attribution and the cache */

@@ -352,3 +352,19 @@ def test_split_k_operator_matches_matmul():
     got_sk, mm_sk = hip_output(case, matmul=bitblas.MatmulWithSplitK(cfg, enable_tuning=False))
     assert np.array_equal(got, got_sk)
     assert_fp_parity(got_sk, oracle_output(case))
+
+
+@pytest.mark.parametrize("M,ks", [(128, 2), (128, 5), (200, 3), (1, 2), (2, 4)])
+def test_k_split_request_is_honoured_and_exact_enough(M, ks):
+    """the caller's k_split sets the split-K count of the pipelined members / the in-workgroup K split of the M <= 2
+    exact-product GEMV; the result meets the same parity bound whatever the split"""
+    import bitblas_amd as bitblas
+    K = 4096 if M > 2 else 16384          # the 4-bit GEMV steps are 4096 deep
+    case = make_case(M, 1024, K, W_dtype="uint4", group_size=128, with_scaling=True, with_zeros=True, scale_mul=0.05, seed=ks)
+    c = case["config"]
+    cfg = bitblas.MatmulConfigWithSplitK(M=M, N=1024, K=K, A_dtype="float16", W_dtype="uint4", group_size=128,
+                                         with_scaling=True, with_zeros=True, zeros_mode=c.zeros_mode, k_split=ks)
+    mm = bitblas.MatmulWithSplitK(cfg, enable_tuning=False, strict_reference=M > 2)
+    got, _ = hip_output(case, matmul=mm)
+    assert mm.plans[M]["split_k"] == ks, mm.plans[M]
+    assert_fp_parity(got, oracle_output(case), rtol=1e-3, atol_frac=1.5e-3 if M <= 2 else 1e-3)

@@ -159,6 +159,29 @@ def test_split_k_operator_mirror():
     assert op.retrieve_weight_shape() == [1024, 2048]
 
 
+def test_k_split_reaches_the_selector():
+    """`MatmulConfigWithSplitK.k_split` (ops/general_matmul_splitk.py:21-23) travels as `wqaa_matmul_desc.k_split_hint`:
+    it sets the split of the members whose K split is a free parameter and is reported back in the plan"""
+    kw = dict(N=4096, K=4096, A_dtype="float16", W_dtype="int4", group_size=128, with_scaling=True)
+    # pipelined MFMA member (M = 128): the split-K count
+    for ks in (2, 8):
+        op = bitblas.MatmulWithSplitK(bitblas.MatmulConfigWithSplitK(M=128, k_split=ks, **kw), enable_tuning=False)
+        assert op.plans[128]["split_k"] == ks, op.plans[128]
+    # clamped to the k-steps there are (K = 512: four 128-deep steps) and to 16
+    op = bitblas.MatmulWithSplitK(bitblas.MatmulConfigWithSplitK(M=128, N=4096, K=512, A_dtype="float16", W_dtype="int4",
+                                                                 group_size=128, with_scaling=True, k_split=64), enable_tuning=False)
+    assert op.plans[128]["split_k"] == 4
+    # the plain operator decides for itself
+    assert bitblas.Matmul(bitblas.MatmulConfig(M=128, **kw), enable_tuning=False).plans[128]["split_k"] == 4
+    # M = 1 exact-product GEMV: the K split across the waves of a workgroup
+    kw.update(N=1024, K=16384)          # four 4096-deep steps of the 4-bit GEMV
+    op = bitblas.MatmulWithSplitK(bitblas.MatmulConfigWithSplitK(M=1, k_split=2, **kw), enable_tuning=False, strict_reference=False)
+    assert op.plans[1]["split_k"] == 2 and op.plans[1]["name"].endswith("k2"), op.plans[1]
+    # structural splits (one-launch decode member at M = 16) keep their own
+    op = bitblas.MatmulWithSplitK(bitblas.MatmulConfigWithSplitK(M=16, k_split=4, **kw), enable_tuning=False)
+    assert op.plans[16]["name"].endswith("xdl")
+
+
 @pytest.mark.parametrize("bits", [4, 2])
 def test_gptq_repack_against_reference_run_vectors(bits):
     """tests/golden/gptq_golden.npz: what the reference's own unpack_qweight / unpack_qzeros[_v2] and
