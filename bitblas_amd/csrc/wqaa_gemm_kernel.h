@@ -65,6 +65,26 @@ struct GemmArgs {
   void* ws;           //      writes fp32 / int32 partial sums to ws[s][M][N]; a second kernel reduces
 };
 
+// lab builds only (tools/decode_trace.hip, -DWQAA_TRACE): per-wave timestamps kept in registers, written through a.lut
+// (unused by the integer formats the harness instantiates) after the last phase
+#ifdef WQAA_TRACE
+#define WQ_TRACE_DECL unsigned long long tr_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; const unsigned long long tr_real0_ = __builtin_amdgcn_s_memrealtime()
+#define WQ_TRACE(i) tr_[i] = __builtin_readcyclecounter()
+#define WQ_TRACE_IF(c, i) if (c) tr_[i] = __builtin_readcyclecounter()
+#define WQ_TRACE_DUMP(nw)                                                                                             \
+  if (lane == 0 && a.lut) {                                                                                             \
+    unsigned long long* d_ = reinterpret_cast<unsigned long long*>(const_cast<void*>(a.lut)) + ((long)blockIdx.x * (nw) + wave) * 16;      \
+    for (int i_ = 0; i_ < 8; ++i_) d_[i_] = tr_[i_];                                                                   \
+    d_[8] = tr_real0_;                                                                                                 \
+    d_[9] = __builtin_amdgcn_s_memrealtime();                                                                          \
+  }
+#else
+#define WQ_TRACE_DECL
+#define WQ_TRACE(i)
+#define WQ_TRACE_IF(c, i)
+#define WQ_TRACE_DUMP(nw)
+#endif
+
 // ------------------------------------------------------------------------------------------
 // policy: one k-step is KS = 4 * KL deep; a lane owns KL consecutive k of one weight row
 // ------------------------------------------------------------------------------------------
@@ -420,6 +440,8 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_kernel(const GemmArgs a) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  WQ_TRACE_DECL;
+  WQ_TRACE(0);
   const int fr = lane & 15;          // fragment row (weight n / activation m)
   const int kb = lane >> 4;          // k-block of the lane
 
@@ -795,8 +817,10 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_kernel(const GemmArgs a) {
       a_load(t_begin);
       w_load(t_begin, bcur);
       g_load(tb4, gs_cur, gz_cur);
+      WQ_TRACE(1);
       a_store(t_begin & 1);
       __syncthreads();
+      WQ_TRACE(2);
       for (int t4 = tb4; t4 < nsteps; t4 += 4) {
         const int nb = t4 + 4 < nsteps ? t4 + 4 : t4;      // next block (the last one reloads itself)
         g_load(nb, gs_nxt, gz_nxt);
@@ -815,6 +839,7 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_kernel(const GemmArgs a) {
           compute_step(bcur, smem_raw + (t & 1) * (P::BM * P::ROW_BYTES));
           a_store((t + 1) & 1);
           __syncthreads();
+          WQ_TRACE_IF(t == t_begin, 3);
           bcur = bnext;
         }
 #pragma unroll
@@ -839,6 +864,7 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_kernel(const GemmArgs a) {
   }
 
   // ---- epilogue: D[i][col]: weight row n = nbase + kb * 4 + i, activation row m = mbase + fr ----
+  WQ_TRACE(4);
   if (a.ksplit > 1) {
     acc_t* ws = reinterpret_cast<acc_t*>(a.ws);
 #pragma unroll
@@ -852,6 +878,8 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_kernel(const GemmArgs a) {
         ws[(((long)split * a.M + m) * a.N + nb) >> 2] = acc[mf][nf];
       }
     }
+    WQ_TRACE(5);
+    WQ_TRACE_DUMP(P::NWAVES);
     return;
   }
 #pragma unroll
@@ -1134,26 +1162,6 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_decode_kernel(const GemmAr
 // and hand-kept per-k-step vmcnt waits were tried and measured no better (the wave is through its DMA queue only
 // when everything else has long arrived).
 // ------------------------------------------------------------------------------------------
-// lab builds only (tools/decode_trace.hip, -DWQAA_TRACE): per-wave timestamps kept in registers, written through a.ws
-// after the last phase
-#ifdef WQAA_TRACE
-#define WQ_TRACE_DECL unsigned long long tr_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; const unsigned long long tr_real0_ = __builtin_amdgcn_s_memrealtime()
-#define WQ_TRACE(i) tr_[i] = __builtin_readcyclecounter()
-#define WQ_TRACE_IF(c, i) if (c) tr_[i] = __builtin_readcyclecounter()
-#define WQ_TRACE_DUMP(nw)                                                                                             \
-  if (lane == 0 && a.ws) {                                                                                             \
-    unsigned long long* d_ = reinterpret_cast<unsigned long long*>(a.ws) + ((long)blockIdx.x * (nw) + wave) * 16;      \
-    for (int i_ = 0; i_ < 8; ++i_) d_[i_] = tr_[i_];                                                                   \
-    d_[8] = tr_real0_;                                                                                                 \
-    d_[9] = __builtin_amdgcn_s_memrealtime();                                                                          \
-  }
-#else
-#define WQ_TRACE_DECL
-#define WQ_TRACE(i)
-#define WQ_TRACE_IF(c, i)
-#define WQ_TRACE_DUMP(nw)
-#endif
-
 template <class P>
 __global__ void __launch_bounds__(P::THREADS) wq_gemm_decode_lds_kernel(const GemmArgs a) {
   using T = typename P::T;

@@ -15,10 +15,14 @@ using namespace wqaa;
 
 int main(int argc, char** argv) {
   const int M = argc > 1 ? atoi(argv[1]) : 16, N = argc > 2 ? atoi(argv[2]) : 4096, K = argc > 3 ? atoi(argv[3]) : 4096;
+  // 4th argument > 0: the pipelined 64-row member (8-byte metadata form, plan suffix xw) with that split-K count
+  const int ksplit = argc > 4 ? atoi(argv[4]) : 0;
   const int launches = 64, g = 128;
-  using P = GemmPolicy<DK_INT4, LAYOUT_LOP3, AT_F16, MD_ZO, 0, 1, 8, 1>;
-  auto fn = wq_gemm_decode_lds_kernel<P>;
-  const int lds = 8 * 4 * 16 * 256 + 8 * 64 * 16;
+  using PD = GemmPolicy<DK_INT4, LAYOUT_LOP3, AT_F16, MD_ZO, 0, 1, 8, 1>;
+  using PP = GemmPolicy<DK_INT4, LAYOUT_LOP3, AT_F16, MD_ZO, 0, 4, 4, 2, 0, true>;
+  void (*fn)(const GemmArgs) = ksplit > 0 ? wq_gemm_kernel<PP> : wq_gemm_decode_lds_kernel<PD>;
+  const int lds = ksplit > 0 ? 2 * 64 * 256 : 8 * 4 * 16 * 256 + 8 * 64 * 16;
+  const int nwaves = ksplit > 0 ? 4 : 8;
   CK(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   const size_t wbytes = (size_t)N * K / 2, sbytes = (size_t)N * (K / g) * 2;
   const int nbuf = (int)std::max<size_t>(2, (640ull << 20) / wbytes);
@@ -35,8 +39,11 @@ int main(int argc, char** argv) {
   void *A, *C;
   CK(hipMalloc(&A, ha.size() * 2)); CK(hipMemcpy(A, ha.data(), ha.size() * 2, hipMemcpyHostToDevice));
   CK(hipMalloc(&C, (size_t)M * N * 2));
-  const int grid = (N + 15) / 16;
-  const size_t trace_words = (size_t)grid * 8 * 16;
+  const int tiles_m = ksplit > 0 ? (M + 63) / 64 : 1, tiles_n = ksplit > 0 ? (N + 127) / 128 : (N + 15) / 16;
+  const int grid = tiles_m * tiles_n * (ksplit > 0 ? ksplit : 1);
+  const size_t trace_words = (size_t)grid * nwaves * 16;
+  void* WS = nullptr;
+  if (ksplit > 1) CK(hipMalloc(&WS, (size_t)ksplit * M * N * 4));
   unsigned long long* T;
   CK(hipMalloc(&T, trace_words * 8 * launches)); CK(hipMemset(T, 0, trace_words * 8 * launches));
   hipStream_t st; CK(hipStreamCreate(&st));
@@ -47,9 +54,10 @@ int main(int argc, char** argv) {
       GemmArgs a{};
       a.A = A; a.B = W[l % nbuf]; a.scale = S[l % nbuf]; a.zeros = Z[l % nbuf]; a.C = C;
       a.M = M; a.N = N; a.K = K; a.kg = K / g; a.gq_shift = 2; a.row_bytes = K / 2; a.out_dtype = 0; a.is_signed = 0;
-      a.tiles_m = 1; a.tiles_n = grid; a.nsteps = K / 128; a.group_m = 1; a.ksplit = 1; a.epi_tensor = 1.f;
-      a.ws = T + (size_t)l * trace_words;
-      hipLaunchKernelGGL(fn, dim3(grid), dim3(512), lds, st, a);
+      a.tiles_m = tiles_m; a.tiles_n = tiles_n; a.nsteps = K / 128; a.group_m = 1; a.ksplit = ksplit > 0 ? ksplit : 1; a.epi_tensor = 1.f;
+      a.ws = WS;
+      a.lut = T + (size_t)l * trace_words;
+      hipLaunchKernelGGL(fn, dim3(grid), dim3(64 * nwaves), lds, st, a);
     }
     CK(hipEventRecord(e1, st));
     CK(hipStreamSynchronize(st));
@@ -61,7 +69,7 @@ int main(int argc, char** argv) {
   for (int l : {launches - 3, launches - 2, launches - 1}) {
     const unsigned long long* d = t.data() + (size_t)l * trace_words;
     const unsigned long long* dprev = t.data() + (size_t)(l - 1) * trace_words;
-    const int nw = grid * 8;
+    const int nw = grid * nwaves;
     unsigned long long r0 = ~0ull, r1 = 0, p1 = 0;
     for (int w = 0; w < nw; ++w) { r0 = std::min(r0, d[w * 16 + 8]); r1 = std::max(r1, d[w * 16 + 9]); p1 = std::max(p1, dprev[w * 16 + 9]); }
     printf("launch %d: first wave start -> last wave end %.2f us; previous launch's last end -> this first start %.2f us\n", l, (r1 - r0) / 100.0,
@@ -75,6 +83,15 @@ int main(int argc, char** argv) {
     stat("wave start since first start", [&](const unsigned long long* x) { return (double)(x[8] - r0); }, 0.01, "us");
     stat("wave end since first start", [&](const unsigned long long* x) { return (double)(x[9] - r0); }, 0.01, "us");
     stat("wave lifetime", [&](const unsigned long long* x) { return (double)(x[9] - x[8]); }, 0.01, "us");
+    if (ksplit > 0) {
+      stat("entry -> first loads issued", [&](const unsigned long long* x) { return (double)(x[1] - x[0]); }, 1.0, "clk");
+      stat("-> first tile in LDS (barrier)", [&](const unsigned long long* x) { return (double)(x[2] - x[1]); }, 1.0, "clk");
+      stat("-> first k-step done (barrier)", [&](const unsigned long long* x) { return (double)(x[3] - x[2]); }, 1.0, "clk");
+      stat("-> all k-steps done", [&](const unsigned long long* x) { return (double)(x[4] - x[3]); }, 1.0, "clk");
+      stat("-> partial sums stored (issued)", [&](const unsigned long long* x) { return (double)(x[5] - x[4]); }, 1.0, "clk");
+      stat("entry -> stores issued", [&](const unsigned long long* x) { return (double)(x[5] - x[0]); }, 1.0, "clk");
+      continue;
+    }
     stat("entry -> loads issued", [&](const unsigned long long* x) { return (double)(x[1] - x[0]); }, 1.0, "clk");
     stat("loads issued -> k-step 0 done", [&](const unsigned long long* x) { return (double)(x[2] - x[1]); }, 1.0, "clk");
     stat("k-step 0 done -> k-step 2 done", [&](const unsigned long long* x) { return (double)(x[3] - x[2]); }, 1.0, "clk");
