@@ -191,6 +191,8 @@ int gemvx_launch(const wqaa_matmul_desc& d, const void* A, const void* B, const 
   a.flip = (is_signed && c.bits == 1) ? 0xFFFFFFFFu : 0u;
   a.zq_row_bytes = d.N * c.bits / 8;
   a.n_rgb = c.n_rgb;
+  a.slots = c.nw / c.kw;
+  a.kw_magic = (65536u + (uint32_t)c.kw - 1u) / (uint32_t)c.kw;
   void* params[] = {&a};
   dim3 grid(c.grid, 1, 1), block(c.nw * 64, 1, 1);
   hipError_t e;

@@ -56,6 +56,8 @@ struct GemvxArgs {
   uint32_t flip;      // int1 signed: ~w
   int zq_row_bytes;
   int n_rgb;          // row-group blocks: ceil(ceil(N / R) / (waves / kw))
+  int slots;          // waves / kw: row groups a workgroup works on at a time
+  uint32_t kw_magic;  // ceil(2^16 / kw): x / kw == (x * kw_magic) >> 16 for x < 4096 (no integer division in the prologue)
 };
 
 // ABL_: ablation bits for tools/ (lab members only, never selected by the library): 1 = loads consumed by one XOR
@@ -97,12 +99,18 @@ __global__ void __launch_bounds__(1024) wq_gemvx_kernel(const GemvxArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nthreads = blockDim.x;
   const int NW = nthreads >> 6;
+  // The prologue is a latency chain in front of the first load (kernel-argument fetch -> address arithmetic -> issue)
+  // that nothing overlaps with: fetch every argument it needs in ONE scalar round trip (the compiler otherwise fetches
+  // them where first used, three dependent s_load waits before the weight loads), and keep integer divisions out of
+  // it (the host passes slots and a reciprocal of kw).
+  asm volatile("" ::"s"(a.A), "s"(a.B), "s"(a.scale), "s"(a.zeros), "s"(a.N), "s"(a.K), "s"(a.kg), "s"(a.gq_shift), "s"(a.cpr),
+               "s"(a.nsteps), "s"(a.kw), "s"(a.row_bytes), "s"(a.n_rgb), "s"(a.slots), "s"(a.kw_magic), "s"(a.m));
   const int kw = a.kw;
-  const int slots = NW / kw;                     // row groups the workgroup works on at a time
-  const int rgl = wave / kw, kpart = wave - rgl * kw;
+  const int slots = a.slots;                     // row groups the workgroup works on at a time
+  const int rgl = (int)(((uint32_t)wave * a.kw_magic) >> 16), kpart = wave - rgl * kw;
   const int nsteps = a.nsteps;
   const int ncp = nsteps * D;                    // chunk slots (zero activations beyond nc)
-  const int nmy = (nsteps - kpart + kw - 1) / kw;   // steps of a row group that fall to this wave (>= 1: kw <= nsteps)
+  const int nmy = (int)(((uint32_t)(nsteps - kpart + kw - 1) * a.kw_magic) >> 16);   // steps of a row group that fall to this wave (>= 1: kw <= nsteps)
   // LDS: activation pieces [mi][chunk][piece][lane] (16 B), chunk sums [mi][chunk][lane] (4 partials, 16 B), K-split partials
   u32x4* a_lds = reinterpret_cast<u32x4*>(smem_raw);
   float* sa_lds = reinterpret_cast<float*>(a_lds + (long)MB * ncp * PIECES * 64);
@@ -119,7 +127,9 @@ __global__ void __launch_bounds__(1024) wq_gemvx_kernel(const GemvxArgs a) {
   // (many small workgroups and the hardware dispatcher balance better than one persistent workgroup per CU: measured)
   int blk = blockIdx.x;
   if ((gridDim.x & 7) == 0) blk = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
-  const int iters = blk < a.n_rgb ? (a.n_rgb - blk + (int)gridDim.x - 1) / (int)gridDim.x : 0;   // uniform over the workgroup
+  int iters;                                                   // uniform over the workgroup
+  if ((int)gridDim.x >= a.n_rgb) iters = blk < a.n_rgb ? 1 : 0;        // the usual case: one block per workgroup, no division
+  else iters = blk < a.n_rgb ? (a.n_rgb - blk + (int)gridDim.x - 1) / (int)gridDim.x : 0;
   const int total = iters * nmy;                               // (row group, step) positions of this wave
 
   struct Stage {
@@ -158,8 +168,8 @@ __global__ void __launch_bounds__(1024) wq_gemvx_kernel(const GemvxArgs a) {
   auto item_src = [&](int idx, bool& valid) -> const u32x4* {
     const int l = idx & 63;
     const int u = (idx >> 6) & 3;
-    const int c = (idx >> 8) % ncp;
-    const int mi = (idx >> 8) / ncp;
+    int c = idx >> 8, mi = 0;                      // idx < items = MB * ncp * 256 wherever the result is used; MB <= 2
+    if (MB > 1 && c >= ncp) { c -= ncp; mi = 1; }
     const int chunk = c * 64 + l;
     valid = idx < items && chunk < a.cpr && mi < a.m;
     return reinterpret_cast<const u32x4*>(reinterpret_cast<const uint8_t*>(a.A) +
@@ -168,8 +178,8 @@ __global__ void __launch_bounds__(1024) wq_gemvx_kernel(const GemvxArgs a) {
   auto item_store = [&](int idx, const u32x4 (&raw)[IVW], bool valid) {
     const int l = idx & 63;
     const int u = (idx >> 6) & 3;
-    const int c = (idx >> 8) % ncp;
-    const int mi = (idx >> 8) / ncp;
+    int c = idx >> 8, mi = 0;                      // idx < items = MB * ncp * 256 wherever the result is used; MB <= 2
+    if (MB > 1 && c >= ncp) { c -= ncp; mi = 1; }
     float sum = 0.f;
     half_t el[EPW];
 #pragma unroll
