@@ -1177,6 +1177,10 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_decode_lds_kernel(const Ge
   constexpr int REGION = PF * STEP_BYTES;                // per wave: 16 KiB
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  // every kernel argument in ONE scalar round trip (the compiler otherwise fetches them where first used: dependent
+  // s_load waits in front of the first load of a kernel whose whole life is ~4 us; see wqaa_gemvx_kernel.h)
+  asm volatile("" ::"s"(a.A), "s"(a.B), "s"(a.scale), "s"(a.zeros), "s"(a.M), "s"(a.N), "s"(a.K), "s"(a.kg), "s"(a.gq_shift),
+               "s"(a.row_bytes), "s"(a.nsteps), "s"(a.is_signed), "s"((int)gridDim.x));
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
