@@ -21,14 +21,15 @@ bool gemvx_eligible(const wqaa_matmul_desc& d, int m) {
   if (d.K % E != 0) return false;
   const int g = d.group_size <= 0 ? d.K : d.group_size;
   if (d.K % g != 0 || (d.with_scaling && g % E != 0)) return false;
-  // Long K with enough rows to fill the chip unsplit: the rounding members win (4096x11008 int4: 8.15 vs 8.5-8.8 us,
-  // same-call A/B profiles/r02_ab_gemvx.txt - staging the 22 KB activation row and its chunk sums before the first dot
-  // costs 1.2 us of the launch there, profiles/r02_abl_gemvx.txt).  Either numerics meets the contract when
-  // strict_reference = 0, so the faster member is taken.
+  // Long K with enough rows to fill the chip unsplit: every workgroup stages the whole activation row and its chunk
+  // sums before its first dot, which the rounding members (wider workgroups, no sums) do cheaper.  Same-call A/B, int4
+  // g128, exact vs rounding member (profiles/r02_ab_gemvx_longk.txt): M=1 4096x11008 7.76 vs 8.14 us (three activation
+  // items per thread in flight ahead of the weights; 8.5 with one), 4096x14336 10.18 vs 10.09, 8192x28672 29.9 vs 27.2;
+  // M=2 4096x11008 11.2 vs 10.2.  Either numerics meets the contract when strict_reference = 0: the faster member is taken.
   {
     const int cus = device_info().ok ? device_info().cus : 256;
-    const long wbytes = (long)d.N * d.K * d.w_bits / 8;
-    if (d.K > 8192 && wbytes < (48l << 20) && (d.N + 1) / 2 >= 8 * cus) return false;
+    const char* f = getenv("WQAA_GEMVX");
+    if (!(f && atoi(f) == 2) && d.K > 8192 && (d.N + 1) / 2 >= 8 * cus && (m > 1 || d.K > 12288)) return false;   // WQAA_GEMVX=2: A/B aid
   }
   // the switch is a plan-time one like every tuning variable (ChoiceMemo): re-read when wqaa_select bumps the epoch
   static thread_local unsigned seen_epoch = 0;

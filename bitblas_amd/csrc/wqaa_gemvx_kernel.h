@@ -65,6 +65,10 @@ struct GemvxArgs {
 template <int BITS_, int LAYOUT_, int MODE_, int MB_, int R_, int D_, int ABL_ = 0>
 struct GemvxPolicy {
   static constexpr int BITS = BITS_, LAYOUT = LAYOUT_, MODE = MODE_, MB = MB_, R = R_, D = D_, ABL = ABL_;
+  // activation items per thread in flight ahead of the weight stream: 8 waves x 3 cover K = 12288 at 4 bit (rounds past
+  // the tile are skipped wave-uniformly; 4096x11008 8.5 -> 7.76 us against one item).  The two-row members serve the
+  // many-row shapes, where K is short and the extra registers cost 4 % (11008x4096 6.7 -> 7.0 us): they keep one.
+  static constexpr int NAI = R_ == 1 ? 3 : 1;
   static constexpr int KIND = BITS_ == 4 ? DK_INT4 : BITS_ == 2 ? DK_INT2 : DK_INT1;
   using T = KindTraits<KIND, AT_F16>;
   static constexpr int EPW = 32 / BITS_;       // fields per 32-bit word
@@ -163,7 +167,7 @@ __global__ void __launch_bounds__(1024) wq_gemvx_kernel(const GemvxArgs a) {
   // chunk cost 87 VGPRs and 10-30 % of the throughput) ----
   constexpr int IVW = EPW / 8;                    // 16-byte vectors per item
   const int items = MB * ncp * 4 * 64;
-  constexpr int NAI = 1;                          // items per thread loaded ahead of the weights (8 waves cover K = 4096 at 4 bit)
+  constexpr int NAI = P::NAI;                     // items per thread loaded ahead of the weights (8 waves x 1 item cover K = 4096 at 4 bit)
   u32x4 araw[NAI][IVW];
   auto item_src = [&](int idx, bool& valid) -> const u32x4* {
     const int l = idx & 63;

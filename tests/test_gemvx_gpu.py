@@ -78,17 +78,18 @@ def test_two_and_one_bit_weights(wd, fd, zm):
 
 
 def test_long_k_unsplit_keeps_the_rounding_member():
-    """4096 x 11008: enough rows to fill the chip without a K split and a 22 KB activation row to stage - the rounding
-    member is the faster one there (csrc/wqaa_gemvx.hip: gemvx_eligible), and either numerics meets the contract"""
-    case = make_case(1, 4096, 11008, W_dtype="int4", group_size=128, with_scaling=True, scale_mul=0.02, seed=5)
-    got, mm = hip_output(case, strict_reference=False)
-    assert "_gemvx_" not in mm.plans[1]["name"], mm.plans[1]["name"]
-    assert_fp_parity(got, oracle_output(case))
-    monkey_kw, _ = hip_output(case, strict_reference=True)
-    assert np.array_equal(got, monkey_kw)
+    """K > 12288 (or M = 2 and K > 8192) with enough rows to fill the chip without a K split: the rounding member is
+    the faster one there (csrc/wqaa_gemvx.hip: gemvx_eligible), and either numerics meets the contract"""
+    for M, N, K in ((1, 4096, 14336), (2, 4096, 11008)):
+        case = make_case(M, N, K, W_dtype="int4", group_size=128, with_scaling=True, scale_mul=0.02, seed=5)
+        got, mm = hip_output(case, strict_reference=False)
+        assert "_gemvx_" not in mm.plans[M]["name"], mm.plans[M]["name"]
+        assert_fp_parity(got, oracle_output(case))
+        strict, _ = hip_output(case, strict_reference=True)
+        assert np.array_equal(got, strict)
 
 
-@pytest.mark.parametrize("N,K", [(4096, 4096), (11008, 4096), (12288, 4096), (1024, 11008)])
+@pytest.mark.parametrize("N,K", [(4096, 4096), (11008, 4096), (4096, 11008), (12288, 4096), (1024, 11008)])
 def test_baseline_c2_full_size(N, K):
     """BASELINE c2: W_int4 A_fp16 GEMV, M = 1, Llama-2-7B linear shapes, g = 128 - what bench.py times"""
     case = make_case(1, N, K, W_dtype="int4", group_size=128, with_scaling=True, scale_mul=0.02, seed=N // 128)
