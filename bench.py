@@ -271,13 +271,38 @@ def time_c5_sharded(device, gen, world, rank, steps=5, warmup=2):
             "kernels": [op.op.plans[M]["name"] if M in op.op.plans else None for (op, _, _, _) in ops]}
 
 
+def usable_cores():
+    """host cores this process may actually run on: the affinity mask and the cgroup CPU quota, not the machine's core
+    count (256 OpenMP threads on a 16-CPU quota measure the scheduler: 544 ms for a 16 M element dequantise)"""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                txt = f.read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                        n = min(n, max(1, q // int(f.read().strip())))
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
+
+
 def cpu_baseline(max_seconds=20.0):
     """The reference's CPU path restated: dequantise the int4 weights to float16 values and take
     the fp32 matmul, timed on ALL host cores - both stages in torch (threaded); the first pass is checked against the
     numpy oracle (oracle/wqaa_oracle.py), which is single-threaded and would measure numpy, not the host."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import wqaa_oracle as oracle
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     torch.set_num_threads(cores)
     rng = np.random.default_rng(0)
     N = K = 4096
