@@ -49,6 +49,12 @@ struct GemvArgs {
   int zq_row_bytes; // quantized zeros: bytes per group row (N*bits/8)
   const float* epi_row;   // fused caller epilogue (wqaa_matmul_ex): out = half(acc / epi_row[m] / epi_tensor)
   float epi_tensor;
+  // K split across the waves of a workgroup (few-row shards): kw consecutive waves share a row group, wave part p takes
+  // the lane-chunk steps [p * spp, (p + 1) * spp); the parts meet in LDS in a fixed order.  kw == 1: everything below unused.
+  int kw;               // 1, or a divisor of the workgroup's wave count
+  uint32_t kw_magic;    // ceil(2^16 / kw): wave / kw without an integer division
+  int spp;              // steps per part = ceil(steps / kw)
+  int it_count;         // row-group iterations of every workgroup (uniform: the parts meet behind a barrier)
 };
 
 struct LaunchCfg {

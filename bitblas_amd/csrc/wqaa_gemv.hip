@@ -28,6 +28,7 @@ struct GemvChoice {
   int E;
   int nc, ncp, cpr;
   int grid_x, grid_y, lds, threads, variant;
+  int kw, spp, it_count;      // K split across the waves of a workgroup (1 = none)
   int fp4_table;
   int a_fmt;
 };
@@ -183,16 +184,52 @@ static int choose(const wqaa_matmul_desc& d, int m, GemvChoice* c, bool quant_in
   }
   const char* force = getenv("WQAA_GEMV_THREADS");   // tuning aid
   if (force && atoi(force) >= 64) nw = atoi(force) / 64;
-  if (blocks_per_cu * nw > 32) blocks_per_cu = 32 / nw;
-  c->threads = nw * 64;
   const int n_rg = (d.N + c->R - 1) / c->R;
-  int blocks = (n_rg + nw - 1) / nw;
+  // Few-row shards (N / 8 slices of a column-parallel layer: 1024 x 28672, 1280 x 8192): one wave per row group leaves
+  // most of the chip without a wave.  Split K across kw waves of a workgroup until ~8 waves per CU are busy; the parts
+  // meet in LDS in a fixed order (bit-stable; integer members bit-exact).  Not for the register-resident members (one
+  // step) nor the in-kernel quantiser.
+  c->kw = 1;
+  {
+    const int nsteps = c->ncp / c->D;
+    const bool can = !direct && !(c->flags & FL_AQ) && m <= mb && nsteps >= 2;
+    int kw = 1;
+    if (can && n_rg < 4 * cus) {
+      kw = (8 * cus + n_rg - 1) / n_rg;              // waves per row group that bring the chip to ~8 waves per CU
+      if (kw > 8) kw = 8;
+      if (kw > nsteps) kw = nsteps;
+      while (kw > 1 && ((nsteps + kw - 1) / kw) * (kw - 1) >= nsteps) --kw;   // every part gets at least one step
+    }
+    if (can && d.k_split_hint > 1) kw = d.k_split_hint;       // the caller's MatmulConfigWithSplitK.k_split
+    if (const char* f = getenv("WQAA_GEMV_KW")) { if (can && atoi(f) > 0) kw = atoi(f); }   // tuning aid
+    if (kw > nsteps) kw = nsteps;
+    if (kw > 16) kw = 16;
+    while (kw > 1 && ((nsteps + kw - 1) / kw) * (kw - 1) >= nsteps) --kw;
+    if (kw > 1 && c->lds + 2 * 16 * c->R * mb * 4 > 160 * 1024) kw = 1;   // no room for the parts' partial sums
+    if (kw > 1) {
+      int slots = nw / kw;                            // keep the workgroup near the width chosen above
+      if (slots < 1) slots = 1;
+      while (slots > 1 && (n_rg + slots - 1) / slots < cus) slots /= 2;
+      if (slots * kw > 16) slots = 16 / kw;
+      if (slots < 1) slots = 1;
+      nw = slots * kw;
+      c->kw = kw;
+      c->spp = (nsteps + kw - 1) / kw;
+      c->lds += 2 * nw * c->R * mb * 4;               // the parts' partial sums, double buffered
+    }
+  }
+  if (blocks_per_cu * nw > 32) blocks_per_cu = 32 / nw;
+  if (blocks_per_cu < 1) blocks_per_cu = 1;
+  c->threads = nw * 64;
+  const int rg_per_block = nw / c->kw;
+  int blocks = (n_rg + rg_per_block - 1) / rg_per_block;
   const int cap = cus * blocks_per_cu;
   if (blocks > cap) blocks = cap;
   if (blocks < 1) blocks = 1;
   if (blocks >= 8) blocks = (blocks + 7) / 8 * 8;   // whole XCD rounds: keeps the block swizzle on
   c->grid_x = blocks;
   c->grid_y = (m + mb - 1) / mb;
+  c->it_count = ((n_rg + rg_per_block - 1) / rg_per_block + blocks - 1) / blocks;   // uniform per workgroup (kw > 1)
   return WQAA_OK;
 }
 
@@ -227,6 +264,10 @@ static void fill_args(const wqaa_matmul_desc& d, const GemvChoice& c, const void
   a->zq_row_bytes = d.N * (c.bits < 8 ? c.bits : 8) / 8;
   a->epi_row = nullptr;
   a->epi_tensor = 1.f;
+  a->kw = c.kw;
+  a->kw_magic = (65536u + (uint32_t)c.kw - 1u) / (uint32_t)c.kw;
+  a->spp = c.kw > 1 ? c.spp : 0;
+  a->it_count = c.it_count;
 }
 
 int gemv_plan(const wqaa_matmul_desc& d, int m, wqaa_plan* plan) {
@@ -244,12 +285,14 @@ int gemv_plan(const wqaa_matmul_desc& d, int m, wqaa_plan* plan) {
     plan->rows_per_wave = c.R;
     plan->batch_tile = c.mb;
     plan->pipeline_depth = c.D;
-    plan->split_k = 1;
+    plan->split_k = c.kw;
     plan->lds_bytes = c.lds;
     char wd[24];
     short_wdtype(d, wd, sizeof(wd));
-    snprintf(plan->name, sizeof(plan->name), "matmul_m%dn%dk%d_%sx%s_gemv_b%dr%dd%d%s", m, d.N, d.K,
-             short_dtype(d.a_dtype), wd, c.mb, c.R, c.D, c.variant ? "_areg" : "");
+    char ks[8] = "";
+    if (c.kw > 1) snprintf(ks, sizeof(ks), "k%d", c.kw);
+    snprintf(plan->name, sizeof(plan->name), "matmul_m%dn%dk%d_%sx%s_gemv_b%dr%dd%d%s%s", m, d.N, d.K,
+             short_dtype(d.a_dtype), wd, c.mb, c.R, c.D, ks, c.variant ? "_areg" : "");
   }
   return WQAA_OK;
 }

@@ -375,12 +375,20 @@ __global__ void __launch_bounds__(1024) wq_gemv_kernel(const GemvArgs a) {
   const int n_rg = (a.N + R - 1) / R;
   const int nthreads = blockDim.x;      // 64 / 128 / 256: picked by the selector
   const int NW = nthreads >> 6;
-  const int total_waves = gridDim.x * NW;
+  // K split (few-row shards): kw consecutive waves share a row group
+  const int kw = a.kw;
+  int wslot = wave, kpart = 0, slots = NW;
+  if (kw > 1) {
+    wslot = (int)(((uint32_t)wave * a.kw_magic) >> 16);
+    kpart = wave - wslot * kw;
+    slots = (int)(((uint32_t)NW * a.kw_magic) >> 16);
+  }
+  const int total_waves = gridDim.x * slots;     // row groups in flight on the chip
   // XCD-aware block order (block b runs on XCD b % 8): every XCD owns a contiguous range of rows,
   // so the 2-byte results that share a 128-byte line of C are written through one L2
   int blk = blockIdx.x;
   if ((gridDim.x & 7) == 0) blk = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
-  const int wg = blk * NW + wave;
+  const int wg = blk * slots + wslot;
   const int m0 = blockIdx.y * MB;
   const uint8_t* Bp = reinterpret_cast<const uint8_t*>(a.B);
   const uint16_t* Sp = reinterpret_cast<const uint16_t*>(a.scale);
@@ -461,10 +469,13 @@ __global__ void __launch_bounds__(1024) wq_gemv_kernel(const GemvArgs a) {
     }
   };
 
+  // this wave's lane-chunk range [c_lo, c_hi): all of the row, or its part of the K split
+  const int c_lo = kw > 1 ? kpart * a.spp * D : 0;
+  const int c_hi = kw > 1 ? (c_lo + a.spp * D < nc ? c_lo + a.spp * D : nc) : nc;
   Stage<P> st[D];
   int rg = wg;
-  const bool have_work = rg < n_rg;
-  issue(st, have_work ? rg : n_rg - 1, 0, true);
+  const bool have_work = kw > 1 || rg < n_rg;      // split workgroups iterate uniformly (barrier in finish), rows clamped
+  issue(st, rg < n_rg ? rg : n_rg - 1, c_lo, true);
 
   float aq_s[MB];                         // AQ: act_quant_scale(max |row|) of every row of the batch tile
 #pragma unroll
@@ -671,7 +682,50 @@ __global__ void __launch_bounds__(1024) wq_gemv_kernel(const GemvArgs a) {
     }
   };
 
+  int it_idx = 0;
   auto finish = [&](int rg_now) {
+    if constexpr (!AD && !AQ) {
+      if (kw > 1) {
+        // the kw parts of a row group meet in LDS (double buffered: one barrier per row group) and are summed by part
+        // 0 in part order - bit-identical from run to run, bit-exact for the integer members
+        acc_t* red = reinterpret_cast<acc_t*>(a_lds + (long)MB * ncp * T::PIECES * 64) + (it_idx & 1) * (NW * R * MB);
+        ++it_idx;
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+          for (int mi = 0; mi < MB; ++mi) {
+            const acc_t tot = wave_sum(acc[r][mi]);
+            acc[r][mi] = 0;
+            if (lane == 0) red[(wave * R + r) * MB + mi] = tot;
+          }
+        __syncthreads();
+        if (kpart == 0 && lane == 0 && rg_now < n_rg) {
+#pragma unroll
+          for (int r = 0; r < R; ++r) {
+            const int n = rg_now * R + r;
+            if (n >= a.N) continue;
+#pragma unroll
+            for (int mi = 0; mi < MB; ++mi) {
+              if ((m0 + mi) >= a.m) continue;
+              acc_t tot = red[(wave * R + r) * MB + mi];
+              for (int p = 1; p < kw; ++p) tot += red[((wave + p) * R + r) * MB + mi];
+              if constexpr (F16) {
+                float b = 0.f;
+                if (a.has_bias) b = P::BF ? bf16_bits_to_float(reinterpret_cast<const uint16_t*>(a.bias)[n])
+                                         : (float)reinterpret_cast<const half_t*>(a.bias)[n];
+                store_out(a.C, (long)(m0 + mi) * a.N + n, tot, a.out_dtype, a.has_bias != 0, b);
+              } else if (a.epi_row) {
+                store_out_fused(a.C, (long)(m0 + mi) * a.N + n, tot, a.epi_row[m0 + mi], a.epi_tensor, a.has_bias != 0, a.bias, n);
+              } else {
+                const int b = a.has_bias ? (int)reinterpret_cast<const int8_t*>(a.bias)[n] : 0;
+                store_out(a.C, (long)(m0 + mi) * a.N + n, tot, a.out_dtype, a.has_bias != 0, b);
+              }
+            }
+          }
+        }
+        return;
+      }
+    }
     if constexpr (F16 && R == 2 && !P::BF) {
       // the two rows of the group are neighbours in C: one 4- / 8-byte store per batch row instead of two stores
       // (measured on the exact-product members, wqaa_gemvx_kernel.h: 0.15-0.2 us per launch)
@@ -734,16 +788,17 @@ __global__ void __launch_bounds__(1024) wq_gemv_kernel(const GemvArgs a) {
   if (!have_work) return;
   // first step was issued before the barrier; later steps are issued right after the previous
   // step's registers are consumed
-  int c0 = 0;
+  int c0 = c_lo;
+  int it_left = a.it_count;
   while (true) {
 #pragma unroll
     for (int d = 0; d < D; ++d) consume(st[d], c0 + d, rg);
     c0 += D;
-    if (c0 >= nc) {
+    if (c0 >= c_hi) {
       finish(rg);
-      c0 = 0;
+      c0 = c_lo;
       rg += total_waves;
-      if (rg >= n_rg) break;
+      if (kw > 1 ? (--it_left <= 0) : (rg >= n_rg)) break;
     }
     issue(st, rg, c0, false);   // AD members: K fits one step, the activation registers stay as loaded
   }

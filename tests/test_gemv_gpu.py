@@ -191,3 +191,50 @@ def test_non_contiguous_activations_are_read_correctly():
     assert_fp_parity(out3.reshape(4, 256).cpu().numpy(), oracle_output(case))
     with pytest.raises(ValueError):
         mm(tall[0::2], W, output=torch.empty((4, 512), dtype=torch.float16, device="cuda")[:, ::2])
+
+
+# ---- K split across the waves of a workgroup (rounding members; few-row shards of a column-parallel layer) ----
+@pytest.mark.parametrize("kw", [0, 2, 3, 4, 7])
+@pytest.mark.parametrize("N,K", [(1024, 28672), (1280, 8192), (512, 11008), (100, 8192)])
+def test_k_split_rounding_members(N, K, kw, monkeypatch):
+    """kw = 0: the selector's own choice (must split for these shapes); otherwise forced.  Same parity bound as the
+    unsplit member, bit-identical from run to run (the parts meet in LDS in a fixed order)."""
+    if kw:
+        monkeypatch.setenv("WQAA_GEMV_KW", str(kw))
+    case = make_case(1, N, K, W_dtype="uint4", group_size=128, with_scaling=True, with_zeros=True, zeros_mode="original",
+                     scale_mul=0.02, seed=kw + N, out_dtype="float32", accum_dtype="float32")
+    got, mm = hip_output(case)
+    plan = mm.plans[1]
+    assert "_gemvx_" not in plan["name"] and plan["split_k"] > 1, plan
+    if kw:
+        assert plan["split_k"] == min(kw, plan["split_k"]) and plan["name"].endswith(f"k{plan['split_k']}"), plan
+    assert_fp_parity(got, oracle_output(case))
+    got2, _ = hip_output(case, matmul=mm)
+    assert np.array_equal(got.view(np.uint32), got2.view(np.uint32))
+
+
+@pytest.mark.parametrize("M", [1, 2, 4])
+@pytest.mark.parametrize("zm", [None, "rescale", "quantized"])
+def test_k_split_batches_zero_modes_and_bias(M, zm, monkeypatch):
+    monkeypatch.setenv("WQAA_GEMV_KW", "4")
+    case = make_case(M, 384 + 2, 16384, W_dtype="uint4" if zm else "int4", group_size=128, with_scaling=True, with_zeros=zm is not None,
+                     zeros_mode=zm or "original", with_bias=True, scale_mul=0.02, seed=M)
+    got, mm = hip_output(case)
+    assert mm.plans[M]["split_k"] == 4, mm.plans[M]
+    assert_fp_parity(got, oracle_output(case))
+
+
+@pytest.mark.parametrize("wd", ["int2", "int4"])
+def test_k_split_int8_activations_bit_exact(wd, monkeypatch):
+    monkeypatch.setenv("WQAA_GEMV_KW", "3")
+    case = make_case(2, 768, 24576, W_dtype=wd, A_dtype="int8", out_dtype="int32", seed=3)
+    got, mm = hip_output(case)
+    assert mm.plans[2]["split_k"] == 3, mm.plans[2]
+    assert np.array_equal(got, oracle_output(case))
+
+
+def test_k_split_request_from_the_operator():
+    import bitblas_amd as bitblas
+    cfg = bitblas.MatmulConfigWithSplitK(M=1, N=1024, K=16384, A_dtype="float16", W_dtype="int4", group_size=128, with_scaling=True, k_split=2)
+    mm = bitblas.MatmulWithSplitK(cfg, enable_tuning=False)          # strict_reference = True: the rounding member
+    assert mm.plans[1]["split_k"] == 2 and "_gemvx_" not in mm.plans[1]["name"], mm.plans[1]
