@@ -29,7 +29,11 @@ bool gemvx_eligible(const wqaa_matmul_desc& d, int m) {
   {
     const int cus = device_info().ok ? device_info().cus : 256;
     const char* f = getenv("WQAA_GEMVX");
-    if (!(f && atoi(f) == 2) && d.K > 8192 && (d.N + 1) / 2 >= 8 * cus && (m > 1 || d.K > 12288)) return false;   // WQAA_GEMVX=2: A/B aid
+    const bool forced = f && atoi(f) == 2;                    // WQAA_GEMVX=2: A/B aid, ignores the fences
+    if (!forced && d.K > 8192 && (d.N + 1) / 2 >= 8 * cus && (m > 1 || d.K > 12288)) return false;
+    // two activation rows: twice the LDS reads and dots per weight word - the exact member only wins on many-row matrices
+    // (same-call, int4 g128: 11008x4096 8.8 vs 9.4 us; 4096^2 5.4 vs 5.1, 4096x11008 11.2 vs 10.2)
+    if (!forced && m == 2 && d.N < 8192) return false;
   }
   // the switch is a plan-time one like every tuning variable (ChoiceMemo): re-read when wqaa_select bumps the epoch
   static thread_local unsigned seen_epoch = 0;

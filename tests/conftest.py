@@ -11,6 +11,7 @@ for p in (ROOT, os.path.join(ROOT, "oracle")):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu`)")
+    config.addinivalue_line("markers", "selector_choice: tests/test_gemvx_gpu.py - the test checks what the selector picks on its own")
 
 
 @pytest.fixture(scope="session")

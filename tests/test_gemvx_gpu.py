@@ -22,6 +22,15 @@ from helpers import assert_fp_parity, hip_output, make_case, oracle_output
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def exact_members_wherever_they_exist(request, monkeypatch):
+    """The selector hands some shapes (M = 2 on few rows, very long K) to the rounding members because those are faster
+    there; the parity tests below are about the exact members themselves, so they lift those fences (WQAA_GEMVX=2).
+    Tests of the selector's own choice opt out with `@pytest.mark.selector_choice`."""
+    if request.node.get_closest_marker("selector_choice") is None:
+        monkeypatch.setenv("WQAA_GEMVX", "2")
+
+
 def exact_output(case):
     return oracle.matmul_dequant_exact(case["A"], case["codes"], source_format=case["source_format"], bit=case["bit"],
                                        scale=case["scale"], zeros=case["zeros"], zeros_mode=case["zeros_mode"],
@@ -77,10 +86,11 @@ def test_two_and_one_bit_weights(wd, fd, zm):
     check(case)
 
 
+@pytest.mark.selector_choice
 def test_long_k_unsplit_keeps_the_rounding_member():
     """K > 12288 (or M = 2 and K > 8192) with enough rows to fill the chip without a K split: the rounding member is
     the faster one there (csrc/wqaa_gemvx.hip: gemvx_eligible), and either numerics meets the contract"""
-    for M, N, K in ((1, 4096, 14336), (2, 4096, 11008)):
+    for M, N, K in ((1, 4096, 14336), (2, 4096, 11008), (2, 4096, 4096)):
         case = make_case(M, N, K, W_dtype="int4", group_size=128, with_scaling=True, scale_mul=0.02, seed=5)
         got, mm = hip_output(case, strict_reference=False)
         assert "_gemvx_" not in mm.plans[M]["name"], mm.plans[M]["name"]
@@ -116,6 +126,7 @@ def test_k_split_across_the_waves_of_a_workgroup(N, K, kw, monkeypatch):
     assert np.array_equal(got.view(np.uint32), got2.view(np.uint32))
 
 
+@pytest.mark.selector_choice
 def test_selector_splits_k_for_few_rows():
     import bitblas_amd as bitblas
     for (N, K) in ((1024, 28672), (1280, 8192)):
@@ -132,6 +143,7 @@ def test_ragged_n_bias_and_outputs(with_bias, out_dtype):
     check(case)
 
 
+@pytest.mark.selector_choice
 def test_strict_reference_keeps_the_rounding_members():
     case = make_case(1, 1024, 1024, W_dtype="int4", group_size=128, with_scaling=True, seed=1)
     _, mm = hip_output(case, strict_reference=True)
