@@ -8,7 +8,7 @@ struct GemvxChoice {
   gemvx_fn fn;
   int bits, layout, mode, mb, R, D, kw, nw;
   int E, cpr, nc, nsteps, n_rgb;
-  int grid, lds;
+  int grid, lds, areg;
 };
 
 // sub-byte integer weights x float16 activations, M <= 2, and the caller did not ask for the TE definition's
@@ -125,7 +125,19 @@ static int gemvx_choose(const wqaa_matmul_desc& d, int m, GemvxChoice* c) {
   if (blocks >= 8) blocks = (blocks + 7) / 8 * 8;       // whole XCD rounds keep the block swizzle on
   if (const char* f = getenv("WQAA_GEMVX_GRID")) blocks = atoi(f) > 0 ? atoi(f) : 1;
   c->grid = blocks;
-  const int rd = c->R * 10 + c->D;
+  // register-resident activations (4-bit LOP3, M = 1, K within one step, no K split): no LDS tile, no barrier.
+  // WQAA_GEMVX_AREG=0/1 forces it off/on (A/B aid).
+  c->areg = 0;
+  if (c->bits == 4 && c->layout == LAYOUT_LOP3 && c->mb == 1 && c->nsteps == 1 && c->kw == 1) {
+    // same-call A/B against the LDS-staged member (profiles/r02_ab_gemvx_areg.txt): 1024 rows 2.81 -> 2.62 us, 2048 3.27 ->
+    // 3.22, 28672 15.5 -> 14.8; 4096 rows 4.07 -> 4.38, 11008 6.64 -> 7.08, 12288 6.93 -> 7.37 (every wave re-reads the
+    // activation row through the texture path and sums it itself) - so: few rows, or so many that the barrier of
+    // tens of workgroups per CU costs more than the re-reads
+    c->areg = (d.N <= 2048 || d.N >= 24576) ? 1 : 0;
+    if (const char* f = getenv("WQAA_GEMVX_AREG")) c->areg = atoi(f) != 0;
+  }
+  if (c->areg) c->lds = 64;
+  const int rd = c->R * 10 + c->D + (c->areg ? 1 : 0);
   c->fn = c->bits == 4 ? pick_gemvx_int4(c->layout, c->mode, c->mb, rd)
           : c->bits == 2 ? pick_gemvx_int2(c->layout, c->mode, c->mb, rd)
                          : pick_gemvx_int1(c->layout, c->mode, c->mb, rd);
@@ -160,6 +172,7 @@ int gemvx_plan(const wqaa_matmul_desc& d, int m, wqaa_plan* plan) {
     short_wdtype(d, wd, sizeof(wd));
     snprintf(plan->name, sizeof(plan->name), "matmul_m%dn%dk%d_%sx%s_gemvx_b%dr%dd%dk%d", m, d.N, d.K, short_dtype(d.a_dtype), wd,
              c.mb, c.R, c.D, c.kw);
+    if (c.areg) strncat(plan->name, "_areg", sizeof(plan->name) - strlen(plan->name) - 1);
   }
   return WQAA_OK;
 }
@@ -215,7 +228,7 @@ void gemvx_init() {
     for (int layout = 0; layout < 2; ++layout)
       for (int mode = 0; mode <= MD_ZQ; ++mode)
         for (int mb = 1; mb <= 2; ++mb)
-          for (int rd : {12, 22}) {
+          for (int rd : {12, 22, 13, 23}) {
             gemvx_fn fn = bits == 4 ? pick_gemvx_int4(layout, mode, mb, rd) : bits == 2 ? pick_gemvx_int2(layout, mode, mb, rd)
                                                                                        : pick_gemvx_int1(layout, mode, mb, rd);
             if (fn) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

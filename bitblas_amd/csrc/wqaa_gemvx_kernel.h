@@ -62,9 +62,15 @@ struct GemvxArgs {
 
 // ABL_: ablation bits for tools/ (lab members only, never selected by the library): 1 = loads consumed by one XOR
 // instead of the decode + dot, 2 = no activation staging / barrier, 4 = no wave reduction / store, 8 = no store
-template <int BITS_, int LAYOUT_, int MODE_, int MB_, int R_, int D_, int ABL_ = 0>
+// AREG_: the lane keeps the activations of its own lane chunks in registers (4-bit LOP3 weights, M = 1, K within one
+// step): the LOP3 interleave puts consecutive elements 2j, 2j + 1 into the two halves of field j, so the natural-order
+// activation dword j IS the partner of masked field j - no LDS tile, no staging pass, no barrier; the chunk's
+// activation sum is taken from the same registers.
+template <int BITS_, int LAYOUT_, int MODE_, int MB_, int R_, int D_, int ABL_ = 0, bool AREG_ = false>
 struct GemvxPolicy {
   static constexpr int BITS = BITS_, LAYOUT = LAYOUT_, MODE = MODE_, MB = MB_, R = R_, D = D_, ABL = ABL_;
+  static constexpr bool AREG = AREG_;
+  static_assert(!AREG_ || (BITS_ == 4 && LAYOUT_ == LAYOUT_LOP3 && MB_ == 1), "register-resident activations: 4-bit LOP3 weights, M = 1");
   // activation items per thread in flight ahead of the weight stream: 8 waves x 3 cover K = 12288 at 4 bit (rounds past
   // the tile are skipped wave-uniformly; 4096x11008 8.5 -> 7.76 us against one item).  The two-row members serve the
   // many-row shapes, where K is short and the extra registers cost 4 % (11008x4096 6.7 -> 7.0 us): they keep one.
@@ -206,7 +212,24 @@ __global__ void __launch_bounds__(1024) wq_gemvx_kernel(const GemvxArgs a) {
     sa_lds[((mi * ncp + c) * 64 + l) * 4 + u] = valid ? sum : 0.f;          // the chunk's sum arrives as four partials
   };
   bool avalid[NAI];
-  if constexpr (!(P::ABL & 2)) {
+  // register-resident activations (AREG): word u of lane chunk d pairs with areg[d][u]; sa_reg[d] = the chunk's sum
+  u32x4 areg[D][4];
+  float sa_reg[D];
+  if constexpr (P::AREG) {
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      const int chunk = d * 64 + lane;                 // one step, no K split: chunk d of the row
+      const bool valid = chunk < a.cpr;
+      const u32x4* src = reinterpret_cast<const u32x4*>(reinterpret_cast<const uint8_t*>(a.A) + (long)(valid ? chunk : 0) * (E * 2));
+#pragma unroll
+      for (int u = 0; u < 4; ++u) areg[d][u] = src[u];
+      if (!valid) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) areg[d][u] = u32x4{0u, 0u, 0u, 0u};
+      }
+    }
+  }
+  if constexpr (!(P::ABL & 2) && !P::AREG) {
 #pragma unroll
     for (int j = 0; j < NAI; ++j) {
       const u32x4* src = item_src(j * nthreads + tid, avalid[j]);
@@ -222,7 +245,18 @@ __global__ void __launch_bounds__(1024) wq_gemvx_kernel(const GemvxArgs a) {
 #pragma unroll
   for (int d = 0; d < D; ++d) issue(st[d], 0, 0, d);
 
-  if constexpr (!(P::ABL & 2)) {
+  if constexpr (P::AREG) {
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      float sum = 0.f;
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sum = __builtin_amdgcn_fdot2(as_h2(areg[d][u][e]), half2_t{(half_t)1.f, (half_t)1.f}, sum, false);
+      sa_reg[d] = sum;
+    }
+  }
+  if constexpr (!(P::ABL & 2) && !P::AREG) {
 #pragma unroll
     for (int j = 0; j < NAI; ++j) {
       const int idx = j * nthreads + tid;
@@ -248,7 +282,8 @@ __global__ void __launch_bounds__(1024) wq_gemvx_kernel(const GemvxArgs a) {
     for (int mi = 0; mi < MB; ++mi) acc[r][mi] = 0.f;
 
   // one lane chunk of R rows against MB activation rows
-  auto consume = [&](const Stage& s, int c, int rg_now) {
+  auto consume = [&](const Stage& s, int c, int rg_now, auto dc) {
+    constexpr int DC = decltype(dc)::value;         // chunk index inside the step (register-resident activations)
     if constexpr (P::ABL & 1) {
 #pragma unroll
       for (int r = 0; r < R; ++r) acc[r][0] += __builtin_bit_cast(float, (s.w[r][0] ^ s.w[r][1] ^ s.w[r][2] ^ s.w[r][3] ^ s.s[r]) & 0x3fffffu);
@@ -280,7 +315,9 @@ __global__ void __launch_bounds__(1024) wq_gemvx_kernel(const GemvxArgs a) {
       for (int pp = 0; pp < PPW; ++pp) {
 #pragma unroll
         for (int mi = 0; mi < MB; ++mi) {
-          const u32x4 av = a_lds[((long)(mi * ncp + c) * PIECES + u * PPW + pp) * 64 + lane];
+          u32x4 av;
+          if constexpr (P::AREG) av = areg[DC][u];
+          else av = a_lds[((long)(mi * ncp + c) * PIECES + u * PPW + pp) * 64 + lane];
 #pragma unroll
           for (int r = 0; r < R; ++r)
 #pragma unroll
@@ -295,8 +332,13 @@ __global__ void __launch_bounds__(1024) wq_gemvx_kernel(const GemvxArgs a) {
     // chunk epilogue: combine the classes, remove the zero point, apply the group scale
 #pragma unroll
     for (int mi = 0; mi < MB; ++mi) {
-      const f32x4_t sa4 = reinterpret_cast<const f32x4_t*>(sa_lds)[(mi * ncp + c) * 64 + lane];
-      const float sa = (sa4[0] + sa4[1]) + (sa4[2] + sa4[3]);
+      float sa;
+      if constexpr (P::AREG) {
+        sa = sa_reg[DC];
+      } else {
+        const f32x4_t sa4 = reinterpret_cast<const f32x4_t*>(sa_lds)[(mi * ncp + c) * 64 + lane];
+        sa = (sa4[0] + sa4[1]) + (sa4[2] + sa4[3]);
+      }
 #pragma unroll
       for (int r = 0; r < R; ++r) {
         // class k holds sum q * a * 2^(BITS * k - 24): Horner towards class 0, then undo the 2^-24 (all exact scalings)
@@ -434,14 +476,19 @@ __global__ void __launch_bounds__(1024) wq_gemvx_kernel(const GemvxArgs a) {
     int c = (kpart + si * kw) * D;
     int it2 = it, si2 = si + 1;
     if (si2 == nmy) { si2 = 0; ++it2; }
-#pragma unroll
-    for (int d = 0; d < D; ++d) {
-      consume(st[d], c, rg_now);
+    static_assert(D == 2, "two lane chunks per step");
+    {
+      consume(st[0], c, rg_now, std::integral_constant<int, 0>{});
       ++c;
       // order fence by DATA dependence: the next chunk's LDS addresses and the next position's global addresses are
       // made to depend on this chunk's result.  Left alone hipcc hoists every chunk's LDS reads AND the next position's
       // global loads (renamed into a second register set) above the decode - 93 VGPRs, 5 waves per SIMD instead of 7;
       // sched_barrier / an asm memory clobber do not stop it (the loads are from memory it has proven read-only)
+      asm volatile("" : "+v"(acc[0][0]), "+v"(acc[R - 1][0]), "+v"(acc[0][MB - 1]), "+v"(acc[R - 1][MB - 1]), "+s"(c), "+s"(it2), "+s"(si2));
+    }
+    {
+      consume(st[1], c, rg_now, std::integral_constant<int, 1>{});
+      ++c;
       asm volatile("" : "+v"(acc[0][0]), "+v"(acc[R - 1][0]), "+v"(acc[0][MB - 1]), "+v"(acc[R - 1][MB - 1]), "+s"(c), "+s"(it2), "+s"(si2));
     }
     if (q + 1 < total) {
@@ -462,6 +509,12 @@ static gemvx_fn pick_gemvx_rd(int rd) {
   switch (rd) {
     case 12: return wq_gemvx_kernel<GemvxPolicy<BITS, LAYOUT, MODE, MB, 1, 2>>;
     case 22: return wq_gemvx_kernel<GemvxPolicy<BITS, LAYOUT, MODE, MB, 2, 2>>;
+    case 13:   // activations in registers
+      if constexpr (BITS == 4 && LAYOUT == LAYOUT_LOP3 && MB == 1) return wq_gemvx_kernel<GemvxPolicy<BITS, LAYOUT, MODE, MB, 1, 2, 0, true>>;
+      else return nullptr;
+    case 23:
+      if constexpr (BITS == 4 && LAYOUT == LAYOUT_LOP3 && MB == 1) return wq_gemvx_kernel<GemvxPolicy<BITS, LAYOUT, MODE, MB, 2, 2, 0, true>>;
+      else return nullptr;
   }
   return nullptr;
 }

@@ -148,3 +148,16 @@ def test_strict_reference_keeps_the_rounding_members():
     case = make_case(1, 1024, 1024, W_dtype="int4", group_size=128, with_scaling=True, seed=1)
     _, mm = hip_output(case, strict_reference=True)
     assert "_gemvx_" not in mm.plans[1]["name"]
+
+
+@pytest.mark.parametrize("areg", [0, 1])
+@pytest.mark.parametrize("N,K,zm", [(4096, 4096, None), (11008, 4096, "original"), (1000, 2048 + 64, "rescale"), (516, 4096, "quantized")])
+def test_register_resident_activations_member(N, K, zm, areg, monkeypatch):
+    """4-bit LOP3 weights, M = 1, K within one step: the lane keeps its own activations in registers (no LDS tile, no
+    barrier); forced on and off it must meet the same bounds, ragged K / N and every zero mode included"""
+    monkeypatch.setenv("WQAA_GEMVX_AREG", str(areg))
+    case = make_case(1, N, K, W_dtype="uint4" if zm else "int4", group_size=64 if K % 128 else 128, with_scaling=True,
+                     with_zeros=zm is not None, zeros_mode=zm or "original", scale_mul=0.02, seed=N + areg,
+                     out_dtype="float32", accum_dtype="float32")
+    got, mm = check(case)
+    assert mm.plans[1]["name"].endswith("_areg") == bool(areg), mm.plans[1]["name"]
