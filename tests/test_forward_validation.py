@@ -58,3 +58,30 @@ def test_linear_follows_replaced_scale_zero_and_bias_buffers():
     lin.zeros = dev(case2["zeros"])
     lin.bias = dev(case2["bias"])
     assert_fp_parity(lin(A).cpu().numpy(), oracle_output(case2))
+
+
+@pytest.mark.gpu
+def test_empty_batch_and_leading_batch_dimensions():
+    """dynamic-M operator: `m = prod(A.shape[:-1])` (general_matmul/__init__.py:735-741); m == 0 returns at once like the
+    generated dispatcher (`if (m == 0) return;`, builder/wrapper/tl.py:277) - no launch, an empty (0, N) result"""
+    import numpy as np
+    import torch
+    import bitblas_amd as bitblas
+    from helpers import assert_fp_parity, make_case, oracle_output
+    case = make_case(6, 256, 512, W_dtype="int4", group_size=128, with_scaling=True, scale_mul=0.05, seed=1)
+    cfg = bitblas.MatmulConfig(M=[1, 16], N=256, K=512, A_dtype="float16", W_dtype="int4", group_size=128, with_scaling=True)
+    mm = bitblas.Matmul(cfg, enable_tuning=False)
+    W = mm.weight_transform(torch.from_numpy(case["codes"])).cuda()      # pre-offset codes, as the reference's op test feeds them
+    scale = torch.from_numpy(case["scale"]).cuda()
+    empty = mm(torch.empty((0, 512), dtype=torch.float16, device="cuda"), W, scale=scale)
+    assert tuple(empty.shape) == (0, 256)
+    torch.cuda.synchronize()
+    A = torch.from_numpy(case["A"]).cuda().reshape(2, 3, 512)
+    out = mm(A, W, scale=scale)
+    assert tuple(out.shape) == (2, 3, 256)
+    assert_fp_parity(out.reshape(6, 256).cpu().numpy(), oracle_output(case))
+    # the C entry itself
+    import ctypes
+    from bitblas_amd import lib as wl
+    st = wl.load_library().wqaa_matmul(ctypes.byref(mm.lib.desc), None, None, None, None, None, None, None, 0, None)
+    assert st == 0
