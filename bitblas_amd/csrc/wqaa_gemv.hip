@@ -192,7 +192,8 @@ static int choose(const wqaa_matmul_desc& d, int m, GemvChoice* c, bool quant_in
   c->kw = 1;
   {
     const int nsteps = c->ncp / c->D;
-    const bool can = !direct && !(c->flags & FL_AQ) && m <= mb && nsteps >= 2;
+    const bool can = !direct && !(c->flags & FL_AQ) && m <= mb && mb <= 2 && nsteps >= 2 &&
+                     pick_kernel(c->kind, c->layout, c->at, c->mode, c->flags, kSplitTile + mb) != nullptr;
     int kw = 1;
     if (can && n_rg < 4 * cus) {
       kw = (8 * cus + n_rg - 1) / n_rg;              // waves per row group that bring the chip to ~8 waves per CU
@@ -214,6 +215,7 @@ static int choose(const wqaa_matmul_desc& d, int m, GemvChoice* c, bool quant_in
       if (slots < 1) slots = 1;
       nw = slots * kw;
       c->kw = kw;
+      c->fn = pick_kernel(c->kind, c->layout, c->at, c->mode, c->flags, kSplitTile + mb);   // the K-split twin
       c->spp = (nsteps + kw - 1) / kw;
       c->lds += 2 * nw * c->R * mb * 4;               // the parts' partial sums, double buffered
     }

@@ -74,7 +74,7 @@ __device__ inline float act_quant_scale(float absmax) {
   return __fmul_rn(r, 127.0f);
 }
 
-template <int KIND_, int LAYOUT_, int AT_, int MB_, int MODE_, int FLAGS_, int R_ = 2, int D_ = 2, bool AD_ = false>
+template <int KIND_, int LAYOUT_, int AT_, int MB_, int MODE_, int FLAGS_, int R_ = 2, int D_ = 2, bool AD_ = false, bool KS_ = false>
 struct GemvPolicy {
   static constexpr int KIND = KIND_, LAYOUT = LAYOUT_, AT = AT_, MB = MB_, MODE = MODE_, FLAGS = FLAGS_;
   static constexpr int R = R_;       // weight rows per wave per step
@@ -94,6 +94,10 @@ struct GemvPolicy {
   // caller's quantise -> matmul -> rescale chain is one launch
   static constexpr bool AQ = (FLAGS_ & FL_AQ) != 0 && AT_ == AT_I8;
   static constexpr bool AD = AD_ && MB_ <= 2 && !A8 && !A4 && !AQ;
+  // KS: the member can split K across the waves of a workgroup (few-row shards).  A compile-time twin rather than a
+  // run-time switch: the switch alone cost the unsplit LDS-staged member 4-7 % (11008x4096 7.4 -> 7.7 us, 28672x8192
+  // 28.9 -> 30.9: different register allocation and scheduling of the hot loop), which the many-row shapes must not pay.
+  static constexpr bool KS = KS_ && !AD && !AQ;
   using T = KindTraits<KIND_, AT_>;
   // words of raw activation data per staging item (one decode unit = G elements)
   static constexpr int AW = AT_ == AT_I4 ? T::G / 8 : AQ ? T::G / 2 : (AT_ == AT_I8 || A8) ? T::G / 4 : T::G / 2;
@@ -376,7 +380,7 @@ __global__ void __launch_bounds__(1024) wq_gemv_kernel(const GemvArgs a) {
   const int nthreads = blockDim.x;      // 64 / 128 / 256: picked by the selector
   const int NW = nthreads >> 6;
   // K split (few-row shards): kw consecutive waves share a row group
-  const int kw = a.kw;
+  const int kw = P::KS ? a.kw : 1;                // folds away in the unsplit members
   int wslot = wave, kpart = 0, slots = NW;
   if (kw > 1) {
     wslot = (int)(((uint32_t)wave * a.kw_magic) >> 16);
@@ -684,7 +688,7 @@ __global__ void __launch_bounds__(1024) wq_gemv_kernel(const GemvArgs a) {
 
   int it_idx = 0;
   auto finish = [&](int rg_now) {
-    if constexpr (!AD && !AQ) {
+    if constexpr (P::KS) {
       if (kw > 1) {
         // the kw parts of a row group meet in LDS (double buffered: one barrier per row group) and are summed by part
         // 0 in part order - bit-identical from run to run, bit-exact for the integer members
@@ -811,7 +815,8 @@ __global__ void __launch_bounds__(1024) wq_gemv_kernel(const GemvArgs a) {
 typedef void (*gemv_fn)(const GemvArgs);
 
 static constexpr int kDirectTile = 101;   // pick_mb code of the M = 1 "activations direct" member
-static constexpr int kBatchTiles[] = {1, kDirectTile, kDirectTile + 1, kDirectTile + 2, 2, 4};
+static constexpr int kSplitTile = 200;    // + mb (1, 2): the K-split twins of the LDS-staged members
+static constexpr int kBatchTiles[] = {1, kDirectTile, kDirectTile + 1, kDirectTile + 2, 2, 4, kSplitTile + 1, kSplitTile + 2};
 
 template <int KIND, int LAYOUT, int AT, int MODE, int FLAGS>
 static gemv_fn pick_mb(int mb) {
@@ -822,6 +827,8 @@ static gemv_fn pick_mb(int mb) {
     case kDirectTile + 2: return wq_gemv_kernel<GemvPolicy<KIND, LAYOUT, AT, 2, MODE, FLAGS, 2, 2, true>>;
     case 2: return wq_gemv_kernel<GemvPolicy<KIND, LAYOUT, AT, 2, MODE, FLAGS>>;
     case 4: return wq_gemv_kernel<GemvPolicy<KIND, LAYOUT, AT, 4, MODE, FLAGS>>;
+    case kSplitTile + 1: return wq_gemv_kernel<GemvPolicy<KIND, LAYOUT, AT, 1, MODE, FLAGS, 2, 2, false, true>>;
+    case kSplitTile + 2: return wq_gemv_kernel<GemvPolicy<KIND, LAYOUT, AT, 2, MODE, FLAGS, 2, 2, false, true>>;
     default: return nullptr;
   }
 }

@@ -213,7 +213,7 @@ def test_k_split_rounding_members(N, K, kw, monkeypatch):
     assert np.array_equal(got.view(np.uint32), got2.view(np.uint32))
 
 
-@pytest.mark.parametrize("M", [1, 2, 4])
+@pytest.mark.parametrize("M", [1, 2])                # the K-split twins exist for the M <= 2 tiles (M >= 3 is MFMA territory)
 @pytest.mark.parametrize("zm", [None, "rescale", "quantized"])
 def test_k_split_batches_zero_modes_and_bias(M, zm, monkeypatch):
     monkeypatch.setenv("WQAA_GEMV_KW", "4")
