@@ -10,7 +10,12 @@ One JSON line on stdout (rank 0).
 A "step" is one decode pass over LAYERS synthetic decoder layers: each layer = the 7 linear GEMVs of a
 Llama-2-7B block (q,k,v,o: 4096x4096; gate,up: 11008x4096; down: 4096x11008), every layer with its
 own weight buffers, so a step streams LAYERS x 105 MB of distinct packed weights (> the 256 MiB
-Infinity Cache): the bytes really come from HBM.  The launches of a step are captured once into a
+Infinity Cache): the bytes really come from HBM.  The projections of a layer that read the same input -
+q/k/v and gate/up - go through `bitblas_amd.matmul_group` (wqaa_matmul_group: one launch per group, every
+member with its own packed tensors and output; the reference's integration fuses the same projections by
+concatenating their weights, integration/BitNet/modeling_bitnet.py:1433-1445), so a layer is 4 launches:
+{q,k,v}, o, {gate,up}, down.  `--no-groups` launches the 7 GEMVs one by one (also timed under
+`members["step_ungrouped"]`).  The launches of a step are captured once into a
 hipGraph (the GEMV is ~4-8 us: eager Python launches would measure the interpreter) and a step is
 one graph replay.  Inputs are resident in HBM before the timed region.
 value = algorithmic bytes moved per second by the whole job (GB/s).
@@ -365,6 +370,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-members", action="store_true")
     ap.add_argument("--eager", action="store_true", help="launch the step eagerly instead of replaying a hipGraph")
+    ap.add_argument("--no-groups", action="store_true", help="7 launches per layer instead of {q,k,v}, o, {gate,up}, down")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -391,7 +397,9 @@ def main():
     acts = {K: (torch.rand((1, K), device=device, generator=gen) - 0.5).to(torch.float16)
             for K in (4096, 11008)}
     step_bytes = args.layers * sum(algorithmic_bytes(1, N, K) for (_, N, K) in LLAMA2_7B_LINEARS)
-    launches_per_step = args.layers * len(LLAMA2_7B_LINEARS)
+    # launch structure of a layer: the projections that share an input form one group (one launch)
+    LAYER_GROUPS = [[0], [1], [2], [3], [4], [5], [6]] if args.no_groups else [[0, 1, 2], [3], [4, 5], [6]]
+    launches_per_step = args.layers * len(LAYER_GROUPS)
 
     # N > 1: every rank writes its column slice of a step into one of TWO staging buffers and the RCCL all-gather
     # of step i runs on RCCL's stream while step i+1 computes into the other buffer (a buffer is reused only after
@@ -403,16 +411,22 @@ def main():
         local_out = [torch.empty((args.layers, flat_n), dtype=torch.float16, device=device) for _ in range(n_slots)]
         gathered = [torch.empty((world * args.layers, flat_n), dtype=torch.float16, device=device) for _ in range(n_slots)]
 
-    def launch_layers(slot):
+    def launch_layers(slot, groups=None):
+        groups = LAYER_GROUPS if groups is None else groups
         stream = torch.cuda.current_stream(device).cuda_stream
         for li, layer in enumerate(layers):
-            off = 0
-            for (op, qw, sc, out) in layer:
-                A = acts[op.K]
-                dst = out if not dist_on else local_out[slot][li:li + 1, off:off + op.N]
-                op.lib.run(A.data_ptr(), qw.data_ptr(), None, sc.data_ptr(), None, None,
-                           dst.data_ptr(), 1, stream)
-                off += op.N
+            offs = np.cumsum([0] + [op.N for (op, _, _, _) in layer])
+            dsts = [out if not dist_on else local_out[slot][li:li + 1, offs[i]:offs[i] + op.N]
+                    for i, (op, _, _, out) in enumerate(layer)]
+            for grp in groups:
+                if len(grp) == 1:
+                    op, qw, sc, _ = layer[grp[0]]
+                    op.lib.run(acts[op.K].data_ptr(), qw.data_ptr(), None, sc.data_ptr(), None, None,
+                               dsts[grp[0]].data_ptr(), 1, stream)
+                else:
+                    ops = [layer[i][0] for i in grp]
+                    bitblas.matmul_group(ops, acts[ops[0].K], [(layer[i][1], layer[i][2]) for i in grp],
+                                         outputs=[dsts[i] for i in grp])
 
     # The collective rides in the hipGraph: the graph of a step forks a side stream that all-gathers the PREVIOUS
     # step's staging buffer while the main branch runs this step's GEMVs into the other one, then joins.  One graph
@@ -536,6 +550,10 @@ def main():
         avg_bytes = step_bytes / launches_per_step
         achieved = avg_bytes / avg_launch_s / 1e9
         kernel_name = layers[0][0][0].plans[1]["name"].replace("m1n4096k4096", "m1")
+        from bitblas_amd import group_plan
+        group_names = [("+".join(LLAMA2_7B_LINEARS[i][0] for i in grp),
+                        (group_plan([layers[0][i][0] for i in grp], 1)["plan"] or layers[0][grp[0]][0].plans[1])["name"])
+                       for grp in LAYER_GROUPS]
         result = {
             "metric": "achieved HBM GB/s of the W_int4 A_fp16 GEMV at M=1, Llama-2-7B linear shapes, g=128 "
                       "(+ TFLOP/s of the M=4096 MFMA GEMM under `members`)",
@@ -543,8 +561,12 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f16", "data": "synthetic",
             "config": {"workload": f"W_int4 A_fp16 GEMV M=1, Llama-2-7B linears (N,K in {{4096,11008}}), g=128: "
-                                   f"{args.layers} layers x 7 GEMV per step per GPU, "
-                                   f"{'one hipGraph replay per step' if graph is not None else 'eager launches'}",
+                                   f"{args.layers} layers x 7 GEMV per step per GPU"
+                                   + (", 7 launches per layer, " if args.no_groups else
+                                      " in 4 launches per layer ({q,k,v}, o, {gate,up}, down: wqaa_matmul_group runs the projections "
+                                      "that share an input as one launch, each with its own packed tensors and output), ")
+                                   + f"{'one hipGraph replay per step' if graph is not None else 'eager launches'}",
+                       "launches": {k: v for k, v in group_names},
                        "launches_per_step": launches_per_step, "bytes_per_step_per_gpu": step_bytes,
                        "sharding": (f"column (N) shard per rank + 1 RCCL all-gather per step ({gather_mode}: " +
                                     {"serial": "captured at the end of the step's hipGraph",
@@ -554,7 +576,8 @@ def main():
                        if dist_on else "none"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(),
-                         "kernel": "wq_gemvx_kernel<int4, lop3, scale, mb1> (" + kernel_name + ")",
+                         "kernel": "wq_gemvx_kernel<int4, lop3, scale, mb1> (every launch of the step: " +
+                                   ", ".join(sorted({v for _, v in group_names})) + ")",
                          "numerics": "strict_reference=False: exact products, group scale on fp32 partial sums (1e-3 contract vs the "
                                      "reference definition: tests/test_gemvx_gpu.py); the per-element-rounding members are timed "
                                      "under members[*_strict]",
@@ -564,6 +587,15 @@ def main():
         }
         if not args.no_members and world == 1:
             members = {}
+            if not args.no_groups:
+                # the same step with every GEMV as its own launch (7 per layer): what the grouping buys
+                flat = [[i] for i in range(len(LLAMA2_7B_LINEARS))]
+                t_step = graph_time(device, lambda: launch_layers(0, flat), 1)
+                members["step_ungrouped"] = {
+                    "workload": "the headline step, 7 launches per layer", "us_per_step": t_step * 1e6,
+                    "GBps": step_bytes / t_step / 1e9, "frac_of_hbm_peak": step_bytes / t_step / 1e9 / HBM_PEAK_GBS,
+                    "roofline": {"bound": "hbm", "achieved": step_bytes / t_step / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": step_bytes / t_step / 1e9 / HBM_PEAK_GBS}}
             for (N, K) in ((4096, 4096), (11008, 4096), (4096, 11008), (12288, 4096)):     # c2 shapes
                 members[f"gemv_int4_n{N}k{K}"] = time_member_gemv(device, gen, N, K)
                 members[f"gemv_int4_n{N}k{K}_strict"] = time_member_gemv(device, gen, N, K, strict=True)

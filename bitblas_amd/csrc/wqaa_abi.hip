@@ -13,6 +13,7 @@
 #include <mutex>
 
 #include "wqaa_common.h"
+#include "wqaa_kinds.h"
 
 namespace wqaa {
 
@@ -220,6 +221,37 @@ static int matmul_impl(const wqaa_matmul_desc* desc, const void* A, const void* 
   return st;
 }
 
+// ---- groups (wqaa_matmul_group) ------------------------------------------------------------------------------------
+// A group fuses into one launch when every member has the same descriptor apart from N and the merged operator
+// (N = the sum of the members' rows) is served by a GEMV-family member at this m.  *fused_x: 1 = exact-product family.
+static bool group_fusable(const wqaa_matmul_desc* const* descs, int count, int m, wqaa_matmul_desc* merged, int* fused_x) {
+  if (count < 2 || count > WQAA_GROUP_MAX || m < 1 || m > 2) return false;
+  if (const char* f = getenv("WQAA_GROUP_FUSE")) { if (atoi(f) == 0) return false; }    // A/B aid: members launched one by one
+  long total = 0;
+  for (int i = 0; i < count; ++i) {
+    wqaa_matmul_desc a = *descs[i], b = *descs[0];
+    a.N = b.N = 0;
+    if (memcmp(&a, &b, sizeof(a)) != 0) return false;
+    total += descs[i]->N;
+  }
+  if (total > 0x7fffffffl) return false;
+  *merged = *descs[0];
+  merged->N = (int32_t)total;
+  bool use_gemm = false;
+  dispatch(*merged, m, &use_gemm);
+  if (use_gemm) return false;
+  const int saved = g_last_error;
+  char saved_msg[sizeof(g_last_error_msg)];
+  memcpy(saved_msg, g_last_error_msg, sizeof(saved_msg));
+  bool ok = true;
+  if (gemvx_group_eligible(*merged, count, m)) *fused_x = 1;
+  else if (gemv_group_eligible(*merged, count, m)) *fused_x = 0;
+  else ok = false;
+  g_last_error = saved;
+  memcpy(g_last_error_msg, saved_msg, sizeof(saved_msg));
+  return ok;
+}
+
 // ------------------------------------------------------------------------------------------
 // CPU weight packer: general_compress order (quantization/utils.py:54-70) + optional LOP3
 // interleave (lop3_permutate_impl.py:12-132).  One 32-bit word at a time.
@@ -295,6 +327,95 @@ int wqaa_matmul_opts(const wqaa_matmul_desc* desc, const void* A, const void* B,
     return WQAA_ERR_BAD_DESC;
   }
   return matmul_impl(desc, A, B, LUT, Scale, Zeros, Bias, C, m, stream, nullptr, nullptr, opts ? opts->epilogue : nullptr, opts);
+}
+
+int wqaa_group_plan(const wqaa_matmul_desc* const* descs, int count, int m, int* launches, wqaa_plan* plan) {
+  if (!descs || count < 1) {
+    set_error(WQAA_ERR_BAD_DESC, "group_plan: no members");
+    return WQAA_ERR_BAD_DESC;
+  }
+  for (int i = 0; i < count; ++i)
+    if (!valid_desc(descs[i])) return WQAA_ERR_BAD_DESC;
+  if (plan) memset(plan, 0, sizeof(*plan));
+  if (m <= 0) m = 1;
+  g_plan_epoch.fetch_add(1, std::memory_order_relaxed);
+  wqaa_matmul_desc merged;
+  int fx = 0;
+  if (!group_fusable(descs, count, m, &merged, &fx)) {
+    if (launches) *launches = count;
+    return WQAA_OK;                      // members run one by one: their own plans are wqaa_select's
+  }
+  if (launches) *launches = 1;
+  int Ns[WQAA_GROUP_MAX];
+  for (int i = 0; i < count; ++i) Ns[i] = descs[i]->N;
+  return fx ? gemvx_group_plan(merged, Ns, count, m, plan) : gemv_group_plan(merged, Ns, count, m, plan);
+}
+
+int wqaa_matmul_group(const wqaa_group_item* items, int count, int m, void* stream) {
+  if (!items || count < 0) {
+    set_error(WQAA_ERR_BAD_DESC, "matmul_group: bad arguments (items=%p count=%d)", (const void*)items, count);
+    return WQAA_ERR_BAD_DESC;
+  }
+  if (count == 0 || m == 0) return WQAA_OK;
+  const wqaa_matmul_desc* descs[WQAA_GROUP_MAX];
+  bool fuse = count >= 2 && count <= WQAA_GROUP_MAX && m >= 1 && m <= 2;
+  for (int i = 0; i < count && fuse; ++i) {
+    const wqaa_group_item& it = items[i];
+    if (!valid_desc(it.desc)) return WQAA_ERR_BAD_DESC;
+    // the per-member pointer checks of wqaa_matmul; a malformed member fails the whole group before anything is launched
+    if (!it.A || !it.B || !it.C || (it.desc->with_scaling && !it.Scale) || (it.desc->zeros_mode != WQAA_Z_NONE && !it.Zeros) ||
+        (it.desc->with_bias && !it.Bias) || (it.desc->w_format == WQAA_W_NF && !it.LUT)) {
+      set_error(WQAA_ERR_BAD_DESC, "matmul_group: member %d has a null operand its descriptor requires", i);
+      return WQAA_ERR_BAD_DESC;
+    }
+    descs[i] = it.desc;
+  }
+  if (fuse) {
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    StreamDeviceScope scope(s);
+    if (!device_info().ok) {
+      set_error(WQAA_ERR_NO_DEVICE, "no HIP device visible");
+      return WQAA_ERR_NO_DEVICE;
+    }
+    wqaa_matmul_desc merged;
+    int fx = 0;
+    bool ok;
+    {
+      // fusability per (merged descriptor, m, count): memoised like every tile choice
+      struct Fuse { int ok, fx; };
+      static thread_local ChoiceMemo<Fuse> memo;
+      wqaa_matmul_desc key = *descs[0];
+      long total = 0;
+      bool same = true;
+      for (int i = 0; i < count; ++i) {
+        wqaa_matmul_desc a = *descs[i], b = *descs[0];
+        a.N = b.N = 0;
+        same = same && memcmp(&a, &b, sizeof(a)) == 0;
+        total += descs[i]->N;
+      }
+      key.N = (int32_t)(total & 0x7fffffff);
+      const Fuse* hit = same ? memo.find(key, m, 32 + count) : nullptr;
+      if (hit) {
+        ok = hit->ok != 0;
+        fx = hit->fx;
+        merged = key;
+      } else {
+        ok = group_fusable(descs, count, m, &merged, &fx);
+        if (same) memo.put(key, m, 32 + count, Fuse{ok ? 1 : 0, fx});
+      }
+    }
+    if (ok) {
+      int st = fx ? gemvx_group_launch(merged, items, count, m, s) : gemv_group_launch(merged, items, count, m, s);
+      if (st == WQAA_OK) g_last_error = WQAA_OK;
+      return st;
+    }
+  }
+  for (int i = 0; i < count; ++i) {
+    const wqaa_group_item& it = items[i];
+    int st = matmul_impl(it.desc, it.A, it.B, it.LUT, it.Scale, it.Zeros, it.Bias, it.C, m, stream, nullptr, nullptr);
+    if (st != WQAA_OK) return st;
+  }
+  return WQAA_OK;
 }
 
 int wqaa_act_quant_int8(const void* X, int64_t rows, int K, void* Q, float* S, void* stream) {
@@ -405,6 +526,13 @@ int wqaa_debug_decode(const void* packed_dev, int64_t nwords, int w_format, int 
   }
   return debug_decode_launch(packed_dev, nwords, w_format, bits, layout, a_dtype, strict_reference,
                              lut_dev, out_dev, reinterpret_cast<hipStream_t>(stream));
+}
+
+void wqaa_debug_row_blocks(int b, int grid, int n_blocks, int* out3) {
+  const RowBlocks rb = xcd_row_blocks(b, grid, n_blocks);
+  out3[0] = rb.first;
+  out3[1] = rb.stride;
+  out3[2] = rb.end;
 }
 
 int wqaa_last_error(void) { return g_last_error; }

@@ -54,7 +54,14 @@ struct GemvArgs {
   int kw;               // 1, or a divisor of the workgroup's wave count
   uint32_t kw_magic;    // ceil(2^16 / kw): wave / kw without an integer division
   int spp;              // steps per part = ceil(steps / kw)
-  int it_count;         // row-group iterations of every workgroup (uniform: the parts meet behind a barrier)
+  int n_rgb;            // row-group blocks: ceil(ceil(N / R) / (waves / kw)) - what the workgroups share out (xcd_row_blocks)
+};
+
+// One launch serves up to kGemvGroupMax independent operators of one tile configuration (wqaa_matmul_group): blockIdx.z
+// names the operator, every operator gets gridDim.x x gridDim.y workgroups.  A single call is the group of one.
+constexpr int kGemvGroupMax = 8;
+struct GemvGroupArgs {
+  GemvArgs p[kGemvGroupMax];
 };
 
 struct LaunchCfg {
@@ -76,6 +83,13 @@ void gemv_init();
 
 // exact-product GEMV members (strict_reference = 0, sub-byte integer weights x float16, M <= 2)
 bool gemvx_eligible(const wqaa_matmul_desc& d, int m);
+// groups: `merged` = the members' descriptor with N = the sum of their rows (what selects the tile configuration)
+bool gemvx_group_eligible(const wqaa_matmul_desc& merged, int count, int m);
+int gemvx_group_plan(const wqaa_matmul_desc& merged, const int* Ns, int count, int m, wqaa_plan* plan);
+int gemvx_group_launch(const wqaa_matmul_desc& merged, const wqaa_group_item* items, int count, int m, hipStream_t stream);
+bool gemv_group_eligible(const wqaa_matmul_desc& merged, int count, int m);
+int gemv_group_plan(const wqaa_matmul_desc& merged, const int* Ns, int count, int m, wqaa_plan* plan);
+int gemv_group_launch(const wqaa_matmul_desc& merged, const wqaa_group_item* items, int count, int m, hipStream_t stream);
 int gemvx_plan(const wqaa_matmul_desc& d, int m, wqaa_plan* plan);
 int gemvx_launch(const wqaa_matmul_desc& d, const void* A, const void* B, const void* Scale, const void* Zeros,
                  const void* Bias, void* C, int m, hipStream_t stream, hipEvent_t start, hipEvent_t stop);

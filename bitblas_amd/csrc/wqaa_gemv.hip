@@ -28,7 +28,7 @@ struct GemvChoice {
   int E;
   int nc, ncp, cpr;
   int grid_x, grid_y, lds, threads, variant;
-  int kw, spp, it_count;      // K split across the waves of a workgroup (1 = none)
+  int kw, spp;                // K split across the waves of a workgroup (1 = none)
   int fp4_table;
   int a_fmt;
 };
@@ -231,7 +231,6 @@ static int choose(const wqaa_matmul_desc& d, int m, GemvChoice* c, bool quant_in
   if (blocks >= 8) blocks = (blocks + 7) / 8 * 8;   // whole XCD rounds: keeps the block swizzle on
   c->grid_x = blocks;
   c->grid_y = (m + mb - 1) / mb;
-  c->it_count = ((n_rg + rg_per_block - 1) / rg_per_block + blocks - 1) / blocks;   // uniform per workgroup (kw > 1)
   return WQAA_OK;
 }
 
@@ -269,7 +268,10 @@ static void fill_args(const wqaa_matmul_desc& d, const GemvChoice& c, const void
   a->kw = c.kw;
   a->kw_magic = (65536u + (uint32_t)c.kw - 1u) / (uint32_t)c.kw;
   a->spp = c.kw > 1 ? c.spp : 0;
-  a->it_count = c.it_count;
+  {
+    const int rg_per_block = (c.threads / 64) / c.kw;
+    a->n_rgb = ((d.N + c.R - 1) / c.R + rg_per_block - 1) / rg_per_block;
+  }
 }
 
 int gemv_plan(const wqaa_matmul_desc& d, int m, wqaa_plan* plan) {
@@ -299,6 +301,23 @@ int gemv_plan(const wqaa_matmul_desc& d, int m, wqaa_plan* plan) {
   return WQAA_OK;
 }
 
+static int gemv_dispatch(const GemvChoice& c, GemvGroupArgs& ga, int grid_x, int count, hipStream_t stream, hipEvent_t start,
+                         hipEvent_t stop) {
+  void* params[] = {&ga};
+  dim3 grid(grid_x, c.grid_y, count), block(c.threads, 1, 1);
+  hipError_t e;
+  if (start || stop) {
+    e = hipExtLaunchKernel(reinterpret_cast<const void*>(c.fn), grid, block, params, c.lds, stream, start, stop, 0);
+  } else {
+    e = hipLaunchKernel(reinterpret_cast<const void*>(c.fn), grid, block, params, c.lds, stream);
+  }
+  if (e != hipSuccess) {
+    set_error(WQAA_ERR_LAUNCH, "gemv launch failed: %s", hipGetErrorString(e));
+    return WQAA_ERR_LAUNCH;
+  }
+  return WQAA_OK;
+}
+
 int gemv_launch(const wqaa_matmul_desc& d, const void* A, const void* B, const void* LUT,
                 const void* Scale, const void* Zeros, const void* Bias, void* C, int m,
                 hipStream_t stream, hipEvent_t start, hipEvent_t stop, const wqaa_epilogue* epi) {
@@ -315,7 +334,8 @@ int gemv_launch(const wqaa_matmul_desc& d, const void* A, const void* B, const v
       memo.put(d, m, q, c);
     }
   }
-  GemvArgs a;
+  GemvGroupArgs ga;
+  GemvArgs& a = ga.p[0];
   fill_args(d, c, A, B, LUT, Scale, Zeros, Bias, C, m, &a);
   if (epi) {
     if (!at_is_int(c.at) || d.out_dtype != WQAA_F16) {
@@ -325,19 +345,69 @@ int gemv_launch(const wqaa_matmul_desc& d, const void* A, const void* B, const v
     a.epi_row = epi->row_scale;
     a.epi_tensor = epi->tensor_scale;
   }
-  void* params[] = {&a};
-  dim3 grid(c.grid_x, c.grid_y, 1), block(c.threads, 1, 1);
-  hipError_t e;
-  if (start || stop) {
-    e = hipExtLaunchKernel(reinterpret_cast<const void*>(c.fn), grid, block, params, c.lds, stream, start, stop, 0);
-  } else {
-    e = hipLaunchKernel(reinterpret_cast<const void*>(c.fn), grid, block, params, c.lds, stream);
+  return gemv_dispatch(c, ga, c.grid_x, 1, stream, start, stop);
+}
+
+// ---- a group of independent operators in one launch (wqaa_matmul_group): tile configuration of the MERGED operator
+// (N = the sum of the members' rows), every member takes gridDim.x x gridDim.y workgroups of it (blockIdx.z = member) ----
+static int gemv_group_choose(const wqaa_matmul_desc& merged, const int* Ns, int count, int m, GemvChoice* c, int* grid_x) {
+  {
+    static thread_local ChoiceMemo<GemvChoice> memo;
+    if (const GemvChoice* hit = memo.find(merged, m, 16 + count)) {
+      *c = *hit;
+    } else {
+      int st = choose(merged, m, c);
+      if (st != WQAA_OK) return st;
+      memo.put(merged, m, 16 + count, *c);
+    }
   }
-  if (e != hipSuccess) {
-    set_error(WQAA_ERR_LAUNCH, "gemv launch failed: %s", hipGetErrorString(e));
-    return WQAA_ERR_LAUNCH;
+  const int rg_per_block = (c->threads / 64) / c->kw;
+  int need = 1;
+  for (int i = 0; i < count; ++i) {
+    const int blocks = ((Ns[i] + c->R - 1) / c->R + rg_per_block - 1) / rg_per_block;
+    if (blocks > need) need = blocks;
   }
+  int gx = c->grid_x / count;            // the merged operator's grid (capped at what the chip holds), shared between the members
+  if (gx < 1) gx = 1;
+  if (gx > need) gx = need;
+  if (gx >= 8) gx = (gx + 7) / 8 * 8;
+  *grid_x = gx;
   return WQAA_OK;
+}
+
+bool gemv_group_eligible(const wqaa_matmul_desc& merged, int count, int m) {
+  if (count < 1 || count > kGemvGroupMax || m < 1 || m > 2) return false;
+  GemvChoice c;
+  return choose(merged, m, &c) == WQAA_OK;      // (the caller restores the error side channel)
+}
+
+int gemv_group_plan(const wqaa_matmul_desc& merged, const int* Ns, int count, int m, wqaa_plan* plan) {
+  GemvChoice c;
+  int gx = 0;
+  int st = gemv_group_choose(merged, Ns, count, m, &c, &gx);
+  if (st != WQAA_OK) return st;
+  st = gemv_plan(merged, m, plan);
+  if (st == WQAA_OK && plan) {
+    plan->grid = gx * c.grid_y * count;
+    char tail[16];
+    snprintf(tail, sizeof(tail), "_x%d", count);
+    strncat(plan->name, tail, sizeof(plan->name) - strlen(plan->name) - 1);
+  }
+  return st;
+}
+
+int gemv_group_launch(const wqaa_matmul_desc& merged, const wqaa_group_item* items, int count, int m, hipStream_t stream) {
+  int Ns[kGemvGroupMax];
+  for (int i = 0; i < count; ++i) Ns[i] = items[i].desc->N;
+  GemvChoice c;
+  int gx = 0;
+  int st = gemv_group_choose(merged, Ns, count, m, &c, &gx);
+  if (st != WQAA_OK) return st;
+  GemvGroupArgs ga;
+  for (int i = 0; i < count; ++i)
+    fill_args(*items[i].desc, c, items[i].A, items[i].B, items[i].LUT, items[i].Scale, items[i].Zeros, items[i].Bias, items[i].C, m,
+              &ga.p[i]);
+  return gemv_dispatch(c, ga, gx, count, stream, nullptr, nullptr);
 }
 
 void gemv_init() {

@@ -360,8 +360,9 @@ __device__ __forceinline__ void decode_unit_i8(const u32x4& w, int u, uint32_t z
 // the kernel
 // ------------------------------------------------------------------------------------------
 template <class P>
-__global__ void __launch_bounds__(1024) wq_gemv_kernel(const GemvArgs a) {
+__global__ void __launch_bounds__(1024) wq_gemv_kernel(const GemvGroupArgs grp) {
   using T = typename P::T;
+  const GemvArgs a = grp.p[blockIdx.z];          // kernel-argument segment, indexed by a dispatch-time scalar
   constexpr int R = P::R, MB = P::MB, D = P::D, NA = P::NA, MODE = P::MODE;
   constexpr int E = T::E, G = T::G, PU = T::PU, UNITS = T::UNITS, PIECES = T::PIECES;
   constexpr bool F16 = P::AT == AT_F16;
@@ -387,12 +388,11 @@ __global__ void __launch_bounds__(1024) wq_gemv_kernel(const GemvArgs a) {
     kpart = wave - wslot * kw;
     slots = (int)(((uint32_t)NW * a.kw_magic) >> 16);
   }
-  const int total_waves = gridDim.x * slots;     // row groups in flight on the chip
-  // XCD-aware block order (block b runs on XCD b % 8): every XCD owns a contiguous range of rows,
-  // so the 2-byte results that share a 128-byte line of C are written through one L2
-  int blk = blockIdx.x;
-  if ((gridDim.x & 7) == 0) blk = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
-  const int wg = blk * slots + wslot;
+  // this workgroup's row-group blocks (XCD-aware, wqaa_kinds.h); a workgroup without one leaves before any load
+  const RowBlocks rb = xcd_row_blocks((int)blockIdx.x, (int)gridDim.x, a.n_rgb);
+  if (rb.first >= rb.end) return;
+  const int wg = rb.first * slots + wslot;
+  const int rg_step = rb.stride * slots;
   const int m0 = blockIdx.y * MB;
   const uint8_t* Bp = reinterpret_cast<const uint8_t*>(a.B);
   const uint16_t* Sp = reinterpret_cast<const uint16_t*>(a.scale);
@@ -793,7 +793,8 @@ __global__ void __launch_bounds__(1024) wq_gemv_kernel(const GemvArgs a) {
   // first step was issued before the barrier; later steps are issued right after the previous
   // step's registers are consumed
   int c0 = c_lo;
-  int it_left = a.it_count;
+  int it_left = 1;                                 // blocks of this workgroup (uniform: the K-split parts meet behind a barrier)
+  if (rb.first + rb.stride < rb.end) it_left = (rb.end - rb.first + rb.stride - 1) / rb.stride;
   while (true) {
 #pragma unroll
     for (int d = 0; d < D; ++d) consume(st[d], c0 + d, rg);
@@ -801,8 +802,8 @@ __global__ void __launch_bounds__(1024) wq_gemv_kernel(const GemvArgs a) {
     if (c0 >= c_hi) {
       finish(rg);
       c0 = c_lo;
-      rg += total_waves;
-      if (kw > 1 ? (--it_left <= 0) : (rg >= n_rg)) break;
+      rg += rg_step;
+      if (--it_left <= 0 || (kw == 1 && rg >= n_rg)) break;
     }
     issue(st, rg, c0, false);   // AD members: K fits one step, the activation registers stay as loaded
   }
@@ -812,7 +813,7 @@ __global__ void __launch_bounds__(1024) wq_gemv_kernel(const GemvArgs a) {
 // member tables.  The family is instantiated in wqaa_gemv_inst_*.hip, one translation unit per group of members
 // (parallel builds; a probe can include this header and instantiate a single member in seconds).
 // ------------------------------------------------------------------------------------------
-typedef void (*gemv_fn)(const GemvArgs);
+typedef void (*gemv_fn)(const GemvGroupArgs);
 
 static constexpr int kDirectTile = 101;   // pick_mb code of the M = 1 "activations direct" member
 static constexpr int kSplitTile = 200;    // + mb (1, 2): the K-split twins of the LDS-staged members

@@ -177,21 +177,10 @@ int gemvx_plan(const wqaa_matmul_desc& d, int m, wqaa_plan* plan) {
   return WQAA_OK;
 }
 
-int gemvx_launch(const wqaa_matmul_desc& d, const void* A, const void* B, const void* Scale, const void* Zeros,
-                 const void* Bias, void* C, int m, hipStream_t stream, hipEvent_t start, hipEvent_t stop) {
-  GemvxChoice c;
-  {
-    static thread_local ChoiceMemo<GemvxChoice> memo;
-    if (const GemvxChoice* hit = memo.find(d, m, 7)) {
-      c = *hit;
-    } else {
-      int st = gemvx_choose(d, m, &c);
-      if (st != WQAA_OK) return st;
-      memo.put(d, m, 7, c);
-    }
-  }
+static void gemvx_fill(const wqaa_matmul_desc& d, const GemvxChoice& c, const void* A, const void* B, const void* Scale,
+                       const void* Zeros, const void* Bias, void* C, int m, GemvxArgs* out) {
   const int g = d.group_size <= 0 ? d.K : d.group_size;
-  GemvxArgs a;
+  GemvxArgs& a = *out;
   a.A = A; a.B = B; a.scale = Scale; a.zeros = Zeros; a.bias = Bias; a.C = C;
   a.m = m; a.N = d.N; a.K = d.K;
   a.kg = d.K / g;
@@ -208,11 +197,16 @@ int gemvx_launch(const wqaa_matmul_desc& d, const void* A, const void* B, const 
   a.zint = is_signed ? (c.bits == 1 ? 1 : (1 << (c.bits - 1))) : 0;
   a.flip = (is_signed && c.bits == 1) ? 0xFFFFFFFFu : 0u;
   a.zq_row_bytes = d.N * c.bits / 8;
-  a.n_rgb = c.n_rgb;
-  a.slots = c.nw / c.kw;
+  const int slots = c.nw / c.kw;
+  a.n_rgb = ((d.N + c.R - 1) / c.R + slots - 1) / slots;
+  a.slots = slots;
   a.kw_magic = (65536u + (uint32_t)c.kw - 1u) / (uint32_t)c.kw;
-  void* params[] = {&a};
-  dim3 grid(c.grid, 1, 1), block(c.nw * 64, 1, 1);
+}
+
+static int gemvx_dispatch(const GemvxChoice& c, GemvxGroupArgs& ga, int grid_x, int count, hipStream_t stream, hipEvent_t start,
+                          hipEvent_t stop) {
+  void* params[] = {&ga};
+  dim3 grid(grid_x, count, 1), block(c.nw * 64, 1, 1);
   hipError_t e;
   if (start || stop) e = hipExtLaunchKernel(reinterpret_cast<const void*>(c.fn), grid, block, params, c.lds, stream, start, stop, 0);
   else e = hipLaunchKernel(reinterpret_cast<const void*>(c.fn), grid, block, params, c.lds, stream);
@@ -221,6 +215,85 @@ int gemvx_launch(const wqaa_matmul_desc& d, const void* A, const void* B, const 
     return WQAA_ERR_LAUNCH;
   }
   return WQAA_OK;
+}
+
+int gemvx_launch(const wqaa_matmul_desc& d, const void* A, const void* B, const void* Scale, const void* Zeros,
+                 const void* Bias, void* C, int m, hipStream_t stream, hipEvent_t start, hipEvent_t stop) {
+  GemvxChoice c;
+  {
+    static thread_local ChoiceMemo<GemvxChoice> memo;
+    if (const GemvxChoice* hit = memo.find(d, m, 7)) {
+      c = *hit;
+    } else {
+      int st = gemvx_choose(d, m, &c);
+      if (st != WQAA_OK) return st;
+      memo.put(d, m, 7, c);
+    }
+  }
+  GemvxGroupArgs ga;
+  gemvx_fill(d, c, A, B, Scale, Zeros, Bias, C, m, &ga.p[0]);
+  return gemvx_dispatch(c, ga, c.grid, 1, stream, start, stop);
+}
+
+// ---- a group of independent operators in one launch (wqaa_matmul_group) -------------------------------------------------
+// The tile configuration is the one the selector gives the MERGED operator (N = sum of the members' rows: what a caller
+// that concatenates q/k/v or gate/up into one Linear would get); every member then takes gridDim.x workgroups of it.
+static int gemvx_group_choose(const wqaa_matmul_desc& merged, const int* Ns, int count, int m, GemvxChoice* c, int* grid_x) {
+  {
+    static thread_local ChoiceMemo<GemvxChoice> memo;
+    if (const GemvxChoice* hit = memo.find(merged, m, 16 + count)) {
+      *c = *hit;
+    } else {
+      int st = gemvx_choose(merged, m, c);
+      if (st != WQAA_OK) return st;
+      memo.put(merged, m, 16 + count, *c);
+    }
+  }
+  const int slots = c->nw / c->kw;
+  int need = 1;
+  for (int i = 0; i < count; ++i) {
+    const int n_rgb = ((Ns[i] + c->R - 1) / c->R + slots - 1) / slots;
+    if (n_rgb > need) need = n_rgb;
+  }
+  // c->grid: the merged operator's grid (capped at the workgroups the chip holds at once); share it between the members
+  int gx = c->grid / count;
+  if (gx < 1) gx = 1;
+  if (gx > need) gx = need;
+  if (gx >= 8) gx = (gx + 7) / 8 * 8;                 // whole XCD rounds per member: blockIdx.x % 8 stays the XCD
+  *grid_x = gx;
+  return WQAA_OK;
+}
+
+bool gemvx_group_eligible(const wqaa_matmul_desc& merged, int count, int m) {
+  return count >= 1 && count <= kGemvxGroupMax && gemvx_eligible(merged, m);
+}
+
+int gemvx_group_plan(const wqaa_matmul_desc& merged, const int* Ns, int count, int m, wqaa_plan* plan) {
+  GemvxChoice c;
+  int gx = 0;
+  int st = gemvx_group_choose(merged, Ns, count, m, &c, &gx);
+  if (st != WQAA_OK) return st;
+  st = gemvx_plan(merged, m, plan);
+  if (st == WQAA_OK && plan) {
+    plan->grid = gx * count;
+    char tail[16];
+    snprintf(tail, sizeof(tail), "_x%d", count);
+    strncat(plan->name, tail, sizeof(plan->name) - strlen(plan->name) - 1);
+  }
+  return st;
+}
+
+int gemvx_group_launch(const wqaa_matmul_desc& merged, const wqaa_group_item* items, int count, int m, hipStream_t stream) {
+  int Ns[kGemvxGroupMax];
+  for (int i = 0; i < count; ++i) Ns[i] = items[i].desc->N;
+  GemvxChoice c;
+  int gx = 0;
+  int st = gemvx_group_choose(merged, Ns, count, m, &c, &gx);
+  if (st != WQAA_OK) return st;
+  GemvxGroupArgs ga;
+  for (int i = 0; i < count; ++i)
+    gemvx_fill(*items[i].desc, c, items[i].A, items[i].B, items[i].Scale, items[i].Zeros, items[i].Bias, items[i].C, m, &ga.p[i]);
+  return gemvx_dispatch(c, ga, gx, count, stream, nullptr, nullptr);
 }
 
 void gemvx_init() {

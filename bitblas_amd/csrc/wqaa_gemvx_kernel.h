@@ -60,6 +60,16 @@ struct GemvxArgs {
   uint32_t kw_magic;  // ceil(2^16 / kw): x / kw == (x * kw_magic) >> 16 for x < 4096 (no integer division in the prologue)
 };
 
+// One launch serves up to kGemvxGroupMax INDEPENDENT operators of one tile configuration (wqaa_matmul_group: the q/k/v
+// or gate/up projections of a decoder layer - same K and format, their own N and pointers): blockIdx.y names the
+// operator, every operator gets gridDim.x workgroups (those beyond its row-group blocks leave at once).  The launch
+// boundary (~1.3 us) and the load ramp / decode tail of a 4 us GEMV are paid once instead of per operator.  A single
+// call is the group of one (gridDim.y = 1): the same kernels, the same code path.
+constexpr int kGemvxGroupMax = 8;
+struct GemvxGroupArgs {
+  GemvxArgs p[kGemvxGroupMax];
+};
+
 // ABL_: ablation bits for tools/ (lab members only, never selected by the library): 1 = loads consumed by one XOR
 // instead of the decode + dot, 2 = no activation staging / barrier, 4 = no wave reduction / store, 8 = no store
 // AREG_: the lane keeps the activations of its own lane chunks in registers (4-bit LOP3 weights, M = 1, K within one
@@ -97,8 +107,9 @@ __device__ __forceinline__ float wave_sum_l63(float v) {
 }
 
 template <class P>
-__global__ void __launch_bounds__(1024) wq_gemvx_kernel(const GemvxArgs a) {
+__global__ void __launch_bounds__(1024) wq_gemvx_kernel(const GemvxGroupArgs grp) {
   using T = typename P::T;
+  const GemvxArgs a = grp.p[blockIdx.y];         // kernel-argument segment, indexed by a dispatch-time scalar
   constexpr int R = P::R, MB = P::MB, D = P::D, MODE = P::MODE, BITS = P::BITS;
   constexpr int EPW = P::EPW, NPAIR = P::NPAIR, NCLS = P::NCLS, E = P::E, PIECES = P::PIECES, PPW = P::PPW;
   constexpr int ZPB = 8 / BITS;                  // quantized zero points per byte
@@ -132,21 +143,19 @@ __global__ void __launch_bounds__(1024) wq_gemvx_kernel(const GemvxArgs a) {
   const uint8_t* Qp = reinterpret_cast<const uint8_t*>(a.zeros);
   const int n_rg = (a.N + R - 1) / R;
 
-  // XCD-aware block order (block b runs on XCD b % 8): an XCD owns a contiguous range of rows, so the 2-byte results
-  // that share a 128-byte line of C are written through one L2.  Workgroup b works on row-group blocks b, b + grid, ...
-  // (many small workgroups and the hardware dispatcher balance better than one persistent workgroup per CU: measured)
-  int blk = blockIdx.x;
-  if ((gridDim.x & 7) == 0) blk = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
-  int iters;                                                   // uniform over the workgroup
-  if ((int)gridDim.x >= a.n_rgb) iters = blk < a.n_rgb ? 1 : 0;        // the usual case: one block per workgroup, no division
-  else iters = blk < a.n_rgb ? (a.n_rgb - blk + (int)gridDim.x - 1) / (int)gridDim.x : 0;
+  // this workgroup's row-group blocks rb.first, rb.first + rb.stride, ... < rb.end (XCD-aware, wqaa_kinds.h; many small
+  // workgroups and the hardware dispatcher balance better than one persistent workgroup per CU: measured)
+  const RowBlocks rb = xcd_row_blocks((int)blockIdx.x, (int)gridDim.x, a.n_rgb);
+  if (rb.first >= rb.end) return;                              // grid padding / a shorter operator of a group: nothing to load
+  int iters = 1;                                               // uniform over the workgroup; the usual case: one block, no division
+  if (rb.first + rb.stride < rb.end) iters = (rb.end - rb.first + rb.stride - 1) / rb.stride;
   const int total = iters * nmy;                               // (row group, step) positions of this wave
 
   struct Stage {
     u32x4 w[R];
     uint32_t s[R], z[R];
   };
-  auto rg_of = [&](int it) { return (blk + it * (int)gridDim.x) * slots + rgl; };
+  auto rg_of = [&](int it) { return (rb.first + it * rb.stride) * slots + rgl; };
   // weight loads of chunk d of position (it, si) = (it-th row-group block of this workgroup, si-th own step): unconditional
   auto issue = [&](Stage& st, int it, int si, int d) {
     int rg = rg_of(it);
@@ -501,7 +510,7 @@ __global__ void __launch_bounds__(1024) wq_gemvx_kernel(const GemvxArgs a) {
   }
 }
 
-typedef void (*gemvx_fn)(const GemvxArgs);
+typedef void (*gemvx_fn)(const GemvxGroupArgs);
 
 // member tables: wqaa_gemvx_inst_*.hip.  rd code = R * 10 + D
 template <int BITS, int LAYOUT, int MODE, int MB>

@@ -19,6 +19,23 @@ enum : int { FL_STRICT = 1, FL_A8 = 2, FL_ABF8 = 4, FL_BF16 = 8, FL_AQ = 16 };  
 
 constexpr int cmax(int a, int b) { return a > b ? a : b; }
 
+// Which row-group blocks a GEMV workgroup works on: first, first + stride, ... < end.
+// XCD-aware (workgroup b runs on XCD b % 8): every XCD owns a CONTIGUOUS eighth of the blocks - the 2-byte results that
+// share a 128-byte line of C are written through one L2 - and its gridDim.x / 8 workgroups stride over that eighth, so
+// a grid smaller than the block count (the chip holds only so many workgroups) or larger than it (a short member of a
+// group launch) still loads the eight XCDs evenly.  With gridDim.x = the block count rounded up to 8 this is the plain
+// swizzle blk = (b & 7) * (gridDim.x >> 3) + (b >> 3), one block per workgroup.
+struct RowBlocks {
+  int first, stride, end;
+};
+__host__ __device__ __forceinline__ RowBlocks xcd_row_blocks(int b, int grid, int n_blocks) {
+  if (grid & 7) return RowBlocks{b, grid, n_blocks};
+  const int chunk = (n_blocks + 7) >> 3;
+  const int lo = (b & 7) * chunk;
+  const int hi = lo + chunk < n_blocks ? lo + chunk : n_blocks;
+  return RowBlocks{lo + (b >> 3), grid >> 3, hi};
+}
+
 template <int KIND, int AT>
 struct KindTraits {
   static constexpr int BITS = (KIND == DK_INT4 || KIND == DK_LUT4) ? 4

@@ -1,0 +1,206 @@
+"""Groups of independent operators in one launch: `matmul_group`, `LinearGroup`.
+
+The reference runs the projections of a decoder layer that share an input as separate operator calls, or fuses them by
+concatenating their weights along N before quantisation (integration/BitNet/modeling_bitnet.py:
+`BitnetAttentionQKVFused.from_bit_attention` :496-517, `BitnetMLPFuseGateUp.from_bit_mlp` :271-280, on by default in
+`quantize(fuse_qkv=True, fuse_gateup=True)` :1433-1445).  On MI355X a dependent kernel boundary costs ~1.3 us against
+~4 us for a whole 4096 x 4096 int4 GEMV, so at decode batch sizes the boundaries are a third of a layer.
+`wqaa_matmul_group` (include/wqaa.h) is the launch-level form of the same fusion: the members keep their own packed
+tensors (no re-quantisation, no concatenated copy, q/k/v of different widths are fine) and run as ONE kernel launch
+whenever they share a GEMV tile configuration (same K / dtypes / format / group size / flags, M <= 2); anything else
+runs member by member in order, so the call is always equivalent to calling each operator in turn - bit for bit
+(tests/test_group_gpu.py).
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import List, Optional, Sequence, Union
+
+import torch
+
+from . import lib as _lib
+from .matmul import Matmul
+
+GROUP_MAX = 8
+
+
+class GroupItem(ctypes.Structure):
+    """struct wqaa_group_item (include/wqaa.h)."""
+    _fields_ = [("desc", ctypes.POINTER(_lib.MatmulDesc)), ("A", ctypes.c_void_p), ("B", ctypes.c_void_p),
+                ("LUT", ctypes.c_void_p), ("Scale", ctypes.c_void_p), ("Zeros", ctypes.c_void_p),
+                ("Bias", ctypes.c_void_p), ("C", ctypes.c_void_p)]
+
+
+_bound = False
+
+
+def _library():
+    global _bound
+    lib = _lib.load_library()
+    if not _bound:
+        lib.wqaa_matmul_group.restype = ctypes.c_int
+        lib.wqaa_matmul_group.argtypes = [ctypes.POINTER(GroupItem), ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+        lib.wqaa_group_plan.restype = ctypes.c_int
+        lib.wqaa_group_plan.argtypes = [ctypes.POINTER(ctypes.POINTER(_lib.MatmulDesc)), ctypes.c_int, ctypes.c_int,
+                                        ctypes.POINTER(ctypes.c_int), ctypes.POINTER(_lib.Plan)]
+        _bound = True
+    return lib
+
+
+def group_plan(ops: Sequence[Matmul], m: int = 1) -> dict:
+    """How a group of operators would run at `m` rows: {"launches": 1 (fused) | len(ops), "plan": {...} | None}.
+    Needs no device."""
+    lib = _library()
+    n = len(ops)
+    descs = (ctypes.POINTER(_lib.MatmulDesc) * n)(*[ctypes.pointer(op.lib.desc) for op in ops])
+    launches = ctypes.c_int(0)
+    plan = _lib.Plan()
+    _lib.check(lib.wqaa_group_plan(descs, n, int(m), ctypes.byref(launches), ctypes.byref(plan)))
+    return {"launches": launches.value, "plan": plan.as_dict() if launches.value == 1 and n > 1 else None}
+
+
+def _as_list(x, n, what):
+    if isinstance(x, torch.Tensor) or x is None:
+        return [x] * n
+    x = list(x)
+    if len(x) != n:
+        raise ValueError(f"{what}: expected {n} entries, got {len(x)}")
+    return x
+
+
+def matmul_group(ops: Sequence[Matmul], A: Union[torch.Tensor, Sequence[torch.Tensor]], weights: Sequence,
+                 outputs: Optional[Sequence[Optional[torch.Tensor]]] = None) -> List[torch.Tensor]:
+    """`[op(A_i, *weights_i) for op in ops]` with as few launches as the library can do it in.
+
+    ops      the operators (every member must have been built for the row count of its A);
+    A        one tensor shared by all members, or one per member (all with the same row count);
+    weights  per member the arguments of `Matmul.forward` after A: `W` or `(W, scale, zeros, bias)` (trailing ones optional);
+    outputs  optional preallocated outputs (contiguous, on A's device); they must not overlap.
+    Asynchronous on the current stream of A's device, like `Matmul.forward`."""
+    n = len(ops)
+    if n == 0:
+        return []
+    if len(weights) != n:
+        raise ValueError(f"weights: expected {n} entries, got {len(weights)}")
+    As = _as_list(A, n, "A")
+    outs = _as_list(outputs, n, "outputs") if outputs is not None else [None] * n
+    items = (GroupItem * n)()
+    m = None
+    keep = []
+    dev = As[0].device
+    for i, (op, a, w) in enumerate(zip(ops, As, weights)):
+        mi = op.check_activation(a)
+        if m is None:
+            m = mi
+        elif mi != m:
+            raise ValueError(f"member {i} has {mi} activation rows, member 0 has {m}: a group shares one row count")
+        if a.device != dev:
+            raise ValueError("all members of a group run on one device")
+        if not a.is_contiguous():
+            a = a.contiguous()
+        w = (w,) if isinstance(w, torch.Tensor) else tuple(w)
+        W, scale, zeros, bias = (w + (None,) * 4)[:4]
+        if W.numel() * W.element_size() != op._w_bytes:
+            raise ValueError(f"member {i}: W holds {W.numel() * W.element_size()} bytes, the operator expects {op._w_bytes} "
+                             f"(shape {op.retrieve_weight_shape()}: run transform_weight first)")
+        out = outs[i]
+        if out is None:
+            out = torch.empty(a.shape[:-1] + (op.N,), dtype=op.torch_output_dtype, device=a.device)
+        elif not out.is_contiguous() or out.device != a.device:
+            raise ValueError("outputs must be contiguous tensors on A's device")
+        outs[i] = out
+        lut = op._ensure_lut(a.device)
+        keep.append((a, lut))
+        it = items[i]
+        it.desc = ctypes.pointer(op.lib.desc)
+        it.A, it.B, it.C = a.data_ptr(), W.data_ptr(), out.data_ptr()
+        it.LUT = lut.data_ptr() if lut is not None else None
+        it.Scale = scale.data_ptr() if scale is not None else None
+        it.Zeros = zeros.data_ptr() if zeros is not None else None
+        it.Bias = bias.data_ptr() if bias is not None else None
+    if m == 0:
+        return outs
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    # members that need scratch (split-K MFMA members, m > 2) are never fused: run them through their own fast path,
+    # which hands the library a caller-owned workspace
+    if any(op.lib.workspace_need(m) for op in ops):
+        for i, op in enumerate(ops):
+            it = items[i]
+            op.lib.run(it.A, it.B, it.LUT, it.Scale, it.Zeros, it.Bias, it.C, m, stream, dev)
+        return outs
+    status = _library().wqaa_matmul_group(items, n, m, stream)
+    if status != _lib.OK:
+        _lib.check(status)
+    return outs
+
+
+class LinearGroup(torch.nn.Module):
+    """`bitblas_amd.Linear` layers that read the same input (q/k/v, gate/up), called as one: `q, k, v = group(x)`.
+
+    The launch-level counterpart of the reference's `fuse_qkv` / `fuse_gateup` (modeling_bitnet.py:1433-1445), which
+    concatenates the weights into one `BitLinear` instead; here the layers keep their own buffers and state_dict keys.
+    The descriptor / weight-pointer array is built once and only the activation and output pointers change per call."""
+
+    def __init__(self, layers: Sequence[torch.nn.Module]):
+        super().__init__()
+        if not 1 <= len(layers) <= GROUP_MAX:
+            raise ValueError(f"a group holds 1..{GROUP_MAX} layers")
+        self.layers = torch.nn.ModuleList(layers)
+        self._items = None
+        self._keys = None
+
+    def _build(self):
+        n = len(self.layers)
+        items = (GroupItem * n)()
+        keys = []
+        for i, layer in enumerate(self.layers):
+            if not layer._params_current():
+                layer.init_params()
+            B, scale, zeros, bias = layer._q_run
+            it = items[i]
+            it.desc = ctypes.pointer(layer.bitblas_matmul.lib.desc)
+            it.B, it.Scale, it.Zeros, it.Bias = B, scale, zeros, bias
+            keys.append(layer._q_param_keys)
+        self._items, self._keys = items, keys
+
+    def forward(self, A, outputs: Optional[Sequence[torch.Tensor]] = None):
+        n = len(self.layers)
+        mm0 = self.layers[0].bitblas_matmul
+        A = mm0.transform_input(A)
+        m = mm0.check_activation(A)
+        for layer in self.layers[1:]:
+            if layer.bitblas_matmul.check_activation(A) != m:
+                raise ValueError("the layers of a group take the same input")
+        if not A.is_contiguous():
+            A = A.contiguous()
+        if self._items is None or any(not l._params_current() or l._q_param_keys != k for l, k in zip(self.layers, self._keys)):
+            self._build()
+        outs = list(outputs) if outputs is not None else [None] * n
+        a_ptr = A.data_ptr()
+        luts = []
+        for i, layer in enumerate(self.layers):
+            mm = layer.bitblas_matmul
+            if outs[i] is None:
+                outs[i] = torch.empty(A.shape[:-1] + (layer.out_features,), dtype=mm.torch_output_dtype, device=A.device)
+            elif not outs[i].is_contiguous() or outs[i].device != A.device:
+                raise ValueError("outputs must be contiguous tensors on A's device")
+            lut = mm._ensure_lut(A.device) if layer.source_format == "nf" else None
+            luts.append(lut)
+            it = self._items[i]
+            it.A, it.C = a_ptr, outs[i].data_ptr()
+            it.LUT = lut.data_ptr() if lut is not None else None
+        if m == 0:
+            return tuple(outs)
+        stream = torch.cuda.current_stream(A.device).cuda_stream
+        if any(l.bitblas_matmul.lib.workspace_need(m) for l in self.layers):
+            for i, layer in enumerate(self.layers):
+                it = self._items[i]
+                layer.bitblas_matmul.lib.run(it.A, it.B, it.LUT, it.Scale, it.Zeros, it.Bias, it.C, m, stream, A.device)
+            return tuple(outs)
+        status = _library().wqaa_matmul_group(self._items, n, m, stream)
+        if status != _lib.OK:
+            _lib.check(status)
+        return tuple(outs)
+
+
+__all__ = ["matmul_group", "group_plan", "LinearGroup", "GroupItem", "GROUP_MAX"]

@@ -39,7 +39,7 @@ ZEROS_CODE = {"original": Z_ORIGINAL, "rescale": Z_RESCALE, "quantized": Z_QUANT
 
 EXPORTED_SYMBOLS = (
     "init", "wqaa_abi_version", "wqaa_device_count", "wqaa_matmul", "wqaa_matmul_timed",
-    "wqaa_matmul_ex", "wqaa_matmul_opts", "wqaa_workspace_bytes", "wqaa_act_quant_int8", "wqaa_select", "wqaa_pack_weight", "wqaa_unpack_weight", "wqaa_debug_decode",
+    "wqaa_matmul_ex", "wqaa_matmul_opts", "wqaa_workspace_bytes", "wqaa_matmul_group", "wqaa_group_plan", "wqaa_act_quant_int8", "wqaa_select", "wqaa_pack_weight", "wqaa_unpack_weight", "wqaa_debug_decode", "wqaa_debug_row_blocks",
     "wqaa_last_error", "wqaa_last_error_string",
 )
 
@@ -247,9 +247,7 @@ class BoundLib:
         stream), allocated by torch's caching allocator - which also works while the stream is being captured into a
         graph (the block then lives in the graph's private pool for the graph's lifetime; `torch.cuda.graph` captures
         on a side stream the library's own per-stream slab has never seen).  Two streams never share a workspace."""
-        need = self._ws_need.get(m)
-        if need is None:
-            need = self._ws_need[m] = self.workspace_bytes(m)
+        need = self.workspace_need(m)
         if need:
             key = (stream, device)
             ws = self._ws.get(key)
@@ -273,6 +271,13 @@ class BoundLib:
 
     def workspace_bytes(self, m: int) -> int:
         return int(self._lib.wqaa_workspace_bytes(self._desc_ref, int(m)))
+
+    def workspace_need(self, m: int) -> int:
+        """`workspace_bytes`, asked once per row count"""
+        need = self._ws_need.get(m)
+        if need is None:
+            need = self._ws_need[m] = self.workspace_bytes(m)
+        return need
 
     def run_timed(self, A, B, lut, scale, zeros, bias, C, m, stream, ev_start, ev_stop):
         status = self._lib.wqaa_matmul_timed(self._desc_ref, A, B, lut, scale, zeros, bias, C, m,

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define WQAA_ABI_VERSION 2   /* 2: wqaa_matmul_opts, wqaa_workspace_bytes */
+#define WQAA_ABI_VERSION 2   /* 2: wqaa_matmul_opts, wqaa_workspace_bytes; wqaa_matmul_group added without a bump (new symbols only) */
 
 /* element types of A / C / Scale / Bias */
 enum wqaa_dtype {
@@ -188,6 +188,35 @@ int wqaa_matmul_opts(const wqaa_matmul_desc* desc, const void* A, const void* B,
                      const void* Scale, const void* Zeros, const void* Bias, void* C, int m, void* stream,
                      const wqaa_call_opts* opts);
 
+/* ---- groups of independent operators: one launch for the q/k/v or gate/up projections of a layer ------------------
+ * The reference has one `call` per operator; its own model integration fuses the projections of a decoder layer that
+ * share an input by CONCATENATING their weights along N before quantisation (integration/BitNet/modeling_bitnet.py:
+ * BitnetAttentionQKVFused.from_bit_attention :496-517, BitnetMLPFuseGateUp.from_bit_mlp :271-280, switched on by
+ * default in quantize(fuse_qkv=True, fuse_gateup=True) :1433-1445).  This entry is the launch-level form of the same
+ * fusion for operators that already exist as separate packed tensors (checkpoints with q/k/v and gate/up apart).
+ * On MI355X a dependent kernel boundary costs ~1.3 us and a 4096 x 4096 int4 GEMV about 4 us, so at M <= 2 the boundaries are a third of a decoder layer.  wqaa_matmul_group runs `count` operators as
+ * if wqaa_matmul had been called on each in turn - same results bit for bit, own pointers, own N - and, when they
+ * share one GEMV tile configuration (same K, dtypes, format, group size and flags; M <= 2), in ONE launch whose grid
+ * gives every member its own workgroups; no weight has to be re-packed or concatenated.  Groups the fused path does
+ * not cover (M > 2, mixed configurations, more than WQAA_GROUP_MAX members) run as `count` launches in order.
+ * Members must not alias each other's outputs (they run concurrently); inputs may be shared.
+ * wqaa_group_plan reports the number of launches the group takes and, for a fused group, its plan (name suffix
+ * "_x<count>"; tile configuration = the selector's choice for the merged operator, N = the sum of the members' rows). */
+#define WQAA_GROUP_MAX 8
+typedef struct wqaa_group_item {
+  const wqaa_matmul_desc* desc;
+  const void* A;
+  const void* B;
+  const void* LUT;
+  const void* Scale;
+  const void* Zeros;
+  const void* Bias;
+  void* C;
+} wqaa_group_item;
+
+int wqaa_matmul_group(const wqaa_group_item* items, int count, int m, void* stream);
+int wqaa_group_plan(const wqaa_matmul_desc* const* descs, int count, int m, int* launches, wqaa_plan* plan);
+
 /* per-row absmax quantiser (utils_quant.py:161-168): s = (1 / max(|x|, 1e-5)) * 127 - two fp32 roundings, what torch
  * evaluates for the reference's `Qp / tensor` (Tensor.__rtruediv__) -, q = clamp(rint(x * s)).
  * X: (rows, K) float16; Q: (rows, K) int8; S: (rows,) float32.  K % 8 == 0. */
@@ -213,6 +242,10 @@ int wqaa_unpack_weight(const int8_t* packed, int64_t rows, int64_t cols, int bit
 int wqaa_debug_decode(const void* packed_dev, int64_t nwords, int w_format, int bits, int layout,
                       int a_dtype, int strict_reference, const void* lut_dev, void* out_dev,
                       void* stream);
+
+/* host twin of the GEMV kernels' workgroup -> row-group-block map (csrc/wqaa_kinds.h xcd_row_blocks): workgroup `b` of a
+ * grid of `grid` works on blocks out3[0], out3[0] + out3[1], ... < out3[2] of `n_blocks`.  Test aid, needs no device. */
+void wqaa_debug_row_blocks(int b, int grid, int n_blocks, int* out3);
 
 /* ---- error side channel ---------------------------------------------------------------------- */
 int wqaa_last_error(void);

@@ -1,0 +1,108 @@
+"""Groups of operators in one launch (wqaa_matmul_group): what can be checked without a GPU.
+
+* the GEMV kernels' workgroup -> row-group-block map (csrc/wqaa_kinds.h `xcd_row_blocks`, through its host twin
+  `wqaa_debug_row_blocks`): every block is worked on exactly once for any grid, and the eight XCDs get equal shares;
+* which groups the library fuses (`wqaa_group_plan`): the q/k/v and gate/up projections of a decoder layer - the
+  reference fuses the same projections by concatenating their weights, integration/BitNet/modeling_bitnet.py:1433-1445 -
+  and which it runs member by member;
+* argument checking of the C entry.
+"""
+import ctypes
+
+import pytest
+
+import bitblas_amd as bitblas
+from bitblas_amd import group as wgroup
+from bitblas_amd import lib as wlib
+
+
+def row_blocks(b, grid, n_blocks):
+    L = wlib.load_library()
+    out = (ctypes.c_int * 3)()
+    L.wqaa_debug_row_blocks(int(b), int(grid), int(n_blocks), out)
+    first, stride, end = out[0], out[1], out[2]
+    return list(range(first, end, stride)) if first < end else []
+
+
+@pytest.mark.parametrize("grid,n_blocks", [
+    (512, 512), (688, 688), (696, 688),            # one block per workgroup (the usual launch), with grid padding
+    (1024, 1376), (2048, 3584), (8, 1000), (16, 17),   # fewer workgroups than blocks: several rounds
+    (512, 128), (768, 64), (64, 1), (8, 3),        # a short member of a group launch: more workgroups than blocks
+    (5, 23), (7, 7), (3, 1), (1, 9),               # grids that are no multiple of 8: plain striding
+])
+def test_row_block_map_covers_every_block_once(grid, n_blocks):
+    seen = []
+    per_xcd = [0] * 8
+    for b in range(grid):
+        mine = row_blocks(b, grid, n_blocks)
+        seen += mine
+        per_xcd[b % 8] += len(mine)
+    assert sorted(seen) == list(range(n_blocks))
+    if grid % 8 == 0:
+        # XCD x owns the contiguous eighth [x * ceil(n / 8), ...): equal shares up to the rounding of the last one
+        chunk = (n_blocks + 7) // 8
+        assert max(per_xcd) <= chunk
+        assert sum(1 for c in per_xcd if c == chunk) >= min(8, n_blocks // chunk)
+        for b in range(grid):
+            for blk in row_blocks(b, grid, n_blocks):
+                assert blk // chunk == b % 8
+
+
+def test_row_block_map_is_the_plain_swizzle_when_grid_matches():
+    # grid = blocks rounded up to 8: blk = (b & 7) * (grid >> 3) + (b >> 3), one block per workgroup
+    for n_blocks in (512, 688, 1371):
+        grid = (n_blocks + 7) // 8 * 8
+        for b in range(grid):
+            want = (b & 7) * (grid >> 3) + (b >> 3)
+            assert row_blocks(b, grid, n_blocks) == ([want] if want < n_blocks else [])
+
+
+def op(N, K=4096, M=1, W_dtype="int4", strict=False, **kw):
+    cfg = bitblas.MatmulConfig(M=M, N=N, K=K, A_dtype="float16", W_dtype=W_dtype, accum_dtype="float16",
+                               out_dtype="float16", group_size=128, with_scaling=True, **kw)
+    return bitblas.Matmul(cfg, enable_tuning=False, strict_reference=strict)
+
+
+@pytest.mark.parametrize("strict", [False, True])
+def test_decoder_layer_projections_fuse(strict):
+    family = "_gemv_" if strict else "_gemvx_"
+    qkv = wgroup.group_plan([op(4096, strict=strict)] * 3, 1)
+    assert qkv["launches"] == 1
+    # the tile configuration is the merged operator's (what a concatenated qkv Linear would get)
+    merged = op(12288, strict=strict).plans[1]
+    assert qkv["plan"]["name"] == merged["name"] + "_x3" and family in merged["name"]
+    assert qkv["plan"]["threads"] == merged["threads"] and qkv["plan"]["lds_bytes"] == merged["lds_bytes"]
+    gate_up = wgroup.group_plan([op(11008, strict=strict)] * 2, 1)
+    assert gate_up["launches"] == 1 and gate_up["plan"]["name"].endswith("_x2")
+    assert gate_up["plan"]["grid"] % 16 == 0          # every member: whole XCD rounds
+    # grouped-query attention: k / v narrower than q
+    gqa = wgroup.group_plan([op(4096, strict=strict), op(1024, strict=strict), op(1024, strict=strict)], 1)
+    assert gqa["launches"] == 1 and "n6144" in gqa["plan"]["name"]
+    assert wgroup.group_plan([op(4096, strict=strict)] * 2, 2)["launches"] == 1
+
+
+def test_groups_that_run_member_by_member():
+    a, b = op(4096), op(4096, K=8192)
+    assert wgroup.group_plan([a, b], 1) == {"launches": 2, "plan": None}            # different K
+    assert wgroup.group_plan([op(4096), op(4096, W_dtype="uint4")], 1)["launches"] == 2   # different format
+    assert wgroup.group_plan([op(4096, strict=True), op(4096, strict=False)], 1)["launches"] == 2
+    dyn = [op(4096, M=[1, 16]), op(4096, M=[1, 16])]
+    assert wgroup.group_plan(dyn, 1)["launches"] == 1
+    assert wgroup.group_plan(dyn, 16)["launches"] == 2                               # MFMA members are not fused
+    assert wgroup.group_plan([op(4096)], 1)["launches"] == 1                         # a group of one: the plain call
+    assert wgroup.group_plan([op(256)] * 9, 1)["launches"] == 9                      # beyond WQAA_GROUP_MAX
+
+
+def test_group_entry_argument_checks():
+    L = wgroup._library()
+    assert ctypes.sizeof(wgroup.GroupItem) == 8 * ctypes.sizeof(ctypes.c_void_p)
+    assert L.wqaa_matmul_group(None, 2, 1, None) == wlib.ERR_BAD_DESC
+    items = (wgroup.GroupItem * 2)()
+    assert L.wqaa_matmul_group(items, 0, 1, None) == wlib.OK            # empty group
+    assert L.wqaa_matmul_group(items, 2, 0, None) == wlib.OK            # m == 0 (wrapper/tl.py:277)
+    assert L.wqaa_matmul_group(items, 2, 1, None) == wlib.ERR_BAD_DESC  # null descriptors
+    d = op(4096).lib.desc
+    for it in items:
+        it.desc = ctypes.pointer(d)
+    assert L.wqaa_matmul_group(items, 2, 1, None) == wlib.ERR_BAD_DESC  # null operands, refused before any launch
+    assert b"member 0" in L.wqaa_last_error_string()
