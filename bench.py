@@ -347,15 +347,18 @@ def cpu_baseline(max_seconds=20.0):
                       f"bit for bit against the numpy oracle (dequant {deq_t / n * 1e3:.1f} ms + matmul {mm_t / n * 1e3:.1f} ms per pass)"}
 
 
-def pmc_traffic():
-    """HBM bytes per launch from a committed rocprofv3 --pmc run (profiles/*pmc*.json), or None."""
+def pmc_traffic(launches_per_step):
+    """HBM bytes per launch of the step from the newest committed rocprofv3 --pmc run (profiles/*pmc*.json), or None.
+    The counters are collected per step (tools/profile_round.sh) and divided by this run's launches per step."""
     import glob
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc*.json")), reverse=True):
         try:
             with open(path) as f:
-                v = json.load(f).get("gemv_hbm_bytes_per_launch")
-            if v is not None:
-                return v
+                d = json.load(f)
+            if d.get("gemv_hbm_bytes_per_step") is not None:
+                return d["gemv_hbm_bytes_per_step"] / launches_per_step
+            if d.get("gemv_hbm_bytes_per_launch") is not None:      # files from before the group launches: 28 launches per step
+                return d["gemv_hbm_bytes_per_launch"] * 28 / launches_per_step
         except Exception:
             continue
     return None
@@ -575,7 +578,7 @@ def main():
                                      }.get(gather_mode, "") + ")")
                        if dist_on else "none"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(),
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(launches_per_step),
                          "kernel": "wq_gemvx_kernel<int4, lop3, scale, mb1> (every launch of the step: " +
                                    ", ".join(sorted({v for _, v in group_names})) + ")",
                          "numerics": "strict_reference=False: exact products, group scale on fp32 partial sums (1e-3 contract vs the "

@@ -5,6 +5,7 @@
 #include <atomic>
 #include <cstring>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include "../../include/wqaa.h"
 
@@ -182,6 +183,12 @@ inline void short_wdtype(const wqaa_matmul_desc& d, char* buf, size_t n) {
   }
 }
 
+
+// WQAA_GEMV_UNCAP=1 (A/B aid, plan-time): GEMV grids are not capped at the workgroups the chip holds at once
+inline bool gemv_uncapped() {
+  const char* f = getenv("WQAA_GEMV_UNCAP");
+  return f && atoi(f) != 0;
+}
 
 inline int ilog2_exact(int v) {
   if (v <= 0 || (v & (v - 1))) return -1;

@@ -226,8 +226,9 @@ static int choose(const wqaa_matmul_desc& d, int m, GemvChoice* c, bool quant_in
   const int rg_per_block = nw / c->kw;
   int blocks = (n_rg + rg_per_block - 1) / rg_per_block;
   const int cap = cus * blocks_per_cu;
-  if (blocks > cap) blocks = cap;
+  if (blocks > cap && !gemv_uncapped()) blocks = cap;
   if (blocks < 1) blocks = 1;
+  if (const char* f = getenv("WQAA_GEMV_GRID")) { if (atoi(f) > 0) blocks = atoi(f); }   // tuning aid
   if (blocks >= 8) blocks = (blocks + 7) / 8 * 8;   // whole XCD rounds: keeps the block swizzle on
   c->grid_x = blocks;
   c->grid_y = (m + mb - 1) / mb;
@@ -367,9 +368,8 @@ static int gemv_group_choose(const wqaa_matmul_desc& merged, const int* Ns, int 
     const int blocks = ((Ns[i] + c->R - 1) / c->R + rg_per_block - 1) / rg_per_block;
     if (blocks > need) need = blocks;
   }
-  int gx = c->grid_x / count;            // the merged operator's grid (capped at what the chip holds), shared between the members
-  if (gx < 1) gx = 1;
-  if (gx > need) gx = need;
+  int gx = need;                         // one row-group block per workgroup, sized by the largest member (see gemvx_group_choose)
+  if (const char* f = getenv("WQAA_GROUP_GRID")) { if (atoi(f) > 0 && atoi(f) < gx) gx = atoi(f); }    // tuning aid
   if (gx >= 8) gx = (gx + 7) / 8 * 8;
   *grid_x = gx;
   return WQAA_OK;

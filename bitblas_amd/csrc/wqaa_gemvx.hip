@@ -121,7 +121,11 @@ static int gemvx_choose(const wqaa_matmul_desc& d, int m, GemvxChoice* c) {
   if (blocks_per_cu > 32 / c->nw) blocks_per_cu = 32 / c->nw;
   if (blocks_per_cu < 1) blocks_per_cu = 1;
   int blocks = c->n_rgb;
-  if (blocks > cus * blocks_per_cu) blocks = cus * blocks_per_cu;
+  // more row-group blocks than workgroups the chip holds at once: cap the grid and let the workgroups take several
+  // blocks of their XCD's eighth (28672x4096 2048 vs 3584 workgroups: 13.8 vs 14.3 us; 28672x8192 1792 vs 3584: 24.9
+  // vs 27.0) - unless the second round would be a short one, where the hardware dispatcher balances better than a
+  // static assignment (22016x4096, 1376 blocks: 1024 workgroups 11.5 us, 1376 10.7; tools/ab_grid.py, ab_cap.py)
+  if (blocks > cus * blocks_per_cu + cus * blocks_per_cu / 2 && !gemv_uncapped()) blocks = cus * blocks_per_cu;
   if (blocks >= 8) blocks = (blocks + 7) / 8 * 8;       // whole XCD rounds keep the block swizzle on
   if (const char* f = getenv("WQAA_GEMVX_GRID")) blocks = atoi(f) > 0 ? atoi(f) : 1;
   c->grid = blocks;
@@ -255,10 +259,12 @@ static int gemvx_group_choose(const wqaa_matmul_desc& merged, const int* Ns, int
     const int n_rgb = ((Ns[i] + c->R - 1) / c->R + slots - 1) / slots;
     if (n_rgb > need) need = n_rgb;
   }
-  // c->grid: the merged operator's grid (capped at the workgroups the chip holds at once); share it between the members
-  int gx = c->grid / count;
-  if (gx < 1) gx = 1;
-  if (gx > need) gx = need;
+  // every member gets the workgroups of its LARGEST member (one row-group block each; the shorter members' surplus
+  // workgroups leave at once).  No cap at what the chip holds at once: same-call A/B of the gate/up group of the
+  // headline step (2 x 688 blocks): 1024 workgroups taking up to two blocks each 11.94 us, 1376 workgroups 10.81 us -
+  // the hardware dispatcher balances better than a static second round (tools/ab_group.py)
+  int gx = need;
+  if (const char* f = getenv("WQAA_GROUP_GRID")) { if (atoi(f) > 0 && atoi(f) < gx) gx = atoi(f); }    // tuning aid: workgroups per member
   if (gx >= 8) gx = (gx + 7) / 8 * 8;                 // whole XCD rounds per member: blockIdx.x % 8 stays the XCD
   *grid_x = gx;
   return WQAA_OK;

@@ -68,7 +68,7 @@ def test_qkv_and_gate_up_of_a_llama2_7b_layer(strict):
     gu = [int4_case(11008, seed=s) for s in (4, 5)]
     gu[1]["A"] = gu[0]["A"]
     ops, outs, plan = run_both(gu, strict)
-    # 2 x 688 row-group blocks on a grid the chip holds at once: workgroups take several blocks, XCD-balanced
+    # 2 x 688 row-group blocks, one workgroup each (the grid of a group is not capped at what the chip holds at once)
     for c, o in zip(gu, outs):
         assert_fp_parity(o.cpu().numpy(), oracle_output(c), rtol=1e-3, atol_frac=1.5e-3)
 
@@ -160,6 +160,39 @@ def test_many_row_single_launch_on_a_capped_grid_matches_oracle():
         torch.cuda.synchronize()
         assert_fp_parity(out.cpu().numpy(), oracle_output(c), rtol=1e-3, atol_frac=1.5e-3)
         assert plan["grid"] >= 256
+
+
+def test_results_do_not_depend_on_the_grid(monkeypatch):
+    """fewer workgroups than row-group blocks (workgroups take several blocks of their XCD's eighth, csrc/wqaa_kinds.h
+    xcd_row_blocks), single launches of both families and a group launch: bit-identical to the one-block-per-workgroup grids"""
+    c = int4_case(11008, seed=21)
+    cases = [c, dict(int4_case(11008, seed=22), A=c["A"])]
+    A = _to_dev(c["A"], DEV)
+    for strict in (False, True):
+        built = [build(x, strict) for x in cases]
+        ops = [b[0] for b in built]
+        ws = [b[1] for b in built]
+        base = [op(A, *w) for op, w in zip(ops, ws)]
+        gbase = bitblas.matmul_group(ops, A, ws)
+        for grid, ggrid in ((344, 344), (504, 200), (8, 16)):
+            monkeypatch.setenv("WQAA_GEMVX_GRID", str(grid))
+            monkeypatch.setenv("WQAA_GEMV_GRID", str(grid))
+            monkeypatch.setenv("WQAA_GROUP_GRID", str(ggrid))
+            plan = ops[0].lib.plan(1)                     # planning re-reads the tuning variables
+            assert plan["grid"] == grid
+            gplan = wgroup.group_plan(ops, 1)
+            assert gplan["plan"]["grid"] == 2 * ggrid
+            for op, w, b in zip(ops, ws, base):
+                assert torch.equal(op(A, *w), b)
+            for g_, b in zip(bitblas.matmul_group(ops, A, ws), gbase):
+                assert torch.equal(g_, b)
+        monkeypatch.delenv("WQAA_GEMVX_GRID")
+        monkeypatch.delenv("WQAA_GEMV_GRID")
+        monkeypatch.delenv("WQAA_GROUP_GRID")
+        ops[0].lib.plan(1)
+        for g_, b in zip(gbase, base):
+            assert torch.equal(g_, b)
+    torch.cuda.synchronize()
 
 
 def test_linear_group_and_graph_replay():

@@ -20,4 +20,4 @@ for ctr in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $ctr --output-format csv -d $out/${tag}_pmc_$ctr -o pmc -- python $root/bench.py --steps 3 --warmup 1 --layers 4 --no-cpu-baseline --no-members --eager > $out/${tag}_pmc_${ctr}_stdout.log 2>&1
   ls $out/${tag}_pmc_$ctr | head
 done
-python $root/tools/summarize_pmc.py $out $tag
+python $root/tools/summarize_pmc.py $out $tag 16

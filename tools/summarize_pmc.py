@@ -10,6 +10,7 @@ import os
 import sys
 
 out, tag = sys.argv[1], sys.argv[2]
+launches_per_step = int(sys.argv[3]) if len(sys.argv) > 3 else 16     # bench.py: 4 layers x ({q,k,v}, o, {gate,up}, down)
 res = {"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, eager launches of bench.py's step"}
 for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
     files = glob.glob(os.path.join(out, f"{tag}_pmc_{ctr}", "*counter_collection.csv"))
@@ -36,6 +37,8 @@ if "FETCH_SIZE_KiB_mean_per_launch" in res:
     res["gemv_hbm_read_bytes_per_launch_corrected"] = rd
     res["gemv_hbm_write_bytes_per_launch"] = wr
     res["gemv_hbm_bytes_per_launch"] = rd + wr
+    res["launches_per_step"] = launches_per_step
+    res["gemv_hbm_bytes_per_step"] = (rd + wr) * launches_per_step
 path = os.path.join(out, f"{tag}_pmc_gemv.json")
 json.dump(res, open(path, "w"), indent=1)
 print(json.dumps(res, indent=1))
