@@ -80,3 +80,75 @@ class BitLinear(nn.Module):
                                           None if self.bias is None else self.bias.data_ptr(), out.data_ptr(), m,
                                           torch.cuda.current_stream(x.device).cuda_stream, si.data_ptr(), sw)
         return out
+
+
+class BitLinearGroup(nn.Module):
+    """`BitLinear` layers that read the same input (q/k/v, gate/up of a BitNet block), called as one:
+    `q, k, v = BitLinearGroup([q_proj, k_proj, v_proj])(x)`.
+
+    Decode steps (m <= 2) run the whole group - per-token activation quantiser, W_int2 x A_int8 matmuls, `out / si / sw ->
+    half (+bias)` - as ONE launch (`wqaa_matmul_group_ex`); larger batches quantise the activations once and run the layers
+    one by one on the MFMA members.  Results are bit-identical to the layers' own `forward`.  The reference fuses the same
+    projections by concatenating their float weights before quantisation (integration/BitNet/modeling_bitnet.py:1433-1445),
+    which also merges their weight scales `sw`; here every layer keeps its own `sw` and packed tensor."""
+
+    def __init__(self, layers):
+        super().__init__()
+        from .group import GROUP_MAX
+        if not 1 <= len(layers) <= GROUP_MAX:
+            raise ValueError(f"a group holds 1..{GROUP_MAX} layers")
+        if len({l.in_features for l in layers}) != 1:
+            raise ValueError("the layers of a group take the same input")
+        self.layers = nn.ModuleList(layers)
+
+    def forward(self, x: torch.Tensor):
+        import ctypes
+        from .group import GroupItem, _library
+        layers = list(self.layers)
+        l0 = layers[0]
+        if not x.is_cuda:
+            raise RuntimeError("bitblas_amd.bitnet.BitLinearGroup runs on the GPU only")
+        m = x.numel() // l0.in_features
+        if not (m <= 2 and x.dtype == torch.float16 and all(l.fuse_activation_quant for l in layers)):
+            if m <= 4 or x.dtype != torch.float16:
+                return tuple(l(x) for l in layers)
+            # larger batches: one quantiser launch for the group, then the layers' matmuls with the fused post-process
+            q, si = l0.activation_quant(x)
+            outs = []
+            stream = torch.cuda.current_stream(x.device).cuda_stream
+            for l in layers:
+                out = torch.empty(x.shape[:-1] + (l.out_features,), dtype=torch.float16, device=x.device)
+                sw = getattr(l, "_sw_host", None)
+                if sw is None:
+                    sw = l._sw_host = float(l.sw)
+                l.bitblas_matmul.lib.run_fused(q.data_ptr(), l.qweight.data_ptr(), None if l.bias is None else l.bias.data_ptr(),
+                                               out.data_ptr(), m, stream, si.data_ptr(), sw)
+                outs.append(out)
+            return tuple(outs)
+        xc = x if x.is_contiguous() else x.contiguous()
+        n = len(layers)
+        items = (GroupItem * n)()
+        epis = (_lib.Epilogue * n)()
+        eptr = (ctypes.POINTER(_lib.Epilogue) * n)()
+        outs = []
+        for i, l in enumerate(layers):
+            out = torch.empty(x.shape[:-1] + (l.out_features,), dtype=torch.float16, device=x.device)
+            outs.append(out)
+            sw = getattr(l, "_sw_host", None)
+            if sw is None:
+                sw = l._sw_host = float(l.sw)
+            it = items[i]
+            it.desc = ctypes.pointer(l.bitblas_matmul.lib.desc)
+            it.A, it.B, it.C = xc.data_ptr(), l.qweight.data_ptr(), out.data_ptr()
+            it.Bias = None if l.bias is None else l.bias.data_ptr()
+            e = epis[i]
+            e.struct_size = ctypes.sizeof(_lib.Epilogue)
+            e.flags = _lib.EPI_QUANTIZE_INPUT
+            e.row_scale = None
+            e.tensor_scale = float(sw)
+            eptr[i] = ctypes.pointer(e)
+        lib = _library()
+        status = lib.wqaa_matmul_group_ex(items, eptr, n, m, torch.cuda.current_stream(x.device).cuda_stream)
+        if status != _lib.OK:
+            _lib.check(status)
+        return tuple(outs)

@@ -224,7 +224,8 @@ static int matmul_impl(const wqaa_matmul_desc* desc, const void* A, const void* 
 // ---- groups (wqaa_matmul_group) ------------------------------------------------------------------------------------
 // A group fuses into one launch when every member has the same descriptor apart from N and the merged operator
 // (N = the sum of the members' rows) is served by a GEMV-family member at this m.  *fused_x: 1 = exact-product family.
-static bool group_fusable(const wqaa_matmul_desc* const* descs, int count, int m, wqaa_matmul_desc* merged, int* fused_x) {
+static bool group_fusable(const wqaa_matmul_desc* const* descs, int count, int m, wqaa_matmul_desc* merged, int* fused_x,
+                          int epi_mode = 0) {      // epi_mode: 0 none, 1 caller's row scales, 2 in-kernel activation quantiser
   if (count < 2 || count > WQAA_GROUP_MAX || m < 1 || m > 2) return false;
   if (const char* f = getenv("WQAA_GROUP_FUSE")) { if (atoi(f) == 0) return false; }    // A/B aid: members launched one by one
   long total = 0;
@@ -239,13 +240,13 @@ static bool group_fusable(const wqaa_matmul_desc* const* descs, int count, int m
   merged->N = (int32_t)total;
   bool use_gemm = false;
   dispatch(*merged, m, &use_gemm);
-  if (use_gemm) return false;
+  if (use_gemm && epi_mode != 2) return false;
   const int saved = g_last_error;
   char saved_msg[sizeof(g_last_error_msg)];
   memcpy(saved_msg, g_last_error_msg, sizeof(saved_msg));
   bool ok = true;
-  if (gemvx_group_eligible(*merged, count, m)) *fused_x = 1;
-  else if (gemv_group_eligible(*merged, count, m)) *fused_x = 0;
+  if (epi_mode == 0 && gemvx_group_eligible(*merged, count, m)) *fused_x = 1;
+  else if (gemv_group_eligible(*merged, count, m, epi_mode != 0, epi_mode == 2)) *fused_x = 0;
   else ok = false;
   g_last_error = saved;
   memcpy(g_last_error_msg, saved_msg, sizeof(saved_msg));
@@ -351,14 +352,29 @@ int wqaa_group_plan(const wqaa_matmul_desc* const* descs, int count, int m, int*
   return fx ? gemvx_group_plan(merged, Ns, count, m, plan) : gemv_group_plan(merged, Ns, count, m, plan);
 }
 
-int wqaa_matmul_group(const wqaa_group_item* items, int count, int m, void* stream) {
+static int group_impl(const wqaa_group_item* items, const wqaa_epilogue* const* epis, int count, int m, void* stream) {
   if (!items || count < 0) {
     set_error(WQAA_ERR_BAD_DESC, "matmul_group: bad arguments (items=%p count=%d)", (const void*)items, count);
     return WQAA_ERR_BAD_DESC;
   }
   if (count == 0 || m == 0) return WQAA_OK;
+  // epilogues: all members or none; the fused launch needs one kind (caller's row scales / in-kernel quantiser)
+  int epi_mode = 0;
+  bool epi_uniform = true;
+  if (epis) {
+    for (int i = 0; i < count; ++i) {
+      const wqaa_epilogue* e = epis[i];
+      if (!e || e->struct_size != (int32_t)sizeof(wqaa_epilogue) || (!e->row_scale && !(e->flags & WQAA_EPI_QUANTIZE_INPUT))) {
+        set_error(WQAA_ERR_BAD_DESC, "matmul_group_ex: member %d has a missing or malformed epilogue descriptor", i);
+        return WQAA_ERR_BAD_DESC;
+      }
+      const int mode = (e->flags & WQAA_EPI_QUANTIZE_INPUT) ? 2 : 1;
+      if (i == 0) epi_mode = mode;
+      else if (mode != epi_mode) epi_uniform = false;
+    }
+  }
   const wqaa_matmul_desc* descs[WQAA_GROUP_MAX];
-  bool fuse = count >= 2 && count <= WQAA_GROUP_MAX && m >= 1 && m <= 2;
+  bool fuse = count >= 2 && count <= WQAA_GROUP_MAX && m >= 1 && m <= 2 && epi_uniform;
   for (int i = 0; i < count && fuse; ++i) {
     const wqaa_group_item& it = items[i];
     if (!valid_desc(it.desc)) return WQAA_ERR_BAD_DESC;
@@ -381,7 +397,7 @@ int wqaa_matmul_group(const wqaa_group_item* items, int count, int m, void* stre
     int fx = 0;
     bool ok;
     {
-      // fusability per (merged descriptor, m, count): memoised like every tile choice
+      // fusability per (merged descriptor, m, count, epilogue kind): memoised like every tile choice
       struct Fuse { int ok, fx; };
       static thread_local ChoiceMemo<Fuse> memo;
       wqaa_matmul_desc key = *descs[0];
@@ -394,28 +410,38 @@ int wqaa_matmul_group(const wqaa_group_item* items, int count, int m, void* stre
         total += descs[i]->N;
       }
       key.N = (int32_t)(total & 0x7fffffff);
-      const Fuse* hit = same ? memo.find(key, m, 32 + count) : nullptr;
+      const int q = 32 + count + 16 * epi_mode;
+      const Fuse* hit = same ? memo.find(key, m, q) : nullptr;
       if (hit) {
         ok = hit->ok != 0;
         fx = hit->fx;
         merged = key;
       } else {
-        ok = group_fusable(descs, count, m, &merged, &fx);
-        if (same) memo.put(key, m, 32 + count, Fuse{ok ? 1 : 0, fx});
+        ok = group_fusable(descs, count, m, &merged, &fx, epi_mode);
+        if (same) memo.put(key, m, q, Fuse{ok ? 1 : 0, fx});
       }
     }
     if (ok) {
-      int st = fx ? gemvx_group_launch(merged, items, count, m, s) : gemv_group_launch(merged, items, count, m, s);
+      int st = fx ? gemvx_group_launch(merged, items, count, m, s) : gemv_group_launch(merged, items, count, m, s, epis);
       if (st == WQAA_OK) g_last_error = WQAA_OK;
       return st;
     }
   }
   for (int i = 0; i < count; ++i) {
     const wqaa_group_item& it = items[i];
-    int st = matmul_impl(it.desc, it.A, it.B, it.LUT, it.Scale, it.Zeros, it.Bias, it.C, m, stream, nullptr, nullptr);
+    int st = matmul_impl(it.desc, it.A, it.B, it.LUT, it.Scale, it.Zeros, it.Bias, it.C, m, stream, nullptr, nullptr,
+                         epis ? epis[i] : nullptr);
     if (st != WQAA_OK) return st;
   }
   return WQAA_OK;
+}
+
+int wqaa_matmul_group(const wqaa_group_item* items, int count, int m, void* stream) {
+  return group_impl(items, nullptr, count, m, stream);
+}
+
+int wqaa_matmul_group_ex(const wqaa_group_item* items, const wqaa_epilogue* const* epilogues, int count, int m, void* stream) {
+  return group_impl(items, epilogues, count, m, stream);
 }
 
 int wqaa_act_quant_int8(const void* X, int64_t rows, int K, void* Q, float* S, void* stream) {

@@ -88,9 +88,10 @@ bool gemvx_eligible(const wqaa_matmul_desc& d, int m);
 bool gemvx_group_eligible(const wqaa_matmul_desc& merged, int count, int m);
 int gemvx_group_plan(const wqaa_matmul_desc& merged, const int* Ns, int count, int m, wqaa_plan* plan);
 int gemvx_group_launch(const wqaa_matmul_desc& merged, const wqaa_group_item* items, int count, int m, hipStream_t stream);
-bool gemv_group_eligible(const wqaa_matmul_desc& merged, int count, int m);
+bool gemv_group_eligible(const wqaa_matmul_desc& merged, int count, int m, bool with_epilogue = false, bool quant_in = false);
 int gemv_group_plan(const wqaa_matmul_desc& merged, const int* Ns, int count, int m, wqaa_plan* plan);
-int gemv_group_launch(const wqaa_matmul_desc& merged, const wqaa_group_item* items, int count, int m, hipStream_t stream);
+int gemv_group_launch(const wqaa_matmul_desc& merged, const wqaa_group_item* items, int count, int m, hipStream_t stream,
+                      const wqaa_epilogue* const* epis = nullptr);
 int gemvx_plan(const wqaa_matmul_desc& d, int m, wqaa_plan* plan);
 int gemvx_launch(const wqaa_matmul_desc& d, const void* A, const void* B, const void* Scale, const void* Zeros,
                  const void* Bias, void* C, int m, hipStream_t stream, hipEvent_t start, hipEvent_t stop);

@@ -351,15 +351,17 @@ int gemv_launch(const wqaa_matmul_desc& d, const void* A, const void* B, const v
 
 // ---- a group of independent operators in one launch (wqaa_matmul_group): tile configuration of the MERGED operator
 // (N = the sum of the members' rows), every member takes gridDim.x x gridDim.y workgroups of it (blockIdx.z = member) ----
-static int gemv_group_choose(const wqaa_matmul_desc& merged, const int* Ns, int count, int m, GemvChoice* c, int* grid_x) {
+static int gemv_group_choose(const wqaa_matmul_desc& merged, const int* Ns, int count, int m, GemvChoice* c, int* grid_x,
+                             bool quant_in = false) {
   {
     static thread_local ChoiceMemo<GemvChoice> memo;
-    if (const GemvChoice* hit = memo.find(merged, m, 16 + count)) {
+    const int q = 16 + count + (quant_in ? 64 : 0);
+    if (const GemvChoice* hit = memo.find(merged, m, q)) {
       *c = *hit;
     } else {
-      int st = choose(merged, m, c);
+      int st = choose(merged, m, c, quant_in);
       if (st != WQAA_OK) return st;
-      memo.put(merged, m, 16 + count, *c);
+      memo.put(merged, m, q, *c);
     }
   }
   const int rg_per_block = (c->threads / 64) / c->kw;
@@ -375,10 +377,11 @@ static int gemv_group_choose(const wqaa_matmul_desc& merged, const int* Ns, int 
   return WQAA_OK;
 }
 
-bool gemv_group_eligible(const wqaa_matmul_desc& merged, int count, int m) {
+bool gemv_group_eligible(const wqaa_matmul_desc& merged, int count, int m, bool with_epilogue, bool quant_in) {
   if (count < 1 || count > kGemvGroupMax || m < 1 || m > 2) return false;
   GemvChoice c;
-  return choose(merged, m, &c) == WQAA_OK;      // (the caller restores the error side channel)
+  if (choose(merged, m, &c, quant_in) != WQAA_OK) return false;      // (the caller restores the error side channel)
+  return !with_epilogue || (at_is_int(c.at) && merged.out_dtype == WQAA_F16);
 }
 
 int gemv_group_plan(const wqaa_matmul_desc& merged, const int* Ns, int count, int m, wqaa_plan* plan) {
@@ -396,17 +399,28 @@ int gemv_group_plan(const wqaa_matmul_desc& merged, const int* Ns, int count, in
   return st;
 }
 
-int gemv_group_launch(const wqaa_matmul_desc& merged, const wqaa_group_item* items, int count, int m, hipStream_t stream) {
+int gemv_group_launch(const wqaa_matmul_desc& merged, const wqaa_group_item* items, int count, int m, hipStream_t stream,
+                      const wqaa_epilogue* const* epis) {
   int Ns[kGemvGroupMax];
   for (int i = 0; i < count; ++i) Ns[i] = items[i].desc->N;
   GemvChoice c;
   int gx = 0;
-  int st = gemv_group_choose(merged, Ns, count, m, &c, &gx);
+  const bool quant_in = epis && (epis[0]->flags & WQAA_EPI_QUANTIZE_INPUT);
+  int st = gemv_group_choose(merged, Ns, count, m, &c, &gx, quant_in);
   if (st != WQAA_OK) return st;
+  if (epis && (!at_is_int(c.at) || merged.out_dtype != WQAA_F16)) {
+    set_error(WQAA_ERR_UNSUPPORTED, "matmul_group_ex: the fused epilogue needs int8 activations and float16 output");
+    return WQAA_ERR_UNSUPPORTED;
+  }
   GemvGroupArgs ga;
-  for (int i = 0; i < count; ++i)
+  for (int i = 0; i < count; ++i) {
     fill_args(*items[i].desc, c, items[i].A, items[i].B, items[i].LUT, items[i].Scale, items[i].Zeros, items[i].Bias, items[i].C, m,
               &ga.p[i]);
+    if (epis) {
+      ga.p[i].epi_row = epis[i]->row_scale;
+      ga.p[i].epi_tensor = epis[i]->tensor_scale;
+    }
+  }
   return gemv_dispatch(c, ga, gx, count, stream, nullptr, nullptr);
 }
 

@@ -40,6 +40,9 @@ def _library():
     if not _bound:
         lib.wqaa_matmul_group.restype = ctypes.c_int
         lib.wqaa_matmul_group.argtypes = [ctypes.POINTER(GroupItem), ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+        lib.wqaa_matmul_group_ex.restype = ctypes.c_int
+        lib.wqaa_matmul_group_ex.argtypes = [ctypes.POINTER(GroupItem), ctypes.POINTER(ctypes.POINTER(_lib.Epilogue)), ctypes.c_int,
+                                             ctypes.c_int, ctypes.c_void_p]
         lib.wqaa_group_plan.restype = ctypes.c_int
         lib.wqaa_group_plan.argtypes = [ctypes.POINTER(ctypes.POINTER(_lib.MatmulDesc)), ctypes.c_int, ctypes.c_int,
                                         ctypes.POINTER(ctypes.c_int), ctypes.POINTER(_lib.Plan)]

@@ -215,6 +215,11 @@ typedef struct wqaa_group_item {
 } wqaa_group_item;
 
 int wqaa_matmul_group(const wqaa_group_item* items, int count, int m, void* stream);
+/* as wqaa_matmul_group, every member with the fused epilogue of wqaa_matmul_ex (`epilogues[i]`, all members or NULL):
+ * the q/k/v projections of a BitNet layer - in-kernel activation quantiser (WQAA_EPI_QUANTIZE_INPUT), W_int2 x A_int8,
+ * `out / si / sw -> half` - as ONE launch (integration/BitNet/utils_quant.py:205-216 runs three such layers back to
+ * back).  Members with different epilogue kinds run one by one. */
+int wqaa_matmul_group_ex(const wqaa_group_item* items, const wqaa_epilogue* const* epilogues, int count, int m, void* stream);
 int wqaa_group_plan(const wqaa_matmul_desc* const* descs, int count, int m, int* launches, wqaa_plan* plan);
 
 /* per-row absmax quantiser (utils_quant.py:161-168): s = (1 / max(|x|, 1e-5)) * 127 - two fp32 roundings, what torch

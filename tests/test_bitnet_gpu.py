@@ -105,3 +105,70 @@ def test_quantiser_and_layer_against_reference_run_vectors(tag):
     q, s = lin.activation_quant(torch.from_numpy(x).cuda())
     assert np.array_equal(q.cpu().numpy(), g[f"{tag}_q"])
     assert np.array_equal(s.cpu().numpy(), g[f"{tag}_si"][:, 0])
+
+
+@pytest.mark.parametrize("m", [1, 2, 3, 16])
+@pytest.mark.parametrize("bias", [False, True])
+def test_bitlinear_group_one_launch_for_qkv(m, bias):
+    """q/k/v of a BitNet block through `BitLinearGroup` (wqaa_matmul_group_ex: in-kernel quantiser + W_int2 x A_int8 +
+    `out / si / sw -> half` for all three in one launch at m <= 2): bit-identical to the layers' own forward, every
+    layer with its own sw, and equal to the oracle.  The reference runs three BitLinear calls or concatenates the
+    weights (integration/BitNet/modeling_bitnet.py:1433-1445)."""
+    from bitblas_amd.bitnet import BitLinearGroup
+    rng = np.random.default_rng(100 + m + bias)
+    K = 2048
+    layers, raw = [], []
+    for i, N in enumerate((2048, 512, 512)):
+        w = (rng.standard_normal((N, K)) * 0.02 * (i + 1)).astype(np.float32)        # different mean|W| -> different sw
+        b = rng.standard_normal(N).astype(np.float16) if bias else None
+        lin = BitLinear(K, N, bias=bias).cuda()
+        lin.load_float_weight(torch.from_numpy(w).cuda(), None if b is None else torch.from_numpy(b).cuda())
+        layers.append(lin)
+        raw.append(b)
+    x = (rng.standard_normal((m, K)) * 2).astype(np.float16)
+    xd = torch.from_numpy(x).cuda()
+    want = [l(xd) for l in layers]
+    got = BitLinearGroup(layers)(xd)
+    torch.cuda.synchronize()
+    assert len({l.sw.item() for l in layers}) == 3
+    for l, b, w_, g_ in zip(layers, raw, want, got):
+        assert torch.equal(w_, g_)
+        ref = oracle.bitnet_forward(x, module_codes(l), np.float32(l.sw.item()), b)
+        assert np.array_equal(g_.cpu().numpy(), ref)
+
+
+def test_group_ex_argument_checks_and_mixed_epilogues():
+    """epilogues for all members or none; members whose epilogue kinds differ run one by one with the same results"""
+    import ctypes
+    from bitblas_amd import group as wgroup
+    rng = np.random.default_rng(5)
+    K, N = 1024, 512
+    lins = []
+    for i in range(2):
+        lin = BitLinear(K, N).cuda()
+        lin.load_float_weight(torch.from_numpy((rng.standard_normal((N, K)) * 0.03).astype(np.float32)).cuda())
+        lins.append(lin)
+    x = torch.from_numpy((rng.standard_normal((1, K)) * 2).astype(np.float16)).cuda()
+    q, si = lins[0].activation_quant(x)
+    want = [l(x) for l in lins]
+    L = wgroup._library()
+    items = (wgroup.GroupItem * 2)()
+    epis = (wlib.Epilogue * 2)()
+    eptr = (ctypes.POINTER(wlib.Epilogue) * 2)()
+    outs = [torch.empty_like(w) for w in want]
+    for i, l in enumerate(lins):
+        items[i].desc = ctypes.pointer(l.bitblas_matmul.lib.desc)
+        items[i].B, items[i].C = l.qweight.data_ptr(), outs[i].data_ptr()
+        epis[i].struct_size = ctypes.sizeof(wlib.Epilogue)
+        epis[i].tensor_scale = float(l.sw)
+        eptr[i] = ctypes.pointer(epis[i])
+    # member 0: in-kernel quantiser on the float16 input; member 1: pre-quantised input + the caller's row scales
+    items[0].A, epis[0].flags = x.data_ptr(), wlib.EPI_QUANTIZE_INPUT
+    items[1].A, epis[1].row_scale = q.data_ptr(), si.data_ptr()
+    stream = torch.cuda.current_stream().cuda_stream
+    assert L.wqaa_matmul_group_ex(items, eptr, 2, 1, stream) == wlib.OK
+    torch.cuda.synchronize()
+    for w_, o in zip(want, outs):
+        assert torch.equal(w_, o)
+    eptr[1] = None
+    assert L.wqaa_matmul_group_ex(items, eptr, 2, 1, stream) == wlib.ERR_BAD_DESC

@@ -49,6 +49,21 @@ def main():
         assert torch.allclose(a.float(), b.float(), rtol=2e-3, atol=2e-3), (a - b).abs().max()  # torch GPU division is not IEEE-exact
         print(f"M={m}: fused {graph_us(lambda: lin(x)):.2f} us/call   reference structure {graph_us(unfused):.2f} us/call")
 
+    # q/k/v of a block: three layers one by one against BitLinearGroup (wqaa_matmul_group_ex: one launch at m <= 2)
+    from bitblas_amd.bitnet import BitLinearGroup
+    qkv = []
+    for _ in range(3):
+        l = BitLinear(K, N).cuda()
+        l.load_float_weight(torch.randn(N, K, device="cuda") * 0.02)
+        qkv.append(l)
+    grp = BitLinearGroup(qkv)
+    for m in (1, 2):
+        x = torch.randn(m, K, device="cuda", dtype=torch.float16)
+        for a, b in zip([l(x) for l in qkv], grp(x)):
+            assert torch.equal(a, b)
+        print(f"M={m} q/k/v (3 x {N}x{K}): layers one by one {graph_us(lambda: [l(x) for l in qkv]):.2f} us   "
+              f"BitLinearGroup {graph_us(lambda: grp(x)):.2f} us")
+
 
 if __name__ == "__main__":
     main()
