@@ -151,6 +151,10 @@ def time_member_gemm(device, gen, M=4096, N=4096, K=4096, W_dtype="uint4", A_dty
     except Exception as exc:  # member not built: report, never fake
         return {"error": str(exc)}
     bits = op.bit
+    if M <= 256:
+        # decode batches are microseconds per launch: as many launches per replayed graph as the M = 1 members take (the
+        # fixed cost of a replay was a tenth of an 8-launch graph of these), over > 256 MB of distinct weights
+        n_buf = max(n_buf, min(64, (640 << 20) // max(1, N * K * bits // 8)))
     if int8:
         A = torch.randint(-128, 128, (M, K), device=device, dtype=torch.int8, generator=gen)
     else:

@@ -1384,22 +1384,37 @@ __global__ void __launch_bounds__(256) wq_splitk_reduce_kernel(const void* ws_, 
   const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= quads) return;
   const acc_t* ws = reinterpret_cast<const acc_t*>(ws_);
-  // slices are read 8 at a time with independent loads (clamped index, masked add): a plain loop
-  // waits for every 16-byte load before issuing the next one
+  // slices are read 4 at a time with independent loads (a plain loop waits for every 16-byte load before issuing the
+  // next one); a slice beyond ksplit is not read at all (split 2 and 4 moved twice and four times the bytes they had to
+  // when every round read 8 clamped slices).  Summation order: ((s0 + s1) + s2) + ... as before - bit-identical results.
   acc_t sum = acc_t{0, 0, 0, 0};
-  for (int s0 = 0; s0 < ksplit; s0 += 8) {
-    acc_t part[8];
+  for (int s0 = 0; s0 < ksplit; s0 += 4) {
+    acc_t part[4];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int sl = s0 + i < ksplit ? s0 + i : ksplit - 1;
-      part[i] = ws[(long)sl * quads + q];
+    for (int i = 0; i < 4; ++i) {
+      part[i] = acc_t{0, 0, 0, 0};
+      if (s0 + i < ksplit) part[i] = __builtin_nontemporal_load(ws + (long)(s0 + i) * quads + q);     // read once
     }
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < 4; ++i)
       if (s0 + i < ksplit) sum += part[i];
   }
   const long base = q * 4;
   const int n = (int)(base % N);
+  if constexpr (F16) {
+    if (out_dtype == WQAA_F16 && has_bias != 2) {
+      // the common output: the quad's four float16 results as ONE 8-byte store (was four 2-byte stores per thread)
+      half_t v[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        v[i] = (half_t)sum[i];
+        if (has_bias) v[i] = v[i] + (half_t)(float)reinterpret_cast<const half_t*>(bias)[n + i];
+      }
+      const half2_t lo = {v[0], v[1]}, hi = {v[2], v[3]};
+      *reinterpret_cast<u32x2*>(reinterpret_cast<half_t*>(C) + base) = u32x2{as_u32(lo), as_u32(hi)};
+      return;
+    }
+  }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     if constexpr (F16) {

@@ -310,6 +310,7 @@ class BoundLib:
             check(status)
 
     def plan(self, m: int) -> dict:
+        self._ws_need.clear()      # planning re-reads the tuning variables: the scratch a member needs may change with them
         return select(self.desc, m)
 
 
