@@ -21,16 +21,17 @@ bool gemvx_eligible(const wqaa_matmul_desc& d, int m) {
   if (d.K % E != 0) return false;
   const int g = d.group_size <= 0 ? d.K : d.group_size;
   if (d.K % g != 0 || (d.with_scaling && g % E != 0)) return false;
-  // Long K with enough rows to fill the chip unsplit: every workgroup stages the whole activation row and its chunk
-  // sums before its first dot, which the rounding members (wider workgroups, no sums) do cheaper.  Same-call A/B, int4
-  // g128, exact vs rounding member (profiles/r02_ab_gemvx_longk.txt): M=1 4096x11008 7.76 vs 8.14 us (three activation
-  // items per thread in flight ahead of the weights; 8.5 with one), 4096x14336 10.18 vs 10.09, 8192x28672 29.9 vs 27.2;
-  // M=2 4096x11008 11.2 vs 10.2.  Either numerics meets the contract when strict_reference = 0: the faster member is taken.
+  // Long K with enough rows to fill the chip unsplit, two activation rows: every workgroup stages both activation rows
+  // and their chunk sums before its first dot, which the rounding members (wider workgroups, no sums) do cheaper
+  // (same-call A/B, int4 g128, exact vs rounding member, profiles/r02_ab_gemvx_longk.txt: M=2 4096x11008 11.2 vs 10.2 us).
+  // At M = 1 the exact members keep long K too since their workgroups take 16 rows there (gemvx_choose; profiles/
+  // r02_ab_knobs_longk.txt: 5120x13824 13.0 vs 14.8 us, 8192x28672 24.7 vs 26.7, 4096x14336 9.9-10.2 vs 9.6-10.2).
+  // Either numerics meets the contract when strict_reference = 0: the faster member is taken.
   {
     const int cus = device_info().ok ? device_info().cus : 256;
     const char* f = getenv("WQAA_GEMVX");
     const bool forced = f && atoi(f) == 2;                    // WQAA_GEMVX=2: A/B aid, ignores the fences
-    if (!forced && d.K > 8192 && (d.N + 1) / 2 >= 8 * cus && (m > 1 || d.K > 12288)) return false;
+    if (!forced && d.K > 8192 && (d.N + 1) / 2 >= 8 * cus && m > 1) return false;
     // two activation rows: twice the LDS reads and dots per weight word - the exact member only wins on many-row matrices
     // (same-call, int4 g128: 11008x4096 8.8 vs 9.4 us; 4096^2 5.4 vs 5.1, 4096x11008 11.2 vs 10.2)
     if (!forced && m == 2 && d.N < 8192) return false;
@@ -106,6 +107,21 @@ static int gemvx_choose(const wqaa_matmul_desc& d, int m, GemvxChoice* c) {
   if (slots < 1) slots = 1;
   // ... but never so wide that CUs are left without a workgroup
   while (slots > 1 && (n_rg + slots - 1) / slots < cus) slots /= 2;
+  // Long K (three lane-chunk steps or more): every workgroup stages the whole activation row and its chunk sums, 4 B per
+  // B of weights of ONE row - half the weight bytes of an 8-row workgroup.  Twice the rows per workgroup (up to 16 waves)
+  // wherever the workgroups still fill the chip in whole rounds (same-process A/B, tools/ab_knobs.py, profiles/
+  // r02_ab_knobs_longk.txt): 4096x11008 7.7 -> 7.4 us, 1024x28672 8.6 -> 7.65, 8192x28672 29.2 -> 24.7 (now ahead of the
+  // rounding member's 26.7), 14336x12288 22.0 -> 20.6; 5120x13824 would leave 320 workgroups for 256 CUs (13.0 -> 16.4):
+  // not taken there.
+  if (c->nsteps >= 3) {
+    while (slots * 2 * kw <= 16) {
+      const int nb = (n_rg + slots * 2 - 1) / (slots * 2);
+      const int rounds = (nb + cus - 1) / cus;
+      // one or two rounds of workgroups must be whole ones (> 5 % of a round idle otherwise); three and more even out
+      if (nb < cus || (nb < 3 * cus && (long)rounds * cus * 100 > (long)nb * 105)) break;
+      slots *= 2;
+    }
+  }
   if (const char* f = getenv("WQAA_GEMVX_SLOTS")) slots = atoi(f) > 0 ? atoi(f) : 1;
   if (slots * kw > 16) slots = 16 / kw;
   if (slots < 1) slots = 1;

@@ -87,16 +87,27 @@ def test_two_and_one_bit_weights(wd, fd, zm):
 
 
 @pytest.mark.selector_choice
-def test_long_k_unsplit_keeps_the_rounding_member():
-    """K > 12288 (or M = 2 and K > 8192) with enough rows to fill the chip without a K split: the rounding member is
-    the faster one there (csrc/wqaa_gemvx.hip: gemvx_eligible), and either numerics meets the contract"""
-    for M, N, K in ((1, 4096, 14336), (2, 4096, 11008), (2, 4096, 4096)):
+def test_two_rows_on_few_rows_or_long_k_keeps_the_rounding_member():
+    """M = 2 with K > 8192 on enough rows to fill the chip without a K split, or on fewer than 8192 rows: the rounding
+    member is the faster one there (csrc/wqaa_gemvx.hip: gemvx_eligible), and either numerics meets the contract"""
+    for M, N, K in ((2, 4096, 11008), (2, 4096, 4096)):
         case = make_case(M, N, K, W_dtype="int4", group_size=128, with_scaling=True, scale_mul=0.02, seed=5)
         got, mm = hip_output(case, strict_reference=False)
         assert "_gemvx_" not in mm.plans[M]["name"], mm.plans[M]["name"]
         assert_fp_parity(got, oracle_output(case))
         strict, _ = hip_output(case, strict_reference=True)
         assert np.array_equal(got, strict)
+
+
+@pytest.mark.selector_choice
+@pytest.mark.parametrize("N,K,threads", [(4096, 14336, 1024), (4096, 11008, 1024), (5120, 13824, 512), (1024, 28672, 896)])
+def test_long_k_one_row_batch_takes_sixteen_wave_workgroups_where_they_fill_the_chip(N, K, threads):
+    """M = 1, three lane-chunk steps or more: the exact members, with twice the rows per workgroup (the activation row is
+    staged once per workgroup) wherever that still fills the chip in whole rounds - 5120 x 13824 would leave 320
+    workgroups for 256 CUs and keeps 8 waves (csrc/wqaa_gemvx.hip: gemvx_choose)"""
+    case = make_case(1, N, K, W_dtype="int4", group_size=128, with_scaling=True, scale_mul=0.02, seed=N // 64)
+    got, mm = check(case)
+    assert mm.plans[1]["threads"] == threads, mm.plans[1]
 
 
 @pytest.mark.parametrize("N,K", [(4096, 4096), (11008, 4096), (4096, 11008), (12288, 4096), (1024, 11008)])
