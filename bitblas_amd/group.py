@@ -165,42 +165,64 @@ class LinearGroup(torch.nn.Module):
             it.B, it.Scale, it.Zeros, it.Bias = B, scale, zeros, bias
             keys.append(layer._q_param_keys)
         self._items, self._keys = items, keys
+        mm0 = self.layers[0].bitblas_matmul
+        # the layers accept the same activations iff they agree on K, A_dtype and the M they were built for
+        self._same_input = all((l.bitblas_matmul._a_cols, l.bitblas_matmul._a_torch_dtype, l.bitblas_matmul.dynamic_range is None,
+                                l.bitblas_matmul.config.M) == (mm0._a_cols, mm0._a_torch_dtype, mm0.dynamic_range is None, mm0.config.M)
+                               for l in self.layers)
+        self._ns = [l.out_features for l in self.layers]
+        self._out_dtype = mm0.torch_output_dtype if len({l.bitblas_matmul.torch_output_dtype for l in self.layers}) == 1 else None
+        self._nf = [l for l in self.layers if l.source_format == "nf"]
 
     def forward(self, A, outputs: Optional[Sequence[torch.Tensor]] = None):
         n = len(self.layers)
         mm0 = self.layers[0].bitblas_matmul
         A = mm0.transform_input(A)
         m = mm0.check_activation(A)
-        for layer in self.layers[1:]:
-            if layer.bitblas_matmul.check_activation(A) != m:
-                raise ValueError("the layers of a group take the same input")
-        if not A.is_contiguous():
-            A = A.contiguous()
         if self._items is None or any(not l._params_current() or l._q_param_keys != k for l, k in zip(self.layers, self._keys)):
             self._build()
-        outs = list(outputs) if outputs is not None else [None] * n
+        if not self._same_input:
+            for layer in self.layers[1:]:
+                if layer.bitblas_matmul.check_activation(A) != m:
+                    raise ValueError("the layers of a group take the same input")
+        if not A.is_contiguous():
+            A = A.contiguous()
+        items = self._items
         a_ptr = A.data_ptr()
-        luts = []
-        for i, layer in enumerate(self.layers):
-            mm = layer.bitblas_matmul
-            if outs[i] is None:
-                outs[i] = torch.empty(A.shape[:-1] + (layer.out_features,), dtype=mm.torch_output_dtype, device=A.device)
-            elif not outs[i].is_contiguous() or outs[i].device != A.device:
-                raise ValueError("outputs must be contiguous tensors on A's device")
-            lut = mm._ensure_lut(A.device) if layer.source_format == "nf" else None
-            luts.append(lut)
-            it = self._items[i]
-            it.A, it.C = a_ptr, outs[i].data_ptr()
-            it.LUT = lut.data_ptr() if lut is not None else None
+        if outputs is None:
+            if self._out_dtype is not None:
+                # ONE allocation for the group: the members' (m, N_i) outputs are consecutive contiguous blocks of it
+                flat = torch.empty(m * sum(self._ns), dtype=self._out_dtype, device=A.device)
+                lead = A.shape[:-1]
+                outs = [p.view(lead + (N,)) for p, N in zip(flat.split([m * N for N in self._ns]), self._ns)]
+                base, esz = flat.data_ptr(), flat.element_size()
+                off = 0
+                for i, N in enumerate(self._ns):
+                    items[i].A, items[i].C = a_ptr, base + off * esz
+                    off += m * N
+            else:
+                outs = [torch.empty(A.shape[:-1] + (l.out_features,), dtype=l.bitblas_matmul.torch_output_dtype, device=A.device)
+                        for l in self.layers]
+                for i, o in enumerate(outs):
+                    items[i].A, items[i].C = a_ptr, o.data_ptr()
+        else:
+            outs = list(outputs)
+            for i, o in enumerate(outs):
+                if not o.is_contiguous() or o.device != A.device:
+                    raise ValueError("outputs must be contiguous tensors on A's device")
+                items[i].A, items[i].C = a_ptr, o.data_ptr()
+        for layer in self._nf:
+            lut = layer.bitblas_matmul._ensure_lut(A.device)
+            items[list(self.layers).index(layer)].LUT = lut.data_ptr()
         if m == 0:
             return tuple(outs)
         stream = torch.cuda.current_stream(A.device).cuda_stream
         if any(l.bitblas_matmul.lib.workspace_need(m) for l in self.layers):
             for i, layer in enumerate(self.layers):
-                it = self._items[i]
+                it = items[i]
                 layer.bitblas_matmul.lib.run(it.A, it.B, it.LUT, it.Scale, it.Zeros, it.Bias, it.C, m, stream, A.device)
             return tuple(outs)
-        status = _library().wqaa_matmul_group(self._items, n, m, stream)
+        status = _library().wqaa_matmul_group(items, n, m, stream)
         if status != _lib.OK:
             _lib.check(status)
         return tuple(outs)

@@ -120,3 +120,48 @@ def test_random_int4_activation_configurations():
         fd = False if wd == "int4" else [None, False, True][int(rng.integers(3))]
         M, N, K = int(rng.choice(MS)), int(rng.choice([64, 128, 272, 520])), int(rng.choice([256, 512, 1024, 2048]))
         run_case(M, N, K, wd, fd, seed=int(rng.integers(1 << 30)), out_dtype=str(rng.choice(["int32", "float32"])))
+
+
+def test_random_groups_equal_single_calls():
+    """wqaa_matmul_group over random configurations, member counts and row counts: whether the group fuses into one
+    launch (same descriptor apart from N, M <= 2) or runs member by member, every output equals the member's own call
+    bit for bit - the definition of the entry (include/wqaa.h)."""
+    import torch
+    from bitblas_amd import group as wgroup
+    from test_group_gpu import build
+    from helpers import _to_dev
+    rng = np.random.default_rng(4242)
+    ran = fused = 0
+    for _ in range(60):
+        M, N0, K, kw = draw(rng)
+        M = int(rng.choice([1, 1, 1, 2, 2, 3, 16]))
+        g = kw.get("group_size", -1)
+        if g != -1 and K % g:
+            continue
+        bit = bitblas.Matmul.BITBLAS_TRICK_DTYPE_MAP[kw["W_dtype"]][1]
+        count = int(rng.integers(2, 5))
+        Ns = [int(rng.choice(NS + [1024, 2048])) for _ in range(count)]
+        if kw.get("zeros_mode") == "quantized" and any((n * bit) % 8 for n in Ns):
+            continue
+        strict = bool(rng.random() < 0.5)
+        try:
+            cases = [make_case(M, n, K, seed=int(rng.integers(1 << 30)), **kw) for n in Ns]
+            for c in cases[1:]:
+                c["A"] = cases[0]["A"]
+            built = [build(c, strict) for c in cases]
+        except (ValueError, RuntimeError, AssertionError):
+            continue
+        ops, ws = [b[0] for b in built], [b[1] for b in built]
+        A = _to_dev(cases[0]["A"], "cuda")
+        try:
+            single = [op(A, *w) for op, w in zip(ops, ws)]
+        except (ValueError, RuntimeError):
+            continue            # a configuration the selector refuses (covered by test_random_configurations)
+        plan = wgroup.group_plan(ops, M)
+        grouped = bitblas.matmul_group(ops, A, ws)
+        torch.cuda.synchronize()
+        for i, (s, g_) in enumerate(zip(single, grouped)):
+            assert torch.equal(s, g_), (M, Ns, K, kw, strict, plan, i)
+        ran += 1
+        fused += plan["launches"] == 1
+    assert ran >= 30 and fused >= 10, (ran, fused)
