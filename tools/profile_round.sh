@@ -21,7 +21,7 @@ rm -rf $out/${tag}_trace/*kernel_trace.csv
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_steptrace -o trace -- python $root/bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-members > $out/${tag}_steptrace_stdout.log 2>&1
 f=$(ls $out/${tag}_steptrace/*kernel_stats.csv 2>/dev/null | head -1)
 [ -n "$f" ] && grep -E "Name|wqaa::" $f > $out/${tag}_step_kernel_stats.csv && cat $out/${tag}_step_kernel_stats.csv
-tail -1 $out/${tag}_steptrace_stdout.log > $out/${tag}_step_bench.json
+grep -a "^{\"metric\"" $out/${tag}_steptrace_stdout.log | tail -1 > $out/${tag}_step_bench.json
 rm -rf $out/${tag}_steptrace/*kernel_trace.csv
 for ctr in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $ctr --output-format csv -d $out/${tag}_pmc_$ctr -o pmc -- python $root/bench.py --steps 3 --warmup 1 --layers 4 --no-cpu-baseline --no-members --eager > $out/${tag}_pmc_${ctr}_stdout.log 2>&1
