@@ -353,11 +353,11 @@ int wqaa_group_plan(const wqaa_matmul_desc* const* descs, int count, int m, int*
 }
 
 static int group_impl(const wqaa_group_item* items, const wqaa_epilogue* const* epis, int count, int m, void* stream) {
+  if (count == 0 || m == 0) return WQAA_OK;       // an empty group / m == 0 returns at once (wrapper/tl.py:277)
   if (!items || count < 0) {
     set_error(WQAA_ERR_BAD_DESC, "matmul_group: bad arguments (items=%p count=%d)", (const void*)items, count);
     return WQAA_ERR_BAD_DESC;
   }
-  if (count == 0 || m == 0) return WQAA_OK;
   // epilogues: all members or none; the fused launch needs one kind (caller's row scales / in-kernel quantiser)
   int epi_mode = 0;
   bool epi_uniform = true;

@@ -161,3 +161,49 @@ def test_c_packer_reproduces_the_reference_int4_tests_operands():
         codes = oracle.general_decompress(packed, bits).astype(np.int8)
         assert np.array_equal(wlib.pack_weight(codes, bits, wlib.LAYOUT_PLAIN, wlib.I4), packed)
         assert np.array_equal(wlib.unpack_weight(packed, codes.shape[1], bits, wlib.LAYOUT_PLAIN, wlib.I4), codes)
+
+
+def test_header_is_plain_c_and_links_from_c(tmp_path):
+    """include/wqaa.h is the drop-in boundary: it must compile as C (no C++, no HIP, no torch types) and a C program that
+    sees nothing but the header must be able to plan an operator and a group through the shared library."""
+    import shutil
+    import subprocess
+    cc = shutil.which("gcc") or shutil.which("cc")
+    if cc is None:
+        pytest.skip("no C compiler")
+    src = tmp_path / "use_wqaa.c"
+    src.write_text(r'''
+#include <stdio.h>
+#include <string.h>
+#include "wqaa.h"
+int main(void) {
+  wqaa_matmul_desc d, k;
+  wqaa_plan p;
+  const wqaa_matmul_desc* grp[3];
+  int launches = 0;
+  memset(&d, 0, sizeof d);
+  d.struct_size = (int32_t)sizeof d; d.N = 4096; d.K = 4096; d.a_dtype = WQAA_F16; d.w_format = WQAA_W_INT; d.w_bits = 4;
+  d.out_dtype = WQAA_F16; d.group_size = 128; d.with_scaling = 1; d.w_layout = WQAA_LAYOUT_LOP3;
+  init();
+  if (wqaa_abi_version() != WQAA_ABI_VERSION) return 2;
+  if (wqaa_select(&d, 1, &p) != WQAA_OK || p.kernel_family != 1) return 3;
+  printf("%s\n", p.name);
+  k = d; k.N = 1024;
+  grp[0] = &d; grp[1] = &k; grp[2] = &k;
+  if (wqaa_group_plan(grp, 3, 1, &launches, &p) != WQAA_OK || launches != 1) return 4;
+  printf("%s\n", p.name);
+  if (wqaa_matmul(&d, NULL, NULL, NULL, NULL, NULL, NULL, NULL, 0, NULL) != WQAA_OK) return 5;   /* m == 0: returns at once */
+  if (wqaa_matmul_group(NULL, 0, 1, NULL) != WQAA_OK) return 6;
+  d.struct_size = 4;
+  if (wqaa_select(&d, 1, &p) != WQAA_ERR_BAD_DESC || wqaa_last_error() != WQAA_ERR_BAD_DESC) return 7;
+  return 0;
+}
+''')
+    exe = tmp_path / "use_wqaa"
+    libdir = os.path.dirname(wlib.LIB_PATH)
+    subprocess.run([cc, "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe),
+                    "-L", libdir, "-lwqaa_hip", f"-Wl,-rpath,{libdir}"], check=True, capture_output=True, text=True)
+    res = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert res.returncode == 0, (res.returncode, res.stdout, res.stderr)
+    lines = res.stdout.split()
+    assert "gemv" in lines[0] and lines[1].endswith("_x3")
