@@ -57,7 +57,7 @@ class BitLinear(nn.Module):
             x = x.to(torch.float16)
         q = torch.empty(x.shape, dtype=torch.int8, device=x.device)
         s = torch.empty(x.shape[:-1], dtype=torch.float32, device=x.device)
-        _lib.act_quant_int8(x, q, s, torch.cuda.current_stream(x.device).cuda_stream)
+        _lib.act_quant_int8(x, q, s, _lib.current_stream_handle(x.device))
         return q, s
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
@@ -73,12 +73,12 @@ class BitLinear(nn.Module):
             xc = x if x.is_contiguous() else x.contiguous()
             self.bitblas_matmul.lib.run_fused_quant(xc.data_ptr(), self.qweight.data_ptr(),
                                                     None if self.bias is None else self.bias.data_ptr(), out.data_ptr(), m,
-                                                    torch.cuda.current_stream(x.device).cuda_stream, sw)
+                                                    _lib.current_stream_handle(x.device), sw)
             return out
         q, si = self.activation_quant(x)
         self.bitblas_matmul.lib.run_fused(q.data_ptr(), self.qweight.data_ptr(),
                                           None if self.bias is None else self.bias.data_ptr(), out.data_ptr(), m,
-                                          torch.cuda.current_stream(x.device).cuda_stream, si.data_ptr(), sw)
+                                          _lib.current_stream_handle(x.device), si.data_ptr(), sw)
         return out
 
 
@@ -115,7 +115,7 @@ class BitLinearGroup(nn.Module):
             # larger batches: one quantiser launch for the group, then the layers' matmuls with the fused post-process
             q, si = l0.activation_quant(x)
             outs = []
-            stream = torch.cuda.current_stream(x.device).cuda_stream
+            stream = _lib.current_stream_handle(x.device)
             for l in layers:
                 out = torch.empty(x.shape[:-1] + (l.out_features,), dtype=torch.float16, device=x.device)
                 sw = getattr(l, "_sw_host", None)
@@ -148,7 +148,7 @@ class BitLinearGroup(nn.Module):
             e.tensor_scale = float(sw)
             eptr[i] = ctypes.pointer(e)
         lib = _library()
-        status = lib.wqaa_matmul_group_ex(items, eptr, n, m, torch.cuda.current_stream(x.device).cuda_stream)
+        status = lib.wqaa_matmul_group_ex(items, eptr, n, m, _lib.current_stream_handle(x.device))
         if status != _lib.OK:
             _lib.check(status)
         return tuple(outs)

@@ -123,7 +123,7 @@ def matmul_group(ops: Sequence[Matmul], A: Union[torch.Tensor, Sequence[torch.Te
         it.Bias = bias.data_ptr() if bias is not None else None
     if m == 0:
         return outs
-    stream = torch.cuda.current_stream(dev).cuda_stream
+    stream = _lib.current_stream_handle(dev)
     # members that need scratch (split-K MFMA members, m > 2) are never fused: run them through their own fast path,
     # which hands the library a caller-owned workspace
     if any(op.lib.workspace_need(m) for op in ops):
@@ -216,7 +216,7 @@ class LinearGroup(torch.nn.Module):
             items[list(self.layers).index(layer)].LUT = lut.data_ptr()
         if m == 0:
             return tuple(outs)
-        stream = torch.cuda.current_stream(A.device).cuda_stream
+        stream = _lib.current_stream_handle(A.device)
         if any(l.bitblas_matmul.lib.workspace_need(m) for l in self.layers):
             for i, layer in enumerate(self.layers):
                 it = items[i]

@@ -539,7 +539,7 @@ class Matmul:
         if not output.is_contiguous():
             raise ValueError("output must be a contiguous tensor")
         lut = self._ensure_lut(A.device)
-        stream = torch.cuda.current_stream(A.device).cuda_stream
+        stream = _lib.current_stream_handle(A.device)
         self.lib.run(
             A.data_ptr(), W.data_ptr(), lut.data_ptr() if lut is not None else None,
             scale.data_ptr() if scale is not None else None,

@@ -17,6 +17,7 @@ import torch
 import torch.nn as nn
 
 from .cache import get_database_path, global_operator_cache
+from .lib import current_stream_handle
 from .matmul import Matmul, MatmulConfig, torch_dtype
 from .quantization import general_compress
 from .target import auto_detect_nvidia_target
@@ -185,7 +186,7 @@ class Linear(nn.Module):
         lut = mm._ensure_lut(A.device) if self.source_format == "nf" else None
         B, scale, zeros, bias = self._q_run
         mm.lib.run(A.data_ptr(), B, lut.data_ptr() if lut is not None else None, scale, zeros, bias,
-                   output.data_ptr(), m, torch.cuda.current_stream(A.device).cuda_stream, A.device)
+                   output.data_ptr(), m, current_stream_handle(A.device), A.device)
         return output
 
     def load_and_transform_weight(self, weight: torch.Tensor, scales: torch.Tensor = None,
