@@ -191,10 +191,14 @@ def time_member_gemm(device, gen, M=4096, N=4096, K=4096, W_dtype="uint4", A_dty
             "GBps_algorithmic": nbytes / t / 1e9, "frac_of_mfma_peak": tf / peak, "mfma_peak": peak}
 
 
-def time_member_dense(device, gen, M, N, K, kind="fp8", n_buf=4):
+def time_member_dense(device, gen, M, N, K, kind="fp8", n_buf=4, own=False):
     """Dense members: e4m3 x e4m3 MFMA GEMM on Llama-3-70B shapes (BASELINE config c5, one GPU's unsharded
     matrix) and the M = 1 W_int2 A_int8 GEMV (c4)."""
     import bitblas_amd as bitblas
+    # own=True: the library's own HIP MFMA member instead of the vendor GEMM the plain dense pairs take by default from
+    # M = 16 up (csrc/wqaa_dense_lib.hip; WQAA_DENSE_LIB is a plan-time switch: set while the operator is planned AND timed)
+    if own:
+        os.environ["WQAA_DENSE_LIB"] = "0"
     try:
         if kind == "fp8":
             cfg = bitblas.MatmulConfig(M=M, N=N, K=K, A_dtype="e4m3_float8", W_dtype="e4m3_float8", accum_dtype="float32",
@@ -202,8 +206,18 @@ def time_member_dense(device, gen, M, N, K, kind="fp8", n_buf=4):
         else:
             cfg = bitblas.MatmulConfig(M=M, N=N, K=K, A_dtype="int8", W_dtype="int2", accum_dtype="int32", out_dtype="int32")
         op = bitblas.Matmul(cfg, enable_tuning=False)
+        return _time_member_dense(device, gen, op, M, N, K, kind, n_buf)
     except Exception as exc:  # member not built: report, never fake
         return {"error": str(exc)}
+    finally:
+        if own:
+            del os.environ["WQAA_DENSE_LIB"]
+            op_ = locals().get("op")
+            if op_ is not None:
+                op_.lib.plan(M)          # planning re-reads the switch for whatever runs next
+
+
+def _time_member_dense(device, gen, op, M, N, K, kind, n_buf):
     if kind == "fp8":
         A = (torch.rand((M, K), device=device, generator=gen) * 2 - 1).to(torch.float8_e4m3fn)
         Ws = [(torch.rand((N, K), device=device, generator=gen) * 2 - 1).to(torch.float8_e4m3fn) for _ in range(n_buf)]
@@ -612,8 +626,10 @@ def main():
             members["gemm_int2_int8_m4096"] = time_member_gemm(device, gen, 4096, W_dtype="int2", A_dtype="int8")
             members["gemv_int2_int8_m1"] = time_member_dense(device, gen, 1, 4096, 4096, kind="int2", n_buf=64)
             # c5: dense e4m3 x e4m3 on every Llama-3-70B linear of one (unsharded) GPU, M = 4096 and M = 1
+            # (plain dense pairs: the vendor library by default, this library's own MFMA member under `_own`)
             for (name, N, K, nb) in (("o", 8192, 8192, 4), ("down", 8192, 28672, 2), ("qkv", 10240, 8192, 4), ("gate", 28672, 8192, 2)):
                 members[f"gemm_fp8_m4096_{name}_n{N}_k{K}"] = time_member_dense(device, gen, 4096, N, K, n_buf=nb)
+                members[f"gemm_fp8_m4096_{name}_n{N}_k{K}_own"] = time_member_dense(device, gen, 4096, N, K, n_buf=nb, own=True)
             for (name, N, K) in (("o", 8192, 8192), ("down", 8192, 28672)):
                 members[f"gemv_fp8_m1_{name}_n{N}_k{K}"] = time_member_dense(device, gen, 1, N, K, n_buf=max(3, (640 << 20) // (N * K)))
             result["members"] = members

@@ -63,7 +63,8 @@ def build(force: bool = False, jobs: int | None = None, verbose: bool = False) -
     with cf.ThreadPoolExecutor(max_workers=jobs) as pool:
         objs = list(pool.map(lambda s: compile_one(s, force), sources))
     if force or _mtime(LIB) < max(_mtime(o) for o in objs):
-        cmd = [hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB] + objs
+        # hipBLASLt: the plain dense GEMMs (csrc/wqaa_dense_lib.hip); everything quantised is the library's own kernels
+        cmd = [hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB] + objs + ["-lhipblaslt"]
         res = subprocess.run(cmd, capture_output=True, text=True)
         if res.returncode != 0:
             raise RuntimeError(f"link failed:\n{res.stdout}\n{res.stderr}")

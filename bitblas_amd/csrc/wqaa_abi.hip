@@ -203,6 +203,24 @@ static int matmul_impl(const wqaa_matmul_desc* desc, const void* A, const void* 
     }
   }
   hipEvent_t e0 = reinterpret_cast<hipEvent_t>(ev0), e1 = reinterpret_cast<hipEvent_t>(ev1);
+  // plain dense GEMMs (no decode, no bias, no caller epilogue) at M >= 16: the vendor library (wqaa_dense_lib.hip)
+  if (!epi && !e0 && !e1) {
+    static thread_local ChoiceMemo<int> lib_memo;
+    bool lib;
+    if (const int* hit = lib_memo.find(*desc, m, 3)) {
+      lib = *hit != 0;
+    } else {
+      const int saved = g_last_error;
+      lib = dense_lib_eligible(*desc, m);
+      g_last_error = saved;
+      lib_memo.put(*desc, m, 3, lib ? 1 : 0);
+    }
+    if (lib) {
+      int st = dense_lib_launch(*desc, A, B, C, m, s, opts);
+      if (st == WQAA_OK) g_last_error = WQAA_OK;
+      return st;
+    }
+  }
   const bool quant_in = epi && (epi->flags & WQAA_EPI_QUANTIZE_INPUT);
   if (epi && (epi->struct_size != (int32_t)sizeof(wqaa_epilogue) || (!epi->row_scale && !quant_in))) {
     set_error(WQAA_ERR_BAD_DESC, "matmul_ex: malformed epilogue descriptor");
@@ -315,6 +333,7 @@ int wqaa_matmul_ex(const wqaa_matmul_desc* desc, const void* A, const void* B, c
 
 uint64_t wqaa_workspace_bytes(const wqaa_matmul_desc* desc, int m) {
   if (!valid_desc(desc) || m <= 0) return 0;
+  if (dense_lib_eligible(*desc, m)) return (uint64_t)dense_lib_workspace_bytes(*desc, m);
   bool use_gemm = false;
   dispatch(*desc, m, &use_gemm);
   return use_gemm ? (uint64_t)gemm_workspace_bytes(*desc, m) : 0;
@@ -458,6 +477,7 @@ int wqaa_select(const wqaa_matmul_desc* desc, int m, wqaa_plan* plan) {
   if (plan) memset(plan, 0, sizeof(*plan));
   if (m <= 0) m = 1;
   g_plan_epoch.fetch_add(1, std::memory_order_relaxed);   // planning re-reads the tuning environment (ChoiceMemo)
+  if (dense_lib_eligible(*desc, m)) return dense_lib_plan(*desc, m, plan);
   bool use_gemm = false;
   dispatch(*desc, m, &use_gemm);
   return use_gemm ? gemm_plan(*desc, m, plan) : gemv_plan(*desc, m, plan);

@@ -106,6 +106,16 @@ size_t gemm_workspace_bytes(const wqaa_matmul_desc& d, int m);
 int act_quant_launch(const void* X, int64_t rows, int K, void* Q, float* S, hipStream_t stream);
 void gemm_init();
 
+// the library's scratch pool: one slab per (device, stream), retired - never freed - when it has to grow (wqaa_gemm.hip)
+void* pool_workspace(hipStream_t stream, size_t bytes);
+
+// plain dense GEMMs (W_dtype == A_dtype, a float type, no scale / zeros / bias, M >= 16) through hipBLASLt (wqaa_dense_lib.hip)
+bool dense_lib_eligible(const wqaa_matmul_desc& d, int m);
+int dense_lib_plan(const wqaa_matmul_desc& d, int m, wqaa_plan* plan);
+size_t dense_lib_workspace_bytes(const wqaa_matmul_desc& d, int m);
+int dense_lib_launch(const wqaa_matmul_desc& d, const void* A, const void* B, void* C, int m, hipStream_t stream,
+                     const wqaa_call_opts* opts);
+
 int debug_decode_launch(const void* packed, int64_t nwords, int w_format, int bits, int layout,
                         int a_dtype, int strict, const void* lut, void* out, hipStream_t stream);
 

@@ -1,0 +1,185 @@
+// wqaa_dense_lib.hip - the PLAIN dense GEMMs of the operator (W_dtype == A_dtype, a float type, no scale / zeros / bias:
+// BASELINE c5's e4m3 x e4m3 and the float16 / bfloat16 fallbacks, reference: bitblas/ops/general_matmul/tirscript/
+// matmul_impl.py:50-86, tilelang/dense/matmul.py:62-145) go to the vendor library, hipBLASLt, from M = 16 up.
+//
+// Nothing is decoded in these: C = A . W^T with fp32 accumulation is exactly what the library's tuned assembly kernels
+// compute, and on MI355X they are ahead of this library's own HIP MFMA members (same operands, hipGraph replays,
+// tools/blaslt_probe.py -> profiles/r02_blaslt_probe.txt): e4m3 M = 4096 on the Llama-3-70B shapes 2.3-2.6 PFLOP/s
+// against 1.6-1.8 (results bit-identical), float16 4096^3 1331 against 889 TFLOP/s, and ahead at every M >= 16 tried.
+// The quantised paths - everything that fuses an unpack / dequant into the loop - stay on the hand-written kernels, as
+// do the dense members for M < 16 (GEMV, decode-batch), with a bias (the reference adds it AFTER the cast to out_dtype,
+// the library's epilogue before), with the callers' fused epilogues, for int8 and for mixed fp8 pairs.
+// WQAA_DENSE_LIB=0 (plan-time) keeps every dense shape on the own members.
+//
+// Row-major C[m, n] = sum_k A[m, k] W[n, k] is the column-major product C^T = op_T(Wcm) . Acm with Wcm = W's memory
+// read as K x N (ld = K), Acm = A's memory read as K x M (ld = K), C^T = N x M (ld = N): the "TN" form the library's
+// fp8 kernels want.  Workspace: caller-owned through wqaa_matmul_opts (wqaa_workspace_bytes reports the selected
+// algorithm's need) or the per-(device, stream) pool of wqaa_gemm.hip - the same ownership rules as the split-K scratch.
+#include <hipblaslt/hipblaslt.h>
+
+#include <deque>
+#include <mutex>
+
+#include "wqaa_common.h"
+
+namespace wqaa {
+
+namespace {
+
+struct LtPlan {
+  wqaa_matmul_desc d;
+  int m, dev;
+  bool ok;
+  hipblasLtMatmulDesc_t op;
+  hipblasLtMatrixLayout_t la, lb, lc;
+  hipblasLtMatmulAlgo_t algo;
+  size_t ws;
+};
+
+std::mutex g_mu;
+std::deque<LtPlan> g_plans;       // references stay valid when it grows
+hipblasLtHandle_t g_handle[32] = {};
+
+constexpr size_t kMaxWorkspace = 64u << 20;
+
+bool to_hip_type(int dt, hipDataType* out) {
+  switch (dt) {
+    case WQAA_F16: *out = HIP_R_16F; return true;
+    case WQAA_BF16: *out = HIP_R_16BF; return true;
+    case WQAA_F32: *out = HIP_R_32F; return true;
+    case WQAA_E4M3: *out = HIP_R_8F_E4M3; return true;
+    case WQAA_E5M2: *out = HIP_R_8F_E5M2; return true;
+  }
+  return false;
+}
+
+bool enabled() {
+  static thread_local unsigned seen_epoch = 0;
+  static thread_local bool on = true;
+  const unsigned ep = g_plan_epoch.load(std::memory_order_relaxed);
+  if (ep != seen_epoch) {
+    const char* f = getenv("WQAA_DENSE_LIB");
+    on = !(f && atoi(f) == 0);
+    seen_epoch = ep;
+  }
+  return on;
+}
+
+bool shape_ok(const wqaa_matmul_desc& d, int m) {
+  if (m < 16 || d.w_format != WQAA_W_NATIVE || d.with_bias || d.with_scaling || d.zeros_mode != WQAA_Z_NONE) return false;
+  if (d.a_dtype != WQAA_F16 && d.a_dtype != WQAA_BF16 && d.a_dtype != WQAA_E4M3 && d.a_dtype != WQAA_E5M2) return false;
+  if (d.out_dtype != WQAA_F16 && d.out_dtype != WQAA_BF16 && d.out_dtype != WQAA_F32) return false;
+  const bool f8 = d.a_dtype == WQAA_E4M3 || d.a_dtype == WQAA_E5M2;
+  if (d.K % (f8 ? 16 : 8) != 0 || d.N % 8 != 0) return false;      // 16-byte rows: what the library's vector kernels assume
+  return true;
+}
+
+// the plan of (desc, m) on the current device: descriptors + the heuristic's first algorithm; nullptr if the library
+// has none for it (the caller then stays on the own members)
+const LtPlan* get_plan(const wqaa_matmul_desc& d, int m) {
+  const int dev = current_device();
+  if (dev < 0 || dev >= 32) return nullptr;
+  std::lock_guard<std::mutex> lk(g_mu);
+  for (const auto& p : g_plans)
+    if (p.m == m && p.dev == dev && memcmp(&p.d, &d, sizeof(d)) == 0) return p.ok ? &p : nullptr;
+  LtPlan p;
+  memset(&p, 0, sizeof(p));
+  p.d = d; p.m = m; p.dev = dev; p.ok = false;
+  hipDataType ta, tc;
+  bool good = to_hip_type(d.a_dtype, &ta) && to_hip_type(d.out_dtype, &tc);
+  if (good && !g_handle[dev]) good = hipblasLtCreate(&g_handle[dev]) == HIPBLAS_STATUS_SUCCESS;
+  hipblasLtMatmulPreference_t pref = nullptr;
+  if (good) {
+    good = hipblasLtMatmulDescCreate(&p.op, HIPBLAS_COMPUTE_32F, HIP_R_32F) == HIPBLAS_STATUS_SUCCESS;
+    const hipblasOperation_t tr = HIPBLAS_OP_T, no = HIPBLAS_OP_N;
+    good = good && hipblasLtMatmulDescSetAttribute(p.op, HIPBLASLT_MATMUL_DESC_TRANSA, &tr, sizeof(tr)) == HIPBLAS_STATUS_SUCCESS;
+    good = good && hipblasLtMatmulDescSetAttribute(p.op, HIPBLASLT_MATMUL_DESC_TRANSB, &no, sizeof(no)) == HIPBLAS_STATUS_SUCCESS;
+    good = good && hipblasLtMatrixLayoutCreate(&p.la, ta, d.K, d.N, d.K) == HIPBLAS_STATUS_SUCCESS;     // W as K x N, ld K
+    good = good && hipblasLtMatrixLayoutCreate(&p.lb, ta, d.K, m, d.K) == HIPBLAS_STATUS_SUCCESS;       // A as K x M, ld K
+    good = good && hipblasLtMatrixLayoutCreate(&p.lc, tc, d.N, m, d.N) == HIPBLAS_STATUS_SUCCESS;       // C^T as N x M, ld N
+    good = good && hipblasLtMatmulPreferenceCreate(&pref) == HIPBLAS_STATUS_SUCCESS;
+    uint64_t maxws = kMaxWorkspace;
+    good = good && hipblasLtMatmulPreferenceSetAttribute(pref, HIPBLASLT_MATMUL_PREF_MAX_WORKSPACE_BYTES, &maxws, sizeof(maxws)) ==
+                       HIPBLAS_STATUS_SUCCESS;
+    if (good) {
+      hipblasLtMatmulHeuristicResult_t res[1];
+      int found = 0;
+      good = hipblasLtMatmulAlgoGetHeuristic(g_handle[dev], p.op, p.la, p.lb, p.lc, p.lc, pref, 1, res, &found) == HIPBLAS_STATUS_SUCCESS &&
+             found > 0 && res[0].state == HIPBLAS_STATUS_SUCCESS;
+      if (good) {
+        p.algo = res[0].algo;
+        p.ws = res[0].workspaceSize;
+      }
+    }
+    if (pref) (void)hipblasLtMatmulPreferenceDestroy(pref);
+  }
+  (void)hipGetLastError();
+  p.ok = good;
+  g_plans.push_back(p);
+  return good ? &g_plans.back() : nullptr;
+}
+
+}  // namespace
+
+bool dense_lib_eligible(const wqaa_matmul_desc& d, int m) {
+  if (!shape_ok(d, m) || !enabled() || !device_info().ok) return false;
+  return get_plan(d, m) != nullptr;
+}
+
+int dense_lib_plan(const wqaa_matmul_desc& d, int m, wqaa_plan* plan) {
+  const LtPlan* p = get_plan(d, m);
+  if (!p) {
+    set_error(WQAA_ERR_UNSUPPORTED, "dense: hipBLASLt has no algorithm for this shape");
+    return WQAA_ERR_UNSUPPORTED;
+  }
+  if (plan) {
+    plan->kernel_family = 3;
+    plan->block_m = plan->block_n = plan->block_k = 0;       // the library's choice
+    plan->threads = plan->grid = 0;
+    plan->split_k = 1;
+    plan->lds_bytes = 0;
+    char wd[24];
+    short_wdtype(d, wd, sizeof(wd));
+    snprintf(plan->name, sizeof(plan->name), "matmul_m%dn%dk%d_%sx%s_hipblaslt", m, d.N, d.K, short_dtype(d.a_dtype), wd);
+  }
+  return WQAA_OK;
+}
+
+size_t dense_lib_workspace_bytes(const wqaa_matmul_desc& d, int m) {
+  const LtPlan* p = get_plan(d, m);
+  return p ? p->ws : 0;
+}
+
+int dense_lib_launch(const wqaa_matmul_desc& d, const void* A, const void* B, void* C, int m, hipStream_t stream,
+                     const wqaa_call_opts* opts) {
+  const LtPlan* p = get_plan(d, m);
+  if (!p) {
+    set_error(WQAA_ERR_UNSUPPORTED, "dense: hipBLASLt has no algorithm for this shape");
+    return WQAA_ERR_UNSUPPORTED;
+  }
+  void* ws = nullptr;
+  if (p->ws) {
+    if (opts && opts->workspace) {
+      if (opts->workspace_bytes < p->ws || (reinterpret_cast<uintptr_t>(opts->workspace) & 15)) {
+        set_error(WQAA_ERR_BAD_DESC, "dense: workspace of %zu B (16-byte aligned) needed, got %zu B at %p", p->ws,
+                  (size_t)opts->workspace_bytes, opts->workspace);
+        return WQAA_ERR_BAD_DESC;
+      }
+      ws = opts->workspace;
+    } else {
+      ws = pool_workspace(stream, p->ws);
+      if (!ws) return WQAA_ERR_LAUNCH;
+    }
+  }
+  const float alpha = 1.f, beta = 0.f;
+  const hipblasStatus_t st = hipblasLtMatmul(g_handle[p->dev], p->op, &alpha, B, p->la, A, p->lb, &beta, C, p->lc, C, p->lc, &p->algo, ws,
+                                             p->ws, stream);
+  if (st != HIPBLAS_STATUS_SUCCESS) {
+    (void)hipGetLastError();
+    set_error(WQAA_ERR_LAUNCH, "dense: hipblasLtMatmul failed with status %d", (int)st);
+    return WQAA_ERR_LAUNCH;
+  }
+  return WQAA_OK;
+}
+
+}  // namespace wqaa

@@ -22,7 +22,7 @@ struct WsSlab {
 static std::vector<WsSlab> g_ws;
 static std::vector<void*> g_ws_retired;
 static std::mutex g_ws_mu;
-static void* workspace(hipStream_t stream, size_t bytes) {
+void* pool_workspace(hipStream_t stream, size_t bytes) {
   const int dev = current_device();
   if (dev < 0) return nullptr;
   std::lock_guard<std::mutex> lk(g_ws_mu);
@@ -348,7 +348,7 @@ int gemm_launch(const wqaa_matmul_desc& d, const void* A, const void* B, const v
       }
       a.ws = opts->workspace;
     } else {
-      a.ws = workspace(stream, need);
+      a.ws = pool_workspace(stream, need);
       if (!a.ws) return WQAA_ERR_LAUNCH;
     }
   }

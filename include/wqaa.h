@@ -109,7 +109,7 @@ typedef struct wqaa_matmul_desc {
 
 /* what the selector chose for (desc, m): reported for tests, rocprof attribution and the cache */
 typedef struct wqaa_plan {
-  int32_t kernel_family;  /* 0 none, 1 gemv (VALU dot), 2 gemm (MFMA) */
+  int32_t kernel_family;  /* 0 none, 1 gemv (VALU dot), 2 gemm (MFMA), 3 vendor-library GEMM (hipBLASLt: plain dense pairs, M >= 16) */
   int32_t block_m, block_n, block_k;
   int32_t threads;
   int32_t grid;
