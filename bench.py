@@ -140,7 +140,7 @@ def time_member_gemv(device, gen, N, K, n_buf=64, strict=False):
             "frac_of_hbm_peak": nbytes / t / 1e9 / HBM_PEAK_GBS, "buffers": n_buf}
 
 
-def time_member_gemm(device, gen, M=4096, N=4096, K=4096, W_dtype="uint4", A_dtype="float16", n_buf=8):
+def time_member_gemm(device, gen, M=4096, N=4096, K=4096, W_dtype="uint4", A_dtype="float16", n_buf=8, tuned=False):
     """MFMA GEMM members (BASELINE configs c3 / c4): TFLOP/s from graph-replayed launches."""
     int8 = A_dtype == "int8"
     try:
@@ -148,6 +148,11 @@ def time_member_gemm(device, gen, M=4096, N=4096, K=4096, W_dtype="uint4", A_dty
                     zeros=not int8, scaling=not int8, accum="int32" if int8 else "float16")
         if op.plans[M]["kernel_family"] != 2:
             return None
+        if tuned:
+            # `Matmul.hardware_aware_finetune` (the reference's default: enable_tuning=True): the fused MFMA member and the
+            # two-pass member (B_decode to a scratch + the vendor GEMM) are timed on the device, the faster one is kept
+            op = bitblas.Matmul(op.config, enable_tuning=False)
+            op.hardware_aware_finetune()
     except Exception as exc:  # member not built: report, never fake
         return {"error": str(exc)}
     bits = op.bit
@@ -187,7 +192,8 @@ def time_member_gemm(device, gen, M=4096, N=4096, K=4096, W_dtype="uint4", A_dty
         roof = {"bound": "mfma", "achieved": tf, "peak": peak, "unit": "TFLOP/s" if not int8 else "TOP/s", "frac": tf / peak,
                 "flops_per_launch": 2.0 * M * N * K}
     return {"workload": f"W_{W_dtype} A_{A_dtype} GEMM M={M} N={N} K={K}" + ("" if int8 else " g=128 zeros=original"),
-            "kernel": op.plans[M]["name"], "us_per_launch": t * 1e6, "TFLOPs": tf, "roofline": roof,
+            "kernel": op.plans[M]["name"], **({"tuning": getattr(op, "_tuned", {}).get(M, "fused member kept")} if tuned else {}),
+            "us_per_launch": t * 1e6, "TFLOPs": tf, "roofline": roof,
             "GBps_algorithmic": nbytes / t / 1e9, "frac_of_mfma_peak": tf / peak, "mfma_peak": peak}
 
 
@@ -621,9 +627,11 @@ def main():
                 members[f"gemv_int4_n{N}k{K}"] = time_member_gemv(device, gen, N, K)
                 members[f"gemv_int4_n{N}k{K}_strict"] = time_member_gemv(device, gen, N, K, strict=True)
             members["gemm_uint4_m4096"] = time_member_gemm(device, gen, 4096)
+            members["gemm_uint4_m4096_tuned"] = time_member_gemm(device, gen, 4096, tuned=True)
             members["gemm_uint4_m128"] = time_member_gemm(device, gen, 128)
             members["gemm_uint4_m16"] = time_member_gemm(device, gen, 16)
             members["gemm_int2_int8_m4096"] = time_member_gemm(device, gen, 4096, W_dtype="int2", A_dtype="int8")
+            members["gemm_int2_int8_m4096_tuned"] = time_member_gemm(device, gen, 4096, W_dtype="int2", A_dtype="int8", tuned=True)
             members["gemv_int2_int8_m1"] = time_member_dense(device, gen, 1, 4096, 4096, kind="int2", n_buf=64)
             # c5: dense e4m3 x e4m3 on every Llama-3-70B linear of one (unsharded) GPU, M = 4096 and M = 1
             # (plain dense pairs: the vendor library by default, this library's own MFMA member under `_own`)

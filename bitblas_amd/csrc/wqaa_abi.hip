@@ -220,6 +220,24 @@ static int matmul_impl(const wqaa_matmul_desc* desc, const void* A, const void* 
       if (st == WQAA_OK) g_last_error = WQAA_OK;
       return st;
     }
+    // the tuned two-pass member (desc.two_pass_min_m): B_decode to a scratch, then the plain GEMM through the library
+    if (desc->two_pass_min_m > 0 || getenv("WQAA_TWO_PASS")) {
+      static thread_local ChoiceMemo<int> tp_memo;
+      bool tp;
+      if (const int* hit = tp_memo.find(*desc, m, 5)) {
+        tp = *hit != 0;
+      } else {
+        const int saved = g_last_error;
+        tp = gemm_two_pass_eligible(*desc, m);
+        g_last_error = saved;
+        tp_memo.put(*desc, m, 5, tp ? 1 : 0);
+      }
+      if (tp) {
+        int st = gemm_two_pass_launch(*desc, A, B, LUT, Scale, Zeros, C, m, s, opts);
+        if (st == WQAA_OK) g_last_error = WQAA_OK;
+        return st;
+      }
+    }
   }
   const bool quant_in = epi && (epi->flags & WQAA_EPI_QUANTIZE_INPUT);
   if (epi && (epi->struct_size != (int32_t)sizeof(wqaa_epilogue) || (!epi->row_scale && !quant_in))) {
@@ -334,6 +352,7 @@ int wqaa_matmul_ex(const wqaa_matmul_desc* desc, const void* A, const void* B, c
 uint64_t wqaa_workspace_bytes(const wqaa_matmul_desc* desc, int m) {
   if (!valid_desc(desc) || m <= 0) return 0;
   if (dense_lib_eligible(*desc, m)) return (uint64_t)dense_lib_workspace_bytes(*desc, m);
+  if (gemm_two_pass_eligible(*desc, m)) return (uint64_t)gemm_two_pass_workspace_bytes(*desc, m);
   bool use_gemm = false;
   dispatch(*desc, m, &use_gemm);
   return use_gemm ? (uint64_t)gemm_workspace_bytes(*desc, m) : 0;
@@ -463,6 +482,25 @@ int wqaa_matmul_group_ex(const wqaa_group_item* items, const wqaa_epilogue* cons
   return group_impl(items, epilogues, count, m, stream);
 }
 
+int wqaa_dequantize(const wqaa_matmul_desc* desc, const void* B, const void* LUT, const void* Scale, const void* Zeros,
+                    void* out, void* stream) {
+  if (!valid_desc(desc)) return WQAA_ERR_BAD_DESC;
+  if (!B || !out || (desc->with_scaling && !Scale) || (desc->zeros_mode != WQAA_Z_NONE && !Zeros) ||
+      (desc->w_format == WQAA_W_NF && !LUT)) {
+    set_error(WQAA_ERR_BAD_DESC, "dequantize: null operand the descriptor requires");
+    return WQAA_ERR_BAD_DESC;
+  }
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  StreamDeviceScope scope(s);
+  if (!device_info().ok) {
+    set_error(WQAA_ERR_NO_DEVICE, "no HIP device visible");
+    return WQAA_ERR_NO_DEVICE;
+  }
+  int st = gemm_dequantize_launch(*desc, B, LUT, Scale, Zeros, out, s);
+  if (st == WQAA_OK) g_last_error = WQAA_OK;
+  return st;
+}
+
 int wqaa_act_quant_int8(const void* X, int64_t rows, int K, void* Q, float* S, void* stream) {
   StreamDeviceScope scope(reinterpret_cast<hipStream_t>(stream));
   if (!device_info().ok) {
@@ -478,6 +516,7 @@ int wqaa_select(const wqaa_matmul_desc* desc, int m, wqaa_plan* plan) {
   if (m <= 0) m = 1;
   g_plan_epoch.fetch_add(1, std::memory_order_relaxed);   // planning re-reads the tuning environment (ChoiceMemo)
   if (dense_lib_eligible(*desc, m)) return dense_lib_plan(*desc, m, plan);
+  if (gemm_two_pass_eligible(*desc, m)) return gemm_two_pass_plan(*desc, m, plan);
   bool use_gemm = false;
   dispatch(*desc, m, &use_gemm);
   return use_gemm ? gemm_plan(*desc, m, plan) : gemv_plan(*desc, m, plan);

@@ -103,6 +103,14 @@ int gemm_launch(const wqaa_matmul_desc& d, const void* A, const void* B, const v
                 hipStream_t stream, hipEvent_t start, hipEvent_t stop, const wqaa_epilogue* epi = nullptr,
                 const wqaa_call_opts* opts = nullptr);
 size_t gemm_workspace_bytes(const wqaa_matmul_desc& d, int m);
+// two-pass member (large M): B_decode to a scratch by wq_dequant_kernel, then the plain GEMM through the vendor library
+bool gemm_two_pass_eligible(const wqaa_matmul_desc& d, int m);
+int gemm_two_pass_plan(const wqaa_matmul_desc& d, int m, wqaa_plan* plan);
+size_t gemm_two_pass_workspace_bytes(const wqaa_matmul_desc& d, int m);
+int gemm_two_pass_launch(const wqaa_matmul_desc& d, const void* A, const void* B, const void* LUT, const void* Scale, const void* Zeros,
+                         void* C, int m, hipStream_t stream, const wqaa_call_opts* opts);
+int gemm_dequantize_launch(const wqaa_matmul_desc& d, const void* B, const void* LUT, const void* Scale, const void* Zeros, void* out,
+                           hipStream_t stream);
 int act_quant_launch(const void* X, int64_t rows, int K, void* Q, float* S, hipStream_t stream);
 void gemm_init();
 
@@ -110,7 +118,7 @@ void gemm_init();
 void* pool_workspace(hipStream_t stream, size_t bytes);
 
 // plain dense GEMMs (W_dtype == A_dtype, a float type, no scale / zeros / bias, M >= 16) through hipBLASLt (wqaa_dense_lib.hip)
-bool dense_lib_eligible(const wqaa_matmul_desc& d, int m);
+bool dense_lib_eligible(const wqaa_matmul_desc& d, int m, bool second_pass = false);
 int dense_lib_plan(const wqaa_matmul_desc& d, int m, wqaa_plan* plan);
 size_t dense_lib_workspace_bytes(const wqaa_matmul_desc& d, int m);
 int dense_lib_launch(const wqaa_matmul_desc& d, const void* A, const void* B, void* C, int m, hipStream_t stream,

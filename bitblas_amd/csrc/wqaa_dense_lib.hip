@@ -49,6 +49,8 @@ bool to_hip_type(int dt, hipDataType* out) {
     case WQAA_F32: *out = HIP_R_32F; return true;
     case WQAA_E4M3: *out = HIP_R_8F_E4M3; return true;
     case WQAA_E5M2: *out = HIP_R_8F_E5M2; return true;
+    case WQAA_I8: *out = HIP_R_8I; return true;
+    case WQAA_I32: *out = HIP_R_32I; return true;
   }
   return false;
 }
@@ -65,8 +67,13 @@ bool enabled() {
   return on;
 }
 
-bool shape_ok(const wqaa_matmul_desc& d, int m) {
+bool shape_ok(const wqaa_matmul_desc& d, int m, bool int8_too) {
   if (m < 16 || d.w_format != WQAA_W_NATIVE || d.with_bias || d.with_scaling || d.zeros_mode != WQAA_Z_NONE) return false;
+  if (d.a_dtype == WQAA_I8) {
+    // int8 x int8 -> int32: only as the second pass of the two-pass member (the dense int8 pair itself stays on the own
+    // MFMA member: not probed against the library)
+    return int8_too && d.out_dtype == WQAA_I32 && d.K % 16 == 0 && d.N % 8 == 0;
+  }
   if (d.a_dtype != WQAA_F16 && d.a_dtype != WQAA_BF16 && d.a_dtype != WQAA_E4M3 && d.a_dtype != WQAA_E5M2) return false;
   if (d.out_dtype != WQAA_F16 && d.out_dtype != WQAA_BF16 && d.out_dtype != WQAA_F32) return false;
   const bool f8 = d.a_dtype == WQAA_E4M3 || d.a_dtype == WQAA_E5M2;
@@ -90,7 +97,8 @@ const LtPlan* get_plan(const wqaa_matmul_desc& d, int m) {
   if (good && !g_handle[dev]) good = hipblasLtCreate(&g_handle[dev]) == HIPBLAS_STATUS_SUCCESS;
   hipblasLtMatmulPreference_t pref = nullptr;
   if (good) {
-    good = hipblasLtMatmulDescCreate(&p.op, HIPBLAS_COMPUTE_32F, HIP_R_32F) == HIPBLAS_STATUS_SUCCESS;
+    const bool i8 = d.a_dtype == WQAA_I8;
+    good = hipblasLtMatmulDescCreate(&p.op, i8 ? HIPBLAS_COMPUTE_32I : HIPBLAS_COMPUTE_32F, i8 ? HIP_R_32I : HIP_R_32F) == HIPBLAS_STATUS_SUCCESS;
     const hipblasOperation_t tr = HIPBLAS_OP_T, no = HIPBLAS_OP_N;
     good = good && hipblasLtMatmulDescSetAttribute(p.op, HIPBLASLT_MATMUL_DESC_TRANSA, &tr, sizeof(tr)) == HIPBLAS_STATUS_SUCCESS;
     good = good && hipblasLtMatmulDescSetAttribute(p.op, HIPBLASLT_MATMUL_DESC_TRANSB, &no, sizeof(no)) == HIPBLAS_STATUS_SUCCESS;
@@ -121,8 +129,8 @@ const LtPlan* get_plan(const wqaa_matmul_desc& d, int m) {
 
 }  // namespace
 
-bool dense_lib_eligible(const wqaa_matmul_desc& d, int m) {
-  if (!shape_ok(d, m) || !enabled() || !device_info().ok) return false;
+bool dense_lib_eligible(const wqaa_matmul_desc& d, int m, bool second_pass) {
+  if (!shape_ok(d, m, second_pass) || (!second_pass && !enabled()) || !device_info().ok) return false;
   return get_plan(d, m) != nullptr;
 }
 
@@ -172,8 +180,10 @@ int dense_lib_launch(const wqaa_matmul_desc& d, const void* A, const void* B, vo
     }
   }
   const float alpha = 1.f, beta = 0.f;
-  const hipblasStatus_t st = hipblasLtMatmul(g_handle[p->dev], p->op, &alpha, B, p->la, A, p->lb, &beta, C, p->lc, C, p->lc, &p->algo, ws,
-                                             p->ws, stream);
+  const int32_t alpha_i = 1, beta_i = 0;
+  const bool i8 = d.a_dtype == WQAA_I8;
+  const hipblasStatus_t st = hipblasLtMatmul(g_handle[p->dev], p->op, i8 ? (const void*)&alpha_i : (const void*)&alpha, B, p->la, A, p->lb,
+                                             i8 ? (const void*)&beta_i : (const void*)&beta, C, p->lc, C, p->lc, &p->algo, ws, p->ws, stream);
   if (st != HIPBLAS_STATUS_SUCCESS) {
     (void)hipGetLastError();
     set_error(WQAA_ERR_LAUNCH, "dense: hipblasLtMatmul failed with status %d", (int)st);

@@ -381,6 +381,139 @@ int gemm_launch(const wqaa_matmul_desc& d, const void* A, const void* B, const v
   return WQAA_OK;
 }
 
+// ---- B_decode to memory + the two-pass member -----------------------------------------------------------------------
+static int dequant_setup(const wqaa_matmul_desc& d, GemmChoice* c, GemmArgs* a, gemm_fn* fn, const void* B, const void* LUT,
+                         const void* Scale, const void* Zeros) {
+  int st = gemm_choose(d, 4096, c);              // classification only (kind, layout, activation type, mode, flags)
+  if (st != WQAA_OK) return st;
+  if (c->at != AT_F16 && c->at != AT_I8) {
+    set_error(WQAA_ERR_UNSUPPORTED, "dequantize: B_decode exists for float16 / bfloat16 / int8 activations");
+    return WQAA_ERR_UNSUPPORTED;
+  }
+  *fn = pick_gemm(c->kind, c->layout, c->at, c->mode, c->flags, 900);
+  if (!*fn) {
+    set_error(WQAA_ERR_UNSUPPORTED, "dequantize: no member for kind=%d layout=%d at=%d mode=%d", c->kind, c->layout, c->at, c->mode);
+    return WQAA_ERR_UNSUPPORTED;
+  }
+  const int g = d.group_size <= 0 ? d.K : d.group_size;
+  memset(a, 0, sizeof(*a));
+  a->B = B; a->lut = LUT; a->scale = Scale; a->zeros = Zeros;
+  a->N = d.N; a->K = d.K;
+  a->kg = d.K / g;
+  const int dq = g / c->kl > 0 ? g / c->kl : 1;
+  a->gq_shift = ilog2_exact(dq);
+  a->gq_magic = a->gq_shift >= 0 ? 0u : (uint32_t)(((1ull << 32) + dq - 1) / dq);
+  a->row_bytes = (long)d.K * c->bits / 8;
+  a->is_signed = d.w_format == WQAA_W_INT || (d.w_format == WQAA_W_UINT && d.w_bits == 8 && d.strict_reference);
+  a->fp4_table = c->fp4_table;
+  a->zq_row_bytes = d.N * (c->bits < 8 ? c->bits : 8) / 8;
+  return WQAA_OK;
+}
+
+int gemm_dequantize_launch(const wqaa_matmul_desc& d, const void* B, const void* LUT, const void* Scale, const void* Zeros, void* out,
+                           hipStream_t stream) {
+  GemmChoice c;
+  GemmArgs a;
+  gemm_fn fn = nullptr;
+  int st = dequant_setup(d, &c, &a, &fn, B, LUT, Scale, Zeros);
+  if (st != WQAA_OK) return st;
+  const long items = (long)d.N * (d.K / c.kl);
+  void* params[] = {&a, &out};
+  const hipError_t e = hipLaunchKernel(reinterpret_cast<const void*>(fn), dim3((unsigned)((items + 255) / 256)), dim3(256), params, 0, stream);
+  if (e != hipSuccess) {
+    set_error(WQAA_ERR_LAUNCH, "dequantize launch failed: %s", hipGetErrorString(e));
+    return WQAA_ERR_LAUNCH;
+  }
+  return WQAA_OK;
+}
+
+// the plain GEMM of the second pass: same N, K, activation / output types, W "stored in A_dtype"
+static bool two_pass_dense_desc(const wqaa_matmul_desc& d, wqaa_matmul_desc* dd) {
+  if (d.w_format == WQAA_W_NATIVE || d.with_bias) return false;      // nothing to decode / bias after the cast: fused members
+  if (d.a_dtype != WQAA_F16 && d.a_dtype != WQAA_BF16 && d.a_dtype != WQAA_I8) return false;
+  *dd = d;
+  dd->w_format = WQAA_W_NATIVE;
+  dd->w_bits = d.a_dtype == WQAA_I8 ? 8 : 16;
+  dd->group_size = -1;
+  dd->with_scaling = 0;
+  dd->zeros_mode = WQAA_Z_NONE;
+  dd->w_layout = WQAA_LAYOUT_PLAIN;
+  dd->k_split_hint = 0;
+  dd->two_pass_min_m = 0;
+  return true;
+}
+
+bool gemm_two_pass_eligible(const wqaa_matmul_desc& d, int m) {
+  int min_m = d.two_pass_min_m;
+  if (const char* f = getenv("WQAA_TWO_PASS")) min_m = atoi(f);      // A/B aid (plan-time): 0 never, n > 0 from n rows on
+  if (min_m <= 0 || m < min_m || m < 16) return false;
+  wqaa_matmul_desc dd;
+  if (!two_pass_dense_desc(d, &dd)) return false;
+  GemmChoice c;
+  GemmArgs a;
+  gemm_fn fn = nullptr;
+  if (dequant_setup(d, &c, &a, &fn, nullptr, nullptr, nullptr, nullptr) != WQAA_OK) return false;
+  return dense_lib_eligible(dd, m, true);
+}
+
+static size_t two_pass_scratch(const wqaa_matmul_desc& d) {
+  const size_t esz = d.a_dtype == WQAA_I8 ? 1 : 2;
+  return ((size_t)d.N * d.K * esz + 255) & ~(size_t)255;
+}
+
+size_t gemm_two_pass_workspace_bytes(const wqaa_matmul_desc& d, int m) {
+  wqaa_matmul_desc dd;
+  if (!two_pass_dense_desc(d, &dd)) return 0;
+  return two_pass_scratch(d) + dense_lib_workspace_bytes(dd, m);
+}
+
+int gemm_two_pass_plan(const wqaa_matmul_desc& d, int m, wqaa_plan* plan) {
+  wqaa_matmul_desc dd;
+  if (!two_pass_dense_desc(d, &dd)) {
+    set_error(WQAA_ERR_UNSUPPORTED, "two-pass member: not defined for this configuration");
+    return WQAA_ERR_UNSUPPORTED;
+  }
+  int st = dense_lib_plan(dd, m, plan);
+  if (st == WQAA_OK && plan) {
+    plan->kernel_family = 4;
+    char wd[24];
+    short_wdtype(d, wd, sizeof(wd));
+    snprintf(plan->name, sizeof(plan->name), "matmul_m%dn%dk%d_%sx%s_dq_hipblaslt", m, d.N, d.K, short_dtype(d.a_dtype), wd);
+  }
+  return st;
+}
+
+int gemm_two_pass_launch(const wqaa_matmul_desc& d, const void* A, const void* B, const void* LUT, const void* Scale, const void* Zeros,
+                         void* C, int m, hipStream_t stream, const wqaa_call_opts* opts) {
+  wqaa_matmul_desc dd;
+  if (!two_pass_dense_desc(d, &dd)) {
+    set_error(WQAA_ERR_UNSUPPORTED, "two-pass member: not defined for this configuration");
+    return WQAA_ERR_UNSUPPORTED;
+  }
+  const size_t scratch = two_pass_scratch(d);
+  const size_t need = scratch + dense_lib_workspace_bytes(dd, m);
+  uint8_t* ws = nullptr;
+  if (opts && opts->workspace) {
+    if (opts->workspace_bytes < need || (reinterpret_cast<uintptr_t>(opts->workspace) & 15)) {
+      set_error(WQAA_ERR_BAD_DESC, "two-pass member: workspace of %zu B (16-byte aligned) needed, got %zu B at %p", need,
+                (size_t)opts->workspace_bytes, opts->workspace);
+      return WQAA_ERR_BAD_DESC;
+    }
+    ws = reinterpret_cast<uint8_t*>(opts->workspace);
+  } else {
+    ws = reinterpret_cast<uint8_t*>(pool_workspace(stream, need));
+    if (!ws) return WQAA_ERR_LAUNCH;
+  }
+  int st = gemm_dequantize_launch(d, B, LUT, Scale, Zeros, ws, stream);
+  if (st != WQAA_OK) return st;
+  wqaa_call_opts sub;
+  memset(&sub, 0, sizeof(sub));
+  sub.struct_size = (int32_t)sizeof(sub);
+  sub.workspace = need > scratch ? ws + scratch : nullptr;
+  sub.workspace_bytes = need - scratch;
+  return dense_lib_launch(dd, A, ws, C, m, stream, need > scratch ? &sub : nullptr);
+}
+
 void gemm_init() {
   const int kinds[] = {DK_INT4, DK_INT2, DK_INT1, DK_INT8, DK_LUT4, DK_E4M3, DK_E5M2, DK_NATIVE};
   for (int kind : kinds)

@@ -1433,6 +1433,66 @@ __global__ void __launch_bounds__(256) wq_splitk_reduce_kernel(const void* ws_, 
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// B_decode to memory: the TE graph's first stage on its own (tirscript/matmul_dequantize_impl.py:391-449) - every weight
+// decoded and (zero, scale)-dequantised by the SAME routines the MFMA members use in their loop (dequant_lane_*), written
+// row-major (N, K) in A_dtype.  A thread owns one lane's k-block: WL packed words in, KL elements out (16-byte loads, NJ
+// 16-byte stores; a wave reads 1 KiB and writes 4 KiB of one row, contiguous).  Used by the two-pass member (wqaa_gemm.hip)
+// and by wqaa_dequantize.
+// ------------------------------------------------------------------------------------------
+template <class P>
+__global__ void __launch_bounds__(256) wq_dequant_kernel(const GemmArgs a, void* out) {
+  using T = typename P::T;
+  constexpr int NJ = P::NJ, WL = P::WL, MODE = P::MODE;
+  constexpr bool F16 = P::AT == AT_F16;
+  static_assert(P::AT == AT_F16 || P::AT == AT_I8, "B_decode exists in float16 / bfloat16 / int8");
+  constexpr int ZB = T::SUBBYTE ? T::BITS : 8;
+  constexpr int ZPB = 8 / ZB;
+  const int nkb = a.K / P::KL;                           // k-blocks per row
+  const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (id >= (long)a.N * nkb) return;
+  const int n = (int)(id / nkb), kidx = (int)(id - (long)n * nkb);
+  const uint8_t* Bp = reinterpret_cast<const uint8_t*>(a.B);
+  uint32_t w[WL];
+  load_lane_words<WL>(Bp + (long)n * a.row_bytes + (long)kidx * (WL * 4), w);
+  int gi = 0;
+  if (MODE != MD_NONE) gi = a.gq_shift >= 0 ? (kidx >> a.gq_shift) : (int)__umulhi((uint32_t)kidx, a.gq_magic);
+  uint32_t sbits = 0, zbits = 0;
+  if constexpr (MODE != MD_NONE) sbits = reinterpret_cast<const uint16_t*>(a.scale)[(long)n * a.kg + gi];
+  if constexpr (MODE == MD_ZO || MODE == MD_ZR) zbits = reinterpret_cast<const uint16_t*>(a.zeros)[(long)n * a.kg + gi];
+  if constexpr (MODE == MD_ZQ) zbits = reinterpret_cast<const uint8_t*>(a.zeros)[(long)gi * a.zq_row_bytes + n / ZPB];
+  DecodeCtx cx;
+  cx.zf = (F16 && a.is_signed && T::SUBBYTE) ? (half_t)(float)(1 << (T::BITS - 1)) : (half_t)0.0f;
+  cx.flip = 0u;
+  if (P::KIND == DK_INT1 && a.is_signed) cx.flip = 0xFFFFFFFFu;
+  if (P::KIND == DK_INT8 && a.is_signed) cx.flip = 0x80808080u;
+  cx.off8 = (half_t)(a.is_signed ? 1152.0f : 1024.0f);
+  make_magic(cx.magic);
+  Lut16 lut;
+  if constexpr (P::KIND == DK_LUT4) {
+    if (a.fp4_table) lut = make_fp4_lut(P::BF);
+    else lut = make_lut16(reinterpret_cast<const half_t*>(a.lut));
+  }
+  uint32_t frag[NJ][4];
+  if constexpr (F16) {
+    half_t zf = cx.zf;
+    if constexpr (MODE == MD_ZQ) zf = (half_t)(float)((zbits >> ((n % ZPB) * ZB)) & ((1u << ZB) - 1u));
+    const half2_t s2 = MODE != MD_NONE ? splat(bits_to_half(sbits)) : splat((half_t)1.0f);
+    const half2_t z2 = (MODE == MD_ZO || MODE == MD_ZR) ? splat(bits_to_half(zbits)) : splat((half_t)0.0f);
+    if constexpr (P::BF)
+      dequant_lane_bf16<P>(w, (float)zf, MODE != MD_NONE ? bf16_bits_to_float(sbits) : 1.f, a.is_signed != 0, cx.flip, lut, frag,
+                           (MODE == MD_ZO || MODE == MD_ZR) ? bf16_bits_to_float(zbits) : 0.f);
+    else
+      dequant_lane_f16<P>(w, zf, s2, z2, cx, lut, frag);
+  } else {
+    const uint32_t zp4 = (a.is_signed && T::SUBBYTE) ? (uint32_t)(1u << (T::BITS - 1)) * 0x01010101u : 0u;
+    dequant_lane_i8<P>(w, zp4, cx.flip, frag);
+  }
+  u32x4* dst = reinterpret_cast<u32x4*>(reinterpret_cast<uint8_t*>(out) + ((long)n * a.K + (long)kidx * P::KL) * (F16 ? 2 : 1));
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) dst[j] = u32x4{frag[j][0], frag[j][1], frag[j][2], frag[j][3]};
+}
+
 typedef void (*gemm_fn)(const GemmArgs);
 
 // member tables, one translation unit each (parallel builds): wqaa_gemm_inst_*.hip
@@ -1458,6 +1518,10 @@ static gemm_fn pick_mf(int mf) {
     // 128-row skinny member: 8 waves x one weight fragment each (BN = 128), 4 k-steps per workgroup, every load first
     case 201: return wq_gemm_decode_kernel<GemmPolicy<KIND, LAYOUT, AT, MODE, FLAGS, 1, 8, 1>>;
     case 211: if constexpr (AT != AT_I4) return wq_gemm_decode_lds_kernel<GemmPolicy<KIND, LAYOUT, AT, MODE, FLAGS, 1, 8, 1>>; else return nullptr;
+    // 900: not a GEMM - B_decode to memory (two-pass member, wqaa_dequantize); launched with (GemmArgs, void* out)
+    case 900:
+      if constexpr (AT == AT_F16 || AT == AT_I8) return reinterpret_cast<gemm_fn>(wq_dequant_kernel<GemmPolicy<KIND, LAYOUT, AT, MODE, FLAGS, 1>>);
+      else return nullptr;
     case 404: if constexpr (KIND == DK_INT4 && AT == AT_F16 && FLAGS == 0 && (MODE == MD_ZO || MODE == MD_ZR)) return wq_gemm_kernel<GemmPolicy<KIND, LAYOUT, AT, MODE, FLAGS, 4, 4, 2, 0, true>>; else return nullptr;
   }
   return nullptr;

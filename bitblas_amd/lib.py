@@ -39,7 +39,7 @@ ZEROS_CODE = {"original": Z_ORIGINAL, "rescale": Z_RESCALE, "quantized": Z_QUANT
 
 EXPORTED_SYMBOLS = (
     "init", "wqaa_abi_version", "wqaa_device_count", "wqaa_matmul", "wqaa_matmul_timed",
-    "wqaa_matmul_ex", "wqaa_matmul_opts", "wqaa_workspace_bytes", "wqaa_matmul_group", "wqaa_matmul_group_ex", "wqaa_group_plan", "wqaa_act_quant_int8", "wqaa_select", "wqaa_pack_weight", "wqaa_unpack_weight", "wqaa_debug_decode", "wqaa_debug_row_blocks",
+    "wqaa_matmul_ex", "wqaa_matmul_opts", "wqaa_workspace_bytes", "wqaa_matmul_group", "wqaa_matmul_group_ex", "wqaa_group_plan", "wqaa_dequantize", "wqaa_act_quant_int8", "wqaa_select", "wqaa_pack_weight", "wqaa_unpack_weight", "wqaa_debug_decode", "wqaa_debug_row_blocks",
     "wqaa_last_error", "wqaa_last_error_string",
 )
 
@@ -52,7 +52,8 @@ class MatmulDesc(ctypes.Structure):
         ("out_dtype", ctypes.c_int32), ("group_size", ctypes.c_int32),
         ("with_scaling", ctypes.c_int32), ("zeros_mode", ctypes.c_int32),
         ("with_bias", ctypes.c_int32), ("w_layout", ctypes.c_int32),
-        ("strict_reference", ctypes.c_int32), ("k_split_hint", ctypes.c_int32), ("reserved", ctypes.c_int32 * 2),
+        ("strict_reference", ctypes.c_int32), ("k_split_hint", ctypes.c_int32), ("two_pass_min_m", ctypes.c_int32),
+        ("reserved", ctypes.c_int32 * 1),
     ]
 
 
@@ -127,6 +128,8 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
         lib.wqaa_workspace_bytes.argtypes = [dp, ci]
         lib.wqaa_act_quant_int8.restype = ci
         lib.wqaa_act_quant_int8.argtypes = [vp, i64, ci, vp, vp, vp]
+        lib.wqaa_dequantize.restype = ci
+        lib.wqaa_dequantize.argtypes = [dp, vp, vp, vp, vp, vp, vp]
         lib.wqaa_select.restype = ci
         lib.wqaa_select.argtypes = [dp, ci, ctypes.POINTER(Plan)]
         lib.wqaa_pack_weight.restype = ci
@@ -166,7 +169,7 @@ def check(status: int) -> None:
 
 
 def make_desc(*, N, K, a_dtype, w_format, w_bits, out_dtype, group_size=-1, with_scaling=False,
-              zeros_mode=Z_NONE, with_bias=False, w_layout=LAYOUT_PLAIN, strict_reference=True, k_split_hint=0) -> MatmulDesc:
+              zeros_mode=Z_NONE, with_bias=False, w_layout=LAYOUT_PLAIN, strict_reference=True, k_split_hint=0, two_pass_min_m=0) -> MatmulDesc:
     d = MatmulDesc()
     d.struct_size = ctypes.sizeof(MatmulDesc)
     d.N, d.K = int(N), int(K)
@@ -178,6 +181,7 @@ def make_desc(*, N, K, a_dtype, w_format, w_bits, out_dtype, group_size=-1, with
     d.w_layout = int(w_layout)
     d.strict_reference = int(bool(strict_reference))
     d.k_split_hint = max(0, int(k_split_hint or 0))
+    d.two_pass_min_m = max(0, int(two_pass_min_m or 0))
     return d
 
 
@@ -196,6 +200,26 @@ def _ptr(x) -> Optional[int]:
     if isinstance(x, int):
         return x
     return x.data_ptr()  # torch.Tensor
+
+
+# Large scratch (> 16 MiB: the two-pass member's B_decode, N*K*sizeof(A_dtype)) is shared by every operator of a
+# (stream, device): one buffer, grown geometrically; a buffer that is replaced is kept alive (a captured hipGraph may
+# still point at it) - the ownership rules of the C library's own pool (csrc/wqaa_gemm.hip), held by the caller.
+_SHARED_WS_MIN = 16 << 20
+_shared_ws = {}
+_shared_ws_retired = []
+
+
+def shared_workspace(stream, device, need: int):
+    key = (stream, str(device))
+    ws = _shared_ws.get(key)
+    if ws is None or ws.numel() < need:
+        import torch
+        if ws is not None:
+            _shared_ws_retired.append(ws)
+            need = max(need, 2 * ws.numel())
+        ws = _shared_ws[key] = torch.empty(need, dtype=torch.uint8, device=device if device is not None else "cuda")
+    return ws
 
 
 class BoundLib:
@@ -263,6 +287,11 @@ class BoundLib:
         on a side stream the library's own per-stream slab has never seen).  Two streams never share a workspace."""
         need = self.workspace_need(m)
         if need:
+            if need > _SHARED_WS_MIN:
+                # the two-pass member's B_decode scratch is N*K*sizeof(A_dtype): one buffer per (stream, device) for ALL
+                # operators (launches on a stream are ordered; a per-operator copy would be a float16 copy of the model)
+                ws = shared_workspace(stream, device, need)
+                return self.run_ws(A, B, lut, scale, zeros, bias, C, m, stream, ws.data_ptr(), need)
             key = (stream, device)
             ws = self._ws.get(key)
             if ws is None or ws.numel() < need:

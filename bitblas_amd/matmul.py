@@ -434,11 +434,69 @@ class Matmul:
         return MatmulKernelNameGenerator(self.config)
 
     def hardware_aware_finetune(self, topk: int = 20, parallel_build: bool = True):
-        """The reference runs the roller + profiler here (ops/operator.py:347-382).  The static
-        library has nothing to tune: tile choice is `wqaa_select`'s table.  Kept as a no-op that
-        refreshes the recorded plans so callers (`Linear.warmup`) keep working."""
+        """The reference runs the roller + profiler here and keeps the fastest candidate (ops/operator.py:262-293, 347-382).
+        The static library's tile choice is `wqaa_select`'s table; what IS measured here, on the device, is the one choice
+        that depends on the vendor library's per-shape heuristic: from which row count on the TWO-PASS member (B_decode to a
+        scratch, then hipBLASLt's plain GEMM - `wqaa_matmul_desc.two_pass_min_m`) beats the fused MFMA member.  Each planned
+        M >= 256 is timed both ways on synthetic operands (hipEvents, a few launches); the smallest M where the two-pass
+        member wins by > 3 % becomes the threshold.  Without a GPU, or for configurations that have no two-pass member, it
+        only refreshes the recorded plans (so `Linear.warmup` keeps working)."""
+        cand = sorted(m for m in self.plans if isinstance(m, int) and m >= 256)
+        native = self.W_dtype == self.A_dtype
+        if cand and not native and not self.with_bias and torch.cuda.is_available() and self.A_dtype in ("float16", "bfloat16", "int8"):
+            try:
+                self._tune_two_pass(cand)
+            except (_lib.WqaaError, RuntimeError) as exc:      # no member / no memory for the scratch: the fused members stay
+                logger.info("two-pass tuning skipped: %s", exc)
+                self._desc.two_pass_min_m = 0
         self.plans = {m: self.lib.plan(m) for m in self.plans}
         return self.plans
+
+    def _tune_two_pass(self, cand, iters: int = 5):
+        dev = self.device if isinstance(self.device, torch.device) else torch.device("cuda", torch.cuda.current_device())
+        a_dt = torch_dtype(self.A_dtype)
+        g = self.K if self.group_size in (-1, None) else self.group_size
+        W = torch.randint(-128, 127, self.retrieve_weight_shape(), device=dev, dtype=torch.int8)
+        scale = (torch.rand(self.N, self.K // g, device=dev) * 0.02).to(a_dt) if self.with_scaling else None
+        zeros = None
+        if self.with_zeros:
+            zeros = (torch.zeros(self.K // g, self.N * self.bit // 8, device=dev, dtype=torch.int8) if self.zeros_mode == "quantized"
+                     else torch.full((self.N, self.K // g), float(1 << (self.bit - 1)), device=dev).to(a_dt))
+        lut = self._ensure_lut(dev)
+        stream = _lib.current_stream_handle(dev)
+
+        def time_at(m, min_m):
+            self._desc.two_pass_min_m = min_m
+            plan = self.lib.plan(m)                          # re-plans (and drops the cached scratch size)
+            if min_m and plan["kernel_family"] != 4:
+                return None
+            A = (torch.rand(m, self._a_cols, device=dev) - 0.5).to(a_dt) if a_dt.is_floating_point else \
+                torch.randint(-128, 127, (m, self._a_cols), device=dev, dtype=a_dt)
+            out = torch.empty((m, self.N), dtype=self.torch_output_dtype, device=dev)
+            args = (A.data_ptr(), W.data_ptr(), lut.data_ptr() if lut is not None else None,
+                    scale.data_ptr() if scale is not None else None, zeros.data_ptr() if zeros is not None else None, None,
+                    out.data_ptr(), m, stream, dev)
+            for _ in range(2):
+                self.lib.run(*args)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(iters):
+                self.lib.run(*args)
+            e1.record()
+            e1.synchronize()
+            return e0.elapsed_time(e1) / iters
+
+        threshold = 0
+        for m in reversed(cand):                             # the two-pass member's advantage grows with M
+            fused, two = time_at(m, 0), time_at(m, 1)
+            if two is None or two > 0.97 * fused:
+                break
+            threshold = m
+            self._tuned = getattr(self, "_tuned", {})
+            self._tuned[m] = {"fused_ms": fused, "two_pass_ms": two}
+        self._desc.two_pass_min_m = threshold
+        self.lib._ws.clear()                                 # scratch buffers of the losing member
+        self.lib.plan(cand[-1])
 
     def is_tir_backend(self):
         return self.backend == "tir"

@@ -104,12 +104,20 @@ typedef struct wqaa_matmul_desc {
                             count of the pipelined MFMA members (clamped to the k-steps available).  Members whose split is
                             structural (one-launch decode member: 8 waves; skinny member: 4 k-steps per workgroup) keep it;
                             wqaa_plan.split_k reports what was taken.  (was reserved[0], must-be-zero: ABI compatible) */
-  int32_t reserved[2];
+  int32_t two_pass_min_m; /* 0: never.  > 0: from this many activation rows on, run the TWO-PASS member where it exists -
+                             B_decode written once to a scratch in A_dtype (the TE graph's first stage,
+                             matmul_dequantize_impl.py:391-449, by the kernels' own decode routines), then the plain GEMM
+                             through the vendor library - instead of the fused MFMA member.  Which of the two is faster is
+                             shape-dependent (the library's heuristic), so this is a TUNED value: `Matmul.hardware_aware_
+                             finetune` times both on the device, like the reference's tuner picks its hint
+                             (ops/operator.py:262-293).  Needs N*K*sizeof(A_dtype) more scratch (wqaa_workspace_bytes).
+                             (was reserved[0], must-be-zero: ABI compatible) */
+  int32_t reserved[1];
 } wqaa_matmul_desc;
 
 /* what the selector chose for (desc, m): reported for tests, rocprof attribution and the cache */
 typedef struct wqaa_plan {
-  int32_t kernel_family;  /* 0 none, 1 gemv (VALU dot), 2 gemm (MFMA), 3 vendor-library GEMM (hipBLASLt: plain dense pairs, M >= 16) */
+  int32_t kernel_family;  /* 0 none, 1 gemv (VALU dot), 2 gemm (MFMA), 3 vendor-library GEMM (hipBLASLt: plain dense pairs, M >= 16), 4 two-pass (B_decode to scratch + 3) */
   int32_t block_m, block_n, block_k;
   int32_t threads;
   int32_t grid;
@@ -221,6 +229,12 @@ int wqaa_matmul_group(const wqaa_group_item* items, int count, int m, void* stre
  * back).  Members with different epilogue kinds run one by one. */
 int wqaa_matmul_group_ex(const wqaa_group_item* items, const wqaa_epilogue* const* epilogues, int count, int m, void* stream);
 int wqaa_group_plan(const wqaa_matmul_desc* const* descs, int count, int m, int* launches, wqaa_plan* plan);
+
+/* B_decode on its own: out (N, K) row-major in A_dtype = every weight decoded and (zero, scale)-dequantised as the TE
+ * definition's first stage does (matmul_dequantize_impl.py:391-449) by the routines the MFMA members use in their loop.
+ * float16 / bfloat16 / int8 activations' operators; K a multiple of 128 (256 for int8).  Asynchronous on `stream`. */
+int wqaa_dequantize(const wqaa_matmul_desc* desc, const void* B, const void* LUT, const void* Scale, const void* Zeros,
+                    void* out, void* stream);
 
 /* per-row absmax quantiser (utils_quant.py:161-168): s = (1 / max(|x|, 1e-5)) * 127 - two fp32 roundings, what torch
  * evaluates for the reference's `Qp / tensor` (Tensor.__rtruediv__) -, q = clamp(rint(x * s)).
