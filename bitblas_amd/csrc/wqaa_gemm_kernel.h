@@ -1450,11 +1450,11 @@ __global__ void __launch_bounds__(256) wq_dequant_kernel(const GemmArgs a, void*
   constexpr int ZPB = 8 / ZB;
   const int nkb = a.K / P::KL;                           // k-blocks per row
   const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (id >= (long)a.N * nkb) return;
+  if (id >= (long)a.N * nkb) return;                       // whole waves when nkb % 64 == 0 (the exchange below needs that)
   const int n = (int)(id / nkb), kidx = (int)(id - (long)n * nkb);
   const uint8_t* Bp = reinterpret_cast<const uint8_t*>(a.B);
   uint32_t w[WL];
-  load_lane_words<WL>(Bp + (long)n * a.row_bytes + (long)kidx * (WL * 4), w);
+  load_lane_words<WL, true>(Bp + (long)n * a.row_bytes + (long)kidx * (WL * 4), w);      // read once: non-temporal
   int gi = 0;
   if (MODE != MD_NONE) gi = a.gq_shift >= 0 ? (kidx >> a.gq_shift) : (int)__umulhi((uint32_t)kidx, a.gq_magic);
   uint32_t sbits = 0, zbits = 0;
@@ -1488,9 +1488,27 @@ __global__ void __launch_bounds__(256) wq_dequant_kernel(const GemmArgs a, void*
     const uint32_t zp4 = (a.is_signed && T::SUBBYTE) ? (uint32_t)(1u << (T::BITS - 1)) * 0x01010101u : 0u;
     dequant_lane_i8<P>(w, zp4, cx.flip, frag);
   }
-  u32x4* dst = reinterpret_cast<u32x4*>(reinterpret_cast<uint8_t*>(out) + ((long)n * a.K + (long)kidx * P::KL) * (F16 ? 2 : 1));
+  // A lane holds NJ consecutive 16-byte pieces of the row; written as they are, one store instruction of a wave would
+  // touch 64 pieces NJ * 16 bytes apart (a quarter of every 64-byte segment).  Through LDS the wave's NJ * 64 pieces are
+  // handed round so that store j of lane l writes piece j * 64 + l of the wave's contiguous NJ KiB: full lines.
+  // (row ends are wave-aligned: K / KL k-blocks per row, 64 lanes per wave, K a multiple of the 4 * KL k-step)
+  __shared__ u32x4 xch[256 * NJ];
+  const int lane = threadIdx.x & 63, wave0 = threadIdx.x & ~63;
+  const bool whole_wave = (nkb & 63) == 0;                 // a wave never straddles two rows
+  if (whole_wave) {
 #pragma unroll
-  for (int j = 0; j < NJ; ++j) dst[j] = u32x4{frag[j][0], frag[j][1], frag[j][2], frag[j][3]};
+    for (int j = 0; j < NJ; ++j) xch[(wave0 + lane) * NJ + j] = u32x4{frag[j][0], frag[j][1], frag[j][2], frag[j][3]};
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    uint8_t* wbase = reinterpret_cast<uint8_t*>(out) + ((long)n * a.K + (long)(kidx - lane) * P::KL) * (F16 ? 2 : 1);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) reinterpret_cast<u32x4*>(wbase)[j * 64 + lane] = xch[wave0 * NJ + j * 64 + lane];
+  } else {
+    u32x4* dst = reinterpret_cast<u32x4*>(reinterpret_cast<uint8_t*>(out) + ((long)n * a.K + (long)kidx * P::KL) * (F16 ? 2 : 1));
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) dst[j] = u32x4{frag[j][0], frag[j][1], frag[j][2], frag[j][3]};
+  }
 }
 
 typedef void (*gemm_fn)(const GemmArgs);
