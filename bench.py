@@ -197,7 +197,7 @@ def time_member_gemm(device, gen, M=4096, N=4096, K=4096, W_dtype="uint4", A_dty
             "GBps_algorithmic": nbytes / t / 1e9, "frac_of_mfma_peak": tf / peak, "mfma_peak": peak}
 
 
-def time_member_dense(device, gen, M, N, K, kind="fp8", n_buf=4, own=False):
+def time_member_dense(device, gen, M, N, K, kind="fp8", n_buf=4, own=False, tuned=False):
     """Dense members: e4m3 x e4m3 MFMA GEMM on Llama-3-70B shapes (BASELINE config c5, one GPU's unsharded
     matrix) and the M = 1 W_int2 A_int8 GEMV (c4)."""
     import bitblas_amd as bitblas
@@ -212,6 +212,8 @@ def time_member_dense(device, gen, M, N, K, kind="fp8", n_buf=4, own=False):
         else:
             cfg = bitblas.MatmulConfig(M=M, N=N, K=K, A_dtype="int8", W_dtype="int2", accum_dtype="int32", out_dtype="int32")
         op = bitblas.Matmul(cfg, enable_tuning=False)
+        if tuned:
+            op.hardware_aware_finetune()       # the vendor library's candidate algorithms timed on the device (wqaa_tune)
         return _time_member_dense(device, gen, op, M, N, K, kind, n_buf)
     except Exception as exc:  # member not built: report, never fake
         return {"error": str(exc)}
@@ -637,6 +639,7 @@ def main():
             # (plain dense pairs: the vendor library by default, this library's own MFMA member under `_own`)
             for (name, N, K, nb) in (("o", 8192, 8192, 4), ("down", 8192, 28672, 2), ("qkv", 10240, 8192, 4), ("gate", 28672, 8192, 2)):
                 members[f"gemm_fp8_m4096_{name}_n{N}_k{K}"] = time_member_dense(device, gen, 4096, N, K, n_buf=nb)
+                members[f"gemm_fp8_m4096_{name}_n{N}_k{K}_tuned"] = time_member_dense(device, gen, 4096, N, K, n_buf=nb, tuned=True)
                 members[f"gemm_fp8_m4096_{name}_n{N}_k{K}_own"] = time_member_dense(device, gen, 4096, N, K, n_buf=nb, own=True)
             for (name, N, K) in (("o", 8192, 8192), ("down", 8192, 28672)):
                 members[f"gemv_fp8_m1_{name}_n{N}_k{K}"] = time_member_dense(device, gen, 1, N, K, n_buf=max(3, (640 << 20) // (N * K)))

@@ -482,6 +482,21 @@ int wqaa_matmul_group_ex(const wqaa_group_item* items, const wqaa_epilogue* cons
   return group_impl(items, epilogues, count, m, stream);
 }
 
+int wqaa_tune(const wqaa_matmul_desc* desc, int m, void* stream) {
+  if (!valid_desc(desc)) return WQAA_ERR_BAD_DESC;
+  if (m <= 0) return WQAA_OK;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  StreamDeviceScope scope(s);
+  if (!device_info().ok) return WQAA_OK;                      // nothing to measure on
+  const int saved = g_last_error;
+  int st = WQAA_OK;
+  if (dense_lib_eligible(*desc, m)) st = dense_lib_tune(*desc, m, s, nullptr);
+  else st = gemm_two_pass_tune(*desc, m, s);
+  g_plan_epoch.fetch_add(1, std::memory_order_relaxed);       // workspace sizes may have changed with the algorithm
+  if (st == WQAA_OK) g_last_error = saved;
+  return st;
+}
+
 int wqaa_dequantize(const wqaa_matmul_desc* desc, const void* B, const void* LUT, const void* Scale, const void* Zeros,
                     void* out, void* stream) {
   if (!valid_desc(desc)) return WQAA_ERR_BAD_DESC;

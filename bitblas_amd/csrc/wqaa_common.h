@@ -105,6 +105,7 @@ int gemm_launch(const wqaa_matmul_desc& d, const void* A, const void* B, const v
 size_t gemm_workspace_bytes(const wqaa_matmul_desc& d, int m);
 // two-pass member (large M): B_decode to a scratch by wq_dequant_kernel, then the plain GEMM through the vendor library
 bool gemm_two_pass_eligible(const wqaa_matmul_desc& d, int m);
+int gemm_two_pass_tune(const wqaa_matmul_desc& d, int m, hipStream_t stream);
 int gemm_two_pass_plan(const wqaa_matmul_desc& d, int m, wqaa_plan* plan);
 size_t gemm_two_pass_workspace_bytes(const wqaa_matmul_desc& d, int m);
 int gemm_two_pass_launch(const wqaa_matmul_desc& d, const void* A, const void* B, const void* LUT, const void* Scale, const void* Zeros,
@@ -121,6 +122,7 @@ void* pool_workspace(hipStream_t stream, size_t bytes);
 bool dense_lib_eligible(const wqaa_matmul_desc& d, int m, bool second_pass = false);
 int dense_lib_plan(const wqaa_matmul_desc& d, int m, wqaa_plan* plan);
 size_t dense_lib_workspace_bytes(const wqaa_matmul_desc& d, int m);
+int dense_lib_tune(const wqaa_matmul_desc& d, int m, hipStream_t stream, float* best_ms);
 int dense_lib_launch(const wqaa_matmul_desc& d, const void* A, const void* B, void* C, int m, hipStream_t stream,
                      const wqaa_call_opts* opts);
 

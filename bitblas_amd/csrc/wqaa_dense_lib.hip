@@ -24,6 +24,18 @@
 
 namespace wqaa {
 
+// tuning operands: pseudo-random bytes in 0x20..0x5f - finite and of mixed magnitude as e4m3 / e5m2 bytes, as the high
+// byte of float16 / bfloat16 values and as int8 (constant or zero operands flatter every candidate: data-dependent clocks)
+__global__ void lt_fill_kernel(uint8_t* p, size_t n, uint32_t seed) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i * 4 >= n) return;
+  uint32_t x = (uint32_t)i * 2654435761u + seed;
+  x ^= x >> 15; x *= 2246822519u; x ^= x >> 13;
+  const uint32_t v = (x & 0x3f3f3f3fu) + 0x20202020u;
+  if (i * 4 + 4 <= n) *reinterpret_cast<uint32_t*>(p + i * 4) = v;
+  else for (size_t k = i * 4; k < n; ++k) p[k] = (uint8_t)(v >> (8 * (k & 3)));
+}
+
 namespace {
 
 struct LtPlan {
@@ -149,6 +161,86 @@ int dense_lib_plan(const wqaa_matmul_desc& d, int m, wqaa_plan* plan) {
     char wd[24];
     short_wdtype(d, wd, sizeof(wd));
     snprintf(plan->name, sizeof(plan->name), "matmul_m%dn%dk%d_%sx%s_hipblaslt", m, d.N, d.K, short_dtype(d.a_dtype), wd);
+  }
+  return WQAA_OK;
+}
+
+// Tuning (Matmul.hardware_aware_finetune -> wqaa_tune): the heuristic's first algorithm is not always the fastest one
+// (float16 N = 11008: 888 TFLOP/s; e4m3 M = 256 at 8192 x 28672: slower than this library's own member), so the top
+// candidates are TIMED on the device - synthetic operands in temporary buffers, hipEvents - and the plan keeps the winner.
+// The reference's tuner does the same with its roller candidates (ops/operator.py:262-293).
+int dense_lib_tune(const wqaa_matmul_desc& d, int m, hipStream_t stream, float* best_ms) {
+  const LtPlan* base = get_plan(d, m);
+  if (!base) {
+    set_error(WQAA_ERR_UNSUPPORTED, "dense: hipBLASLt has no algorithm for this shape");
+    return WQAA_ERR_UNSUPPORTED;
+  }
+  constexpr int kCand = 12;
+  hipblasLtMatmulHeuristicResult_t res[kCand];
+  int found = 0;
+  {
+    hipblasLtMatmulPreference_t pref = nullptr;
+    if (hipblasLtMatmulPreferenceCreate(&pref) != HIPBLAS_STATUS_SUCCESS) return WQAA_OK;      // keep the heuristic's choice
+    uint64_t maxws = kMaxWorkspace;
+    (void)hipblasLtMatmulPreferenceSetAttribute(pref, HIPBLASLT_MATMUL_PREF_MAX_WORKSPACE_BYTES, &maxws, sizeof(maxws));
+    if (hipblasLtMatmulAlgoGetHeuristic(g_handle[base->dev], base->op, base->la, base->lb, base->lc, base->lc, pref, kCand, res, &found) !=
+        HIPBLAS_STATUS_SUCCESS)
+      found = 0;
+    (void)hipblasLtMatmulPreferenceDestroy(pref);
+  }
+  if (found <= 1) return WQAA_OK;
+  const size_t esz_a = (d.a_dtype == WQAA_F16 || d.a_dtype == WQAA_BF16) ? 2 : 1;
+  const size_t esz_c = d.out_dtype == WQAA_F32 || d.out_dtype == WQAA_I32 ? 4 : 2;
+  const size_t ab = (size_t)m * d.K * esz_a, wb = (size_t)d.N * d.K * esz_a, cb = (size_t)m * d.N * esz_c;
+  void *A = nullptr, *W = nullptr, *C = nullptr, *ws = nullptr;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  bool ok = hipMalloc(&A, ab) == hipSuccess && hipMalloc(&W, wb) == hipSuccess && hipMalloc(&C, cb) == hipSuccess &&
+            hipMalloc(&ws, kMaxWorkspace) == hipSuccess && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess;
+  int best = -1;
+  float best_t = 0.f, first_t = 0.f;
+  if (ok) {
+    hipLaunchKernelGGL(lt_fill_kernel, dim3((unsigned)((ab / 4 + 256) / 256)), dim3(256), 0, stream, (uint8_t*)A, ab, 1u);
+    hipLaunchKernelGGL(lt_fill_kernel, dim3((unsigned)((wb / 4 + 256) / 256)), dim3(256), 0, stream, (uint8_t*)W, wb, 2u);
+    const float alpha = 1.f, beta = 0.f;
+    const int32_t alpha_i = 1, beta_i = 0;
+    const bool i8 = d.a_dtype == WQAA_I8;
+    const void* al = i8 ? (const void*)&alpha_i : (const void*)&alpha;
+    const void* be = i8 ? (const void*)&beta_i : (const void*)&beta;
+    for (int i = 0; i < found; ++i) {
+      if (res[i].state != HIPBLAS_STATUS_SUCCESS || res[i].workspaceSize > kMaxWorkspace) continue;
+      bool run_ok = true;
+      for (int rep = 0; rep < 4 && run_ok; ++rep) {          // 1 warm-up + 3 timed
+        if (rep == 1) (void)hipEventRecord(e0, stream);
+        run_ok = hipblasLtMatmul(g_handle[base->dev], base->op, al, W, base->la, A, base->lb, be, C, base->lc, C, base->lc, &res[i].algo, ws,
+                                 res[i].workspaceSize, stream) == HIPBLAS_STATUS_SUCCESS;
+      }
+      (void)hipEventRecord(e1, stream);
+      if (hipEventSynchronize(e1) != hipSuccess || !run_ok) {
+        (void)hipGetLastError();
+        continue;
+      }
+      float t = 0.f;
+      if (hipEventElapsedTime(&t, e0, e1) != hipSuccess) continue;
+      if (i == 0) first_t = t;
+      if (best < 0 || t < best_t) { best = i; best_t = t; }
+    }
+    // the heuristic's own first choice stays unless a candidate is clearly (> 3 %) ahead: a short measurement has noise
+    if (best > 0 && first_t > 0.f && best_t > 0.97f * first_t) { best = 0; best_t = first_t; }
+  }
+  (void)hipStreamSynchronize(stream);
+  if (A) (void)hipFree(A);
+  if (W) (void)hipFree(W);
+  if (C) (void)hipFree(C);
+  if (ws) (void)hipFree(ws);
+  if (e0) (void)hipEventDestroy(e0);
+  if (e1) (void)hipEventDestroy(e1);
+  (void)hipGetLastError();
+  if (best >= 0) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    LtPlan* p = const_cast<LtPlan*>(base);
+    p->algo = res[best].algo;
+    p->ws = res[best].workspaceSize;
+    if (best_ms) *best_ms = best_t / 3.f;
   }
   return WQAA_OK;
 }

@@ -456,6 +456,13 @@ bool gemm_two_pass_eligible(const wqaa_matmul_desc& d, int m) {
   return dense_lib_eligible(dd, m, true);
 }
 
+// the vendor GEMM of the second pass, tuned (dense_lib_tune) - independent of two_pass_min_m, which the caller sets afterwards
+int gemm_two_pass_tune(const wqaa_matmul_desc& d, int m, hipStream_t stream) {
+  wqaa_matmul_desc dd;
+  if (m < 16 || !two_pass_dense_desc(d, &dd) || !dense_lib_eligible(dd, m, true)) return WQAA_OK;     // nothing to tune
+  return dense_lib_tune(dd, m, stream, nullptr);
+}
+
 static size_t two_pass_scratch(const wqaa_matmul_desc& d) {
   const size_t esz = d.a_dtype == WQAA_I8 ? 1 : 2;
   return ((size_t)d.N * d.K * esz + 255) & ~(size_t)255;

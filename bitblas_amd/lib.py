@@ -39,7 +39,7 @@ ZEROS_CODE = {"original": Z_ORIGINAL, "rescale": Z_RESCALE, "quantized": Z_QUANT
 
 EXPORTED_SYMBOLS = (
     "init", "wqaa_abi_version", "wqaa_device_count", "wqaa_matmul", "wqaa_matmul_timed",
-    "wqaa_matmul_ex", "wqaa_matmul_opts", "wqaa_workspace_bytes", "wqaa_matmul_group", "wqaa_matmul_group_ex", "wqaa_group_plan", "wqaa_dequantize", "wqaa_act_quant_int8", "wqaa_select", "wqaa_pack_weight", "wqaa_unpack_weight", "wqaa_debug_decode", "wqaa_debug_row_blocks",
+    "wqaa_matmul_ex", "wqaa_matmul_opts", "wqaa_workspace_bytes", "wqaa_matmul_group", "wqaa_matmul_group_ex", "wqaa_group_plan", "wqaa_dequantize", "wqaa_tune", "wqaa_act_quant_int8", "wqaa_select", "wqaa_pack_weight", "wqaa_unpack_weight", "wqaa_debug_decode", "wqaa_debug_row_blocks",
     "wqaa_last_error", "wqaa_last_error_string",
 )
 
@@ -128,6 +128,8 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
         lib.wqaa_workspace_bytes.argtypes = [dp, ci]
         lib.wqaa_act_quant_int8.restype = ci
         lib.wqaa_act_quant_int8.argtypes = [vp, i64, ci, vp, vp, vp]
+        lib.wqaa_tune.restype = ci
+        lib.wqaa_tune.argtypes = [dp, ci, vp]
         lib.wqaa_dequantize.restype = ci
         lib.wqaa_dequantize.argtypes = [dp, vp, vp, vp, vp, vp, vp]
         lib.wqaa_select.restype = ci
@@ -351,6 +353,11 @@ class BoundLib:
                                           ctypes.byref(epi))
         if status != OK:
             check(status)
+
+    def tune(self, m: int, stream) -> None:
+        """`wqaa_tune`: time the vendor library's candidate algorithms behind (desc, m) on the device, keep the fastest"""
+        check(self._lib.wqaa_tune(self._desc_ref, int(m), stream))
+        self._ws_need.clear()
 
     def plan(self, m: int) -> dict:
         self._ws_need.clear()      # planning re-reads the tuning variables: the scratch a member needs may change with them

@@ -443,6 +443,14 @@ class Matmul:
         only refreshes the recorded plans (so `Linear.warmup` keeps working)."""
         cand = sorted(m for m in self.plans if isinstance(m, int) and m >= 256)
         native = self.W_dtype == self.A_dtype
+        if cand and torch.cuda.is_available():
+            # the vendor GEMM behind the operator (plain dense pairs / second pass of the two-pass member): candidates timed
+            dev = self.device if isinstance(self.device, torch.device) else torch.device("cuda", torch.cuda.current_device())
+            try:
+                for m in cand:
+                    self.lib.tune(m, _lib.current_stream_handle(dev))
+            except (_lib.WqaaError, RuntimeError) as exc:
+                logger.info("library tuning skipped: %s", exc)
         if cand and not native and not self.with_bias and torch.cuda.is_available() and self.A_dtype in ("float16", "bfloat16", "int8"):
             try:
                 self._tune_two_pass(cand)

@@ -230,6 +230,12 @@ int wqaa_matmul_group(const wqaa_group_item* items, int count, int m, void* stre
 int wqaa_matmul_group_ex(const wqaa_group_item* items, const wqaa_epilogue* const* epilogues, int count, int m, void* stream);
 int wqaa_group_plan(const wqaa_matmul_desc* const* descs, int count, int m, int* launches, wqaa_plan* plan);
 
+/* measured tuning of the vendor-library GEMM behind (desc, m) - the plain dense pairs, or the second pass of the two-pass
+ * member: the heuristic's top candidates are timed on the device (temporary buffers, synchronises `stream`) and the
+ * fastest is kept for the process.  The counterpart of the reference's profiler pass (ops/operator.py:262-293); called by
+ * `Matmul.hardware_aware_finetune`.  No-op without a device or where no library GEMM is involved. */
+int wqaa_tune(const wqaa_matmul_desc* desc, int m, void* stream);
+
 /* B_decode on its own: out (N, K) row-major in A_dtype = every weight decoded and (zero, scale)-dequantised as the TE
  * definition's first stage does (matmul_dequantize_impl.py:391-449) by the routines the MFMA members use in their loop.
  * float16 / bfloat16 / int8 activations' operators; K a multiple of 128 (256 for int8).  Asynchronous on `stream`. */

@@ -207,3 +207,19 @@ int main(void) {
     assert res.returncode == 0, (res.returncode, res.stdout, res.stderr)
     lines = res.stdout.split()
     assert "gemv" in lines[0] and lines[1].endswith("_x3")
+
+
+def test_tune_and_dequantize_entries_without_a_device():
+    """wqaa_tune is a no-op where there is nothing to measure on; wqaa_dequantize checks its operands before it needs a device"""
+    L = wlib.load_library()
+    d = wlib.make_desc(N=4096, K=4096, a_dtype=wlib.F16, w_format=wlib.W_UINT, w_bits=4, out_dtype=wlib.F16, group_size=128,
+                       with_scaling=True, zeros_mode=wlib.Z_ORIGINAL)
+    if L.wqaa_device_count() == 0:
+        assert L.wqaa_tune(ctypes.byref(d), 4096, None) == wlib.OK
+    assert L.wqaa_dequantize(ctypes.byref(d), None, None, None, None, None, None) == wlib.ERR_BAD_DESC
+    # the tuned threshold is part of the descriptor: planning honours it only where the two-pass member exists (needs the device)
+    d.two_pass_min_m = 1024
+    p = wlib.select(d, 4096)
+    assert p["kernel_family"] in (2, 4)
+    if L.wqaa_device_count() == 0:
+        assert p["kernel_family"] == 2

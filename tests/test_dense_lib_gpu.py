@@ -131,3 +131,33 @@ def test_capture_replay_two_streams_and_caller_workspace():
         with pytest.raises(bitblas.lib.WqaaError):
             op.lib.run_ws(Ad.data_ptr(), Wd.data_ptr(), None, None, None, None, o3.data_ptr(), M, torch.cuda.current_stream().cuda_stream,
                           ws.data_ptr(), 16)
+
+
+def test_measured_tuning_keeps_results_and_never_a_slower_algorithm():
+    """`Matmul.hardware_aware_finetune` -> `wqaa_tune`: the library's candidate algorithms are timed on the device; whichever
+    is kept, the result still meets the contract, and the operator is not slower than before (3 % margin + noise)"""
+    M, N, K = 2048, 10240, 8192                     # the c5 shape on which the heuristic's first choice is a slow one
+    A, W = operands(M, N, K, "e4m3_float8", 8)
+    Ad, Wd = A.to(DEV), W.to(DEV)
+    op = op_for(M, N, K, "e4m3_float8")
+
+    def ms(n=5):
+        out = torch.empty((M, N), dtype=torch.float16, device=DEV)
+        for _ in range(2):
+            op(Ad, Wd, output=out)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            op(Ad, Wd, output=out)
+        e1.record()
+        e1.synchronize()
+        return e0.elapsed_time(e1) / n, out
+
+    before, ref = ms()
+    op.hardware_aware_finetune()
+    assert op.plans[M]["kernel_family"] == 3
+    after, out = ms()
+    assert after <= 1.15 * before, (before, after)
+    rows = np.arange(0, M, 37)
+    assert_fp_parity(out[rows].float().cpu().numpy(), reference_rows(A, W, rows, torch.float16), rtol=1e-3, atol_frac=1e-3)
+    assert_fp_parity(out[rows].float().cpu().numpy(), ref[rows].float().cpu().numpy(), rtol=1e-3, atol_frac=1e-3)

@@ -24,5 +24,18 @@ def main():
               f"{b['TFLOPs']:7.0f} T [{b['kernel'].split('_', 2)[2]}] {b.get('tuning')}")
 
 
+def dense():
+    dev = torch.device("cuda", 0)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1)
+    for (N, K) in ((8192, 8192), (8192, 28672), (10240, 8192), (28672, 8192)):
+        a = bench.time_member_dense(dev, gen, 4096, N, K, n_buf=2)
+        b = bench.time_member_dense(dev, gen, 4096, N, K, n_buf=2, tuned=True)
+        print(f"e4m3 M=4096 N={N} K={K}: heuristic {a['us_per_launch']:8.1f} us {a['TFLOPs']:7.0f} T | tuned {b['us_per_launch']:8.1f} us {b['TFLOPs']:7.0f} T")
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "dense":
+        dense()
+        sys.exit(0)
     main()
