@@ -70,7 +70,10 @@ class OperatorCache:
                 with open(os.path.join(config_path, f"{config_type}.json"), "w") as f:
                     json.dump(asdict(config), f)
                 with open(os.path.join(config_path, "mapping.json"), "w") as f:
-                    json.dump({"config_type": config_type, "operator_type": operator_type}, f)
+                    # "tuned": what hardware_aware_finetune measured on the device (the reference stores its tuned hint as the
+                    # generated source; here it is one integer of the descriptor)
+                    tuned = {"two_pass_min_m": int(getattr(getattr(op_inst, "_desc", None), "two_pass_min_m", 0) or 0)}
+                    json.dump({"config_type": config_type, "operator_type": operator_type, "tuned": tuned}, f)
                 with open(os.path.join(config_path, "source.txt"), "w") as f:
                     f.write(op_inst.get_source())
             return database_path
@@ -111,6 +114,10 @@ class OperatorCache:
                 config["M"] = tuple(config["M"])
             cfg = config_cls(**config)
             op = operator_cls(config=cfg, target=target, enable_tuning=False, from_database=True)
+            tuned = mapping.get("tuned") or {}
+            if tuned.get("two_pass_min_m") and hasattr(op, "_desc"):
+                op._desc.two_pass_min_m = int(tuned["two_pass_min_m"])
+                op.plans = {m: op.lib.plan(m) for m in op.plans}
         except Exception as exc:  # an entry written by another build that we cannot serve
             logger.warning("skipping database entry %s: %s", config_path, exc)
             return

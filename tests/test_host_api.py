@@ -234,3 +234,21 @@ def test_bench_algorithmic_bytes_are_the_survey_figures():
     assert bench.algorithmic_bytes(1, 1024, 1024, g=1024) == 2048 + 524_288 + 2048 + 2048          # c1, g = -1
     names = [n for (n, _, _) in bench.LLAMA2_7B_LINEARS]
     assert len(names) == 7 and bench.HBM_PEAK_GBS == 8000.0
+
+
+def test_operator_cache_persists_the_tuned_threshold(tmp_path):
+    """what hardware_aware_finetune measured (desc.two_pass_min_m) travels with the operator database
+    (reference: cache/operator.py:62-120 stores the tuned source next to the config)"""
+    import bitblas_amd as bb
+    from bitblas_amd.cache import OperatorCache
+    cfg = bb.MatmulConfig(M=[1, 4096], N=1024, K=1024, A_dtype="float16", W_dtype="uint4", group_size=128, with_scaling=True,
+                          with_zeros=True)
+    op = bb.Matmul(cfg, enable_tuning=False)
+    assert op._desc.two_pass_min_m == 0
+    op._desc.two_pass_min_m = 1024
+    c = OperatorCache()
+    c.add(cfg, op)
+    d = c.save_into_database(str(tmp_path), target="hip")
+    c2 = OperatorCache()
+    c2.load_from_database(d, target="hip")
+    assert c2.size() == 1 and c2.get(cfg)._desc.two_pass_min_m == 1024
