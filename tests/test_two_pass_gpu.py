@@ -143,3 +143,14 @@ def test_finetune_measures_and_keeps_the_faster_member():
     rows = np.random.default_rng(0).choice(4096, size=32, replace=False)
     sub = dict(case, A=case["A"][rows], M=32)
     assert_fp_parity(out[rows].cpu().numpy(), oracle_output(sub), rtol=1e-3, atol_frac=1e-3)
+
+
+@pytest.mark.parametrize("wd,zm", [("uint4", "original"), ("uint4", "quantized"), ("int4", None), ("nf4", None), ("uint2", "rescale")])
+def test_two_pass_bfloat16(wd, zm, monkeypatch):
+    """bfloat16 activations: B_decode in bfloat16 (one rounding per operation as the TE expression), plain GEMM in the library;
+    WQAA_TWO_PASS forces the member at plan time (reference cases: testing/python/operators/test_general_matmul_bf16.py:56-178)"""
+    from test_gemm_gpu import _bf16_case
+    monkeypatch.setenv("WQAA_TWO_PASS", "16")
+    out, want, mm = _bf16_case(300, 528, 1024, wd, 128, True, zm, seed=4)
+    assert mm.plans[300]["kernel_family"] == 4, mm.plans[300]
+    assert_fp_parity(out, want, rtol=1e-5, atol_frac=1e-5)
