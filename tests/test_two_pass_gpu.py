@@ -154,3 +154,54 @@ def test_two_pass_bfloat16(wd, zm, monkeypatch):
     out, want, mm = _bf16_case(300, 528, 1024, wd, 128, True, zm, seed=4)
     assert mm.plans[300]["kernel_family"] == 4, mm.plans[300]
     assert_fp_parity(out, want, rtol=1e-5, atol_frac=1e-5)
+
+
+def test_two_pass_capture_replay_and_two_streams():
+    """the two-pass member under the workspace ownership rules: caller-owned scratch shared per (stream, device)
+    (`lib.shared_workspace`), capturable into a hipGraph, two streams at once with their own scratch"""
+    M, N, K = 512, 4096, 4096              # N * K * 2 B = 32 MiB of B_decode: above the shared-workspace threshold
+    case = make_case(M, N, K, W_dtype="uint4", group_size=128, with_scaling=True, with_zeros=True, zeros_mode="original",
+                     scale_mul=0.02, seed=2)
+    case2 = make_case(M, N, K, W_dtype="uint4", group_size=128, with_scaling=True, with_zeros=True, zeros_mode="original",
+                      scale_mul=0.02, seed=3)
+    mm, w = build(case, True)
+    _, w2 = build(case2, True)
+    mm.lib.desc.two_pass_min_m = 256
+    assert mm.lib.plan(M)["kernel_family"] == 4
+    assert mm.lib.workspace_bytes(M) >= N * K * 2
+    A = _to_dev(case["A"], DEV)
+    base = mm(A, *w).clone()
+    base2 = mm(A, *w2).clone()
+    torch.cuda.synchronize()
+    rows = np.arange(0, M, 17)
+    assert_fp_parity(base[rows].cpu().numpy(), oracle_output(dict(case, A=case["A"][rows], M=len(rows))), rtol=1e-3, atol_frac=1e-3)
+    # capture -> replay with other weights in the same buffers
+    wbuf = [t.clone() if t is not None else None for t in w]
+    out = torch.empty_like(base)
+    mm(A, *wbuf, output=out)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        mm(A, *wbuf, output=out)
+    for dst, src in zip(wbuf, w2):
+        if dst is not None:
+            dst.copy_(src)
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, base2)
+    # two streams, different weights, many rounds: each stream has its own scratch
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    o1, o2 = torch.empty_like(base), torch.empty_like(base)
+    torch.cuda.synchronize()
+    for _ in range(4):
+        with torch.cuda.stream(s1):
+            mm(A, *w, output=o1)
+        with torch.cuda.stream(s2):
+            mm(A, *w2, output=o2)
+    torch.cuda.synchronize()
+    assert torch.equal(o1, base) and torch.equal(o2, base2)
+    # a caller workspace that is too small is refused
+    small = torch.empty(1 << 20, dtype=torch.uint8, device=DEV)
+    with pytest.raises(wlib.WqaaError):
+        mm.lib.run_ws(A.data_ptr(), w[0].data_ptr(), None, w[1].data_ptr(), w[2].data_ptr(), None, o1.data_ptr(), M,
+                      torch.cuda.current_stream().cuda_stream, small.data_ptr(), small.numel())
