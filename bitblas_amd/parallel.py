@@ -178,3 +178,73 @@ class ColumnParallelMatmul:
         return out
 
     __call__ = forward
+
+
+class ColumnParallelGroup:
+    """The projections of a decoder layer that read the same input (q/k/v, gate/up), every one column-sharded over the
+    ranks: ONE kernel launch per rank for the whole group (`matmul_group`, include/wqaa.h wqaa_matmul_group) and ONE
+    all-gather for all of its outputs.
+
+    At M = 1 the collective, not the kernel, is the cost of a column-parallel layer: a 2-16 KB all-gather is a fixed
+    RCCL latency of tens of microseconds against ~7 us for the grouped GEMV, and xGMI is point-to-point - three small
+    gathers queue behind each other.  Every rank writes its slices of all members side by side into one staging row
+    block `[rows, sum_i N_i / P]` (the group launch gives each member its own output pointer inside it), the staging is
+    gathered once, and member i's `[rows, N_i]` output is the rank-major view `gathered[:, :, off_i : off_i + N_i / P]`
+    - returned as a strided view (`as_views=True`: no copy; rank p's columns are contiguous, which is what per-head
+    consumers read) or copied out contiguous (default).  SURVEY.md section 8(e); the reference has no multi-GPU code.
+    `compute` lets the CPU tests swap the kernel launch for the oracle."""
+
+    def __init__(self, configs, group=None, compute: Optional[Callable] = None, **matmul_kwargs):
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.full_configs = list(configs)
+        if not self.full_configs:
+            raise ValueError("a group needs at least one member")
+        out_dtypes = {c.out_dtype for c in self.full_configs}
+        if len(out_dtypes) != 1:
+            raise ValueError("the members of a group share one out_dtype (one staging buffer is gathered)")
+        self.bounds = []
+        for c in self.full_configs:
+            bits = Matmul.BITBLAS_TRICK_DTYPE_MAP[c.W_dtype][1]
+            self.bounds.append(shard_bounds(c.N, self.rank, self.world, bits, c.with_zeros and c.zeros_mode == "quantized"))
+        self.local_configs = [replace(c, N=c.N // self.world) for c in self.full_configs]
+        self.pers = [c.N for c in self.local_configs]
+        self.offs = [sum(self.pers[:i]) for i in range(len(self.pers))]
+        self.per_total = sum(self.pers)
+        self._compute = compute
+        self.ops = None if compute is not None else [Matmul(c, enable_tuning=False, **matmul_kwargs) for c in self.local_configs]
+        self._out_dtype = torch_dtype(self.full_configs[0].out_dtype)
+
+    def forward(self, A, weights, as_views: bool = False):
+        """`weights[i]`: the rank's shard of member i as `Matmul.forward` takes it after A - `W` or `(W, scale, zeros, bias)`
+        (see `shard_operands`).  Returns the members' full `[..., N_i]` outputs, identical on every rank."""
+        lead = A.shape[:-1]
+        rows = A.numel() // A.shape[-1]
+        world, P = self.world, self.per_total
+        ws = [((w,) if isinstance(w, torch.Tensor) else tuple(w)) for w in weights]
+        ws = [(w + (None,) * 4)[:4] for w in ws]
+        # every member's slice goes into its own contiguous block of ONE flat staging buffer: block i is [rows, N_i / P]
+        staging = torch.empty(rows * P, dtype=self._out_dtype, device=A.device)
+        blocks, off = [], 0
+        for n in self.pers:
+            blocks.append(staging[off:off + rows * n].view(rows, n))
+            off += rows * n
+        A2 = A.reshape(rows, A.shape[-1])
+        if self._compute is not None:
+            for b, w in zip(blocks, ws):
+                b.copy_(self._compute(A2, *w))
+        else:
+            from .group import matmul_group
+            matmul_group(self.ops, A2, ws, outputs=blocks)
+        gathered = torch.empty(world * rows * P, dtype=self._out_dtype, device=A.device)
+        dist.all_gather_into_tensor(gathered, staging, group=self.group)           # the ONE collective of the group
+        g = gathered.view(world, rows * P)
+        outs, off = [], 0
+        for n in self.pers:
+            v = g[:, off:off + rows * n].view(world, rows, n).permute(1, 0, 2)     # [rows, P, N_i / P]: rank-major columns
+            off += rows * n
+            outs.append(v if as_views else v.reshape(*lead, world * n))
+        return outs
+
+    __call__ = forward

@@ -103,6 +103,64 @@ def _worker_dense_blocked(rank, world, port, M, row_block, ret):
         dist.destroy_process_group()
 
 
+def _worker_group(rank, world, port, M, ret):
+    """q/k/v (grouped-query widths) column-sharded, one staging buffer, ONE all-gather: ColumnParallelGroup on CPU with the
+    oracle in place of the kernel launch"""
+    for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import wqaa_oracle as oracle
+        from bitblas_amd import MatmulConfig
+        from bitblas_amd import parallel
+        from bitblas_amd.parallel import ColumnParallelGroup, shard_operands
+        rng = np.random.default_rng(5)
+        K, g, bit = 256, 64, 4
+        Ns = (128, 64, 32)
+        A = (rng.random((M, K), dtype=np.float32) - 0.5).astype(np.float16)
+        cfgs, parts, wants = [], [], []
+        for N in Ns:
+            codes = rng.integers(0, 16, size=(N, K)).astype(np.int8)
+            scale = rng.random((N, K // g), dtype=np.float32).astype(np.float16)
+            wants.append(oracle.matmul_dequant(A, codes, source_format="uint", bit=bit, scale=scale, group_size=g))
+            cfgs.append(MatmulConfig(M=M, N=N, K=K, A_dtype="float16", W_dtype="uint4", group_size=g, with_scaling=True))
+            sh = shard_operands(rank, world, W=torch.from_numpy(oracle.general_compress(codes, bit)), bits=bit,
+                                scale=torch.from_numpy(scale))
+            parts.append((sh["W"], sh["scale"]))
+
+        def compute(A_t, W_t, s, z, b):
+            c = oracle.general_decompress(W_t.numpy(), bit)
+            return torch.from_numpy(oracle.matmul_dequant(A_t.numpy(), c, source_format="uint", bit=bit, scale=s.numpy(), group_size=g))
+
+        calls = []
+        real = dist.all_gather_into_tensor
+        parallel.dist.all_gather_into_tensor = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+        try:
+            op = ColumnParallelGroup(cfgs, compute=compute)
+            outs = op(torch.from_numpy(A), parts)
+            views = op(torch.from_numpy(A), parts, as_views=True)
+        finally:
+            parallel.dist.all_gather_into_tensor = real
+        ok = len(calls) == 2                                   # one collective per call, whatever the member count
+        for N, o, v, w in zip(Ns, outs, views, wants):
+            ok = ok and tuple(o.shape) == (M, N) and o.is_contiguous() and bool(np.array_equal(o.numpy(), w))
+            ok = ok and tuple(v.shape) == (M, world, N // world) and bool(np.array_equal(v.reshape(M, N).numpy(), w))
+        ret[rank] = ok
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("M", [1, 3])
+def test_column_parallel_group_one_gather_for_qkv(M):
+    world = 2
+    ret = mp.Manager().dict()
+    mp.spawn(_worker_group, args=(world, _free_port(), M, ret), nprocs=world, join=True)
+    assert all(ret.get(r) for r in range(world)), dict(ret)
+
+
 @pytest.mark.parametrize("M,row_block", [(7, 512), (40, 16), (33, 8)])
 def test_dense_fp8_row_blocked_gather(M, row_block):
     world = 2
