@@ -205,6 +205,7 @@ def time_member_dense(device, gen, M, N, K, kind="fp8", n_buf=4, own=False, tune
     # M = 16 up (csrc/wqaa_dense_lib.hip; WQAA_DENSE_LIB is a plan-time switch: set while the operator is planned AND timed)
     if own:
         os.environ["WQAA_DENSE_LIB"] = "0"
+    op = None
     try:
         if kind == "fp8":
             cfg = bitblas.MatmulConfig(M=M, N=N, K=K, A_dtype="e4m3_float8", W_dtype="e4m3_float8", accum_dtype="float32",
@@ -220,9 +221,8 @@ def time_member_dense(device, gen, M, N, K, kind="fp8", n_buf=4, own=False, tune
     finally:
         if own:
             del os.environ["WQAA_DENSE_LIB"]
-            op_ = locals().get("op")
-            if op_ is not None:
-                op_.lib.plan(M)          # planning re-reads the switch for whatever runs next
+            if op is not None:
+                op.lib.plan(M)                 # planning re-reads the switch for whatever runs next
 
 
 def _time_member_dense(device, gen, op, M, N, K, kind, n_buf):
