@@ -252,3 +252,19 @@ def test_operator_cache_persists_the_tuned_threshold(tmp_path):
     c2 = OperatorCache()
     c2.load_from_database(d, target="hip")
     assert c2.size() == 1 and c2.get(cfg)._desc.two_pass_min_m == 1024
+
+
+def test_shared_workspace_grows_geometrically_and_keeps_retired_buffers():
+    """`lib.shared_workspace`: ONE large scratch per (stream, device) for all operators (the two-pass member's B_decode); a
+    buffer that is replaced stays alive - a captured hipGraph may still point at it (the C pool's rule, csrc/wqaa_gemm.hip)"""
+    from bitblas_amd import lib as wlib
+    wlib._shared_ws.clear()
+    del wlib._shared_ws_retired[:]
+    a = wlib.shared_workspace(7, "cpu", 1000)
+    assert a.numel() >= 1000 and wlib.shared_workspace(7, "cpu", 500) is a          # reused while it is large enough
+    b = wlib.shared_workspace(7, "cpu", 1500)
+    assert b is not a and b.numel() >= 2 * a.numel() and wlib._shared_ws_retired == [a]
+    c = wlib.shared_workspace(8, "cpu", 10)                                          # another stream: its own buffer
+    assert c is not b and wlib.shared_workspace(7, "cpu", 1) is b
+    wlib._shared_ws.clear()
+    del wlib._shared_ws_retired[:]
