@@ -198,6 +198,7 @@ int dense_lib_tune(const wqaa_matmul_desc& d, int m, hipStream_t stream, float* 
             hipMalloc(&ws, kMaxWorkspace) == hipSuccess && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess;
   int best = -1;
   float best_t = 0.f, first_t = 0.f;
+  bool own_wins = false;
   if (ok) {
     hipLaunchKernelGGL(lt_fill_kernel, dim3((unsigned)((ab / 4 + 256) / 256)), dim3(256), 0, stream, (uint8_t*)A, ab, 1u);
     hipLaunchKernelGGL(lt_fill_kernel, dim3((unsigned)((wb / 4 + 256) / 256)), dim3(256), 0, stream, (uint8_t*)W, wb, 2u);
@@ -226,6 +227,22 @@ int dense_lib_tune(const wqaa_matmul_desc& d, int m, hipStream_t stream, float* 
     }
     // the heuristic's own first choice stays unless a candidate is clearly (> 3 %) ahead: a short measurement has noise
     if (best > 0 && first_t > 0.f && best_t > 0.97f * first_t) { best = 0; best_t = first_t; }
+    // ... and this library's own MFMA member of the same shape is a candidate too (the vendor heuristic has holes: e4m3
+    // M = 256 at 8192 x 28672 190 us against 127 us): if it is clearly ahead, the library path is switched off for (desc, m)
+    if (best >= 0 && d.a_dtype != WQAA_I8) {
+      bool run_ok = true;
+      for (int rep = 0; rep < 4 && run_ok; ++rep) {
+        if (rep == 1) (void)hipEventRecord(e0, stream);
+        run_ok = gemm_launch(d, A, W, nullptr, nullptr, nullptr, nullptr, C, m, stream, nullptr, nullptr, nullptr, nullptr) == WQAA_OK;
+      }
+      (void)hipEventRecord(e1, stream);
+      float t = 0.f;
+      if (run_ok && hipEventSynchronize(e1) == hipSuccess && hipEventElapsedTime(&t, e0, e1) == hipSuccess && t < 0.97f * best_t) {
+        own_wins = true;
+        best_t = t;
+      }
+      (void)hipGetLastError();
+    }
   }
   (void)hipStreamSynchronize(stream);
   if (A) (void)hipFree(A);
@@ -240,6 +257,7 @@ int dense_lib_tune(const wqaa_matmul_desc& d, int m, hipStream_t stream, float* 
     LtPlan* p = const_cast<LtPlan*>(base);
     p->algo = res[best].algo;
     p->ws = res[best].workspaceSize;
+    if (own_wins) p->ok = false;               // dense_lib_eligible answers no from now on: the own member serves (desc, m)
     if (best_ms) *best_ms = best_t / 3.f;
   }
   return WQAA_OK;
