@@ -16,7 +16,7 @@ __version__ = "0.1.0"
 
 from .target import auto_detect_nvidia_target, auto_detect_target, get_arch  # noqa: F401
 from .matmul import (  # noqa: F401
-    Matmul, MatmulConfig, MatmulConfigWithSplitK, MatmulKernelNameGenerator, MatmulWithSplitK, OperatorConfig,
+    Matmul, MatmulConfig, MatmulConfigWithSplitK, MatmulKernelNameGenerator, MatmulWithSplitK, Operator, OperatorConfig,
     OptimizeStrategy, TransformKind, is_native_compute,
 )
 from .module import Linear  # noqa: F401
@@ -27,6 +27,7 @@ from .cache import (  # noqa: F401
 )
 from . import quantization, testing  # noqa: F401
 from .quantization import general_compress, interleave_weight  # noqa: F401
+from .compat import install_as_bitblas  # noqa: F401  (`import bitblas` and its submodule paths answered by this package)
 
 
 def set_log_level(level):

@@ -19,6 +19,7 @@ from hashlib import sha256
 
 logger = logging.getLogger(__name__)
 
+BITBLAS_DEFAULT_CACHE_PATH = os.path.expanduser("~/.cache/bitblas")       # bitblas/common.py:6
 BITBLAS_DATABASE_PATH = os.path.expanduser(os.environ.get("BITBLAS_DATABASE_PATH", "~/.cache/bitblas"))
 
 

@@ -337,7 +337,31 @@ class OPExecutorCPU:
         return len(self.operators)
 
 
-class Matmul:
+class Operator:
+    """`bitblas.ops.Operator` (ops/operator.py:92-527): the type callers annotate and check against, and the calls they make
+    on any operator - `op(*tensors)`, `hardware_aware_finetune`, `profile_latency`, `get_source`, `cleanup`.  Upstream's
+    base class owns the TVM build / wrap / compile pipeline; with a prebuilt kernel library that part is empty, so the base
+    keeps only the backend predicates and the call protocol.  Subclasses define `forward`."""
+
+    backend = "tl"
+
+    def is_tir_backend(self):
+        return self.backend == "tir"
+
+    def is_tilelang_backend(self):
+        return self.backend == "tl"
+
+    def forward(self, *args, **kwargs):  # pragma: no cover - interface
+        raise NotImplementedError
+
+    def __call__(self, *args, **kwargs):
+        return self.forward(*args, **kwargs)
+
+    def cleanup(self):
+        pass
+
+
+class Matmul(Operator):
     """Mixed-precision `C = A @ dq(W)^T (+bias)` on MI355X; API of `bitblas.Matmul` (:321-841)."""
 
     BITBLAS_TRICK_DTYPE_MAP = {
@@ -505,12 +529,6 @@ class Matmul:
         self._desc.two_pass_min_m = threshold
         self.lib._ws.clear()                                 # scratch buffers of the losing member
         self.lib.plan(cand[-1])
-
-    def is_tir_backend(self):
-        return self.backend == "tir"
-
-    def is_tilelang_backend(self):
-        return self.backend == "tl"
 
     def get_source(self, *args, **kwargs) -> str:
         names = sorted({p["name"] for p in self.plans.values()})

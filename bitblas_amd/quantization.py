@@ -51,3 +51,26 @@ def interleave_weight(qweight, nbits=4, target_dtype="float16"):
         out = _swizzle(out, 0xF000000F, [(0x000000F0, 4, 8), (0x00000F00, 8, 16), (0x0000F000, 12, 24),
                                          (0x000F0000, 16, 4), (0x00F00000, 20, 12), (0x0F000000, 24, 20)])
     return out.view(np.int8).reshape(np.asarray(qweight).shape)
+
+
+def gen_quant4(k, n, groupsize=-1):
+    """Synthetic 4-bit symmetric quantisation of a random `(k, n)` half matrix, the helper the reference's GPTQ / QuantLinear
+    tests draw their weights from (bitblas/quantization/utils.py:8-51; used by testing/python/module/test_repack_from_gptq*.py
+    and integration/pytorch/test_bitblas_quant_linear.py).  Groups of `groupsize` consecutive k share, per output column,
+    the scale `absmax / 8`; codes are `clamp(round(w / s) + 8, 0, 16)` (the upper bound 16 is upstream's, kept).
+
+    Returns `(original_w (k, n) half, nn.Linear(k, n) holding the dequantised weight, s (k / groupsize, n) half,
+    signed codes (k, n) int32)`; consumes the torch CPU generator exactly as upstream does (one `randn((k, n), half)`)."""
+    import torch
+    import torch.nn as nn
+    levels = 16
+    original_w = torch.randn((k, n), dtype=torch.half, device="cpu")
+    g = k if groupsize == -1 else groupsize
+    grouped = original_w.view(k // g, g, n)
+    s = grouped.abs().amax(dim=1, keepdim=True) * (2 / levels)          # exact in half: a power of two
+    codes = torch.clamp(torch.round(grouped / s).int() + levels // 2, 0, levels)
+    signed = codes - levels // 2
+    dequant = signed.half() * s
+    linear = nn.Linear(k, n, bias=False)
+    linear.weight.data = dequant.reshape(k, n).t()
+    return original_w, linear, s.reshape(k // g, n).contiguous(), signed.reshape(k, n).contiguous()

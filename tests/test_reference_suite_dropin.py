@@ -20,19 +20,17 @@ pytestmark = pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "testing", "
 
 @pytest.fixture
 def as_bitblas():
-    """alias bitblas_amd as `bitblas` (+ inert stand-ins for the tvm names the test modules import but the selected
-    tests never use); everything is removed from sys.modules afterwards"""
+    """`bitblas_amd.install_as_bitblas()` (bitblas_amd/compat.py) + inert stand-ins for the code-generator names the test
+    modules import at their top but the selected tests never use (`tvm`, `bitblas.tl.lower`); everything is removed from
+    sys.modules afterwards"""
+    from bitblas_amd import compat
     added = {}
 
     def put(name, mod):
         added[name] = sys.modules.get(name)
         sys.modules[name] = mod
 
-    shim = types.ModuleType("bitblas")
-    shim.__path__ = []
-    for k in dir(bitblas_amd):
-        if not k.startswith("__"):
-            setattr(shim, k, getattr(bitblas_amd, k))
+    shim = bitblas_amd.install_as_bitblas()
     tvm = types.ModuleType("tvm")
     tvm.__path__ = []
     contrib = types.ModuleType("tvm.contrib")
@@ -41,20 +39,12 @@ def as_bitblas():
     contrib.utils = cutils
     tvm.contrib = contrib
     shim.tvm = tvm
-    utils = types.ModuleType("bitblas.utils")
-    utils.auto_detect_nvidia_target = bitblas_amd.auto_detect_nvidia_target
-    shim.utils = utils
     tl = types.ModuleType("bitblas.tl")
     tl.__path__ = []
     lower = types.ModuleType("bitblas.tl.lower")
     lower.tl_lower = None
     tl.lower = lower
     shim.tl = tl
-    put("bitblas", shim)
-    put("bitblas.testing", bitblas_amd.testing)
-    put("bitblas.cache", bitblas_amd.cache)
-    put("bitblas.quantization", bitblas_amd.quantization)
-    put("bitblas.utils", utils)
     put("bitblas.tl", tl)
     put("bitblas.tl.lower", lower)
     put("tvm", tvm)
@@ -66,6 +56,7 @@ def as_bitblas():
             sys.modules.pop(name, None)
         else:
             sys.modules[name] = old
+    compat.uninstall()
 
 
 def load(relpath):
@@ -104,3 +95,33 @@ def test_reference_operator_cache_tests_pass_against_this_package(as_bitblas):
     ns = load("cache/test_operator_cache.py")
     assert run_parametrized(ns["test_config_hashable"]) == 3
     assert run_parametrized(ns["test_global_cache_inquery"]) == 3
+
+
+def test_reference_cache_spin_lock_threads_pass_against_this_package(as_bitblas, tmp_path):
+    """cache/test_operator_cache_spin_lock.py:21-46: the reference's own worker - construct, add to the global cache, save the
+    database, clear, reload - run from four threads at once on one database path, exactly as its test does (:87-98); the
+    test's tail (:100-122) is a GPU forward and travels as tests/test_gemv_gpu.py instead."""
+    import threading
+    ns = load("cache/test_operator_cache_spin_lock.py")
+    cfg = bitblas_amd.MatmulConfig(M=1, N=1024, K=1024, A_dtype="float16", out_dtype="float16", accum_dtype="float16",
+                                   with_bias=False, propagate_a=False, propagate_b=False, layout="nt")
+    bitblas_amd.global_operator_cache.clear()
+    errors = []
+
+    def worker(i):
+        try:
+            ns["tune_op_in_thread"](i, cfg, str(tmp_path))
+        except BaseException as exc:  # noqa: BLE001 - an assertion in a thread must fail the test
+            errors.append((i, exc))
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    try:
+        assert not errors, errors
+        op = bitblas_amd.global_operator_cache.get(cfg)
+        assert isinstance(op, bitblas_amd.Matmul) and op.config == cfg
+    finally:
+        bitblas_amd.global_operator_cache.clear()
