@@ -289,27 +289,6 @@ static bool group_fusable(const wqaa_matmul_desc* const* descs, int count, int m
   return ok;
 }
 
-// ------------------------------------------------------------------------------------------
-// CPU weight packer: general_compress order (quantization/utils.py:54-70) + optional LOP3
-// interleave (lop3_permutate_impl.py:12-132).  One 32-bit word at a time.
-// ------------------------------------------------------------------------------------------
-static inline int nibble_move(int bits, int S, int nib) {
-  static const int id[8] = {0, 1, 2, 3, 4, 5, 6, 7};
-  static const int i8_1b[8] = {0, 4, 2, 6, 1, 5, 3, 7};
-  static const int f16_2b[8] = {0, 1, 4, 5, 2, 3, 6, 7};
-  static const int f16_1b[8] = {0, 2, 4, 6, 1, 3, 5, 7};
-  const int* t = id;
-  if (bits == 1 && S == 8) t = i8_1b;
-  else if (bits == 2 && S == 16) t = f16_2b;
-  else if (bits == 1 && S == 16) t = f16_1b;
-  return t[nib];
-}
-static inline int dst_bit(int bits, int S, int o) {
-  const int G = 32 / S;
-  const int b = (o % G) * S + (o / G) * bits;
-  return nibble_move(bits, S, b / 4) * 4 + (b % 4);
-}
-
 }  // namespace wqaa
 
 using namespace wqaa;
@@ -537,84 +516,7 @@ int wqaa_select(const wqaa_matmul_desc* desc, int m, wqaa_plan* plan) {
   return use_gemm ? gemm_plan(*desc, m, plan) : gemv_plan(*desc, m, plan);
 }
 
-int wqaa_pack_weight(const int8_t* codes, int64_t rows, int64_t cols, int bits, int layout,
-                     int a_dtype, int8_t* out) {
-  if (!codes || !out || rows < 0 || cols < 0 || !(bits == 1 || bits == 2 || bits == 4 || bits == 8)) {
-    set_error(WQAA_ERR_BAD_DESC, "pack_weight: bad arguments (bits=%d)", bits);
-    return WQAA_ERR_BAD_DESC;
-  }
-  const int epb = 8 / bits;
-  if (cols % epb) {
-    set_error(WQAA_ERR_BAD_DESC, "pack_weight: cols=%ld not a multiple of %d", (long)cols, epb);
-    return WQAA_ERR_BAD_DESC;
-  }
-  const int64_t row_bytes = cols / epb;
-  const uint32_t mask = (1u << bits) - 1u;
-  if (bits == 8) {
-    memcpy(out, codes, (size_t)(rows * cols));
-    return WQAA_OK;
-  }
-  if (layout == WQAA_LAYOUT_LOP3 && row_bytes % 4) {
-    set_error(WQAA_ERR_BAD_DESC, "pack_weight: LOP3 layout needs K*bits %% 32 == 0");
-    return WQAA_ERR_BAD_DESC;
-  }
-  const int S = a_dtype == WQAA_I8 ? 8 : a_dtype == WQAA_I4 ? 4 : 16;
-  const int epw = 32 / bits;
-  int dst[32];
-  for (int o = 0; o < epw; ++o) dst[o] = layout == WQAA_LAYOUT_LOP3 ? dst_bit(bits, S, o) : o * bits;
-  for (int64_t r = 0; r < rows; ++r) {
-    const int8_t* src = codes + r * cols;
-    uint8_t* dstp = reinterpret_cast<uint8_t*>(out) + r * row_bytes;
-    int64_t c = 0;
-    if (layout == WQAA_LAYOUT_LOP3 || row_bytes % 4 == 0) {
-      for (; c + epw <= cols; c += epw) {
-        uint32_t w = 0;
-        for (int o = 0; o < epw; ++o) w |= ((uint32_t)(uint8_t)src[c + o] & mask) << dst[o];
-        memcpy(dstp + (c / epw) * 4, &w, 4);
-      }
-    }
-    for (; c < cols; c += epb) {  // plain tail, byte at a time
-      uint8_t b = 0;
-      for (int k = 0; k < epb; ++k) b |= (uint8_t)(((uint8_t)src[c + k] & mask) << (bits * k));
-      dstp[c / epb] = b;
-    }
-  }
-  return WQAA_OK;
-}
-
-int wqaa_unpack_weight(const int8_t* packed, int64_t rows, int64_t cols, int bits, int layout,
-                       int a_dtype, int8_t* codes) {
-  if (!codes || !packed || !(bits == 1 || bits == 2 || bits == 4 || bits == 8)) {
-    set_error(WQAA_ERR_BAD_DESC, "unpack_weight: bad arguments");
-    return WQAA_ERR_BAD_DESC;
-  }
-  if (bits == 8) {
-    memcpy(codes, packed, (size_t)(rows * cols));
-    return WQAA_OK;
-  }
-  const int epb = 8 / bits, epw = 32 / bits;
-  const int64_t row_bytes = cols / epb;
-  const uint32_t mask = (1u << bits) - 1u;
-  const int S = a_dtype == WQAA_I8 ? 8 : a_dtype == WQAA_I4 ? 4 : 16;
-  if (layout == WQAA_LAYOUT_LOP3 && row_bytes % 4) {
-    set_error(WQAA_ERR_BAD_DESC, "unpack_weight: LOP3 layout needs K*bits %% 32 == 0");
-    return WQAA_ERR_BAD_DESC;
-  }
-  for (int64_t r = 0; r < rows; ++r) {
-    const uint8_t* src = reinterpret_cast<const uint8_t*>(packed) + r * row_bytes;
-    int8_t* dstp = codes + r * cols;
-    if (layout == WQAA_LAYOUT_LOP3) {
-      for (int64_t c = 0; c < cols; c += epw) {
-        uint32_t w;
-        memcpy(&w, src + (c / epw) * 4, 4);
-        for (int o = 0; o < epw; ++o) dstp[c + o] = (int8_t)((w >> dst_bit(bits, S, o)) & mask);
-      }
-    } else {
-      for (int64_t c = 0; c < cols; ++c) dstp[c] = (int8_t)((src[c / epb] >> (bits * (c % epb))) & mask);
-    }
-  }
-  return WQAA_OK;
-}
+// wqaa_pack_weight / wqaa_unpack_weight / wqaa_relayout_weight: csrc/wqaa_pack.hip (host only)
 
 int wqaa_debug_decode(const void* packed_dev, int64_t nwords, int w_format, int bits, int layout,
                       int a_dtype, int strict_reference, const void* lut_dev, void* out_dev,

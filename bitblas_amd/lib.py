@@ -39,7 +39,7 @@ ZEROS_CODE = {"original": Z_ORIGINAL, "rescale": Z_RESCALE, "quantized": Z_QUANT
 
 EXPORTED_SYMBOLS = (
     "init", "wqaa_abi_version", "wqaa_device_count", "wqaa_matmul", "wqaa_matmul_timed",
-    "wqaa_matmul_ex", "wqaa_matmul_opts", "wqaa_workspace_bytes", "wqaa_matmul_group", "wqaa_matmul_group_ex", "wqaa_group_plan", "wqaa_dequantize", "wqaa_tune", "wqaa_act_quant_int8", "wqaa_select", "wqaa_pack_weight", "wqaa_unpack_weight", "wqaa_debug_decode", "wqaa_debug_row_blocks",
+    "wqaa_matmul_ex", "wqaa_matmul_opts", "wqaa_workspace_bytes", "wqaa_matmul_group", "wqaa_matmul_group_ex", "wqaa_group_plan", "wqaa_dequantize", "wqaa_tune", "wqaa_act_quant_int8", "wqaa_select", "wqaa_pack_weight", "wqaa_unpack_weight", "wqaa_relayout_weight", "wqaa_debug_decode", "wqaa_debug_row_blocks",
     "wqaa_last_error", "wqaa_last_error_string",
 )
 
@@ -138,6 +138,8 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
         lib.wqaa_pack_weight.argtypes = [vp, i64, i64, ci, ci, ci, vp]
         lib.wqaa_unpack_weight.restype = ci
         lib.wqaa_unpack_weight.argtypes = [vp, i64, i64, ci, ci, ci, vp]
+        lib.wqaa_relayout_weight.restype = ci
+        lib.wqaa_relayout_weight.argtypes = [vp, i64, i64, ci, ci, ci, ci, vp]
         lib.wqaa_debug_decode.restype = ci
         lib.wqaa_debug_decode.argtypes = [vp, i64, ci, ci, ci, ci, ci, vp, vp, vp]
         lib.wqaa_last_error.restype = ci
@@ -389,4 +391,16 @@ def unpack_weight(packed, cols: int, bits: int, layout: int, a_dtype_code: int):
     rows = p.shape[0]
     out = np.empty((rows, cols), dtype=np.int8)
     check(lib.wqaa_unpack_weight(p.ctypes.data, rows, cols, bits, layout, a_dtype_code, out.ctypes.data))
+    return out
+
+
+def relayout_weight(packed, bits: int, from_layout: int, to_layout: int, a_dtype_code: int):
+    """numpy (rows, row_bytes) packed bytes of one layout -> the other (PLAIN -> LOP3 is the reference's LOP3Permutate
+    stage, ops/lop3_permutate/lop3_permutate_impl.py:12-132), word by word in C."""
+    import numpy as np
+    lib = load_library()
+    p = np.ascontiguousarray(packed).view(np.int8)
+    rows, row_bytes = p.shape
+    out = np.empty_like(p)
+    check(lib.wqaa_relayout_weight(p.ctypes.data, rows, row_bytes, bits, from_layout, to_layout, a_dtype_code, out.ctypes.data))
     return out

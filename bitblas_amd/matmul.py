@@ -307,9 +307,7 @@ class _Lop3Permutate:
 
     def forward(self, packed: torch.Tensor) -> torch.Tensor:
         p = packed.detach().cpu().contiguous().view(torch.int8).numpy()
-        cols = p.shape[1] * 8 // self.bits
-        codes = _lib.unpack_weight(p, cols, self.bits, _lib.LAYOUT_PLAIN, self.a_code)
-        return torch.from_numpy(_lib.pack_weight(codes, self.bits, _lib.LAYOUT_LOP3, self.a_code))
+        return torch.from_numpy(_lib.relayout_weight(p, self.bits, _lib.LAYOUT_PLAIN, _lib.LAYOUT_LOP3, self.a_code))
 
 
 class OPExecutorCPU:

@@ -260,6 +260,12 @@ int wqaa_pack_weight(const int8_t* codes, int64_t rows, int64_t cols, int bits, 
 /* inverse: bytes in either layout -> unsigned field values */
 int wqaa_unpack_weight(const int8_t* packed, int64_t rows, int64_t cols, int bits, int layout,
                        int a_dtype, int8_t* codes);
+/* packed bytes of one layout -> packed bytes of the other, word by word (the reference's LOP3Permutate stage on its own:
+ * ops/lop3_permutate/lop3_permutate_impl.py:12-132 is PLAIN -> LOP3; the inverse serves checkpoints that have to go back).
+ * packed/out: (rows, row_bytes) bytes, row_bytes % 4 == 0; may not alias unless equal layouts.  All three functions split
+ * the rows of large tensors over host threads (WQAA_PACK_THREADS overrides the count; 1 = serial). */
+int wqaa_relayout_weight(const int8_t* packed, int64_t rows, int64_t row_bytes, int bits, int from_layout, int to_layout,
+                         int a_dtype, int8_t* out);
 
 /* ---- device self-test helper: decode `nwords` 32-bit words of packed weights with the kernels'
  * own decode routines (the HIP twin of testing/cpp/lop3_type_conversion/ *.cu known-answer tests).

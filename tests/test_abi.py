@@ -99,6 +99,37 @@ def test_c_packer_against_oracle_and_golden(golden):
             assert np.array_equal(wlib.pack_weight(golden["codes_" + tag], bits, wlib.LAYOUT_PLAIN, wlib.F16), golden[key])
 
 
+def test_relayout_and_threaded_packer(monkeypatch):
+    """wqaa_relayout_weight (the LOP3Permutate stage on packed bytes, both directions) against the oracle's restatement of
+    the reference's interleave, and the row-parallel path of all three packer entries (taken from 2 M fields on; forced
+    to 5 threads here, ragged against the row count) against the serial one - bit identical."""
+    import wqaa_oracle as oracle
+    rng = np.random.default_rng(11)
+    for bits in (1, 2, 4):
+        for code, tgt in ((wlib.F16, "float16"), (wlib.I8, "int8")) + (((wlib.I4, "int4"),) if bits == 2 else ()):
+            codes = rng.integers(0, 1 << bits, size=(13, 256), dtype=np.int8)
+            plain = wlib.pack_weight(codes, bits, wlib.LAYOUT_PLAIN, code)
+            lop3 = wlib.relayout_weight(plain, bits, wlib.LAYOUT_PLAIN, wlib.LAYOUT_LOP3, code)
+            assert np.array_equal(lop3, oracle.interleave_weight(plain, bits, tgt)), (bits, tgt)
+            assert np.array_equal(lop3, wlib.pack_weight(codes, bits, wlib.LAYOUT_LOP3, code))
+            assert np.array_equal(wlib.relayout_weight(lop3, bits, wlib.LAYOUT_LOP3, wlib.LAYOUT_PLAIN, code), plain)
+    assert np.array_equal(wlib.relayout_weight(plain, 8, wlib.LAYOUT_PLAIN, wlib.LAYOUT_LOP3, wlib.F16), plain)   # 8 bit: nothing moves
+    with pytest.raises(wlib.WqaaError):                     # a row that is not a whole number of 32-bit words
+        wlib.relayout_weight(np.zeros((4, 6), dtype=np.int8), 4, wlib.LAYOUT_PLAIN, wlib.LAYOUT_LOP3, wlib.F16)
+    rows, cols = 1027, 2048                                 # 2.1 M fields: the threaded path
+    for bits in (4, 2):
+        codes = rng.integers(0, 1 << bits, size=(rows, cols), dtype=np.int8)
+        monkeypatch.setenv("WQAA_PACK_THREADS", "1")
+        serial = [wlib.pack_weight(codes, bits, lay, wlib.F16) for lay in (wlib.LAYOUT_PLAIN, wlib.LAYOUT_LOP3)]
+        monkeypatch.setenv("WQAA_PACK_THREADS", "5")
+        threaded = [wlib.pack_weight(codes, bits, lay, wlib.F16) for lay in (wlib.LAYOUT_PLAIN, wlib.LAYOUT_LOP3)]
+        assert np.array_equal(serial[0], threaded[0]) and np.array_equal(serial[1], threaded[1])
+        assert np.array_equal(serial[0], oracle.general_compress(codes, bits))
+        assert np.array_equal(wlib.unpack_weight(threaded[1], cols, bits, wlib.LAYOUT_LOP3, wlib.F16), codes)
+        assert np.array_equal(wlib.relayout_weight(threaded[0], bits, wlib.LAYOUT_PLAIN, wlib.LAYOUT_LOP3, wlib.F16), serial[1])
+    monkeypatch.delenv("WQAA_PACK_THREADS")
+
+
 def test_selector_invariants_over_a_random_configuration_sweep():
     """Host logic only (wqaa_select needs no GPU): whatever the selector answers must be launchable - workgroup
     size a multiple of 64 and <= 1024, LDS within the 160 KB of a CU, non-empty grid, a name in the reference's
