@@ -6,6 +6,8 @@ test_general_matmul_fp8.py:149-158) and adds BASELINE.json configs c1/c2/c4.
 Tolerance: 1e-3 relative (north star) with an absolute floor of 1e-3 * rms(output); integer
 paths must be bit exact.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -173,6 +175,27 @@ def test_register_and_lds_activation_members_agree(wd, g, ws, wz, zm, M, monkeyp
     assert not mm2.plans[M]["name"].endswith("_areg")
     assert np.array_equal(got, got_lds)
     assert_fp_parity(got, oracle_output(case))
+
+
+@pytest.mark.skipif(not os.environ.get("WQAA_TEST_NEXT"), reason="queued for round 3 (DESIGN section 8 item 0): set WQAA_TEST_NEXT=1")
+@pytest.mark.parametrize("wd,ad", [("uint1", "float16"), ("int1", "float16"), ("uint2", "float16"), ("int1", "int8")])
+@pytest.mark.parametrize("M", [1, 2])
+def test_lds_staged_low_bit_members_agree_with_the_register_members(wd, ad, M, monkeypatch):
+    """The register-resident members of 1-bit (any M) and 2-bit (M = 2) weights spill (profiles/r02_static_isa.txt); before
+    the selector stops choosing them, their LDS-staged twins - never selected for K within one step today - must give the
+    same bits.  Not part of the default suite until it has run once on a GPU."""
+    int8 = ad == "int8"
+    case = make_case(M, 512, 4096, W_dtype=wd, A_dtype=ad, out_dtype="int32" if int8 else "float16",
+                     **({} if int8 else dict(group_size=128, with_scaling=True, scale_mul=0.05)))
+    got, mm = hip_output(case)
+    monkeypatch.setenv("WQAA_GEMV_NO_DIRECT", "1")
+    got_lds, mm2 = hip_output(case)
+    assert not mm2.plans[M]["name"].endswith("_areg")
+    assert np.array_equal(got, got_lds), (mm.plans[M]["name"], mm2.plans[M]["name"])
+    if int8:
+        assert np.array_equal(got, oracle_output(case))
+    else:
+        assert_fp_parity(got, oracle_output(case))
 
 
 def test_non_contiguous_activations_are_read_correctly():
