@@ -197,6 +197,39 @@ def time_member_gemm(device, gen, M=4096, N=4096, K=4096, W_dtype="uint4", A_dty
             "GBps_algorithmic": nbytes / t / 1e9, "frac_of_mfma_peak": tf / peak, "mfma_peak": peak}
 
 
+def time_member_resident_decode(device, gen, M=4096, N=4096, K=4096, n_buf=4):
+    """`Linear.enable_decoded_weight_cache` (bitblas_amd/module.py): the TE graph's B_decode kept resident in HBM (N*K*2 bytes
+    per layer) and the plain dense GEMM run against it - the two-pass member with its first pass hoisted out of the call.
+    Same operands as `gemm_uint4_m4096`; the decode happens once, in the untimed first call."""
+    try:
+        lins = []
+        for _ in range(n_buf):
+            lin = bitblas.Linear(K, N, A_dtype="float16", W_dtype="uint4", group_size=GROUP, with_scaling=True, with_zeros=True,
+                                 zeros_mode="original", opt_M=[16, M], enable_tuning=False).to(device)
+            lin.qweight = torch.randint(-128, 128, (N, K // 2), dtype=torch.int8, device=device, generator=gen)
+            lin.scales = (torch.rand((N, K // GROUP), device=device, generator=gen) * 0.02).to(torch.float16)
+            lin.zeros = torch.full((N, K // GROUP), 8.0, dtype=torch.float16, device=device)
+            lin.enable_decoded_weight_cache(min_m=256)
+            lins.append(lin)
+        lins[0]._dense_op.hardware_aware_finetune()        # the vendor library's candidates for the dense pair, timed (shared operator)
+        A = (torch.rand((M, K), device=device, generator=gen) - 0.5).to(torch.float16)
+        out = torch.empty((M, N), dtype=torch.float16, device=device)
+
+        def launch_all():
+            for lin in lins:
+                lin(A, output=out)
+
+        t = graph_time(device, launch_all, n_buf)
+        tf = 2.0 * M * N * K / t / 1e12
+        return {"workload": f"W_uint4 A_float16 GEMM M={M} N={N} K={K} g=128 zeros=original, B_decode resident ({N * K * 2 >> 20} MiB per layer)",
+                "kernel": lins[0]._dense_op.plans[M]["name"] if M in lins[0]._dense_op.plans else lins[0]._dense_op.lib.plan(M)["name"],
+                "us_per_launch": t * 1e6, "TFLOPs": tf, "frac_of_mfma_peak": tf / MFMA_F16_PEAK_TF, "mfma_peak": MFMA_F16_PEAK_TF,
+                "roofline": {"bound": "mfma", "achieved": tf, "peak": MFMA_F16_PEAK_TF, "unit": "TFLOP/s", "frac": tf / MFMA_F16_PEAK_TF,
+                             "flops_per_launch": 2.0 * M * N * K}}
+    except Exception as exc:  # member not available: report, never fake
+        return {"error": f"{type(exc).__name__}: {exc}"}
+
+
 def time_member_dense(device, gen, M, N, K, kind="fp8", n_buf=4, own=False, tuned=False):
     """Dense members: e4m3 x e4m3 MFMA GEMM on Llama-3-70B shapes (BASELINE config c5, one GPU's unsharded
     matrix) and the M = 1 W_int2 A_int8 GEMV (c4)."""
@@ -630,6 +663,7 @@ def main():
                 members[f"gemv_int4_n{N}k{K}_strict"] = time_member_gemv(device, gen, N, K, strict=True)
             members["gemm_uint4_m4096"] = time_member_gemm(device, gen, 4096)
             members["gemm_uint4_m4096_tuned"] = time_member_gemm(device, gen, 4096, tuned=True)
+            members["gemm_uint4_m4096_resident_decode"] = time_member_resident_decode(device, gen, 4096)
             members["gemm_uint4_m128"] = time_member_gemm(device, gen, 128)
             members["gemm_uint4_m16"] = time_member_gemm(device, gen, 16)
             members["gemm_int2_int8_m4096"] = time_member_gemm(device, gen, 4096, W_dtype="int2", A_dtype="int8")

@@ -589,6 +589,28 @@ class Matmul(Operator):
                 result.append(extra)
         return next(iter(result), result)
 
+    def dequantize_weight(self, W, scale=None, zeros=None, out=None):
+        """`B_decode` of the TE graph (tirscript/matmul_dequantize_impl.py:391-449) as a tensor: `(N, K)` in A_dtype, every
+        weight decoded and (zero, scale)-dequantised by the routines the MFMA members use in their loop (`wqaa_dequantize`;
+        bit-identical to the oracle's `dequantize_weight`, tests/test_two_pass_gpu.py).  float16 / bfloat16 / int8
+        activations' operators, K a multiple of 128 (256 for int8).  Asynchronous on the current stream of W's device."""
+        import ctypes
+        if not W.is_cuda:
+            raise RuntimeError("bitblas_amd.Matmul runs on the GPU only (no CPU fallback)")
+        if W.numel() * W.element_size() != self._w_bytes:
+            raise ValueError(f"W holds {W.numel() * W.element_size()} bytes, the operator expects {self._w_bytes}")
+        if out is None:
+            out = torch.empty((self.N, self.K), dtype=self._a_torch_dtype, device=W.device)
+        elif tuple(out.shape) != (self.N, self.K) or out.dtype != self._a_torch_dtype or not out.is_contiguous() or out.device != W.device:
+            raise ValueError(f"out must be a contiguous ({self.N}, {self.K}) {self._a_torch_dtype} tensor on W's device")
+        lut = self._ensure_lut(W.device)
+        L = _lib.load_library()
+        _lib.check(L.wqaa_dequantize(ctypes.byref(self._desc), W.data_ptr(), lut.data_ptr() if lut is not None else None,
+                                     scale.data_ptr() if scale is not None else None,
+                                     zeros.data_ptr() if zeros is not None else None,
+                                     out.data_ptr(), _lib.current_stream_handle(W.device)))
+        return out
+
     def transform_input(self, input_tensor):
         return input_tensor  # propagate_a is always NonTransform on CDNA (see propagate_a)
 

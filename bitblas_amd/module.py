@@ -88,6 +88,8 @@ class Linear(nn.Module):
         self.source_format = self.bitblas_matmul.source_format
         self._initialize_buffers(in_features, out_features, bias)
         self.q_params = None
+        self._decoded_min_m = 0          # enable_decoded_weight_cache
+        self._decoded = self._decoded_key = self._dense_op = None
 
     @property
     def consistent(self):
@@ -167,10 +169,55 @@ class Linear(nn.Module):
         live = self._live_params()
         return len(live) == len(self._q_param_keys) and all(t.data_ptr() == k for t, k in zip(live, self._q_param_keys))
 
+    # -- MI355X extension: the decoded weight kept resident for large-M calls ----------------------------------------------
+    def enable_decoded_weight_cache(self, min_m: int = 256):
+        """From `min_m` activation rows on, multiply by a RESIDENT copy of `B_decode` - the TE graph's first stage
+        (tirscript/matmul_dequantize_impl.py:391-449), written once by `Matmul.dequantize_weight` - through the plain dense
+        GEMM of the same shape, instead of decoding the packed weight again in every call.  It is the two-pass member
+        (`wqaa_matmul_desc.two_pass_min_m`) with its first pass hoisted out of the call: same B_decode bits, same GEMM, so
+        the same results; what it costs is memory, N*K*sizeof(A_dtype) per layer (4x a 4-bit weight) - the trade 288 GB of
+        HBM per GPU is there for: a 70B model's float16 B_decode is 140 GB next to 35 GB of packed weights.  Prefill
+        (M in the thousands) takes the dense path, decode (M = 1 ... 64) keeps streaming 4-bit weights.
+        The copy follows the live buffers: replacing `qweight` / `scales` / `zeros`, writing into them in place
+        (`load_state_dict`) or moving the module re-decodes at the next large-M call.  float16 / bfloat16 activations."""
+        cfg = self.bitblas_matmul.config
+        if self.consistent:
+            raise ValueError("W_dtype == A_dtype: the weight already is its own B_decode")
+        if cfg.A_dtype not in ("float16", "bfloat16") or cfg.K % 128 != 0:
+            raise ValueError("the decoded-weight cache serves float16 / bfloat16 activations with K a multiple of 128")
+        if int(min_m) < 16:
+            raise ValueError("min_m >= 16: below that the packed weight stream IS the cost (GEMV / decode-batch members)")
+        dense = MatmulConfig(M=cfg.M, N=cfg.N, K=cfg.K, A_dtype=cfg.A_dtype, W_dtype=cfg.A_dtype, accum_dtype=cfg.accum_dtype,
+                             out_dtype=cfg.out_dtype, with_bias=False)
+        self._dense_op = Matmul(dense, enable_tuning=False)
+        self._decoded_min_m = int(min_m)
+        self._decoded = self._decoded_key = None
+        return self
+
+    def disable_decoded_weight_cache(self):
+        self._decoded_min_m = 0
+        self._decoded = self._decoded_key = self._dense_op = None
+
+    def _decoded_weight(self):
+        cfg = self.bitblas_matmul.config
+        live = [self.qweight] + ([self.scales] if cfg.with_scaling else []) + ([self.zeros] if cfg.with_zeros else [])
+        key = tuple((t.data_ptr(), t._version) for t in live)
+        if self._decoded is None or key != self._decoded_key or self._decoded.device != self.qweight.device:
+            self._decoded = self.bitblas_matmul.dequantize_weight(
+                self.qweight, self.scales if cfg.with_scaling else None, self.zeros if cfg.with_zeros else None,
+                out=self._decoded if self._decoded is not None and self._decoded.device == self.qweight.device else None)
+            self._decoded_key = key
+        return self._decoded
+
     def forward(self, A, output=None):
         mm = self.bitblas_matmul
         A = mm.transform_input(A)
         m = mm.check_activation(A)           # cuda, K columns, A_dtype, and M rows for a static-M operator
+        if self._decoded_min_m and m >= self._decoded_min_m:
+            out = self._dense_op.forward(A, self._decoded_weight(), output=output)
+            if self.bias is not None:
+                out += self.bias             # after the cast to out_dtype, as the TE graph adds it (:462-477)
+            return out
         if not A.is_contiguous():
             A = A.contiguous()   # the kernels read raw row-major memory
         if not self._params_current():
