@@ -47,12 +47,12 @@ def test_decoded_cache_matches_the_packed_members_and_the_oracle(wd, zm, bias):
     assert lin._decoded is not None and tuple(lin._decoded.shape) == (N, K)
     rows = np.arange(0, M, 7)
     assert_fp_parity(cached[rows], want_rows(A, codes, bits, scale, zeros, zm, b, rows), rtol=1e-3, atol_frac=1e-3)
-    assert_fp_parity(cached, packed, rtol=1e-3, atol_frac=1e-3)
+    assert_fp_parity(cached, packed, rtol=2e-3, atol_frac=2e-3)      # two members, each within 1e-3 of the oracle
     # the resident copy IS the TE graph's B_decode: bit-identical to the oracle's
     d = oracle.dequantize_weight(codes, "uint", bits, K=K, scale=scale, zeros=zeros, zeros_mode=zm or "original", group_size=128)
     assert np.array_equal(lin._decoded.cpu().numpy().view(np.uint16), np.asarray(d, dtype=np.float16).view(np.uint16))
     small = lin(Ad[:8]).cpu().numpy()            # below the threshold: the packed path, untouched
-    assert_fp_parity(small, packed[:8], rtol=1e-3, atol_frac=1e-3)
+    assert_fp_parity(small, packed[:8], rtol=2e-3, atol_frac=2e-3)      # M = 8 and M = 300 take different members
 
 
 def test_decoded_cache_follows_in_place_updates():
@@ -69,4 +69,4 @@ def test_decoded_cache_follows_in_place_updates():
     assert_fp_parity(out2.cpu().numpy(), (out1.float() * 2).half().cpu().numpy(), rtol=2e-3, atol_frac=2e-3)
     lin.disable_decoded_weight_cache()
     out3 = lin(A)
-    assert_fp_parity(out3.cpu().numpy(), out2.cpu().numpy(), rtol=1e-3, atol_frac=1e-3)
+    assert_fp_parity(out3.cpu().numpy(), out2.cpu().numpy(), rtol=2e-3, atol_frac=2e-3)
