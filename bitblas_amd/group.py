@@ -111,6 +111,8 @@ def matmul_group(ops: Sequence[Matmul], A: Union[torch.Tensor, Sequence[torch.Te
             out = torch.empty(a.shape[:-1] + (op.N,), dtype=op.torch_output_dtype, device=a.device)
         elif not out.is_contiguous() or out.device != a.device:
             raise ValueError("outputs must be contiguous tensors on A's device")
+        else:
+            op.check_output(out, mi)
         outs[i] = out
         lut = op._ensure_lut(a.device)
         keep.append((a, lut))
@@ -210,6 +212,7 @@ class LinearGroup(torch.nn.Module):
             for i, o in enumerate(outs):
                 if not o.is_contiguous() or o.device != A.device:
                     raise ValueError("outputs must be contiguous tensors on A's device")
+                self.layers[i].bitblas_matmul.check_output(o, m)
                 items[i].A, items[i].C = a_ptr, o.data_ptr()
         for layer in self._nf:
             lut = layer.bitblas_matmul._ensure_lut(A.device)

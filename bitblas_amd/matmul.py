@@ -629,6 +629,12 @@ class Matmul(Operator):
             raise ValueError(f"operator was built for M={self.config.M}, got {m} rows")
         return m
 
+    def check_output(self, output, m: int):
+        """a caller's `output` receives m * N elements of out_dtype through a raw pointer (the reference passes `data_ptr()`
+        on unchecked, ops/operator.py:458-463): a smaller or differently-typed buffer is an out-of-bounds write"""
+        if output.dtype != self.torch_output_dtype or output.numel() != m * self.N:
+            raise ValueError(f"output must hold {m} x {self.N} {self.torch_output_dtype} elements, got {tuple(output.shape)} {output.dtype}")
+
     def forward(self, A, W, scale=None, zeros=None, bias=None, output=None) -> Any:
         """`matmul(A, W, scale, zeros, bias, output)` (:724-753).  Launches on the current stream
         of A's device; returns immediately (asynchronous)."""
@@ -642,6 +648,7 @@ class Matmul(Operator):
             A = A.contiguous()   # the kernels read raw row-major memory (upstream passes data_ptr() unchecked)
         if not output.is_contiguous():
             raise ValueError("output must be a contiguous tensor")
+        self.check_output(output, m)
         lut = self._ensure_lut(A.device)
         stream = _lib.current_stream_handle(A.device)
         self.lib.run(

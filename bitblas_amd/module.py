@@ -228,6 +228,8 @@ class Linear(nn.Module):
                                  dtype=torch_dtype(mm.out_dtype), device=A.device)
         elif not output.is_contiguous() or output.device != A.device:
             raise ValueError("output must be a contiguous tensor on A's device")
+        else:
+            mm.check_output(output, m)
         # upstream rebuilds a ctypes argument list and goes through the positional `lib.call` here
         # (:271-287); same pointers, same order, without the per-call wrapping
         lut = mm._ensure_lut(A.device) if self.source_format == "nf" else None

@@ -35,6 +35,14 @@ def test_forward_checks_shape_dtype_and_static_m():
         lin(torch.zeros(4, 256, dtype=torch.float32, device="cuda"))
     with pytest.raises(ValueError, match="output"):
         lin(ok, output=torch.zeros(128, 4, dtype=torch.float16, device="cuda").t())
+    with pytest.raises(ValueError, match="output must hold"):
+        lin(ok, output=torch.zeros(4, 64, dtype=torch.float16, device="cuda"))        # too small: an out-of-bounds write
+    with pytest.raises(ValueError, match="output must hold"):
+        lin(ok, output=torch.zeros(4, 128, dtype=torch.float32, device="cuda"))       # right shape, wrong element type
+    with pytest.raises(ValueError, match="output must hold"):
+        lin.bitblas_matmul(ok, lin.qweight, lin.scales, lin.zeros, output=torch.zeros(2, 128, dtype=torch.float16, device="cuda"))
+    flat = torch.zeros(4 * 128, dtype=torch.float16, device="cuda")                   # same bytes, another view: fine
+    assert lin(ok, output=flat).data_ptr() == flat.data_ptr()
 
 
 @pytest.mark.gpu
