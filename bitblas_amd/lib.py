@@ -300,7 +300,14 @@ class BoundLib:
             ws = self._ws.get(key)
             if ws is None or ws.numel() < need:
                 import torch
-                ws = self._ws[key] = torch.empty(need, dtype=torch.uint8, device=device if device is not None else "cuda")
+                size = need
+                if ws is not None:
+                    # a dynamic-M operator met a taller batch: the old buffer is RETIRED, not freed - a hipGraph captured
+                    # at the smaller row count still points at it (same rule as the C pool and `shared_workspace`);
+                    # geometric growth bounds what accumulates
+                    _shared_ws_retired.append(ws)
+                    size = max(need, 2 * ws.numel())
+                ws = self._ws[key] = torch.empty(size, dtype=torch.uint8, device=device if device is not None else "cuda")
             return self.run_ws(A, B, lut, scale, zeros, bias, C, m, stream, ws.data_ptr(), need)
         status = self._fn(self._desc_ref, A, B, lut, scale, zeros, bias, C, m, stream)
         if status != OK:

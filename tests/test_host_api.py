@@ -268,3 +268,25 @@ def test_shared_workspace_grows_geometrically_and_keeps_retired_buffers():
     assert c is not b and wlib.shared_workspace(7, "cpu", 1) is b
     wlib._shared_ws.clear()
     del wlib._shared_ws_retired[:]
+
+
+def test_operator_workspace_is_retired_not_freed_when_a_taller_batch_needs_more(monkeypatch):
+    """`BoundLib.run`: the per-(operator, stream) split-K scratch of a dynamic-M operator grows with the row count; the
+    buffer it replaces must stay alive - a hipGraph captured at the smaller row count still holds its address"""
+    from bitblas_amd import lib as wlib
+    del wlib._shared_ws_retired[:]
+    desc = wlib.make_desc(N=256, K=1024, a_dtype=wlib.F16, w_format=wlib.W_UINT, w_bits=4, out_dtype=wlib.F16, group_size=128,
+                          with_scaling=True)
+    b = wlib.BoundLib(desc, has_lut=False, dynamic_m=True)
+    seen = []
+    monkeypatch.setattr(b, "workspace_need", lambda m: {48: 4096, 64: 6000, 32: 1000}[m])
+    monkeypatch.setattr(b, "run_ws", lambda *a: seen.append((a[-2], a[-1])))
+    b.run(1, 2, None, 3, None, None, 4, 48, 0, "cpu")
+    first = b._ws[(0, "cpu")]
+    b.run(1, 2, None, 3, None, None, 4, 32, 0, "cpu")                 # a shorter batch reuses it
+    assert b._ws[(0, "cpu")] is first and seen[1] == (first.data_ptr(), 1000)
+    b.run(1, 2, None, 3, None, None, 4, 64, 0, "cpu")                 # a taller one outgrows it
+    second = b._ws[(0, "cpu")]
+    assert second is not first and second.numel() >= 2 * first.numel()
+    assert wlib._shared_ws_retired == [first] and seen[2] == (second.data_ptr(), 6000)
+    del wlib._shared_ws_retired[:]
