@@ -197,6 +197,43 @@ def time_member_gemm(device, gen, M=4096, N=4096, K=4096, W_dtype="uint4", A_dty
             "GBps_algorithmic": nbytes / t / 1e9, "frac_of_mfma_peak": tf / peak, "mfma_peak": peak}
 
 
+def time_member_f16_gemv(device, gen, N, K, int4_us=None):
+    """The reference's published figure for this path is a SPEED-UP over the vendor library's float16 GEMV (README.md:43-48,
+    images/figures/op_benchmark_a100_wq_gemv_e7.png: W_INT4 A_FP16 M = 1 about 3.9-4.3x cuBLAS on A100).  Same
+    yardstick here: the float16 weight of the same shape through torch.matmul (the vendor library on this box) and through this
+    library's own dense float16 GEMV, hipGraph replays over rotating weights like the quantised members."""
+    try:
+        n_buf = max(4, min(32, (640 << 20) // (N * K * 2)))
+        Ws = [(torch.rand((N, K), device=device, generator=gen) - 0.5).to(torch.float16) for _ in range(n_buf)]
+        A = (torch.rand((1, K), device=device, generator=gen) - 0.5).to(torch.float16)
+        out = torch.empty((1, N), dtype=torch.float16, device=device)
+        op = bitblas.Matmul(bitblas.MatmulConfig(M=1, N=N, K=K, A_dtype="float16", W_dtype="float16", accum_dtype="float16",
+                                                 out_dtype="float16"), enable_tuning=False)
+
+        def launch_own():
+            stream = torch.cuda.current_stream(device).cuda_stream
+            for W in Ws:
+                op.lib.run(A.data_ptr(), W.data_ptr(), None, None, None, None, out.data_ptr(), 1, stream)
+
+        def launch_vendor():
+            for W in Ws:
+                torch.matmul(A, W.t(), out=out)
+
+        t_own = graph_time(device, launch_own, n_buf)
+        t_vendor = graph_time(device, launch_vendor, n_buf)
+        nbytes = N * K * 2 + K * 2 + N * 2
+        res = {"workload": f"float16 x float16 GEMV M=1 N={N} K={K} ({nbytes >> 20} MiB per launch)",
+               "own_us_per_launch": t_own * 1e6, "own_GBps": nbytes / t_own / 1e9, "own_kernel": op.plans[1]["name"],
+               "vendor_us_per_launch": t_vendor * 1e6, "vendor_GBps": nbytes / t_vendor / 1e9, "vendor": "torch.matmul (rocBLAS / hipBLASLt)"}
+        if int4_us:
+            res["int4_speedup_vs_vendor_f16"] = t_vendor * 1e6 / int4_us
+            res["int4_speedup_vs_own_f16"] = t_own * 1e6 / int4_us
+            res["reference_published"] = "W_INT4 A_FP16 GEMV about 3.9-4.3x cuBLAS float16 on A100 (chart, other hardware)"
+        return res
+    except Exception as exc:  # yardstick not available: report, never fake
+        return {"error": f"{type(exc).__name__}: {exc}"}
+
+
 def time_member_resident_decode(device, gen, M=4096, N=4096, K=4096, n_buf=4):
     """`Linear.enable_decoded_weight_cache` (bitblas_amd/module.py): the TE graph's B_decode kept resident in HBM (N*K*2 bytes
     per layer) and the plain dense GEMM run against it - the two-pass member with its first pass hoisted out of the call.
@@ -661,6 +698,9 @@ def main():
             for (N, K) in ((4096, 4096), (11008, 4096), (4096, 11008), (12288, 4096)):     # c2 shapes
                 members[f"gemv_int4_n{N}k{K}"] = time_member_gemv(device, gen, N, K)
                 members[f"gemv_int4_n{N}k{K}_strict"] = time_member_gemv(device, gen, N, K, strict=True)
+            for (N, K) in ((4096, 4096), (11008, 4096)):        # the reference's own yardstick: speed-up over the float16 GEMV
+                members[f"gemv_f16_yardstick_n{N}k{K}"] = time_member_f16_gemv(
+                    device, gen, N, K, int4_us=members[f"gemv_int4_n{N}k{K}"].get("us_per_launch"))
             members["gemm_uint4_m4096"] = time_member_gemm(device, gen, 4096)
             members["gemm_uint4_m4096_tuned"] = time_member_gemm(device, gen, 4096, tuned=True)
             members["gemm_uint4_m4096_resident_decode"] = time_member_resident_decode(device, gen, 4096)
