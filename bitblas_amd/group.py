@@ -62,6 +62,25 @@ def group_plan(ops: Sequence[Matmul], m: int = 1) -> dict:
     return {"launches": launches.value, "plan": plan.as_dict() if launches.value == 1 and n > 1 else None}
 
 
+def _log_group(descs, m):
+    """WQAA_PLAN_LOG (lib._log_plan): a fused group logs its group plan once, an unfused one its members"""
+    key = (tuple(bytes(d) for d in descs), int(m))
+    if key in _lib._plan_logged:
+        return
+    _lib._plan_logged.add(key)
+    lib = _library()
+    n = len(descs)
+    arr = (ctypes.POINTER(_lib.MatmulDesc) * n)(*[ctypes.pointer(d) for d in descs])
+    launches = ctypes.c_int(0)
+    plan = _lib.Plan()
+    if lib.wqaa_group_plan(arr, n, int(m), ctypes.byref(launches), ctypes.byref(plan)) == _lib.OK and launches.value == 1 and n > 1:
+        with open(_lib._PLAN_LOG, "a") as f:
+            f.write(f"{int(m)}\t{plan.as_dict()['name']}\n")
+    else:
+        for d in descs:
+            _lib._log_plan(d, m)
+
+
 def _as_list(x, n, what):
     if isinstance(x, torch.Tensor) or x is None:
         return [x] * n
@@ -133,6 +152,8 @@ def matmul_group(ops: Sequence[Matmul], A: Union[torch.Tensor, Sequence[torch.Te
             it = items[i]
             op.lib.run(it.A, it.B, it.LUT, it.Scale, it.Zeros, it.Bias, it.C, m, stream, dev)
         return outs
+    if _lib._PLAN_LOG:
+        _log_group([op.lib.desc for op in ops], m)
     status = _library().wqaa_matmul_group(items, n, m, stream)
     if status != _lib.OK:
         _lib.check(status)
@@ -225,6 +246,8 @@ class LinearGroup(torch.nn.Module):
                 it = items[i]
                 layer.bitblas_matmul.lib.run(it.A, it.B, it.LUT, it.Scale, it.Zeros, it.Bias, it.C, m, stream, A.device)
             return tuple(outs)
+        if _lib._PLAN_LOG:
+            _log_group([l.bitblas_matmul.lib.desc for l in self.layers], m)
         status = _library().wqaa_matmul_group(items, n, m, stream)
         if status != _lib.OK:
             _lib.check(status)

@@ -93,6 +93,25 @@ class WqaaError(RuntimeError):
 
 
 _lib = None
+
+# WQAA_PLAN_LOG=<file>: every (operator, row count) the Python layer launches appends its plan name once - what a parity run
+# actually exercised (tools/member_coverage.py compares it with what the selector can reach).  Hooked where a row count is
+# first seen (`workspace_need`), so the launch path itself pays nothing when the variable is unset.
+_PLAN_LOG = os.environ.get("WQAA_PLAN_LOG") or None
+_plan_logged = set()
+
+
+def _log_plan(desc, m, tag=""):
+    key = (bytes(desc), int(m), tag)
+    if key in _plan_logged:
+        return
+    _plan_logged.add(key)
+    try:
+        name = select(desc, m)["name"] + tag
+    except WqaaError as exc:
+        name = f"refused({exc})"
+    with open(_PLAN_LOG, "a") as f:
+        f.write(f"{int(m)}\t{name}\n")
 _lib_lock = threading.Lock()
 
 
@@ -331,6 +350,8 @@ class BoundLib:
         need = self._ws_need.get(m)
         if need is None:
             need = self._ws_need[m] = self.workspace_bytes(m)
+            if _PLAN_LOG:
+                _log_plan(self.desc, m)
         return need
 
     def run_timed(self, A, B, lut, scale, zeros, bias, C, m, stream, ev_start, ev_stop):
@@ -341,6 +362,8 @@ class BoundLib:
 
     def run_fused(self, A, B, bias, C, m, stream, row_scale_ptr, tensor_scale):
         """int8 path with the caller's `out / si / sw -> half (+bias)` folded into the epilogue."""
+        if _PLAN_LOG:
+            _log_plan(self.desc, m, "+epi")
         epi = Epilogue()
         epi.struct_size = ctypes.sizeof(Epilogue)
         epi.row_scale = row_scale_ptr
@@ -353,6 +376,8 @@ class BoundLib:
     def run_fused_quant(self, X, B, bias, C, m, stream, tensor_scale):
         """BitNet layer in one launch (m <= 4): X is the float16 input; the kernel applies activation_quant
         itself (WQAA_EPI_QUANTIZE_INPUT) and folds `out / si / sw -> half (+bias)` into its epilogue."""
+        if _PLAN_LOG:
+            _log_plan(self.desc, m, "+epi_quant")
         epi = Epilogue()
         epi.struct_size = ctypes.sizeof(Epilogue)
         epi.flags = EPI_QUANTIZE_INPUT

@@ -1,0 +1,85 @@
+#!/usr/bin/env python
+"""tools/member_coverage.py [plan.log ...]: which kernel members did a parity run exercise?
+
+    WQAA_PLAN_LOG=gpurun_out/plan.log python -m pytest tests -m gpu -q        # on the GPU box
+    python tools/member_coverage.py gpurun_out/plan.log                       # anywhere
+
+`WQAA_PLAN_LOG` makes the Python layer append the plan name of every (operator, row count) it launches (bitblas_amd/lib.py).
+A plan name minus its shape - `f16xu4_tcx64x128x128xrxw`, `i8xi2_gemv_b1r1d2_areg`, `f16xi4_gemvx_b1r2d2k1_x3` - names a member
+CLASS: activation x weight types, family, tile / variant suffix.  This tool prints the classes in the log and, from a
+device-less sweep of the selector over the operator's configuration space (dtype pairs x zero modes x layouts x row counts x
+shapes that hit every rule of the selectors), the classes the selector can reach that the log does not contain.  Without a
+log it prints the reachable set only."""
+import itertools
+import os
+import re
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bitblas_amd as bitblas  # noqa: E402
+
+
+def member_class(name: str) -> str:
+    m = re.match(r"^matmul_m\d+n\d+k\d+_(.*)$", name)
+    cls = m.group(1) if m else name
+    return re.sub(r"_x\d+$", "_xG", cls)            # group launches: one class whatever the member count
+
+
+def reachable():
+    f16 = [("float16", w) for w in ("uint4", "int4", "uint2", "int2", "uint1", "int1", "uint8", "int8", "nf4", "fp4_e2m1", "e4m3_float8", "float16")]
+    bf16 = [("bfloat16", w) for w in ("uint4", "int4", "uint2", "uint1", "int8", "nf4", "fp4_e2m1", "e4m3_float8", "bfloat16")]
+    i8 = [("int8", w) for w in ("int8", "int4", "uint4", "int2", "uint2", "int1")]
+    f8 = [("e4m3_float8", "e4m3_float8"), ("e5m2_float8", "e5m2_float8")]
+    i4 = [("int4", "int4"), ("int4", "int2")]
+    shapes = [(1024, 1024), (4096, 4096), (11008, 4096), (4096, 11008), (1024, 28672), (28672, 8192), (272, 2048), (5120, 4096), (2048, 8192)]
+    ms = [1, 2, 3, 8, 16, 32, 64, 128, 256, 1024, 4096]
+    seen = {}
+    for (a, w) in f16 + bf16 + i8 + f8 + i4:
+        quant = a in ("float16", "bfloat16") and w not in (a, "fp4_e2m1")
+        modes = [dict()]
+        if quant:
+            modes.append(dict(with_scaling=True, group_size=128))
+            if w.startswith("uint") and w != "uint8":
+                modes += [dict(with_scaling=True, group_size=128, with_zeros=True, zeros_mode=z) for z in ("original", "rescale", "quantized")]
+        fds = [None, False] if (w[0] in "ui" and w not in ("uint8", "int8") and a in ("float16", "int8")) else [None]
+        for (N, K), mode, fd, strict in itertools.product(shapes, modes, fds, (True, False)):
+            if not strict and not (a == "float16" and w[0] in "ui" and w not in ("uint8", "int8")):
+                continue
+            out = "int32" if a in ("int8", "int4") else ("bfloat16" if a == "bfloat16" else "float16")
+            acc = "int32" if a in ("int8", "int4") else "float32"
+            try:
+                op = bitblas.Matmul(bitblas.MatmulConfig(M=ms, N=N, K=K, A_dtype=a, W_dtype=w, out_dtype=out, accum_dtype=acc,
+                                                         fast_decoding=fd, **mode), enable_tuning=False, strict_reference=strict)
+            except Exception:  # noqa: BLE001 - a refused configuration reaches no member
+                continue
+            for m in ms:
+                seen.setdefault(member_class(op.plans[m]["name"]), f"M={m} N={N} K={K} {a} x {w} {mode} fd={fd} strict={strict}")
+    return seen
+
+
+def main():
+    logs = [a for a in sys.argv[1:] if os.path.exists(a)]
+    reach = reachable()
+    print(f"{len(reach)} member classes reachable by the selector over the sweep (no device: own members for the plain dense pairs)")
+    if not logs:
+        for c in sorted(reach):
+            print("  ", c)
+        return
+    hit = {}
+    for path in logs:
+        for line in open(path):
+            parts = line.rstrip("\n").split("\t")
+            if len(parts) == 2:
+                hit[member_class(parts[1].split("+")[0])] = hit.get(member_class(parts[1].split("+")[0]), 0) + 1
+    print(f"{len(hit)} member classes in the log(s) ({sum(hit.values())} (operator, row count) pairs)")
+    missing = sorted(c for c in reach if c not in hit)
+    print(f"{len(missing)} reachable classes NOT exercised by the logged run:")
+    for c in missing:
+        print(f"   {c:44s} e.g. {reach[c]}")
+    extra = sorted(c for c in hit if c not in reach)
+    print(f"{len(extra)} logged classes outside the sweep (vendor-library members, forced variants): " + ", ".join(extra[:40]))
+
+
+if __name__ == "__main__":
+    main()

@@ -5,7 +5,9 @@
 # 2. A/B of the selector rule WQAA_GEMV_DIRECT_FIT=1 (spilling register-resident members)     -> gpurun_out/r03_ab_direct_fit.txt
 # 3. A/B of the grid cap of the SGPR-bound two-row exact-product members (3 vs 4 resident workgroups per CU)
 #                                                                                              -> gpurun_out/r03_ab_gemvx_grid.txt
-# 4. bench.py (carries members.gemm_uint4_m4096_resident_decode)                              -> gpurun_out/r03_bench.json
+# 4. bench.py (carries members.gemm_uint4_m4096_resident_decode, gemv_f16_yardstick_*)        -> gpurun_out/r03_bench.json
+# 5. (R03_COVERAGE=1) the whole parity suite with WQAA_PLAN_LOG: which member classes it exercises
+#                                                                                              -> gpurun_out/r03_member_coverage.txt
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out
 mkdir -p $out
@@ -25,3 +27,10 @@ print("headline", d["value"], d["roofline"]["frac"])
 for k in ("gemm_uint4_m4096", "gemm_uint4_m4096_tuned", "gemm_uint4_m4096_resident_decode"):
     print(k, {x: d["members"][k].get(x) for x in ("us_per_launch", "TFLOPs", "kernel", "error")})
 PY
+if [ -n "$R03_COVERAGE" ]; then
+  rm -f $out/r03_plan.log
+  WQAA_PLAN_LOG=$out/r03_plan.log timeout 1500 python -m pytest tests -m gpu -q -x > $out/r03_suite.log 2>&1
+  tail -3 $out/r03_suite.log
+  python tools/member_coverage.py $out/r03_plan.log > $out/r03_member_coverage.txt 2>&1
+  head -60 $out/r03_member_coverage.txt
+fi
