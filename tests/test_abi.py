@@ -130,6 +130,33 @@ def test_relayout_and_threaded_packer(monkeypatch):
     monkeypatch.delenv("WQAA_PACK_THREADS")
 
 
+def test_packer_fuzz_ragged_rows_and_tails():
+    """random (rows, cols) incl. rows that are not a whole number of 32-bit words (the byte-at-a-time tail), every bit width,
+    both layouts and interleave targets, against the oracle's restatement of general_compress / interleave_weight"""
+    import wqaa_oracle as oracle
+    rng = np.random.default_rng(0)
+    for bits in (1, 2, 4):
+        epb = 8 // bits
+        for _ in range(60):
+            rows, cols = int(rng.integers(1, 9)), int(rng.integers(1, 40)) * epb
+            codes = rng.integers(0, 1 << bits, size=(rows, cols), dtype=np.int8)
+            plain = wlib.pack_weight(codes, bits, wlib.LAYOUT_PLAIN, wlib.F16)
+            assert np.array_equal(plain, oracle.general_compress(codes, bits)), (bits, rows, cols)
+            assert np.array_equal(wlib.unpack_weight(plain, cols, bits, wlib.LAYOUT_PLAIN, wlib.F16), codes)
+            if (cols * bits // 8) % 4 == 0:
+                for code, tgt in ((wlib.F16, "float16"), (wlib.I8, "int8")):
+                    lop3 = wlib.pack_weight(codes, bits, wlib.LAYOUT_LOP3, code)
+                    assert np.array_equal(lop3, oracle.interleave_weight(plain, bits, tgt)), (bits, rows, cols, tgt)
+                    assert np.array_equal(wlib.unpack_weight(lop3, cols, bits, wlib.LAYOUT_LOP3, code), codes)
+                    assert np.array_equal(wlib.relayout_weight(plain, bits, wlib.LAYOUT_PLAIN, wlib.LAYOUT_LOP3, code), lop3)
+            else:
+                with pytest.raises(wlib.WqaaError):
+                    wlib.pack_weight(codes, bits, wlib.LAYOUT_LOP3, wlib.F16)
+    c8 = rng.integers(-128, 128, size=(3, 16), dtype=np.int8)
+    assert np.array_equal(wlib.pack_weight(c8, 8, wlib.LAYOUT_PLAIN, wlib.F16), c8)
+    assert wlib.pack_weight(np.zeros((0, 64), dtype=np.int8), 4, wlib.LAYOUT_PLAIN, wlib.F16).shape == (0, 32)
+
+
 def test_selector_invariants_over_a_random_configuration_sweep():
     """Host logic only (wqaa_select needs no GPU): whatever the selector answers must be launchable - workgroup
     size a multiple of 64 and <= 1024, LDS within the 160 KB of a CU, non-empty grid, a name in the reference's
