@@ -686,40 +686,58 @@ def main():
         }
         if not args.no_members and world == 1:
             members = {}
-            if not args.no_groups:
+
+            def member(name, fn, *a, **k):
+                """one member = one try: a member that cannot run (or a capture that fails) is reported under its name and
+                the JSON line still comes out with everything else"""
+                try:
+                    members[name] = fn(*a, **k)
+                except Exception as exc:  # noqa: BLE001
+                    members[name] = {"error": f"{type(exc).__name__}: {exc}"}
+                    try:
+                        torch.cuda.synchronize(device)
+                    except Exception:  # noqa: BLE001
+                        pass
+
+            def step_ungrouped():
                 # the same step with every GEMV as its own launch (7 per layer): what the grouping buys
                 flat = [[i] for i in range(len(LLAMA2_7B_LINEARS))]
                 t_step = graph_time(device, lambda: launch_layers(0, flat), 1)
-                members["step_ungrouped"] = {
-                    "workload": "the headline step, 7 launches per layer", "us_per_step": t_step * 1e6,
-                    "GBps": step_bytes / t_step / 1e9, "frac_of_hbm_peak": step_bytes / t_step / 1e9 / HBM_PEAK_GBS,
-                    "roofline": {"bound": "hbm", "achieved": step_bytes / t_step / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                 "frac": step_bytes / t_step / 1e9 / HBM_PEAK_GBS}}
+                return {"workload": "the headline step, 7 launches per layer", "us_per_step": t_step * 1e6,
+                        "GBps": step_bytes / t_step / 1e9, "frac_of_hbm_peak": step_bytes / t_step / 1e9 / HBM_PEAK_GBS,
+                        "roofline": {"bound": "hbm", "achieved": step_bytes / t_step / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                     "frac": step_bytes / t_step / 1e9 / HBM_PEAK_GBS}}
+
+            if not args.no_groups:
+                member("step_ungrouped", step_ungrouped)
             for (N, K) in ((4096, 4096), (11008, 4096), (4096, 11008), (12288, 4096)):     # c2 shapes (SURVEY.md 8(d))
-                members[f"gemv_int4_n{N}k{K}"] = time_member_gemv(device, gen, N, K)
-                members[f"gemv_int4_n{N}k{K}_strict"] = time_member_gemv(device, gen, N, K, strict=True)
+                member(f"gemv_int4_n{N}k{K}", time_member_gemv, device, gen, N, K)
+                member(f"gemv_int4_n{N}k{K}_strict", time_member_gemv, device, gen, N, K, strict=True)
             for (N, K) in ((4096, 4096), (11008, 4096)):        # the reference's own yardstick: speed-up over the float16 GEMV
-                members[f"gemv_f16_yardstick_n{N}k{K}"] = time_member_f16_gemv(
-                    device, gen, N, K, int4_us=members[f"gemv_int4_n{N}k{K}"].get("us_per_launch"))
-            members["gemm_uint4_m4096"] = time_member_gemm(device, gen, 4096)
-            members["gemm_uint4_m4096_tuned"] = time_member_gemm(device, gen, 4096, tuned=True)
-            members["gemm_uint4_m4096_resident_decode"] = time_member_resident_decode(device, gen, 4096)
-            members["gemm_uint4_m128"] = time_member_gemm(device, gen, 128)
-            members["gemm_uint4_m16"] = time_member_gemm(device, gen, 16)
-            members["gemm_int2_int8_m4096"] = time_member_gemm(device, gen, 4096, W_dtype="int2", A_dtype="int8")
-            members["gemm_int2_int8_m4096_tuned"] = time_member_gemm(device, gen, 4096, W_dtype="int2", A_dtype="int8", tuned=True)
-            members["gemv_int2_int8_m1"] = time_member_dense(device, gen, 1, 4096, 4096, kind="int2", n_buf=64)
+                member(f"gemv_f16_yardstick_n{N}k{K}", time_member_f16_gemv, device, gen, N, K,
+                       int4_us=(members.get(f"gemv_int4_n{N}k{K}") or {}).get("us_per_launch"))
+            member("gemm_uint4_m4096", time_member_gemm, device, gen, 4096)
+            member("gemm_uint4_m4096_tuned", time_member_gemm, device, gen, 4096, tuned=True)
+            member("gemm_uint4_m4096_resident_decode", time_member_resident_decode, device, gen, 4096)
+            member("gemm_uint4_m128", time_member_gemm, device, gen, 128)
+            member("gemm_uint4_m16", time_member_gemm, device, gen, 16)
+            member("gemm_int2_int8_m4096", time_member_gemm, device, gen, 4096, W_dtype="int2", A_dtype="int8")
+            member("gemm_int2_int8_m4096_tuned", time_member_gemm, device, gen, 4096, W_dtype="int2", A_dtype="int8", tuned=True)
+            member("gemv_int2_int8_m1", time_member_dense, device, gen, 1, 4096, 4096, kind="int2", n_buf=64)
             # c5: dense e4m3 x e4m3 on every Llama-3-70B linear of one (unsharded) GPU, M = 4096 and M = 1
             # (plain dense pairs: the vendor library by default, this library's own MFMA member under `_own`)
             for (name, N, K, nb) in (("o", 8192, 8192, 4), ("down", 8192, 28672, 2), ("qkv", 10240, 8192, 4), ("gate", 28672, 8192, 2)):
-                members[f"gemm_fp8_m4096_{name}_n{N}_k{K}"] = time_member_dense(device, gen, 4096, N, K, n_buf=nb)
-                members[f"gemm_fp8_m4096_{name}_n{N}_k{K}_tuned"] = time_member_dense(device, gen, 4096, N, K, n_buf=nb, tuned=True)
-                members[f"gemm_fp8_m4096_{name}_n{N}_k{K}_own"] = time_member_dense(device, gen, 4096, N, K, n_buf=nb, own=True)
+                member(f"gemm_fp8_m4096_{name}_n{N}_k{K}", time_member_dense, device, gen, 4096, N, K, n_buf=nb)
+                member(f"gemm_fp8_m4096_{name}_n{N}_k{K}_tuned", time_member_dense, device, gen, 4096, N, K, n_buf=nb, tuned=True)
+                member(f"gemm_fp8_m4096_{name}_n{N}_k{K}_own", time_member_dense, device, gen, 4096, N, K, n_buf=nb, own=True)
             for (name, N, K) in (("o", 8192, 8192), ("down", 8192, 28672)):
-                members[f"gemv_fp8_m1_{name}_n{N}_k{K}"] = time_member_dense(device, gen, 1, N, K, n_buf=max(3, (640 << 20) // (N * K)))
+                member(f"gemv_fp8_m1_{name}_n{N}_k{K}", time_member_dense, device, gen, 1, N, K, n_buf=max(3, (640 << 20) // (N * K)))
             result["members"] = members
         if not args.no_cpu_baseline and world == 1:
-            result["cpu_baseline"] = cpu_baseline()
+            try:
+                result["cpu_baseline"] = cpu_baseline()
+            except Exception as exc:  # noqa: BLE001 - the line must come out
+                result["cpu_baseline"] = {"error": f"{type(exc).__name__}: {exc}"}
     if dist_on and not args.no_members:
         c5 = time_c5_sharded(device, gen, world, rank)          # every rank takes part; rank 0 reports
         if rank == 0:
