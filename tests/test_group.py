@@ -106,3 +106,38 @@ def test_group_entry_argument_checks():
         it.desc = ctypes.pointer(d)
     assert L.wqaa_matmul_group(items, 2, 1, None) == wlib.ERR_BAD_DESC  # null operands, refused before any launch
     assert b"member 0" in L.wqaa_last_error_string()
+
+
+def test_matmul_group_validates_before_it_launches(monkeypatch):
+    """`matmul_group` on CPU tensors with the two device-touching calls replaced: a valid call reaches the C entry with every
+    member's own pointers; wrong row counts, short or mistyped outputs and short weights are refused before it"""
+    import torch
+    ops = [bitblas.Matmul(bitblas.MatmulConfig(M=1, N=n, K=256, A_dtype="float16", W_dtype="int4", group_size=128, with_scaling=True),
+                          enable_tuning=False, strict_reference=False) for n in (128, 64)]
+    for op in ops:
+        monkeypatch.setattr(op, "check_activation", lambda A: A.numel() // A.shape[-1], raising=False)
+    monkeypatch.setattr(wgroup._lib, "current_stream_handle", lambda dev: 0)
+    seen = []
+
+    class FakeLib:
+        def wqaa_matmul_group(self, items, n, m, stream):
+            seen.append([(items[i].A, items[i].B, items[i].Scale, items[i].C, items[i].desc.contents.N) for i in range(n)] + [m])
+            return wlib.OK
+    monkeypatch.setattr(wgroup, "_library", lambda: FakeLib())
+    A = torch.zeros(1, 256, dtype=torch.float16)
+    Ws = [(torch.zeros(n, 128, dtype=torch.int8), torch.zeros(n, 2, dtype=torch.float16)) for n in (128, 64)]
+    outs = bitblas.matmul_group(ops, A, Ws)
+    assert [tuple(o.shape) for o in outs] == [(1, 128), (1, 64)] and len(seen) == 1 and seen[0][-1] == 1
+    for (a, b, s, c, n), (W, sc), o in zip(seen[0][:-1], Ws, outs):
+        assert (a, b, s, c) == (A.data_ptr(), W.data_ptr(), sc.data_ptr(), o.data_ptr()) and n == o.shape[1]
+    mine = [torch.empty(1, 128, dtype=torch.float16), torch.empty(64, dtype=torch.float16)]      # any contiguous view of m x N
+    assert bitblas.matmul_group(ops, A, Ws, outputs=mine)[1] is mine[1]
+    with pytest.raises(ValueError, match="output must hold"):
+        bitblas.matmul_group(ops, A, Ws, outputs=[torch.empty(1, 128, dtype=torch.float16), torch.empty(1, 32, dtype=torch.float16)])
+    with pytest.raises(ValueError, match="output must hold"):
+        bitblas.matmul_group(ops, A, Ws, outputs=[torch.empty(1, 128, dtype=torch.float32), torch.empty(1, 64, dtype=torch.float16)])
+    with pytest.raises(ValueError, match="W holds"):
+        bitblas.matmul_group(ops, A, [(Ws[0][0][:64], Ws[0][1]), Ws[1]])
+    with pytest.raises(ValueError, match="weights"):
+        bitblas.matmul_group(ops, A, Ws[:1])
+    assert len(seen) == 2                                                                     # none of the refused calls launched
