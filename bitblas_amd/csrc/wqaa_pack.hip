@@ -45,7 +45,12 @@ void for_rows(int64_t rows, int64_t fields_per_row, F body) {
   const int64_t per = (rows + nt - 1) / nt;
   for (int t = 1; t < nt; ++t) {
     const int64_t r0 = t * per, r1 = std::min(rows, r0 + per);
-    if (r0 < r1) pool.emplace_back([=] { body(r0, r1); });
+    if (r0 >= r1) continue;
+    try {
+      pool.emplace_back([=] { body(r0, r1); });
+    } catch (...) {          // no thread to be had (pids limit of a container): this share runs here - never an exception across the C ABI
+      body(r0, r1);
+    }
   }
   body(int64_t(0), std::min(rows, per));
   for (auto& th : pool) th.join();
