@@ -641,14 +641,15 @@ class Matmul(Operator):
         m = self.check_activation(A)
         if output is None:
             output = torch.empty(A.shape[:-1] + (self.N,), dtype=self.torch_output_dtype, device=A.device)
+        elif not output.is_contiguous():
+            raise ValueError("output must be a contiguous tensor")
+        else:
+            self.check_output(output, m)
         if W.numel() * W.element_size() != self._w_bytes:
             raise ValueError(f"W holds {W.numel() * W.element_size()} bytes, the operator expects {self._w_bytes} "
                              f"(shape {self.retrieve_weight_shape()}: run transform_weight first)")
         if not A.is_contiguous():
             A = A.contiguous()   # the kernels read raw row-major memory (upstream passes data_ptr() unchecked)
-        if not output.is_contiguous():
-            raise ValueError("output must be a contiguous tensor")
-        self.check_output(output, m)
         lut = self._ensure_lut(A.device)
         stream = _lib.current_stream_handle(A.device)
         self.lib.run(
