@@ -248,3 +248,55 @@ class ColumnParallelGroup:
         return outs
 
     __call__ = forward
+
+
+class ColumnParallelLinear(torch.nn.Module):
+    """`bitblas.Linear` column-sharded over the ranks: rank p owns output features `[p N/P, (p+1) N/P)` as an ordinary
+    `Linear(in_features, out_features / P)` (same buffers, same kernels) and `forward` all-gathers the `[..., N/P]` slices
+    (`gather_output=False` returns the local slice, for a row-parallel consumer).
+
+    `load_full_state_dict` takes the state_dict of the UNSHARDED layer - the reference's checkpoint layout: `qweight`
+    `(N, K*bits/8)`, `scales` / `zeros` `(N, K/g)` or packed `zeros` `(K/g, N*bits/8)`, `bias` `(N,)`
+    (bitblas/module/__init__.py:164-205) - and keeps this rank's rows of each: a checkpoint written by upstream BitBLAS
+    (or by `Linear.repack_from_gptq`) loads on any world size without re-quantisation.  The reference has no multi-GPU
+    code; sharding rule = `shard_operands`."""
+
+    def __init__(self, in_features: int, out_features: int, group=None, gather_output: bool = True, **linear_kwargs):
+        super().__init__()
+        from .module import Linear
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.in_features, self.out_features = in_features, out_features
+        self.gather_output = gather_output
+        w_dtype = linear_kwargs.get("W_dtype", "float16")
+        self.bits = Matmul.BITBLAS_TRICK_DTYPE_MAP[w_dtype][1]
+        self.quantized_zeros = bool(linear_kwargs.get("with_zeros")) and linear_kwargs.get("zeros_mode") == "quantized"
+        self.lo, self.hi = shard_bounds(out_features, self.rank, self.world, self.bits, self.quantized_zeros)
+        self.local = Linear(in_features, out_features // self.world, **linear_kwargs)
+
+    def shard_state_dict(self, full: dict) -> dict:
+        """this rank's slice of an unsharded `Linear.state_dict()` (keys without a prefix)"""
+        lo, hi, bits = self.lo, self.hi, self.bits
+        out = {}
+        for key, t in full.items():
+            if key == "zeros" and self.quantized_zeros:
+                if t.shape[-1] * 8 != self.out_features * bits:
+                    raise ValueError(f"zeros: packed width {t.shape[-1]} does not hold {self.out_features} {bits}-bit zero points")
+                out[key] = t[:, lo * bits // 8: hi * bits // 8].contiguous()
+            elif key in ("qweight", "weight", "scales", "zeros", "bias"):
+                if t.shape[0] != self.out_features:
+                    raise ValueError(f"{key}: {t.shape[0]} rows, the unsharded layer has {self.out_features}")
+                out[key] = t[lo:hi].contiguous()
+            else:
+                raise KeyError(f"unexpected key {key!r} in a Linear state_dict")
+        return out
+
+    def load_full_state_dict(self, full: dict, strict: bool = True):
+        return self.local.load_state_dict(self.shard_state_dict(full), strict=strict)
+
+    def forward(self, A, out: Optional[torch.Tensor] = None):
+        local = self.local(A)
+        if not self.gather_output:
+            return local
+        return gather_columns(local, self.group, out=out)

@@ -199,3 +199,83 @@ def test_shard_bounds_validation():
         shard_bounds(100, 0, 8)
     with pytest.raises(ValueError):
         shard_bounds(8 * 24, 0, 8)          # 24 rows per rank: not a multiple of 16
+
+
+def _worker_linear(rank, world, port, zeros_mode, ret):
+    """ColumnParallelLinear: an unsharded `Linear` state_dict (the reference's checkpoint layout) loaded on two ranks, each
+    keeping its rows; forward = local layer (oracle in place of the launch) + all-gather == the unsharded oracle"""
+    for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import wqaa_oracle as oracle
+        import bitblas_amd as bitblas
+        from bitblas_amd import lib as wlib
+        from bitblas_amd.parallel import ColumnParallelLinear
+        rng = np.random.default_rng(3)
+        N, K, g, bit = 128, 256, 64, 4
+        kw = dict(bias=True, A_dtype="float16", W_dtype="uint4", group_size=g, with_scaling=True, with_zeros=True,
+                  zeros_mode=zeros_mode, opt_M=[1, 16], enable_tuning=False)
+        full = bitblas.Linear(K, N, **kw)
+        codes = rng.integers(0, 16, size=(N, K)).astype(np.int8)
+        scale = rng.random((N, K // g), dtype=np.float32).astype(np.float16)
+        bias = rng.random((N,), dtype=np.float32).astype(np.float16)
+        if zeros_mode == "quantized":
+            zeros = oracle.general_compress(rng.integers(6, 10, size=(K // g, N)).astype(np.int8), bit)
+        else:
+            zeros = (8 + rng.integers(-1, 2, size=(N, K // g))).astype(np.float16)
+        full.load_and_transform_weight(torch.from_numpy(codes), scales=torch.from_numpy(scale), zeros=torch.from_numpy(zeros),
+                                       bias=torch.from_numpy(bias))
+        sd = full.state_dict()
+        layer = ColumnParallelLinear(K, N, **kw)
+        layer.load_full_state_dict(sd)
+        lo, hi = layer.lo, layer.hi
+        ok = (lo, hi) == (rank * N // world, (rank + 1) * N // world)
+        ok = ok and torch.equal(layer.local.qweight, sd["qweight"][lo:hi]) and torch.equal(layer.local.scales, sd["scales"][lo:hi])
+        ok = ok and torch.equal(layer.local.bias, sd["bias"][lo:hi])
+        if zeros_mode == "quantized":
+            ok = ok and torch.equal(layer.local.zeros, sd["zeros"][:, lo * bit // 8: hi * bit // 8])
+        else:
+            ok = ok and torch.equal(layer.local.zeros, sd["zeros"][lo:hi])
+        layout = wlib.LAYOUT_LOP3 if layer.local.bitblas_matmul.config.fast_decoding else wlib.LAYOUT_PLAIN
+
+        def local_forward(A_t, output=None):          # the launch, replaced by the oracle on THIS rank's buffers
+            c = wlib.unpack_weight(layer.local.qweight.numpy(), K, bit, layout, wlib.F16)
+            return torch.from_numpy(oracle.matmul_dequant(A_t.numpy(), c, source_format="uint", bit=bit, scale=layer.local.scales.numpy(),
+                                                          zeros=layer.local.zeros.numpy(), zeros_mode=zeros_mode, group_size=g,
+                                                          bias=layer.local.bias.numpy()))
+        layer.local.forward = local_forward
+        for M in (1, 5):
+            A = (rng.random((M, K), dtype=np.float32) - 0.5).astype(np.float16)
+            want = oracle.matmul_dequant(A, codes, source_format="uint", bit=bit, scale=scale, zeros=zeros, zeros_mode=zeros_mode,
+                                         group_size=g, bias=bias)
+            got = layer(torch.from_numpy(A))
+            ok = ok and got.shape == (M, N) and bool(np.array_equal(got.numpy(), want))
+        layer.gather_output = False
+        ok = ok and layer(torch.from_numpy(A)).shape == (5, N // world)
+        try:
+            layer.shard_state_dict({"qweight": sd["qweight"][:64]})
+            ok = False
+        except ValueError:
+            pass
+        ret[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("zeros_mode", ["original", "quantized"])
+def test_column_parallel_linear_loads_an_unsharded_checkpoint(zeros_mode):
+    world = 2
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_linear, args=(r, world, port, zeros_mode, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=180)
+        assert p.exitcode == 0
+    assert all(ret.get(r) for r in range(world)), dict(ret)
