@@ -50,6 +50,18 @@ class BitLinear(nn.Module):
             self.bias = bias.to(torch.float16).to(self.qweight.device)
         self._sw_host = float(self.sw)
 
+    @classmethod
+    def from_bit_linear(cls, bitlinear, weight_group: int = 1, opt_M=None):
+        """`BitLinearBitBLAS.from_bit_linear` (utils_quant.py:103-114): a float `BitLinear` / `nn.Linear` -> this layer, ternary
+        weights packed in the reference layout.  `weight_group` > 1 is how upstream gives the q / k / v blocks of a
+        concatenated weight their own `sw` (:116-138); here the projections stay separate layers with a scalar `sw` each and
+        share a launch through `BitLinearGroup`, so only 1 is accepted."""
+        if weight_group != 1:
+            raise NotImplementedError("weight_group > 1: keep q / k / v as separate layers and wrap them in BitLinearGroup")
+        layer = cls(bitlinear.in_features, bitlinear.out_features, bias=bitlinear.bias is not None, opt_M=opt_M)
+        layer.load_float_weight(bitlinear.weight.data, None if bitlinear.bias is None else bitlinear.bias.data)
+        return layer
+
     def activation_quant(self, x: torch.Tensor):
         """utils_quant.py:157-164 on the GPU: one HIP launch."""
         x = x.contiguous()

@@ -141,8 +141,9 @@ def test_reference_bitnet_caller_runs_unmodified_on_the_alias(bitblas_alias, tmp
         assert again.bitblas_matmul is ref_layer.bitblas_matmul
         assert "found in global_operator_cache" in capsys.readouterr().out
         assert tuple(ref_layer.qweight.shape) == (N, K // 4) and ref_layer.qweight.dtype == torch.int8
-        mine = BitLinear(K, N)
-        mine.load_float_weight(fp.weight.data)
+        mine = BitLinear.from_bit_linear(fp)
+        with pytest.raises(NotImplementedError):
+            BitLinear.from_bit_linear(fp, weight_group=3)
         assert np.array_equal(ref_layer.qweight.numpy(), mine.qweight.numpy())
         assert torch.allclose(ref_layer.sw.float().reshape(-1)[0], mine.sw.reshape(-1)[0], rtol=0, atol=0)
     finally:
