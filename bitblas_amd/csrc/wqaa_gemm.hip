@@ -72,12 +72,12 @@ static gemm_fn pick_gemm(int kind, int layout, int at, int mode, int flags, int 
 struct GemmChoice {
   gemm_fn fn;
   int kind, layout, at, mode, flags, bits;
-  int mf, ks, kl, nwaves, bn, ksplit, skinny, decode, wide;
+  int mf, ks, kl, nwaves, bn, ksplit, skinny, decode, wide, pp, pp_shift;
   int tiles_m, tiles_n, lds;
   int fp4_table;
 };
 
-static int gemm_choose(const wqaa_matmul_desc& d, int m, GemmChoice* c) {
+static int gemm_choose(const wqaa_matmul_desc& d, int m, GemmChoice* c, bool fused_epilogue = false) {
   const int a = d.a_dtype;
   c->fp4_table = 0;
   c->flags = 0;
@@ -163,6 +163,38 @@ static int gemm_choose(const wqaa_matmul_desc& d, int m, GemmChoice* c) {
           : m > 128 ? 8 : m > 32 ? 4 : m > 16 ? 2 : 1;
   if (const char* f = getenv("WQAA_GEMM_MF")) c->mf = atoi(f);   // tuning aid
   const int nsteps = d.K / c->ks;
+  // the 256 x 256 tile runs the ping-pong member (wqaa_gemm_pp_kernel.h) where one exists: 4-bit weights x float16 and 2-bit
+  // weights x int8, four k-tiles (256 / 512 k) per trip, groups of 128 * 2^i (Scale / Zeros rows 4-byte aligned: K / g even),
+  // float16 / int32 output through LDS (N a multiple of 8), 32-bit buffer offsets.  WQAA_GEMM_PP=0: the lockstep member.
+  c->pp = 0;
+  c->pp_shift = 0;
+  if (c->mf == 16) {
+    const char* pf = getenv("WQAA_GEMM_PP");
+    const int kb = c->at == AT_F16 ? 256 : 512;
+    const int gb = g / (kb / 2);                                       // k-bodies (two k-tiles) per group
+    const bool meta_ok = c->mode == MD_NONE || (g % (kb / 2) == 0 && ilog2_exact(gb) >= 0 && ((d.K / g) & 1) == 0 && (long)d.N * (d.K / g) >= 8);
+    const bool out_ok = c->at == AT_F16 ? d.out_dtype == WQAA_F16 : d.out_dtype == WQAA_I32;
+    const long a_bytes = (long)m * d.K * (c->at == AT_F16 ? 2 : 1), w_bytes = (long)d.N * d.K * c->bits / 8;
+    int lds = 0;
+    gemm_fn fn = (!pf || atoi(pf) != 0) ? pick_gemm_pp(c->kind, c->layout, c->at, c->mode, c->flags, &lds) : nullptr;
+    if (fn && !fused_epilogue && d.K % kb == 0 && meta_ok && out_ok && d.N % 8 == 0 && a_bytes + 256L * d.K * 2 < (1L << 31) && w_bytes < (1L << 31) &&
+        d.k_split_hint <= 1 && getenv("WQAA_GEMM_KSPLIT") == nullptr) {
+      c->pp = 1;
+      c->pp_shift = c->mode == MD_NONE ? 0 : ilog2_exact(gb);
+      c->fn = fn;
+      c->nwaves = 8;
+      c->bn = 256;
+      c->skinny = 0;
+      c->decode = 0;
+      c->wide = 0;
+      c->ks = c->at == AT_F16 ? 64 : 128;
+      c->tiles_m = (m + 255) / 256;
+      c->tiles_n = (d.N + 255) / 256;
+      c->lds = lds;
+      c->ksplit = 1;
+      return WQAA_OK;
+    }
+  }
   // small decode batches: one launch with K split across the 8 waves of a workgroup, no partial sums
   // in memory (WQAA_GEMM_DECODE=0: back to the split-K skinny member + reduce launch).  Every
   // workgroup reads all M activation rows, so it pays only while M and the number of 16-row weight
@@ -276,7 +308,7 @@ int gemm_plan(const wqaa_matmul_desc& d, int m, wqaa_plan* plan) {
     char wd[24];
     short_wdtype(d, wd, sizeof(wd));
     snprintf(plan->name, sizeof(plan->name), "matmul_m%dn%dk%d_%sx%s_tcx%dx%dx%d%s%s", m, d.N, d.K, short_dtype(d.a_dtype),
-             wd, 16 * c.mf, c.bn, c.ks, c.ksplit > 1 ? "xr" : "", c.skinny ? "xs" : c.decode == 2 ? "xdl" : c.decode ? "xd" : c.wide ? "xw" : "");
+             wd, 16 * c.mf, c.bn, c.ks, c.ksplit > 1 ? "xr" : "", c.pp ? "pp" : c.skinny ? "xs" : c.decode == 2 ? "xdl" : c.decode ? "xd" : c.wide ? "xw" : "");
   }
   return WQAA_OK;
 }
@@ -293,12 +325,13 @@ int gemm_launch(const wqaa_matmul_desc& d, const void* A, const void* B, const v
   GemmChoice c;
   {
     static thread_local ChoiceMemo<GemmChoice> memo;
-    if (const GemmChoice* hit = memo.find(d, m, 0)) {
+    const int q = epi ? 1 : 0;            // the callers' fused epilogue lives in wq_gemm_kernel only
+    if (const GemmChoice* hit = memo.find(d, m, q)) {
       c = *hit;
     } else {
-      int st = gemm_choose(d, m, &c);
+      int st = gemm_choose(d, m, &c, epi != nullptr);
       if (st != WQAA_OK) return st;
-      memo.put(d, m, 0, c);
+      memo.put(d, m, q, c);
     }
   }
   const int g = d.group_size <= 0 ? d.K : d.group_size;
@@ -326,6 +359,10 @@ int gemm_launch(const wqaa_matmul_desc& d, const void* A, const void* B, const v
   a.tiles_m = c.tiles_m;
   a.tiles_n = c.tiles_n;
   a.nsteps = d.K / c.ks;
+  if (c.pp) {                               // the ping-pong member reads gq_shift as log2(k-bodies per group)
+    a.gq_shift = c.pp_shift;
+    a.gq_magic = 0u;
+  }
   a.epi_row = nullptr;
   a.epi_tensor = 1.f;
   if (epi) {
@@ -532,6 +569,14 @@ void gemm_init() {
               gemm_fn fn = pick_gemm(kind, layout, at, mode, flags, mf);
               if (fn) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             }
+  for (int kind : {DK_INT4, DK_LUT4, DK_INT2})
+    for (int layout = 0; layout < 2; ++layout)
+      for (int at : {AT_F16, AT_I8})
+        for (int mode = 0; mode <= MD_ZR; ++mode) {
+          int lds = 0;
+          gemm_fn fn = pick_gemm_pp(kind, layout, at, mode, 0, &lds);
+          if (fn) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        }
   (void)hipGetLastError();   // a refused attribute must not linger as this thread's "last error"
 }
 

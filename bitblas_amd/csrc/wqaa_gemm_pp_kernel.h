@@ -1,0 +1,588 @@
+// wqaa_gemm_pp_kernel.h - the large-M W_q x A MFMA member: a role-alternating ("ping-pong") main loop for gfx950.
+//
+// Replaces the reference's tensor-core main loops `MatmulDequantizeMMAScheduler` / `MatmulMMAScheduler`
+// (bitblas/ops/general_matmul/tilelang/dequantize/matmul_dequantize_mma.py:333-508, tilelang/dense/matmul_mma.py:220-320)
+// for M >= 256.  Same computation and the same per-element dequant arithmetic as wq_gemm_kernel (wqaa_gemm_kernel.h);
+// what changes is the machine schedule:
+//   * 256 x 256 tile, 8 waves, every wave owns 32 weight rows (n) and multiplies them by all 256 activation rows.
+//     The matrix instruction is the 32x32 form (v_mfma_f32_32x32x16_f16 / v_mfma_i32_32x32x32_i8: 32 matrix-pipe cycles,
+//     half the issue slots of the 16x16 form per flop), weights as its A operand: a lane owns weight row n = lane & 31
+//     and the k-half h = lane >> 5, so ONE 32-bit word of packed weights (8 int4 / 16 int2) decodes in registers into
+//     exactly one MFMA operand.  Packed weights never become fp16 in LDS;
+//   * every byte from global memory arrives by LDS-DMA (buffer_load ... lds): the activation tile (256 rows x 128 B per
+//     k-tile, XOR-swizzled through the SOURCE address so the ds_read_b128 operand reads are conflict free), the wave's
+//     own packed weights (1 KiB per k-tile, read back by the lane that owns them) and its Scale / Zeros.  One load
+//     KIND in flight means the counted `s_waitcnt vmcnt(N)` is in order, so the prefetch ring (RING k-tiles) is never
+//     drained inside the loop, and no VGPR waits for memory;
+//   * the two waves of a SIMD alternate roles (MI355X_MICROARCH "Two waves per SIMD"): waves 0-3 and waves 4-7 run the
+//     same instruction stream one s_barrier apart, so while one wave of a SIMD is in a COMPUTE segment (8 MFMAs with the
+//     decode of the next weight word interleaved in their shadow), its partner is in a LOAD segment (8 ds_read_b128 for
+//     its next 8 MFMAs, its share of the LDS-DMA issue, the waits).  No register double buffer for the operands: the
+//     partner's compute covers the LDS latency;
+//   * the output tile leaves through LDS, whole rows per store instruction (the accumulator layout gives a lane 4
+//     consecutive n of one m: 8-byte pieces 512 B apart; the store tail was issue-bound).
+#pragma once
+#include "wqaa_gemm_kernel.h"
+
+namespace wqaa {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef int i32x16 __attribute__((ext_vector_type(16)));
+
+enum : int {
+  PPO_ZINT_OFF = 1,      // never take the integer-zero-point decode (A/B aid)
+  PPO_TRACE = 32,        // lab: s_memtime stamps of the four phases of k-tile 16, written through a.lut ([block][wave][20])
+  PPO_ABL_NODMA = 64,    // lab ablations (timing only, results wrong): no LDS-DMA inside the loop,
+  PPO_ABL_NOREAD = 128,  //   no operand reads from LDS,
+  PPO_ABL_NODEC = 256,   //   no weight decode
+};
+
+template <int KIND_, int LAYOUT_, int AT_, int MODE_, int FLAGS_, int RING_ = 3, int OPT_ = 0>
+struct PPPolicy {
+  static constexpr int KIND = KIND_, LAYOUT = LAYOUT_, AT = AT_, MODE = MODE_, FLAGS = FLAGS_, RING = RING_, OPT = OPT_;
+  static constexpr int D = RING_ - 1;               // k-tiles of prefetch distance
+  static constexpr int BM = 256, BN = 256, THREADS = 512, NWAVES = 8;
+    static constexpr int TILE_ROW = 128;              // bytes of one activation row per k-tile
+  static constexpr int KT = AT_ == AT_F16 ? 64 : 128;   // k per tile
+  static constexpr int KB = 4 * KT;                 // k per loop trip: four k-tiles = one 128-byte line of every weight row
+  static constexpr int A_SLOT = BM * TILE_ROW;      // 32 KiB
+  static constexpr int W_OFF = RING_ * A_SLOT;      // per wave: one 4 KiB chunk (32 rows x 128 B = four k-tiles)
+  static constexpr int META_OFF = W_OFF + NWAVES * 4096;
+  static constexpr bool HAS_META = MODE_ != MD_NONE;
+  static constexpr int LDS_USED = META_OFF + (HAS_META ? NWAVES * 2 * 1024 : 0);   // per wave: two 1 KiB windows (8 groups of Scale | Zeros)
+  static constexpr int LDS_BYTES = LDS_USED > BM * BN * 2 ? LDS_USED : BM * BN * 2;   // the epilogue stages the output tile (128 KiB)
+  using T = KindTraits<KIND_, AT_>;
+  static_assert(T::BITS * KT == 256, "one k-tile of a weight row is 32 bytes: 16 per lane half");
+  static_assert(RING_ == 3 || RING_ == 4, "ring of 3 or 4 k-tiles");
+  static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+};
+
+template <int V>
+using ic = std::integral_constant<int, V>;
+
+#define PP_FENCE() asm volatile("" ::: "memory")
+#define PP_BARRIER()                        \
+  do {                                      \
+    PP_FENCE();                             \
+    __builtin_amdgcn_sched_barrier(0);      \
+    __builtin_amdgcn_s_barrier();           \
+    __builtin_amdgcn_sched_barrier(0);      \
+    PP_FENCE();                             \
+  } while (0)
+
+// a value the optimiser cannot trace back: what is computed from it stays where it is written (rarely used addresses are
+// recomputed at their use instead of occupying registers across the main loop)
+__device__ __forceinline__ int pp_opaque(int x) {
+  asm volatile("" : "+v"(x));
+  return x;
+}
+
+template <int N>
+__device__ __forceinline__ void pp_wait_vmcnt() {
+  static_assert(N >= 0 && N < 64, "vmcnt is 6 bits");
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// one packed word -> one MFMA operand (8 fp16 in natural k order); arithmetic identical to dequant_lane_f16.
+// ZINT (zeros-original, every zero point of the wave's rows an integer the magic exponents hold exactly): zA / zB are
+// (2^10 + zf + z) / (2^6 + zf + z), and (magic + q) - (magic + z) IS q - z, exactly - one vector operation less per pair.
+template <class P, bool ZINT>
+__device__ __forceinline__ void pp_decode_f16(uint32_t w, half_t zf, half2_t s2, half2_t zA, half2_t zB, const DecodeCtx& cx, const Lut16& lut,
+                                              uint32_t (&out)[4]) {
+  using T = typename P::T;
+  static_assert(T::EPW == 8, "4-bit weights");
+  half2_t q[4];
+  if constexpr (P::KIND == DK_LUT4) {
+    lut16_word(lut, w, q);
+  } else if constexpr (ZINT) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int bit = 4 * i, b = bit & 7;
+      const uint32_t src = (bit >= 8) ? (w >> 8) : w;
+      const uint32_t m = (0xFu << b) * 0x00010001u;
+      const uint32_t t = (src & m) | cx.magic[b];
+      q[i] = as_h2(t) - (b ? zB : zA);
+    }
+  } else {
+    F16Unpack<4>::run(w, zf, cx.magic, q);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if constexpr (P::MODE == MD_S || P::MODE == MD_ZQ) q[i] = q[i] * s2;
+    if constexpr (P::MODE == MD_ZO) {
+      if constexpr (ZINT) q[i] = q[i] * s2;
+      else q[i] = (q[i] - zA) * s2;
+    }
+    if constexpr (P::MODE == MD_ZR) {
+      half2_t t = q[i] * s2;
+      asm volatile("" : "+v"(t));   // two roundings, no fma contraction
+      q[i] = t - zA;
+    }
+  }
+  to_natural_f16<T, P::LAYOUT>(q, out, std::make_integer_sequence<int, 4>{});
+}
+
+template <class P>
+__device__ __forceinline__ void pp_decode_i8(uint32_t w, uint32_t zp4, uint32_t flip, uint32_t (&out)[4]) {
+  using T = typename P::T;
+  static_assert(T::EPW == 16, "2-bit weights");
+  uint32_t t[4];
+  I8Unpack<2>::run(w ^ flip, t);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) t[i] = sub_bytes(t[i], zp4);
+  to_natural_i8<T, P::LAYOUT>(t, out, std::make_integer_sequence<int, 4>{});
+}
+
+template <class P>
+__global__ void __launch_bounds__(P::THREADS) wq_gemm_pp_kernel(const GemmArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)   // the host pass only needs the stub (the buffer-resource builtins do not exist there)
+  using T = typename P::T;
+  constexpr bool F16 = P::AT == AT_F16;
+  constexpr int MODE = P::MODE, D = P::D, RING = P::RING;
+  constexpr int NMF = P::BM / 16;       // 16-row activation fragments: 16
+  constexpr bool ZP = MODE == MD_ZO || MODE == MD_ZR;
+  using acc_t = typename std::conditional<F16, f32x4, i32x4>::type;
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave >> 2;            // 0: waves 0-3, 1: waves 4-7 (one of each per SIMD)
+  const int ln = lane & 31, h = lane >> 5;   // LDS-DMA / metadata role of the lane: row ln of the wave's 32, half h
+  const int fr = lane & 15, kb = lane >> 4;  // MFMA role: fragment row (weight n / activation m), k-block
+
+  unsigned long long tr[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long tr_c0 = 0, tr_r0 = 0;
+  if constexpr (P::OPT & PPO_TRACE) {
+    tr_c0 = __builtin_readcyclecounter();
+    tr_r0 = __builtin_amdgcn_s_memrealtime();
+  }
+  auto stamp = [&](int t, int idx) {
+    if constexpr (P::OPT & PPO_TRACE) {
+      if (t == 16) tr[idx] = __builtin_readcyclecounter();
+    }
+  };
+
+  // ---- tile of this workgroup: XCD-contiguous ranges of the grouped order (see wq_gemm_kernel) ----
+  int blk = blockIdx.x;
+  const int nblk = gridDim.x;
+  if ((nblk & 7) == 0) blk = (blockIdx.x & 7) * (nblk >> 3) + (blockIdx.x >> 3);
+  const int per_group = a.group_m * a.tiles_n;
+  const int first_m = (blk / per_group) * a.group_m;
+  const int gsz = a.tiles_m - first_m < a.group_m ? a.tiles_m - first_m : a.group_m;
+  const int tile_m = first_m + (blk % per_group) % gsz, tile_n = (blk % per_group) / gsz;
+  const int m0 = tile_m * P::BM;
+  const int n0 = tile_n * P::BN;
+  const int nw0 = n0 + wave * 32;       // first weight row of this wave
+
+  const int ntiles = a.K / P::KT;       // a multiple of 4 (K is a multiple of KB)
+  const int nchunks = ntiles >> 2;
+
+  // ---- LDS-DMA sources ----
+  const int a_row_bytes = F16 ? a.K * 2 : a.K;
+  const auto a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.A), 0, (int)((long)a.M * a_row_bytes), 0x00020000);
+  const auto w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.B), 0, (int)((long)a.N * a.row_bytes), 0x00020000);
+  // activation piece j of a tile: this wave's rows [wave * 32 + j * 8, + 8), 8 lanes per row (one 128-byte line); the lane
+  // that fills physical granule p of row r fetches natural granule p ^ ((r >> 1) & 7) = p ^ (((j & 1) * 4 + (lane >> 4)) & 7).
+  // Two registers serve the four pieces: the offset of piece 0 and the +-64 bytes an odd piece's swizzle moves the granule by;
+  // rows and k-tile go through scalar adds.  Rows beyond M are out of the buffer's range (they read as zero, never stored).
+  const int g0_ = (lane & 7) ^ ((lane >> 4) & 7);
+  const uint32_t a_v0 = (uint32_t)(wave * 32 + (lane >> 3)) * (uint32_t)a_row_bytes + (uint32_t)(g0_ * 16);
+  const int a_vd = ((g0_ ^ 4) - g0_) * 16;
+  const uint32_t a_rows0 = (uint32_t)m0 * (uint32_t)a_row_bytes;
+  // weight piece p of a chunk: rows [8p, 8p + 8) of this wave's 32, the 128-byte line that holds four k-tiles of the row,
+  // swizzled like the activations (offsets recomputed at every use: four uses per trip of the main loop)
+  auto w_voff = [&](int p) -> uint32_t {
+    const int l = pp_opaque(lane);
+    const int r = p * 8 + (l >> 3);
+    const int g = (l & 7) ^ ((r >> 1) & 7);
+    const int row = nw0 + r < a.N ? nw0 + r : a.N - 1;
+    return (uint32_t)row * (uint32_t)a.row_bytes + (uint32_t)(g * 16);
+  };
+  const int nrow = nw0 + ln < a.N ? nw0 + ln : a.N - 1;
+  // Scale (lanes 0-31) / Zeros (lanes 32-63) of row nrow come as 16-byte windows of 8 consecutive groups and are consumed by
+  // the lanes that own rows fr and 16 + fr of the MFMA operand
+  const uint32_t mlim = P::HAS_META ? (uint32_t)a.N * (uint32_t)a.kg - 8u : 0u;
+  const uint32_t rowbase = (uint32_t)nrow * (uint32_t)a.kg;     // (prologue only)
+  const int nbodies = ntiles >> 1;
+  auto group_of_body = [&](int b) -> int {   // k-body b (two k-tiles: 128 k for fp16) -> group index; a group is 2^gq_shift bodies
+    b = b < nbodies ? b : nbodies - 1;
+    return b >> a.gq_shift;
+  };
+  auto window_start = [&](uint32_t rb, int q) -> uint32_t {   // first element of window q of a row (kept inside the array)
+    const uint32_t e = rb + (uint32_t)(q * 8);
+    return e < mlim ? e : mlim;
+  };
+
+  unsigned char* const a_ring = smem;
+  unsigned char* const w_buf = smem + P::W_OFF + wave * 4096;
+  unsigned char* const meta = smem + P::META_OFF + wave * 2048;
+
+  auto dma_a = [&](int tt, int slot, int j) {       // activation piece j of k-tile tt -> ring slot
+    const int tc = tt < ntiles ? tt : ntiles - 1;
+    unsigned char* dst = a_ring + slot * P::A_SLOT + (wave * 32 + j * 8) * P::TILE_ROW;
+    const uint32_t rows = a_rows0 + (uint32_t)(j * 8) * (uint32_t)a_row_bytes;     // scalar
+    const uint32_t voff = (j & 1) ? a_v0 + (uint32_t)a_vd + rows : a_v0 + rows;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (lds_ptr_t)dst, 16, voff, tc * P::TILE_ROW, 0, 0);
+  };
+  auto dma_w = [&](int chunk, int p) {
+    const int cc = chunk < nchunks ? chunk : nchunks - 1;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_ptr_t)(w_buf + p * 1024), 16, w_voff(p), cc * 128, 0, 0);
+  };
+  auto dma_meta = [&](int q) {                      // window q -> buffer q & 1
+    if constexpr (P::HAS_META) {
+      const int l = pp_opaque(lane);
+      const int n = nw0 + (l & 31);
+      const uint16_t* mbase = (ZP && (l >> 5) == 1) ? reinterpret_cast<const uint16_t*>(a.zeros) : reinterpret_cast<const uint16_t*>(a.scale);
+      const uint16_t* src = mbase + window_start((uint32_t)(n < a.N ? n : a.N - 1) * (uint32_t)a.kg, q);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src), (lds_ptr_t)(meta + (q & 1) * 1024), 16, 0, 0);
+    }
+  };
+
+  // ---- operand reads ----
+  // A k-tile is 8 granules of 16 bytes per row; MFMA jj (0, 1) of the tile takes granule 4 * jj + kb from the lane: the two
+  // 8-lane halves of a ds_read_b128 service group (k-blocks kb, kb ^ 1) then never meet on a 16-byte slot
+  const int swl = (fr >> 1) & 7;
+  uint32_t a_rd[2];
+#pragma unroll
+  for (int jj = 0; jj < 2; ++jj) a_rd[jj] = (uint32_t)(fr * P::TILE_ROW + (((4 * jj + kb) ^ swl) * 16));
+  DecodeCtx cx;
+  cx.zf = (F16 && a.is_signed && P::KIND != DK_LUT4) ? (half_t)8.0f : (half_t)0.0f;
+  cx.flip = 0u;
+  cx.off8 = (half_t)0.0f;
+  if constexpr (F16) {                     // 4-bit fields sit at bit 0 and bit 4 of a byte: two magic exponent words, pinned in VGPRs
+#pragma unroll
+    for (int b = 0; b < 8; ++b) cx.magic[b] = (uint32_t)((25 - b) << 10) * 0x00010001u;
+    asm volatile("" : "+v"(cx.magic[0]));
+    asm volatile("" : "+v"(cx.magic[4]));
+  }
+  const uint32_t zp4 = (!F16 && a.is_signed) ? 0x02020202u : 0u;
+  Lut16 lut;
+  if constexpr (P::KIND == DK_LUT4) {
+    if (a.fp4_table) lut = make_fp4_lut(false);
+    else lut = make_lut16(reinterpret_cast<const half_t*>(a.lut));
+  }
+
+  // ---- zeros-original: are all zero points of this wave's rows integers the magic subtraction holds exactly? ----
+  bool zint = false;
+  if constexpr (F16 && MODE == MD_ZO && P::KIND == DK_INT4 && !(P::OPT & PPO_ZINT_OFF)) {
+    bool ok = true;
+    const uint16_t* zrow = reinterpret_cast<const uint16_t*>(a.zeros);
+    for (int i = 0; i < a.kg; i += 8) {
+      const uint32_t e = rowbase + (uint32_t)i;
+      const u32x4 v = *reinterpret_cast<const u32x4*>(zrow + (e < mlim ? e : mlim));   // (neighbours' elements checked too near the end: conservative)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float z = (float)bits_to_half(v[k >> 1] >> ((k & 1) * 16)) + (float)cx.zf;
+        ok = ok && z == __builtin_truncf(z) && z > -48.f && z < 48.f;
+      }
+    }
+    zint = __all(ok);
+  }
+
+  acc_t acc[NMF][2];
+#pragma unroll
+  for (int f = 0; f < NMF; ++f)
+#pragma unroll
+    for (int nf = 0; nf < 2; ++nf) acc[f][nf] = acc_t{0, 0, 0, 0};
+
+  u32x4 afrag[8];
+  uint32_t bw[2][2][4];                   // decoded weight operands: [pair parity][n fragment]
+  uint32_t rawc[2][2][2];                 // packed words of two k-tiles of the chunk in hand: [k-tile parity][n fragment][MFMA of the tile]
+  half2_t s2c[2], zAc[2], zBc[2];         // Scale / Zeros of the k-body being decoded, per weight fragment
+#pragma unroll
+  for (int nf = 0; nf < 2; ++nf) {
+    s2c[nf] = splat((half_t)1.0f);
+    zAc[nf] = zBc[nf] = splat((half_t)0.0f);
+  }
+  uint32_t m_s[2] = {0, 0}, m_z[2] = {0, 0};   // Scale / Zeros bits of the next body
+
+  auto meta_read = [&](int b) {            // Scale / Zeros of body b (its window has landed)
+    if constexpr (P::HAS_META) {
+      const int gi = group_of_body(b);
+      const int q = gi >> 3;
+      const unsigned char* p = meta + (q & 1) * 1024;
+      const int fr_ = pp_opaque(lane) & 15;
+#pragma unroll
+      for (int nf = 0; nf < 2; ++nf) {
+        const int n = nw0 + nf * 16 + fr_;
+        const uint32_t rb = (uint32_t)(n < a.N ? n : a.N - 1) * (uint32_t)a.kg;
+        const uint32_t e = rb + (uint32_t)gi - window_start(rb, q);
+        m_s[nf] = *reinterpret_cast<const uint16_t*>(p + (nf * 16 + fr_) * 16 + e * 2);
+        if constexpr (ZP) m_z[nf] = *reinterpret_cast<const uint16_t*>(p + (32 + nf * 16 + fr_) * 16 + e * 2);
+      }
+    }
+  };
+  auto meta_convert = [&](auto ZI, half2_t (&s2)[2], half2_t (&zA)[2], half2_t (&zB)[2]) {
+    if constexpr (P::HAS_META) {
+#pragma unroll
+      for (int nf = 0; nf < 2; ++nf) {
+        s2[nf] = splat(bits_to_half(m_s[nf]));
+        if constexpr (ZP) {
+          const half_t z = bits_to_half(m_z[nf]);
+          if constexpr (decltype(ZI)::value) {
+            zA[nf] = splat((half_t)1024.0f + cx.zf + z);
+            zB[nf] = splat((half_t)64.0f + cx.zf + z);
+          } else {
+            zA[nf] = splat(z);
+          }
+        }
+      }
+    }
+  };
+  auto decode = [&](auto ZI, uint32_t w, half2_t s2, half2_t zA, half2_t zB, uint32_t (&out)[4]) {
+    if constexpr (F16) pp_decode_f16<P, decltype(ZI)::value != 0>(w, cx.zf, s2, zA, zB, cx, lut, out);
+    else pp_decode_i8<P>(w, zp4, cx.flip, out);
+  };
+  auto read_words = [&](int half) {        // k-tiles 2 * half, 2 * half + 1 of the landed chunk -> registers
+    const int l = pp_opaque(lane);
+    const uint32_t w_rd0 = (uint32_t)((l & 15) * 128 + (l >> 4) * 4);
+    const int swl = ((l & 15) >> 1) & 7;
+#pragma unroll
+    for (int tp = 0; tp < 2; ++tp)
+#pragma unroll
+      for (int nf = 0; nf < 2; ++nf)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+          rawc[tp][nf][jj] = *reinterpret_cast<const uint32_t*>(w_buf + nf * 2048 + w_rd0 + (uint32_t)(((2 * (2 * half + tp) + jj) ^ swl) * 16));
+  };
+
+  // ---- prologue: the first window, chunk 0 and D k-tiles in flight; tile 0 landed; first operands decoded ----
+  dma_meta(0);
+#pragma unroll
+  for (int p = 0; p < 4; ++p) dma_w(0, p);
+#pragma unroll
+  for (int tt = 0; tt < D; ++tt)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) dma_a(tt, tt, j);
+  pp_wait_vmcnt<(D - 1) * 4>();           // tiles 1 .. D-1 may stay in flight
+  PP_BARRIER();
+  read_words(0);
+  meta_read(0);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  if (zint) {
+    meta_convert(ic<1>{}, s2c, zAc, zBc);
+#pragma unroll
+    for (int nf = 0; nf < 2; ++nf) decode(ic<1>{}, rawc[0][nf][0], s2c[nf], zAc[nf], zBc[nf], bw[0][nf]);
+  } else {
+    meta_convert(ic<0>{}, s2c, zAc, zBc);
+#pragma unroll
+    for (int nf = 0; nf < 2; ++nf) decode(ic<0>{}, rawc[0][nf][0], s2c[nf], zAc[nf], zBc[nf], bw[0][nf]);
+  }
+  if (grp == 1) PP_BARRIER();             // waves 4-7 run one segment behind waves 0-3
+
+  // ---- main loop: four k-tiles (one weight chunk) per trip; every index below is a compile-time constant.
+  // Phase p of a tile: MFMA jj = p >> 1 of the tile, activation fragments 8 * (p & 1) .. + 8, both weight fragments: 16 MFMAs.
+  int slot = 0;                            // ring slot of the k-tile in hand
+  auto load_segment = [&](auto TQ, auto PH, int t) {
+    constexpr int tq = decltype(TQ)::value, p = decltype(PH)::value;
+    constexpr int jj = p >> 1, mh = p & 1;
+    const unsigned char* sl = a_ring + slot * P::A_SLOT;
+    if constexpr (tq == 0) stamp(t, p * 4 + 0);
+    if constexpr (P::OPT & PPO_ABL_NOREAD) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(afrag[i]));
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) afrag[i] = *reinterpret_cast<const u32x4*>(sl + a_rd[jj] + (mh * 8 + i) * (16 * P::TILE_ROW));
+    }
+    if constexpr (!(P::OPT & PPO_ABL_NODMA)) {
+      const int dslot = slot + D >= RING ? slot + D - RING : slot + D;
+      dma_a(t + D, dslot, p);
+      if constexpr (tq == 2) dma_w((t >> 2) + 1, p);       // the next chunk: its four pieces ride with tile 2 (this chunk's words are all in registers by then)
+    }
+    if constexpr (tq == 0) stamp(t, p * 4 + 1);
+    if constexpr (p == 2) {
+      // everything of tile t + 1 (and older) has landed when at most the pieces issued in segments 0..2 of this tile (and, with
+      // a ring of 4, in tile t - 1) are outstanding; a metadata window issued in between only makes the wait cover one operation more
+      if constexpr (!(P::OPT & PPO_ABL_NODMA))
+        pp_wait_vmcnt<(D - 2) * 4 + 3 + (tq == 2 ? 3 : 0) + ((D > 2 && tq == 3) ? 4 : 0)>();
+      // ... so the next chunk (its pieces went out with tiles 0 and 1) and the next body's Scale / Zeros can be picked up: the
+      // compute segments 2 and 3 of this tile decode the first operands of the next tile
+      if constexpr (tq == 3) read_words(0);         // first half of the next chunk (landed: it went out with tile 2)
+      if constexpr (tq == 1) read_words(1);         // second half of this chunk
+      if constexpr ((tq & 1) == 1) meta_read((t + 1) >> 1);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if constexpr (tq == 0) stamp(t, p * 4 + 2);
+    PP_BARRIER();
+  };
+  auto compute_segment = [&](auto ZI, auto TQ, auto PH, int t) {
+    constexpr int tq = decltype(TQ)::value, p = decltype(PH)::value;
+    constexpr int jj = p >> 1, mh = p & 1;
+    constexpr int par = jj;                // operand pair in use; the other one is being decoded
+    if constexpr (tq == 0) stamp(t, p * 4 + 3);
+    // the next pair of operands, one weight fragment per phase: MFMA 1 of this tile, then MFMA 0 of the next tile (with the
+    // next body's Scale / Zeros after an odd tile)
+    constexpr int nf_dec = mh;
+    if constexpr (P::OPT & PPO_ABL_NODEC) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        bw[par ^ 1][nf_dec][i] = bw[par][nf_dec][i];
+        asm volatile("" : "+v"(bw[par ^ 1][nf_dec][i]));
+      }
+    } else if constexpr (jj == 0) {
+      decode(ZI, rawc[tq & 1][nf_dec][1], s2c[nf_dec], zAc[nf_dec], zBc[nf_dec], bw[1][nf_dec]);
+    } else if constexpr ((tq & 1) == 0) {
+      decode(ZI, rawc[(tq + 1) & 1][nf_dec][0], s2c[nf_dec], zAc[nf_dec], zBc[nf_dec], bw[0][nf_dec]);
+    } else {
+      // after an odd tile the next tile opens a new k-body: segments 0 and 1 were the last to decode with the old values
+      if constexpr (mh == 0) meta_convert(ZI, s2c, zAc, zBc);
+      decode(ZI, rawc[(tq + 1) & 1][nf_dec][0], s2c[nf_dec], zAc[nf_dec], zBc[nf_dec], bw[0][nf_dec]);   // the words read in load segment 2
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+#pragma unroll
+      for (int nf = 0; nf < 2; ++nf) {
+        const u32x4 bv = {bw[par][nf][0], bw[par][nf][1], bw[par][nf][2], bw[par][nf][3]};
+        if constexpr (F16)
+          acc[mh * 8 + i][nf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8_t, bv), __builtin_bit_cast(half8_t, afrag[i]),
+                                                                     acc[mh * 8 + i][nf], 0, 0, 0);
+        else
+          acc[mh * 8 + i][nf] = __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4, bv), __builtin_bit_cast(i32x4, afrag[i]),
+                                                                    acc[mh * 8 + i][nf], 0, 0, 0);
+      }
+    }
+    // two MFMAs (32 matrix-pipe cycles), then up to three of the decode's vector operations in their shadow
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+    }
+    PP_BARRIER();
+  };
+  auto tile = [&](auto ZI, auto TQ, int t) {
+    load_segment(TQ, ic<0>{}, t);
+    compute_segment(ZI, TQ, ic<0>{}, t);
+    load_segment(TQ, ic<1>{}, t);
+    compute_segment(ZI, TQ, ic<1>{}, t);
+    load_segment(TQ, ic<2>{}, t);
+    compute_segment(ZI, TQ, ic<2>{}, t);
+    load_segment(TQ, ic<3>{}, t);
+    compute_segment(ZI, TQ, ic<3>{}, t);
+    slot = slot + 1 == RING ? 0 : slot + 1;
+  };
+  auto main_loop = [&](auto ZI) {
+    if constexpr (P::OPT & PPO_ABL_NOREAD) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) afrag[i] = *reinterpret_cast<const u32x4*>(a_ring + a_rd[0] + i * (16 * P::TILE_ROW));
+    }
+    // A metadata window (8 groups) lasts 16 << gq_shift k-tiles; the next one is asked for a whole window ahead, between two
+    // trips (the trip itself stays free of branches: one basic block per segment)
+    const int wtiles = 16 << a.gq_shift;
+    for (int t = 0; t < ntiles; t += 4) {
+      if constexpr (P::HAS_META) {
+        if ((t & (wtiles - 1)) == 0) dma_meta((t >> (4 + a.gq_shift)) + 1);
+      }
+      tile(ZI, ic<0>{}, t);
+      tile(ZI, ic<1>{}, t + 1);
+      tile(ZI, ic<2>{}, t + 2);
+      tile(ZI, ic<3>{}, t + 3);
+    }
+  };
+  if (zint) main_loop(ic<1>{});
+  else main_loop(ic<0>{});
+  if (grp == 0) PP_BARRIER();
+  if constexpr (P::OPT & PPO_TRACE) {
+    if (lane == 0 && a.lut) {
+      unsigned long long* dst = reinterpret_cast<unsigned long long*>(const_cast<void*>(a.lut)) + ((long)blockIdx.x * 8 + wave) * 20;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) dst[i] = tr[i];
+      dst[16] = tr_c0;
+      dst[17] = tr_r0;
+      dst[18] = __builtin_readcyclecounter();
+      dst[19] = __builtin_amdgcn_s_memrealtime();
+    }
+  }
+
+  // ---- epilogue: the 256 x 256 tile leaves through LDS, whole rows per store ----
+  // accumulator (f, nf): activation row m = 16 f + fr, weight rows n = 32 wave + 16 nf + 4 kb + {0..3}
+  pp_wait_vmcnt<0>();                      // the clamped tail pieces still write ring slots
+  PP_BARRIER();
+  const int el = pp_opaque(lane);          // (lane roles recomputed: nothing of the epilogue stays live across the loop)
+  const int e_fr = el & 15, e_kb = el >> 4, e_ln = el & 31, e_h = el >> 5;
+  if constexpr (F16) {
+    // unit = 4 consecutive n (8 bytes); unit u of row m lives at pair ((u >> 1) ^ (m & 7)), half ((u & 1) ^ ((m >> 3) & 1)):
+    // the 16 lanes of a ds_write_b64 group (16 consecutive m, one u) hit 16 distinct 8-byte slots of a 128-byte window
+    half_t bias_h[2][4];
+    if (a.has_bias) {
+#pragma unroll
+      for (int nf = 0; nf < 2; ++nf)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int n = nw0 + nf * 16 + e_kb * 4 + i;
+          bias_h[nf][i] = reinterpret_cast<const half_t*>(a.bias)[n < a.N ? n : a.N - 1];
+        }
+    }
+#pragma unroll
+    for (int f = 0; f < NMF; ++f) {
+      const int m = f * 16 + e_fr;
+#pragma unroll
+      for (int nf = 0; nf < 2; ++nf) {
+        half_t v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          v[i] = (half_t)acc[f][nf][i];
+          if (a.has_bias) v[i] = v[i] + bias_h[nf][i];
+        }
+        const int u = wave * 8 + nf * 4 + e_kb;
+        const int up = (((u >> 1) ^ (m & 7)) << 1) | ((u & 1) ^ ((m >> 3) & 1));
+        const half2_t lo = {v[0], v[1]}, hi = {v[2], v[3]};
+        *reinterpret_cast<u32x2*>(smem + m * 512 + up * 8) = u32x2{as_u32(lo), as_u32(hi)};
+      }
+    }
+    PP_FENCE();
+    __syncthreads();
+    // a wave stores its 32 rows, two per instruction: lane c = lane & 31 takes the 16-byte pair c of row m
+#pragma unroll
+    for (int rr = 0; rr < 16; ++rr) {
+      const int m = wave * 32 + rr * 2 + e_h;
+      const int c = e_ln;
+      u32x4 x = *reinterpret_cast<const u32x4*>(smem + m * 512 + ((c ^ (m & 7)) * 16));
+      if ((m >> 3) & 1) x = u32x4{x[2], x[3], x[0], x[1]};
+      const int n = n0 + c * 8;
+      if (m0 + m < a.M && n < a.N)
+        *reinterpret_cast<u32x4*>(reinterpret_cast<half_t*>(a.C) + (long)(m0 + m) * a.N + n) = x;
+    }
+  } else {
+    // int32 output: 16 bytes per (lane, fragment); two passes of 128 rows (128 KiB each).  Slot s = n / 4 of row m lives at
+    // s ^ (m & 7): the 8 lanes of a ds_write_b128 group (8 consecutive m) hit 8 distinct 16-byte slots
+    int bias_i[2][4];
+#pragma unroll
+    for (int nf = 0; nf < 2; ++nf)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int n = nw0 + nf * 16 + e_kb * 4 + i;
+        bias_i[nf][i] = a.has_bias ? (int)reinterpret_cast<const int8_t*>(a.bias)[n < a.N ? n : a.N - 1] : 0;
+      }
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+      if (pass) __syncthreads();
+#pragma unroll
+      for (int ff = 0; ff < NMF / 2; ++ff) {
+        const int f = pass * (NMF / 2) + ff;
+        const int ml = ff * 16 + e_fr;       // row inside the pass
+#pragma unroll
+        for (int nf = 0; nf < 2; ++nf) {
+          const int sidx = wave * 8 + nf * 4 + e_kb;
+          const i32x4 v = {acc[f][nf][0] + bias_i[nf][0], acc[f][nf][1] + bias_i[nf][1], acc[f][nf][2] + bias_i[nf][2], acc[f][nf][3] + bias_i[nf][3]};
+          *reinterpret_cast<i32x4*>(smem + ml * 1024 + ((sidx ^ (ml & 7)) * 16)) = v;
+        }
+      }
+      PP_FENCE();
+      __syncthreads();
+#pragma unroll
+      for (int rr = 0; rr < 16; ++rr) {
+        const int ml = wave * 16 + rr;
+        const i32x4 x = *reinterpret_cast<const i32x4*>(smem + ml * 1024 + ((el ^ (ml & 7)) * 16));
+        const int m = m0 + pass * 128 + ml, n = n0 + el * 4;
+        if (m < a.M && n < a.N) *reinterpret_cast<i32x4*>(reinterpret_cast<int*>(a.C) + (long)m * a.N + n) = x;
+      }
+    }
+  }
+#endif
+}
+
+}  // namespace wqaa

@@ -1,0 +1,112 @@
+"""The ping-pong 256 x 256 MFMA member (csrc/wqaa_gemm_pp_kernel.h) against the CPU oracle.
+
+The selector takes it for large M (one 256 x 256 tile per CU and more); `WQAA_GEMM_MF=16` (a plan-time tuning aid) pins the
+256-row tile so that its edge cases run at sizes the oracle finishes in seconds: ragged M and N, one trip of the main loop,
+every dequant mode it implements, integer and non-integer zero points (two decode paths), both checkpoint layouts, bias.
+BASELINE c3 / c4 at full size run through it in tests/test_gemm_gpu.py."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import assert_fp_parity, hip_output, make_case, oracle_output
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def pin_the_256_row_tile(monkeypatch):
+    monkeypatch.setenv("WQAA_GEMM_MF", "16")
+
+
+def _run(case, M, exact=False):
+    got, mm = hip_output(case)
+    plan = mm.plans[M]
+    assert plan["kernel_family"] == 2 and plan["name"].endswith("pp"), plan["name"]
+    want = oracle_output(case)
+    if exact:
+        assert np.array_equal(got, want)
+    else:
+        assert_fp_parity(got, want)
+    return got, mm
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 520, 512), (256, 256, 256), (513, 264, 1024)])
+@pytest.mark.parametrize("zeros_mode", ["original", "rescale"])
+def test_uint4_scale_zeros(M, N, K, zeros_mode):
+    case = make_case(M, N, K, W_dtype="uint4", group_size=128, with_scaling=True, with_zeros=True, zeros_mode=zeros_mode, seed=M + K)
+    _run(case, M)
+
+
+def test_uint4_fractional_zero_points_take_the_general_decode():
+    case = make_case(300, 520, 512, W_dtype="uint4", group_size=128, with_scaling=True, with_zeros=True, seed=5)
+    case["zeros"] = (case["zeros"].astype(np.float32) + 0.375).astype(np.float16)
+    _run(case, 300)
+    # one fractional zero point in one row of one wave is enough to leave the integer path for that wave only
+    case2 = make_case(300, 520, 512, W_dtype="uint4", group_size=128, with_scaling=True, with_zeros=True, seed=6)
+    case2["zeros"][37, 2] = np.float16(7.25)
+    _run(case2, 300)
+
+
+@pytest.mark.parametrize("wd", ["int4", "uint4"])
+@pytest.mark.parametrize("g", [128, 256, 512])
+def test_int4_scale_only_group_sizes(wd, g):
+    case = make_case(260, 512, 1024, W_dtype=wd, group_size=g, with_scaling=True, seed=g)
+    _run(case, 260)
+
+
+@pytest.mark.parametrize("wd", ["int4", "uint4", "nf4", "fp4_e2m1"])
+def test_no_scaling(wd):
+    case = make_case(257, 256, 512, W_dtype=wd, seed=11)
+    _run(case, 257)
+
+
+@pytest.mark.parametrize("wd", ["nf4", "fp4_e2m1"])
+def test_lut_formats_with_scaling(wd):
+    case = make_case(300, 512, 512, W_dtype=wd, group_size=128, with_scaling=True, seed=12)
+    _run(case, 300)
+
+
+def test_plain_layout_and_bias():
+    case = make_case(300, 520, 512, W_dtype="uint4", group_size=128, with_scaling=True, with_zeros=True, with_bias=True,
+                     fast_decoding=False, seed=13)
+    _run(case, 300)
+    case = make_case(300, 520, 512, W_dtype="int4", group_size=128, with_scaling=True, with_bias=True, seed=14)
+    _run(case, 300)
+
+
+@pytest.mark.parametrize("wd", ["int2", "uint2"])
+@pytest.mark.parametrize("fd", [None, False])
+@pytest.mark.parametrize("M,N,K", [(300, 520, 512), (256, 256, 1024)])
+def test_int2_int8_bit_exact(wd, fd, M, N, K):
+    case = make_case(M, N, K, W_dtype=wd, A_dtype="int8", out_dtype="int32", fast_decoding=fd, seed=M)
+    _run(case, M, exact=True)
+
+
+def test_int2_int8_bias_bit_exact():
+    case = make_case(300, 520, 512, W_dtype="int2", A_dtype="int8", out_dtype="int32", with_bias=True, seed=15)
+    _run(case, 300, exact=True)
+
+
+def test_what_the_member_does_not_cover_falls_back():
+    """bfloat16 activations, float32 output, quantized zeros, per-channel scales, K off the 256 grid: the lockstep member."""
+    import bitblas_amd as bitblas
+    for kw in (dict(A_dtype="bfloat16", out_dtype="bfloat16", accum_dtype="float32", W_dtype="uint4", group_size=128, with_scaling=True),
+               dict(A_dtype="float16", out_dtype="float32", accum_dtype="float32", W_dtype="uint4", group_size=128, with_scaling=True),
+               dict(A_dtype="float16", W_dtype="uint4", group_size=128, with_scaling=True, with_zeros=True, zeros_mode="quantized"),
+               dict(A_dtype="float16", W_dtype="uint4", group_size=-1, with_scaling=True)):
+        mm = bitblas.Matmul(bitblas.MatmulConfig(M=512, N=512, K=512, **kw), enable_tuning=False)
+        assert not mm.plans[512]["name"].endswith("pp"), mm.plans[512]["name"]
+    mm = bitblas.Matmul(bitblas.MatmulConfig(M=512, N=512, K=384, A_dtype="float16", W_dtype="uint4", group_size=128, with_scaling=True),
+                        enable_tuning=False)
+    assert not mm.plans[512]["name"].endswith("pp")
+
+
+def test_two_launches_of_different_rows_share_nothing():
+    """identical activation rows give identical output rows (each row of C depends on its own row of A only), also across the
+    two wave groups and the 16-row fragments of a tile"""
+    case = make_case(512, 512, 512, W_dtype="uint4", group_size=128, with_scaling=True, with_zeros=True, seed=21)
+    A = case["A"].copy()
+    A[1::2] = A[0::2]
+    case["A"] = A
+    got, _ = _run(case, 512)
+    assert np.array_equal(got[1::2], got[0::2])
