@@ -149,8 +149,9 @@ def time_member_gemm(device, gen, M=4096, N=4096, K=4096, W_dtype="uint4", A_dty
         if op.plans[M]["kernel_family"] != 2:
             return None
         if tuned:
-            # `Matmul.hardware_aware_finetune` (the reference's default: enable_tuning=True): the fused MFMA member and the
-            # two-pass member (B_decode to a scratch + the vendor GEMM) are timed on the device, the faster one is kept
+            # YARDSTICK, not the product: with the vendor library opted in (WQAA_DENSE_LIB=1) `Matmul.hardware_aware_finetune`
+            # times the fused MFMA member against the two-pass member (B_decode to a scratch + hipBLASLt's GEMM) and keeps the faster
+            os.environ["WQAA_DENSE_LIB"] = "1"
             op = bitblas.Matmul(op.config, enable_tuning=False)
             op.hardware_aware_finetune()
     except Exception as exc:  # member not built: report, never fake
@@ -178,7 +179,11 @@ def time_member_gemm(device, gen, M=4096, N=4096, K=4096, W_dtype="uint4", A_dty
             op.lib.run(A.data_ptr(), qw.data_ptr(), None, None if int8 else sc.data_ptr(),
                        None if int8 else zr.data_ptr(), None, out.data_ptr(), M, stream)
 
-    t = graph_time(device, launch_all, n_buf)
+    try:
+        t = graph_time(device, launch_all, n_buf)
+    finally:
+        if tuned:
+            os.environ.pop("WQAA_DENSE_LIB", None)
     peak = MFMA_I8_PEAK_TOPS if int8 else MFMA_F16_PEAK_TF
     tf = 2.0 * M * N * K / t / 1e12
     nbytes = algorithmic_bytes(M, N, K, bits=bits, zeros=not int8, scale=not int8, out_bytes=4 if int8 else 2, a_bytes=1 if int8 else 2)
@@ -267,14 +272,14 @@ def time_member_resident_decode(device, gen, M=4096, N=4096, K=4096, n_buf=4):
         return {"error": f"{type(exc).__name__}: {exc}"}
 
 
-def time_member_dense(device, gen, M, N, K, kind="fp8", n_buf=4, own=False, tuned=False):
+def time_member_dense(device, gen, M, N, K, kind="fp8", n_buf=4, vendor=False, tuned=False):
     """Dense members: e4m3 x e4m3 MFMA GEMM on Llama-3-70B shapes (BASELINE config c5, one GPU's unsharded
     matrix) and the M = 1 W_int2 A_int8 GEMV (c4)."""
     import bitblas_amd as bitblas
-    # own=True: the library's own HIP MFMA member instead of the vendor GEMM the plain dense pairs take by default from
-    # M = 16 up (csrc/wqaa_dense_lib.hip; WQAA_DENSE_LIB is a plan-time switch: set while the operator is planned AND timed)
-    if own:
-        os.environ["WQAA_DENSE_LIB"] = "0"
+    # vendor=True: the YARDSTICK - hipBLASLt's GEMM on the same operands (csrc/wqaa_dense_lib.hip).  The product runs this
+    # library's own kernels; WQAA_DENSE_LIB=1 is the opt-in, a plan-time switch: set while the operator is planned AND timed
+    if vendor:
+        os.environ["WQAA_DENSE_LIB"] = "1"
     op = None
     try:
         if kind == "fp8":
@@ -289,7 +294,7 @@ def time_member_dense(device, gen, M, N, K, kind="fp8", n_buf=4, own=False, tune
     except Exception as exc:  # member not built: report, never fake
         return {"error": str(exc)}
     finally:
-        if own:
+        if vendor:
             del os.environ["WQAA_DENSE_LIB"]
             if op is not None:
                 op.lib.plan(M)                 # planning re-reads the switch for whatever runs next
@@ -717,19 +722,16 @@ def main():
                 member(f"gemv_f16_yardstick_n{N}k{K}", time_member_f16_gemv, device, gen, N, K,
                        int4_us=(members.get(f"gemv_int4_n{N}k{K}") or {}).get("us_per_launch"))
             member("gemm_uint4_m4096", time_member_gemm, device, gen, 4096)
-            member("gemm_uint4_m4096_tuned", time_member_gemm, device, gen, 4096, tuned=True)
-            member("gemm_uint4_m4096_resident_decode", time_member_resident_decode, device, gen, 4096)
+            member("gemm_uint4_m4096_two_pass_vendor", time_member_gemm, device, gen, 4096, tuned=True)
             member("gemm_uint4_m128", time_member_gemm, device, gen, 128)
             member("gemm_uint4_m16", time_member_gemm, device, gen, 16)
             member("gemm_int2_int8_m4096", time_member_gemm, device, gen, 4096, W_dtype="int2", A_dtype="int8")
-            member("gemm_int2_int8_m4096_tuned", time_member_gemm, device, gen, 4096, W_dtype="int2", A_dtype="int8", tuned=True)
             member("gemv_int2_int8_m1", time_member_dense, device, gen, 1, 4096, 4096, kind="int2", n_buf=64)
             # c5: dense e4m3 x e4m3 on every Llama-3-70B linear of one (unsharded) GPU, M = 4096 and M = 1
-            # (plain dense pairs: the vendor library by default, this library's own MFMA member under `_own`)
+            # (this library's own ping-pong MFMA member; `_vendor` = the hipBLASLt yardstick on the same operands, tuned)
             for (name, N, K, nb) in (("o", 8192, 8192, 4), ("down", 8192, 28672, 2), ("qkv", 10240, 8192, 4), ("gate", 28672, 8192, 2)):
                 member(f"gemm_fp8_m4096_{name}_n{N}_k{K}", time_member_dense, device, gen, 4096, N, K, n_buf=nb)
-                member(f"gemm_fp8_m4096_{name}_n{N}_k{K}_tuned", time_member_dense, device, gen, 4096, N, K, n_buf=nb, tuned=True)
-                member(f"gemm_fp8_m4096_{name}_n{N}_k{K}_own", time_member_dense, device, gen, 4096, N, K, n_buf=nb, own=True)
+                member(f"gemm_fp8_m4096_{name}_n{N}_k{K}_vendor", time_member_dense, device, gen, 4096, N, K, n_buf=nb, vendor=True, tuned=True)
             for (name, N, K) in (("o", 8192, 8192), ("down", 8192, 28672)):
                 member(f"gemv_fp8_m1_{name}_n{N}_k{K}", time_member_dense, device, gen, 1, N, K, n_buf=max(3, (640 << 20) // (N * K)))
             result["members"] = members

@@ -140,10 +140,7 @@ static int gemm_choose(const wqaa_matmul_desc& d, int m, GemmChoice* c, bool fus
                                                : MD_S;
   c->kl = c->at == AT_F16 ? 32 : 64;   // int8: 16 k per MFMA lane; fp8: 8 k per MFMA lane, two MFMAs per granule
   c->ks = 4 * c->kl;
-  if (d.K % c->ks != 0) {
-    set_error(WQAA_ERR_UNSUPPORTED, "gemm: K=%d must be a multiple of %d", d.K, c->ks);
-    return WQAA_ERR_UNSUPPORTED;
-  }
+  const bool k_ok = d.K % c->ks == 0;      // (the ping-pong members have their own K grid: checked after them)
   const int g = d.group_size <= 0 ? d.K : d.group_size;
   if (d.K % g != 0 || (c->mode != MD_NONE && g % c->kl != 0)) {
     set_error(WQAA_ERR_UNSUPPORTED, "gemm: group_size=%d must divide K=%d and be a multiple of %d", g, d.K, c->kl);
@@ -170,10 +167,10 @@ static int gemm_choose(const wqaa_matmul_desc& d, int m, GemmChoice* c, bool fus
   c->pp_shift = 0;
   if (c->mf == 16) {
     const char* pf = getenv("WQAA_GEMM_PP");
-    const int kb = c->at == AT_F16 ? 256 : 512;
-    const int gb = g / (kb / 2);                                       // k-bodies (two k-tiles) per group
+    const int kb = c->at == AT_F16 ? 256 : c->at == AT_F8 ? 128 : 512;   // k per trip of the main loop
+    const int gb = c->at == AT_F8 ? 1 : g / (kb / 2);                   // k-bodies (two k-tiles) per group
     const bool meta_ok = c->mode == MD_NONE || (g % (kb / 2) == 0 && ilog2_exact(gb) >= 0 && ((d.K / g) & 1) == 0 && (long)d.N * (d.K / g) >= 8);
-    const bool out_ok = c->at == AT_F16 ? d.out_dtype == WQAA_F16 : d.out_dtype == WQAA_I32;
+    const bool out_ok = c->at == AT_I8 ? d.out_dtype == WQAA_I32 : d.out_dtype == WQAA_F16;
     const long a_bytes = (long)m * d.K * (c->at == AT_F16 ? 2 : 1), w_bytes = (long)d.N * d.K * c->bits / 8;
     int lds = 0;
     gemm_fn fn = (!pf || atoi(pf) != 0) ? pick_gemm_pp(c->kind, c->layout, c->at, c->mode, c->flags, &lds) : nullptr;
@@ -194,6 +191,10 @@ static int gemm_choose(const wqaa_matmul_desc& d, int m, GemmChoice* c, bool fus
       c->ksplit = 1;
       return WQAA_OK;
     }
+  }
+  if (!k_ok) {
+    set_error(WQAA_ERR_UNSUPPORTED, "gemm: K=%d must be a multiple of %d", d.K, c->ks);
+    return WQAA_ERR_UNSUPPORTED;
   }
   // small decode batches: one launch with K split across the 8 waves of a workgroup, no partial sums
   // in memory (WQAA_GEMM_DECODE=0: back to the split-K skinny member + reduce launch).  Every
@@ -569,12 +570,13 @@ void gemm_init() {
               gemm_fn fn = pick_gemm(kind, layout, at, mode, flags, mf);
               if (fn) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             }
-  for (int kind : {DK_INT4, DK_LUT4, DK_INT2})
+  for (int kind : {DK_INT4, DK_LUT4, DK_INT2, DK_E4M3, DK_E5M2})
     for (int layout = 0; layout < 2; ++layout)
-      for (int at : {AT_F16, AT_I8})
-        for (int mode = 0; mode <= MD_ZR; ++mode) {
+      for (int at : {AT_F16, AT_I8, AT_F8})
+        for (int mode = 0; mode <= MD_ZR; ++mode)
+          for (int flags : {0, (int)FL_ABF8}) {
           int lds = 0;
-          gemm_fn fn = pick_gemm_pp(kind, layout, at, mode, 0, &lds);
+          gemm_fn fn = pick_gemm_pp(kind, layout, at, mode, flags, &lds);
           if (fn) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         }
   (void)hipGetLastError();   // a refused attribute must not linger as this thread's "last error"

@@ -15,8 +15,15 @@ static gemm_fn pp_modes_f16(int mode) {
 
 // nullptr: no ping-pong member for this combination (the caller falls back to wq_gemm_kernel)
 gemm_fn pick_gemm_pp(int kind, int layout, int at, int mode, int flags, int* lds_bytes) {
-  if (flags != 0) return nullptr;                       // bfloat16 / strict e4m3 / e5m2 activations: wq_gemm_kernel
   gemm_fn fn = nullptr;
+  if (at == AT_F8 && mode == MD_NONE && (kind == DK_E4M3 || kind == DK_E5M2) && (flags & ~FL_ABF8) == 0) {   // dense fp8 x fp8, all four pairings
+    const bool wb = kind == DK_E5M2, ab = (flags & FL_ABF8) != 0;
+    fn = !wb ? (!ab ? wq_gemm_pp8_kernel<PP8Policy<0, 0>> : wq_gemm_pp8_kernel<PP8Policy<0, 1>>)
+             : (!ab ? wq_gemm_pp8_kernel<PP8Policy<1, 0>> : wq_gemm_pp8_kernel<PP8Policy<1, 1>>);
+    *lds_bytes = PP8Policy<0, 0>::LDS_BYTES;
+    return fn;
+  }
+  if (flags != 0) return nullptr;                       // bfloat16 / strict e4m3: wq_gemm_kernel
   if (at == AT_F16) {
     if (kind == DK_INT4) fn = layout == LAYOUT_LOP3 ? pp_modes_f16<DK_INT4, LAYOUT_LOP3>(mode) : pp_modes_f16<DK_INT4, LAYOUT_PLAIN>(mode);
     else if (kind == DK_LUT4) fn = pp_modes_f16<DK_LUT4, LAYOUT_PLAIN>(mode);

@@ -585,4 +585,185 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_pp_kernel(const GemmArgs a
 #endif
 }
 
+
+// ------------------------------------------------------------------------------------------
+// dense fp8 x fp8 (BASELINE c5; replaces tilelang/dense/matmul_mma.py:220-320 for M >= 256): the same skeleton with
+// nothing to decode.  v_mfma_scale_f32_16x16x128_f8f6f4 with unit scales (the 128-deep form runs at twice the 32-deep
+// form's rate, and the 16x16 shape sustains ~6 % more than 32x32 under the power limit: tools/mfma_power.hip): one k-tile
+// (128 k = one 128-byte line of every row of BOTH operands) is one instruction per fragment pair.  A lane feeds k-slots
+// [16 kb, +16) and [64 + 16 kb, +16) of the tile: granules kb and 4 + kb, whose two 8-lane halves of a ds_read_b128 service
+// group never meet on a 16-byte slot.  A wave keeps its own 32 weight rows in a private two-slot LDS ring (4 KiB per k-tile,
+// LDS-DMA in full lines, swizzled like the activations) and reads them into registers at the head of the tile.
+// Phase p of a tile: activation fragments 4p .. 4p+3 x both weight fragments = 8 MFMAs of 32 matrix-pipe cycles.
+// ------------------------------------------------------------------------------------------
+template <int WFMT_, int AFMT_, int OPT_ = 0>
+struct PP8Policy {
+  static constexpr int WFMT = WFMT_, AFMT = AFMT_, OPT = OPT_;   // 0 e4m3, 1 e5m2
+  static constexpr int RING = 3, D = 2;
+  static constexpr int BM = 256, BN = 256, THREADS = 512, KT = 128, TILE_ROW = 128;
+  static constexpr int A_SLOT = BM * TILE_ROW;
+  static constexpr int W_OFF = RING * A_SLOT;
+  static constexpr int LDS_BYTES = W_OFF + 8 * 2 * 4096;
+  static_assert(LDS_BYTES <= 160 * 1024 && LDS_BYTES >= BM * BN * 2, "LDS budget / output staging");
+};
+
+template <class P>
+__global__ void __launch_bounds__(P::THREADS) wq_gemm_pp8_kernel(const GemmArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int D = P::D, RING = P::RING;
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+  typedef int i32x8 __attribute__((ext_vector_type(8)));
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave >> 2;
+  const int fr = lane & 15, kb = lane >> 4;
+
+  int blk = blockIdx.x;
+  const int nblk = gridDim.x;
+  if ((nblk & 7) == 0) blk = (blockIdx.x & 7) * (nblk >> 3) + (blockIdx.x >> 3);
+  const int per_group = a.group_m * a.tiles_n;
+  const int first_m = (blk / per_group) * a.group_m;
+  const int gsz = a.tiles_m - first_m < a.group_m ? a.tiles_m - first_m : a.group_m;
+  const int tile_m = first_m + (blk % per_group) % gsz, tile_n = (blk % per_group) / gsz;
+  const int m0 = tile_m * P::BM, n0 = tile_n * P::BN, nw0 = n0 + wave * 32;
+  const int ntiles = a.K / P::KT;
+
+  const auto a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.A), 0, (int)((long)a.M * a.K), 0x00020000);
+  const auto w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.B), 0, (int)((long)a.N * a.K), 0x00020000);
+  // piece j of either operand: 8 rows x one 128-byte line; rows beyond the matrix are out of the buffer's range (read as zero)
+  const int g0_ = (lane & 7) ^ ((lane >> 4) & 7);
+  const uint32_t v0 = (uint32_t)(wave * 32 + (lane >> 3)) * (uint32_t)a.K + (uint32_t)(g0_ * 16);
+  const int vd = ((g0_ ^ 4) - g0_) * 16;
+  const uint32_t a_rows0 = (uint32_t)m0 * (uint32_t)a.K, w_rows0 = (uint32_t)n0 * (uint32_t)a.K;
+
+  unsigned char* const a_ring = smem;
+  unsigned char* const w_ring = smem + P::W_OFF + wave * 8192;
+  auto dma_a = [&](int tt, int slot, int j) {
+    const int tc = tt < ntiles ? tt : ntiles - 1;
+    unsigned char* dst = a_ring + slot * P::A_SLOT + (wave * 32 + j * 8) * P::TILE_ROW;
+    const uint32_t rows = a_rows0 + (uint32_t)(j * 8) * (uint32_t)a.K;
+    const uint32_t voff = (j & 1) ? v0 + (uint32_t)vd + rows : v0 + rows;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (lds_ptr_t)dst, 16, voff, tc * P::TILE_ROW, 0, 0);
+  };
+  auto dma_w = [&](int tt, int j) {                  // piece j of the wave's 32 weight rows of k-tile tt -> slot tt & 1
+    const int tc = tt < ntiles ? tt : ntiles - 1;
+    unsigned char* dst = w_ring + (tt & 1) * 4096 + j * 1024;
+    const uint32_t rows = w_rows0 + (uint32_t)(j * 8) * (uint32_t)a.K;
+    const uint32_t voff = (j & 1) ? v0 + (uint32_t)vd + rows : v0 + rows;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_ptr_t)dst, 16, voff, tc * P::TILE_ROW, 0, 0);
+  };
+
+  const int swl = (fr >> 1) & 7;
+  uint32_t rd[2];                                    // granules kb and 4 + kb of row fr
+  rd[0] = (uint32_t)(fr * P::TILE_ROW + ((kb ^ swl) * 16));
+  rd[1] = (uint32_t)(fr * P::TILE_ROW + (((4 + kb) ^ swl) * 16));
+
+  f32x4 acc[16][2];
+#pragma unroll
+  for (int f = 0; f < 16; ++f)
+#pragma unroll
+    for (int nf = 0; nf < 2; ++nf) acc[f][nf] = f32x4{0, 0, 0, 0};
+  u32x4 afrag[4][2], wfrag[2][2];
+
+  // ---- prologue ----
+#pragma unroll
+  for (int j = 0; j < 4; ++j) dma_w(0, j);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) dma_a(0, 0, j);
+#pragma unroll
+  for (int j = 0; j < 3; ++j) dma_w(1, j);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) dma_a(1, 1, j);
+  pp_wait_vmcnt<7>();
+  PP_BARRIER();
+  if (grp == 1) PP_BARRIER();
+
+  int slot = 0;
+  auto load_segment = [&](auto PH, int t) {
+    constexpr int p = decltype(PH)::value;
+    const unsigned char* sl = a_ring + slot * P::A_SLOT;
+    if constexpr (p == 0) {                          // this tile's weights (landed: the wait of the previous tile's segment 2)
+      const unsigned char* ws = w_ring + (t & 1) * 4096;
+#pragma unroll
+      for (int nf = 0; nf < 2; ++nf)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) wfrag[nf][i] = *reinterpret_cast<const u32x4*>(ws + nf * 2048 + rd[i]);
+    }
+#pragma unroll
+    for (int f = 0; f < 4; ++f)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) afrag[f][i] = *reinterpret_cast<const u32x4*>(sl + (p * 4 + f) * (16 * P::TILE_ROW) + rd[i]);
+    // weights: piece 3 of tile t + 1 rides with segment 0 (its slot is the one tile t - 1 has left), pieces 0..2 of tile t + 2
+    // with segments 1..3 (this tile's weights are in registers by then)
+    if constexpr (p == 0) dma_w(t + 1, 3);
+    else dma_w(t + 2, p - 1);
+    {
+      const int dslot = slot + D >= RING ? slot + D - RING : slot + D;
+      dma_a(t + D, dslot, p);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    // tile t + 1 complete (activations and weights) when only what followed its last weight piece is outstanding
+    if constexpr (p == 2) pp_wait_vmcnt<5>();
+    PP_BARRIER();
+  };
+  auto compute_segment = [&](auto PH, int t) {
+    constexpr int p = decltype(PH)::value;
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      const i32x8 av = {(int)afrag[f][0][0], (int)afrag[f][0][1], (int)afrag[f][0][2], (int)afrag[f][0][3],
+                        (int)afrag[f][1][0], (int)afrag[f][1][1], (int)afrag[f][1][2], (int)afrag[f][1][3]};
+#pragma unroll
+      for (int nf = 0; nf < 2; ++nf) {
+        const i32x8 wv = {(int)wfrag[nf][0][0], (int)wfrag[nf][0][1], (int)wfrag[nf][0][2], (int)wfrag[nf][0][3],
+                          (int)wfrag[nf][1][0], (int)wfrag[nf][1][1], (int)wfrag[nf][1][2], (int)wfrag[nf][1][3]};
+        acc[p * 4 + f][nf] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wv, av, acc[p * 4 + f][nf], P::WFMT, P::AFMT, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+      }
+    }
+    PP_BARRIER();
+  };
+  for (int t = 0; t < ntiles; ++t) {
+    load_segment(ic<0>{}, t);
+    compute_segment(ic<0>{}, t);
+    load_segment(ic<1>{}, t);
+    compute_segment(ic<1>{}, t);
+    load_segment(ic<2>{}, t);
+    compute_segment(ic<2>{}, t);
+    load_segment(ic<3>{}, t);
+    compute_segment(ic<3>{}, t);
+    slot = slot + 1 == RING ? 0 : slot + 1;
+  }
+  if (grp == 0) PP_BARRIER();
+
+  // ---- epilogue: as wq_gemm_pp_kernel (float16 out of fp32 accumulators; the reference defines no fp8 bias) ----
+  pp_wait_vmcnt<0>();
+  PP_BARRIER();
+  const int el = pp_opaque(lane);
+  const int e_fr = el & 15, e_kb = el >> 4, e_ln = el & 31, e_h = el >> 5;
+#pragma unroll
+  for (int f = 0; f < 16; ++f) {
+    const int m = f * 16 + e_fr;
+#pragma unroll
+    for (int nf = 0; nf < 2; ++nf) {
+      const half2_t lo = {(half_t)acc[f][nf][0], (half_t)acc[f][nf][1]}, hi = {(half_t)acc[f][nf][2], (half_t)acc[f][nf][3]};
+      const int u = wave * 8 + nf * 4 + e_kb;
+      const int up = (((u >> 1) ^ (m & 7)) << 1) | ((u & 1) ^ ((m >> 3) & 1));
+      *reinterpret_cast<u32x2*>(smem + m * 512 + up * 8) = u32x2{as_u32(lo), as_u32(hi)};
+    }
+  }
+  PP_FENCE();
+  __syncthreads();
+#pragma unroll
+  for (int rr = 0; rr < 16; ++rr) {
+    const int m = wave * 32 + rr * 2 + e_h;
+    u32x4 x = *reinterpret_cast<const u32x4*>(smem + m * 512 + ((e_ln ^ (m & 7)) * 16));
+    if ((m >> 3) & 1) x = u32x4{x[2], x[3], x[0], x[1]};
+    const int n = n0 + e_ln * 8;
+    if (m0 + m < a.M && n < a.N) *reinterpret_cast<u32x4*>(reinterpret_cast<half_t*>(a.C) + (long)(m0 + m) * a.N + n) = x;
+  }
+#endif
+}
+
 }  // namespace wqaa

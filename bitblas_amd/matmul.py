@@ -457,12 +457,12 @@ class Matmul(Operator):
 
     def hardware_aware_finetune(self, topk: int = 20, parallel_build: bool = True):
         """The reference runs the roller + profiler here and keeps the fastest candidate (ops/operator.py:262-293, 347-382).
-        The static library's tile choice is `wqaa_select`'s table; what IS measured here, on the device, is the one choice
-        that depends on the vendor library's per-shape heuristic: from which row count on the TWO-PASS member (B_decode to a
-        scratch, then hipBLASLt's plain GEMM - `wqaa_matmul_desc.two_pass_min_m`) beats the fused MFMA member.  Each planned
-        M >= 256 is timed both ways on synthetic operands (hipEvents, a few launches); the smallest M where the two-pass
-        member wins by > 3 % becomes the threshold.  Without a GPU, or for configurations that have no two-pass member, it
-        only refreshes the recorded plans (so `Linear.warmup` keeps working)."""
+        The static library's tile choice is `wqaa_select`'s table, and every member it can pick is one of this library's own
+        kernels; there is nothing to measure by default, the call refreshes the recorded plans (so `Linear.warmup` keeps
+        working).  Only with the vendor-library yardstick opted in (WQAA_DENSE_LIB=1, a plan-time switch) is one choice timed on
+        the device: from which row count on the TWO-PASS member (B_decode to a scratch, then hipBLASLt's plain GEMM -
+        `wqaa_matmul_desc.two_pass_min_m`) beats the fused MFMA member; the smallest M where it wins by > 3 % becomes the
+        threshold."""
         cand = sorted(m for m in self.plans if isinstance(m, int) and m >= 256)
         native = self.W_dtype == self.A_dtype
         if cand and torch.cuda.is_available():

@@ -12,16 +12,18 @@ for p in (ROOT, os.path.join(ROOT, "oracle")):
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu`)")
     config.addinivalue_line("markers", "selector_choice: tests/test_gemvx_gpu.py - the test checks what the selector picks on its own")
-    config.addinivalue_line("markers", "dense_lib: the plain dense GEMMs may go to hipBLASLt (csrc/wqaa_dense_lib.hip), the product default")
+    config.addinivalue_line("markers", "dense_lib: opts into the vendor-library yardstick (WQAA_DENSE_LIB=1, csrc/wqaa_dense_lib.hip)")
 
 
 @pytest.fixture(autouse=True)
-def own_dense_members_unless_asked(request, monkeypatch):
-    """Plain dense GEMMs (W_dtype == A_dtype, M >= 16, no bias) go to hipBLASLt by default.  The parity tests of this suite
-    are about the library's OWN kernels, so they pin the dense shapes to the own members (WQAA_DENSE_LIB=0, a plan-time
-    switch); tests of the vendor-library path itself carry `@pytest.mark.dense_lib` (tests/test_dense_lib_gpu.py)."""
-    if request.node.get_closest_marker("dense_lib") is None:
-        monkeypatch.setenv("WQAA_DENSE_LIB", "0")
+def vendor_library_only_where_asked(request, monkeypatch):
+    """Every operator runs this library's own kernels by default - the suite tests what ships.  hipBLASLt is an opt-in
+    yardstick (WQAA_DENSE_LIB=1, a plan-time switch: plain dense pairs, and the second pass of the two-pass member); the tests
+    of that path carry `@pytest.mark.dense_lib` (tests/test_dense_lib_gpu.py, tests/test_two_pass_gpu.py)."""
+    if request.node.get_closest_marker("dense_lib") is not None:
+        monkeypatch.setenv("WQAA_DENSE_LIB", "1")
+    else:
+        monkeypatch.delenv("WQAA_DENSE_LIB", raising=False)
 
 
 @pytest.fixture(scope="session")

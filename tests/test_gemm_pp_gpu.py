@@ -87,6 +87,28 @@ def test_int2_int8_bias_bit_exact():
     _run(case, 300, exact=True)
 
 
+@pytest.mark.parametrize("a_dt,w_dt", [("e4m3_float8", "e4m3_float8"), ("e5m2_float8", "e4m3_float8"), ("e4m3_float8", "e5m2_float8"),
+                                       ("e5m2_float8", "e5m2_float8")])
+@pytest.mark.parametrize("M,N,K", [(300, 520, 512), (256, 256, 128), (513, 264, 1152)])
+def test_dense_fp8_pairings_ragged(a_dt, w_dt, M, N, K):
+    """BASELINE c5's kernel at sizes where the oracle checks EVERY element: ragged M / N, one k-tile, all four fp8 pairings"""
+    import bitblas_amd as bitblas
+    import wqaa_oracle as oracle
+    tdt = {"e4m3_float8": torch.float8_e4m3fn, "e5m2_float8": torch.float8_e5m2}
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(M + K)
+    A = (torch.rand((M, K), device="cuda", generator=gen) * 2 - 1).to(tdt[a_dt])
+    W = (torch.rand((N, K), device="cuda", generator=gen) * 2 - 1).to(tdt[w_dt])
+    mm = bitblas.Matmul(bitblas.MatmulConfig(M=M, N=N, K=K, A_dtype=a_dt, W_dtype=w_dt, accum_dtype="float32", out_dtype="float16"),
+                        enable_tuning=False)
+    assert mm.plans[M]["name"].endswith("pp"), mm.plans[M]["name"]
+    out = mm(A, W)
+    torch.cuda.synchronize()
+    want = oracle.matmul_dense(A.view(torch.int8).cpu().numpy(), W.view(torch.int8).cpu().numpy(), a_dtype=a_dt, w_dtype=w_dt,
+                               out_dtype="float32")
+    assert_fp_parity(out.float().cpu().numpy(), want.astype(np.float16).astype(np.float32), rtol=1e-3, atol_frac=1e-4)
+
+
 def test_what_the_member_does_not_cover_falls_back():
     """bfloat16 activations, float32 output, quantized zeros, per-channel scales, K off the 256 grid: the lockstep member."""
     import bitblas_amd as bitblas

@@ -84,6 +84,7 @@ def test_dequantize_int8_operand(wd):
     assert np.array_equal(out.cpu().numpy().astype(np.int64), want)
 
 
+@pytest.mark.dense_lib
 @pytest.mark.parametrize("kw", [F16_CASES[0], F16_CASES[2], F16_CASES[3], F16_CASES[5], F16_CASES[10], F16_CASES[12]],
                          ids=lambda kw: kw["W_dtype"] + "_" + str(kw.get("zeros_mode", "")))
 @pytest.mark.parametrize("M", [16, 300, 1024])
@@ -107,6 +108,7 @@ def test_two_pass_member_against_the_oracle_and_the_fused_member(kw, M):
     assert mm.lib.plan(M)["kernel_family"] == 2
 
 
+@pytest.mark.dense_lib
 def test_two_pass_int8_is_bit_exact():
     """W_int2 x A_int8 (BASELINE c4) through B_decode (int8) + the library's int8 GEMM: integer results, equal to the oracle"""
     M, N, K = 512, 1024, 2048
@@ -121,6 +123,7 @@ def test_two_pass_int8_is_bit_exact():
     assert np.array_equal(out.cpu().numpy(), oracle_output(case))
 
 
+@pytest.mark.dense_lib
 def test_finetune_measures_and_keeps_the_faster_member():
     cfg = bitblas.MatmulConfig(M=[1, 16, 1024, 4096], N=4096, K=4096, A_dtype="float16", W_dtype="uint4", accum_dtype="float16",
                                out_dtype="float16", group_size=128, with_scaling=True, with_zeros=True, zeros_mode="original")
@@ -145,6 +148,7 @@ def test_finetune_measures_and_keeps_the_faster_member():
     assert_fp_parity(out[rows].cpu().numpy(), oracle_output(sub), rtol=1e-3, atol_frac=1e-3)
 
 
+@pytest.mark.dense_lib
 @pytest.mark.parametrize("wd,zm", [("uint4", "original"), ("uint4", "quantized"), ("int4", None), ("nf4", None), ("uint2", "rescale")])
 def test_two_pass_bfloat16(wd, zm, monkeypatch):
     """bfloat16 activations: B_decode in bfloat16 (one rounding per operation as the TE expression), plain GEMM in the library;
@@ -156,6 +160,7 @@ def test_two_pass_bfloat16(wd, zm, monkeypatch):
     assert_fp_parity(out, want, rtol=1e-5, atol_frac=1e-5)
 
 
+@pytest.mark.dense_lib
 def test_two_pass_capture_replay_and_two_streams():
     """the two-pass member under the workspace ownership rules: caller-owned scratch shared per (stream, device)
     (`lib.shared_workspace`), capturable into a hipGraph, two streams at once with their own scratch"""

@@ -48,6 +48,7 @@ using namespace wqaa;
   X("abl_i2_all", DK_INT2, LAYOUT_LOP3, AT_I8, MD_NONE, 0, 3, PPO_ABL_NODMA | PPO_ABL_NOREAD | PPO_ABL_NODEC)
 #define LAB_PUSH(name, ...) vs.push_back(mk<PPPolicy<__VA_ARGS__>>(name));
 
+
 struct Variant {
   const char* name;
   gemm_fn fn;
@@ -57,6 +58,13 @@ struct Variant {
 template <class P>
 static Variant mk(const char* name) {
   gemm_fn fn = wq_gemm_pp_kernel<P>;
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  return Variant{name, fn, P::LDS_BYTES};
+}
+
+template <class P>
+static Variant mk8(const char* name) {
+  gemm_fn fn = wq_gemm_pp8_kernel<P>;
   CK(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   return Variant{name, fn, P::LDS_BYTES};
 }
@@ -83,18 +91,21 @@ int main(int argc, char** argv) {
     else pos.push_back(atoi(argv[i]));
   }
   if (pos.size() >= 3) { M = pos[0]; N = pos[1]; K = pos[2]; }
-  const bool i2 = kind == "i2";
+  const bool i2 = kind == "i2", f8 = kind == "f8";
   const int G = 128;
+  if (f8) setenv("WQAA_DENSE_LIB", "0", 1);     // the reference is this library's own lockstep member, not the vendor's
   init();
 
   // ---- operands (bench.py's: A = rand - 0.5, random codes, Scale = rand * 0.02, Zeros = 2^(bits-1)) ----
-  const int bits = i2 ? 2 : 4;
-  const size_t a_bytes = (size_t)M * K * (i2 ? 1 : 2), w_bytes = (size_t)N * K * bits / 8, c_bytes = (size_t)M * N * (i2 ? 4 : 2);
+  const int bits = i2 ? 2 : f8 ? 8 : 4;
+  const size_t a_bytes = (size_t)M * K * ((i2 || f8) ? 1 : 2), w_bytes = (size_t)N * K * bits / 8, c_bytes = (size_t)M * N * (i2 ? 4 : 2);
   const size_t sz_meta = (size_t)N * (K / G) * 2;
   std::vector<uint8_t> hA(a_bytes), hW(w_bytes);
   std::vector<_Float16> hS(N * (K / G)), hZ(N * (K / G));
   if (i2) {
     for (auto& b : hA) b = (uint8_t)(rng() & 0xFF);
+  } else if (f8) {
+    for (auto& b : hA) b = (uint8_t)(rng() & 0xBF);          // e4m3, |x| < 2, no NaN
   } else {
     _Float16* p = reinterpret_cast<_Float16*>(hA.data());
     for (size_t i = 0; i < (size_t)M * K; ++i) p[i] = (_Float16)(frand() - 0.5f);
@@ -112,7 +123,7 @@ int main(int argc, char** argv) {
   CK(hipMemcpy(dS, hS.data(), sz_meta, hipMemcpyHostToDevice));
   CK(hipMemcpy(dZ, hZ.data(), sz_meta, hipMemcpyHostToDevice));
   for (int s = 0; s < NSETS; ++s) {
-    for (auto& b : hW) b = (uint8_t)(rng() & 0xFF);
+    for (auto& b : hW) b = (uint8_t)(rng() & (f8 ? 0xBF : 0xFF));
     CK(hipMalloc(&dW[s], w_bytes));
     CK(hipMemcpy(dW[s], hW.data(), w_bytes, hipMemcpyHostToDevice));
   }
@@ -122,14 +133,14 @@ int main(int argc, char** argv) {
   memset(&d, 0, sizeof(d));
   d.struct_size = sizeof(d);
   d.N = N; d.K = K;
-  d.a_dtype = i2 ? WQAA_I8 : WQAA_F16;
-  d.w_format = i2 ? WQAA_W_INT : WQAA_W_UINT;
+  d.a_dtype = i2 ? WQAA_I8 : f8 ? WQAA_E4M3 : WQAA_F16;
+  d.w_format = i2 ? WQAA_W_INT : f8 ? WQAA_W_NATIVE : WQAA_W_UINT;
   d.w_bits = bits;
   d.out_dtype = i2 ? WQAA_I32 : WQAA_F16;
-  d.group_size = i2 ? -1 : G;
-  d.with_scaling = i2 ? 0 : 1;
-  d.zeros_mode = i2 ? WQAA_Z_NONE : WQAA_Z_ORIGINAL;
-  d.w_layout = WQAA_LAYOUT_LOP3;
+  d.group_size = (i2 || f8) ? -1 : G;
+  d.with_scaling = (i2 || f8) ? 0 : 1;
+  d.zeros_mode = (i2 || f8) ? WQAA_Z_NONE : WQAA_Z_ORIGINAL;
+  d.w_layout = f8 ? WQAA_LAYOUT_PLAIN : WQAA_LAYOUT_LOP3;
   d.strict_reference = 1;
   wqaa_plan plan;
   if (wqaa_select(&d, M, &plan) != WQAA_OK) { fprintf(stderr, "select: %s\n", wqaa_last_error_string()); return 2; }
@@ -137,7 +148,7 @@ int main(int argc, char** argv) {
   hipStream_t st;
   CK(hipStreamCreate(&st));
   auto run_ref = [&](int set, void* C) {
-    if (wqaa_matmul(&d, dA, dW[set], nullptr, i2 ? nullptr : dS, i2 ? nullptr : dZ, nullptr, C, M, st) != WQAA_OK) {
+    if (wqaa_matmul(&d, dA, dW[set], nullptr, (i2 || f8) ? nullptr : dS, (i2 || f8) ? nullptr : dZ, nullptr, C, M, st) != WQAA_OK) {
       fprintf(stderr, "matmul: %s\n", wqaa_last_error_string());
       exit(2);
     }
@@ -145,7 +156,9 @@ int main(int argc, char** argv) {
 
   // ---- variants ----
   std::vector<Variant> vs;
-  if (!i2) {
+  if (f8) {
+    vs.push_back(mk8<PP8Policy<0, 0>>("pp8_e4m3"));
+  } else if (!i2) {
     LAB_F16_VARIANTS(LAB_PUSH)
   } else {
     LAB_I8_VARIANTS(LAB_PUSH)
@@ -156,8 +169,8 @@ int main(int argc, char** argv) {
   memset(&a, 0, sizeof(a));
   a.A = dA; a.scale = dS; a.zeros = dZ; a.C = dC1;
   a.M = M; a.N = N; a.K = K;
-  a.kg = i2 ? 1 : K / G;
-  a.gq_shift = i2 ? 30 : 0;                 // k-bodies per group, as a shift (g = 128: one body per group)
+  a.kg = (i2 || f8) ? 1 : K / G;
+  a.gq_shift = (i2 || f8) ? 0 : 0;                 // k-bodies per group, as a shift (g = 128: one body per group)
   a.row_bytes = (long)K * bits / 8;
   a.out_dtype = i2 ? WQAA_I32 : WQAA_F16;
   a.is_signed = i2 ? 1 : 0;
