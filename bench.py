@@ -82,7 +82,8 @@ def get_op(M, N, K, W_dtype="int4", A_dtype="float16", out_dtype="float16", zero
         cfg = bitblas.MatmulConfig(M=M, N=N, K=K, A_dtype=A_dtype, W_dtype=W_dtype, out_dtype=out_dtype,
                                    accum_dtype=accum, group_size=GROUP if scaling else -1, with_scaling=scaling,
                                    with_zeros=zeros)
-        _OPS[key] = bitblas.Matmul(cfg, enable_tuning=False, strict_reference=strict)
+        # strict=False: constructed exactly as a caller of the reference would (no extra argument): the library's default
+        _OPS[key] = bitblas.Matmul(cfg, enable_tuning=False, strict_reference=True) if strict else bitblas.Matmul(cfg, enable_tuning=False)
     return _OPS[key]
 
 

@@ -192,7 +192,7 @@ def check(status: int) -> None:
 
 
 def make_desc(*, N, K, a_dtype, w_format, w_bits, out_dtype, group_size=-1, with_scaling=False,
-              zeros_mode=Z_NONE, with_bias=False, w_layout=LAYOUT_PLAIN, strict_reference=True, k_split_hint=0, two_pass_min_m=0) -> MatmulDesc:
+              zeros_mode=Z_NONE, with_bias=False, w_layout=LAYOUT_PLAIN, strict_reference=False, k_split_hint=0, two_pass_min_m=0) -> MatmulDesc:
     d = MatmulDesc()
     d.struct_size = ctypes.sizeof(MatmulDesc)
     d.N, d.K = int(N), int(K)

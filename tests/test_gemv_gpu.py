@@ -259,5 +259,5 @@ def test_k_split_int8_activations_bit_exact(wd, monkeypatch):
 def test_k_split_request_from_the_operator():
     import bitblas_amd as bitblas
     cfg = bitblas.MatmulConfigWithSplitK(M=1, N=1024, K=16384, A_dtype="float16", W_dtype="int4", group_size=128, with_scaling=True, k_split=2)
-    mm = bitblas.MatmulWithSplitK(cfg, enable_tuning=False)          # strict_reference = True: the rounding member
+    mm = bitblas.MatmulWithSplitK(cfg, enable_tuning=False, strict_reference=True)          # the rounding member
     assert mm.plans[1]["split_k"] == 2 and "_gemvx_" not in mm.plans[1]["name"], mm.plans[1]

@@ -60,7 +60,9 @@ def test_weight_only_linear(W_dtype, group_size, zeros_mode, m):
     got = lin(torch.from_numpy(A).cuda()).cpu().numpy()
     want = oracle.matmul_dequant(A, codes, source_format="uint", bit=bit, scale=scale, zeros=zeros,
                                  zeros_mode=zeros_mode, group_size=g, bias=bias)
-    assert_fp_parity(got, want)
+    # `Linear` runs the library's default members: at M <= 2 the exact-product GEMV (no per-element rounding of B_decode), held
+    # to rtol 1e-3 + 1.5e-3 rms against the TE definition like tests/test_gemvx_gpu.py (one float16 ulp of the output at most)
+    assert_fp_parity(got, want, atol_frac=1.5e-3 if m <= 2 else 1e-3)
     # the module round-trips through state_dict (checkpoint layout = the kernel operand layout)
     lin2 = bitblas.Linear(K, N, bias=True, A_dtype="float16", W_dtype=W_dtype, group_size=group_size, with_scaling=True,
                           with_zeros=True, zeros_mode=zeros_mode, opt_M=[1, 16, 128], enable_tuning=False).cuda()
