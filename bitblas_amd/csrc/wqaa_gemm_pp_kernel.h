@@ -265,22 +265,7 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_pp_kernel(const GemmArgs a
     else lut = make_lut16(reinterpret_cast<const half_t*>(a.lut));
   }
 
-  // ---- zeros-original: are all zero points of this wave's rows integers the magic subtraction holds exactly? ----
   bool zint = false;
-  if constexpr (F16 && MODE == MD_ZO && P::KIND == DK_INT4 && !(P::OPT & PPO_ZINT_OFF)) {
-    bool ok = true;
-    const uint16_t* zrow = reinterpret_cast<const uint16_t*>(a.zeros);
-    for (int i = 0; i < a.kg; i += 8) {
-      const uint32_t e = rowbase + (uint32_t)i;
-      const u32x4 v = *reinterpret_cast<const u32x4*>(zrow + (e < mlim ? e : mlim));   // (neighbours' elements checked too near the end: conservative)
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const float z = (float)bits_to_half(v[k >> 1] >> ((k & 1) * 16)) + (float)cx.zf;
-        ok = ok && z == __builtin_truncf(z) && z > -48.f && z < 48.f;
-      }
-    }
-    zint = __all(ok);
-  }
 
   acc_t acc[NMF][2];
 #pragma unroll
@@ -290,7 +275,7 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_pp_kernel(const GemmArgs a
 
   u32x4 afrag[8];
   uint32_t bw[2][2][4];                   // decoded weight operands: [pair parity][n fragment]
-  uint32_t rawc[2][2][2];                 // packed words of two k-tiles of the chunk in hand: [k-tile parity][n fragment][MFMA of the tile]
+  uint32_t rawc[4][2][2];                 // packed words of the chunk in hand, read half a chunk at a time: [k-tile][n fragment][MFMA of the tile]
   half2_t s2c[2], zAc[2], zBc[2];         // Scale / Zeros of the k-body being decoded, per weight fragment
 #pragma unroll
   for (int nf = 0; nf < 2; ++nf) {
@@ -299,19 +284,25 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_pp_kernel(const GemmArgs a
   }
   uint32_t m_s[2] = {0, 0}, m_z[2] = {0, 0};   // Scale / Zeros bits of the next body
 
+  // element of a row's window that holds group gi: gi - min(8 q, mlim - rowbase); the per-row term is kept per weight fragment
+  int mlim_f[2] = {0, 0};
+  if constexpr (P::HAS_META) {
+#pragma unroll
+    for (int nf = 0; nf < 2; ++nf) {
+      const int n = nw0 + nf * 16 + fr;
+      mlim_f[nf] = (int)(mlim - (uint32_t)(n < a.N ? n : a.N - 1) * (uint32_t)a.kg);
+    }
+  }
   auto meta_read = [&](int b) {            // Scale / Zeros of body b (its window has landed)
     if constexpr (P::HAS_META) {
       const int gi = group_of_body(b);
-      const int q = gi >> 3;
-      const unsigned char* p = meta + (q & 1) * 1024;
-      const int fr_ = pp_opaque(lane) & 15;
+      const int q8 = gi & ~7;
+      const unsigned char* p = meta + ((gi >> 3) & 1) * 1024 + (pp_opaque(lane) & 15) * 16;
 #pragma unroll
       for (int nf = 0; nf < 2; ++nf) {
-        const int n = nw0 + nf * 16 + fr_;
-        const uint32_t rb = (uint32_t)(n < a.N ? n : a.N - 1) * (uint32_t)a.kg;
-        const uint32_t e = rb + (uint32_t)gi - window_start(rb, q);
-        m_s[nf] = *reinterpret_cast<const uint16_t*>(p + (nf * 16 + fr_) * 16 + e * 2);
-        if constexpr (ZP) m_z[nf] = *reinterpret_cast<const uint16_t*>(p + (32 + nf * 16 + fr_) * 16 + e * 2);
+        const int e = gi - (q8 < mlim_f[nf] ? q8 : mlim_f[nf]);
+        m_s[nf] = *reinterpret_cast<const uint16_t*>(p + nf * 256 + e * 2);
+        if constexpr (ZP) m_z[nf] = *reinterpret_cast<const uint16_t*>(p + 512 + nf * 256 + e * 2);
       }
     }
   };
@@ -346,7 +337,7 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_pp_kernel(const GemmArgs a
       for (int nf = 0; nf < 2; ++nf)
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj)
-          rawc[tp][nf][jj] = *reinterpret_cast<const uint32_t*>(w_buf + nf * 2048 + w_rd0 + (uint32_t)(((2 * (2 * half + tp) + jj) ^ swl) * 16));
+          rawc[2 * half + tp][nf][jj] = *reinterpret_cast<const uint32_t*>(w_buf + nf * 2048 + w_rd0 + (uint32_t)(((2 * (2 * half + tp) + jj) ^ swl) * 16));
   };
 
   // ---- prologue: the first window, chunk 0 and D k-tiles in flight; tile 0 landed; first operands decoded ----
@@ -357,6 +348,22 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_pp_kernel(const GemmArgs a
   for (int tt = 0; tt < D; ++tt)
 #pragma unroll
     for (int j = 0; j < 4; ++j) dma_a(tt, tt, j);
+  // zeros-original: are all zero points of this wave's rows integers the magic subtraction holds exactly?  (asked for behind
+  // the first LDS-DMA pieces: the answer travels with them)
+  if constexpr (F16 && MODE == MD_ZO && P::KIND == DK_INT4 && !(P::OPT & PPO_ZINT_OFF)) {
+    bool ok = true;
+    const uint16_t* zrow = reinterpret_cast<const uint16_t*>(a.zeros);
+    for (int i = 0; i < a.kg; i += 8) {
+      const uint32_t e = rowbase + (uint32_t)i;
+      const u32x4 v = *reinterpret_cast<const u32x4*>(zrow + (e < mlim ? e : mlim));   // (neighbours' elements checked too near the end: conservative)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float z = (float)bits_to_half(v[k >> 1] >> ((k & 1) * 16)) + (float)cx.zf;
+        ok = ok && z == __builtin_truncf(z) && z > -48.f && z < 48.f;
+      }
+    }
+    zint = __all(ok);
+  }
   pp_wait_vmcnt<(D - 1) * 4>();           // tiles 1 .. D-1 may stay in flight
   PP_BARRIER();
   read_words(0);
@@ -394,16 +401,22 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_pp_kernel(const GemmArgs a
       if constexpr (tq == 2) dma_w((t >> 2) + 1, p);       // the next chunk: its four pieces ride with tile 2 (this chunk's words are all in registers by then)
     }
     if constexpr (tq == 0) stamp(t, p * 4 + 1);
+    if constexpr (p == 1) {
+      // the lightest load segment picks up what compute segments 2 and 3 decode from: the next chunk's words (its pieces went
+      // out with tile 2; private to the wave, so its own counter is all the ordering they need: only the two activation pieces
+      // issued since may be outstanding) and, on odd tiles, the next body's Scale / Zeros (their window landed long ago)
+      if constexpr (tq == 3) {
+        if constexpr (!(P::OPT & PPO_ABL_NODMA)) pp_wait_vmcnt<2>();
+        read_words(0);
+      }
+      if constexpr (tq == 1) read_words(1);         // second half of this chunk
+      if constexpr ((tq & 1) == 1) meta_read((t + 1) >> 1);
+    }
     if constexpr (p == 2) {
       // everything of tile t + 1 (and older) has landed when at most the pieces issued in segments 0..2 of this tile (and, with
       // a ring of 4, in tile t - 1) are outstanding; a metadata window issued in between only makes the wait cover one operation more
       if constexpr (!(P::OPT & PPO_ABL_NODMA))
         pp_wait_vmcnt<(D - 2) * 4 + 3 + (tq == 2 ? 3 : 0) + ((D > 2 && tq == 3) ? 4 : 0)>();
-      // ... so the next chunk (its pieces went out with tiles 0 and 1) and the next body's Scale / Zeros can be picked up: the
-      // compute segments 2 and 3 of this tile decode the first operands of the next tile
-      if constexpr (tq == 3) read_words(0);         // first half of the next chunk (landed: it went out with tile 2)
-      if constexpr (tq == 1) read_words(1);         // second half of this chunk
-      if constexpr ((tq & 1) == 1) meta_read((t + 1) >> 1);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if constexpr (tq == 0) stamp(t, p * 4 + 2);
@@ -424,13 +437,13 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_pp_kernel(const GemmArgs a
         asm volatile("" : "+v"(bw[par ^ 1][nf_dec][i]));
       }
     } else if constexpr (jj == 0) {
-      decode(ZI, rawc[tq & 1][nf_dec][1], s2c[nf_dec], zAc[nf_dec], zBc[nf_dec], bw[1][nf_dec]);
+      decode(ZI, rawc[tq][nf_dec][1], s2c[nf_dec], zAc[nf_dec], zBc[nf_dec], bw[1][nf_dec]);
     } else if constexpr ((tq & 1) == 0) {
-      decode(ZI, rawc[(tq + 1) & 1][nf_dec][0], s2c[nf_dec], zAc[nf_dec], zBc[nf_dec], bw[0][nf_dec]);
+      decode(ZI, rawc[tq + 1][nf_dec][0], s2c[nf_dec], zAc[nf_dec], zBc[nf_dec], bw[0][nf_dec]);
     } else {
       // after an odd tile the next tile opens a new k-body: segments 0 and 1 were the last to decode with the old values
       if constexpr (mh == 0) meta_convert(ZI, s2c, zAc, zBc);
-      decode(ZI, rawc[(tq + 1) & 1][nf_dec][0], s2c[nf_dec], zAc[nf_dec], zBc[nf_dec], bw[0][nf_dec]);   // the words read in load segment 2
+      decode(ZI, rawc[(tq + 1) & 3][nf_dec][0], s2c[nf_dec], zAc[nf_dec], zBc[nf_dec], bw[0][nf_dec]);   // (tq == 3: the half chunk read in load segment 1)
     }
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
