@@ -94,18 +94,26 @@ int current_device() {
   return dev;
 }
 
-// RAII: make the stream's device current (and initialised) for one call
+// RAII: make the launch device current (and initialised) for one call.  The device is the stream's; the NULL stream exists
+// on every device (torch's default stream is handle 0 everywhere), so there the device is taken from the operand `ptr`
+// (device memory owned by the caller): A on cuda:1 with cuda:0 current launches on cuda:1's null stream, not cuda:0's.
 struct StreamDeviceScope {
   int prev = -1, dev = -1;
   bool switched = false;
-  explicit StreamDeviceScope(hipStream_t s) {
+  explicit StreamDeviceScope(hipStream_t s, const void* ptr = nullptr) {
     if (device_count_cached() <= 0) return;
     (void)hipGetDevice(&prev);
     dev = prev;
-    if (s != nullptr && g_ndev > 1) {
-      hipDevice_t sd = 0;
-      if (hipStreamGetDevice(s, &sd) == hipSuccess) dev = (int)sd;
-      else (void)hipGetLastError();
+    if (g_ndev > 1) {
+      if (s != nullptr) {
+        hipDevice_t sd = 0;
+        if (hipStreamGetDevice(s, &sd) == hipSuccess) dev = (int)sd;
+        else (void)hipGetLastError();
+      } else if (ptr != nullptr) {
+        hipPointerAttribute_t at;
+        if (hipPointerGetAttributes(&at, ptr) == hipSuccess && at.type == hipMemoryTypeDevice && at.device >= 0 && at.device < g_ndev) dev = at.device;
+        else (void)hipGetLastError();
+      }
     }
     if (dev != prev) switched = hipSetDevice(dev) == hipSuccess;
     ensure_device(dev);
@@ -187,7 +195,7 @@ static int matmul_impl(const wqaa_matmul_desc* desc, const void* A, const void* 
     return WQAA_ERR_BAD_DESC;
   }
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  StreamDeviceScope scope(s);
+  StreamDeviceScope scope(s, A);
   if (!device_info().ok) {
     set_error(WQAA_ERR_NO_DEVICE, "no HIP device visible");
     return WQAA_ERR_NO_DEVICE;
@@ -281,8 +289,8 @@ static bool group_fusable(const wqaa_matmul_desc* const* descs, int count, int m
   char saved_msg[sizeof(g_last_error_msg)];
   memcpy(saved_msg, g_last_error_msg, sizeof(saved_msg));
   bool ok = true;
-  if (epi_mode == 0 && gemvx_group_eligible(*merged, count, m)) *fused_x = 1;
-  else if (gemv_group_eligible(*merged, count, m, epi_mode != 0, epi_mode == 2)) *fused_x = 0;
+  if (epi_mode == 0 && gemvx_group_eligible(*merged, descs, count, m)) *fused_x = 1;
+  else if (gemv_group_eligible(*merged, descs, count, m, epi_mode != 0, epi_mode == 2)) *fused_x = 0;
   else ok = false;
   g_last_error = saved;
   memcpy(g_last_error_msg, saved_msg, sizeof(saved_msg));
@@ -405,7 +413,7 @@ static int group_impl(const wqaa_group_item* items, const wqaa_epilogue* const* 
   }
   if (fuse) {
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    StreamDeviceScope scope(s);
+    StreamDeviceScope scope(s, items[0].A);
     if (!device_info().ok) {
       set_error(WQAA_ERR_NO_DEVICE, "no HIP device visible");
       return WQAA_ERR_NO_DEVICE;
@@ -485,7 +493,7 @@ int wqaa_dequantize(const wqaa_matmul_desc* desc, const void* B, const void* LUT
     return WQAA_ERR_BAD_DESC;
   }
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  StreamDeviceScope scope(s);
+  StreamDeviceScope scope(s, B);
   if (!device_info().ok) {
     set_error(WQAA_ERR_NO_DEVICE, "no HIP device visible");
     return WQAA_ERR_NO_DEVICE;
@@ -496,7 +504,7 @@ int wqaa_dequantize(const wqaa_matmul_desc* desc, const void* B, const void* LUT
 }
 
 int wqaa_act_quant_int8(const void* X, int64_t rows, int K, void* Q, float* S, void* stream) {
-  StreamDeviceScope scope(reinterpret_cast<hipStream_t>(stream));
+  StreamDeviceScope scope(reinterpret_cast<hipStream_t>(stream), X);
   if (!device_info().ok) {
     set_error(WQAA_ERR_NO_DEVICE, "no HIP device visible");
     return WQAA_ERR_NO_DEVICE;
@@ -521,7 +529,7 @@ int wqaa_select(const wqaa_matmul_desc* desc, int m, wqaa_plan* plan) {
 int wqaa_debug_decode(const void* packed_dev, int64_t nwords, int w_format, int bits, int layout,
                       int a_dtype, int strict_reference, const void* lut_dev, void* out_dev,
                       void* stream) {
-  StreamDeviceScope scope(reinterpret_cast<hipStream_t>(stream));
+  StreamDeviceScope scope(reinterpret_cast<hipStream_t>(stream), packed_dev);
   if (!device_info().ok) {
     set_error(WQAA_ERR_NO_DEVICE, "no HIP device visible");
     return WQAA_ERR_NO_DEVICE;

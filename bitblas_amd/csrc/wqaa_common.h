@@ -85,10 +85,10 @@ void gemv_init();
 // exact-product GEMV members (strict_reference = 0, sub-byte integer weights x float16, M <= 2)
 bool gemvx_eligible(const wqaa_matmul_desc& d, int m);
 // groups: `merged` = the members' descriptor with N = the sum of their rows (what selects the tile configuration)
-bool gemvx_group_eligible(const wqaa_matmul_desc& merged, int count, int m);
+bool gemvx_group_eligible(const wqaa_matmul_desc& merged, const wqaa_matmul_desc* const* descs, int count, int m);
 int gemvx_group_plan(const wqaa_matmul_desc& merged, const int* Ns, int count, int m, wqaa_plan* plan);
 int gemvx_group_launch(const wqaa_matmul_desc& merged, const wqaa_group_item* items, int count, int m, hipStream_t stream);
-bool gemv_group_eligible(const wqaa_matmul_desc& merged, int count, int m, bool with_epilogue = false, bool quant_in = false);
+bool gemv_group_eligible(const wqaa_matmul_desc& merged, const wqaa_matmul_desc* const* descs, int count, int m, bool with_epilogue = false, bool quant_in = false);
 int gemv_group_plan(const wqaa_matmul_desc& merged, const int* Ns, int count, int m, wqaa_plan* plan);
 int gemv_group_launch(const wqaa_matmul_desc& merged, const wqaa_group_item* items, int count, int m, hipStream_t stream,
                       const wqaa_epilogue* const* epis = nullptr);

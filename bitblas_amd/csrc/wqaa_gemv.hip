@@ -382,10 +382,19 @@ static int gemv_group_choose(const wqaa_matmul_desc& merged, const int* Ns, int 
   return WQAA_OK;
 }
 
-bool gemv_group_eligible(const wqaa_matmul_desc& merged, int count, int m, bool with_epilogue, bool quant_in) {
+bool gemv_group_eligible(const wqaa_matmul_desc& merged, const wqaa_matmul_desc* const* descs, int count, int m, bool with_epilogue, bool quant_in) {
   if (count < 1 || count > kGemvGroupMax || m < 1 || m > 2) return false;
   GemvChoice c;
   if (choose(merged, m, &c, quant_in) != WQAA_OK) return false;      // (the caller restores the error side channel)
+  // bit-for-bit with the single calls: every member alone must get the merged operator's member variant, K split and depth
+  // (the summation order of a row; see gemvx_group_eligible).  Integer accumulation is order-free: nothing to compare there.
+  if (!at_is_int(c.at)) {
+    for (int i = 0; descs && i < count; ++i) {
+      GemvChoice ci;
+      if (choose(*descs[i], m, &ci, quant_in) != WQAA_OK) return false;
+      if (ci.kw != c.kw || ci.D != c.D) return false;
+    }
+  }
   return !with_epilogue || (at_is_int(c.at) && merged.out_dtype == WQAA_F16);
 }
 

@@ -286,8 +286,20 @@ static int gemvx_group_choose(const wqaa_matmul_desc& merged, const int* Ns, int
   return WQAA_OK;
 }
 
-bool gemvx_group_eligible(const wqaa_matmul_desc& merged, int count, int m) {
-  return count >= 1 && count <= kGemvxGroupMax && gemvx_eligible(merged, m);
+// A fused group must give every member the bits a single call would: the family (exact products vs per-element rounding)
+// and the K split across waves (the fp32 summation order of a row) are chosen from N, so each member ALONE has to land on
+// the merged operator's choice - otherwise the group runs as separate launches.  (Rows per wave, workgroup width, grid and
+// register-resident vs LDS-staged activations do not change a row's arithmetic: tests/test_group_gpu.py.)
+bool gemvx_group_eligible(const wqaa_matmul_desc& merged, const wqaa_matmul_desc* const* descs, int count, int m) {
+  if (count < 1 || count > kGemvxGroupMax || !gemvx_eligible(merged, m)) return false;
+  GemvxChoice cm;
+  if (gemvx_choose(merged, m, &cm) != WQAA_OK) return false;
+  for (int i = 0; descs && i < count; ++i) {
+    GemvxChoice ci;
+    if (!gemvx_eligible(*descs[i], m) || gemvx_choose(*descs[i], m, &ci) != WQAA_OK) return false;
+    if (ci.kw != cm.kw || ci.D != cm.D) return false;
+  }
+  return true;
 }
 
 int gemvx_group_plan(const wqaa_matmul_desc& merged, const int* Ns, int count, int m, wqaa_plan* plan) {

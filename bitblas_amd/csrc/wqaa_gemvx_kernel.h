@@ -257,12 +257,16 @@ __global__ void __launch_bounds__(1024) wq_gemvx_kernel(const GemvxGroupArgs grp
   if constexpr (P::AREG) {
 #pragma unroll
     for (int d = 0; d < D; ++d) {
-      float sum = 0.f;
+      // the same additions in the same order as the LDS-staged members (item_store: one partial per weight word, then
+      // (p0 + p1) + (p2 + p3)): which member a row runs through must not show in its bits (groups fuse members of both kinds)
+      float part[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u)
+      for (int u = 0; u < 4; ++u) {
+        part[u] = 0.f;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) sum = __builtin_amdgcn_fdot2(as_h2(areg[d][u][e]), half2_t{(half_t)1.f, (half_t)1.f}, sum, false);
-      sa_reg[d] = sum;
+        for (int e = 0; e < 4; ++e) part[u] = __builtin_amdgcn_fdot2(as_h2(areg[d][u][e]), half2_t{(half_t)1.f, (half_t)1.f}, part[u], false);
+      }
+      sa_reg[d] = (part[0] + part[1]) + (part[2] + part[3]);
     }
   }
   if constexpr (!(P::ABL & 2) && !P::AREG) {

@@ -237,3 +237,30 @@ def test_linear_group_and_graph_replay():
     torch.cuda.synchronize()
     for l, o in zip(layers, outs):
         assert torch.equal(l(x2), o)
+
+
+def test_groups_whose_members_alone_would_run_differently_stay_bit_identical():
+    """The tile configuration of a fused launch is chosen for the MERGED row count.  Where a member alone would land on
+    another family (M = 2, N < 8192: rounding members; the merged 3 x 4096 would take exact products) or another K split
+    across waves (few rows x long K), fusing would change its bits - those groups run member by member, and either way
+    the result is the single calls', bit for bit."""
+    qkv = [int4_case(4096, M=2, seed=s) for s in (31, 32, 33)]
+    for c in qkv[1:]:
+        c["A"] = qkv[0]["A"]
+    ops = [build(c, False)[0] for c in qkv]
+    launches = wgroup.group_plan(ops, 2)["launches"]
+    run_both(qkv, False, expect_launches=launches)
+    # long K, few rows: a member of 1024 rows splits K four ways alone, the merged 2048 rows would not
+    longk = [int4_case(1024, K=11008, M=1, seed=s) for s in (41, 42)]
+    longk[1]["A"] = longk[0]["A"]
+    ops = [build(c, False)[0] for c in longk]
+    alone, merged = ops[0].plans[1]["split_k"], wgroup.group_plan(ops, 1)
+    if merged["launches"] == 1:
+        assert merged["plan"]["split_k"] == alone, (alone, merged)
+    run_both(longk, False, expect_launches=merged["launches"])
+    for strict in (False, True):
+        longk8 = [int4_case(768, K=8192, M=1, seed=s) for s in (51, 52, 53)]
+        for c in longk8[1:]:
+            c["A"] = longk8[0]["A"]
+        ops = [build(c, strict)[0] for c in longk8]
+        run_both(longk8, strict, expect_launches=wgroup.group_plan(ops, 1)["launches"])
