@@ -112,7 +112,7 @@ def _sampled_rows_check(case, got, rows, exact=False):
 
 
 @pytest.mark.parametrize("M", [16, 128, 4096])
-def test_baseline_c3_uint4_zeros_full_size(M):
+def test_baseline_c3_uint4_zeros_full_size_64_sampled_rows_at_m4096(M):
     """BASELINE c3 at full size.  The oracle checks every row for M <= 128 and 64 sampled rows at
     M = 4096 (each output row depends on its activation row only)."""
     case = make_case(M, 4096, 4096, W_dtype="uint4", group_size=128, with_scaling=True, with_zeros=True,
@@ -132,7 +132,7 @@ def test_baseline_c3_uint4_zeros_full_size(M):
         assert np.array_equal(got2[0::2], got[0::2])
 
 
-def test_baseline_c4_int2_int8_gemm_full_size():
+def test_baseline_c4_int2_int8_gemm_full_size_64_sampled_rows():
     case = make_case(4096, 4096, 4096, W_dtype="int2", A_dtype="int8", out_dtype="int32", seed=4)
     got, mm = hip_output(case)
     assert mm.plans[4096]["kernel_family"] == 2
