@@ -35,6 +35,8 @@ enum : int {
   PPO_ABL_NODMA = 64,    // lab ablations (timing only, results wrong): no LDS-DMA inside the loop,
   PPO_ABL_NOREAD = 128,  //   no operand reads from LDS,
   PPO_ABL_NODEC = 256,   //   no weight decode
+  PPO_ABL_NOBAR = 512,   //   no s_barrier in the loop (wqaa_gemm_mm_kernel.h),
+  PPO_ABL_NOMFMA = 1024, //   no MFMA (wqaa_gemm_mm_kernel.h)
 };
 
 template <int KIND_, int LAYOUT_, int AT_, int MODE_, int FLAGS_, int RING_ = 3, int OPT_ = 0>

@@ -5,7 +5,7 @@
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -I bitblas_amd/csrc tools/gemm_lab.hip \
 //         -L bitblas_amd -lwqaa_hip -Wl,-rpath,'$ORIGIN/../bitblas_amd' -o tools/gemm_lab
 //   tools/gemm_lab [M N K] [--kind u4|i2] [--rounds R] [--iters I] [--only name]
-#include "wqaa_gemm_pp_kernel.h"
+#include "mm_lab_kernel.h"
 
 #include <algorithm>
 #include <cmath>
@@ -69,6 +69,13 @@ static Variant mk8(const char* name) {
   return Variant{name, fn, P::LDS_BYTES};
 }
 
+template <class P>
+static Variant mkmm(const char* name) {
+  gemm_fn fn = wq_gemm_mm_kernel<P>;
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  return Variant{name, fn, P::LDS_BYTES};
+}
+
 static uint32_t rng_state = 12345u;
 static inline uint32_t rng() {
   rng_state ^= rng_state << 13;
@@ -81,6 +88,7 @@ static inline float frand() { return (rng() >> 8) * (1.0f / 16777216.0f); }
 int main(int argc, char** argv) {
   int M = 4096, N = 4096, K = 4096, rounds = 5, iters = 20;
   std::string kind = "u4", only;
+  int nmf_arg = 0;
   std::vector<int> pos;
   for (int i = 1; i < argc; ++i) {
     std::string s = argv[i];
@@ -88,6 +96,7 @@ int main(int argc, char** argv) {
     else if (s == "--rounds" && i + 1 < argc) rounds = atoi(argv[++i]);
     else if (s == "--iters" && i + 1 < argc) iters = atoi(argv[++i]);
     else if (s == "--only" && i + 1 < argc) only = argv[++i];
+    else if (s == "--nmf" && i + 1 < argc) nmf_arg = atoi(argv[++i]);
     else pos.push_back(atoi(argv[i]));
   }
   if (pos.size() >= 3) { M = pos[0]; N = pos[1]; K = pos[2]; }
@@ -153,6 +162,160 @@ int main(int argc, char** argv) {
       exit(2);
     }
   };
+
+  // ---- mid-M streaming member (--kind mm): every split count against the shipped member, partial sums reduced on the host ----
+  if (kind == "mm") {
+    const int nmf = nmf_arg ? nmf_arg : M <= 32 ? 2 : M <= 64 ? 4 : 8;      // tile rows / 16
+    Variant v = nmf == 2 ? mkmm<MMPolicy<DK_INT4, LAYOUT_LOP3, MD_ZO, 1, 2>>("mm32") : nmf == 4 ? mkmm<MMPolicy<DK_INT4, LAYOUT_LOP3, MD_ZO, 2, 2>>("mm64")
+                                                                                             : mkmm<MMPolicy<DK_INT4, LAYOUT_LOP3, MD_ZO, 2, 4>>("mm128");
+    run_ref(0, dC0);
+    CK(hipStreamSynchronize(st));
+    std::vector<_Float16> h0((size_t)M * N);
+    CK(hipMemcpy(h0.data(), dC0, c_bytes, hipMemcpyDeviceToHost));
+    double sr = 0;
+    for (auto x : h0) sr += (double)(float)x * (double)(float)x;
+    const double rms = std::sqrt(sr / ((double)M * N));
+    float* dWS;
+    CK(hipMalloc(&dWS, (size_t)16 * M * N * 4));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    for (int ks : {1, 2, 4, 8, 16}) {
+      if (K / 256 < ks) continue;
+      GemmArgs b;
+      memset(&b, 0, sizeof(b));
+      b.A = dA; b.B = dW[0]; b.scale = dS; b.zeros = dZ; b.C = dC1; b.M = M; b.N = N; b.K = K; b.kg = K / G; b.gq_shift = 0;
+      b.row_bytes = (long)K / 2; b.out_dtype = WQAA_F16; b.tiles_m = (M + 16 * nmf - 1) / (16 * nmf); b.tiles_n = (N + 127) / 128;
+      b.ksplit = ks; b.ws = dWS;
+      const int grid = b.tiles_m * b.tiles_n * ks;
+      void* params[] = {&b};
+      CK(hipMemset(dC1, 0xFF, c_bytes));
+      CK(hipMemset(dWS, 0xFF, (size_t)16 * M * N * 4));
+      CK(hipLaunchKernel(reinterpret_cast<const void*>(v.fn), dim3(grid), dim3(512), params, v.lds, st));
+      CK(hipStreamSynchronize(st));
+      std::vector<float> got((size_t)M * N, 0.f);
+      if (ks == 1) {
+        std::vector<_Float16> h1((size_t)M * N);
+        CK(hipMemcpy(h1.data(), dC1, c_bytes, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < got.size(); ++i) got[i] = (float)h1[i];
+      } else {
+        std::vector<float> part((size_t)ks * M * N);
+        CK(hipMemcpy(part.data(), dWS, part.size() * 4, hipMemcpyDeviceToHost));
+        for (int sidx = 0; sidx < ks; ++sidx)
+          for (size_t i = 0; i < got.size(); ++i) got[i] += part[(size_t)sidx * M * N + i];
+        for (auto& x : got) x = (float)(_Float16)x;
+      }
+      size_t nbad = 0, nan = 0;
+      double worst = 0;
+      for (size_t i = 0; i < got.size(); ++i) {
+        const double p = (double)(float)h0[i], q = got[i];
+        if (!(q == q)) { ++nan; continue; }
+        worst = std::max(worst, std::fabs(p - q));
+        if (std::fabs(p - q) > 1e-3 * std::fabs(p) + 1.5e-3 * rms) ++nbad;
+      }
+      std::vector<double> us;
+      for (int r = 0; r < rounds + 1; ++r) {
+        CK(hipEventRecord(e0, st));
+        for (int it = 0; it < iters; ++it) {
+          b.B = dW[it % NSETS];
+          CK(hipLaunchKernel(reinterpret_cast<const void*>(v.fn), dim3(grid), dim3(512), params, v.lds, st));
+        }
+        CK(hipEventRecord(e1, st));
+        CK(hipEventSynchronize(e1));
+        float ms = 0;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        if (r) us.push_back(ms * 1e3 / iters);
+      }
+      std::sort(us.begin(), us.end());
+      printf("%s ksplit %2d grid %4d : max|diff| %.3e outside %zu nan %zu%s   %8.2f us (main kernel only)\n", v.name, ks, grid, worst, nbad, nan,
+             (nbad || nan) ? "  <-- FAIL" : "", us[us.size() / 2]);
+    }
+    // ablations of the 128-row tile at ksplit 1 (timing only)
+    if (nmf == 8) {
+      struct { const char* name; Variant v; } abl[] = {
+          {"full", mkmm<MMPolicy<DK_INT4, LAYOUT_LOP3, MD_ZO, 2, 4>>("a")},
+          {"no dma in loop", mkmm<MMPolicy<DK_INT4, LAYOUT_LOP3, MD_ZO, 2, 4, PPO_ABL_NODMA>>("a")},
+          {"no A reads", mkmm<MMPolicy<DK_INT4, LAYOUT_LOP3, MD_ZO, 2, 4, PPO_ABL_NOREAD>>("a")},
+          {"no decode", mkmm<MMPolicy<DK_INT4, LAYOUT_LOP3, MD_ZO, 2, 4, PPO_ABL_NODEC>>("a")},
+          {"no barrier", mkmm<MMPolicy<DK_INT4, LAYOUT_LOP3, MD_ZO, 2, 4, PPO_ABL_NOBAR>>("a")},
+          {"no mfma", mkmm<MMPolicy<DK_INT4, LAYOUT_LOP3, MD_ZO, 2, 4, PPO_ABL_NOMFMA>>("a")},
+          {"no dma, no reads", mkmm<MMPolicy<DK_INT4, LAYOUT_LOP3, MD_ZO, 2, 4, PPO_ABL_NODMA | PPO_ABL_NOREAD>>("a")},
+          {"no dma, reads, decode", mkmm<MMPolicy<DK_INT4, LAYOUT_LOP3, MD_ZO, 2, 4, PPO_ABL_NODMA | PPO_ABL_NOREAD | PPO_ABL_NODEC>>("a")},
+          {"barrier + mfma only", mkmm<MMPolicy<DK_INT4, LAYOUT_LOP3, MD_ZO, 2, 4, PPO_ABL_NODMA | PPO_ABL_NOREAD | PPO_ABL_NODEC>>("a")},
+          {"mfma only", mkmm<MMPolicy<DK_INT4, LAYOUT_LOP3, MD_ZO, 2, 4, PPO_ABL_NODMA | PPO_ABL_NOREAD | PPO_ABL_NODEC | PPO_ABL_NOBAR>>("a")},
+      };
+      for (int aks : {1, 8})
+      for (auto& ab : abl) {
+        GemmArgs b;
+        memset(&b, 0, sizeof(b));
+        b.A = dA; b.B = dW[0]; b.scale = dS; b.zeros = dZ; b.C = dC1; b.M = M; b.N = N; b.K = K; b.kg = K / G; b.gq_shift = 0;
+        b.row_bytes = (long)K / 2; b.out_dtype = WQAA_F16; b.tiles_m = (M + 127) / 128; b.tiles_n = (N + 127) / 128;
+        b.ksplit = aks; b.ws = dWS;
+        const int grid = b.tiles_m * b.tiles_n * aks;
+        void* params[] = {&b};
+        std::vector<double> us;
+        for (int r = 0; r < rounds + 1; ++r) {
+          CK(hipEventRecord(e0, st));
+          for (int it = 0; it < iters; ++it) CK(hipLaunchKernel(reinterpret_cast<const void*>(ab.v.fn), dim3(grid), dim3(512), params, ab.v.lds, st));
+          CK(hipEventRecord(e1, st));
+          CK(hipEventSynchronize(e1));
+          float ms = 0;
+          CK(hipEventElapsedTime(&ms, e0, e1));
+          if (r) us.push_back(ms * 1e3 / iters);
+        }
+        std::sort(us.begin(), us.end());
+        printf("ablation ksplit %d: %-24s %8.2f us\n", aks, ab.name, us[us.size() / 2]);
+      }
+    }
+    // in-kernel time line (s_memrealtime, 100 MHz): every wave's stamps relative to the earliest start of the launch
+    for (int ks : {1, 4, 8}) {
+      Variant vt = nmf == 2 ? mkmm<MMPolicy<DK_INT4, LAYOUT_LOP3, MD_ZO, 1, 2, PPO_TRACE>>("mm32t")
+                            : nmf == 4 ? mkmm<MMPolicy<DK_INT4, LAYOUT_LOP3, MD_ZO, 2, 2, PPO_TRACE>>("mm64t") : mkmm<MMPolicy<DK_INT4, LAYOUT_LOP3, MD_ZO, 2, 4, PPO_TRACE>>("mm128t");
+      GemmArgs b;
+      memset(&b, 0, sizeof(b));
+      b.A = dA; b.B = dW[0]; b.scale = dS; b.zeros = dZ; b.C = dC1; b.M = M; b.N = N; b.K = K; b.kg = K / G; b.gq_shift = 0;
+      b.row_bytes = (long)K / 2; b.out_dtype = WQAA_F16; b.tiles_m = (M + 16 * nmf - 1) / (16 * nmf); b.tiles_n = (N + 127) / 128;
+      b.ksplit = ks; b.ws = dWS;
+      const int grid = b.tiles_m * b.tiles_n * ks;
+      unsigned long long* dT;
+      CK(hipMalloc(&dT, (size_t)grid * 64 * 8));
+      CK(hipMemset(dT, 0, (size_t)grid * 64 * 8));
+      b.lut = dT;
+      void* params[] = {&b};
+      for (int rep = 0; rep < 3; ++rep) {
+        b.B = dW[rep % NSETS];
+        CK(hipLaunchKernel(reinterpret_cast<const void*>(vt.fn), dim3(grid), dim3(512), params, vt.lds, st));
+      }
+      CK(hipStreamSynchronize(st));
+      std::vector<unsigned long long> hT((size_t)grid * 64);
+      CK(hipMemcpy(hT.data(), dT, hT.size() * 8, hipMemcpyDeviceToHost));
+      unsigned long long t0 = ~0ull;
+      for (size_t i = 0; i < hT.size(); i += 8) if (hT[i]) t0 = std::min(t0, hT[i]);
+      const char* nm[7] = {"start", "setup done", "dma issued", "first data + barrier", "loop done", "dma drained", "stores done"};
+      printf("time line ksplit %d (us after the first wave's start; median [min .. max] over waves):\n", ks);
+      for (int j = 0; j < 7; ++j) {
+        std::vector<double> v;
+        for (size_t i = 0; i < hT.size(); i += 8) if (hT[i + j]) v.push_back((double)(hT[i + j] - t0) * 0.01);
+        if (v.empty()) continue;
+        std::sort(v.begin(), v.end());
+        printf("  %-22s %7.2f [%7.2f .. %7.2f]\n", nm[j], v[v.size() / 2], v.front(), v.back());
+      }
+      CK(hipFree(dT));
+    }
+    std::vector<double> us;
+    for (int r = 0; r < rounds + 1; ++r) {
+      CK(hipEventRecord(e0, st));
+      for (int it = 0; it < iters; ++it) run_ref(it % NSETS, dC0);
+      CK(hipEventRecord(e1, st));
+      CK(hipEventSynchronize(e1));
+      float ms = 0;
+      CK(hipEventElapsedTime(&ms, e0, e1));
+      if (r) us.push_back(ms * 1e3 / iters);
+    }
+    std::sort(us.begin(), us.end());
+    printf("shipped member (all its launches) : %8.2f us\n", us[us.size() / 2]);
+    return 0;
+  }
 
   // ---- variants ----
   std::vector<Variant> vs;
