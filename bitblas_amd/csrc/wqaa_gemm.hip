@@ -72,7 +72,7 @@ static gemm_fn pick_gemm(int kind, int layout, int at, int mode, int flags, int 
 struct GemmChoice {
   gemm_fn fn;
   int kind, layout, at, mode, flags, bits;
-  int mf, ks, kl, nwaves, bn, ksplit, skinny, decode, wide, pp, pp_shift;
+  int mf, ks, kl, nwaves, bn, ksplit, skinny, decode, wide, pp, pp_shift, pp_bm;
   int tiles_m, tiles_n, lds;
   int fp4_table;
 };
@@ -160,34 +160,65 @@ static int gemm_choose(const wqaa_matmul_desc& d, int m, GemmChoice* c, bool fus
           : m > 128 ? 8 : m > 32 ? 4 : m > 16 ? 2 : 1;
   if (const char* f = getenv("WQAA_GEMM_MF")) c->mf = atoi(f);   // tuning aid
   const int nsteps = d.K / c->ks;
-  // the 256 x 256 tile runs the ping-pong member (wqaa_gemm_pp_kernel.h) where one exists: 4-bit weights x float16 and 2-bit
-  // weights x int8, four k-tiles (256 / 512 k) per trip, groups of 128 * 2^i (Scale / Zeros rows 4-byte aligned: K / g even),
-  // float16 / int32 output through LDS (N a multiple of 8), 32-bit buffer offsets.  WQAA_GEMM_PP=0: the lockstep member.
+  // The ping-pong members (wqaa_gemm_pp_kernel.h), where one exists: 4-bit weights x float16, 2-bit weights x int8, dense fp8;
+  // four k-tiles (256 / 512 / 128 k) per trip, groups of 128 * 2^i (Scale / Zeros rows 4-byte aligned: K / g even), float16 /
+  // int32 output through LDS (N a multiple of 8), 32-bit buffer offsets.  WQAA_GEMM_PP=0: the lockstep members only.
+  // Which tile: a workgroup is alone on its CU, so time goes by ROUNDS of the chip.  Same-box medians, uint4 g128 + zeros, K =
+  // 4096 (profiles/r03_lab_pp128.txt): a round of x 256 x 256 tiles 80 + 0.113 x us (109 full: the chip is power-limited), of
+  // 128 x 256 tiles 55 + 0.052 x (68.5 full), the lockstep 128 x 128 member 12 + 40 per round of 256 tiles, in half rounds.  All
+  // three scale with K and, near enough, together with the formats - only the ratios matter here.
   c->pp = 0;
   c->pp_shift = 0;
-  if (c->mf == 16) {
+  c->pp_bm = 0;
+  if (m > 128 && d.N >= 256) {
     const char* pf = getenv("WQAA_GEMM_PP");
     const int kb = c->at == AT_F16 ? 256 : c->at == AT_F8 ? 128 : 512;   // k per trip of the main loop
     const int gb = c->at == AT_F8 ? 1 : g / (kb / 2);                   // k-bodies (two k-tiles) per group
     const bool meta_ok = c->mode == MD_NONE || (g % (kb / 2) == 0 && ilog2_exact(gb) >= 0 && ((d.K / g) & 1) == 0 && (long)d.N * (d.K / g) >= 8);
     const bool out_ok = c->at == AT_I8 ? d.out_dtype == WQAA_I32 : d.out_dtype == WQAA_F16;
     const long a_bytes = (long)m * d.K * (c->at == AT_F16 ? 2 : 1), w_bytes = (long)d.N * d.K * c->bits / 8;
-    int lds = 0;
-    gemm_fn fn = (!pf || atoi(pf) != 0) ? pick_gemm_pp(c->kind, c->layout, c->at, c->mode, c->flags, &lds) : nullptr;
-    if (fn && !fused_epilogue && d.K % kb == 0 && meta_ok && out_ok && d.N % 8 == 0 && a_bytes + 256L * d.K * 2 < (1L << 31) && w_bytes < (1L << 31) &&
-        d.k_split_hint <= 1 && getenv("WQAA_GEMM_KSPLIT") == nullptr) {
+    const bool shape_ok = !fused_epilogue && d.K % kb == 0 && meta_ok && out_ok && d.N % 8 == 0 && a_bytes + 256L * d.K * 2 < (1L << 31) &&
+                          w_bytes < (1L << 31) && d.k_split_hint <= 1 && getenv("WQAA_GEMM_KSPLIT") == nullptr && (!pf || atoi(pf) != 0);
+    auto rounds_time = [&](long tiles, double base, double slope) {
+      const long full = tiles / cus_, rem = tiles % cus_;
+      return (double)full * (base + slope * cus_) + (rem ? base + slope * (double)rem : 0.0);
+    };
+    const long tiles_n256 = (d.N + 255) / 256;
+    const double t256 = rounds_time((long)((m + 255) / 256) * tiles_n256, 80.0, 0.113);
+    const double t128 = rounds_time((long)((m + 127) / 128) * tiles_n256, 55.0, 0.052);
+    const long tiles_l = (long)((m + 127) / 128) * ((d.N + 127) / 128);
+    // (the lockstep int8 / fp8 members are further behind their ping-pong counterparts than the fp16 one: tools/ab_pp_tile.py,
+    // profiles/r03_ab_pp_tile_*.txt - int2 x int8 M = 1024 4096^2 39.6 vs 34.4 us on the 128-row tile, e4m3 1024 x 8192 x 8192 106 vs 84)
+    const double tlock = (12.0 + 40.0 * 0.5 * (double)((2 * tiles_l + cus_ - 1) / cus_)) * (c->at == AT_I8 ? 1.35 : c->at == AT_F8 ? 1.3 : 1.0);
+    int lds256 = 0, lds128 = 0;
+    gemm_fn fn256 = shape_ok && m >= 256 ? pick_gemm_pp(c->kind, c->layout, c->at, c->mode, c->flags, 256, &lds256) : nullptr;
+    gemm_fn fn128 = shape_ok ? pick_gemm_pp(c->kind, c->layout, c->at, c->mode, c->flags, 128, &lds128) : nullptr;
+    int bm = 0;
+    if (const char* f = getenv("WQAA_GEMM_PP_BM")) {               // tuning aid: force a tile (0: the lockstep members)
+      bm = atoi(f);
+      if ((bm == 256 && !fn256) || (bm == 128 && !fn128)) bm = 0;
+    } else if (getenv("WQAA_GEMM_MF") != nullptr) {
+      bm = (c->mf == 16 && fn256) ? 256 : 0;                       // a forced tile height keeps its round-2 meaning
+    } else {
+      double best = 0.97 * tlock;
+      if (fn256 && t256 < best) { bm = 256; best = t256; }
+      if (fn128 && t128 < best) { bm = 128; best = t128; }
+    }
+    if (bm) {
       c->pp = 1;
+      c->pp_bm = bm;
       c->pp_shift = c->mode == MD_NONE ? 0 : ilog2_exact(gb);
-      c->fn = fn;
+      c->fn = bm == 256 ? fn256 : fn128;
+      c->mf = bm / 16;
       c->nwaves = 8;
       c->bn = 256;
       c->skinny = 0;
       c->decode = 0;
       c->wide = 0;
       c->ks = c->at == AT_F16 ? 64 : 128;
-      c->tiles_m = (m + 255) / 256;
+      c->tiles_m = (m + bm - 1) / bm;
       c->tiles_n = (d.N + 255) / 256;
-      c->lds = lds;
+      c->lds = bm == 256 ? lds256 : lds128;
       c->ksplit = 1;
       return WQAA_OK;
     }
@@ -575,9 +606,11 @@ void gemm_init() {
       for (int at : {AT_F16, AT_I8, AT_F8})
         for (int mode = 0; mode <= MD_ZR; ++mode)
           for (int flags : {0, (int)FL_ABF8}) {
-          int lds = 0;
-          gemm_fn fn = pick_gemm_pp(kind, layout, at, mode, flags, &lds);
-          if (fn) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+          for (int bm : {256, 128}) {
+            int lds = 0;
+            gemm_fn fn = pick_gemm_pp(kind, layout, at, mode, flags, bm, &lds);
+            if (fn) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+          }
         }
   (void)hipGetLastError();   // a refused attribute must not linger as this thread's "last error"
 }

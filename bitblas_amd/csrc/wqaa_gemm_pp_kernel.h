@@ -4,20 +4,21 @@
 // (bitblas/ops/general_matmul/tilelang/dequantize/matmul_dequantize_mma.py:333-508, tilelang/dense/matmul_mma.py:220-320)
 // for M >= 256.  Same computation and the same per-element dequant arithmetic as wq_gemm_kernel (wqaa_gemm_kernel.h);
 // what changes is the machine schedule:
-//   * 256 x 256 tile, 8 waves, every wave owns 32 weight rows (n) and multiplies them by all 256 activation rows.
-//     The matrix instruction is the 32x32 form (v_mfma_f32_32x32x16_f16 / v_mfma_i32_32x32x32_i8: 32 matrix-pipe cycles,
-//     half the issue slots of the 16x16 form per flop), weights as its A operand: a lane owns weight row n = lane & 31
-//     and the k-half h = lane >> 5, so ONE 32-bit word of packed weights (8 int4 / 16 int2) decodes in registers into
-//     exactly one MFMA operand.  Packed weights never become fp16 in LDS;
+//   * 256 x 256 tile (128 x 256 where that fills the chip in fewer rounds), 8 waves, every wave owns 32 weight rows (n) and
+//     multiplies them by all the tile's activation rows.  The matrix instruction is the 16x16 form (v_mfma_f32_16x16x32_f16 /
+//     v_mfma_i32_16x16x64_i8), weights as its A operand: a lane owns weight row n = lane & 15 of a 16-row fragment and the
+//     k-block lane >> 4, so ONE 32-bit word of packed weights (8 int4 / 16 int2) decodes in registers into exactly one MFMA
+//     operand.  Packed weights never become fp16 in LDS.  (The 32x32 form halves the LDS reads per flop but draws more power
+//     per flop - tools/mfma_power.hip: 1774 vs 1950 TFLOP/s sustained on random operands - and the chip is power-limited.)
 //   * every byte from global memory arrives by LDS-DMA (buffer_load ... lds): the activation tile (256 rows x 128 B per
 //     k-tile, XOR-swizzled through the SOURCE address so the ds_read_b128 operand reads are conflict free), the wave's
 //     own packed weights (1 KiB per k-tile, read back by the lane that owns them) and its Scale / Zeros.  One load
 //     KIND in flight means the counted `s_waitcnt vmcnt(N)` is in order, so the prefetch ring (RING k-tiles) is never
 //     drained inside the loop, and no VGPR waits for memory;
 //   * the two waves of a SIMD alternate roles (MI355X_MICROARCH "Two waves per SIMD"): waves 0-3 and waves 4-7 run the
-//     same instruction stream one s_barrier apart, so while one wave of a SIMD is in a COMPUTE segment (8 MFMAs with the
+//     same instruction stream one s_barrier apart, so while one wave of a SIMD is in a COMPUTE segment (16 MFMAs with the
 //     decode of the next weight word interleaved in their shadow), its partner is in a LOAD segment (8 ds_read_b128 for
-//     its next 8 MFMAs, its share of the LDS-DMA issue, the waits).  No register double buffer for the operands: the
+//     its next 16 MFMAs, its share of the LDS-DMA issue, the waits).  No register double buffer for the operands: the
 //     partner's compute covers the LDS latency;
 //   * the output tile leaves through LDS, whole rows per store instruction (the accumulator layout gives a lane 4
 //     consecutive n of one m: 8-byte pieces 512 B apart; the store tail was issue-bound).
@@ -39,23 +40,31 @@ enum : int {
   PPO_ABL_NOMFMA = 1024, //   no MFMA (wqaa_gemm_mm_kernel.h)
 };
 
-template <int KIND_, int LAYOUT_, int AT_, int MODE_, int FLAGS_, int RING_ = 3, int OPT_ = 0>
+// BM_ = 256: the full tile.  BM_ = 128: the same loop on half the activation rows, for shapes whose 256-row tiles would leave the
+// chip short of whole rounds (M = 512 ... 3584 at N = 4096 ... 22016): two phases per k-tile instead of four, so a k-tile
+// lasts half as long and the latencies are covered by depth instead - ring of 5 k-tiles (the slots are half the size) and the
+// weight chunks double buffered, asked for a whole trip ahead.
+template <int KIND_, int LAYOUT_, int AT_, int MODE_, int FLAGS_, int RING_ = 3, int OPT_ = 0, int BM_ = 256>
 struct PPPolicy {
   static constexpr int KIND = KIND_, LAYOUT = LAYOUT_, AT = AT_, MODE = MODE_, FLAGS = FLAGS_, RING = RING_, OPT = OPT_;
   static constexpr int D = RING_ - 1;               // k-tiles of prefetch distance
-  static constexpr int BM = 256, BN = 256, THREADS = 512, NWAVES = 8;
+  static constexpr int BM = BM_, BN = 256, THREADS = 512, NWAVES = 8;
+  static constexpr int NPH = BM_ / 64;              // phases (16 MFMAs per wave each) per k-tile: 4 / 2
+  static constexpr int WBUFS = BM_ == 128 ? 2 : 1;  // weight-chunk buffers per wave
     static constexpr int TILE_ROW = 128;              // bytes of one activation row per k-tile
   static constexpr int KT = AT_ == AT_F16 ? 64 : 128;   // k per tile
   static constexpr int KB = 4 * KT;                 // k per loop trip: four k-tiles = one 128-byte line of every weight row
-  static constexpr int A_SLOT = BM * TILE_ROW;      // 32 KiB
-  static constexpr int W_OFF = RING_ * A_SLOT;      // per wave: one 4 KiB chunk (32 rows x 128 B = four k-tiles)
-  static constexpr int META_OFF = W_OFF + NWAVES * 4096;
+  static constexpr int A_SLOT = BM * TILE_ROW;      // 32 / 16 KiB
+  static constexpr int W_OFF = RING_ * A_SLOT;      // per wave: WBUFS 4 KiB chunks (32 rows x 128 B = four k-tiles)
+  static constexpr int META_OFF = W_OFF + NWAVES * WBUFS * 4096;
   static constexpr bool HAS_META = MODE_ != MD_NONE;
   static constexpr int LDS_USED = META_OFF + (HAS_META ? NWAVES * 2 * 1024 : 0);   // per wave: two 1 KiB windows (8 groups of Scale | Zeros)
-  static constexpr int LDS_BYTES = LDS_USED > BM * BN * 2 ? LDS_USED : BM * BN * 2;   // the epilogue stages the output tile (128 KiB)
+  static constexpr int EPI_BYTES = AT_ == AT_F16 ? BM * BN * 2 : 128 * BN * 4;        // the epilogue stages the output tile (int32: 128 rows a pass)
+  static constexpr int LDS_BYTES = LDS_USED > EPI_BYTES ? LDS_USED : EPI_BYTES;
   using T = KindTraits<KIND_, AT_>;
   static_assert(T::BITS * KT == 256, "one k-tile of a weight row is 32 bytes: 16 per lane half");
-  static_assert(RING_ == 3 || RING_ == 4, "ring of 3 or 4 k-tiles");
+  static_assert(BM_ == 256 || BM_ == 128, "256- or 128-row tile");
+  static_assert(BM_ == 128 ? RING_ == 5 : (RING_ == 3 || RING_ == 4), "ring of 3 or 4 k-tiles (5 for the 128-row tile: its counted wait assumes it)");
   static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 };
 
@@ -141,7 +150,10 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_pp_kernel(const GemmArgs a
   using T = typename P::T;
   constexpr bool F16 = P::AT == AT_F16;
   constexpr int MODE = P::MODE, D = P::D, RING = P::RING;
-  constexpr int NMF = P::BM / 16;       // 16-row activation fragments: 16
+  constexpr int NMF = P::BM / 16;       // 16-row activation fragments: 16 / 8
+  constexpr int NPH = P::NPH, HP = NPH / 2;   // phases per k-tile; phases per MFMA (k-half) of the tile
+  constexpr int WROWS = P::BM / 8;      // activation rows a wave feeds per k-tile: 32 / 16 (NPH pieces of 8)
+  constexpr bool HALF = P::BM == 128;
   constexpr bool ZP = MODE == MD_ZO || MODE == MD_ZR;
   using acc_t = typename std::conditional<F16, f32x4, i32x4>::type;
   typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -191,7 +203,7 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_pp_kernel(const GemmArgs a
   // Two registers serve the four pieces: the offset of piece 0 and the +-64 bytes an odd piece's swizzle moves the granule by;
   // rows and k-tile go through scalar adds.  Rows beyond M are out of the buffer's range (they read as zero, never stored).
   const int g0_ = (lane & 7) ^ ((lane >> 4) & 7);
-  const uint32_t a_v0 = (uint32_t)(wave * 32 + (lane >> 3)) * (uint32_t)a_row_bytes + (uint32_t)(g0_ * 16);
+  const uint32_t a_v0 = (uint32_t)(wave * WROWS + (lane >> 3)) * (uint32_t)a_row_bytes + (uint32_t)(g0_ * 16);
   const int a_vd = ((g0_ ^ 4) - g0_) * 16;
   const uint32_t a_rows0 = (uint32_t)m0 * (uint32_t)a_row_bytes;
   // weight piece p of a chunk: rows [8p, 8p + 8) of this wave's 32, the 128-byte line that holds four k-tiles of the row,
@@ -219,19 +231,19 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_pp_kernel(const GemmArgs a
   };
 
   unsigned char* const a_ring = smem;
-  unsigned char* const w_buf = smem + P::W_OFF + wave * 4096;
+  unsigned char* const w_buf = smem + P::W_OFF + wave * (P::WBUFS * 4096);
   unsigned char* const meta = smem + P::META_OFF + wave * 2048;
 
   auto dma_a = [&](int tt, int slot, int j) {       // activation piece j of k-tile tt -> ring slot
     const int tc = tt < ntiles ? tt : ntiles - 1;
-    unsigned char* dst = a_ring + slot * P::A_SLOT + (wave * 32 + j * 8) * P::TILE_ROW;
+    unsigned char* dst = a_ring + slot * P::A_SLOT + (wave * WROWS + j * 8) * P::TILE_ROW;
     const uint32_t rows = a_rows0 + (uint32_t)(j * 8) * (uint32_t)a_row_bytes;     // scalar
     const uint32_t voff = (j & 1) ? a_v0 + (uint32_t)a_vd + rows : a_v0 + rows;
     __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (lds_ptr_t)dst, 16, voff, tc * P::TILE_ROW, 0, 0);
   };
-  auto dma_w = [&](int chunk, int p) {
+  auto dma_w = [&](int chunk, int p, int buf) {
     const int cc = chunk < nchunks ? chunk : nchunks - 1;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_ptr_t)(w_buf + p * 1024), 16, w_voff(p), cc * 128, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_ptr_t)(w_buf + buf * 4096 + p * 1024), 16, w_voff(p), cc * 128, 0, 0);
   };
   auto dma_meta = [&](int q) {                      // window q -> buffer q & 1
     if constexpr (P::HAS_META) {
@@ -329,7 +341,7 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_pp_kernel(const GemmArgs a
     if constexpr (F16) pp_decode_f16<P, decltype(ZI)::value != 0>(w, cx.zf, s2, zA, zB, cx, lut, out);
     else pp_decode_i8<P>(w, zp4, cx.flip, out);
   };
-  auto read_words = [&](int half) {        // k-tiles 2 * half, 2 * half + 1 of the landed chunk -> registers
+  auto read_words = [&](int half, int buf) {        // k-tiles 2 * half, 2 * half + 1 of the landed chunk (in buffer buf) -> registers
     const int l = pp_opaque(lane);
     const uint32_t w_rd0 = (uint32_t)((l & 15) * 128 + (l >> 4) * 4);
     const int swl = ((l & 15) >> 1) & 7;
@@ -339,17 +351,19 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_pp_kernel(const GemmArgs a
       for (int nf = 0; nf < 2; ++nf)
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj)
-          rawc[2 * half + tp][nf][jj] = *reinterpret_cast<const uint32_t*>(w_buf + nf * 2048 + w_rd0 + (uint32_t)(((2 * (2 * half + tp) + jj) ^ swl) * 16));
+          rawc[2 * half + tp][nf][jj] = *reinterpret_cast<const uint32_t*>(w_buf + buf * 4096 + nf * 2048 + w_rd0 + (uint32_t)(((2 * (2 * half + tp) + jj) ^ swl) * 16));
   };
 
   // ---- prologue: the first window, chunk 0 and D k-tiles in flight; tile 0 landed; first operands decoded ----
   dma_meta(0);
 #pragma unroll
-  for (int p = 0; p < 4; ++p) dma_w(0, p);
+  for (int b = 0; b < P::WBUFS; ++b)
+#pragma unroll
+    for (int p = 0; p < 4; ++p) dma_w(b, p, b);
 #pragma unroll
   for (int tt = 0; tt < D; ++tt)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) dma_a(tt, tt, j);
+    for (int j = 0; j < NPH; ++j) dma_a(tt, tt, j);
   // zeros-original: are all zero points of this wave's rows integers the magic subtraction holds exactly?  (asked for behind
   // the first LDS-DMA pieces: the answer travels with them)
   if constexpr (F16 && MODE == MD_ZO && P::KIND == DK_INT4 && !(P::OPT & PPO_ZINT_OFF)) {
@@ -366,9 +380,9 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_pp_kernel(const GemmArgs a
     }
     zint = __all(ok);
   }
-  pp_wait_vmcnt<(D - 1) * 4>();           // tiles 1 .. D-1 may stay in flight
+  pp_wait_vmcnt<(D - 1) * NPH>();         // tiles 1 .. D-1 may stay in flight
   PP_BARRIER();
-  read_words(0);
+  read_words(0, 0);
   meta_read(0);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   if (zint) {
@@ -387,7 +401,7 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_pp_kernel(const GemmArgs a
   int slot = 0;                            // ring slot of the k-tile in hand
   auto load_segment = [&](auto TQ, auto PH, int t) {
     constexpr int tq = decltype(TQ)::value, p = decltype(PH)::value;
-    constexpr int jj = p >> 1, mh = p & 1;
+    constexpr int jj = p / HP, mh = p % HP;
     const unsigned char* sl = a_ring + slot * P::A_SLOT;
     if constexpr (tq == 0) stamp(t, p * 4 + 0);
     if constexpr (P::OPT & PPO_ABL_NOREAD) {
@@ -400,25 +414,44 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_pp_kernel(const GemmArgs a
     if constexpr (!(P::OPT & PPO_ABL_NODMA)) {
       const int dslot = slot + D >= RING ? slot + D - RING : slot + D;
       dma_a(t + D, dslot, p);
-      if constexpr (tq == 2) dma_w((t >> 2) + 1, p);       // the next chunk: its four pieces ride with tile 2 (this chunk's words are all in registers by then)
+      // the next chunk: its four pieces ride with tile 2 (this chunk's words are all in registers by then).  128-row tile: the
+      // chunk after next, behind the last activation piece of the tile, into the buffer this chunk has left
+      if constexpr (!HALF && tq == 2) dma_w((t >> 2) + 1, p, 0);
+      if constexpr (HALF && tq == 2 && p == 1) {
+#pragma unroll
+        for (int pc = 0; pc < 4; ++pc) dma_w((t >> 2) + 2, pc, (t >> 2) & 1);
+      }
     }
     if constexpr (tq == 0) stamp(t, p * 4 + 1);
-    if constexpr (p == 1) {
+    if constexpr (!HALF && p == 1) {
       // the lightest load segment picks up what compute segments 2 and 3 decode from: the next chunk's words (its pieces went
       // out with tile 2; private to the wave, so its own counter is all the ordering they need: only the two activation pieces
       // issued since may be outstanding) and, on odd tiles, the next body's Scale / Zeros (their window landed long ago)
       if constexpr (tq == 3) {
         if constexpr (!(P::OPT & PPO_ABL_NODMA)) pp_wait_vmcnt<2>();
-        read_words(0);
+        read_words(0, 0);
       }
-      if constexpr (tq == 1) read_words(1);         // second half of this chunk
+      if constexpr (tq == 1) read_words(1, 0);      // second half of this chunk
       if constexpr ((tq & 1) == 1) meta_read((t + 1) >> 1);
     }
-    if constexpr (p == 2) {
+    if constexpr (!HALF && p == 2) {
       // everything of tile t + 1 (and older) has landed when at most the pieces issued in segments 0..2 of this tile (and, with
       // a ring of 4, in tile t - 1) are outstanding; a metadata window issued in between only makes the wait cover one operation more
       if constexpr (!(P::OPT & PPO_ABL_NODMA))
         pp_wait_vmcnt<(D - 2) * 4 + 3 + (tq == 2 ? 3 : 0) + ((D > 2 && tq == 3) ? 4 : 0)>();
+    }
+    if constexpr (HALF && p == 0) {
+      // what compute segment 1 decodes from.  The chunk read here went out a trip and more ago: older than the activation
+      // tile the previous k-tile's wait completed, so it has landed (vmcnt retires in order)
+      if constexpr (tq == 3) read_words(0, ((t >> 2) + 1) & 1);
+      if constexpr (tq == 1) read_words(1, (t >> 2) & 1);
+      if constexpr ((tq & 1) == 1) meta_read((t + 1) >> 1);
+    }
+    if constexpr (HALF && p == 1) {
+      // k-tile t + 1 went out in tile t - 3; since then: two activation pieces per tile of t - 2 .. t and the four weight pieces
+      // of whichever of t - 3 .. t is a chunk's third tile (they follow that tile's last activation piece)
+      static_assert(!HALF || D == 4, "the count below");
+      if constexpr (!(P::OPT & PPO_ABL_NODMA)) pp_wait_vmcnt<10>();
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if constexpr (tq == 0) stamp(t, p * 4 + 2);
@@ -426,13 +459,31 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_pp_kernel(const GemmArgs a
   };
   auto compute_segment = [&](auto ZI, auto TQ, auto PH, int t) {
     constexpr int tq = decltype(TQ)::value, p = decltype(PH)::value;
-    constexpr int jj = p >> 1, mh = p & 1;
+    constexpr int jj = p / HP, mh = p % HP;
     constexpr int par = jj;                // operand pair in use; the other one is being decoded
     if constexpr (tq == 0) stamp(t, p * 4 + 3);
     // the next pair of operands, one weight fragment per phase: MFMA 1 of this tile, then MFMA 0 of the next tile (with the
     // next body's Scale / Zeros after an odd tile)
     constexpr int nf_dec = mh;
-    if constexpr (P::OPT & PPO_ABL_NODEC) {
+    if constexpr (HALF) {
+      // one phase per MFMA of the tile: both weight fragments are decoded in it
+      if constexpr (P::OPT & PPO_ABL_NODEC) {
+#pragma unroll
+        for (int nf = 0; nf < 2; ++nf)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            bw[par ^ 1][nf][i] = bw[par][nf][i];
+            asm volatile("" : "+v"(bw[par ^ 1][nf][i]));
+          }
+      } else if constexpr (jj == 0) {
+#pragma unroll
+        for (int nf = 0; nf < 2; ++nf) decode(ZI, rawc[tq][nf][1], s2c[nf], zAc[nf], zBc[nf], bw[1][nf]);
+      } else {
+        if constexpr ((tq & 1) == 1) meta_convert(ZI, s2c, zAc, zBc);
+#pragma unroll
+        for (int nf = 0; nf < 2; ++nf) decode(ZI, rawc[(tq + 1) & 3][nf][0], s2c[nf], zAc[nf], zBc[nf], bw[0][nf]);
+      }
+    } else if constexpr (P::OPT & PPO_ABL_NODEC) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         bw[par ^ 1][nf_dec][i] = bw[par][nf_dec][i];
@@ -464,7 +515,7 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_pp_kernel(const GemmArgs a
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-      __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, HALF ? 5 : 3, 0);
     }
     PP_BARRIER();
   };
@@ -473,10 +524,12 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_pp_kernel(const GemmArgs a
     compute_segment(ZI, TQ, ic<0>{}, t);
     load_segment(TQ, ic<1>{}, t);
     compute_segment(ZI, TQ, ic<1>{}, t);
-    load_segment(TQ, ic<2>{}, t);
-    compute_segment(ZI, TQ, ic<2>{}, t);
-    load_segment(TQ, ic<3>{}, t);
-    compute_segment(ZI, TQ, ic<3>{}, t);
+    if constexpr (NPH == 4) {
+      load_segment(TQ, ic<(NPH == 4 ? 2 : 0)>{}, t);
+      compute_segment(ZI, TQ, ic<(NPH == 4 ? 2 : 0)>{}, t);
+      load_segment(TQ, ic<(NPH == 4 ? 3 : 0)>{}, t);
+      compute_segment(ZI, TQ, ic<(NPH == 4 ? 3 : 0)>{}, t);
+    }
     slot = slot + 1 == RING ? 0 : slot + 1;
   };
   auto main_loop = [&](auto ZI) {
@@ -550,10 +603,10 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_pp_kernel(const GemmArgs a
     }
     PP_FENCE();
     __syncthreads();
-    // a wave stores its 32 rows, two per instruction: lane c = lane & 31 takes the 16-byte pair c of row m
+    // a wave stores its 32 (16) rows, two per instruction: lane c = lane & 31 takes the 16-byte pair c of row m
 #pragma unroll
-    for (int rr = 0; rr < 16; ++rr) {
-      const int m = wave * 32 + rr * 2 + e_h;
+    for (int rr = 0; rr < WROWS / 2; ++rr) {
+      const int m = wave * WROWS + rr * 2 + e_h;
       const int c = e_ln;
       u32x4 x = *reinterpret_cast<const u32x4*>(smem + m * 512 + ((c ^ (m & 7)) * 16));
       if ((m >> 3) & 1) x = u32x4{x[2], x[3], x[0], x[1]};
@@ -573,11 +626,11 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_pp_kernel(const GemmArgs a
         bias_i[nf][i] = a.has_bias ? (int)reinterpret_cast<const int8_t*>(a.bias)[n < a.N ? n : a.N - 1] : 0;
       }
 #pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
+    for (int pass = 0; pass < P::BM / 128; ++pass) {
       if (pass) __syncthreads();
 #pragma unroll
-      for (int ff = 0; ff < NMF / 2; ++ff) {
-        const int f = pass * (NMF / 2) + ff;
+      for (int ff = 0; ff < 8; ++ff) {
+        const int f = pass * 8 + ff;
         const int ml = ff * 16 + e_fr;       // row inside the pass
 #pragma unroll
         for (int nf = 0; nf < 2; ++nf) {

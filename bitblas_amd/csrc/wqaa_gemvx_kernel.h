@@ -71,7 +71,8 @@ struct GemvxGroupArgs {
 };
 
 // ABL_: ablation bits for tools/ (lab members only, never selected by the library): 1 = loads consumed by one XOR
-// instead of the decode + dot, 2 = no activation staging / barrier, 4 = no wave reduction / store, 8 = no store
+// instead of the decode + dot, 2 = no activation staging / barrier, 4 = no wave reduction / store, 8 = no store,
+// 64 = time line: s_memrealtime stamps per wave written through a.bias ([workgroup][wave][8]; tools/gemv_lab.hip)
 // AREG_: the lane keeps the activations of its own lane chunks in registers (4-bit LOP3 weights, M = 1, K within one
 // step): the LOP3 interleave puts consecutive elements 2j, 2j + 1 into the two halves of field j, so the natural-order
 // activation dword j IS the partner of masked field j - no LDS tile, no staging pass, no barrier; the chunk's
@@ -120,6 +121,21 @@ __global__ void __launch_bounds__(1024) wq_gemvx_kernel(const GemvxGroupArgs grp
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nthreads = blockDim.x;
   const int NW = nthreads >> 6;
+  unsigned long long tr_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  auto stamp = [&](int i) {
+    if constexpr ((P::ABL & 64) != 0) tr_[i] = __builtin_amdgcn_s_memrealtime();
+  };
+  auto trace_out = [&]() {
+    if constexpr ((P::ABL & 64) != 0) {
+      if (lane == 0 && a.bias) {
+        unsigned long long* dst = reinterpret_cast<unsigned long long*>(const_cast<void*>(a.bias)) +
+                                  (((long)blockIdx.y * gridDim.x + blockIdx.x) * NW + wave) * 8;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) dst[i] = tr_[i];
+      }
+    }
+  };
+  stamp(0);
   // The prologue is a latency chain in front of the first load (kernel-argument fetch -> address arithmetic -> issue)
   // that nothing overlaps with: fetch every argument it needs in ONE scalar round trip (the compiler otherwise fetches
   // them where first used, three dependent s_load waits before the weight loads), and keep integer divisions out of
@@ -253,6 +269,7 @@ __global__ void __launch_bounds__(1024) wq_gemvx_kernel(const GemvxGroupArgs grp
   Stage st[D];
 #pragma unroll
   for (int d = 0; d < D; ++d) issue(st[d], 0, 0, d);
+  stamp(1);
 
   if constexpr (P::AREG) {
 #pragma unroll
@@ -285,6 +302,7 @@ __global__ void __launch_bounds__(1024) wq_gemvx_kernel(const GemvxGroupArgs grp
     }
     __syncthreads();
   }
+  stamp(2);
   if (total <= 0) return;
 
   const float zint = (float)a.zint;
@@ -491,6 +509,12 @@ __global__ void __launch_bounds__(1024) wq_gemvx_kernel(const GemvxGroupArgs grp
     if (si2 == nmy) { si2 = 0; ++it2; }
     static_assert(D == 2, "two lane chunks per step");
     {
+      if constexpr ((P::ABL & 64) != 0) {
+        if (q == 0) {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          stamp(3);
+        }
+      }
       consume(st[0], c, rg_now, std::integral_constant<int, 0>{});
       ++c;
       // order fence by DATA dependence: the next chunk's LDS addresses and the next position's global addresses are
@@ -508,9 +532,18 @@ __global__ void __launch_bounds__(1024) wq_gemvx_kernel(const GemvxGroupArgs grp
 #pragma unroll
       for (int d = 0; d < D; ++d) issue(st[d], it2, si2, d);
     }
+    if constexpr ((P::ABL & 64) != 0) {
+      if (q == 0) stamp(4);
+      if (q + 1 == total) stamp(5);
+    }
     if (si2 == 0) finish(it);
     it = it2;
     si = si2;
+  }
+  if constexpr ((P::ABL & 64) != 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    stamp(6);
+    trace_out();
   }
 }
 

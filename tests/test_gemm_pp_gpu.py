@@ -1,9 +1,9 @@
-"""The ping-pong 256 x 256 MFMA member (csrc/wqaa_gemm_pp_kernel.h) against the CPU oracle.
+"""The ping-pong MFMA members (csrc/wqaa_gemm_pp_kernel.h: 256 x 256 and 128 x 256 tiles) against the CPU oracle.
 
-The selector takes it for large M (one 256 x 256 tile per CU and more); `WQAA_GEMM_MF=16` (a plan-time tuning aid) pins the
-256-row tile so that its edge cases run at sizes the oracle finishes in seconds: ragged M and N, one trip of the main loop,
-every dequant mode it implements, integer and non-integer zero points (two decode paths), both checkpoint layouts, bias.
-BASELINE c3 / c4 at full size run through it in tests/test_gemm_gpu.py."""
+The selector takes them for large M by an estimate of the rounds of the chip each tile needs; `WQAA_GEMM_PP_BM=256 / 128` (a
+plan-time tuning aid) pins the tile so that its edge cases run at sizes the oracle finishes in seconds: ragged M and N, one trip
+of the main loop, every dequant mode it implements, integer and non-integer zero points (two decode paths), both checkpoint
+layouts, bias.  BASELINE c3 / c4 at full size run through the 256-row tile in tests/test_gemm_gpu.py."""
 import numpy as np
 import pytest
 import torch
@@ -13,15 +13,18 @@ from helpers import assert_fp_parity, hip_output, make_case, oracle_output
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True)
-def pin_the_256_row_tile(monkeypatch):
-    monkeypatch.setenv("WQAA_GEMM_MF", "16")
+@pytest.fixture(autouse=True, params=[256, 128], ids=["tile256", "tile128"])
+def pin_the_tile(monkeypatch, request):
+    monkeypatch.setenv("WQAA_GEMM_PP_BM", str(request.param))
+    return request.param
 
 
 def _run(case, M, exact=False):
+    import os
     got, mm = hip_output(case)
     plan = mm.plans[M]
     assert plan["kernel_family"] == 2 and plan["name"].endswith("pp"), plan["name"]
+    assert f"_tcx{os.environ['WQAA_GEMM_PP_BM']}x256x" in plan["name"], plan["name"]
     want = oracle_output(case)
     if exact:
         assert np.array_equal(got, want)
@@ -90,8 +93,10 @@ def test_int2_int8_bias_bit_exact():
 @pytest.mark.parametrize("a_dt,w_dt", [("e4m3_float8", "e4m3_float8"), ("e5m2_float8", "e4m3_float8"), ("e4m3_float8", "e5m2_float8"),
                                        ("e5m2_float8", "e5m2_float8")])
 @pytest.mark.parametrize("M,N,K", [(300, 520, 512), (256, 256, 128), (513, 264, 1152)])
-def test_dense_fp8_pairings_ragged(a_dt, w_dt, M, N, K):
+def test_dense_fp8_pairings_ragged(a_dt, w_dt, M, N, K, pin_the_tile):
     """BASELINE c5's kernel at sizes where the oracle checks EVERY element: ragged M / N, one k-tile, all four fp8 pairings"""
+    if pin_the_tile != 256:
+        pytest.skip("the dense fp8 member has the 256-row tile only")
     import bitblas_amd as bitblas
     import wqaa_oracle as oracle
     tdt = {"e4m3_float8": torch.float8_e4m3fn, "e5m2_float8": torch.float8_e5m2}
@@ -109,8 +114,9 @@ def test_dense_fp8_pairings_ragged(a_dt, w_dt, M, N, K):
     assert_fp_parity(out.float().cpu().numpy(), want.astype(np.float16).astype(np.float32), rtol=1e-3, atol_frac=1e-4)
 
 
-def test_what_the_member_does_not_cover_falls_back():
-    """bfloat16 activations, float32 output, quantized zeros, per-channel scales, K off the 256 grid: the lockstep member."""
+def test_what_the_member_does_not_cover_falls_back(monkeypatch):
+    """bfloat16 activations, float32 output, quantized zeros, per-channel scales, K off the 256 grid: the lockstep member
+    (whichever tile is asked for)."""
     import bitblas_amd as bitblas
     for kw in (dict(A_dtype="bfloat16", out_dtype="bfloat16", accum_dtype="float32", W_dtype="uint4", group_size=128, with_scaling=True),
                dict(A_dtype="float16", out_dtype="float32", accum_dtype="float32", W_dtype="uint4", group_size=128, with_scaling=True),

@@ -33,6 +33,13 @@ def configurations():
                 with_scaling=True, **f16)
     add("c3", [3, 8, 16, 32, 64, 128, 256, 1024, 4096], N=4096, K=4096, W_dtype="uint4", group_size=128, with_scaling=True,
         with_zeros=True, zeros_mode="original", **f16)
+    # prefill-sized M between the decode batches and the full chip: which ping-pong tile (256 / 128 rows) or the lockstep member
+    add("c3_prefill", [512, 1024, 1536, 2048, 2560, 3072, 8192], N=4096, K=4096, W_dtype="uint4", group_size=128, with_scaling=True,
+        with_zeros=True, zeros_mode="original", **f16)
+    add("c3_prefill_n11008", [256, 512, 1024, 2048, 4096], N=11008, K=4096, W_dtype="uint4", group_size=128, with_scaling=True,
+        with_zeros=True, zeros_mode="original", **f16)
+    add("c4_prefill", [1024, 2048], N=4096, K=4096, W_dtype="int2", **i8)
+    add("c5_prefill", [1024, 2048], N=8192, K=8192, **f8)
     add("c3_quantized_zeros", [16, 128, 4096], N=4096, K=4096, W_dtype="uint4", group_size=128, with_scaling=True,
         with_zeros=True, zeros_mode="quantized", **f16)
     add("c4", [1, 2, 16, 128, 4096], N=4096, K=4096, W_dtype="int2", **i8)

@@ -53,13 +53,14 @@ struct Variant {
   const char* name;
   gemm_fn fn;
   int lds;
+  int bm = 256;
 };
 
 template <class P>
 static Variant mk(const char* name) {
   gemm_fn fn = wq_gemm_pp_kernel<P>;
   CK(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  return Variant{name, fn, P::LDS_BYTES};
+  return Variant{name, fn, P::LDS_BYTES, P::BM};
 }
 
 template <class P>
@@ -323,10 +324,16 @@ int main(int argc, char** argv) {
     vs.push_back(mk8<PP8Policy<0, 0>>("pp8_e4m3"));
   } else if (!i2) {
     LAB_F16_VARIANTS(LAB_PUSH)
+    vs.push_back(mk<PPPolicy<DK_INT4, LAYOUT_LOP3, AT_F16, MD_ZO, 0, 5, 0, 128>>("pp128"));
+    vs.push_back(mk<PPPolicy<DK_INT4, LAYOUT_LOP3, AT_F16, MD_ZO, 0, 5, PPO_ABL_NODMA | PPO_ABL_NOREAD | PPO_ABL_NODEC, 128>>("abl128_all"));
   } else {
     LAB_I8_VARIANTS(LAB_PUSH)
+    vs.push_back(mk<PPPolicy<DK_INT2, LAYOUT_LOP3, AT_I8, MD_NONE, 0, 5, 0, 128>>("pp128_i2"));
   }
-  if (!only.empty()) vs.erase(std::remove_if(vs.begin(), vs.end(), [&](const Variant& v) { return only != v.name; }), vs.end());
+  if (!only.empty()) {             // --only a,b,c
+    const std::string list = "," + only + ",";
+    vs.erase(std::remove_if(vs.begin(), vs.end(), [&](const Variant& v) { return list.find("," + std::string(v.name) + ",") == std::string::npos; }), vs.end());
+  }
 
   GemmArgs a;
   memset(&a, 0, sizeof(a));
@@ -345,8 +352,10 @@ int main(int argc, char** argv) {
     GemmArgs b = a;
     b.B = dW[set];
     b.C = C;
+    b.tiles_m = (M + v.bm - 1) / v.bm;
+    b.group_m = b.tiles_m >= 4 ? 4 : 1;
     void* params[] = {&b};
-    CK(hipLaunchKernel(reinterpret_cast<const void*>(v.fn), dim3(a.tiles_m * a.tiles_n), dim3(512), params, v.lds, st));
+    CK(hipLaunchKernel(reinterpret_cast<const void*>(v.fn), dim3(b.tiles_m * b.tiles_n), dim3(512), params, v.lds, st));
   };
 
   // ---- parity against the shipped member ----
