@@ -61,8 +61,17 @@ def test_weight_only_linear(W_dtype, group_size, zeros_mode, m):
     want = oracle.matmul_dequant(A, codes, source_format="uint", bit=bit, scale=scale, zeros=zeros,
                                  zeros_mode=zeros_mode, group_size=g, bias=bias)
     # `Linear` runs the library's default members: at M <= 2 the exact-product GEMV (no per-element rounding of B_decode), held
-    # to rtol 1e-3 + 1.5e-3 rms against the TE definition like tests/test_gemvx_gpu.py (one float16 ulp of the output at most)
-    assert_fp_parity(got, want, atol_frac=1.5e-3 if m <= 2 else 1e-3)
+    # to rtol 1e-3 + 1.5e-3 rms against the TE definition like tests/test_gemvx_gpu.py (one float16 ulp of the output at most).
+    # One group over all of K (group_size = -1) is where the TE definition's per-element rounding averages out least: here the
+    # REAL-valued product (float64 below) sits 1.6e-3 rms from it at one of the 1024 outputs - so that case gets 2e-3 against the
+    # definition, and every M <= 2 case is also held to 1e-3 against the real-valued product, which is what the member computes
+    assert_fp_parity(got, want, atol_frac=(2e-3 if group_size == -1 else 1.5e-3) if m <= 2 else 1e-3)
+    if m <= 2 and zeros_mode != "quantized":
+        zf = np.repeat(zeros.astype(np.float64), g, axis=1)
+        sf = np.repeat(scale.astype(np.float64), g, axis=1)
+        bdec = (codes.astype(np.float64) - zf) * sf if zeros_mode == "original" else codes.astype(np.float64) * sf - zf
+        real = (A.astype(np.float64) @ bdec.T).astype(np.float16)
+        assert_fp_parity(got, (real + bias).astype(np.float16), atol_frac=1e-3)
     # the module round-trips through state_dict (checkpoint layout = the kernel operand layout)
     lin2 = bitblas.Linear(K, N, bias=True, A_dtype="float16", W_dtype=W_dtype, group_size=group_size, with_scaling=True,
                           with_zeros=True, zeros_mode=zeros_mode, opt_M=[1, 16, 128], enable_tuning=False).cuda()
