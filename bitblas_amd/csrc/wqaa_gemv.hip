@@ -149,11 +149,9 @@ static int choose(const wqaa_matmul_desc& d, int m, GemvChoice* c, bool quant_in
     }
     c->flags |= FL_AQ;
   }
-  // WQAA_GEMV_DIRECT_FIT=1 (queued A/B): the register-resident member only where its activation
-  // slice fits the register file - mb * D * E elements per lane, i.e. mb * E * sizeof(A) <= 128 bytes per lane chunk for the
-  // 64 dwords a 128-VGPR kernel can spare.  4-bit weights pass at M <= 2, 2-bit at M = 1; 1-bit (and 2-bit at M = 2) members
-  // compile to 440-3400 B of scratch per lane today (profiles/r02_static_isa.txt) and would go to their LDS-staged twins.
-  const bool slice_fits = mb * c->E * (c->at == AT_F16 ? 2 : 1) <= 128 || !getenv("WQAA_GEMV_DIRECT_FIT");
+  // the register-resident member only where its activation slice fits the register file (gemv_direct_fits, wqaa_gemv_kernel.h:
+  // the members that spilled are not built; same-process A/B in profiles/r03_ab_direct_fit.txt)
+  const bool slice_fits = mb * c->E * (c->at == AT_F16 ? 2 : 1) <= 128;
   const bool direct = mb <= 2 && m == mb && !(c->flags & (FL_A8 | FL_AQ)) && c->at != AT_I4 && c->ncp == c->D && (d.N + c->R - 1) / c->R <= 10 * cus0 &&
                       slice_fits && !getenv("WQAA_GEMV_NO_DIRECT");
   // small matrices: one row per wave doubles the waves in flight (same-box A/B: 1024 x 1024 2.87 -> 2.45 us,

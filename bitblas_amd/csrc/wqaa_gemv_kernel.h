@@ -819,13 +819,29 @@ static constexpr int kDirectTile = 101;   // pick_mb code of the M = 1 "activati
 static constexpr int kSplitTile = 200;    // + mb (1, 2): the K-split twins of the LDS-staged members
 static constexpr int kBatchTiles[] = {1, kDirectTile, kDirectTile + 1, kDirectTile + 2, 2, 4, kSplitTile + 1, kSplitTile + 2};
 
+// The register-resident ("direct") members exist only where the activation slice of a lane chunk fits the register file:
+// mb * E elements of 2 (1) bytes <= 128 bytes for the 64 dwords a 128-VGPR kernel can spare.  4-bit weights pass at M <= 2,
+// 2-bit x fp16 at M = 1, 1-bit x fp16 never: those compiled to 440 - 3400 B of scratch per lane with the reloads inside the row
+// loop and ran 5 - 23 x slower than their LDS-staged twins (profiles/r03_ab_direct_fit.txt: uint1 x fp16 M = 2 4096^2 220.6 vs
+// 9.5 us, uint2 51.0 vs 6.0, int1 x int8 40.8 vs 6.8) - they are not built, and gemv_choose asks for the same condition.
+template <int KIND, int AT, int MB>
+constexpr bool gemv_direct_fits() {
+  return MB * (128 / KindTraits<KIND, AT>::BITS) * (AT == AT_F16 ? 2 : 1) <= 128;
+}
+
 template <int KIND, int LAYOUT, int AT, int MODE, int FLAGS>
 static gemv_fn pick_mb(int mb) {
   switch (mb) {
     case 1: return wq_gemv_kernel<GemvPolicy<KIND, LAYOUT, AT, 1, MODE, FLAGS>>;
-    case kDirectTile: return wq_gemv_kernel<GemvPolicy<KIND, LAYOUT, AT, 1, MODE, FLAGS, 2, 2, true>>;
-    case kDirectTile + 1: return wq_gemv_kernel<GemvPolicy<KIND, LAYOUT, AT, 1, MODE, FLAGS, 1, 2, true>>;
-    case kDirectTile + 2: return wq_gemv_kernel<GemvPolicy<KIND, LAYOUT, AT, 2, MODE, FLAGS, 2, 2, true>>;
+    case kDirectTile:
+      if constexpr (gemv_direct_fits<KIND, AT, 1>()) return wq_gemv_kernel<GemvPolicy<KIND, LAYOUT, AT, 1, MODE, FLAGS, 2, 2, true>>;
+      else return nullptr;
+    case kDirectTile + 1:
+      if constexpr (gemv_direct_fits<KIND, AT, 1>()) return wq_gemv_kernel<GemvPolicy<KIND, LAYOUT, AT, 1, MODE, FLAGS, 1, 2, true>>;
+      else return nullptr;
+    case kDirectTile + 2:
+      if constexpr (gemv_direct_fits<KIND, AT, 2>()) return wq_gemv_kernel<GemvPolicy<KIND, LAYOUT, AT, 2, MODE, FLAGS, 2, 2, true>>;
+      else return nullptr;
     case 2: return wq_gemv_kernel<GemvPolicy<KIND, LAYOUT, AT, 2, MODE, FLAGS>>;
     case 4: return wq_gemv_kernel<GemvPolicy<KIND, LAYOUT, AT, 4, MODE, FLAGS>>;
     case kSplitTile + 1: return wq_gemv_kernel<GemvPolicy<KIND, LAYOUT, AT, 1, MODE, FLAGS, 2, 2, false, true>>;
