@@ -203,6 +203,47 @@ def time_member_gemm(device, gen, M=4096, N=4096, K=4096, W_dtype="uint4", A_dty
             "GBps_algorithmic": nbytes / t / 1e9, "frac_of_mfma_peak": tf / peak, "mfma_peak": peak}
 
 
+def time_step_int2_int8(device, gen, n_layers=4, grouped=True):
+    """BASELINE c4 at M = 1 as a STEP like c2's: a BitNet-b1.58 decoder layer's seven projections on the Llama-2-7B shapes,
+    W_int2 x A_int8 -> int32 (bit exact), the projections that share an input as one launch ({q,k,v}, o, {gate,up}, down)."""
+    import bitblas_amd as bitblas
+    ops = {}
+    layers = []
+    for _ in range(n_layers):
+        layer = []
+        for (_, N, K) in LLAMA2_7B_LINEARS:
+            if (N, K) not in ops:
+                ops[(N, K)] = bitblas.Matmul(bitblas.MatmulConfig(M=1, N=N, K=K, A_dtype="int8", W_dtype="int2", accum_dtype="int32",
+                                                                  out_dtype="int32"), enable_tuning=False)
+            W = torch.randint(-128, 128, (N, K // 4), dtype=torch.int8, device=device, generator=gen)
+            layer.append((ops[(N, K)], W, torch.empty((1, N), dtype=torch.int32, device=device)))
+        layers.append(layer)
+    acts = {K: torch.randint(-128, 128, (1, K), dtype=torch.int8, device=device, generator=gen) for K in (4096, 11008)}
+    groups = [[0, 1, 2], [3], [4, 5], [6]] if grouped else [[i] for i in range(7)]
+
+    def launch_all():
+        stream = torch.cuda.current_stream(device).cuda_stream
+        for layer in layers:
+            for grp in groups:
+                if len(grp) == 1:
+                    op, W, out = layer[grp[0]]
+                    op.lib.run(acts[op.K].data_ptr(), W.data_ptr(), None, None, None, None, out.data_ptr(), 1, stream)
+                else:
+                    gops = [layer[i][0] for i in grp]
+                    bitblas.matmul_group(gops, acts[gops[0].K], [layer[i][1] for i in grp], outputs=[layer[i][2] for i in grp])
+
+    t = graph_time(device, launch_all, 1)
+    nbytes = n_layers * sum(N * K // 4 + K + 4 * N for (_, N, K) in LLAMA2_7B_LINEARS)
+    from bitblas_amd import group_plan
+    names = {"+".join(LLAMA2_7B_LINEARS[i][0] for i in grp):
+             (group_plan([layers[0][i][0] for i in grp], 1)["plan"] or layers[0][grp[0]][0].plans[1])["name"] for grp in groups}
+    return {"workload": f"W_int2 A_int8 GEMV M=1 (bit exact), Llama-2-7B linear shapes, {n_layers} layers x 7 GEMV in "
+                        f"{len(groups)} launches per layer, one hipGraph replay; weights rotate over {nbytes >> 20} MB",
+            "launches": names, "us_per_step": t * 1e6, "bytes_per_step": nbytes, "GBps": nbytes / t / 1e9,
+            "mean_launch_us": t * 1e6 / (n_layers * len(groups)),
+            "roofline": {"bound": "hbm", "achieved": nbytes / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": nbytes / t / 1e9 / HBM_PEAK_GBS}}
+
+
 def time_member_f16_gemv(device, gen, N, K, int4_us=None):
     """The reference's published figure for this path is a SPEED-UP over the vendor library's float16 GEMV (README.md:43-48,
     images/figures/op_benchmark_a100_wq_gemv_e7.png: W_INT4 A_FP16 M = 1 about 3.9-4.3x cuBLAS on A100).  Same
@@ -728,6 +769,8 @@ def main():
             member("gemm_uint4_m16", time_member_gemm, device, gen, 16)
             member("gemm_int2_int8_m4096", time_member_gemm, device, gen, 4096, W_dtype="int2", A_dtype="int8")
             member("gemv_int2_int8_m1", time_member_dense, device, gen, 1, 4096, 4096, kind="int2", n_buf=64)
+            member("step_int2_int8", time_step_int2_int8, device, gen)
+            member("step_int2_int8_ungrouped", time_step_int2_int8, device, gen, grouped=False)
             # c5: dense e4m3 x e4m3 on every Llama-3-70B linear of one (unsharded) GPU, M = 4096 and M = 1
             # (this library's own ping-pong MFMA member; `_vendor` = the hipBLASLt yardstick on the same operands, tuned)
             for (name, N, K, nb) in (("o", 8192, 8192, 4), ("down", 8192, 28672, 2), ("qkv", 10240, 8192, 4), ("gate", 28672, 8192, 2)):

@@ -336,8 +336,12 @@ __device__ __forceinline__ void decode_unit_f16(const u32x4& w, int u, half_t zf
   }
 }
 
+// The fields come out as unsigned bytes; the zero point of the signed formats (2^(bits-1), one value for the whole
+// matrix: the reference defines no Scale / Zeros next to integer activations) is NOT subtracted per byte - the caller removes
+// z * sum(a) from the row's sum instead (same int32 result, a third of the vector operations: the per-byte subtract was 3
+// of the 6 operations per 4 weights)
 template <class P>
-__device__ __forceinline__ void decode_unit_i8(const u32x4& w, int u, uint32_t zp4, uint32_t flip,
+__device__ __forceinline__ void decode_unit_i8(const u32x4& w, int u, uint32_t flip,
                                                uint32_t (&q)[P::T::G / 4]) {
   using T = typename P::T;
   if constexpr (T::SUBBYTE) {
@@ -348,7 +352,7 @@ __device__ __forceinline__ void decode_unit_i8(const u32x4& w, int u, uint32_t z
       // int1 signed: value = -u = (1 - u) - 1 -> invert the word first (see decode_unit_f16)
       I8Unpack<T::BITS>::run(w[u * T::WPU + j] ^ flip, t);
 #pragma unroll
-      for (int i = 0; i < NQ; ++i) q[j * NQ + i] = sub_bytes(t[i], zp4);
+      for (int i = 0; i < NQ; ++i) q[j * NQ + i] = t[i];
     }
   } else {
 #pragma unroll
@@ -542,13 +546,16 @@ __global__ void __launch_bounds__(1024) wq_gemv_kernel(const GemvGroupArgs grp) 
   if (P::A4 && P::KIND == DK_INT4 && a.is_signed) cx.flip = 0x88888888u;
   cx.off8 = (half_t)(a.is_signed ? 1152.0f : 1024.0f);
   make_magic(cx.magic);
-  const uint32_t zp4 = (!F16 && a.is_signed && T::SUBBYTE) ? (uint32_t)(1u << (T::BITS - 1)) * 0x01010101u : 0u;
+  const int zpi = (!F16 && a.is_signed && T::SUBBYTE) ? (1 << (T::BITS - 1)) : 0;   // integer zero point of the sub-byte signed formats
 
   acc_t acc[R][MB];
 #pragma unroll
   for (int r = 0; r < R; ++r)
 #pragma unroll
     for (int mi = 0; mi < MB; ++mi) acc[r][mi] = 0;
+  int sa[MB];                                      // integer members: sum of the activations this lane has multiplied (per batch row)
+#pragma unroll
+  for (int mi = 0; mi < MB; ++mi) sa[mi] = 0;
 
   const bool need_mask = ncp * 64 != cpr;    // some lanes of the last step lie beyond K
   auto consume = [&](const Stage<P>& s, int c, int rg_now) {
@@ -663,7 +670,7 @@ __global__ void __launch_bounds__(1024) wq_gemv_kernel(const GemvGroupArgs grp) 
       } else {
         uint32_t q[R][G / 4];
 #pragma unroll
-        for (int r = 0; r < R; ++r) decode_unit_i8<P>(s.w[r], u, zp4, cx.flip, q[r]);
+        for (int r = 0; r < R; ++r) decode_unit_i8<P>(s.w[r], u, cx.flip, q[r]);
 #pragma unroll
         for (int pp = 0; pp < PU; ++pp) {
 #pragma unroll
@@ -674,6 +681,10 @@ __global__ void __launch_bounds__(1024) wq_gemv_kernel(const GemvGroupArgs grp) 
               if (need_mask && !s.avalid) av = u32x4{0u, 0u, 0u, 0u};   // wave-uniform outer test: free when K has no ragged chunk
             } else {
               av = a_lds[((long)(mi * ncp + c) * PIECES + u * PU + pp) * 64 + lane];
+            }
+            if constexpr (T::SUBBYTE) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) sa[mi] = __builtin_amdgcn_sdot4((int)av[e], 0x01010101, sa[mi], false);
             }
 #pragma unroll
             for (int r = 0; r < R; ++r)
@@ -688,6 +699,15 @@ __global__ void __launch_bounds__(1024) wq_gemv_kernel(const GemvGroupArgs grp) 
 
   int it_idx = 0;
   auto finish = [&](int rg_now) {
+    if constexpr (!F16 && T::SUBBYTE) {
+      // sum_k (q - z) a = sum_k q a - z sum_k a over the chunks this lane multiplied (exact in int32)
+#pragma unroll
+      for (int mi = 0; mi < MB; ++mi) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc[r][mi] -= zpi * sa[mi];
+        sa[mi] = 0;
+      }
+    }
     if constexpr (P::KS) {
       if (kw > 1) {
         // the kw parts of a row group meet in LDS (double buffered: one barrier per row group) and are summed by part

@@ -169,7 +169,10 @@ def test_register_and_lds_activation_members_agree(wd, g, ws, wz, zm, M, monkeyp
     case = make_case(M, 512, 2048 if wd != "uint2" else 4096, W_dtype=wd, group_size=g, with_scaling=ws,
                      with_zeros=wz, zeros_mode=zm)
     got, mm = hip_output(case)
-    assert mm.plans[M]["name"].endswith("_areg")
+    # (2-bit weights x float16 at M = 2: 128 dwords of activations per lane do not fit the register file - that member spilled
+    # and is no longer built, csrc/wqaa_gemv_kernel.h gemv_direct_fits; the LDS-staged member is the only one)
+    fits = not (wd == "uint2" and M == 2)
+    assert mm.plans[M]["name"].endswith("_areg") == fits, mm.plans[M]["name"]
     monkeypatch.setenv("WQAA_GEMV_NO_DIRECT", "1")
     got_lds, mm2 = hip_output(case)
     assert not mm2.plans[M]["name"].endswith("_areg")
@@ -177,13 +180,12 @@ def test_register_and_lds_activation_members_agree(wd, g, ws, wz, zm, M, monkeyp
     assert_fp_parity(got, oracle_output(case))
 
 
-@pytest.mark.skipif(not os.environ.get("WQAA_TEST_NEXT"), reason="queued for round 3 (DESIGN section 8 item 0): set WQAA_TEST_NEXT=1")
 @pytest.mark.parametrize("wd,ad", [("uint1", "float16"), ("int1", "float16"), ("uint2", "float16"), ("int1", "int8")])
 @pytest.mark.parametrize("M", [1, 2])
 def test_lds_staged_low_bit_members_agree_with_the_register_members(wd, ad, M, monkeypatch):
-    """The register-resident members of 1-bit (any M) and 2-bit (M = 2) weights spill (profiles/r02_static_isa.txt); before
-    the selector stops choosing them, their LDS-staged twins - never selected for K within one step today - must give the
-    same bits.  Not part of the default suite until it has run once on a GPU."""
+    """1-bit (any M) and 2-bit (M = 2) weights run the LDS-staged members (their register-resident twins spilled and are gone:
+    round 3, profiles/r03_ab_direct_fit.txt); where a register-resident member still exists (2-bit M = 1, int1 x int8 M = 1)
+    the two must give the same bits, and every case must match the oracle."""
     int8 = ad == "int8"
     case = make_case(M, 512, 4096, W_dtype=wd, A_dtype=ad, out_dtype="int32" if int8 else "float16",
                      **({} if int8 else dict(group_size=128, with_scaling=True, scale_mul=0.05)))
