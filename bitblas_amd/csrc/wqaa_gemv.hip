@@ -149,6 +149,20 @@ static int choose(const wqaa_matmul_desc& d, int m, GemvChoice* c, bool quant_in
     }
     c->flags |= FL_AQ;
   }
+  // rows with an odd number of lane chunks, integer activations: four rows x one chunk per step instead of two x two (no
+  // padding chunk).  Same-process A/B, int2 x int8 (profiles/r03_ab_chunk_tile.txt): 12288 x 4096 5.95 -> 5.25 us, 22016 x 4096
+  // 8.78 -> 7.42, 8640 x 3200 5.22 -> 4.53; but 4096 x 11008 (three chunks, 1024 groups of four rows: 4 waves per CU) 5.71 ->
+  // 6.49 - so: one-chunk rows, or enough rows that four per wave still give every CU 8 waves.  WQAA_GEMV_CHUNK=0: the (2, 2) members.
+  bool chunk_tile = false;
+  if (c->at == AT_I8 && c->bits < 8 && (c->nc & 1) && (c->nc == 1 || (d.N + 3) / 4 >= 8 * cus0)) {
+    const char* f = getenv("WQAA_GEMV_CHUNK");
+    chunk_tile = (!f || atoi(f) != 0) && pick_kernel(c->kind, c->layout, c->at, c->mode, c->flags, kChunkTile + mb) != nullptr;
+  }
+  if (chunk_tile) {
+    c->R = 4;
+    c->D = 1;
+  }
+  c->ncp = (c->nc + c->D - 1) / c->D * c->D;
   // the register-resident member only where its activation slice fits the register file (gemv_direct_fits, wqaa_gemv_kernel.h:
   // the members that spilled are not built; same-process A/B in profiles/r03_ab_direct_fit.txt)
   const bool slice_fits = mb * c->E * (c->at == AT_F16 ? 2 : 1) <= 128;
@@ -156,10 +170,11 @@ static int choose(const wqaa_matmul_desc& d, int m, GemvChoice* c, bool quant_in
                       slice_fits && !getenv("WQAA_GEMV_NO_DIRECT");
   // small matrices: one row per wave doubles the waves in flight (same-box A/B: 1024 x 1024 2.87 -> 2.45 us,
   // 2048 x 4096 equal, 4096 x 4096 4.18 -> 4.43 us)
-  const bool r1 = direct && mb == 1 && (d.N + 1) / 2 < 3 * cus0;
+  const bool r1 = direct && mb == 1 && (d.N + 1) / 2 < 3 * cus0 && !chunk_tile;
   if (r1) c->R = 1;
-  c->fn = pick_kernel(c->kind, c->layout, c->at, c->mode, c->flags,
-                      direct ? (mb == 2 ? kDirectTile + 2 : r1 ? kDirectTile + 1 : kDirectTile) : mb);
+  int code = direct ? (mb == 2 ? kDirectTile + 2 : r1 ? kDirectTile + 1 : kDirectTile) : mb;
+  if (chunk_tile) code = (direct ? kChunkDirect : kChunkTile) + mb;
+  c->fn = pick_kernel(c->kind, c->layout, c->at, c->mode, c->flags, code);
   if (!c->fn) {
     set_error(WQAA_ERR_UNSUPPORTED, "gemv: no kernel for kind=%d layout=%d at=%d mode=%d flags=%d", c->kind,
               c->layout, c->at, c->mode, c->flags);
@@ -195,7 +210,7 @@ static int choose(const wqaa_matmul_desc& d, int m, GemvChoice* c, bool quant_in
   c->kw = 1;
   {
     const int nsteps = c->ncp / c->D;
-    const bool can = !direct && !(c->flags & FL_AQ) && m <= mb && mb <= 2 && nsteps >= 2 &&
+    const bool can = !direct && !chunk_tile && !(c->flags & FL_AQ) && m <= mb && mb <= 2 && nsteps >= 2 &&
                      pick_kernel(c->kind, c->layout, c->at, c->mode, c->flags, kSplitTile + mb) != nullptr;
     int kw = 1;
     if (can && n_rg < 4 * cus) {

@@ -837,7 +837,13 @@ typedef void (*gemv_fn)(const GemvGroupArgs);
 
 static constexpr int kDirectTile = 101;   // pick_mb code of the M = 1 "activations direct" member
 static constexpr int kSplitTile = 200;    // + mb (1, 2): the K-split twins of the LDS-staged members
-static constexpr int kBatchTiles[] = {1, kDirectTile, kDirectTile + 1, kDirectTile + 2, 2, 4, kSplitTile + 1, kSplitTile + 2};
+// + mb (1, 2, 4): four rows per wave, ONE lane chunk per step - for rows with an odd number of lane chunks (2-bit weights at
+// K = 4096 are exactly one: 64 lanes x 64 weights).  The (2, 2) members pad such rows to an even count: a second load of
+// chunk 0 and a decode against zeros, half the work of a one-chunk row.  Integer activations only (BASELINE c4, BitNet).
+static constexpr int kChunkTile = 300;
+static constexpr int kChunkDirect = 310;  // + mb (1, 2): ... with the activations in registers
+static constexpr int kBatchTiles[] = {1, kDirectTile, kDirectTile + 1, kDirectTile + 2, 2, 4, kSplitTile + 1, kSplitTile + 2,
+                                      kChunkTile + 1, kChunkTile + 2, kChunkTile + 4, kChunkDirect + 1, kChunkDirect + 2};
 
 // The register-resident ("direct") members exist only where the activation slice of a lane chunk fits the register file:
 // mb * E elements of 2 (1) bytes <= 128 bytes for the 64 dwords a 128-VGPR kernel can spare.  4-bit weights pass at M <= 2,
@@ -866,6 +872,23 @@ static gemv_fn pick_mb(int mb) {
     case 4: return wq_gemv_kernel<GemvPolicy<KIND, LAYOUT, AT, 4, MODE, FLAGS>>;
     case kSplitTile + 1: return wq_gemv_kernel<GemvPolicy<KIND, LAYOUT, AT, 1, MODE, FLAGS, 2, 2, false, true>>;
     case kSplitTile + 2: return wq_gemv_kernel<GemvPolicy<KIND, LAYOUT, AT, 2, MODE, FLAGS, 2, 2, false, true>>;
+    case kChunkTile + 1:
+      if constexpr (AT == AT_I8 && KindTraits<KIND, AT>::SUBBYTE) return wq_gemv_kernel<GemvPolicy<KIND, LAYOUT, AT, 1, MODE, FLAGS, 4, 1>>;
+      else return nullptr;
+    case kChunkTile + 2:
+      if constexpr (AT == AT_I8 && KindTraits<KIND, AT>::SUBBYTE) return wq_gemv_kernel<GemvPolicy<KIND, LAYOUT, AT, 2, MODE, FLAGS, 4, 1>>;
+      else return nullptr;
+    case kChunkTile + 4:
+      if constexpr (AT == AT_I8 && KindTraits<KIND, AT>::SUBBYTE) return wq_gemv_kernel<GemvPolicy<KIND, LAYOUT, AT, 4, MODE, FLAGS, 4, 1>>;
+      else return nullptr;
+    case kChunkDirect + 1:
+      if constexpr (AT == AT_I8 && KindTraits<KIND, AT>::SUBBYTE && (FLAGS & (FL_A8 | FL_AQ)) == 0 && gemv_direct_fits<KIND, AT, 1>())
+        return wq_gemv_kernel<GemvPolicy<KIND, LAYOUT, AT, 1, MODE, FLAGS, 4, 1, true>>;
+      else return nullptr;
+    case kChunkDirect + 2:
+      if constexpr (AT == AT_I8 && KindTraits<KIND, AT>::SUBBYTE && (FLAGS & (FL_A8 | FL_AQ)) == 0 && gemv_direct_fits<KIND, AT, 2>())
+        return wq_gemv_kernel<GemvPolicy<KIND, LAYOUT, AT, 2, MODE, FLAGS, 4, 1, true>>;
+      else return nullptr;
     default: return nullptr;
   }
 }
