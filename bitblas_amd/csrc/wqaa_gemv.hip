@@ -165,7 +165,7 @@ static int choose(const wqaa_matmul_desc& d, int m, GemvChoice* c, bool quant_in
   c->ncp = (c->nc + c->D - 1) / c->D * c->D;
   // the register-resident member only where its activation slice fits the register file (gemv_direct_fits, wqaa_gemv_kernel.h:
   // the members that spilled are not built; same-process A/B in profiles/r03_ab_direct_fit.txt)
-  const bool slice_fits = mb * c->E * (c->at == AT_F16 ? 2 : 1) <= 128;
+  const bool slice_fits = mb * c->E * (c->at == AT_F16 ? 2 : 1) <= 128 && !(c->kind == DK_LUT4 && mb == 2 && (c->flags & FL_BF16));
   const bool direct = mb <= 2 && m == mb && !(c->flags & (FL_A8 | FL_AQ)) && c->at != AT_I4 && c->ncp == c->D && (d.N + c->R - 1) / c->R <= 10 * cus0 &&
                       slice_fits && !getenv("WQAA_GEMV_NO_DIRECT");
   // small matrices: one row per wave doubles the waves in flight (same-box A/B: 1024 x 1024 2.87 -> 2.45 us,

@@ -850,8 +850,11 @@ static constexpr int kBatchTiles[] = {1, kDirectTile, kDirectTile + 1, kDirectTi
 // 2-bit x fp16 at M = 1, 1-bit x fp16 never: those compiled to 440 - 3400 B of scratch per lane with the reloads inside the row
 // loop and ran 5 - 23 x slower than their LDS-staged twins (profiles/r03_ab_direct_fit.txt: uint1 x fp16 M = 2 4096^2 220.6 vs
 // 9.5 us, uint2 51.0 vs 6.0, int1 x int8 40.8 vs 6.8) - they are not built, and gemv_choose asks for the same condition.
-template <int KIND, int AT, int MB>
+template <int KIND, int AT, int MB, int FLAGS = 0>
 constexpr bool gemv_direct_fits() {
+  // (the table-decoded 4-bit formats with bfloat16 activations at M = 2 need the 16 table registers and the widening on
+  // top of a full slice: 348 B of scratch, profiles/r03_static_isa.txt - LDS-staged as well)
+  if (KIND == DK_LUT4 && MB == 2 && (FLAGS & FL_BF16) != 0) return false;
   return MB * (128 / KindTraits<KIND, AT>::BITS) * (AT == AT_F16 ? 2 : 1) <= 128;
 }
 
@@ -860,13 +863,13 @@ static gemv_fn pick_mb(int mb) {
   switch (mb) {
     case 1: return wq_gemv_kernel<GemvPolicy<KIND, LAYOUT, AT, 1, MODE, FLAGS>>;
     case kDirectTile:
-      if constexpr (gemv_direct_fits<KIND, AT, 1>()) return wq_gemv_kernel<GemvPolicy<KIND, LAYOUT, AT, 1, MODE, FLAGS, 2, 2, true>>;
+      if constexpr (gemv_direct_fits<KIND, AT, 1, FLAGS>()) return wq_gemv_kernel<GemvPolicy<KIND, LAYOUT, AT, 1, MODE, FLAGS, 2, 2, true>>;
       else return nullptr;
     case kDirectTile + 1:
-      if constexpr (gemv_direct_fits<KIND, AT, 1>()) return wq_gemv_kernel<GemvPolicy<KIND, LAYOUT, AT, 1, MODE, FLAGS, 1, 2, true>>;
+      if constexpr (gemv_direct_fits<KIND, AT, 1, FLAGS>()) return wq_gemv_kernel<GemvPolicy<KIND, LAYOUT, AT, 1, MODE, FLAGS, 1, 2, true>>;
       else return nullptr;
     case kDirectTile + 2:
-      if constexpr (gemv_direct_fits<KIND, AT, 2>()) return wq_gemv_kernel<GemvPolicy<KIND, LAYOUT, AT, 2, MODE, FLAGS, 2, 2, true>>;
+      if constexpr (gemv_direct_fits<KIND, AT, 2, FLAGS>()) return wq_gemv_kernel<GemvPolicy<KIND, LAYOUT, AT, 2, MODE, FLAGS, 2, 2, true>>;
       else return nullptr;
     case 2: return wq_gemv_kernel<GemvPolicy<KIND, LAYOUT, AT, 2, MODE, FLAGS>>;
     case 4: return wq_gemv_kernel<GemvPolicy<KIND, LAYOUT, AT, 4, MODE, FLAGS>>;
