@@ -174,7 +174,9 @@ static int gemm_choose(const wqaa_matmul_desc& d, int m, GemmChoice* c, bool fus
     const char* pf = getenv("WQAA_GEMM_PP");
     const int kb = c->at == AT_F16 ? 256 : c->at == AT_F8 ? 128 : 512;   // k per trip of the main loop
     const int gb = c->at == AT_F8 ? 1 : g / (kb / 2);                   // k-bodies (two k-tiles) per group
-    const bool meta_ok = c->mode == MD_NONE || (g % (kb / 2) == 0 && ilog2_exact(gb) >= 0 && ((d.K / g) & 1) == 0 && (long)d.N * (d.K / g) >= 8);
+    // (packed integer zero points - GPTQ checkpoints: a wave fetches the 16 bytes of its 32 rows per group, so N in whole waves)
+    const bool meta_ok = c->mode == MD_NONE || (g % (kb / 2) == 0 && ilog2_exact(gb) >= 0 && ((d.K / g) & 1) == 0 && (long)d.N * (d.K / g) >= 8 &&
+                                                (c->mode != MD_ZQ || (d.N % 32 == 0 && c->bits == 4)));
     const bool out_ok = c->at == AT_I8 ? d.out_dtype == WQAA_I32 : d.out_dtype == WQAA_F16;
     const long a_bytes = (long)m * d.K * (c->at == AT_F16 ? 2 : 1), w_bytes = (long)d.N * d.K * c->bits / 8;
     const bool shape_ok = !fused_epilogue && d.K % kb == 0 && meta_ok && out_ok && d.N % 8 == 0 && a_bytes + 256L * d.K * 2 < (1L << 31) &&
@@ -604,7 +606,7 @@ void gemm_init() {
   for (int kind : {DK_INT4, DK_LUT4, DK_INT2, DK_E4M3, DK_E5M2})
     for (int layout = 0; layout < 2; ++layout)
       for (int at : {AT_F16, AT_I8, AT_F8})
-        for (int mode = 0; mode <= MD_ZR; ++mode)
+        for (int mode = 0; mode <= MD_ZQ; ++mode)
           for (int flags : {0, (int)FL_ABF8}) {
           for (int bm : {256, 128}) {
             int lds = 0;

@@ -13,6 +13,7 @@ static gemm_fn pp_modes_f16(int mode) {
     case MD_S: return wq_gemm_pp_kernel<PPMember<KIND, LAYOUT, AT_F16, MD_S, BM>>;
     case MD_ZO: if constexpr (KIND == DK_INT4) return wq_gemm_pp_kernel<PPMember<KIND, LAYOUT, AT_F16, MD_ZO, BM>>; else return nullptr;
     case MD_ZR: if constexpr (KIND == DK_INT4) return wq_gemm_pp_kernel<PPMember<KIND, LAYOUT, AT_F16, MD_ZR, BM>>; else return nullptr;
+    case MD_ZQ: if constexpr (KIND == DK_INT4) return wq_gemm_pp_kernel<PPMember<KIND, LAYOUT, AT_F16, MD_ZQ, BM>>; else return nullptr;
   }
   return nullptr;
 }

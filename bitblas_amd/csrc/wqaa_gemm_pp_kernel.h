@@ -155,6 +155,7 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_pp_kernel(const GemmArgs a
   constexpr int WROWS = P::BM / 8;      // activation rows a wave feeds per k-tile: 32 / 16 (NPH pieces of 8)
   constexpr bool HALF = P::BM == 128;
   constexpr bool ZP = MODE == MD_ZO || MODE == MD_ZR;
+  constexpr bool ZQ = MODE == MD_ZQ;    // GPTQ-style packed integer zero points: Zeros[K / g][N / 2] bytes, nibble n & 1 of byte n / 2
   using acc_t = typename std::conditional<F16, f32x4, i32x4>::type;
   typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
@@ -249,9 +250,22 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_pp_kernel(const GemmArgs a
     if constexpr (P::HAS_META) {
       const int l = pp_opaque(lane);
       const int n = nw0 + (l & 31);
-      const uint16_t* mbase = (ZP && (l >> 5) == 1) ? reinterpret_cast<const uint16_t*>(a.zeros) : reinterpret_cast<const uint16_t*>(a.scale);
-      const uint16_t* src = mbase + window_start((uint32_t)(n < a.N ? n : a.N - 1) * (uint32_t)a.kg, q);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src), (lds_ptr_t)(meta + (q & 1) * 1024), 16, 0, 0);
+      if constexpr (ZQ) {
+        // lanes 0-31: the Scale windows; lanes 32-39: the 16 bytes that hold the zero points of the wave's 32 rows, one lane per
+        // group of the window (N is a multiple of 32 for this member: a wave's rows are all inside the matrix or all outside)
+        if (l < 40) {
+          const int gz = q * 8 + (l & 7) < a.kg ? q * 8 + (l & 7) : a.kg - 1;
+          const int nz = nw0 + 32 <= a.N ? nw0 : a.N - 32;
+          const unsigned char* src = l < 32
+              ? reinterpret_cast<const unsigned char*>(reinterpret_cast<const uint16_t*>(a.scale) + window_start((uint32_t)(n < a.N ? n : a.N - 1) * (uint32_t)a.kg, q))
+              : reinterpret_cast<const unsigned char*>(a.zeros) + (long)gz * a.zq_row_bytes + (nz >> 1);
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src), (lds_ptr_t)(meta + (q & 1) * 1024), 16, 0, 0);
+        }
+      } else {
+        const uint16_t* mbase = (ZP && (l >> 5) == 1) ? reinterpret_cast<const uint16_t*>(a.zeros) : reinterpret_cast<const uint16_t*>(a.scale);
+        const uint16_t* src = mbase + window_start((uint32_t)(n < a.N ? n : a.N - 1) * (uint32_t)a.kg, q);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src), (lds_ptr_t)(meta + (q & 1) * 1024), 16, 0, 0);
+      }
     }
   };
 
@@ -263,7 +277,7 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_pp_kernel(const GemmArgs a
 #pragma unroll
   for (int jj = 0; jj < 2; ++jj) a_rd[jj] = (uint32_t)(fr * P::TILE_ROW + (((4 * jj + kb) ^ swl) * 16));
   DecodeCtx cx;
-  cx.zf = (F16 && a.is_signed && P::KIND != DK_LUT4) ? (half_t)8.0f : (half_t)0.0f;
+  cx.zf = (F16 && a.is_signed && P::KIND != DK_LUT4 && !ZQ) ? (half_t)8.0f : (half_t)0.0f;   // (quantized zeros act in the code domain: no sign offset)
   cx.flip = 0u;
   cx.off8 = (half_t)0.0f;
   if constexpr (F16) {                     // 4-bit fields sit at bit 0 and bit 4 of a byte: two magic exponent words, pinned in VGPRs
@@ -279,7 +293,7 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_pp_kernel(const GemmArgs a
     else lut = make_lut16(reinterpret_cast<const half_t*>(a.lut));
   }
 
-  bool zint = false;
+  bool zint = ZQ;                         // packed integer zero points always take the magic-exponent decode
 
   acc_t acc[NMF][2];
 #pragma unroll
@@ -317,6 +331,11 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_pp_kernel(const GemmArgs a
         const int e = gi - (q8 < mlim_f[nf] ? q8 : mlim_f[nf]);
         m_s[nf] = *reinterpret_cast<const uint16_t*>(p + nf * 256 + e * 2);
         if constexpr (ZP) m_z[nf] = *reinterpret_cast<const uint16_t*>(p + 512 + nf * 256 + e * 2);
+        if constexpr (ZQ) {
+          const int r = nf * 16 + (pp_opaque(lane) & 15);
+          const uint32_t b = *reinterpret_cast<const uint8_t*>(meta + ((gi >> 3) & 1) * 1024 + 512 + (gi & 7) * 16 + (r >> 1));
+          m_z[nf] = (b >> ((r & 1) * 4)) & 15u;
+        }
       }
     }
   };
@@ -333,6 +352,11 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_pp_kernel(const GemmArgs a
           } else {
             zA[nf] = splat(z);
           }
+        }
+        if constexpr (ZQ) {               // an integer 0..15: always the magic-exponent form
+          const half_t z = (half_t)(float)m_z[nf];
+          zA[nf] = splat((half_t)1024.0f + z);
+          zB[nf] = splat((half_t)64.0f + z);
         }
       }
     }

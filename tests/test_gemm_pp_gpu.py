@@ -40,6 +40,14 @@ def test_uint4_scale_zeros(M, N, K, zeros_mode):
     _run(case, M)
 
 
+@pytest.mark.parametrize("M,N,K", [(300, 544, 512), (256, 256, 256), (513, 288, 1024)])
+@pytest.mark.parametrize("wd", ["uint4", "int4"])
+def test_4bit_packed_integer_zero_points(M, N, K, wd):
+    """zeros_mode = "quantized" (GPTQ checkpoints: Zeros packed 4-bit along N, one row per group), N in whole waves of 32 rows"""
+    case = make_case(M, N, K, W_dtype=wd, group_size=128, with_scaling=True, with_zeros=True, zeros_mode="quantized", seed=M + N)
+    _run(case, M)
+
+
 def test_uint4_fractional_zero_points_take_the_general_decode():
     case = make_case(300, 520, 512, W_dtype="uint4", group_size=128, with_scaling=True, with_zeros=True, seed=5)
     case["zeros"] = (case["zeros"].astype(np.float32) + 0.375).astype(np.float16)
@@ -115,14 +123,14 @@ def test_dense_fp8_pairings_ragged(a_dt, w_dt, M, N, K, pin_the_tile):
 
 
 def test_what_the_member_does_not_cover_falls_back(monkeypatch):
-    """bfloat16 activations, float32 output, quantized zeros, per-channel scales, K off the 256 grid: the lockstep member
-    (whichever tile is asked for)."""
+    """bfloat16 activations, float32 output, per-channel scales, quantized zeros with N off the 32-row grid, K off the 256 grid:
+    the lockstep member (whichever tile is asked for)."""
     import bitblas_amd as bitblas
-    for kw in (dict(A_dtype="bfloat16", out_dtype="bfloat16", accum_dtype="float32", W_dtype="uint4", group_size=128, with_scaling=True),
-               dict(A_dtype="float16", out_dtype="float32", accum_dtype="float32", W_dtype="uint4", group_size=128, with_scaling=True),
-               dict(A_dtype="float16", W_dtype="uint4", group_size=128, with_scaling=True, with_zeros=True, zeros_mode="quantized"),
-               dict(A_dtype="float16", W_dtype="uint4", group_size=-1, with_scaling=True)):
-        mm = bitblas.Matmul(bitblas.MatmulConfig(M=512, N=512, K=512, **kw), enable_tuning=False)
+    for kw in (dict(N=512, A_dtype="bfloat16", out_dtype="bfloat16", accum_dtype="float32", W_dtype="uint4", group_size=128, with_scaling=True),
+               dict(N=512, A_dtype="float16", out_dtype="float32", accum_dtype="float32", W_dtype="uint4", group_size=128, with_scaling=True),
+               dict(N=520, A_dtype="float16", W_dtype="uint4", group_size=128, with_scaling=True, with_zeros=True, zeros_mode="quantized"),
+               dict(N=512, A_dtype="float16", W_dtype="uint4", group_size=-1, with_scaling=True)):
+        mm = bitblas.Matmul(bitblas.MatmulConfig(M=512, K=512, **kw), enable_tuning=False)
         assert not mm.plans[512]["name"].endswith("pp"), mm.plans[512]["name"]
     mm = bitblas.Matmul(bitblas.MatmulConfig(M=512, N=512, K=384, A_dtype="float16", W_dtype="uint4", group_size=128, with_scaling=True),
                         enable_tuning=False)
