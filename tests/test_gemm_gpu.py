@@ -132,6 +132,31 @@ def test_baseline_c3_uint4_zeros_full_size_64_sampled_rows_at_m4096(M):
         assert np.array_equal(got2[0::2], got[0::2])
 
 
+@pytest.mark.parametrize("M,N,K", [(1536, 4096, 1024), (2048, 4096, 512), (3000, 4096, 512), (1024, 11008, 512), (600, 11008, 512),
+                                   (300, 22016, 256), (2500, 4104, 768), (1000, 2048, 1024), (129, 8192, 512), (777, 3000, 256)])
+def test_prefill_sized_m_whichever_tile_the_selector_takes_48_sampled_rows(M, N, K):
+    """M between the decode batches and the full chip: the selector chooses between the 256-row and the 128-row ping-pong tile
+    and the lockstep members by an estimate of the rounds each needs (csrc/wqaa_gemm.hip) - all of them against the oracle on 48
+    sampled rows plus the first and last rows of every 128-row block edge (each output row depends on its activation row only)."""
+    case = make_case(M, N, K, W_dtype="uint4", group_size=128, with_scaling=True, with_zeros=True, zeros_mode="original",
+                     scale_mul=0.02, seed=M + N)
+    got, mm = hip_output(case)
+    assert mm.plans[M]["kernel_family"] == 2
+    rows = set(np.random.default_rng(M).choice(M, 48, replace=False).tolist())
+    for b in range(0, M, 128):
+        rows.update({b, min(M - 1, b + 127)})
+    _sampled_rows_check(case, got, np.array(sorted(rows)))
+
+
+@pytest.mark.parametrize("M,N,K", [(2048, 4096, 1024), (1024, 4096, 512), (1100, 2048, 1536)])
+def test_prefill_sized_m_int2_int8_bit_exact_sampled_rows(M, N, K):
+    case = make_case(M, N, K, W_dtype="int2", A_dtype="int8", out_dtype="int32", seed=M + K)
+    got, mm = hip_output(case)
+    assert mm.plans[M]["kernel_family"] == 2
+    rows = np.unique(np.concatenate([np.random.default_rng(M).choice(M, 48, replace=False), np.arange(0, M, 128), np.array([M - 1])]))
+    _sampled_rows_check(case, got, rows, exact=True)
+
+
 def test_baseline_c4_int2_int8_gemm_full_size_64_sampled_rows():
     case = make_case(4096, 4096, 4096, W_dtype="int2", A_dtype="int8", out_dtype="int32", seed=4)
     got, mm = hip_output(case)
