@@ -392,6 +392,20 @@ int gemm_launch(const wqaa_matmul_desc& d, const void* A, const void* B, const v
   if (const char* f = getenv("WQAA_GEMM_GROUP_M")) a.group_m = atoi(f) > 0 ? atoi(f) : 1;
   a.tiles_m = c.tiles_m;
   a.tiles_n = c.tiles_n;
+  {
+    // split-K partial sums and large output tiles leave the chip write-through (they are read by another kernel, once):
+    // nothing dirty is left for the kernel boundary to write back.  WQAA_GEMM_WS_POLICY=<bits> overrides (tuning aid, plan time)
+    static thread_local unsigned seen = ~0u;
+    static thread_local int policy = -1;
+    const unsigned ep = g_plan_epoch.load(std::memory_order_relaxed);
+    if (ep != seen) {
+      const char* f = getenv("WQAA_GEMM_WS_POLICY");
+      policy = f ? atoi(f) : -1;
+      seen = ep;
+    }
+    const long out_bytes = (long)m * d.N * (d.out_dtype == WQAA_I32 || d.out_dtype == WQAA_F32 ? 4 : 2);
+    a.ws_policy = policy >= 0 ? policy : (3 | (out_bytes >= (8L << 20) ? 16 : 0));
+  }
   a.nsteps = d.K / c.ks;
   if (c.pp) {                               // the ping-pong member reads gq_shift as log2(k-bodies per group)
     a.gq_shift = c.pp_shift;

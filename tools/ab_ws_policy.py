@@ -1,0 +1,13 @@
+import os, sys, torch
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+import bench
+dev = torch.device("cuda", 0); gen = torch.Generator(device=dev); gen.manual_seed(1)
+for (M, N, K) in ((32, 4096, 4096), (64, 4096, 4096), (128, 4096, 4096), (256, 4096, 4096), (128, 11008, 4096), (512, 4096, 4096)):
+    row = []
+    for rnd in range(2):
+        for pol in ("0", "1", "2", "3"):
+            os.environ["WQAA_GEMM_WS_POLICY"] = pol
+            bench._OPS.clear()
+            r = bench.time_member_gemm(dev, gen, M, N, K)
+            row.append((pol, r["us_per_launch"], r["kernel"].split("_")[-1]))
+    print(f"M={M} {N}x{K} {row[0][2]}: " + "  ".join(f"p{p} {u:6.2f}" for p, u, _ in row))
