@@ -1,0 +1,44 @@
+#!/usr/bin/env python
+"""tools/ab_two_libs.py: the same members timed under two builds of the library (WQAA_LIBRARY), alternating processes on one
+box: bitblas_amd/libwqaa_hip_base.so (a copy of the previous build) against bitblas_amd/libwqaa_hip.so."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CHILD = r'''
+import json, os, sys, torch
+sys.path.insert(0, %r)
+import bench
+dev = torch.device("cuda", 0); gen = torch.Generator(device=dev); gen.manual_seed(1)
+out = {}
+for (M, N, K) in ((16, 4096, 4096), (32, 4096, 4096), (128, 4096, 4096), (256, 4096, 4096)):
+    out[f"u4 M={M}"] = bench.time_member_gemm(dev, gen, M, N, K)["us_per_launch"]
+out["c4 step"] = bench.time_step_int2_int8(dev, gen)["us_per_step"]
+for (N, K) in ((4096, 4096), (12288, 4096)):
+    out[f"i2xi8 {N}x{K}"] = bench.time_member_dense(dev, gen, 1, N, K, kind="int2", n_buf=64)["us_per_launch"]
+    out[f"i4 strict {N}x{K}"] = bench.time_member_gemv(dev, gen, N, K, strict=True)["us_per_launch"]
+print(json.dumps(out))
+''' % ROOT
+
+
+def main():
+    libs = {"base": os.path.join(ROOT, "bitblas_amd", "libwqaa_hip_base.so"), "new": os.path.join(ROOT, "bitblas_amd", "libwqaa_hip.so")}
+    res = {k: [] for k in libs}
+    for rnd in range(2):
+        for name, path in libs.items():
+            env = dict(os.environ, WQAA_LIBRARY=path)
+            r = subprocess.run([sys.executable, "-c", CHILD], env=env, capture_output=True, text=True)
+            line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+            if not line:
+                print(name, "failed:", r.stderr[-400:])
+                continue
+            res[name].append(json.loads(line[-1]))
+    keys = res["base"][0].keys() if res["base"] else []
+    for k in keys:
+        print(f"{k:22s} " + "  ".join(f"{n}: " + " ".join(f"{x[k]:7.2f}" for x in res[n]) for n in res))
+
+
+if __name__ == "__main__":
+    main()
