@@ -404,7 +404,7 @@ int gemm_launch(const wqaa_matmul_desc& d, const void* A, const void* B, const v
       seen = ep;
     }
     const long out_bytes = (long)m * d.N * (d.out_dtype == WQAA_I32 || d.out_dtype == WQAA_F32 ? 4 : 2);
-    a.ws_policy = policy >= 0 ? policy : (3 | (out_bytes >= (8L << 20) ? 16 : 0));
+    a.ws_policy = policy >= 0 ? policy : (3 | (out_bytes >= (4L << 20) ? 16 : 0));
   }
   a.nsteps = d.K / c.ks;
   if (c.pp) {                               // the ping-pong member reads gq_shift as log2(k-bodies per group)

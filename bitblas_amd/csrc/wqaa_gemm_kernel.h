@@ -920,7 +920,11 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_kernel(const GemmArgs a) {
             if (a.has_bias) v[i] = v[i] + (half_t)bias_f[i];
           }
           const half2_t lo = {v[0], v[1]}, hi = {v[2], v[3]};
-          *reinterpret_cast<u32x2*>(reinterpret_cast<half_t*>(a.C) + base) = u32x2{as_u32(lo), as_u32(hi)};
+          u32x2* dst = reinterpret_cast<u32x2*>(reinterpret_cast<half_t*>(a.C) + base);
+          const u32x2 x = {as_u32(lo), as_u32(hi)};
+          // a large output leaves the chip write-through (GemmArgs::ws_policy bit 4): nothing dirty for the kernel boundary to write back
+          if (a.ws_policy & 16) asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" ::"v"(dst), "v"(x) : "memory");
+          else *dst = x;
         } else {
 #pragma unroll
           for (int i = 0; i < 4; ++i) store_out(a.C, base + i, acc[mf][nf][i], a.out_dtype, a.has_bias != 0, bias_f[i]);
