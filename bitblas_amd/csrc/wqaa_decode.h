@@ -243,6 +243,12 @@ __device__ __forceinline__ uint32_t sub_bytes(uint32_t u4, uint32_t z4) {
   return ((u4 | 0x80808080u) - z4) ^ 0x80808080u;
 }
 
+// per-byte (u - z) for codes u <= 3 (1- and 2-bit fields): ONE byte permute - the quad's bytes select from the table
+// {0 - z, 1 - z, 2 - z, 3 - z} (built once from z with sub_bytes) - instead of the three operations of sub_bytes
+__device__ __forceinline__ uint32_t sub_bytes_tbl(uint32_t u4, uint32_t tbl) {
+  return __builtin_amdgcn_perm(0u, tbl, u4);
+}
+
 // per-byte (u - z) mod 256 (SWAR, no inter-byte borrow).  8-bit weights with quantized zero points: the
 // TE expression subtracts in the int8 storage type (quantization.py:208-217), so the difference wraps
 __device__ __forceinline__ uint32_t sub_bytes_mod(uint32_t u, uint32_t z) {

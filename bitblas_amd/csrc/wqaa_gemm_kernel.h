@@ -341,7 +341,10 @@ __device__ __forceinline__ void dequant_lane_i8(const uint32_t (&w)[P::WL], uint
       uint32_t t[NQ];
       I8Unpack<T::BITS>::run(w[wi] ^ flip, t);
 #pragma unroll
-      for (int i = 0; i < NQ; ++i) t[i] = sub_bytes(t[i], zp4);
+      for (int i = 0; i < NQ; ++i) {
+        if constexpr (T::BITS <= 2) t[i] = sub_bytes_tbl(t[i], sub_bytes(0x03020100u, zp4));   // one byte permute (the table is loop invariant)
+        else t[i] = sub_bytes(t[i], zp4);
+      }
       uint32_t nat[NQ];
       to_natural_i8<T, P::LAYOUT>(t, nat, std::make_integer_sequence<int, NQ>{});
 #pragma unroll

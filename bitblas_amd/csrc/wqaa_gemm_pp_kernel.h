@@ -148,8 +148,9 @@ __device__ __forceinline__ void pp_decode_i8(uint32_t w, uint32_t zp4, uint32_t 
   static_assert(T::EPW == 16, "2-bit weights");
   uint32_t t[4];
   I8Unpack<2>::run(w ^ flip, t);
+  const uint32_t tbl = sub_bytes(0x03020100u, zp4);      // (loop invariant: the zero point is one value per launch)
 #pragma unroll
-  for (int i = 0; i < 4; ++i) t[i] = sub_bytes(t[i], zp4);
+  for (int i = 0; i < 4; ++i) t[i] = sub_bytes_tbl(t[i], tbl);
   to_natural_i8<T, P::LAYOUT>(t, out, std::make_integer_sequence<int, 4>{});
 }
 

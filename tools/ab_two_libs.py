@@ -13,12 +13,9 @@ sys.path.insert(0, %r)
 import bench
 dev = torch.device("cuda", 0); gen = torch.Generator(device=dev); gen.manual_seed(1)
 out = {}
-for (M, N, K) in ((16, 4096, 4096), (32, 4096, 4096), (128, 4096, 4096), (256, 4096, 4096)):
-    out[f"u4 M={M}"] = bench.time_member_gemm(dev, gen, M, N, K)["us_per_launch"]
-out["c4 step"] = bench.time_step_int2_int8(dev, gen)["us_per_step"]
-for (N, K) in ((4096, 4096), (12288, 4096)):
-    out[f"i2xi8 {N}x{K}"] = bench.time_member_dense(dev, gen, 1, N, K, kind="int2", n_buf=64)["us_per_launch"]
-    out[f"i4 strict {N}x{K}"] = bench.time_member_gemv(dev, gen, N, K, strict=True)["us_per_launch"]
+for (M, N, K) in ((4096, 4096, 4096), (2048, 4096, 4096), (1024, 4096, 4096), (128, 4096, 4096)):
+    out[f"i2xi8 M={M}"] = bench.time_member_gemm(dev, gen, M, N, K, W_dtype="int2", A_dtype="int8")["us_per_launch"]
+out["u4 M=4096"] = bench.time_member_gemm(dev, gen, 4096, 4096, 4096)["us_per_launch"]
 print(json.dumps(out))
 ''' % ROOT
 
