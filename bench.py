@@ -794,7 +794,14 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps(result))
+        # the JSON line is the LAST line of stdout: RCCL prints its banner through C stdio, which (redirected) would otherwise be
+        # flushed at exit, after Python's own buffer
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:  # noqa: BLE001
+            pass
+        print(json.dumps(result), flush=True)
 
 
 if __name__ == "__main__":
