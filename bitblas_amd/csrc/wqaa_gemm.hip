@@ -175,8 +175,11 @@ static int gemm_choose(const wqaa_matmul_desc& d, int m, GemmChoice* c, bool fus
     const int kb = c->at == AT_F16 ? 256 : c->at == AT_F8 ? 128 : 512;   // k per trip of the main loop
     const int gb = c->at == AT_F8 ? 1 : g / (kb / 2);                   // k-bodies (two k-tiles) per group
     // (packed integer zero points - GPTQ checkpoints: a wave fetches the 16 bytes of its 32 rows per group, so N in whole waves)
-    const bool meta_ok = c->mode == MD_NONE || (g % (kb / 2) == 0 && ilog2_exact(gb) >= 0 && ((d.K / g) & 1) == 0 && (long)d.N * (d.K / g) >= 8 &&
-                                                (c->mode != MD_ZQ || (d.N % 32 == 0 && c->bits == 4)));
+    // (one group per row - per-channel scales, the reference's default group_size = -1 - is the one odd K / g the members take:
+    // a row's 16-byte window then opens on the even element in front of it)
+    const bool one_group = d.K / g == 1;
+    const bool meta_ok = c->mode == MD_NONE || (g % (kb / 2) == 0 && (one_group || (ilog2_exact(gb) >= 0 && ((d.K / g) & 1) == 0)) &&
+                                                (long)d.N * (d.K / g) >= 8 && (c->mode != MD_ZQ || (d.N % 32 == 0 && c->bits == 4)));
     const bool out_ok = c->at == AT_I8 ? d.out_dtype == WQAA_I32 : d.out_dtype == WQAA_F16;
     const long a_bytes = (long)m * d.K * (c->at == AT_F16 ? 2 : 1), w_bytes = (long)d.N * d.K * c->bits / 8;
     const bool shape_ok = !fused_epilogue && d.K % kb == 0 && meta_ok && out_ok && d.N % 8 == 0 && a_bytes + 256L * d.K * 2 < (1L << 31) &&
@@ -209,7 +212,7 @@ static int gemm_choose(const wqaa_matmul_desc& d, int m, GemmChoice* c, bool fus
     if (bm) {
       c->pp = 1;
       c->pp_bm = bm;
-      c->pp_shift = c->mode == MD_NONE ? 0 : ilog2_exact(gb);
+      c->pp_shift = c->mode == MD_NONE ? 0 : one_group ? 20 : ilog2_exact(gb);     // (one group: every k-body maps to group 0)
       c->fn = bm == 256 ? fn256 : fn128;
       c->mf = bm / 16;
       c->nwaves = 8;

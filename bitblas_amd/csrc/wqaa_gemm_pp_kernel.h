@@ -236,8 +236,10 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_pp_kernel(const GemmArgs a
     b = b < nbodies ? b : nbodies - 1;
     return b >> a.gq_shift;
   };
-  auto window_start = [&](uint32_t rb, int q) -> uint32_t {   // first element of window q of a row (kept inside the array)
-    const uint32_t e = rb + (uint32_t)(q * 8);
+  // first element of window q of a row: kept inside the array and on a 4-byte boundary (a row starts on one whenever K / g is
+  // even; with ONE group per row - per-channel scales - an odd row's window opens one element early)
+  auto window_start = [&](uint32_t rb, int q) -> uint32_t {
+    const uint32_t e = (rb + (uint32_t)(q * 8)) & ~1u;
     return e < mlim ? e : mlim;
   };
 
@@ -338,7 +340,8 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_pp_kernel(const GemmArgs a
       const unsigned char* p = meta + ((gi >> 3) & 1) * 1024 + (pp_opaque(lane) & 15) * 16;
 #pragma unroll
       for (int nf = 0; nf < 2; ++nf) {
-        const int e = gi - (q8 < mlim_f[nf] ? q8 : mlim_f[nf]);
+        const int q8o = q8 - (mlim_f[nf] & 1);      // (mlim is even: the parity of mlim - rowbase is the row's)
+        const int e = gi - (q8o < mlim_f[nf] ? q8o : mlim_f[nf]);
         m_s[nf] = *reinterpret_cast<const uint16_t*>(p + nf * 256 + e * 2);
         if constexpr (ZP) m_z[nf] = *reinterpret_cast<const uint16_t*>(p + 512 + nf * 256 + e * 2);
         if constexpr (ZQ) {
@@ -405,7 +408,7 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_pp_kernel(const GemmArgs a
     const uint16_t* zrow = reinterpret_cast<const uint16_t*>(a.zeros);
     for (int i = 0; i < a.kg; i += 8) {
       const uint32_t e = rowbase + (uint32_t)i;
-      const u32x4 v = *reinterpret_cast<const u32x4*>(zrow + (e < mlim ? e : mlim));   // (neighbours' elements checked too near the end: conservative)
+      const u32x4 v = *reinterpret_cast<const u32x4*>(zrow + ((e < mlim ? e : mlim) & ~1u));   // (neighbours' elements checked too - near the end, and in front of an odd one-group row: conservative)
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         const float z = (float)bits_to_half(v[k >> 1] >> ((k & 1) * 16)) + (float)cx.zf;

@@ -48,6 +48,18 @@ def test_4bit_packed_integer_zero_points(M, N, K, wd):
     _run(case, M)
 
 
+@pytest.mark.parametrize("M,N,K", [(300, 520, 512), (257, 264, 1024)])
+@pytest.mark.parametrize("zeros_mode", [None, "original", "rescale", "quantized"])
+def test_uint4_one_group_per_row(M, N, K, zeros_mode):
+    """group_size = -1 (the reference's default): per-channel Scale / Zeros - a row's 16-byte window opens on the even element in
+    front of an odd row (ragged N: the last rows' windows are clamped into the array)"""
+    if zeros_mode == "quantized":
+        N = (N + 31) // 32 * 32
+    case = make_case(M, N, K, W_dtype="uint4", group_size=-1, with_scaling=True, with_zeros=zeros_mode is not None,
+                     zeros_mode=zeros_mode or "original", seed=M + N + K)
+    _run(case, M)
+
+
 def test_uint4_fractional_zero_points_take_the_general_decode():
     case = make_case(300, 520, 512, W_dtype="uint4", group_size=128, with_scaling=True, with_zeros=True, seed=5)
     case["zeros"] = (case["zeros"].astype(np.float32) + 0.375).astype(np.float16)
@@ -123,14 +135,15 @@ def test_dense_fp8_pairings_ragged(a_dt, w_dt, M, N, K, pin_the_tile):
 
 
 def test_what_the_member_does_not_cover_falls_back(monkeypatch):
-    """bfloat16 activations, float32 output, per-channel scales, quantized zeros with N off the 32-row grid, K off the 256 grid:
-    the lockstep member (whichever tile is asked for)."""
+    """bfloat16 activations, float32 output, an odd number (> 1) of groups per row, quantized zeros with N off the 32-row grid, K off
+    the 256 grid: the lockstep member (whichever tile is asked for)."""
     import bitblas_amd as bitblas
     for kw in (dict(N=512, A_dtype="bfloat16", out_dtype="bfloat16", accum_dtype="float32", W_dtype="uint4", group_size=128, with_scaling=True),
                dict(N=512, A_dtype="float16", out_dtype="float32", accum_dtype="float32", W_dtype="uint4", group_size=128, with_scaling=True),
                dict(N=520, A_dtype="float16", W_dtype="uint4", group_size=128, with_scaling=True, with_zeros=True, zeros_mode="quantized"),
-               dict(N=512, A_dtype="float16", W_dtype="uint4", group_size=-1, with_scaling=True)):
-        mm = bitblas.Matmul(bitblas.MatmulConfig(M=512, K=512, **kw), enable_tuning=False)
+               dict(N=512, K=768, A_dtype="float16", W_dtype="uint4", group_size=256, with_scaling=True)):      # three groups per row
+        kw.setdefault("K", 512)
+        mm = bitblas.Matmul(bitblas.MatmulConfig(M=512, **kw), enable_tuning=False)
         assert not mm.plans[512]["name"].endswith("pp"), mm.plans[512]["name"]
     mm = bitblas.Matmul(bitblas.MatmulConfig(M=512, N=512, K=384, A_dtype="float16", W_dtype="uint4", group_size=128, with_scaling=True),
                         enable_tuning=False)
