@@ -180,7 +180,9 @@ static int gemm_choose(const wqaa_matmul_desc& d, int m, GemmChoice* c, bool fus
     const bool one_group = d.K / g == 1;
     const bool meta_ok = c->mode == MD_NONE || (g % (kb / 2) == 0 && (one_group || (ilog2_exact(gb) >= 0 && ((d.K / g) & 1) == 0)) &&
                                                 (long)d.N * (d.K / g) >= 8 && (c->mode != MD_ZQ || (d.N % 32 == 0 && c->bits == 4)));
-    const bool out_ok = c->at == AT_I8 ? d.out_dtype == WQAA_I32 : d.out_dtype == WQAA_F16;
+    const bool out_ok = c->at == AT_I8 ? d.out_dtype == WQAA_I32
+                        : c->at == AT_F8 ? d.out_dtype == WQAA_F16
+                        : (d.out_dtype == WQAA_F32 || d.out_dtype == ((c->flags & FL_BF16) ? WQAA_BF16 : WQAA_F16));
     const long a_bytes = (long)m * d.K * (c->at == AT_F16 ? 2 : 1), w_bytes = (long)d.N * d.K * c->bits / 8;
     const bool shape_ok = !fused_epilogue && d.K % kb == 0 && meta_ok && out_ok && d.N % 8 == 0 && a_bytes + 256L * d.K * 2 < (1L << 31) &&
                           w_bytes < (1L << 31) && d.k_split_hint <= 1 && getenv("WQAA_GEMM_KSPLIT") == nullptr && (!pf || atoi(pf) != 0);
@@ -624,7 +626,7 @@ void gemm_init() {
     for (int layout = 0; layout < 2; ++layout)
       for (int at : {AT_F16, AT_I8, AT_F8})
         for (int mode = 0; mode <= MD_ZQ; ++mode)
-          for (int flags : {0, (int)FL_ABF8}) {
+          for (int flags : {0, (int)FL_ABF8, (int)FL_BF16}) {
           for (int bm : {256, 128}) {
             int lds = 0;
             gemm_fn fn = pick_gemm_pp(kind, layout, at, mode, flags, bm, &lds);

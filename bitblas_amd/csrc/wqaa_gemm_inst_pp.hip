@@ -19,6 +19,19 @@ static gemm_fn pp_modes_f16(int mode) {
 }
 
 template <int BM>
+static gemm_fn pp_modes_bf16(int mode) {
+  constexpr int R = BM == 128 ? 5 : 3;
+  switch (mode) {
+    case MD_NONE: return wq_gemm_pp_kernel<PPPolicy<DK_INT4, LAYOUT_PLAIN, AT_F16, MD_NONE, FL_BF16, R, 0, BM>>;
+    case MD_S: return wq_gemm_pp_kernel<PPPolicy<DK_INT4, LAYOUT_PLAIN, AT_F16, MD_S, FL_BF16, R, 0, BM>>;
+    case MD_ZO: return wq_gemm_pp_kernel<PPPolicy<DK_INT4, LAYOUT_PLAIN, AT_F16, MD_ZO, FL_BF16, R, 0, BM>>;
+    case MD_ZR: return wq_gemm_pp_kernel<PPPolicy<DK_INT4, LAYOUT_PLAIN, AT_F16, MD_ZR, FL_BF16, R, 0, BM>>;
+    case MD_ZQ: return wq_gemm_pp_kernel<PPPolicy<DK_INT4, LAYOUT_PLAIN, AT_F16, MD_ZQ, FL_BF16, R, 0, BM>>;
+  }
+  return nullptr;
+}
+
+template <int BM>
 static gemm_fn pick_pp_bm(int kind, int layout, int at, int mode, int* lds_bytes) {
   gemm_fn fn = nullptr;
   if (at == AT_F16) {
@@ -45,7 +58,15 @@ gemm_fn pick_gemm_pp(int kind, int layout, int at, int mode, int flags, int bm, 
     *lds_bytes = PP8Policy<0, 0>::LDS_BYTES;
     return fn;
   }
-  if (flags != 0) return nullptr;                       // bfloat16 / strict e4m3: wq_gemm_kernel
+  if (flags == (int)FL_BF16 && at == AT_F16 && kind == DK_INT4 && layout == LAYOUT_PLAIN) {      // bfloat16 activations x 4-bit integer weights
+    fn = bm == 256 ? pp_modes_bf16<256>(mode) : pp_modes_bf16<128>(mode);
+    if (fn) *lds_bytes = bm == 256 ? PPPolicy<DK_INT4, LAYOUT_PLAIN, AT_F16, MD_S, FL_BF16, 3, 0, 256>::LDS_BYTES
+                                   : PPPolicy<DK_INT4, LAYOUT_PLAIN, AT_F16, MD_S, FL_BF16, 5, 0, 128>::LDS_BYTES;
+    if (fn && mode == MD_NONE) *lds_bytes = bm == 256 ? PPPolicy<DK_INT4, LAYOUT_PLAIN, AT_F16, MD_NONE, FL_BF16, 3, 0, 256>::LDS_BYTES
+                                                      : PPPolicy<DK_INT4, LAYOUT_PLAIN, AT_F16, MD_NONE, FL_BF16, 5, 0, 128>::LDS_BYTES;
+    return fn;
+  }
+  if (flags != 0) return nullptr;                       // strict e4m3, other bfloat16 formats: wq_gemm_kernel
   fn = bm == 256 ? pick_pp_bm<256>(kind, layout, at, mode, lds_bytes) : pick_pp_bm<128>(kind, layout, at, mode, lds_bytes);
   return fn;
 }

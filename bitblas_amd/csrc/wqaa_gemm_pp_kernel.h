@@ -142,6 +142,14 @@ __device__ __forceinline__ void pp_decode_f16(uint32_t w, half_t zf, half2_t s2,
   to_natural_f16<T, P::LAYOUT>(q, out, std::make_integer_sequence<int, 4>{});
 }
 
+// bfloat16 activations (FL_BF16; plain layout): the lockstep member's decode, one word at a time (unpack_word_bf16: field ->
+// float -> the mode's arithmetic with its bfloat16 roundings -> packed bfloat16 pairs in natural k order)
+template <class P>
+__device__ __forceinline__ void pp_decode_bf16(uint32_t w, float zf, float s, float z, uint32_t (&out)[4]) {
+  constexpr int ZM = P::MODE == MD_ZO ? 1 : P::MODE == MD_ZR ? 2 : 0;
+  unpack_word_bf16<4, 1, ZM>(w, zf, s, P::MODE != MD_NONE, out, z);
+}
+
 template <class P>
 __device__ __forceinline__ void pp_decode_i8(uint32_t w, uint32_t zp4, uint32_t flip, uint32_t (&out)[4]) {
   using T = typename P::T;
@@ -159,6 +167,7 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_pp_kernel(const GemmArgs a
 #if defined(__HIP_DEVICE_COMPILE__)   // the host pass only needs the stub (the buffer-resource builtins do not exist there)
   using T = typename P::T;
   constexpr bool F16 = P::AT == AT_F16;
+  constexpr bool BF = F16 && (P::FLAGS & FL_BF16) != 0;     // bfloat16 activations / Scale / Zeros / output (4-bit integer weights, plain layout)
   constexpr int MODE = P::MODE, D = P::D, RING = P::RING;
   constexpr int NMF = P::BM / 16;       // 16-row activation fragments: 16 / 8
   constexpr int NPH = P::NPH, HP = NPH / 2;   // phases per k-tile; phases per MFMA (k-half) of the tile
@@ -353,7 +362,15 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_pp_kernel(const GemmArgs a
     }
   };
   auto meta_convert = [&](auto ZI, half2_t (&s2)[2], half2_t (&zA)[2], half2_t (&zB)[2]) {
-    if constexpr (P::HAS_META) {
+    if constexpr (P::HAS_META && BF) {
+      // bfloat16: Scale and zero point travel as fp32 in the same registers
+#pragma unroll
+      for (int nf = 0; nf < 2; ++nf) {
+        s2[nf] = __builtin_bit_cast(half2_t, bf16_bits_to_float(m_s[nf]));
+        if constexpr (ZP) zA[nf] = __builtin_bit_cast(half2_t, bf16_bits_to_float(m_z[nf]));
+        if constexpr (ZQ) zA[nf] = __builtin_bit_cast(half2_t, (float)m_z[nf]);
+      }
+    } else if constexpr (P::HAS_META) {
 #pragma unroll
       for (int nf = 0; nf < 2; ++nf) {
         s2[nf] = splat(bits_to_half(m_s[nf]));
@@ -375,7 +392,11 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_pp_kernel(const GemmArgs a
     }
   };
   auto decode = [&](auto ZI, uint32_t w, half2_t s2, half2_t zA, half2_t zB, uint32_t (&out)[4]) {
-    if constexpr (F16) pp_decode_f16<P, decltype(ZI)::value != 0>(w, cx.zf, s2, zA, zB, cx, lut, out);
+    if constexpr (BF) {
+      // (quantized zeros: the integer zero point replaces the sign offset, as in the lockstep member)
+      const float zv = __builtin_bit_cast(float, zA);
+      pp_decode_bf16<P>(w, ZQ ? zv : (float)cx.zf, __builtin_bit_cast(float, s2), zv, out);
+    } else if constexpr (F16) pp_decode_f16<P, decltype(ZI)::value != 0>(w, cx.zf, s2, zA, zB, cx, lut, out);
     else pp_decode_i8<P>(w, zp4, cx.flip, out);
   };
   auto read_words = [&](int half, int buf) {        // k-tiles 2 * half, 2 * half + 1 of the landed chunk (in buffer buf) -> registers
@@ -403,7 +424,7 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_pp_kernel(const GemmArgs a
     for (int j = 0; j < NPH; ++j) dma_a(tt, tt, j);
   // zeros-original: are all zero points of this wave's rows integers the magic subtraction holds exactly?  (asked for behind
   // the first LDS-DMA pieces: the answer travels with them)
-  if constexpr (F16 && MODE == MD_ZO && P::KIND == DK_INT4 && !(P::OPT & PPO_ZINT_OFF)) {
+  if constexpr (F16 && !BF && MODE == MD_ZO && P::KIND == DK_INT4 && !(P::OPT & PPO_ZINT_OFF)) {
     bool ok = true;
     const uint16_t* zrow = reinterpret_cast<const uint16_t*>(a.zeros);
     for (int i = 0; i < a.kg; i += 8) {
@@ -540,7 +561,10 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_pp_kernel(const GemmArgs a
 #pragma unroll
       for (int nf = 0; nf < 2; ++nf) {
         const u32x4 bv = {bw[par][nf][0], bw[par][nf][1], bw[par][nf][2], bw[par][nf][3]};
-        if constexpr (F16)
+        if constexpr (BF)
+          acc[mh * 8 + i][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, bv), __builtin_bit_cast(bf16x8_t, afrag[i]),
+                                                                      acc[mh * 8 + i][nf], 0, 0, 0);
+        else if constexpr (F16)
           acc[mh * 8 + i][nf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8_t, bv), __builtin_bit_cast(half8_t, afrag[i]),
                                                                      acc[mh * 8 + i][nf], 0, 0, 0);
         else
@@ -608,17 +632,21 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_pp_kernel(const GemmArgs a
   PP_BARRIER();
   const int el = pp_opaque(lane);          // (lane roles recomputed: nothing of the epilogue stays live across the loop)
   const int e_fr = el & 15, e_kb = el >> 4, e_ln = el & 31, e_h = el >> 5;
-  if constexpr (F16) {
+  const bool wide_out = !F16 || a.out_dtype == WQAA_F32;       // 4-byte output elements: int32, or float32 out of the float members
+  if (!wide_out) {
+   if constexpr (F16) {
     // unit = 4 consecutive n (8 bytes); unit u of row m lives at pair ((u >> 1) ^ (m & 7)), half ((u & 1) ^ ((m >> 3) & 1)):
     // the 16 lanes of a ds_write_b64 group (16 consecutive m, one u) hit 16 distinct 8-byte slots of a 128-byte window
     half_t bias_h[2][4];
+    float bias_bf[2][4];                   // bfloat16: cast, then + bias in bfloat16 (store_out, wqaa_kinds.h)
     if (a.has_bias) {
 #pragma unroll
       for (int nf = 0; nf < 2; ++nf)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int n = nw0 + nf * 16 + e_kb * 4 + i;
-          bias_h[nf][i] = reinterpret_cast<const half_t*>(a.bias)[n < a.N ? n : a.N - 1];
+          if constexpr (BF) bias_bf[nf][i] = bf16_bits_to_float(reinterpret_cast<const uint16_t*>(a.bias)[n < a.N ? n : a.N - 1]);
+          else bias_h[nf][i] = reinterpret_cast<const half_t*>(a.bias)[n < a.N ? n : a.N - 1];
         }
     }
 #pragma unroll
@@ -626,16 +654,30 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_pp_kernel(const GemmArgs a
       const int m = f * 16 + e_fr;
 #pragma unroll
       for (int nf = 0; nf < 2; ++nf) {
-        half_t v[4];
+        uint32_t lo_u, hi_u;
+        if constexpr (BF) {
+          float x[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          v[i] = (half_t)acc[f][nf][i];
-          if (a.has_bias) v[i] = v[i] + bias_h[nf][i];
+          for (int i = 0; i < 4; ++i) {
+            x[i] = bf16_round(acc[f][nf][i]);
+            if (a.has_bias) x[i] = bf16_round(x[i] + bias_bf[nf][i]);
+          }
+          lo_u = (__builtin_bit_cast(uint32_t, x[0]) >> 16) | (__builtin_bit_cast(uint32_t, x[1]) & 0xFFFF0000u);
+          hi_u = (__builtin_bit_cast(uint32_t, x[2]) >> 16) | (__builtin_bit_cast(uint32_t, x[3]) & 0xFFFF0000u);
+        } else {
+          half_t v[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            v[i] = (half_t)acc[f][nf][i];
+            if (a.has_bias) v[i] = v[i] + bias_h[nf][i];
+          }
+          const half2_t lo = {v[0], v[1]}, hi = {v[2], v[3]};
+          lo_u = as_u32(lo);
+          hi_u = as_u32(hi);
         }
         const int u = wave * 8 + nf * 4 + e_kb;
         const int up = (((u >> 1) ^ (m & 7)) << 1) | ((u & 1) ^ ((m >> 3) & 1));
-        const half2_t lo = {v[0], v[1]}, hi = {v[2], v[3]};
-        *reinterpret_cast<u32x2*>(smem + m * 512 + up * 8) = u32x2{as_u32(lo), as_u32(hi)};
+        *reinterpret_cast<u32x2*>(smem + m * 512 + up * 8) = u32x2{lo_u, hi_u};
       }
     }
     PP_FENCE();
@@ -653,16 +695,21 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_pp_kernel(const GemmArgs a
         pp_store_out(dst, x, a.ws_policy);
       }
     }
+   }
   } else {
-    // int32 output: 16 bytes per (lane, fragment); two passes of 128 rows (128 KiB each).  Slot s = n / 4 of row m lives at
+    // int32 / float32 output: 16 bytes per (lane, fragment); passes of 128 rows (128 KiB each).  Slot s = n / 4 of row m lives at
     // s ^ (m & 7): the 8 lanes of a ds_write_b128 group (8 consecutive m) hit 8 distinct 16-byte slots
-    int bias_i[2][4];
+    using bias_t = typename std::conditional<F16, float, int>::type;
+    bias_t bias_i[2][4];
 #pragma unroll
     for (int nf = 0; nf < 2; ++nf)
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int n = nw0 + nf * 16 + e_kb * 4 + i;
-        bias_i[nf][i] = a.has_bias ? (int)reinterpret_cast<const int8_t*>(a.bias)[n < a.N ? n : a.N - 1] : 0;
+        const int nc = n < a.N ? n : a.N - 1;
+        if constexpr (BF) bias_i[nf][i] = a.has_bias ? bf16_bits_to_float(reinterpret_cast<const uint16_t*>(a.bias)[nc]) : 0.f;
+        else if constexpr (F16) bias_i[nf][i] = a.has_bias ? (float)reinterpret_cast<const half_t*>(a.bias)[nc] : 0.f;
+        else bias_i[nf][i] = a.has_bias ? (int)reinterpret_cast<const int8_t*>(a.bias)[nc] : 0;
       }
 #pragma unroll
     for (int pass = 0; pass < P::BM / 128; ++pass) {
@@ -674,8 +721,8 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_pp_kernel(const GemmArgs a
 #pragma unroll
         for (int nf = 0; nf < 2; ++nf) {
           const int sidx = wave * 8 + nf * 4 + e_kb;
-          const i32x4 v = {acc[f][nf][0] + bias_i[nf][0], acc[f][nf][1] + bias_i[nf][1], acc[f][nf][2] + bias_i[nf][2], acc[f][nf][3] + bias_i[nf][3]};
-          *reinterpret_cast<i32x4*>(smem + ml * 1024 + ((sidx ^ (ml & 7)) * 16)) = v;
+          const acc_t v = {acc[f][nf][0] + bias_i[nf][0], acc[f][nf][1] + bias_i[nf][1], acc[f][nf][2] + bias_i[nf][2], acc[f][nf][3] + bias_i[nf][3]};
+          *reinterpret_cast<acc_t*>(smem + ml * 1024 + ((sidx ^ (ml & 7)) * 16)) = v;
         }
       }
       PP_FENCE();

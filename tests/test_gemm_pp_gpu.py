@@ -60,6 +60,24 @@ def test_uint4_one_group_per_row(M, N, K, zeros_mode):
     _run(case, M)
 
 
+@pytest.mark.parametrize("M,N,K", [(300, 544, 512), (513, 288, 1024)])
+@pytest.mark.parametrize("wd,g,ws,zm", [("uint4", -1, False, None), ("int4", 128, True, None), ("uint4", 128, True, "original"),
+                                        ("uint4", 128, True, "rescale"), ("uint4", 128, True, "quantized"), ("uint4", -1, True, "original")])
+def test_bfloat16_activations(M, N, K, wd, g, ws, zm):
+    """A_dtype = bfloat16 (float32 accumulate, float32 output: the reference's test_general_matmul_bf16.py configuration): the
+    lockstep member's per-word decode inside the ping-pong loop, bfloat16 MFMA"""
+    from test_gemm_gpu import _bf16_case
+    out, want, mm = _bf16_case(M, N, K, wd, g, ws, zm, seed=M + N)
+    import os
+    assert mm.plans[M]["name"].endswith("pp") and f"_tcx{os.environ['WQAA_GEMM_PP_BM']}x256x" in mm.plans[M]["name"], mm.plans[M]["name"]
+    assert_fp_parity(out, want, rtol=1e-5, atol_frac=1e-5)
+
+
+def test_float32_output_of_the_float16_members():
+    case = make_case(300, 520, 512, W_dtype="uint4", group_size=128, with_scaling=True, with_zeros=True, out_dtype="float32", seed=9)
+    _run(case, 300)
+
+
 def test_uint4_fractional_zero_points_take_the_general_decode():
     case = make_case(300, 520, 512, W_dtype="uint4", group_size=128, with_scaling=True, with_zeros=True, seed=5)
     case["zeros"] = (case["zeros"].astype(np.float32) + 0.375).astype(np.float16)
@@ -135,11 +153,11 @@ def test_dense_fp8_pairings_ragged(a_dt, w_dt, M, N, K, pin_the_tile):
 
 
 def test_what_the_member_does_not_cover_falls_back(monkeypatch):
-    """bfloat16 activations, float32 output, an odd number (> 1) of groups per row, quantized zeros with N off the 32-row grid, K off
-    the 256 grid: the lockstep member (whichever tile is asked for)."""
+    """bfloat16 activations with 2-bit weights, bfloat16 output of float16 activations... - formats without a ping-pong member; an odd
+    number (> 1) of groups per row, quantized zeros with N off the 32-row grid, K off the 256 grid: the lockstep member."""
     import bitblas_amd as bitblas
-    for kw in (dict(N=512, A_dtype="bfloat16", out_dtype="bfloat16", accum_dtype="float32", W_dtype="uint4", group_size=128, with_scaling=True),
-               dict(N=512, A_dtype="float16", out_dtype="float32", accum_dtype="float32", W_dtype="uint4", group_size=128, with_scaling=True),
+    for kw in (dict(N=512, A_dtype="bfloat16", out_dtype="bfloat16", accum_dtype="float32", W_dtype="uint2", group_size=128, with_scaling=True),
+               dict(N=512, A_dtype="bfloat16", out_dtype="float32", accum_dtype="float32", W_dtype="nf4", group_size=128, with_scaling=True),
                dict(N=520, A_dtype="float16", W_dtype="uint4", group_size=128, with_scaling=True, with_zeros=True, zeros_mode="quantized"),
                dict(N=512, K=768, A_dtype="float16", W_dtype="uint4", group_size=256, with_scaling=True)):      # three groups per row
         kw.setdefault("K", 512)
