@@ -58,6 +58,20 @@ gemm_fn pick_gemm_pp(int kind, int layout, int at, int mode, int flags, int bm, 
     *lds_bytes = PP8Policy<0, 0>::LDS_BYTES;
     return fn;
   }
+  if (flags == (int)FL_BF16 && at == AT_F16 && kind == DK_LUT4 && layout == LAYOUT_PLAIN && (mode == MD_NONE || mode == MD_S)) {   // bfloat16 x nf4 / fp4
+    if (mode == MD_NONE) {
+      fn = bm == 256 ? wq_gemm_pp_kernel<PPPolicy<DK_LUT4, LAYOUT_PLAIN, AT_F16, MD_NONE, FL_BF16, 3, 0, 256>>
+                     : wq_gemm_pp_kernel<PPPolicy<DK_LUT4, LAYOUT_PLAIN, AT_F16, MD_NONE, FL_BF16, 5, 0, 128>>;
+      *lds_bytes = bm == 256 ? PPPolicy<DK_LUT4, LAYOUT_PLAIN, AT_F16, MD_NONE, FL_BF16, 3, 0, 256>::LDS_BYTES
+                             : PPPolicy<DK_LUT4, LAYOUT_PLAIN, AT_F16, MD_NONE, FL_BF16, 5, 0, 128>::LDS_BYTES;
+    } else {
+      fn = bm == 256 ? wq_gemm_pp_kernel<PPPolicy<DK_LUT4, LAYOUT_PLAIN, AT_F16, MD_S, FL_BF16, 3, 0, 256>>
+                     : wq_gemm_pp_kernel<PPPolicy<DK_LUT4, LAYOUT_PLAIN, AT_F16, MD_S, FL_BF16, 5, 0, 128>>;
+      *lds_bytes = bm == 256 ? PPPolicy<DK_LUT4, LAYOUT_PLAIN, AT_F16, MD_S, FL_BF16, 3, 0, 256>::LDS_BYTES
+                             : PPPolicy<DK_LUT4, LAYOUT_PLAIN, AT_F16, MD_S, FL_BF16, 5, 0, 128>::LDS_BYTES;
+    }
+    return fn;
+  }
   if (flags == (int)FL_BF16 && at == AT_F16 && kind == DK_INT4 && layout == LAYOUT_PLAIN) {      // bfloat16 activations x 4-bit integer weights
     fn = bm == 256 ? pp_modes_bf16<256>(mode) : pp_modes_bf16<128>(mode);
     if (fn) *lds_bytes = bm == 256 ? PPPolicy<DK_INT4, LAYOUT_PLAIN, AT_F16, MD_S, FL_BF16, 3, 0, 256>::LDS_BYTES

@@ -145,9 +145,21 @@ __device__ __forceinline__ void pp_decode_f16(uint32_t w, half_t zf, half2_t s2,
 // bfloat16 activations (FL_BF16; plain layout): the lockstep member's decode, one word at a time (unpack_word_bf16: field ->
 // float -> the mode's arithmetic with its bfloat16 roundings -> packed bfloat16 pairs in natural k order)
 template <class P>
-__device__ __forceinline__ void pp_decode_bf16(uint32_t w, float zf, float s, float z, uint32_t (&out)[4]) {
-  constexpr int ZM = P::MODE == MD_ZO ? 1 : P::MODE == MD_ZR ? 2 : 0;
-  unpack_word_bf16<4, 1, ZM>(w, zf, s, P::MODE != MD_NONE, out, z);
+__device__ __forceinline__ void pp_decode_bf16(uint32_t w, float zf, float s, float z, const Lut16& lut, uint32_t (&out)[4]) {
+  if constexpr (P::KIND == DK_LUT4) {
+    // nf4 / fp4: the table holds bfloat16 bit patterns; the scale is applied with one rounding, then natural order
+    using T = typename P::T;
+    half2_t q[4];
+    lut16_word(lut, w, q);
+    if constexpr (P::MODE != MD_NONE) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) q[i] = as_h2(bf16x2_scale(as_u32(q[i]), s));
+    }
+    to_natural_f16<T, P::LAYOUT>(q, out, std::make_integer_sequence<int, 4>{});
+  } else {
+    constexpr int ZM = P::MODE == MD_ZO ? 1 : P::MODE == MD_ZR ? 2 : 0;
+    unpack_word_bf16<4, 1, ZM>(w, zf, s, P::MODE != MD_NONE, out, z);
+  }
 }
 
 template <class P>
@@ -310,7 +322,7 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_pp_kernel(const GemmArgs a
   const uint32_t zp4 = (!F16 && a.is_signed) ? 0x02020202u : 0u;
   Lut16 lut;
   if constexpr (P::KIND == DK_LUT4) {
-    if (a.fp4_table) lut = make_fp4_lut(false);
+    if (a.fp4_table) lut = make_fp4_lut(BF);
     else lut = make_lut16(reinterpret_cast<const half_t*>(a.lut));
   }
 
@@ -395,7 +407,7 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_pp_kernel(const GemmArgs a
     if constexpr (BF) {
       // (quantized zeros: the integer zero point replaces the sign offset, as in the lockstep member)
       const float zv = __builtin_bit_cast(float, zA);
-      pp_decode_bf16<P>(w, ZQ ? zv : (float)cx.zf, __builtin_bit_cast(float, s2), zv, out);
+      pp_decode_bf16<P>(w, ZQ ? zv : (float)cx.zf, __builtin_bit_cast(float, s2), zv, lut, out);
     } else if constexpr (F16) pp_decode_f16<P, decltype(ZI)::value != 0>(w, cx.zf, s2, zA, zB, cx, lut, out);
     else pp_decode_i8<P>(w, zp4, cx.flip, out);
   };

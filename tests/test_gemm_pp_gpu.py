@@ -62,7 +62,8 @@ def test_uint4_one_group_per_row(M, N, K, zeros_mode):
 
 @pytest.mark.parametrize("M,N,K", [(300, 544, 512), (513, 288, 1024)])
 @pytest.mark.parametrize("wd,g,ws,zm", [("uint4", -1, False, None), ("int4", 128, True, None), ("uint4", 128, True, "original"),
-                                        ("uint4", 128, True, "rescale"), ("uint4", 128, True, "quantized"), ("uint4", -1, True, "original")])
+                                        ("uint4", 128, True, "rescale"), ("uint4", 128, True, "quantized"), ("uint4", -1, True, "original"),
+                                        ("nf4", 128, True, None), ("fp4_e2m1", -1, False, None)])
 def test_bfloat16_activations(M, N, K, wd, g, ws, zm):
     """A_dtype = bfloat16 (float32 accumulate, float32 output: the reference's test_general_matmul_bf16.py configuration): the
     lockstep member's per-word decode inside the ping-pong loop, bfloat16 MFMA"""
@@ -157,7 +158,7 @@ def test_what_the_member_does_not_cover_falls_back(monkeypatch):
     number (> 1) of groups per row, quantized zeros with N off the 32-row grid, K off the 256 grid: the lockstep member."""
     import bitblas_amd as bitblas
     for kw in (dict(N=512, A_dtype="bfloat16", out_dtype="bfloat16", accum_dtype="float32", W_dtype="uint2", group_size=128, with_scaling=True),
-               dict(N=512, A_dtype="bfloat16", out_dtype="float32", accum_dtype="float32", W_dtype="nf4", group_size=128, with_scaling=True),
+               dict(N=512, A_dtype="bfloat16", out_dtype="float32", accum_dtype="float32", W_dtype="int8", group_size=128, with_scaling=True),
                dict(N=520, A_dtype="float16", W_dtype="uint4", group_size=128, with_scaling=True, with_zeros=True, zeros_mode="quantized"),
                dict(N=512, K=768, A_dtype="float16", W_dtype="uint4", group_size=256, with_scaling=True)):      # three groups per row
         kw.setdefault("K", 512)
