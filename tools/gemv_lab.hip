@@ -1,5 +1,6 @@
 // gemv_lab.hip - lab harness for the exact-product GEMV (csrc/wqaa_gemvx_kernel.h): in-kernel time lines of the shipped
-// geometry, and A/B of experimental members against the library's launch on the same box, same buffers.
+// geometry (s_memrealtime stamps of every wave, lab-only policy bit 64) next to the library's launch on the same box, same buffers;
+// --rotate-mb: how many MB of weight sets the launches rotate over (cache-residency experiment).
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -I bitblas_amd/csrc -I include tools/gemv_lab.hip \
 //         -L bitblas_amd -lwqaa_hip -Wl,-rpath,'$ORIGIN/../bitblas_amd' -o tools/gemv_lab
 //   tools/gemv_lab N K [--group G] [--iters I] [--rounds R]
@@ -17,7 +18,6 @@
 
 #include "wqaa.h"
 #include "wqaa_gemvx_kernel.h"
-#include "gemvs_lab_kernel.h"
 
 using namespace wqaa;
 
@@ -186,7 +186,5 @@ int main(int argc, char** argv) {
     }
   }
 
-  // ---- experimental members (tools/gemvs_lab_kernel.h) ----
-  run_gemvs_lab(N, K, G, count, dA, dS, dW, NSETS, dC, dC2, st, time_it, bytes);
   return 0;
 }
