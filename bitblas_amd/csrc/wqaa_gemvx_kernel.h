@@ -332,7 +332,7 @@ __global__ void __launch_bounds__(1024) wq_gemvx_kernel(const GemvxGroupArgs grp
       uint32_t f[R][NPAIR];
 #pragma unroll
       for (int r = 0; r < R; ++r) {
-        const uint32_t w = s.w[r][u] ^ a.flip;
+        const uint32_t w = BITS == 1 ? (s.w[r][u] ^ a.flip) : s.w[r][u];      // (only the signed 1-bit format flips its codes)
         const uint32_t w8 = w >> 8;
 #pragma unroll
         for (int i = 0; i < NPAIR; ++i) {

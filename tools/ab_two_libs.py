@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """tools/ab_two_libs.py: the same members timed under two builds of the library (WQAA_LIBRARY), alternating processes on one
-box: bitblas_amd/libwqaa_hip_base.so (a copy of the previous build) against bitblas_amd/libwqaa_hip.so."""
+box: bitblas_amd/libwqaa_hip_base.so (a copy of the previous build) against bitblas_amd/libwqaa_hip.so.  AB_SET=gemv (default) / gemm picks the members."""
 import json
 import os
 import subprocess
@@ -13,9 +13,17 @@ sys.path.insert(0, %r)
 import bench
 dev = torch.device("cuda", 0); gen = torch.Generator(device=dev); gen.manual_seed(1)
 out = {}
-for (M, N, K) in ((4096, 4096, 4096), (2048, 4096, 4096), (1024, 4096, 4096), (128, 4096, 4096)):
-    out[f"i2xi8 M={M}"] = bench.time_member_gemm(dev, gen, M, N, K, W_dtype="int2", A_dtype="int8")["us_per_launch"]
-out["u4 M=4096"] = bench.time_member_gemm(dev, gen, 4096, 4096, 4096)["us_per_launch"]
+which = os.environ.get("AB_SET", "gemv")
+if which == "gemm":
+    for (M, N, K) in ((4096, 4096, 4096), (2048, 4096, 4096), (1024, 4096, 4096), (128, 4096, 4096)):
+        out[f"i2xi8 M={M}"] = bench.time_member_gemm(dev, gen, M, N, K, W_dtype="int2", A_dtype="int8")["us_per_launch"]
+    out["u4 M=4096"] = bench.time_member_gemm(dev, gen, 4096, 4096, 4096)["us_per_launch"]
+else:
+    out["c4 step"] = bench.time_step_int2_int8(dev, gen)["us_per_step"]
+    for (N, K) in ((4096, 4096), (12288, 4096), (22016, 4096), (4096, 11008)):
+        out[f"i2xi8 {N}x{K}"] = bench.time_member_dense(dev, gen, 1, N, K, kind="int2", n_buf=max(3, min(64, (640 << 20) // (N * K // 4))))["us_per_launch"]
+    for (N, K) in ((4096, 4096), (12288, 4096), (22016, 4096)):
+        out[f"i4 exact {N}x{K}"] = bench.time_member_gemv(dev, gen, N, K)["us_per_launch"]
 print(json.dumps(out))
 ''' % ROOT
 
