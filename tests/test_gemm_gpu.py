@@ -157,6 +157,23 @@ def test_prefill_sized_m_int2_int8_bit_exact_sampled_rows(M, N, K):
     _sampled_rows_check(case, got, rows, exact=True)
 
 
+@pytest.mark.parametrize("M,N,K,kw", [(128, 1024, 2048, dict(W_dtype="uint4", group_size=128, with_scaling=True, with_zeros=True, scale_mul=0.05)),
+                                      (48, 768, 4096, dict(W_dtype="int2", A_dtype="int8", out_dtype="int32")),
+                                      (1024, 1024, 1024, dict(W_dtype="uint4", group_size=128, with_scaling=True, with_zeros=True, scale_mul=0.05))])
+def test_store_policy_of_partial_sums_and_large_outputs_does_not_change_a_bit(M, N, K, kw, monkeypatch):
+    """Split-K partial sums and large output tiles leave the chip write-through (sc0 sc1 stores; csrc/wqaa_gemm.hip,
+    `WQAA_GEMM_WS_POLICY`): a cache policy, not arithmetic - plain stores must give the same bits."""
+    case = make_case(M, N, K, seed=M + K, **kw)
+    got, mm = hip_output(case)
+    monkeypatch.setenv("WQAA_GEMM_WS_POLICY", "0")
+    plain, mm2 = hip_output(case)
+    assert mm.plans[M]["name"] == mm2.plans[M]["name"]
+    assert np.array_equal(got, plain)
+    monkeypatch.setenv("WQAA_GEMM_WS_POLICY", "19")
+    forced, _ = hip_output(case)
+    assert np.array_equal(got, forced)
+
+
 def test_baseline_c4_int2_int8_gemm_full_size_64_sampled_rows():
     case = make_case(4096, 4096, 4096, W_dtype="int2", A_dtype="int8", out_dtype="int32", seed=4)
     got, mm = hip_output(case)

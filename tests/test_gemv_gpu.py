@@ -200,6 +200,22 @@ def test_lds_staged_low_bit_members_agree_with_the_register_members(wd, ad, M, m
         assert_fp_parity(got, oracle_output(case))
 
 
+@pytest.mark.parametrize("wd,N,K", [("int2", 512, 4096), ("uint2", 264, 4096), ("int1", 512, 8192), ("int2", 300, 3200)])
+@pytest.mark.parametrize("M", [1, 2])
+def test_integer_gemv_one_chunk_rows_agree_with_the_two_chunk_members(wd, N, K, M, monkeypatch):
+    """Rows of ONE lane chunk (2-bit weights at K = 4096: 64 lanes x 64 weights; K = 3200 fills 50 lanes of it) run the
+    (4 rows x 1 chunk) integer-activation members (`..._b?r4d1`); `WQAA_GEMV_CHUNK=0` pins the (2 x 2) members that pad the row with
+    a second chunk: same int32 bits, both equal to the oracle."""
+    case = make_case(M, N, K, W_dtype=wd, A_dtype="int8", out_dtype="int32", seed=N + K + M)
+    got, mm = hip_output(case)
+    assert "r4d1" in mm.plans[M]["name"], mm.plans[M]["name"]
+    monkeypatch.setenv("WQAA_GEMV_CHUNK", "0")
+    got2, mm2 = hip_output(case)
+    assert "d2" in mm2.plans[M]["name"] and "r4d1" not in mm2.plans[M]["name"], mm2.plans[M]["name"]
+    assert np.array_equal(got, got2)
+    assert np.array_equal(got, oracle_output(case))
+
+
 def test_non_contiguous_activations_are_read_correctly():
     """A strided view (every other row of a taller matrix, and a 3-d batch) must not be read as raw memory."""
     import bitblas_amd as bitblas
