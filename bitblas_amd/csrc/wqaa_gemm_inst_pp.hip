@@ -1,5 +1,5 @@
 // member table: the ping-pong members (wqaa_gemm_pp_kernel.h), 256 x 256 and 128 x 256 tiles - 4-bit weights x fp16,
-// 2-bit weights x int8; dense fp8 (256 x 256 only)
+// 2-bit weights x int8; dense fp8
 #include "wqaa_gemm_pp_kernel.h"
 namespace wqaa {
 
@@ -50,12 +50,17 @@ static gemm_fn pick_pp_bm(int kind, int layout, int at, int mode, int* lds_bytes
 gemm_fn pick_gemm_pp(int kind, int layout, int at, int mode, int flags, int bm, int* lds_bytes) {
   gemm_fn fn = nullptr;
   if (bm != 256 && bm != 128) return nullptr;
-  if (at == AT_F8 && bm != 256) return nullptr;
   if (at == AT_F8 && mode == MD_NONE && (kind == DK_E4M3 || kind == DK_E5M2) && (flags & ~FL_ABF8) == 0) {   // dense fp8 x fp8, all four pairings
     const bool wb = kind == DK_E5M2, ab = (flags & FL_ABF8) != 0;
-    fn = !wb ? (!ab ? wq_gemm_pp8_kernel<PP8Policy<0, 0>> : wq_gemm_pp8_kernel<PP8Policy<0, 1>>)
-             : (!ab ? wq_gemm_pp8_kernel<PP8Policy<1, 0>> : wq_gemm_pp8_kernel<PP8Policy<1, 1>>);
-    *lds_bytes = PP8Policy<0, 0>::LDS_BYTES;
+    if (bm == 256) {
+      fn = !wb ? (!ab ? wq_gemm_pp8_kernel<PP8Policy<0, 0>> : wq_gemm_pp8_kernel<PP8Policy<0, 1>>)
+               : (!ab ? wq_gemm_pp8_kernel<PP8Policy<1, 0>> : wq_gemm_pp8_kernel<PP8Policy<1, 1>>);
+      *lds_bytes = PP8Policy<0, 0>::LDS_BYTES;
+    } else {
+      fn = !wb ? (!ab ? wq_gemm_pp8_kernel<PP8Policy<0, 0, 0, 128>> : wq_gemm_pp8_kernel<PP8Policy<0, 1, 0, 128>>)
+               : (!ab ? wq_gemm_pp8_kernel<PP8Policy<1, 0, 0, 128>> : wq_gemm_pp8_kernel<PP8Policy<1, 1, 0, 128>>);
+      *lds_bytes = PP8Policy<0, 0, 0, 128>::LDS_BYTES;
+    }
     return fn;
   }
   if (flags == (int)FL_BF16 && at == AT_F16 && kind == DK_LUT4 && layout == LAYOUT_PLAIN && (mode == MD_NONE || mode == MD_S)) {   // bfloat16 x nf4 / fp4

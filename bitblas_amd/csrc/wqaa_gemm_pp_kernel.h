@@ -762,21 +762,29 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_pp_kernel(const GemmArgs a
 // LDS-DMA in full lines, swizzled like the activations) and reads them into registers at the head of the tile.
 // Phase p of a tile: activation fragments 4p .. 4p+3 x both weight fragments = 8 MFMAs of 32 matrix-pipe cycles.
 // ------------------------------------------------------------------------------------------
-template <int WFMT_, int AFMT_, int OPT_ = 0>
+// BM_ = 128: the same loop on half the activation rows (two phases per k-tile) for shapes whose 256-row tiles leave the chip
+// short of whole rounds - the N / 8 column shards of BASELINE c5 first of all (4096 x 1024 x 8192 is 64 tiles of 256 x 256).
+// A k-tile then lasts half as long: activation ring of 4 (16 KiB slots), weight ring of 3 per wave, asked for three tiles ahead.
+template <int WFMT_, int AFMT_, int OPT_ = 0, int BM_ = 256>
 struct PP8Policy {
   static constexpr int WFMT = WFMT_, AFMT = AFMT_, OPT = OPT_;   // 0 e4m3, 1 e5m2
-  static constexpr int RING = 3, D = 2;
-  static constexpr int BM = 256, BN = 256, THREADS = 512, KT = 128, TILE_ROW = 128;
+  static constexpr int BM = BM_, BN = 256, THREADS = 512, KT = 128, TILE_ROW = 128;
+  static constexpr int RING = BM_ == 128 ? 4 : 3, D = RING - 1;
+  static constexpr int WS = BM_ == 128 ? 3 : 2;      // weight k-tile slots per wave (4 KiB each)
+  static constexpr int NPH = BM_ / 64;               // phases (8 MFMAs per wave each) per k-tile
   static constexpr int A_SLOT = BM * TILE_ROW;
   static constexpr int W_OFF = RING * A_SLOT;
-  static constexpr int LDS_BYTES = W_OFF + 8 * 2 * 4096;
+  static constexpr int LDS_BYTES = W_OFF + 8 * WS * 4096;
+  static_assert(BM_ == 256 || BM_ == 128, "256- or 128-row tile");
   static_assert(LDS_BYTES <= 160 * 1024 && LDS_BYTES >= BM * BN * 2, "LDS budget / output staging");
 };
 
 template <class P>
 __global__ void __launch_bounds__(P::THREADS) wq_gemm_pp8_kernel(const GemmArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  constexpr int D = P::D, RING = P::RING;
+  constexpr int D = P::D, RING = P::RING, NPH = P::NPH, WS = P::WS;
+  constexpr bool HALF = P::BM == 128;
+  constexpr int NMF = P::BM / 16, WROWS = P::BM / 8;
   typedef __attribute__((address_space(3))) void* lds_ptr_t;
   typedef int i32x8 __attribute__((ext_vector_type(8)));
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -801,22 +809,23 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_pp8_kernel(const GemmArgs 
   const auto w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.B), 0, (int)((long)a.N * a.K), 0x00020000);
   // piece j of either operand: 8 rows x one 128-byte line; rows beyond the matrix are out of the buffer's range (read as zero)
   const int g0_ = (lane & 7) ^ ((lane >> 4) & 7);
-  const uint32_t v0 = (uint32_t)(wave * 32 + (lane >> 3)) * (uint32_t)a.K + (uint32_t)(g0_ * 16);
+  const uint32_t v0 = (uint32_t)(wave * 32 + (lane >> 3)) * (uint32_t)a.K + (uint32_t)(g0_ * 16);         // the wave's weight rows
+  const uint32_t v0a = (uint32_t)(wave * WROWS + (lane >> 3)) * (uint32_t)a.K + (uint32_t)(g0_ * 16);     // ... and its share of the activation rows
   const int vd = ((g0_ ^ 4) - g0_) * 16;
   const uint32_t a_rows0 = (uint32_t)m0 * (uint32_t)a.K, w_rows0 = (uint32_t)n0 * (uint32_t)a.K;
 
   unsigned char* const a_ring = smem;
-  unsigned char* const w_ring = smem + P::W_OFF + wave * 8192;
+  unsigned char* const w_ring = smem + P::W_OFF + wave * (WS * 4096);
   auto dma_a = [&](int tt, int slot, int j) {
     const int tc = tt < ntiles ? tt : ntiles - 1;
-    unsigned char* dst = a_ring + slot * P::A_SLOT + (wave * 32 + j * 8) * P::TILE_ROW;
+    unsigned char* dst = a_ring + slot * P::A_SLOT + (wave * WROWS + j * 8) * P::TILE_ROW;
     const uint32_t rows = a_rows0 + (uint32_t)(j * 8) * (uint32_t)a.K;
-    const uint32_t voff = (j & 1) ? v0 + (uint32_t)vd + rows : v0 + rows;
+    const uint32_t voff = (j & 1) ? v0a + (uint32_t)vd + rows : v0a + rows;
     __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (lds_ptr_t)dst, 16, voff, tc * P::TILE_ROW, 0, 0);
   };
-  auto dma_w = [&](int tt, int j) {                  // piece j of the wave's 32 weight rows of k-tile tt -> slot tt & 1
+  auto dma_w = [&](int tt, int j, int ws) {          // piece j of the wave's 32 weight rows of k-tile tt -> weight slot ws
     const int tc = tt < ntiles ? tt : ntiles - 1;
-    unsigned char* dst = w_ring + (tt & 1) * 4096 + j * 1024;
+    unsigned char* dst = w_ring + ws * 4096 + j * 1024;
     const uint32_t rows = w_rows0 + (uint32_t)(j * 8) * (uint32_t)a.K;
     const uint32_t voff = (j & 1) ? v0 + (uint32_t)vd + rows : v0 + rows;
     __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_ptr_t)dst, 16, voff, tc * P::TILE_ROW, 0, 0);
@@ -827,32 +836,45 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_pp8_kernel(const GemmArgs 
   rd[0] = (uint32_t)(fr * P::TILE_ROW + ((kb ^ swl) * 16));
   rd[1] = (uint32_t)(fr * P::TILE_ROW + (((4 + kb) ^ swl) * 16));
 
-  f32x4 acc[16][2];
+  f32x4 acc[NMF][2];
 #pragma unroll
-  for (int f = 0; f < 16; ++f)
+  for (int f = 0; f < NMF; ++f)
 #pragma unroll
     for (int nf = 0; nf < 2; ++nf) acc[f][nf] = f32x4{0, 0, 0, 0};
   u32x4 afrag[4][2], wfrag[2][2];
 
   // ---- prologue ----
+  if constexpr (HALF) {
+    // three k-tiles in flight, each as [activation piece 0, piece 1, four weight pieces]: the order the loop keeps
 #pragma unroll
-  for (int j = 0; j < 4; ++j) dma_w(0, j);
+    for (int tt = 0; tt < 3; ++tt) {
+      dma_a(tt, tt, 0);
+      dma_a(tt, tt, 1);
 #pragma unroll
-  for (int j = 0; j < 4; ++j) dma_a(0, 0, j);
+      for (int j = 0; j < 4; ++j) dma_w(tt, j, tt);
+    }
+    pp_wait_vmcnt<12>();
+  } else {
 #pragma unroll
-  for (int j = 0; j < 3; ++j) dma_w(1, j);
+    for (int j = 0; j < 4; ++j) dma_w(0, j, 0);
 #pragma unroll
-  for (int j = 0; j < 4; ++j) dma_a(1, 1, j);
-  pp_wait_vmcnt<7>();
+    for (int j = 0; j < 4; ++j) dma_a(0, 0, j);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) dma_w(1, j, 1);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) dma_a(1, 1, j);
+    pp_wait_vmcnt<7>();
+  }
   PP_BARRIER();
   if (grp == 1) PP_BARRIER();
 
   int slot = 0;
+  int wslot = 0;                                     // weight slot of the k-tile in hand (128-row tile: t % 3; 256-row: t & 1)
   auto load_segment = [&](auto PH, int t) {
     constexpr int p = decltype(PH)::value;
     const unsigned char* sl = a_ring + slot * P::A_SLOT;
-    if constexpr (p == 0) {                          // this tile's weights (landed: the wait of the previous tile's segment 2)
-      const unsigned char* ws = w_ring + (t & 1) * 4096;
+    if constexpr (p == 0) {                          // this tile's weights (landed: the wait of the previous tile's last segment)
+      const unsigned char* ws = w_ring + wslot * 4096;
 #pragma unroll
       for (int nf = 0; nf < 2; ++nf)
 #pragma unroll
@@ -862,17 +884,31 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_pp8_kernel(const GemmArgs 
     for (int f = 0; f < 4; ++f)
 #pragma unroll
       for (int i = 0; i < 2; ++i) afrag[f][i] = *reinterpret_cast<const u32x4*>(sl + (p * 4 + f) * (16 * P::TILE_ROW) + rd[i]);
-    // weights: piece 3 of tile t + 1 rides with segment 0 (its slot is the one tile t - 1 has left), pieces 0..2 of tile t + 2
-    // with segments 1..3 (this tile's weights are in registers by then)
-    if constexpr (p == 0) dma_w(t + 1, 3);
-    else dma_w(t + 2, p - 1);
-    {
+    if constexpr (HALF) {
+      // the k-tile three ahead, as [activation piece 0] [activation piece 1, four weight pieces]: its weights take the slot of the
+      // tile in hand, whose fragments went to registers in segment 0
       const int dslot = slot + D >= RING ? slot + D - RING : slot + D;
       dma_a(t + D, dslot, p);
+      if constexpr (p == 1) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dma_w(t + 3, j, wslot);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      // tile t + 1 complete when only the two younger tiles (six operations each) are outstanding
+      if constexpr (p == 1) pp_wait_vmcnt<12>();
+    } else {
+      // weights: piece 3 of tile t + 1 rides with segment 0 (its slot is the one tile t - 1 has left), pieces 0..2 of tile t + 2
+      // with segments 1..3 (this tile's weights are in registers by then)
+      if constexpr (p == 0) dma_w(t + 1, 3, (t + 1) & 1);
+      else dma_w(t + 2, p - 1, t & 1);
+      {
+        const int dslot = slot + D >= RING ? slot + D - RING : slot + D;
+        dma_a(t + D, dslot, p);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      // tile t + 1 complete (activations and weights) when only what followed its last weight piece is outstanding
+      if constexpr (p == 2) pp_wait_vmcnt<5>();
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    // tile t + 1 complete (activations and weights) when only what followed its last weight piece is outstanding
-    if constexpr (p == 2) pp_wait_vmcnt<5>();
     PP_BARRIER();
   };
   auto compute_segment = [&](auto PH, int t) {
@@ -895,11 +931,14 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_pp8_kernel(const GemmArgs 
     compute_segment(ic<0>{}, t);
     load_segment(ic<1>{}, t);
     compute_segment(ic<1>{}, t);
-    load_segment(ic<2>{}, t);
-    compute_segment(ic<2>{}, t);
-    load_segment(ic<3>{}, t);
-    compute_segment(ic<3>{}, t);
+    if constexpr (NPH == 4) {
+      load_segment(ic<(NPH == 4 ? 2 : 0)>{}, t);
+      compute_segment(ic<(NPH == 4 ? 2 : 0)>{}, t);
+      load_segment(ic<(NPH == 4 ? 3 : 0)>{}, t);
+      compute_segment(ic<(NPH == 4 ? 3 : 0)>{}, t);
+    }
     slot = slot + 1 == RING ? 0 : slot + 1;
+    wslot = wslot + 1 == WS ? 0 : wslot + 1;
   }
   if (grp == 0) PP_BARRIER();
 
@@ -909,7 +948,7 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_pp8_kernel(const GemmArgs 
   const int el = pp_opaque(lane);
   const int e_fr = el & 15, e_kb = el >> 4, e_ln = el & 31, e_h = el >> 5;
 #pragma unroll
-  for (int f = 0; f < 16; ++f) {
+  for (int f = 0; f < NMF; ++f) {
     const int m = f * 16 + e_fr;
 #pragma unroll
     for (int nf = 0; nf < 2; ++nf) {
@@ -922,8 +961,8 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_pp8_kernel(const GemmArgs 
   PP_FENCE();
   __syncthreads();
 #pragma unroll
-  for (int rr = 0; rr < 16; ++rr) {
-    const int m = wave * 32 + rr * 2 + e_h;
+  for (int rr = 0; rr < WROWS / 2; ++rr) {
+    const int m = wave * WROWS + rr * 2 + e_h;
     u32x4 x = *reinterpret_cast<const u32x4*>(smem + m * 512 + ((e_ln ^ (m & 7)) * 16));
     if ((m >> 3) & 1) x = u32x4{x[2], x[3], x[0], x[1]};
     const int n = n0 + e_ln * 8;

@@ -133,9 +133,8 @@ def test_int2_int8_bias_bit_exact():
                                        ("e5m2_float8", "e5m2_float8")])
 @pytest.mark.parametrize("M,N,K", [(300, 520, 512), (256, 256, 128), (513, 264, 1152)])
 def test_dense_fp8_pairings_ragged(a_dt, w_dt, M, N, K, pin_the_tile):
-    """BASELINE c5's kernel at sizes where the oracle checks EVERY element: ragged M / N, one k-tile, all four fp8 pairings"""
-    if pin_the_tile != 256:
-        pytest.skip("the dense fp8 member has the 256-row tile only")
+    """BASELINE c5's kernel (both tiles) at sizes where the oracle checks EVERY element: ragged M / N, one k-tile, all four fp8
+    pairings"""
     import bitblas_amd as bitblas
     import wqaa_oracle as oracle
     tdt = {"e4m3_float8": torch.float8_e4m3fn, "e5m2_float8": torch.float8_e5m2}
@@ -145,7 +144,7 @@ def test_dense_fp8_pairings_ragged(a_dt, w_dt, M, N, K, pin_the_tile):
     W = (torch.rand((N, K), device="cuda", generator=gen) * 2 - 1).to(tdt[w_dt])
     mm = bitblas.Matmul(bitblas.MatmulConfig(M=M, N=N, K=K, A_dtype=a_dt, W_dtype=w_dt, accum_dtype="float32", out_dtype="float16"),
                         enable_tuning=False)
-    assert mm.plans[M]["name"].endswith("pp"), mm.plans[M]["name"]
+    assert mm.plans[M]["name"].endswith("pp") and f"_tcx{pin_the_tile}x256x" in mm.plans[M]["name"], mm.plans[M]["name"]
     out = mm(A, W)
     torch.cuda.synchronize()
     want = oracle.matmul_dense(A.view(torch.int8).cpu().numpy(), W.view(torch.int8).cpu().numpy(), a_dtype=a_dt, w_dtype=w_dt,
