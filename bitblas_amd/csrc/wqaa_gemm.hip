@@ -170,7 +170,7 @@ static int gemm_choose(const wqaa_matmul_desc& d, int m, GemmChoice* c, bool fus
   c->pp = 0;
   c->pp_shift = 0;
   c->pp_bm = 0;
-  if (m > 128 && d.N >= 256) {
+  if (m > 128 && d.N >= 128) {
     const char* pf = getenv("WQAA_GEMM_PP");
     const int kb = c->at == AT_F16 ? 256 : c->at == AT_F8 ? 128 : 512;   // k per trip of the main loop
     const int gb = c->at == AT_F8 ? 1 : g / (kb / 2);                   // k-bodies (two k-tiles) per group
@@ -197,35 +197,42 @@ static int gemm_choose(const wqaa_matmul_desc& d, int m, GemmChoice* c, bool fus
     // (the lockstep int8 / fp8 members are further behind their ping-pong counterparts than the fp16 one: tools/ab_pp_tile.py,
     // profiles/r03_ab_pp_tile_*.txt - int2 x int8 M = 1024 4096^2 39.6 vs 34.4 us on the 128-row tile, e4m3 1024 x 8192 x 8192 106 vs 84)
     const double tlock = (12.0 + 40.0 * 0.5 * (double)((2 * tiles_l + cus_ - 1) / cus_)) * (c->at == AT_I8 ? 1.35 : c->at == AT_F8 ? 1.3 : 1.0);
-    int lds256 = 0, lds128 = 0;
-    gemm_fn fn256 = shape_ok && m >= 256 ? pick_gemm_pp(c->kind, c->layout, c->at, c->mode, c->flags, 256, &lds256) : nullptr;
-    gemm_fn fn128 = shape_ok ? pick_gemm_pp(c->kind, c->layout, c->at, c->mode, c->flags, 128, &lds128) : nullptr;
-    int bm = 0;
-    if (const char* f = getenv("WQAA_GEMM_PP_BM")) {               // tuning aid: force a tile (0: the lockstep members)
-      bm = atoi(f);
-      if ((bm == 256 && !fn256) || (bm == 128 && !fn128)) bm = 0;
+    int lds256 = 0, lds128 = 0, ldss = 0;
+    gemm_fn fn256 = shape_ok && m >= 256 && d.N >= 256 ? pick_gemm_pp(c->kind, c->layout, c->at, c->mode, c->flags, 256, 256, &lds256) : nullptr;
+    gemm_fn fn128 = shape_ok && d.N >= 256 ? pick_gemm_pp(c->kind, c->layout, c->at, c->mode, c->flags, 128, 256, &lds128) : nullptr;
+    // dense fp8 also has a 128 x 128 tile, for outputs that give the CUs no wider one each (4096 x 1024: the c5 column shards)
+    gemm_fn fns = shape_ok ? pick_gemm_pp(c->kind, c->layout, c->at, c->mode, c->flags, 128, 128, &ldss) : nullptr;
+    // (a round of x 128 x 128 fp8 tiles: 30 + 0.035 x in the units of the estimates above; profiles/r03_ab_pp_tile_f8_128.txt)
+    const double ts = rounds_time(tiles_l, 30.0, 0.035);
+    int bm = 0, bn = 256;
+    if (const char* f = getenv("WQAA_GEMM_PP_BM")) {               // tuning aid: force a tile (0: the lockstep members; 128 with
+      bm = atoi(f);                                                // WQAA_GEMM_PP_BN=128: the 128 x 128 tile)
+      const char* fb = getenv("WQAA_GEMM_PP_BN");
+      if (bm == 128 && fb && atoi(fb) == 128 && fns) bn = 128;
+      else if ((bm == 256 && !fn256) || (bm == 128 && !fn128)) bm = 0;
     } else if (getenv("WQAA_GEMM_MF") != nullptr) {
       bm = (c->mf == 16 && fn256) ? 256 : 0;                       // a forced tile height keeps its round-2 meaning
     } else {
       double best = 0.97 * tlock;
       if (fn256 && t256 < best) { bm = 256; best = t256; }
       if (fn128 && t128 < best) { bm = 128; best = t128; }
+      if (fns && ts < best) { bm = 128; bn = 128; best = ts; }
     }
     if (bm) {
       c->pp = 1;
       c->pp_bm = bm;
       c->pp_shift = c->mode == MD_NONE ? 0 : one_group ? 20 : ilog2_exact(gb);     // (one group: every k-body maps to group 0)
-      c->fn = bm == 256 ? fn256 : fn128;
+      c->fn = bn == 128 ? fns : bm == 256 ? fn256 : fn128;
       c->mf = bm / 16;
       c->nwaves = 8;
-      c->bn = 256;
+      c->bn = bn;
       c->skinny = 0;
       c->decode = 0;
       c->wide = 0;
       c->ks = c->at == AT_F16 ? 64 : 128;
       c->tiles_m = (m + bm - 1) / bm;
-      c->tiles_n = (d.N + 255) / 256;
-      c->lds = bm == 256 ? lds256 : lds128;
+      c->tiles_n = (d.N + bn - 1) / bn;
+      c->lds = bn == 128 ? ldss : bm == 256 ? lds256 : lds128;
       c->ksplit = 1;
       return WQAA_OK;
     }
@@ -627,11 +634,12 @@ void gemm_init() {
       for (int at : {AT_F16, AT_I8, AT_F8})
         for (int mode = 0; mode <= MD_ZQ; ++mode)
           for (int flags : {0, (int)FL_ABF8, (int)FL_BF16}) {
-          for (int bm : {256, 128}) {
-            int lds = 0;
-            gemm_fn fn = pick_gemm_pp(kind, layout, at, mode, flags, bm, &lds);
-            if (fn) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-          }
+          for (int bm : {256, 128})
+            for (int bn : {256, 128}) {
+              int lds = 0;
+              gemm_fn fn = pick_gemm_pp(kind, layout, at, mode, flags, bm, bn, &lds);
+              if (fn) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            }
         }
   (void)hipGetLastError();   // a refused attribute must not linger as this thread's "last error"
 }

@@ -47,9 +47,16 @@ static gemm_fn pick_pp_bm(int kind, int layout, int at, int mode, int* lds_bytes
 }
 
 // nullptr: no ping-pong member for this combination (the caller falls back to wq_gemm_kernel)
-gemm_fn pick_gemm_pp(int kind, int layout, int at, int mode, int flags, int bm, int* lds_bytes) {
+gemm_fn pick_gemm_pp(int kind, int layout, int at, int mode, int flags, int bm, int bn, int* lds_bytes) {
   gemm_fn fn = nullptr;
-  if (bm != 256 && bm != 128) return nullptr;
+  if (bn == 128) {                                      // the 128 x 128 tile: dense fp8 only
+    if (!(bm == 128 && at == AT_F8 && mode == MD_NONE && (kind == DK_E4M3 || kind == DK_E5M2) && (flags & ~FL_ABF8) == 0)) return nullptr;
+    const bool wb = kind == DK_E5M2, ab = (flags & FL_ABF8) != 0;
+    *lds_bytes = PP8SPolicy<0, 0>::LDS_BYTES;
+    return !wb ? (!ab ? wq_gemm_pp8s_kernel<PP8SPolicy<0, 0>> : wq_gemm_pp8s_kernel<PP8SPolicy<0, 1>>)
+               : (!ab ? wq_gemm_pp8s_kernel<PP8SPolicy<1, 0>> : wq_gemm_pp8s_kernel<PP8SPolicy<1, 1>>);
+  }
+  if (bn != 256 || (bm != 256 && bm != 128)) return nullptr;
   if (at == AT_F8 && mode == MD_NONE && (kind == DK_E4M3 || kind == DK_E5M2) && (flags & ~FL_ABF8) == 0) {   // dense fp8 x fp8, all four pairings
     const bool wb = kind == DK_E5M2, ab = (flags & FL_ABF8) != 0;
     if (bm == 256) {

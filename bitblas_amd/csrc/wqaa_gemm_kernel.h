@@ -1535,7 +1535,7 @@ gemm_fn pick_gemm_f16_int21(int kind, int layout, int mode, int mf);
 gemm_fn pick_gemm_f16_other(int kind, int mode, int flags, int mf);
 gemm_fn pick_gemm_bf16(int kind, int mode, int mf);
 gemm_fn pick_gemm_i8_f8(int kind, int layout, int at, int flags, int mf);
-gemm_fn pick_gemm_pp(int kind, int layout, int at, int mode, int flags, int bm, int* lds_bytes);   // wqaa_gemm_pp_kernel.h members
+gemm_fn pick_gemm_pp(int kind, int layout, int at, int mode, int flags, int bm, int bn, int* lds_bytes);   // wqaa_gemm_pp_kernel.h members
 
 // mf codes: 1, 2, 4, 8 (16*mf x 128, 4 waves), 16 (256 x 256, 8 waves), 101/102/104 (skinny members),
 // 201 (decode-batch member: one launch, K split across the waves of a workgroup), 211 (the same with the activations through LDS-DMA)

@@ -971,4 +971,167 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_pp8_kernel(const GemmArgs 
 #endif
 }
 
+// ------------------------------------------------------------------------------------------
+// dense fp8, 128 x 128 tile: the member for outputs too small to give every CU a wider tile - the N / 8 column shards of
+// BASELINE c5 (4096 x 1024: 128 tiles of 128 x 256, 256 of these).  Wave grid 4 (n) x 2 (m): a wave owns 32 weight rows and
+// 64 activation rows (4 fragments x 2 = 8 MFMAs per k-tile: ONE phase), the two m-halves are the two role groups of the
+// ping-pong (waves w and w + 4 share a SIMD) and each keeps its own copy of the 32 weight rows (the second fetch is an L2 hit).
+// Everything else is wq_gemm_pp8_kernel's 128-row form: activation ring of 4, weight ring of 3 per wave, the k-tile three
+// ahead issued as [two activation pieces, four weight pieces], one counted vmcnt(12) per k-tile.
+// ------------------------------------------------------------------------------------------
+template <int WFMT_, int AFMT_>
+struct PP8SPolicy {
+  static constexpr int WFMT = WFMT_, AFMT = AFMT_;
+  static constexpr int BM = 128, BN = 128, THREADS = 512, KT = 128, TILE_ROW = 128;
+  static constexpr int RING = 4, D = 3, WS = 3;
+  static constexpr int A_SLOT = BM * TILE_ROW;
+  static constexpr int W_OFF = RING * A_SLOT;
+  static constexpr int LDS_BYTES = W_OFF + 8 * WS * 4096;
+  static_assert(LDS_BYTES <= 160 * 1024 && LDS_BYTES >= BM * BN * 2, "LDS budget / output staging");
+};
+
+template <class P>
+__global__ void __launch_bounds__(P::THREADS) wq_gemm_pp8s_kernel(const GemmArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int D = P::D, RING = P::RING, WS = P::WS;
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+  typedef int i32x8 __attribute__((ext_vector_type(8)));
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ng = wave & 3, mg = wave >> 2;           // mg is also the role group
+  const int fr = lane & 15, kb = lane >> 4;
+
+  int blk = blockIdx.x;
+  const int nblk = gridDim.x;
+  if ((nblk & 7) == 0) blk = (blockIdx.x & 7) * (nblk >> 3) + (blockIdx.x >> 3);
+  const int per_group = a.group_m * a.tiles_n;
+  const int first_m = (blk / per_group) * a.group_m;
+  const int gsz = a.tiles_m - first_m < a.group_m ? a.tiles_m - first_m : a.group_m;
+  const int tile_m = first_m + (blk % per_group) % gsz, tile_n = (blk % per_group) / gsz;
+  const int m0 = tile_m * P::BM, n0 = tile_n * P::BN;
+  const int ntiles = a.K / P::KT;
+
+  const auto a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.A), 0, (int)((long)a.M * a.K), 0x00020000);
+  const auto w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.B), 0, (int)((long)a.N * a.K), 0x00020000);
+  const int g0_ = (lane & 7) ^ ((lane >> 4) & 7);
+  const uint32_t v0w = (uint32_t)(ng * 32 + (lane >> 3)) * (uint32_t)a.K + (uint32_t)(g0_ * 16);       // the wave's 32 weight rows
+  const uint32_t v0a = (uint32_t)(wave * 16 + (lane >> 3)) * (uint32_t)a.K + (uint32_t)(g0_ * 16);     // its two pieces of the activation tile
+  const int vd = ((g0_ ^ 4) - g0_) * 16;
+  const uint32_t a_rows0 = (uint32_t)m0 * (uint32_t)a.K, w_rows0 = (uint32_t)n0 * (uint32_t)a.K;
+
+  unsigned char* const a_ring = smem;
+  unsigned char* const w_ring = smem + P::W_OFF + wave * (WS * 4096);
+  auto dma_a = [&](int tt, int slot, int j) {
+    const int tc = tt < ntiles ? tt : ntiles - 1;
+    unsigned char* dst = a_ring + slot * P::A_SLOT + (wave * 16 + j * 8) * P::TILE_ROW;
+    const uint32_t rows = a_rows0 + (uint32_t)(j * 8) * (uint32_t)a.K;
+    const uint32_t voff = (j & 1) ? v0a + (uint32_t)vd + rows : v0a + rows;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (lds_ptr_t)dst, 16, voff, tc * P::TILE_ROW, 0, 0);
+  };
+  auto dma_w = [&](int tt, int j, int ws) {
+    const int tc = tt < ntiles ? tt : ntiles - 1;
+    unsigned char* dst = w_ring + ws * 4096 + j * 1024;
+    const uint32_t rows = w_rows0 + (uint32_t)(j * 8) * (uint32_t)a.K;
+    const uint32_t voff = (j & 1) ? v0w + (uint32_t)vd + rows : v0w + rows;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_ptr_t)dst, 16, voff, tc * P::TILE_ROW, 0, 0);
+  };
+
+  const int swl = (fr >> 1) & 7;
+  uint32_t rd[2];
+  rd[0] = (uint32_t)(fr * P::TILE_ROW + ((kb ^ swl) * 16));
+  rd[1] = (uint32_t)(fr * P::TILE_ROW + (((4 + kb) ^ swl) * 16));
+
+  f32x4 acc[4][2];
+#pragma unroll
+  for (int f = 0; f < 4; ++f)
+#pragma unroll
+    for (int nf = 0; nf < 2; ++nf) acc[f][nf] = f32x4{0, 0, 0, 0};
+  u32x4 afrag[4][2], wfrag[2][2];
+
+#pragma unroll
+  for (int tt = 0; tt < 3; ++tt) {
+    dma_a(tt, tt, 0);
+    dma_a(tt, tt, 1);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) dma_w(tt, j, tt);
+  }
+  pp_wait_vmcnt<12>();
+  PP_BARRIER();
+  if (mg == 1) PP_BARRIER();
+
+  int slot = 0, wslot = 0;
+  for (int t = 0; t < ntiles; ++t) {
+    // ---- load segment ----
+    {
+      const unsigned char* sl = a_ring + slot * P::A_SLOT + mg * (64 * P::TILE_ROW);
+      const unsigned char* ws = w_ring + wslot * 4096;
+#pragma unroll
+      for (int nf = 0; nf < 2; ++nf)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) wfrag[nf][i] = *reinterpret_cast<const u32x4*>(ws + nf * 2048 + rd[i]);
+#pragma unroll
+      for (int f = 0; f < 4; ++f)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) afrag[f][i] = *reinterpret_cast<const u32x4*>(sl + f * (16 * P::TILE_ROW) + rd[i]);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the weight slot is refilled below: its fragments are in registers
+      const int dslot = slot + D >= RING ? slot + D - RING : slot + D;
+      dma_a(t + D, dslot, 0);
+      dma_a(t + D, dslot, 1);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) dma_w(t + 3, j, wslot);
+      pp_wait_vmcnt<12>();                           // tile t + 1 complete: only the two younger tiles (six operations each) outstanding
+      PP_BARRIER();
+    }
+    // ---- compute segment ----
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      const i32x8 av = {(int)afrag[f][0][0], (int)afrag[f][0][1], (int)afrag[f][0][2], (int)afrag[f][0][3],
+                        (int)afrag[f][1][0], (int)afrag[f][1][1], (int)afrag[f][1][2], (int)afrag[f][1][3]};
+#pragma unroll
+      for (int nf = 0; nf < 2; ++nf) {
+        const i32x8 wv = {(int)wfrag[nf][0][0], (int)wfrag[nf][0][1], (int)wfrag[nf][0][2], (int)wfrag[nf][0][3],
+                          (int)wfrag[nf][1][0], (int)wfrag[nf][1][1], (int)wfrag[nf][1][2], (int)wfrag[nf][1][3]};
+        acc[f][nf] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wv, av, acc[f][nf], P::WFMT, P::AFMT, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+      }
+    }
+    PP_BARRIER();
+    slot = slot + 1 == RING ? 0 : slot + 1;
+    wslot = wslot + 1 == WS ? 0 : wslot + 1;
+  }
+  if (mg == 0) PP_BARRIER();
+
+  // ---- epilogue: the 128 x 128 tile through LDS (256-byte rows: 16 pairs of 8-byte units), four rows per store instruction ----
+  pp_wait_vmcnt<0>();
+  PP_BARRIER();
+  const int el = pp_opaque(lane);
+  const int e_fr = el & 15, e_kb = el >> 4;
+#pragma unroll
+  for (int f = 0; f < 4; ++f) {
+    const int m = (mg * 4 + f) * 16 + e_fr;
+#pragma unroll
+    for (int nf = 0; nf < 2; ++nf) {
+      const half2_t lo = {(half_t)acc[f][nf][0], (half_t)acc[f][nf][1]}, hi = {(half_t)acc[f][nf][2], (half_t)acc[f][nf][3]};
+      const int u = ng * 8 + nf * 4 + e_kb;           // 8-byte unit of the row (4 consecutive n)
+      const int up = (((u >> 1) ^ (m & 7)) << 1) | ((u & 1) ^ ((m >> 3) & 1));
+      *reinterpret_cast<u32x2*>(smem + m * 256 + up * 8) = u32x2{as_u32(lo), as_u32(hi)};
+    }
+  }
+  PP_FENCE();
+  __syncthreads();
+  const int e_c = el & 15, e_r = el >> 4;            // 16-byte pair of the row, row of the four
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr) {
+    const int m = wave * 16 + rr * 4 + e_r;
+    u32x4 x = *reinterpret_cast<const u32x4*>(smem + m * 256 + ((e_c ^ (m & 7)) * 16));
+    if ((m >> 3) & 1) x = u32x4{x[2], x[3], x[0], x[1]};
+    const int n = n0 + e_c * 8;
+    if (m0 + m < a.M && n < a.N) pp_store_out(reinterpret_cast<u32x4*>(reinterpret_cast<half_t*>(a.C) + (long)(m0 + m) * a.N + n), x, a.ws_policy);
+  }
+#endif
+}
+
+
 }  // namespace wqaa

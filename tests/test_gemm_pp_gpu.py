@@ -152,6 +152,33 @@ def test_dense_fp8_pairings_ragged(a_dt, w_dt, M, N, K, pin_the_tile):
     assert_fp_parity(out.float().cpu().numpy(), want.astype(np.float16).astype(np.float32), rtol=1e-3, atol_frac=1e-4)
 
 
+@pytest.mark.parametrize("a_dt,w_dt", [("e4m3_float8", "e4m3_float8"), ("e5m2_float8", "e4m3_float8"), ("e4m3_float8", "e5m2_float8"),
+                                       ("e5m2_float8", "e5m2_float8")])
+@pytest.mark.parametrize("M,N,K", [(300, 520, 512), (129, 128, 128), (513, 264, 1152), (1000, 136, 2048)])
+def test_dense_fp8_128x128_tile(a_dt, w_dt, M, N, K, monkeypatch, pin_the_tile):
+    """the dense fp8 member for outputs too small to give every CU a wider tile (the N / 8 column shards of BASELINE c5): wave grid
+    4 x 2, one phase per k-tile - every element against the oracle, ragged M / N, all four pairings"""
+    if pin_the_tile != 128:
+        pytest.skip("one tile: runs once")
+    import bitblas_amd as bitblas
+    import wqaa_oracle as oracle
+    monkeypatch.setenv("WQAA_GEMM_PP_BM", "128")
+    monkeypatch.setenv("WQAA_GEMM_PP_BN", "128")
+    tdt = {"e4m3_float8": torch.float8_e4m3fn, "e5m2_float8": torch.float8_e5m2}
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(M + K)
+    A = (torch.rand((M, K), device="cuda", generator=gen) * 2 - 1).to(tdt[a_dt])
+    W = (torch.rand((N, K), device="cuda", generator=gen) * 2 - 1).to(tdt[w_dt])
+    mm = bitblas.Matmul(bitblas.MatmulConfig(M=M, N=N, K=K, A_dtype=a_dt, W_dtype=w_dt, accum_dtype="float32", out_dtype="float16"),
+                        enable_tuning=False)
+    assert mm.plans[M]["name"].endswith("_tcx128x128x128pp"), mm.plans[M]["name"]
+    out = mm(A, W)
+    torch.cuda.synchronize()
+    want = oracle.matmul_dense(A.view(torch.int8).cpu().numpy(), W.view(torch.int8).cpu().numpy(), a_dtype=a_dt, w_dtype=w_dt,
+                               out_dtype="float32")
+    assert_fp_parity(out.float().cpu().numpy(), want.astype(np.float16).astype(np.float32), rtol=1e-3, atol_frac=1e-4)
+
+
 def test_what_the_member_does_not_cover_falls_back(monkeypatch):
     """bfloat16 activations with 2-bit weights, bfloat16 output of float16 activations... - formats without a ping-pong member; an odd
     number (> 1) of groups per row, quantized zeros with N off the 32-row grid, K off the 256 grid: the lockstep member."""

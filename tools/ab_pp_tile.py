@@ -36,14 +36,19 @@ def main():
     gen.manual_seed(1)
     for (M, N, K) in shapes:
         row = []
-        for force in (None, "256", "128", "0"):
+        for force in (None, "256", "128", "0") + (("128x128",) if kind == "f8" else ()):
+            os.environ.pop("WQAA_GEMM_PP_BN", None)
             if force is None:
                 os.environ.pop("WQAA_GEMM_PP_BM", None)
+            elif force == "128x128":
+                os.environ["WQAA_GEMM_PP_BM"] = "128"
+                os.environ["WQAA_GEMM_PP_BN"] = "128"
             else:
                 os.environ["WQAA_GEMM_PP_BM"] = force
             name, us = time_one(dev, gen, kind, M, N, K)
             row.append((force or "selector", name, us))
         os.environ.pop("WQAA_GEMM_PP_BM", None)
+        os.environ.pop("WQAA_GEMM_PP_BN", None)
         best = min(x[2] for x in row[1:] if x[2] == x[2])
         print(f"{kind} M={M} N={N} K={K}: " + " | ".join(f"{f}: {n.split('_')[-1]} {u:7.1f}" for f, n, u in row) +
               f" | selector/best = {row[0][2] / best:.3f}")
