@@ -244,6 +244,66 @@ def time_step_int2_int8(device, gen, n_layers=4, grouped=True):
             "roofline": {"bound": "hbm", "achieved": nbytes / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": nbytes / t / 1e9 / HBM_PEAK_GBS}}
 
 
+def time_step_chained(device, gen, n_layers=4):
+    """The headline step with the data dependencies of a decoder layer honoured and the caller's elementwise ops between the
+    projections INCLUDED (the reference's layer: integration/BitNet/modeling_bitnet.py:839-860, MLP :240-244): per layer
+    {q,k,v}(x) -> o_proj(v) + x -> silu(gate(h)) * up(h) -> down_proj(act) + h -> next layer's x (the v projection stands in for
+    the attention output: attention and the norms are the caller's kernels either way).  `fused`: the residual adds ride in
+    the GEMVs' stores (`Matmul.forward_ex`) and gate / up / activation are one launch (`matmul_gate_up`) - 4 launches per layer,
+    nothing between them; `composed`: the same projections with torch's own elementwise kernels around them (8 launches per
+    layer).  One hipGraph replay each, same weights."""
+    layers = [[make_linear(N, K, device, gen) for (_, N, K) in LLAMA2_7B_LINEARS] for _ in range(n_layers)]
+    for layer in layers:
+        for (_, _, sc, _) in layer:
+            # random int4 codes have mean -0.5, so every synthetic linear has a common-mode gain of -0.5 * mean(scale) * K: scaled down
+            # until that is < 1 and the chained hidden state stays finite over the layers (timing does not depend on the values)
+            sc.mul_(0.04)
+    x0 = (torch.rand((1, 4096), device=device, generator=gen) - 0.5).to(torch.float16)
+    hid = [torch.empty((1, 4096), dtype=torch.float16, device=device) for _ in range(2 * n_layers)]
+    act = torch.empty((1, 11008), dtype=torch.float16, device=device)
+
+    def run(fused):
+        x = x0
+        for li, layer in enumerate(layers):
+            h, x_next = hid[2 * li], hid[2 * li + 1]
+            q, k, v, o, gate, up, down = layer
+            bitblas.matmul_group([q[0], k[0], v[0]], x, [(t[1], t[2]) for t in (q, k, v)], outputs=[t[3] for t in (q, k, v)])
+            if fused:
+                o[0].forward_ex(v[3], o[1], scale=o[2], residual=x, output=h)
+                bitblas.matmul_gate_up(gate[0], up[0], h, (gate[1], gate[2]), (up[1], up[2]), output=act)
+                down[0].forward_ex(act, down[1], scale=down[2], residual=h, output=x_next)
+            else:
+                o[0].forward(v[3], o[1], scale=o[2], output=h)
+                h += x
+                bitblas.matmul_group([gate[0], up[0]], h, [(t[1], t[2]) for t in (gate, up)], outputs=[gate[3], up[3]])
+                torch.mul(torch.nn.functional.silu(gate[3]), up[3], out=act)
+                down[0].forward(act, down[1], scale=down[2], output=x_next)
+                x_next += h
+            x = x_next
+        return x
+
+    # algorithmic bytes of the fused step: the gate / up outputs never reach memory, the activation and two residuals do
+    nbytes = n_layers * (sum(algorithmic_bytes(1, N, K) for (_, N, K) in LLAMA2_7B_LINEARS) - 11008 * 2 + 2 * 4096 * 2)
+    res = {}
+    outs = {}
+    for name, fused in (("fused", True), ("composed", False)):
+        t = graph_time(device, lambda: run(fused), 1)
+        outs[name] = run(fused).float().clone()
+        launches = n_layers * (4 if fused else 8)
+        res[name] = {"us_per_step": t * 1e6, "launches_per_step": launches, "GBps": nbytes / t / 1e9, "frac": nbytes / t / 1e9 / HBM_PEAK_GBS}
+    torch.cuda.synchronize(device)
+    ref = outs["composed"]
+    err = ((outs["fused"] - ref).abs().max() / ref.abs().max().clamp_min(1e-6)).item()
+    from bitblas_amd import gate_up_plan
+    return {"workload": f"W_int4 A_fp16 M=1 decode, Llama-2-7B linears, {n_layers} layers CHAINED through their data (o_proj reads v, "
+                        "gate/up read o_proj + residual, down_proj reads silu(gate) * up, the next layer reads down_proj + residual), "
+                        "the layer's elementwise ops included; weights as in the headline step",
+            "gate_up_launch": (gate_up_plan(layers[0][4][0], 1) or {}).get("name"),
+            "bytes_per_step": nbytes, **res, "fused_vs_composed_max_rel_err": err,
+            "bit_identical": bool(torch.equal(outs["fused"], ref)),
+            "roofline": {"bound": "hbm", "achieved": res["fused"]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": res["fused"]["frac"]}}
+
+
 def time_member_f16_gemv(device, gen, N, K, int4_us=None):
     """The reference's published figure for this path is a SPEED-UP over the vendor library's float16 GEMV (README.md:43-48,
     images/figures/op_benchmark_a100_wq_gemv_e7.png: W_INT4 A_FP16 M = 1 about 3.9-4.3x cuBLAS on A100).  Same
@@ -769,6 +829,7 @@ def main():
             member("gemm_uint4_m16", time_member_gemm, device, gen, 16)
             member("gemm_int2_int8_m4096", time_member_gemm, device, gen, 4096, W_dtype="int2", A_dtype="int8")
             member("gemv_int2_int8_m1", time_member_dense, device, gen, 1, 4096, 4096, kind="int2", n_buf=64)
+            member("step_chained", time_step_chained, device, gen)
             member("step_int2_int8", time_step_int2_int8, device, gen)
             member("step_int2_int8_ungrouped", time_step_int2_int8, device, gen, grouped=False)
             # c5: dense e4m3 x e4m3 on every Llama-3-70B linear of one (unsharded) GPU, M = 4096 and M = 1

@@ -168,6 +168,8 @@ static int dispatch(const wqaa_matmul_desc& d, int m, bool* use_gemm) {
   return WQAA_OK;
 }
 
+constexpr int32_t kEpilogueV1Bytes = 24;   // wqaa_epilogue up to `reserved2`: callers built before the float16 pre/post ops
+
 static int matmul_impl(const wqaa_matmul_desc* desc, const void* A, const void* B, const void* LUT,
                        const void* Scale, const void* Zeros, const void* Bias, void* C, int m,
                        void* stream, void* ev0, void* ev1, const wqaa_epilogue* epi = nullptr,
@@ -248,7 +250,16 @@ static int matmul_impl(const wqaa_matmul_desc* desc, const void* A, const void* 
     }
   }
   const bool quant_in = epi && (epi->flags & WQAA_EPI_QUANTIZE_INPUT);
-  if (epi && (epi->struct_size != (int32_t)sizeof(wqaa_epilogue) || (!epi->row_scale && !quant_in))) {
+  const bool float_ops = epi && (epi->flags & WQAA_EPI_ADD_RESIDUAL);
+  if (float_ops) {
+    // the float16 path's residual add: the whole descriptor, no int8 flags, the pointer present
+    if (epi->struct_size != (int32_t)sizeof(wqaa_epilogue) || quant_in || !epi->residual) {
+      set_error(WQAA_ERR_BAD_DESC, "matmul_ex: malformed epilogue descriptor (residual add)");
+      return WQAA_ERR_BAD_DESC;
+    }
+    use_gemm = false;   // an exact-product GEMV member; refuses loudly if the config has none
+  } else if (epi && ((epi->struct_size != (int32_t)sizeof(wqaa_epilogue) && epi->struct_size != kEpilogueV1Bytes) ||
+                     (!epi->row_scale && !quant_in))) {
     set_error(WQAA_ERR_BAD_DESC, "matmul_ex: malformed epilogue descriptor");
     return WQAA_ERR_BAD_DESC;
   }
@@ -389,7 +400,8 @@ static int group_impl(const wqaa_group_item* items, const wqaa_epilogue* const* 
   if (epis) {
     for (int i = 0; i < count; ++i) {
       const wqaa_epilogue* e = epis[i];
-      if (!e || e->struct_size != (int32_t)sizeof(wqaa_epilogue) || (!e->row_scale && !(e->flags & WQAA_EPI_QUANTIZE_INPUT))) {
+      if (!e || (e->struct_size != (int32_t)sizeof(wqaa_epilogue) && e->struct_size != kEpilogueV1Bytes) ||
+          (e->flags & WQAA_EPI_ADD_RESIDUAL) || (!e->row_scale && !(e->flags & WQAA_EPI_QUANTIZE_INPUT))) {
         set_error(WQAA_ERR_BAD_DESC, "matmul_group_ex: member %d has a missing or malformed epilogue descriptor", i);
         return WQAA_ERR_BAD_DESC;
       }
@@ -463,6 +475,38 @@ static int group_impl(const wqaa_group_item* items, const wqaa_epilogue* const* 
 
 int wqaa_matmul_group(const wqaa_group_item* items, int count, int m, void* stream) {
   return group_impl(items, nullptr, count, m, stream);
+}
+
+int wqaa_matmul_gate_up(const wqaa_group_item* gate, const wqaa_group_item* up, void* act, int m, void* stream) {
+  if (!gate || !up || !gate->desc || !up->desc || !valid_desc(gate->desc) || !valid_desc(up->desc)) {
+    set_error(WQAA_ERR_BAD_DESC, "matmul_gate_up: missing item or descriptor");
+    return WQAA_ERR_BAD_DESC;
+  }
+  if (m == 0) return WQAA_OK;
+  const wqaa_matmul_desc& d = *gate->desc;
+  if (memcmp(gate->desc, up->desc, sizeof(wqaa_matmul_desc)) != 0 || gate->A != up->A) {
+    set_error(WQAA_ERR_BAD_DESC, "matmul_gate_up: gate and up must share one input and agree in their descriptors");
+    return WQAA_ERR_BAD_DESC;
+  }
+  if (m < 0 || !gate->A || !gate->B || !up->B || !act || (d.with_scaling && (!gate->Scale || !up->Scale)) ||
+      (d.zeros_mode != WQAA_Z_NONE && (!gate->Zeros || !up->Zeros)) || (d.with_bias && (!gate->Bias || !up->Bias))) {
+    set_error(WQAA_ERR_BAD_DESC, "matmul_gate_up: bad call (m=%d, a NULL operand the descriptor asks for)", m);
+    return WQAA_ERR_BAD_DESC;
+  }
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  StreamDeviceScope scope(s, gate->A);
+  if (!device_info().ok) {
+    set_error(WQAA_ERR_NO_DEVICE, "no HIP device visible");
+    return WQAA_ERR_NO_DEVICE;
+  }
+  int st = gemvx_pair_launch(d, gate, up, act, m, s);
+  if (st == WQAA_OK) g_last_error = WQAA_OK;
+  return st;
+}
+
+int wqaa_gate_up_plan(const wqaa_matmul_desc* desc, int m, wqaa_plan* plan) {
+  if (!valid_desc(desc)) return WQAA_ERR_BAD_DESC;
+  return gemvx_pair_plan(*desc, m, plan);
 }
 
 int wqaa_matmul_group_ex(const wqaa_group_item* items, const wqaa_epilogue* const* epilogues, int count, int m, void* stream) {

@@ -84,6 +84,7 @@ void gemv_init();
 
 // exact-product GEMV members (strict_reference = 0, sub-byte integer weights x float16, M <= 2)
 bool gemvx_eligible(const wqaa_matmul_desc& d, int m);
+bool gemvx_covers(const wqaa_matmul_desc& d, int m);
 // groups: `merged` = the members' descriptor with N = the sum of their rows (what selects the tile configuration)
 bool gemvx_group_eligible(const wqaa_matmul_desc& merged, const wqaa_matmul_desc* const* descs, int count, int m);
 int gemvx_group_plan(const wqaa_matmul_desc& merged, const int* Ns, int count, int m, wqaa_plan* plan);
@@ -94,7 +95,10 @@ int gemv_group_launch(const wqaa_matmul_desc& merged, const wqaa_group_item* ite
                       const wqaa_epilogue* const* epis = nullptr);
 int gemvx_plan(const wqaa_matmul_desc& d, int m, wqaa_plan* plan);
 int gemvx_launch(const wqaa_matmul_desc& d, const void* A, const void* B, const void* Scale, const void* Zeros,
-                 const void* Bias, void* C, int m, hipStream_t stream, hipEvent_t start, hipEvent_t stop);
+                 const void* Bias, void* C, int m, hipStream_t stream, hipEvent_t start, hipEvent_t stop, const wqaa_epilogue* epi = nullptr);
+int gemvx_pair_plan(const wqaa_matmul_desc& d, int m, wqaa_plan* plan);
+int gemvx_pair_launch(const wqaa_matmul_desc& d, const wqaa_group_item* gate, const wqaa_group_item* up, void* act, int m,
+                      hipStream_t stream);
 void gemvx_init();
 
 int gemm_plan(const wqaa_matmul_desc& d, int m, wqaa_plan* plan);

@@ -13,14 +13,20 @@ struct GemvxChoice {
 
 // sub-byte integer weights x float16 activations, M <= 2, and the caller did not ask for the TE definition's
 // per-element rounding (strict_reference).  WQAA_GEMVX=0 disables the family (A/B aid).
-bool gemvx_eligible(const wqaa_matmul_desc& d, int m) {
-  if (d.strict_reference || m < 1 || m > 2 || d.a_dtype != WQAA_F16) return false;
+// what the family can compute at all (the fused pre/post ops of wqaa_matmul_ex exist only here, so they ask this)
+bool gemvx_covers(const wqaa_matmul_desc& d, int m) {
+  if (m < 1 || m > 2 || d.a_dtype != WQAA_F16) return false;
   if (d.w_format != WQAA_W_UINT && d.w_format != WQAA_W_INT) return false;
   if (d.w_bits != 4 && d.w_bits != 2 && d.w_bits != 1) return false;
   const int E = 128 / d.w_bits;
   if (d.K % E != 0) return false;
   const int g = d.group_size <= 0 ? d.K : d.group_size;
   if (d.K % g != 0 || (d.with_scaling && g % E != 0)) return false;
+  return true;
+}
+
+bool gemvx_eligible(const wqaa_matmul_desc& d, int m) {
+  if (d.strict_reference || !gemvx_covers(d, m)) return false;
   // Long K with enough rows to fill the chip unsplit, two activation rows: every workgroup stages both activation rows
   // and their chunk sums before its first dot, which the rounding members (wider workgroups, no sums) do cheaper
   // (same-call A/B, int4 g128, exact vs rounding member, profiles/r02_ab_gemvx_longk.txt: M=2 4096x11008 11.2 vs 10.2 us).
@@ -71,7 +77,9 @@ static void gemvx_candidate(int N, int nsteps, int cus, int R, int* kw, double* 
   *score = waves * eff;
 }
 
-static int gemvx_choose(const wqaa_matmul_desc& d, int m, GemvxChoice* c) {
+// pro: 0 plain members, 1 residual add (WQAA_EPI_ADD_RESIDUAL), 2 gate / up pair (wqaa_matmul_gate_up: d.N = the rows the
+// launch streams, 2 x the projections' N; two rows per wave by construction)
+static int gemvx_choose(const wqaa_matmul_desc& d, int m, GemvxChoice* c, int pro = 0) {
   c->bits = d.w_bits;
   c->layout = d.w_layout == WQAA_LAYOUT_LOP3 ? LAYOUT_LOP3 : LAYOUT_PLAIN;
   c->mode = !d.with_scaling ? MD_NONE
@@ -92,6 +100,7 @@ static int gemvx_choose(const wqaa_matmul_desc& d, int m, GemvxChoice* c) {
   gemvx_candidate(d.N, c->nsteps, cus, 1, &k1, &sc1);
   c->R = sc2 >= 0.9 * sc1 ? 2 : 1;
   if (const char* f = getenv("WQAA_GEMVX_R")) c->R = atoi(f) == 1 ? 1 : 2;
+  if (pro == 2) c->R = 2;
   int kw = c->R == 2 ? k2 : k1;
   if (d.k_split_hint > 1) kw = d.k_split_hint;                                          // the caller's k_split
   if (const char* f = getenv("WQAA_GEMVX_KW")) kw = atoi(f) > 0 ? atoi(f) : 1;          // tuning aid
@@ -156,13 +165,20 @@ static int gemvx_choose(const wqaa_matmul_desc& d, int m, GemvxChoice* c) {
     c->areg = (d.N <= 2048 || d.N >= 24576) ? 1 : 0;
     if (const char* f = getenv("WQAA_GEMVX_AREG")) c->areg = atoi(f) != 0;
   }
+  if (pro) c->areg = 0;                                  // the fused post ops come with the LDS-staged members
   if (c->areg) c->lds = 64;
   const int rd = c->R * 10 + c->D + (c->areg ? 1 : 0);
+  if (pro) {
+    const int prd = pro == 2 ? 1000 + rd : rd;
+    c->fn = c->bits == 4 ? pick_gemvx_pro4(c->layout, c->mode, c->mb, prd)
+            : c->bits == 2 ? pick_gemvx_pro2(c->layout, c->mode, c->mb, prd)
+                           : pick_gemvx_pro1(c->layout, c->mode, c->mb, prd);
+  } else
   c->fn = c->bits == 4 ? pick_gemvx_int4(c->layout, c->mode, c->mb, rd)
           : c->bits == 2 ? pick_gemvx_int2(c->layout, c->mode, c->mb, rd)
                          : pick_gemvx_int1(c->layout, c->mode, c->mb, rd);
   if (const char* f = getenv("WQAA_GEMVX_ABL")) {      // ablation members (tools only): wrong results by construction
-    if (atoi(f) > 0 && c->bits == 4 && c->layout == LAYOUT_LOP3 && c->mode == MD_S && c->mb == 1 && c->R == 2 && pick_gemvx_lab(atoi(f)))
+    if (!pro && atoi(f) > 0 && c->bits == 4 && c->layout == LAYOUT_LOP3 && c->mode == MD_S && c->mb == 1 && c->R == 2 && pick_gemvx_lab(atoi(f)))
       c->fn = pick_gemvx_lab(atoi(f));
   }
   if (!c->fn) {
@@ -221,6 +237,7 @@ static void gemvx_fill(const wqaa_matmul_desc& d, const GemvxChoice& c, const vo
   a.n_rgb = ((d.N + c.R - 1) / c.R + slots - 1) / slots;
   a.slots = slots;
   a.kw_magic = (65536u + (uint32_t)c.kw - 1u) / (uint32_t)c.kw;
+  a.residual = nullptr;
 }
 
 static int gemvx_dispatch(const GemvxChoice& c, GemvxGroupArgs& ga, int grid_x, int count, hipStream_t stream, hipEvent_t start,
@@ -238,21 +255,87 @@ static int gemvx_dispatch(const GemvxChoice& c, GemvxGroupArgs& ga, int grid_x, 
 }
 
 int gemvx_launch(const wqaa_matmul_desc& d, const void* A, const void* B, const void* Scale, const void* Zeros,
-                 const void* Bias, void* C, int m, hipStream_t stream, hipEvent_t start, hipEvent_t stop) {
+                 const void* Bias, void* C, int m, hipStream_t stream, hipEvent_t start, hipEvent_t stop, const wqaa_epilogue* epi) {
+  const int pro = epi != nullptr ? 1 : 0;                // WQAA_EPI_ADD_RESIDUAL (checked by the caller)
   GemvxChoice c;
   {
     static thread_local ChoiceMemo<GemvxChoice> memo;
-    if (const GemvxChoice* hit = memo.find(d, m, 7)) {
+    const int q = pro ? 8 : 7;
+    if (const GemvxChoice* hit = memo.find(d, m, q)) {
       c = *hit;
     } else {
-      int st = gemvx_choose(d, m, &c);
+      int st = gemvx_choose(d, m, &c, pro);
       if (st != WQAA_OK) return st;
-      memo.put(d, m, 7, c);
+      memo.put(d, m, q, c);
     }
   }
   GemvxGroupArgs ga;
   gemvx_fill(d, c, A, B, Scale, Zeros, Bias, C, m, &ga.p[0]);
+  if (pro) ga.p[0].residual = epi->residual;
   return gemvx_dispatch(c, ga, c.grid, 1, stream, start, stop);
+}
+
+// ---- gate_proj + up_proj + the gated activation in one launch (wqaa_matmul_gate_up) ---------------------------------------
+// Tile configuration: what the selector gives the two projections concatenated (2 N rows, two rows per wave); a wave's
+// two rows are row n of each.  args.N stays the projections' N: a row group IS an output element.
+static int gemvx_pair_choose(const wqaa_matmul_desc& d, int m, GemvxChoice* c) {
+  if (!gemvx_covers(d, m) || d.out_dtype != WQAA_F16) {
+    set_error(WQAA_ERR_UNSUPPORTED, "matmul_gate_up: needs float16 activations, 1/2/4-bit integer weights, float16 output and m <= 2 (got m=%d)", m);
+    return WQAA_ERR_UNSUPPORTED;
+  }
+  wqaa_matmul_desc merged = d;
+  merged.N = 2 * d.N;
+  static thread_local ChoiceMemo<GemvxChoice> memo;
+  if (const GemvxChoice* hit = memo.find(merged, m, 9)) {
+    *c = *hit;
+    return WQAA_OK;
+  }
+  int st = gemvx_choose(merged, m, c, 2);
+  if (st == WQAA_OK) memo.put(merged, m, 9, *c);
+  return st;
+}
+
+int gemvx_pair_plan(const wqaa_matmul_desc& d, int m, wqaa_plan* plan) {
+  GemvxChoice c;
+  int st = gemvx_pair_choose(d, m, &c);
+  if (st != WQAA_OK || !plan) return st;
+  wqaa_matmul_desc merged = d;
+  merged.N = 2 * d.N;
+  memset(plan, 0, sizeof(*plan));
+  plan->kernel_family = 1;
+  plan->block_m = c.mb;
+  plan->block_n = c.nw / c.kw;             // output elements a workgroup works on at a time
+  plan->block_k = 64 * c.E * c.D;
+  plan->threads = c.nw * 64;
+  plan->grid = c.grid;
+  plan->rows_per_wave = c.R;
+  plan->batch_tile = c.mb;
+  plan->pipeline_depth = c.D;
+  plan->split_k = c.kw;
+  plan->lds_bytes = c.lds;
+  char wd[24];
+  short_wdtype(d, wd, sizeof(wd));
+  snprintf(plan->name, sizeof(plan->name), "matmul_m%dn%dk%d_%sx%s_gemvx_b%dr%dd%dk%d_pair", m, d.N, d.K, short_dtype(d.a_dtype), wd, c.mb,
+           c.R, c.D, c.kw);
+  return WQAA_OK;
+}
+
+int gemvx_pair_launch(const wqaa_matmul_desc& d, const wqaa_group_item* gate, const wqaa_group_item* up, void* act, int m,
+                      hipStream_t stream) {
+  GemvxChoice c;
+  int st = gemvx_pair_choose(d, m, &c);
+  if (st != WQAA_OK) return st;
+  GemvxGroupArgs ga;
+  // filled as the 2 N-row operator (row-group blocks, K split), then N put back: rows of a pair are indexed by output element
+  wqaa_matmul_desc merged = d;
+  merged.N = 2 * d.N;
+  gemvx_fill(merged, c, gate->A, gate->B, gate->Scale, gate->Zeros, gate->Bias, act, m, &ga.p[0]);
+  gemvx_fill(merged, c, up->A, up->B, up->Scale, up->Zeros, up->Bias, act, m, &ga.p[1]);
+  for (int i = 0; i < 2; ++i) {
+    ga.p[i].N = d.N;
+    ga.p[i].zq_row_bytes = d.N * c.bits / 8;
+  }
+  return gemvx_dispatch(c, ga, c.grid, 1, stream, nullptr, nullptr);
 }
 
 // ---- a group of independent operators in one launch (wqaa_matmul_group) -------------------------------------------------
@@ -339,6 +422,11 @@ void gemvx_init() {
             gemvx_fn fn = bits == 4 ? pick_gemvx_int4(layout, mode, mb, rd) : bits == 2 ? pick_gemvx_int2(layout, mode, mb, rd)
                                                                                        : pick_gemvx_int1(layout, mode, mb, rd);
             if (fn) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            for (int prd : {rd, 1000 + rd}) {
+              fn = bits == 4 ? pick_gemvx_pro4(layout, mode, mb, prd) : bits == 2 ? pick_gemvx_pro2(layout, mode, mb, prd)
+                                                                                : pick_gemvx_pro1(layout, mode, mb, prd);
+              if (fn) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            }
           }
   (void)hipGetLastError();
 }

@@ -58,6 +58,7 @@ struct GemvxArgs {
   int n_rgb;          // row-group blocks: ceil(ceil(N / R) / (waves / kw))
   int slots;          // waves / kw: row groups a workgroup works on at a time
   uint32_t kw_magic;  // ceil(2^16 / kw): x / kw == (x * kw_magic) >> 16 for x < 4096 (no integer division in the prologue)
+  const void* residual;  // PRO members (WQAA_EPI_ADD_RESIDUAL): (m, N) float16 added to the float16 result; NULL: none
 };
 
 // One launch serves up to kGemvxGroupMax INDEPENDENT operators of one tile configuration (wqaa_matmul_group: the q/k/v
@@ -77,10 +78,20 @@ struct GemvxGroupArgs {
 // step): the LOP3 interleave puts consecutive elements 2j, 2j + 1 into the two halves of field j, so the natural-order
 // activation dword j IS the partner of masked field j - no LDS tile, no staging pass, no barrier; the chunk's
 // activation sum is taken from the same registers.
-template <int BITS_, int LAYOUT_, int MODE_, int MB_, int R_, int D_, int ABL_ = 0, bool AREG_ = false>
+// PRO_: the caller's elementwise ops behind the GEMV folded in - members of their own, so that the plain members' code
+// (and registers) stay what they are.
+//   1  residual add (wqaa.h WQAA_EPI_ADD_RESIDUAL): the storing lane fetches the residual of its rows while the weights of
+//      the row group stream and adds it to the rounded result
+//   2  gate / up pair (wqaa_matmul_gate_up): the wave's two rows are row n of TWO operators (grp.p[0] = gate_proj,
+//      grp.p[1] = up_proj: same shape and format, own pointers); it stores half(silu(gate_out)) * up_out - the gated
+//      activation, evaluated once per output element by the lane that holds both sums
+template <int BITS_, int LAYOUT_, int MODE_, int MB_, int R_, int D_, int ABL_ = 0, bool AREG_ = false, int PRO_ = 0>
 struct GemvxPolicy {
   static constexpr int BITS = BITS_, LAYOUT = LAYOUT_, MODE = MODE_, MB = MB_, R = R_, D = D_, ABL = ABL_;
   static constexpr bool AREG = AREG_;
+  static constexpr bool PRO = PRO_ == 1, PAIR = PRO_ == 2;
+  static_assert(!(AREG_ && PRO_ != 0), "the fused post ops come with the LDS-staged members");
+  static_assert(PRO_ != 2 || R_ == 2, "a gate / up pair is the two rows of a wave");
   static_assert(!AREG_ || (BITS_ == 4 && LAYOUT_ == LAYOUT_LOP3 && MB_ == 1), "register-resident activations: 4-bit LOP3 weights, M = 1");
   // activation items per thread in flight ahead of the weight stream: 8 waves x 3 cover K = 12288 at 4 bit (rounds past
   // the tile are skipped wave-uniformly; 4096x11008 8.5 -> 7.76 us against one item).  The two-row members serve the
@@ -95,6 +106,13 @@ struct GemvxPolicy {
   static constexpr int PIECES = E / 8;         // 16-byte activation pieces per lane chunk
   static constexpr int PPW = EPW / 8;          // activation pieces per weight word
 };
+
+// torch's `F.silu(gate) * up` on float16 values: silu in fp32 (x / (1 + exp(-x))), rounded to float16, times up (a float16
+// product is the correctly rounded exact product, which is what the fp32 multiply + cast of torch gives)
+__device__ __forceinline__ half_t silu_mul_h(half_t g, half_t u) {
+  const float gf = (float)g;
+  return (half_t)(gf / (1.f + expf(-gf))) * u;
+}
 
 // wave64 sum, result valid in lane 63 (classic GCN row_bcast ladder: 6 DPP adds)
 __device__ __forceinline__ float wave_sum_l63(float v) {
@@ -142,6 +160,7 @@ __global__ void __launch_bounds__(1024) wq_gemvx_kernel(const GemvxGroupArgs grp
   // it (the host passes slots and a reciprocal of kw).
   asm volatile("" ::"s"(a.A), "s"(a.B), "s"(a.scale), "s"(a.zeros), "s"(a.N), "s"(a.K), "s"(a.kg), "s"(a.gq_shift), "s"(a.cpr),
                "s"(a.nsteps), "s"(a.kw), "s"(a.row_bytes), "s"(a.n_rgb), "s"(a.slots), "s"(a.kw_magic), "s"(a.m));
+  if constexpr (P::PAIR) asm volatile("" ::"s"(grp.p[1].B), "s"(grp.p[1].scale), "s"(grp.p[1].zeros));
   const int kw = a.kw;
   const int slots = a.slots;                     // row groups the workgroup works on at a time
   const int rgl = (int)(((uint32_t)wave * a.kw_magic) >> 16), kpart = wave - rgl * kw;
@@ -153,11 +172,24 @@ __global__ void __launch_bounds__(1024) wq_gemvx_kernel(const GemvxGroupArgs grp
   float* sa_lds = reinterpret_cast<float*>(a_lds + (long)MB * ncp * PIECES * 64);
   float* red_lds = sa_lds + (long)MB * ncp * 64 * 4;                               // [2][slot][kpart][R * MB]
 
-  const uint8_t* Bp = reinterpret_cast<const uint8_t*>(a.B);
-  const uint16_t* Sp = reinterpret_cast<const uint16_t*>(a.scale);
-  const uint16_t* Zp = reinterpret_cast<const uint16_t*>(a.zeros);
-  const uint8_t* Qp = reinterpret_cast<const uint8_t*>(a.zeros);
-  const int n_rg = (a.N + R - 1) / R;
+  // operand pointers of row r of a row group: one operator's - or, PAIR, row r = 0 of grp.p[0] (gate) and r = 1 of grp.p[1] (up)
+  const uint8_t* Bp[R];
+  const uint16_t* Sp[R];
+  const uint16_t* Zp[R];
+  const uint8_t* Qp[R];
+  const void* biasp[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const GemvxArgs& o = (P::PAIR && r == 1) ? grp.p[1] : a;
+    Bp[r] = reinterpret_cast<const uint8_t*>(o.B);
+    Sp[r] = reinterpret_cast<const uint16_t*>(o.scale);
+    Zp[r] = reinterpret_cast<const uint16_t*>(o.zeros);
+    Qp[r] = reinterpret_cast<const uint8_t*>(o.zeros);
+    biasp[r] = o.bias;
+  }
+  constexpr int RS = P::PAIR ? 1 : R;             // output rows a row group stands for
+  const int n_rg = (a.N + RS - 1) / RS;
+  auto row_of = [&](int rg, int r) { return P::PAIR ? rg : rg * R + r; };
 
   // this workgroup's row-group blocks rb.first, rb.first + rb.stride, ... < rb.end (XCD-aware, wqaa_kinds.h; many small
   // workgroups and the hardware dispatcher balance better than one persistent workgroup per CU: measured)
@@ -182,12 +214,12 @@ __global__ void __launch_bounds__(1024) wq_gemvx_kernel(const GemvxGroupArgs grp
     if (MODE != MD_NONE) gi = a.gq_shift >= 0 ? (chunk >> a.gq_shift) : (int)__umulhi((uint32_t)chunk, a.gq_magic);
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      int n = rg * R + r;
+      int n = row_of(rg, r);
       n = n < a.N ? n : a.N - 1;
-      st.w[r] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(Bp + (long)n * a.row_bytes + (long)chunk * 16));
-      if constexpr (MODE != MD_NONE) st.s[r] = Sp[(long)n * a.kg + gi];
-      if constexpr (MODE == MD_ZO || MODE == MD_ZR) st.z[r] = Zp[(long)n * a.kg + gi];
-      if constexpr (MODE == MD_ZQ) st.z[r] = Qp[(long)gi * a.zq_row_bytes + n / ZPB];
+      st.w[r] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(Bp[r] + (long)n * a.row_bytes + (long)chunk * 16));
+      if constexpr (MODE != MD_NONE) st.s[r] = Sp[r][(long)n * a.kg + gi];
+      if constexpr (MODE == MD_ZO || MODE == MD_ZR) st.z[r] = Zp[r][(long)n * a.kg + gi];
+      if constexpr (MODE == MD_ZQ) st.z[r] = Qp[r][(long)gi * a.zq_row_bytes + n / ZPB];
     }
   };
 
@@ -380,7 +412,7 @@ __global__ void __launch_bounds__(1024) wq_gemvx_kernel(const GemvxGroupArgs grp
         float z = zint;
         if constexpr (MODE == MD_ZO) z += (float)bits_to_half(s.z[r]);
         if constexpr (MODE == MD_ZQ) {
-          const int n = rg_now * R + r;
+          const int n = row_of(rg_now, r);
           z = (float)((s.z[r] >> ((n % ZPB) * BITS)) & ((1u << BITS) - 1u));    // integer-domain zero: ignores signedness
         }
         t = __builtin_fmaf(-z, sa, t);
@@ -391,6 +423,23 @@ __global__ void __launch_bounds__(1024) wq_gemvx_kernel(const GemvxGroupArgs grp
           if constexpr (MODE == MD_ZR) acc[r][mi] = __builtin_fmaf(-(float)bits_to_half(s.z[r]), sa, acc[r][mi]);
         }
       }
+    }
+  };
+
+  // PRO: the residual of this wave's rows, asked for when a row group starts (every lane the same address: one request),
+  // so that the add in `finish` does not wait on memory
+  float resv[R][MB];
+  auto load_residual = [&](int it) {
+    if constexpr (P::PRO) {
+      const int rg = rg_of(it);
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int mi = 0; mi < MB; ++mi) {
+          const int n = rg * R + r;
+          const bool ok = a.residual != nullptr && kpart == 0 && n < a.N && mi < a.m;   // the storing wave only (residual may alias C)
+          resv[r][mi] = ok ? (float)reinterpret_cast<const half_t*>(a.residual)[(long)mi * a.N + n] : 0.f;
+        }
     }
   };
 
@@ -437,6 +486,50 @@ __global__ void __launch_bounds__(1024) wq_gemvx_kernel(const GemvxGroupArgs grp
         } else {
           __hip_atomic_store(reinterpret_cast<uint16_t*>(cp), __builtin_bit_cast(uint16_t, h0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           __hip_atomic_store(reinterpret_cast<uint16_t*>(cp) + 1, __builtin_bit_cast(uint16_t, h1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+      return;
+    }
+    if constexpr (P::PAIR) {
+      // float16 (the host checks): both projections' results (+ their biases) rounded to float16 as their own launches would
+      // store them, then torch's `F.silu(gate) * up` on the two values
+      if (kpart == 0 && lane == 63 && rg_done < n_rg) {
+#pragma unroll
+        for (int mi = 0; mi < MB; ++mi) {
+          if (mi >= a.m) continue;
+          half_t h[2];
+#pragma unroll
+          for (int r = 0; r < 2; ++r) {
+            h[r] = (half_t)tot[r][mi];
+            if (a.has_bias) h[r] = h[r] + reinterpret_cast<const half_t*>(biasp[r])[rg_done];
+          }
+          reinterpret_cast<half_t*>(a.C)[(long)mi * a.N + rg_done] = silu_mul_h(h[0], h[1]);
+        }
+      }
+      return;
+    }
+    if constexpr (P::PRO) {
+      // float16 output (the host checks): result (+ bias) rounded to float16, then + residual in fp32, rounded again
+      if (kpart == 0 && lane == 63 && rg_done < n_rg) {
+#pragma unroll
+        for (int mi = 0; mi < MB; ++mi) {
+          if (mi >= a.m) continue;
+          half_t h[R];
+#pragma unroll
+          for (int r = 0; r < R; ++r) {
+            const int n = rg_done * R + r;
+            h[r] = (half_t)tot[r][mi];
+            if (a.has_bias && n < a.N) h[r] = h[r] + reinterpret_cast<const half_t*>(a.bias)[n];
+            if (a.residual) h[r] = (half_t)((float)h[r] + resv[r][mi]);
+          }
+          const long idx = (long)mi * a.N + (long)rg_done * R;
+          if (R == 2 && rg_done * R + 1 < a.N && !(idx & 1)) {
+            *reinterpret_cast<uint32_t*>(reinterpret_cast<half_t*>(a.C) + idx) = as_u32(half2_t{h[0], h[R - 1]});
+          } else {
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+              if (rg_done * R + r < a.N) reinterpret_cast<half_t*>(a.C)[idx + r] = h[r];
+          }
         }
       }
       return;
@@ -504,6 +597,9 @@ __global__ void __launch_bounds__(1024) wq_gemvx_kernel(const GemvxGroupArgs grp
   int it = 0, si = 0;
   for (int q = 0; q < total; ++q) {
     const int rg_now = rg_of(it);
+    if constexpr (P::PRO) {
+      if (si == 0) load_residual(it);
+    }
     int c = (kpart + si * kw) * D;
     int it2 = it, si2 = si + 1;
     if (si2 == nmy) { si2 = 0; ++it2; }
@@ -551,6 +647,28 @@ typedef void (*gemvx_fn)(const GemvxGroupArgs);
 
 // member tables: wqaa_gemvx_inst_*.hip.  rd code = R * 10 + D
 template <int BITS, int LAYOUT, int MODE, int MB>
+static gemvx_fn pick_gemvx_pro_rd(int rd) {
+  switch (rd) {
+    case 12: return wq_gemvx_kernel<GemvxPolicy<BITS, LAYOUT, MODE, MB, 1, 2, 0, false, 1>>;
+    case 22: return wq_gemvx_kernel<GemvxPolicy<BITS, LAYOUT, MODE, MB, 2, 2, 0, false, 1>>;
+    case 1022: return wq_gemvx_kernel<GemvxPolicy<BITS, LAYOUT, MODE, MB, 2, 2, 0, false, 2>>;     // gate / up pair
+  }
+  return nullptr;
+}
+template <int BITS, int LAYOUT>
+static gemvx_fn pick_gemvx_pro_mode(int mode, int mb, int rd) {
+#define WQAA_GXP(MODE) (mb == 1 ? pick_gemvx_pro_rd<BITS, LAYOUT, MODE, 1>(rd) : mb == 2 ? pick_gemvx_pro_rd<BITS, LAYOUT, MODE, 2>(rd) : nullptr)
+  switch (mode) {
+    case MD_NONE: return WQAA_GXP(MD_NONE);
+    case MD_S: return WQAA_GXP(MD_S);
+    case MD_ZO: return WQAA_GXP(MD_ZO);
+    case MD_ZR: return WQAA_GXP(MD_ZR);
+    case MD_ZQ: return WQAA_GXP(MD_ZQ);
+  }
+#undef WQAA_GXP
+  return nullptr;
+}
+template <int BITS, int LAYOUT, int MODE, int MB>
 static gemvx_fn pick_gemvx_rd(int rd) {
   switch (rd) {
     case 12: return wq_gemvx_kernel<GemvxPolicy<BITS, LAYOUT, MODE, MB, 1, 2>>;
@@ -580,6 +698,10 @@ static gemvx_fn pick_gemvx_mode(int mode, int mb, int rd) {
 gemvx_fn pick_gemvx_int4(int layout, int mode, int mb, int rd);
 gemvx_fn pick_gemvx_int2(int layout, int mode, int mb, int rd);
 gemvx_fn pick_gemvx_int1(int layout, int mode, int mb, int rd);
+// members with the fused pre/post ops (wqaa_gemvx_inst_pro*.hip)
+gemvx_fn pick_gemvx_pro4(int layout, int mode, int mb, int rd);
+gemvx_fn pick_gemvx_pro2(int layout, int mode, int mb, int rd);
+gemvx_fn pick_gemvx_pro1(int layout, int mode, int mb, int rd);
 gemvx_fn pick_gemvx_lab(int abl);     // ablation members of the int4 / LOP3 / scale / M = 1 / R = 2 configuration (tools only)
 
 }  // namespace wqaa

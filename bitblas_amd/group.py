@@ -43,6 +43,10 @@ def _library():
         lib.wqaa_matmul_group_ex.restype = ctypes.c_int
         lib.wqaa_matmul_group_ex.argtypes = [ctypes.POINTER(GroupItem), ctypes.POINTER(ctypes.POINTER(_lib.Epilogue)), ctypes.c_int,
                                              ctypes.c_int, ctypes.c_void_p]
+        lib.wqaa_matmul_gate_up.restype = ctypes.c_int
+        lib.wqaa_matmul_gate_up.argtypes = [ctypes.POINTER(GroupItem), ctypes.POINTER(GroupItem), ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+        lib.wqaa_gate_up_plan.restype = ctypes.c_int
+        lib.wqaa_gate_up_plan.argtypes = [ctypes.POINTER(_lib.MatmulDesc), ctypes.c_int, ctypes.POINTER(_lib.Plan)]
         lib.wqaa_group_plan.restype = ctypes.c_int
         lib.wqaa_group_plan.argtypes = [ctypes.POINTER(ctypes.POINTER(_lib.MatmulDesc)), ctypes.c_int, ctypes.c_int,
                                         ctypes.POINTER(ctypes.c_int), ctypes.POINTER(_lib.Plan)]
@@ -158,6 +162,54 @@ def matmul_group(ops: Sequence[Matmul], A: Union[torch.Tensor, Sequence[torch.Te
     if status != _lib.OK:
         _lib.check(status)
     return outs
+
+
+def gate_up_plan(op: Matmul, m: int = 1):
+    """plan of the one-launch `matmul_gate_up` of two operators like `op` at `m` rows, or None where it does not exist
+    (then the group launch + torch's `silu`, `mul` run).  Needs no device."""
+    plan = _lib.Plan()
+    if _library().wqaa_gate_up_plan(ctypes.byref(op.lib.desc), int(m), ctypes.byref(plan)) != _lib.OK:
+        return None
+    return plan.as_dict()
+
+
+def matmul_gate_up(gate_op: Matmul, up_op: Matmul, A: torch.Tensor, gate_weights, up_weights,
+                   output: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """`F.silu(gate_op(A, *gate_weights)) * up_op(A, *up_weights)` - the gated activation of a Llama-style MLP (the reference's
+    callers: integration/BitNet/modeling_bitnet.py:240-244, :281-287) with both projections in ONE launch that stores only the
+    activation (wqaa_matmul_gate_up: float16 x 1 / 2 / 4-bit integer weights at m <= 2); elsewhere the group launch followed
+    by torch's two elementwise kernels.  weights: `W` or `(W, scale, zeros, bias)` per projection, as `matmul_group`."""
+    m = gate_op.check_activation(A)
+    if up_op.check_activation(A) != m or bytes(gate_op.lib.desc) != bytes(up_op.lib.desc):
+        raise ValueError("gate and up must be operators of one configuration (same N, K, formats, group size)")
+    if not gate_op.fused_ops_supported(m) or m == 0:
+        g, u = matmul_group([gate_op, up_op], A, [gate_weights, up_weights])
+        return torch.mul(torch.nn.functional.silu(g), u, out=output)
+    if output is None:
+        output = torch.empty(A.shape[:-1] + (gate_op.N,), dtype=gate_op.torch_output_dtype, device=A.device)
+    elif not output.is_contiguous() or output.device != A.device:
+        raise ValueError("output must be a contiguous tensor on A's device")
+    else:
+        gate_op.check_output(output, m)
+    if not A.is_contiguous():
+        A = A.contiguous()
+    items = (GroupItem * 2)()
+    for it, op, w in ((items[0], gate_op, gate_weights), (items[1], up_op, up_weights)):
+        w = (w,) if isinstance(w, torch.Tensor) else tuple(w)
+        W, scale, zeros, bias = (w + (None,) * 4)[:4]
+        if W.numel() * W.element_size() != op._w_bytes:
+            raise ValueError(f"W holds {W.numel() * W.element_size()} bytes, the operator expects {op._w_bytes} "
+                             f"(shape {op.retrieve_weight_shape()}: run transform_weight first)")
+        it.desc = ctypes.pointer(op.lib.desc)
+        it.A, it.B, it.C = A.data_ptr(), W.data_ptr(), None
+        it.Scale = scale.data_ptr() if scale is not None else None
+        it.Zeros = zeros.data_ptr() if zeros is not None else None
+        it.Bias = bias.data_ptr() if bias is not None else None
+    status = _library().wqaa_matmul_gate_up(ctypes.byref(items[0]), ctypes.byref(items[1]), output.data_ptr(), m,
+                                            _lib.current_stream_handle(A.device))
+    if status != _lib.OK:
+        _lib.check(status)
+    return output
 
 
 class LinearGroup(torch.nn.Module):

@@ -27,6 +27,7 @@ Z_NONE, Z_ORIGINAL, Z_RESCALE, Z_QUANTIZED = range(4)
 LAYOUT_PLAIN, LAYOUT_LOP3 = 0, 1
 OK, ERR_BAD_DESC, ERR_UNSUPPORTED, ERR_LAUNCH, ERR_NO_DEVICE = range(5)
 EPI_QUANTIZE_INPUT = 1
+EPI_ADD_RESIDUAL = 2
 
 DTYPE_CODE = {
     "float16": F16, "bfloat16": BF16, "float32": F32, "int8": I8, "int32": I32,
@@ -39,7 +40,7 @@ ZEROS_CODE = {"original": Z_ORIGINAL, "rescale": Z_RESCALE, "quantized": Z_QUANT
 
 EXPORTED_SYMBOLS = (
     "init", "wqaa_abi_version", "wqaa_device_count", "wqaa_matmul", "wqaa_matmul_timed",
-    "wqaa_matmul_ex", "wqaa_matmul_opts", "wqaa_workspace_bytes", "wqaa_matmul_group", "wqaa_matmul_group_ex", "wqaa_group_plan", "wqaa_dequantize", "wqaa_tune", "wqaa_act_quant_int8", "wqaa_select", "wqaa_pack_weight", "wqaa_unpack_weight", "wqaa_relayout_weight", "wqaa_debug_decode", "wqaa_debug_row_blocks",
+    "wqaa_matmul_ex", "wqaa_matmul_opts", "wqaa_workspace_bytes", "wqaa_matmul_group", "wqaa_matmul_group_ex", "wqaa_group_plan", "wqaa_matmul_gate_up", "wqaa_gate_up_plan", "wqaa_dequantize", "wqaa_tune", "wqaa_act_quant_int8", "wqaa_select", "wqaa_pack_weight", "wqaa_unpack_weight", "wqaa_relayout_weight", "wqaa_debug_decode", "wqaa_debug_row_blocks",
     "wqaa_last_error", "wqaa_last_error_string",
 )
 
@@ -77,7 +78,7 @@ class Epilogue(ctypes.Structure):
     """struct wqaa_epilogue (include/wqaa.h): fused `out / si / sw -> half` of BitNet-style callers."""
     _fields_ = [("struct_size", ctypes.c_int32), ("flags", ctypes.c_int32),
                 ("row_scale", ctypes.c_void_p), ("tensor_scale", ctypes.c_float),
-                ("reserved2", ctypes.c_int32)]
+                ("reserved2", ctypes.c_int32), ("residual", ctypes.c_void_p)]
 
 
 class CallOpts(ctypes.Structure):
@@ -385,6 +386,20 @@ class BoundLib:
         epi.tensor_scale = float(tensor_scale)
         status = self._lib.wqaa_matmul_ex(self._desc_ref, X, B, None, None, None, bias, C, m, stream,
                                           ctypes.byref(epi))
+        if status != OK:
+            check(status)
+
+    def run_residual(self, A, B, scale, zeros, bias, C, m, stream, residual):
+        """float16 decode path with the caller's residual add folded in (wqaa_matmul_ex, WQAA_EPI_ADD_RESIDUAL):
+        C = residual + matmul(...).  Raises WqaaError(UNSUPPORTED) where no exact-product GEMV member exists."""
+        if _PLAN_LOG:
+            _log_plan(self.desc, m, "+residual")
+        epi = Epilogue()
+        epi.struct_size = ctypes.sizeof(Epilogue)
+        epi.flags = EPI_ADD_RESIDUAL
+        epi.tensor_scale = 1.0
+        epi.residual = residual
+        status = self._lib.wqaa_matmul_ex(self._desc_ref, A, B, None, scale, zeros, bias, C, m, stream, ctypes.byref(epi))
         if status != OK:
             check(status)
 

@@ -670,6 +670,48 @@ class Matmul(Operator):
 
     __call__ = forward
 
+    def fused_ops_supported(self, m: int) -> bool:
+        """whether the caller's elementwise ops fold into this operator's launch at this row count (`forward_ex`,
+        `bitblas_amd.matmul_gate_up`): float16 activations x 1 / 2 / 4-bit integer weights, float16 output, m <= 2
+        (include/wqaa.h, WQAA_EPI_ADD_RESIDUAL / wqaa_matmul_gate_up)"""
+        cfg = self.config
+        elems = 128 // self.bit if self.bit in (1, 2, 4) else 0
+        group = cfg.K if (cfg.group_size or -1) <= 0 else cfg.group_size
+        return (1 <= m <= 2 and cfg.A_dtype == "float16" and cfg.out_dtype == "float16" and self.source_format in ("int", "uint")
+                and elems > 0 and cfg.K % elems == 0 and cfg.K % group == 0 and (not cfg.with_scaling or group % elems == 0))
+
+    def forward_ex(self, A, W, scale=None, zeros=None, bias=None, output=None, residual=None) -> Any:
+        """`residual + forward(A, W, ...)` - the residual add a decoder layer runs behind o_proj / down_proj (the reference's
+        callers: integration/BitNet/modeling_bitnet.py:839-860); `residual` may be `output` itself.  One launch where
+        `fused_ops_supported(m)`; elsewhere torch's add behind `forward`."""
+        if residual is None:
+            return self.forward(A, W, scale, zeros, bias, output)
+        m = self.check_activation(A)
+        if residual.dtype != self.torch_output_dtype or residual.numel() != m * self.N or residual.device != A.device:
+            raise ValueError(f"`residual` must hold {m} x {self.N} {self.torch_output_dtype} elements on A's device")
+        if not self.fused_ops_supported(m):
+            if output is not None and output.data_ptr() == residual.data_ptr():
+                residual = residual.clone()
+            out = self.forward(A, W, scale, zeros, bias, output)
+            out += residual.view_as(out)
+            return out
+        if output is None:
+            output = torch.empty(A.shape[:-1] + (self.N,), dtype=self.torch_output_dtype, device=A.device)
+        elif not output.is_contiguous():
+            raise ValueError("output must be a contiguous tensor")
+        else:
+            self.check_output(output, m)
+        if W.numel() * W.element_size() != self._w_bytes:
+            raise ValueError(f"W holds {W.numel() * W.element_size()} bytes, the operator expects {self._w_bytes} "
+                             f"(shape {self.retrieve_weight_shape()}: run transform_weight first)")
+        A = A if A.is_contiguous() else A.contiguous()
+        residual = residual if residual.is_contiguous() else residual.contiguous()
+        self.lib.run_residual(
+            A.data_ptr(), W.data_ptr(), scale.data_ptr() if scale is not None else None,
+            zeros.data_ptr() if zeros is not None else None, bias.data_ptr() if bias is not None else None,
+            output.data_ptr(), m, _lib.current_stream_handle(A.device), residual.data_ptr())
+        return output
+
     def _forward_from_prebuild_lib(self, *args, stream=0):
         """ops/operator.py:458-463"""
         self.lib.call(*args, stream)

@@ -166,12 +166,28 @@ int wqaa_matmul_timed(const wqaa_matmul_desc* desc, const void* A, const void* B
                                      * itself (per-token absmax -> int8) and uses its own si; row_scale is ignored
                                      * and may be NULL.  One launch for quantise + matmul + rescale; m <= 4 only
                                      * (WQAA_ERR_UNSUPPORTED otherwise: quantise with wqaa_act_quant_int8 first) */
+/* ---- callers' elementwise ops of the float16 decode path (Llama-style MLP / residual stream) ---------------------
+ * Between the projections of a decoder layer the reference's callers run elementwise kernels of a few KB each - the gated
+ * activation `act_fn(gate_proj(x)) * up_proj(x)` (integration/BitNet/modeling_bitnet.py: BitnetMLP.forward :240-244 and
+ * its fused gate/up twin :281-287) and the residual adds behind o_proj / down_proj (BitnetDecoderLayer.forward :839-860).
+ * On MI355X every such launch is a ~1.3 us dependent boundary plus a tiny kernel next to a 4-8 us GEMV.  Both fold into the
+ * GEMV that PRODUCES the vector, where each output element is in one lane's hands:
+ *   WQAA_EPI_ADD_RESIDUAL  (wqaa_matmul_ex)  C[m, n] = half(float(out[m, n]) + float(residual[m, n])), out = the float16
+ *                          result (bias included): torch's `residual + linear(x)`.  residual may alias C (each element
+ *                          is read before it is written, by the same wave)
+ *   wqaa_matmul_gate_up    (below)           act[m, n] = half(silu(gate_out[m, n])) * up_out[m, n]: gate_proj and up_proj
+ *                          in ONE launch whose waves hold row n of both
+ * For float16 activations x 1 / 2 / 4-bit integer weights, float16 output, m <= 2 (the exact-product GEMV members,
+ * whatever desc.strict_reference says); WQAA_ERR_UNSUPPORTED otherwise - the caller then runs its own elementwise ops.
+ * row_scale / tensor_scale are not used by WQAA_EPI_ADD_RESIDUAL. */
+#define WQAA_EPI_ADD_RESIDUAL 2
 typedef struct wqaa_epilogue {
-  int32_t struct_size;      /* = sizeof(wqaa_epilogue) */
-  int32_t flags;            /* 0 or WQAA_EPI_QUANTIZE_INPUT */
+  int32_t struct_size;      /* = sizeof(wqaa_epilogue); the 24-byte prefix (up to reserved2) of earlier callers is accepted */
+  int32_t flags;            /* 0 or an OR of WQAA_EPI_* */
   const float* row_scale;   /* (m,) si of activation_quant, device pointer */
   float tensor_scale;       /* sw = 1 / mean|W| */
   int32_t reserved2;
+  const void* residual;     /* WQAA_EPI_ADD_RESIDUAL: (m, N) float16 */
 } wqaa_epilogue;
 
 int wqaa_matmul_ex(const wqaa_matmul_desc* desc, const void* A, const void* B, const void* LUT,
@@ -229,6 +245,16 @@ int wqaa_matmul_group(const wqaa_group_item* items, int count, int m, void* stre
  * back).  Members with different epilogue kinds run one by one. */
 int wqaa_matmul_group_ex(const wqaa_group_item* items, const wqaa_epilogue* const* epilogues, int count, int m, void* stream);
 int wqaa_group_plan(const wqaa_matmul_desc* const* descs, int count, int m, int* launches, wqaa_plan* plan);
+
+/* gate_proj and up_proj of a gated MLP with the activation between them and down_proj folded in (see "callers' elementwise
+ * ops" above): act[m, n] = half(silu(g)) * u with g, u = the float16 values wqaa_matmul would have stored for `gate` and
+ * `up` (silu in fp32: g / (1 + exp(-g)), rounded to float16; then the float16 product - the roundings of torch's
+ * `F.silu(gate) * up`).  One launch: every wave streams row n of BOTH weights against the shared input and the lane holding
+ * the two sums stores one value - neither projection's output goes to memory.  gate->C / up->C are ignored (may be NULL);
+ * gate->A == up->A; the two descriptors must agree in everything (N, K, format, group size, flags).
+ * wqaa_gate_up_plan: the plan of that launch (name suffix "_pair") or WQAA_ERR_UNSUPPORTED, without a device. */
+int wqaa_matmul_gate_up(const wqaa_group_item* gate, const wqaa_group_item* up, void* act, int m, void* stream);
+int wqaa_gate_up_plan(const wqaa_matmul_desc* desc, int m, wqaa_plan* plan);
 
 /* measured tuning of the vendor-library GEMM behind (desc, m) - the plain dense pairs, or the second pass of the two-pass
  * member: the heuristic's top candidates are timed on the device (temporary buffers, synchronises `stream`) and the

@@ -570,6 +570,20 @@ def bitnet_forward(x: np.ndarray, weight_q: np.ndarray, sw, bias=None) -> np.nda
 # --------------------------------------------------------------------------------------
 # tolerance helper with the reference's semantics (bitblas/testing/__init__.py:29-91)
 # --------------------------------------------------------------------------------------
+def silu_mul_f16(gate: np.ndarray, up: np.ndarray) -> np.ndarray:
+    """The gated activation the reference's callers run in front of down_proj (integration/BitNet/modeling_bitnet.py:240-244,
+    :281-287: `act_fn(gate) * up`, act_fn = silu) as torch evaluates it on float16 tensors: silu in fp32
+    (x / (1 + exp(-x))) rounded to float16, then the float16 product (fp32 multiply, one rounding)."""
+    g = np.asarray(gate, dtype=np.float16).astype(np.float32)
+    act = f16(g / (np.float32(1.0) + np.exp(-g, dtype=np.float32)))
+    return f16(act.astype(np.float32) * np.asarray(up, dtype=np.float16).astype(np.float32))
+
+
+def add_residual_f16(out: np.ndarray, residual: np.ndarray) -> np.ndarray:
+    """`residual + linear(x)` on float16 tensors (modeling_bitnet.py:839-860): fp32 add of the two float16 values, one rounding"""
+    return f16(np.asarray(out, dtype=np.float16).astype(np.float32) + np.asarray(residual, dtype=np.float16).astype(np.float32))
+
+
 def count_mismatch(a: np.ndarray, b: np.ndarray, rtol: float, atol: float) -> int:
     a = np.asarray(a, dtype=np.float64)
     b = np.asarray(b, dtype=np.float64)

@@ -141,3 +141,38 @@ def test_matmul_group_validates_before_it_launches(monkeypatch):
     with pytest.raises(ValueError, match="weights"):
         bitblas.matmul_group(ops, A, Ws[:1])
     assert len(seen) == 2                                                                     # none of the refused calls launched
+
+
+def test_gate_up_pair_plan_and_argument_checks():
+    """wqaa_matmul_gate_up / wqaa_gate_up_plan (include/wqaa.h) without a device: the pair launch takes the tile configuration of the
+    two projections concatenated, two rows per wave; what the exact-product family does not cover is refused"""
+    gate = op(11008)
+    plan = wgroup.gate_up_plan(gate, 1)
+    merged = op(22016).plans[1]
+    assert plan["name"] == gate.plans[1]["name"].replace("_gemvx_b1r2d2k1", "_gemvx_b1r2d2k1_pair") and plan["rows_per_wave"] == 2
+    assert plan["threads"] == merged["threads"] and plan["split_k"] == merged["split_k"] and plan["lds_bytes"] == merged["lds_bytes"]
+    assert wgroup.gate_up_plan(op(512, K=16384), 1)["split_k"] > 1            # few rows: K split across the waves, like the plain launch
+    assert wgroup.gate_up_plan(op(11008, M=[1, 16]), 2)["batch_tile"] == 2
+    assert wgroup.gate_up_plan(op(11008, M=[1, 16]), 16) is None              # MFMA row counts: the caller's own elementwise kernels
+    assert wgroup.gate_up_plan(op(4096, W_dtype="nf4"), 1) is None
+    L = wgroup._library()
+    items = (wgroup.GroupItem * 2)()
+    assert L.wqaa_matmul_gate_up(None, None, None, 1, None) == wlib.ERR_BAD_DESC
+    d = gate.lib.desc
+    for it in items:
+        it.desc = ctypes.pointer(d)
+    assert L.wqaa_matmul_gate_up(ctypes.byref(items[0]), ctypes.byref(items[1]), None, 0, None) == wlib.OK        # m == 0
+    assert L.wqaa_matmul_gate_up(ctypes.byref(items[0]), ctypes.byref(items[1]), None, 1, None) == wlib.ERR_BAD_DESC
+    other = op(4096).lib.desc
+    items[1].desc = ctypes.pointer(other)
+    assert L.wqaa_matmul_gate_up(ctypes.byref(items[0]), ctypes.byref(items[1]), None, 1, None) == wlib.ERR_BAD_DESC
+    assert b"agree" in L.wqaa_last_error_string()
+
+
+def test_epilogue_descriptor_layout():
+    """struct wqaa_epilogue grew by the residual pointer; its 24-byte prefix is what callers built before that pass"""
+    assert ctypes.sizeof(wlib.Epilogue) == 32 and wlib.Epilogue.residual.offset == 24
+    assert wlib.EPI_QUANTIZE_INPUT == 1 and wlib.EPI_ADD_RESIDUAL == 2
+    mm = op(4096)
+    assert mm.fused_ops_supported(1) and mm.fused_ops_supported(2) and not mm.fused_ops_supported(3)
+    assert not op(4096, W_dtype="nf4").fused_ops_supported(1)
