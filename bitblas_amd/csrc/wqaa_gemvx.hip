@@ -79,7 +79,7 @@ static void gemvx_candidate(int N, int nsteps, int cus, int R, int* kw, double* 
 
 // pro: 0 plain members, 1 residual add (WQAA_EPI_ADD_RESIDUAL), 2 gate / up pair (wqaa_matmul_gate_up: d.N = the rows the
 // launch streams, 2 x the projections' N; two rows per wave by construction)
-static int gemvx_choose(const wqaa_matmul_desc& d, int m, GemvxChoice* c, int pro = 0) {
+static int gemvx_choose(const wqaa_matmul_desc& d, int m, GemvxChoice* c, int pro = 0, int force_kw = 0) {
   c->bits = d.w_bits;
   c->layout = d.w_layout == WQAA_LAYOUT_LOP3 ? LAYOUT_LOP3 : LAYOUT_PLAIN;
   c->mode = !d.with_scaling ? MD_NONE
@@ -104,6 +104,7 @@ static int gemvx_choose(const wqaa_matmul_desc& d, int m, GemvxChoice* c, int pr
   int kw = c->R == 2 ? k2 : k1;
   if (d.k_split_hint > 1) kw = d.k_split_hint;                                          // the caller's k_split
   if (const char* f = getenv("WQAA_GEMVX_KW")) kw = atoi(f) > 0 ? atoi(f) : 1;          // tuning aid
+  if (force_kw > 0) kw = force_kw;                                                      // a pair sums a row as its projection alone does
   if (kw > c->nsteps) kw = c->nsteps;
   if (kw > 16) kw = 16;
   c->kw = kw;
@@ -290,7 +291,12 @@ static int gemvx_pair_choose(const wqaa_matmul_desc& d, int m, GemvxChoice* c) {
     *c = *hit;
     return WQAA_OK;
   }
-  int st = gemvx_choose(merged, m, c, 2);
+  // the K split across waves is the fp32 summation order of a row: the one each projection gets ALONE, so that the pair's g and
+  // u are the float16 values the projections' own launches store (rows per wave, workgroup width and grid do not change a row's bits)
+  GemvxChoice alone;
+  int st = gemvx_choose(d, m, &alone, 1);
+  if (st != WQAA_OK) return st;
+  st = gemvx_choose(merged, m, c, 2, alone.kw);
   if (st == WQAA_OK) memo.put(merged, m, 9, *c);
   return st;
 }

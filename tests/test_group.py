@@ -152,6 +152,9 @@ def test_gate_up_pair_plan_and_argument_checks():
     assert plan["name"] == gate.plans[1]["name"].replace("_gemvx_b1r2d2k1", "_gemvx_b1r2d2k1_pair") and plan["rows_per_wave"] == 2
     assert plan["threads"] == merged["threads"] and plan["split_k"] == merged["split_k"] and plan["lds_bytes"] == merged["lds_bytes"]
     assert wgroup.gate_up_plan(op(512, K=16384), 1)["split_k"] > 1            # few rows: K split across the waves, like the plain launch
+    for n, k in ((512, 16384), (1000, 16384), (300, 8192), (2048, 12288), (11008, 4096)):      # a row is summed as its projection alone sums it
+        alone = op(n, K=k)
+        assert wgroup.gate_up_plan(alone, 1)["split_k"] == alone.plans[1]["split_k"], (n, k)
     assert wgroup.gate_up_plan(op(11008, M=[1, 16]), 2)["batch_tile"] == 2
     assert wgroup.gate_up_plan(op(11008, M=[1, 16]), 16) is None              # MFMA row counts: the caller's own elementwise kernels
     assert wgroup.gate_up_plan(op(4096, W_dtype="nf4"), 1) is None
