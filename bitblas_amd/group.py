@@ -212,6 +212,31 @@ def matmul_gate_up(gate_op: Matmul, up_op: Matmul, A: torch.Tensor, gate_weights
     return output
 
 
+class GatedMLP(torch.nn.Module):
+    """`down(act_fn(gate(x)) * up(x))` (+ residual) over three `bitblas_amd.Linear` layers, act_fn = silu - the MLP of a
+    Llama-style decoder layer (the reference's callers: integration/BitNet/modeling_bitnet.py:209-244 without its extra
+    norm) in TWO launches at decode row counts: `matmul_gate_up` (gate, up and the activation) and `Linear.forward_ex` (down
+    and the residual add).  The layers keep their own buffers and state_dict keys; at other row counts / formats the same ops
+    run as the layers' plain launches with torch's elementwise kernels between them."""
+
+    def __init__(self, gate_proj, up_proj, down_proj):
+        super().__init__()
+        self.gate_proj, self.up_proj, self.down_proj = gate_proj, up_proj, down_proj
+
+    @staticmethod
+    def _weights(lin):
+        cfg = lin.bitblas_matmul.config
+        if lin.consistent:
+            return (lin.weight, None, None, lin.bias if cfg.with_bias else None)
+        return (lin.qweight, lin.scales if cfg.with_scaling else None, lin.zeros if cfg.with_zeros else None,
+                lin.bias if cfg.with_bias else None)
+
+    def forward(self, x, residual=None):
+        act = matmul_gate_up(self.gate_proj.bitblas_matmul, self.up_proj.bitblas_matmul, x, self._weights(self.gate_proj),
+                             self._weights(self.up_proj))
+        return self.down_proj.forward_ex(act, residual=residual)
+
+
 class LinearGroup(torch.nn.Module):
     """`bitblas_amd.Linear` layers that read the same input (q/k/v, gate/up), called as one: `q, k, v = group(x)`.
 

@@ -151,6 +151,7 @@ def test_mlp_in_two_launches():
     act = bitblas.matmul_gate_up(gate.bitblas_matmul, up.bitblas_matmul, h, (gate.qweight, gate.scales, gate.zeros),
                                  (up.qweight, up.scales, up.zeros))
     got = down.forward_ex(act, residual=x)
+    assert torch.equal(bitblas.GatedMLP(gate, up, down)(h, residual=x), got)             # the module form of the same two launches
     want_act = torch.nn.functional.silu(gate(h)) * up(h)
     want = x + down(want_act)
     torch.cuda.synchronize()

@@ -93,3 +93,29 @@ def test_empty_batch_and_leading_batch_dimensions():
     from bitblas_amd import lib as wl
     st = wl.load_library().wqaa_matmul(ctypes.byref(mm.lib.desc), None, None, None, None, None, None, None, 0, None)
     assert st == 0
+
+
+def test_forward_ex_and_gate_up_check_before_they_launch(monkeypatch):
+    """`Matmul.forward_ex` / `matmul_gate_up` hand raw pointers to the C ABI like `forward`: a residual or output of the wrong size
+    or type, or two projections of different configurations, are refused in Python (CPU tensors, device check stubbed)"""
+    lin = _linear([1, 16])
+    mm = lin.bitblas_matmul
+    monkeypatch.setattr(mm, "check_activation", lambda A: A.numel() // A.shape[-1], raising=False)
+    A = torch.zeros(1, 256, dtype=torch.float16)
+    with pytest.raises(ValueError, match="residual"):
+        mm.forward_ex(A, lin.qweight, lin.scales, lin.zeros, residual=torch.zeros(1, 64, dtype=torch.float16))
+    with pytest.raises(ValueError, match="residual"):
+        mm.forward_ex(A, lin.qweight, lin.scales, lin.zeros, residual=torch.zeros(1, 128, dtype=torch.float32))
+    with pytest.raises(ValueError, match="output must hold"):
+        mm.forward_ex(A, lin.qweight, lin.scales, lin.zeros, residual=torch.zeros(1, 128, dtype=torch.float16),
+                      output=torch.zeros(1, 64, dtype=torch.float16))
+    with pytest.raises(ValueError, match="bytes"):
+        mm.forward_ex(A, lin.qweight[:64], lin.scales, lin.zeros, residual=torch.zeros(1, 128, dtype=torch.float16))
+    other = bitblas.Linear(256, 64, A_dtype="float16", W_dtype="uint4", group_size=128, with_scaling=True, with_zeros=True,
+                           zeros_mode="original", opt_M=[1, 16], enable_tuning=False).bitblas_matmul
+    monkeypatch.setattr(other, "check_activation", lambda A: A.numel() // A.shape[-1], raising=False)
+    with pytest.raises(ValueError, match="one configuration"):
+        bitblas.matmul_gate_up(mm, other, A, lin.qweight, lin.qweight)
+    with pytest.raises(ValueError, match="output must hold"):
+        bitblas.matmul_gate_up(mm, mm, A, (lin.qweight, lin.scales, lin.zeros), (lin.qweight, lin.scales, lin.zeros),
+                               output=torch.zeros(1, 64, dtype=torch.float16))

@@ -71,6 +71,12 @@ def snapshot():
                                   enable_tuning=False, strict_reference=False) for n in ns]
             g = bitblas.group_plan(ops, 1)
             snap[f"group_{tag}/m1"] = dict(launches=g["launches"], **{k: g["plan"][k] for k in KEEP})
+            if tag == "gateup":          # gate_proj + up_proj + the gated activation as one launch (wqaa_matmul_gate_up)
+                for m in (1, 2):
+                    p = bitblas.gate_up_plan(bitblas.Matmul(bitblas.MatmulConfig(M=[1, 2], **{k: getattr(ops[0].config, k) for k in
+                                             ("N", "K", "A_dtype", "W_dtype", "out_dtype", "accum_dtype", "group_size", "with_scaling")}),
+                                             enable_tuning=False, strict_reference=False), m)
+                    snap[f"pair_gateup/m{m}"] = {k: p[k] for k in KEEP}
         return snap
     finally:
         os.environ.update(keep_env)
