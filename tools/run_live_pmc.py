@@ -1,0 +1,5 @@
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+t = time.time()
+print(bench.pmc_traffic_live(16, 4), "seconds", round(time.time() - t, 1))
