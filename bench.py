@@ -914,7 +914,27 @@ def main():
             ctypes.CDLL(None).fflush(None)
         except Exception:  # noqa: BLE001
             pass
-        print(json.dumps(result), flush=True)
+        # the line is ~17 KB and logs keep its tail: the long per-member records go first, the contract fields, a compact
+        # per-member summary (time and roofline fraction) and the headline roofline / cpu_baseline last
+        members = result.pop("members", None)
+        ordered = {}
+        if members is not None:
+            ordered["members"] = members
+        tail_keys = ("roofline", "cpu_baseline")
+        ordered.update({k: v for k, v in result.items() if k not in tail_keys})
+        if members is not None:
+            def brief(v):
+                if not isinstance(v, dict) or "error" in v:
+                    return v
+                t = v.get("us_per_launch", v.get("us_per_step"))
+                if t is None and isinstance(v.get("fused"), dict):
+                    return {"fused_us": round(v["fused"]["us_per_step"], 1), "composed_us": round(v["composed"]["us_per_step"], 1),
+                            "frac": round(v["fused"]["frac"], 3)}
+                frac = (v.get("roofline") or {}).get("frac")
+                return {"us": None if t is None else round(t, 2), "frac": None if frac is None else round(frac, 3)}
+            ordered["members_summary"] = {k: brief(v) for k, v in members.items()}
+        ordered.update({k: result[k] for k in tail_keys if k in result})
+        print(json.dumps(ordered), flush=True)
 
 
 if __name__ == "__main__":
