@@ -930,6 +930,9 @@ def main():
                 if t is None and isinstance(v.get("fused"), dict):
                     return {"fused_us": round(v["fused"]["us_per_step"], 1), "composed_us": round(v["composed"]["us_per_step"], 1),
                             "frac": round(v["fused"]["frac"], 3)}
+                if t is None and "own_us_per_launch" in v:
+                    return {"own_f16_us": round(v["own_us_per_launch"], 2), "vendor_f16_us": round(v["vendor_us_per_launch"], 2),
+                            "int4_speedup_vs_vendor_f16": round(v.get("int4_speedup_vs_vendor_f16") or 0.0, 2)}
                 frac = (v.get("roofline") or {}).get("frac")
                 return {"us": None if t is None else round(t, 2), "frac": None if frac is None else round(frac, 3)}
             ordered["members_summary"] = {k: brief(v) for k, v in members.items()}

@@ -205,6 +205,14 @@ def matmul_gate_up(gate_op: Matmul, up_op: Matmul, A: torch.Tensor, gate_weights
         it.Scale = scale.data_ptr() if scale is not None else None
         it.Zeros = zeros.data_ptr() if zeros is not None else None
         it.Bias = bias.data_ptr() if bias is not None else None
+    if _lib._PLAN_LOG:
+        key = (bytes(gate_op.lib.desc), int(m), "pair")
+        if key not in _lib._plan_logged:
+            _lib._plan_logged.add(key)
+            plan = gate_up_plan(gate_op, m)
+            if plan is not None:
+                with open(_lib._PLAN_LOG, "a") as f:
+                    f.write(f"{int(m)}\t{plan['name']}\n")
     status = _library().wqaa_matmul_gate_up(ctypes.byref(items[0]), ctypes.byref(items[1]), output.data_ptr(), m,
                                             _lib.current_stream_handle(A.device))
     if status != _lib.OK:
