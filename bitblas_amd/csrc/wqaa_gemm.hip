@@ -405,6 +405,19 @@ int gemm_launch(const wqaa_matmul_desc& d, const void* A, const void* B, const v
   a.tiles_m = c.tiles_m;
   a.tiles_n = c.tiles_n;
   {
+    // the tile map without integer divisions: exact while (largest dividend) x (divisor) < 2^32 - else the kernel divides
+    const unsigned long long blocks = (unsigned long long)c.tiles_m * c.tiles_n * (c.ksplit > 0 ? c.ksplit : 1);
+    const unsigned long long per_group = (unsigned long long)a.group_m * c.tiles_n;
+    const int tail = c.tiles_m % a.group_m;
+    const unsigned long long ks = (unsigned long long)(c.ksplit > 0 ? c.ksplit : 1);
+    const bool fits = blocks * (blocks > per_group ? blocks : per_group) < (1ull << 32) && ks * ks * (unsigned long long)d.K < (1ull << 32);
+    a.mg_ntiles = fits ? tile_magic((uint32_t)(c.tiles_m * c.tiles_n)) : 0u;
+    a.mg_per_group = fits ? tile_magic((uint32_t)per_group) : 0u;
+    a.mg_group_m = fits ? tile_magic((uint32_t)a.group_m) : 0u;
+    a.mg_tail_m = fits && tail > 1 ? tile_magic((uint32_t)tail) : 0u;
+    a.mg_ksplit = fits ? tile_magic((uint32_t)(c.ksplit > 0 ? c.ksplit : 1)) : 0u;
+  }
+  {
     // split-K partial sums and large output tiles leave the chip write-through (they are read by another kernel, once):
     // nothing dirty is left for the kernel boundary to write back.  WQAA_GEMM_WS_POLICY=<bits> overrides (tuning aid, plan time)
     static thread_local unsigned seen = ~0u;

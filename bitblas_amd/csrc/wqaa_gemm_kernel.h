@@ -65,7 +65,41 @@ struct GemmArgs {
   void* ws;           //      writes fp32 / int32 partial sums to ws[s][M][N]; a second kernel reduces
   int ws_policy;      // bits 0-1: cache policy of the partial-sum stores (0 default, 1 non-temporal, 2 sc1, 3 sc0 sc1: write-through);
                       // bit 4: the ping-pong members store their output tile write-through (large outputs)
+  // reciprocals of the tile map's divisors (tile_magic; 0 = divide): a uniform integer division is ~25 instructions of
+  // float reciprocal + fix-up on this ISA (a 64-bit one ~150) and the tile map had five of them in front of the first load
+  uint32_t mg_ntiles = 0, mg_per_group = 0, mg_group_m = 0, mg_tail_m = 0, mg_ksplit = 0;
 };
+
+// floor(2^32 / d) + 1: __umulhi(x, magic) == x / d whenever x * d < 2^32 (the host checks the largest x it can meet)
+inline uint32_t tile_magic(uint32_t d) { return d <= 1 ? 0u : (uint32_t)((1ull << 32) / d) + 1u; }
+__device__ __forceinline__ int udiv_magic(int x, int d, uint32_t magic) {
+  if (d == 1) return x;
+  return magic ? (int)__umulhi((uint32_t)x, magic) : x / d;
+}
+
+// tile of a workgroup.  XCD-aware order: block b runs on XCD b % 8; every XCD gets a contiguous range of the grouped order
+// (consecutive tile ids sweep `group_m` M-tiles x all N-tiles column by column, so the ~32 tiles an XCD has in flight form a
+// compact 2-D block and share both operand bands in its L2); with split-K the k-slice is the slowest index.
+struct TileOfBlock {
+  int split, tile_m, tile_n;
+};
+__device__ __forceinline__ TileOfBlock tile_of_block(const GemmArgs& a, int block, int nblocks) {
+  int blk = block;
+  if ((nblocks & 7) == 0) blk = (block & 7) * (nblocks >> 3) + (block >> 3);
+  TileOfBlock t;
+  const int ntiles = a.tiles_m * a.tiles_n;
+  t.split = a.ksplit > 1 ? udiv_magic(blk, ntiles, a.mg_ntiles) : 0;        // k-slice of this workgroup
+  blk -= t.split * ntiles;
+  const int per_group = a.group_m * a.tiles_n;
+  const int grp = udiv_magic(blk, per_group, a.mg_per_group);
+  const int rem = blk - grp * per_group;
+  const int first_m = grp * a.group_m;
+  const bool tail = a.tiles_m - first_m < a.group_m;                          // the last, shorter group of M-tiles
+  const int gsz = tail ? a.tiles_m - first_m : a.group_m;
+  t.tile_n = udiv_magic(rem, gsz, tail ? a.mg_tail_m : a.mg_group_m);
+  t.tile_m = first_m + rem - t.tile_n * gsz;
+  return t;
+}
 
 // lab builds only (tools/decode_trace.hip, -DWQAA_TRACE): per-wave timestamps kept in registers, written through a.lut
 // (unused by the integer formats the harness instantiates) after the last phase
@@ -450,21 +484,8 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_kernel(const GemmArgs a) {
   const int fr = lane & 15;          // fragment row (weight n / activation m)
   const int kb = lane >> 4;          // k-block of the lane
 
-  // XCD-aware tile order: block b runs on XCD b % 8; give every XCD a contiguous band of M tiles so
-  // its L2 keeps one activation band and streams the (small, packed) weights
-  int blk = blockIdx.x;
-  const int nblk = gridDim.x;
-  if ((nblk & 7) == 0) blk = (blockIdx.x & 7) * (nblk >> 3) + (blockIdx.x >> 3);
-  const int ntiles = a.tiles_m * a.tiles_n;
-  const int split = blk / ntiles;        // k-slice of this workgroup (0 when ksplit == 1)
-  blk -= split * ntiles;
-  // grouped order: consecutive tile ids sweep `group_m` M-tiles x all N-tiles column by column, so the
-  // ~32 tiles an XCD has in flight form a compact 2-D block and share both operand bands in its L2
-  // (row-major order shares one activation band and streams 32 different weight bands)
-  const int per_group = a.group_m * a.tiles_n;
-  const int first_m = (blk / per_group) * a.group_m;
-  const int gsz = a.tiles_m - first_m < a.group_m ? a.tiles_m - first_m : a.group_m;
-  const int tile_m = first_m + (blk % per_group) % gsz, tile_n = (blk % per_group) / gsz;
+  const TileOfBlock tob = tile_of_block(a, (int)blockIdx.x, (int)gridDim.x);
+  const int split = tob.split, tile_m = tob.tile_m, tile_n = tob.tile_n;
   const int m0 = tile_m * P::BM;
   const int n0 = tile_n * P::BN + wave * (NFW * 16);
 
@@ -799,8 +820,8 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_kernel(const GemmArgs a) {
     for (int q = 0; q < S; ++q)
       if (t0 + q < a.nsteps) compute_step(bs[q], smem_raw + q * (P::BM * P::ROW_BYTES));
   } else {
-    const int t_begin = (int)((long)split * a.nsteps / a.ksplit);
-    const int nsteps = (int)((long)(split + 1) * a.nsteps / a.ksplit);   // end of this workgroup's k range
+    const int t_begin = udiv_magic(split * a.nsteps, a.ksplit, a.mg_ksplit);
+    const int nsteps = udiv_magic((split + 1) * a.nsteps, a.ksplit, a.mg_ksplit);   // end of this workgroup's k range
     BLane<P> bcur, bnext;
     if constexpr (P::WIDE) {
       // one group per k-step: the groups of four consecutive steps come with ONE 8-byte load per row, a

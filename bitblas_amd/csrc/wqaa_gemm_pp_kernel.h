@@ -212,13 +212,8 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_pp_kernel(const GemmArgs a
   };
 
   // ---- tile of this workgroup: XCD-contiguous ranges of the grouped order (see wq_gemm_kernel) ----
-  int blk = blockIdx.x;
-  const int nblk = gridDim.x;
-  if ((nblk & 7) == 0) blk = (blockIdx.x & 7) * (nblk >> 3) + (blockIdx.x >> 3);
-  const int per_group = a.group_m * a.tiles_n;
-  const int first_m = (blk / per_group) * a.group_m;
-  const int gsz = a.tiles_m - first_m < a.group_m ? a.tiles_m - first_m : a.group_m;
-  const int tile_m = first_m + (blk % per_group) % gsz, tile_n = (blk % per_group) / gsz;
+  const TileOfBlock tob = tile_of_block(a, (int)blockIdx.x, (int)gridDim.x);
+  const int tile_m = tob.tile_m, tile_n = tob.tile_n;
   const int m0 = tile_m * P::BM;
   const int n0 = tile_n * P::BN;
   const int nw0 = n0 + wave * 32;       // first weight row of this wave
@@ -795,13 +790,8 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_pp8_kernel(const GemmArgs 
   const int grp = wave >> 2;
   const int fr = lane & 15, kb = lane >> 4;
 
-  int blk = blockIdx.x;
-  const int nblk = gridDim.x;
-  if ((nblk & 7) == 0) blk = (blockIdx.x & 7) * (nblk >> 3) + (blockIdx.x >> 3);
-  const int per_group = a.group_m * a.tiles_n;
-  const int first_m = (blk / per_group) * a.group_m;
-  const int gsz = a.tiles_m - first_m < a.group_m ? a.tiles_m - first_m : a.group_m;
-  const int tile_m = first_m + (blk % per_group) % gsz, tile_n = (blk % per_group) / gsz;
+  const TileOfBlock tob = tile_of_block(a, (int)blockIdx.x, (int)gridDim.x);
+  const int tile_m = tob.tile_m, tile_n = tob.tile_n;
   const int m0 = tile_m * P::BM, n0 = tile_n * P::BN, nw0 = n0 + wave * 32;
   const int ntiles = a.K / P::KT;
 
@@ -1004,13 +994,8 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_pp8s_kernel(const GemmArgs
   const int ng = wave & 3, mg = wave >> 2;           // mg is also the role group
   const int fr = lane & 15, kb = lane >> 4;
 
-  int blk = blockIdx.x;
-  const int nblk = gridDim.x;
-  if ((nblk & 7) == 0) blk = (blockIdx.x & 7) * (nblk >> 3) + (blockIdx.x >> 3);
-  const int per_group = a.group_m * a.tiles_n;
-  const int first_m = (blk / per_group) * a.group_m;
-  const int gsz = a.tiles_m - first_m < a.group_m ? a.tiles_m - first_m : a.group_m;
-  const int tile_m = first_m + (blk % per_group) % gsz, tile_n = (blk % per_group) / gsz;
+  const TileOfBlock tob = tile_of_block(a, (int)blockIdx.x, (int)gridDim.x);
+  const int tile_m = tob.tile_m, tile_n = tob.tile_n;
   const int m0 = tile_m * P::BM, n0 = tile_n * P::BN;
   const int ntiles = a.K / P::KT;
 

@@ -14,7 +14,12 @@ import bench
 dev = torch.device("cuda", 0); gen = torch.Generator(device=dev); gen.manual_seed(1)
 out = {}
 which = os.environ.get("AB_SET", "gemv")
-if which == "gemm":
+if which == "midm":
+    for M in (16, 32, 64, 128, 256, 512, 4096):
+        out[f"u4 M={M}"] = bench.time_member_gemm(dev, gen, M, 4096, 4096)["us_per_launch"]
+    out["u4 M=128 11008x4096"] = bench.time_member_gemm(dev, gen, 128, 11008, 4096)["us_per_launch"]
+    out["i2xi8 M=128"] = bench.time_member_gemm(dev, gen, 128, 4096, 4096, W_dtype="int2", A_dtype="int8")["us_per_launch"]
+elif which == "gemm":
     for (M, N, K) in ((4096, 4096, 4096), (2048, 4096, 4096), (1024, 4096, 4096), (128, 4096, 4096)):
         out[f"i2xi8 M={M}"] = bench.time_member_gemm(dev, gen, M, N, K, W_dtype="int2", A_dtype="int8")["us_per_launch"]
     out["u4 M=4096"] = bench.time_member_gemm(dev, gen, 4096, 4096, 4096)["us_per_launch"]
