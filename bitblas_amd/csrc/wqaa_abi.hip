@@ -589,6 +589,10 @@ void wqaa_debug_row_blocks(int b, int grid, int n_blocks, int* out3) {
   out3[2] = rb.end;
 }
 
+void wqaa_debug_tile_of_block(int tiles_m, int tiles_n, int ksplit, int group_m, int block, int* out4) {
+  gemm_debug_tile_of_block(tiles_m, tiles_n, ksplit, group_m, block, out4);
+}
+
 int wqaa_last_error(void) { return g_last_error; }
 const char* wqaa_last_error_string(void) { return g_last_error_msg; }
 

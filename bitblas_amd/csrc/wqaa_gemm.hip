@@ -365,6 +365,32 @@ size_t gemm_workspace_bytes(const wqaa_matmul_desc& d, int m) {
   return c.ksplit > 1 ? (size_t)c.ksplit * m * d.N * 4 : 0;
 }
 
+// the tile map without integer divisions (tile_of_block): reciprocals of its divisors, exact while (largest dividend) x (divisor)
+// < 2^32 - beyond that they stay 0 and the kernel divides.  Needs a.tiles_m, a.tiles_n, a.group_m.
+static void fill_tile_magics(GemmArgs& a, int ksplit, long K) {
+  const unsigned long long ks = (unsigned long long)(ksplit > 0 ? ksplit : 1);
+  const unsigned long long blocks = (unsigned long long)a.tiles_m * a.tiles_n * ks;
+  const unsigned long long per_group = (unsigned long long)a.group_m * a.tiles_n;
+  const int tail = a.tiles_m % a.group_m;
+  const bool fits = blocks * (blocks > per_group ? blocks : per_group) < (1ull << 32) && ks * ks * (unsigned long long)K < (1ull << 32);
+  a.mg_ntiles = fits ? tile_magic((uint32_t)(a.tiles_m * a.tiles_n)) : 0u;
+  a.mg_per_group = fits ? tile_magic((uint32_t)per_group) : 0u;
+  a.mg_group_m = fits ? tile_magic((uint32_t)a.group_m) : 0u;
+  a.mg_tail_m = fits && tail > 1 ? tile_magic((uint32_t)tail) : 0u;
+  a.mg_ksplit = fits ? tile_magic((uint32_t)ks) : 0u;
+}
+
+// host twin of the kernels' workgroup -> (k-slice, M-tile, N-tile) map, with the reciprocals the launch would pass (test aid)
+void gemm_debug_tile_of_block(int tiles_m, int tiles_n, int ksplit, int group_m, int block, int* out4) {
+  GemmArgs a;
+  memset(&a, 0, sizeof(a));
+  a.tiles_m = tiles_m; a.tiles_n = tiles_n; a.ksplit = ksplit; a.group_m = group_m;
+  fill_tile_magics(a, ksplit, 4096);
+  const TileOfBlock t = tile_of_block(a, block, tiles_m * tiles_n * (ksplit > 0 ? ksplit : 1));
+  out4[0] = t.split; out4[1] = t.tile_m; out4[2] = t.tile_n;
+  out4[3] = (a.mg_ntiles || tiles_m * tiles_n == 1) && (a.mg_per_group || group_m * tiles_n == 1) ? 1 : 0;   // reciprocals in use
+}
+
 int gemm_launch(const wqaa_matmul_desc& d, const void* A, const void* B, const void* LUT,
                 const void* Scale, const void* Zeros, const void* Bias, void* C, int m,
                 hipStream_t stream, hipEvent_t start, hipEvent_t stop, const wqaa_epilogue* epi, const wqaa_call_opts* opts) {
@@ -404,19 +430,7 @@ int gemm_launch(const wqaa_matmul_desc& d, const void* A, const void* B, const v
   if (const char* f = getenv("WQAA_GEMM_GROUP_M")) a.group_m = atoi(f) > 0 ? atoi(f) : 1;
   a.tiles_m = c.tiles_m;
   a.tiles_n = c.tiles_n;
-  {
-    // the tile map without integer divisions: exact while (largest dividend) x (divisor) < 2^32 - else the kernel divides
-    const unsigned long long blocks = (unsigned long long)c.tiles_m * c.tiles_n * (c.ksplit > 0 ? c.ksplit : 1);
-    const unsigned long long per_group = (unsigned long long)a.group_m * c.tiles_n;
-    const int tail = c.tiles_m % a.group_m;
-    const unsigned long long ks = (unsigned long long)(c.ksplit > 0 ? c.ksplit : 1);
-    const bool fits = blocks * (blocks > per_group ? blocks : per_group) < (1ull << 32) && ks * ks * (unsigned long long)d.K < (1ull << 32);
-    a.mg_ntiles = fits ? tile_magic((uint32_t)(c.tiles_m * c.tiles_n)) : 0u;
-    a.mg_per_group = fits ? tile_magic((uint32_t)per_group) : 0u;
-    a.mg_group_m = fits ? tile_magic((uint32_t)a.group_m) : 0u;
-    a.mg_tail_m = fits && tail > 1 ? tile_magic((uint32_t)tail) : 0u;
-    a.mg_ksplit = fits ? tile_magic((uint32_t)(c.ksplit > 0 ? c.ksplit : 1)) : 0u;
-  }
+  fill_tile_magics(a, c.ksplit, d.K);
   {
     // split-K partial sums and large output tiles leave the chip write-through (they are read by another kernel, once):
     // nothing dirty is left for the kernel boundary to write back.  WQAA_GEMM_WS_POLICY=<bits> overrides (tuning aid, plan time)

@@ -72,9 +72,13 @@ struct GemmArgs {
 
 // floor(2^32 / d) + 1: __umulhi(x, magic) == x / d whenever x * d < 2^32 (the host checks the largest x it can meet)
 inline uint32_t tile_magic(uint32_t d) { return d <= 1 ? 0u : (uint32_t)((1ull << 32) / d) + 1u; }
-__device__ __forceinline__ int udiv_magic(int x, int d, uint32_t magic) {
+__host__ __device__ __forceinline__ int udiv_magic(int x, int d, uint32_t magic) {
   if (d == 1) return x;
+#if defined(__HIP_DEVICE_COMPILE__)
   return magic ? (int)__umulhi((uint32_t)x, magic) : x / d;
+#else
+  return magic ? (int)(((unsigned long long)(uint32_t)x * magic) >> 32) : x / d;      // host twin (wqaa_debug_tile_of_block)
+#endif
 }
 
 // tile of a workgroup.  XCD-aware order: block b runs on XCD b % 8; every XCD gets a contiguous range of the grouped order
@@ -83,7 +87,7 @@ __device__ __forceinline__ int udiv_magic(int x, int d, uint32_t magic) {
 struct TileOfBlock {
   int split, tile_m, tile_n;
 };
-__device__ __forceinline__ TileOfBlock tile_of_block(const GemmArgs& a, int block, int nblocks) {
+__host__ __device__ __forceinline__ TileOfBlock tile_of_block(const GemmArgs& a, int block, int nblocks) {
   int blk = block;
   if ((nblocks & 7) == 0) blk = (block & 7) * (nblocks >> 3) + (block >> 3);
   TileOfBlock t;

@@ -303,6 +303,9 @@ int wqaa_debug_decode(const void* packed_dev, int64_t nwords, int w_format, int 
 /* host twin of the GEMV kernels' workgroup -> row-group-block map (csrc/wqaa_kinds.h xcd_row_blocks): workgroup `b` of a
  * grid of `grid` works on blocks out3[0], out3[0] + out3[1], ... < out3[2] of `n_blocks`.  Test aid, needs no device. */
 void wqaa_debug_row_blocks(int b, int grid, int n_blocks, int* out3);
+/* host twin of the MFMA members' workgroup -> tile map (k-slice, M-tile, N-tile; out4[3] = 1 when the division-free form is
+ * in use) for a grid of tiles_m * tiles_n * ksplit workgroups: every tile of every k-slice is taken exactly once (test aid) */
+void wqaa_debug_tile_of_block(int tiles_m, int tiles_n, int ksplit, int group_m, int block, int* out4);
 
 /* ---- error side channel ---------------------------------------------------------------------- */
 int wqaa_last_error(void);

@@ -179,3 +179,28 @@ def test_epilogue_descriptor_layout():
     mm = op(4096)
     assert mm.fused_ops_supported(1) and mm.fused_ops_supported(2) and not mm.fused_ops_supported(3)
     assert not op(4096, W_dtype="nf4").fused_ops_supported(1)
+
+
+@pytest.mark.parametrize("tiles_m,tiles_n,ksplit,group_m", [(16, 16, 1, 4), (1, 32, 8, 1), (2, 32, 4, 1), (5, 43, 1, 4), (7, 3, 2, 4), (9, 86, 1, 4),
+                                                            (32, 224, 1, 4), (1, 1, 1, 1), (3, 7, 16, 1), (13, 5, 3, 4), (6, 11, 1, 8)])
+def test_mfma_tile_map_without_divisions(tiles_m, tiles_n, ksplit, group_m):
+    """the MFMA members' workgroup -> (k-slice, M-tile, N-tile) map (csrc/wqaa_gemm_kernel.h: tile_of_block, host twin
+    `wqaa_debug_tile_of_block`) runs on host-side reciprocals instead of integer divisions: every tile of every k-slice is taken
+    exactly once, and the answer is the one the division-based definition gives"""
+    L = wlib.load_library()
+    L.wqaa_debug_tile_of_block.restype = None
+    L.wqaa_debug_tile_of_block.argtypes = [ctypes.c_int] * 5 + [ctypes.POINTER(ctypes.c_int)]
+    out = (ctypes.c_int * 4)()
+    nblocks = tiles_m * tiles_n * ksplit
+    seen = set()
+    for b in range(nblocks):
+        L.wqaa_debug_tile_of_block(tiles_m, tiles_n, ksplit, group_m, b, out)
+        blk = (b & 7) * (nblocks >> 3) + (b >> 3) if nblocks % 8 == 0 else b
+        split, rest = divmod(blk, tiles_m * tiles_n)
+        grp, rem = divmod(rest, group_m * tiles_n)
+        first_m = grp * group_m
+        gsz = min(group_m, tiles_m - first_m)
+        assert (out[0], out[1], out[2]) == (split, first_m + rem % gsz, rem // gsz), (b, list(out))
+        assert out[3] == 1 or tiles_m * tiles_n == 1
+        seen.add((out[0], out[1], out[2]))
+    assert seen == {(s, m, n) for s in range(ksplit) for m in range(tiles_m) for n in range(tiles_n)}
