@@ -250,12 +250,17 @@ static int matmul_impl(const wqaa_matmul_desc* desc, const void* A, const void* 
     }
   }
   const bool quant_in = epi && (epi->flags & WQAA_EPI_QUANTIZE_INPUT);
-  const bool float_ops = epi && (epi->flags & WQAA_EPI_ADD_RESIDUAL);
+  const bool float_ops = epi && (epi->flags & (WQAA_EPI_ADD_RESIDUAL | WQAA_EPI_RMSNORM_INPUT));
   if (float_ops) {
-    // the float16 path's residual add: the whole descriptor, no int8 flags, the pointer present
-    if (epi->struct_size != (int32_t)sizeof(wqaa_epilogue) || quant_in || !epi->residual) {
-      set_error(WQAA_ERR_BAD_DESC, "matmul_ex: malformed epilogue descriptor (residual add)");
+    // the float16 path's residual add / norm in front: the whole descriptor, no int8 flags, the pointers present
+    if (epi->struct_size != (int32_t)sizeof(wqaa_epilogue) || quant_in || ((epi->flags & WQAA_EPI_ADD_RESIDUAL) && !epi->residual) ||
+        ((epi->flags & WQAA_EPI_RMSNORM_INPUT) && !epi->norm_weight)) {
+      set_error(WQAA_ERR_BAD_DESC, "matmul_ex: malformed epilogue descriptor (residual add / RMSNorm input)");
       return WQAA_ERR_BAD_DESC;
+    }
+    if ((epi->flags & WQAA_EPI_ADD_RESIDUAL) && (epi->flags & WQAA_EPI_RMSNORM_INPUT)) {
+      set_error(WQAA_ERR_UNSUPPORTED, "matmul_ex: RMSNorm input and residual add on one launch (no layer has the two on one projection)");
+      return WQAA_ERR_UNSUPPORTED;
     }
     use_gemm = false;   // an exact-product GEMV member; refuses loudly if the config has none
   } else if (epi && ((epi->struct_size != (int32_t)sizeof(wqaa_epilogue) && epi->struct_size != kEpilogueV1Bytes) ||
@@ -280,7 +285,7 @@ static int matmul_impl(const wqaa_matmul_desc* desc, const void* A, const void* 
 // A group fuses into one launch when every member has the same descriptor apart from N and the merged operator
 // (N = the sum of the members' rows) is served by a GEMV-family member at this m.  *fused_x: 1 = exact-product family.
 static bool group_fusable(const wqaa_matmul_desc* const* descs, int count, int m, wqaa_matmul_desc* merged, int* fused_x,
-                          int epi_mode = 0) {      // epi_mode: 0 none, 1 caller's row scales, 2 in-kernel activation quantiser
+                          int epi_mode = 0) {      // epi_mode: 0 none, 1 caller's row scales, 2 in-kernel activation quantiser, 3 RMSNorm in front
   if (count < 2 || count > WQAA_GROUP_MAX || m < 1 || m > 2) return false;
   if (const char* f = getenv("WQAA_GROUP_FUSE")) { if (atoi(f) == 0) return false; }    // A/B aid: members launched one by one
   long total = 0;
@@ -300,7 +305,10 @@ static bool group_fusable(const wqaa_matmul_desc* const* descs, int count, int m
   char saved_msg[sizeof(g_last_error_msg)];
   memcpy(saved_msg, g_last_error_msg, sizeof(saved_msg));
   bool ok = true;
-  if (epi_mode == 0 && gemvx_group_eligible(*merged, descs, count, m)) *fused_x = 1;
+  if (epi_mode == 3) {
+    if (gemvx_group_eligible(*merged, descs, count, m, true)) *fused_x = 1;
+    else ok = false;
+  } else if (epi_mode == 0 && gemvx_group_eligible(*merged, descs, count, m)) *fused_x = 1;
   else if (gemv_group_eligible(*merged, descs, count, m, epi_mode != 0, epi_mode == 2)) *fused_x = 0;
   else ok = false;
   g_last_error = saved;
@@ -400,14 +408,17 @@ static int group_impl(const wqaa_group_item* items, const wqaa_epilogue* const* 
   if (epis) {
     for (int i = 0; i < count; ++i) {
       const wqaa_epilogue* e = epis[i];
-      if (!e || (e->struct_size != (int32_t)sizeof(wqaa_epilogue) && e->struct_size != kEpilogueV1Bytes) ||
-          (e->flags & WQAA_EPI_ADD_RESIDUAL) || (!e->row_scale && !(e->flags & WQAA_EPI_QUANTIZE_INPUT))) {
+      const bool norm = e && e->struct_size == (int32_t)sizeof(wqaa_epilogue) && e->flags == WQAA_EPI_RMSNORM_INPUT && e->norm_weight;
+      if (!norm && (!e || (e->struct_size != (int32_t)sizeof(wqaa_epilogue) && e->struct_size != kEpilogueV1Bytes) ||
+                    (e->flags & (WQAA_EPI_ADD_RESIDUAL | WQAA_EPI_RMSNORM_INPUT)) || (!e->row_scale && !(e->flags & WQAA_EPI_QUANTIZE_INPUT)))) {
         set_error(WQAA_ERR_BAD_DESC, "matmul_group_ex: member %d has a missing or malformed epilogue descriptor", i);
         return WQAA_ERR_BAD_DESC;
       }
-      const int mode = (e->flags & WQAA_EPI_QUANTIZE_INPUT) ? 2 : 1;
+      const int mode = norm ? 3 : (e->flags & WQAA_EPI_QUANTIZE_INPUT) ? 2 : 1;
       if (i == 0) epi_mode = mode;
       else if (mode != epi_mode) epi_uniform = false;
+      // one norm per fused group: its members read the same hidden state through the same weight
+      if (norm && (e->norm_weight != epis[0]->norm_weight || e->norm_eps != epis[0]->norm_eps || items[i].A != items[0].A)) epi_uniform = false;
     }
   }
   const wqaa_matmul_desc* descs[WQAA_GROUP_MAX];
@@ -459,7 +470,8 @@ static int group_impl(const wqaa_group_item* items, const wqaa_epilogue* const* 
       }
     }
     if (ok) {
-      int st = fx ? gemvx_group_launch(merged, items, count, m, s) : gemv_group_launch(merged, items, count, m, s, epis);
+      int st = fx ? gemvx_group_launch(merged, items, count, m, s, epi_mode == 3 ? epis[0] : nullptr)
+                  : gemv_group_launch(merged, items, count, m, s, epis);
       if (st == WQAA_OK) g_last_error = WQAA_OK;
       return st;
     }
@@ -477,12 +489,17 @@ int wqaa_matmul_group(const wqaa_group_item* items, int count, int m, void* stre
   return group_impl(items, nullptr, count, m, stream);
 }
 
-int wqaa_matmul_gate_up(const wqaa_group_item* gate, const wqaa_group_item* up, void* act, int m, void* stream) {
+int wqaa_matmul_gate_up(const wqaa_group_item* gate, const wqaa_group_item* up, void* act, int m, void* stream,
+                        const wqaa_epilogue* norm) {
   if (!gate || !up || !gate->desc || !up->desc || !valid_desc(gate->desc) || !valid_desc(up->desc)) {
     set_error(WQAA_ERR_BAD_DESC, "matmul_gate_up: missing item or descriptor");
     return WQAA_ERR_BAD_DESC;
   }
   if (m == 0) return WQAA_OK;
+  if (norm && (norm->struct_size != (int32_t)sizeof(wqaa_epilogue) || norm->flags != WQAA_EPI_RMSNORM_INPUT || !norm->norm_weight)) {
+    set_error(WQAA_ERR_BAD_DESC, "matmul_gate_up: the epilogue must be a whole descriptor with WQAA_EPI_RMSNORM_INPUT and its weight");
+    return WQAA_ERR_BAD_DESC;
+  }
   const wqaa_matmul_desc& d = *gate->desc;
   if (memcmp(gate->desc, up->desc, sizeof(wqaa_matmul_desc)) != 0 || gate->A != up->A) {
     set_error(WQAA_ERR_BAD_DESC, "matmul_gate_up: gate and up must share one input and agree in their descriptors");
@@ -499,14 +516,14 @@ int wqaa_matmul_gate_up(const wqaa_group_item* gate, const wqaa_group_item* up, 
     set_error(WQAA_ERR_NO_DEVICE, "no HIP device visible");
     return WQAA_ERR_NO_DEVICE;
   }
-  int st = gemvx_pair_launch(d, gate, up, act, m, s);
+  int st = gemvx_pair_launch(d, gate, up, act, m, s, norm);
   if (st == WQAA_OK) g_last_error = WQAA_OK;
   return st;
 }
 
-int wqaa_gate_up_plan(const wqaa_matmul_desc* desc, int m, wqaa_plan* plan) {
+int wqaa_gate_up_plan(const wqaa_matmul_desc* desc, int m, int with_norm, wqaa_plan* plan) {
   if (!valid_desc(desc)) return WQAA_ERR_BAD_DESC;
-  return gemvx_pair_plan(*desc, m, plan);
+  return gemvx_pair_plan(*desc, m, plan, with_norm != 0);
 }
 
 int wqaa_matmul_group_ex(const wqaa_group_item* items, const wqaa_epilogue* const* epilogues, int count, int m, void* stream) {

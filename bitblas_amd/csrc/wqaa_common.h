@@ -86,9 +86,10 @@ void gemv_init();
 bool gemvx_eligible(const wqaa_matmul_desc& d, int m);
 bool gemvx_covers(const wqaa_matmul_desc& d, int m);
 // groups: `merged` = the members' descriptor with N = the sum of their rows (what selects the tile configuration)
-bool gemvx_group_eligible(const wqaa_matmul_desc& merged, const wqaa_matmul_desc* const* descs, int count, int m);
+bool gemvx_group_eligible(const wqaa_matmul_desc& merged, const wqaa_matmul_desc* const* descs, int count, int m, bool norm = false);
 int gemvx_group_plan(const wqaa_matmul_desc& merged, const int* Ns, int count, int m, wqaa_plan* plan);
-int gemvx_group_launch(const wqaa_matmul_desc& merged, const wqaa_group_item* items, int count, int m, hipStream_t stream);
+int gemvx_group_launch(const wqaa_matmul_desc& merged, const wqaa_group_item* items, int count, int m, hipStream_t stream,
+                       const wqaa_epilogue* norm = nullptr);
 bool gemv_group_eligible(const wqaa_matmul_desc& merged, const wqaa_matmul_desc* const* descs, int count, int m, bool with_epilogue = false, bool quant_in = false);
 int gemv_group_plan(const wqaa_matmul_desc& merged, const int* Ns, int count, int m, wqaa_plan* plan);
 int gemv_group_launch(const wqaa_matmul_desc& merged, const wqaa_group_item* items, int count, int m, hipStream_t stream,
@@ -96,9 +97,9 @@ int gemv_group_launch(const wqaa_matmul_desc& merged, const wqaa_group_item* ite
 int gemvx_plan(const wqaa_matmul_desc& d, int m, wqaa_plan* plan);
 int gemvx_launch(const wqaa_matmul_desc& d, const void* A, const void* B, const void* Scale, const void* Zeros,
                  const void* Bias, void* C, int m, hipStream_t stream, hipEvent_t start, hipEvent_t stop, const wqaa_epilogue* epi = nullptr);
-int gemvx_pair_plan(const wqaa_matmul_desc& d, int m, wqaa_plan* plan);
+int gemvx_pair_plan(const wqaa_matmul_desc& d, int m, wqaa_plan* plan, bool norm);
 int gemvx_pair_launch(const wqaa_matmul_desc& d, const wqaa_group_item* gate, const wqaa_group_item* up, void* act, int m,
-                      hipStream_t stream);
+                      hipStream_t stream, const wqaa_epilogue* norm);
 void gemvx_init();
 
 void gemm_debug_tile_of_block(int tiles_m, int tiles_n, int ksplit, int group_m, int block, int* out4);

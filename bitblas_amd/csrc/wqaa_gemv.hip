@@ -341,11 +341,11 @@ int gemv_launch(const wqaa_matmul_desc& d, const void* A, const void* B, const v
                 const void* Scale, const void* Zeros, const void* Bias, void* C, int m,
                 hipStream_t stream, hipEvent_t start, hipEvent_t stop, const wqaa_epilogue* epi) {
   if (!epi && gemvx_eligible(d, m)) return gemvx_launch(d, A, B, Scale, Zeros, Bias, C, m, stream, start, stop);
-  if (epi && (epi->flags & WQAA_EPI_ADD_RESIDUAL)) {
-    // the float16 path's residual add exists in the exact-product family only (whatever strict_reference says: the caller asked
-    // for a fusion the per-element-rounding definition does not have)
+  if (epi && (epi->flags & (WQAA_EPI_ADD_RESIDUAL | WQAA_EPI_RMSNORM_INPUT))) {
+    // the float16 path's residual add / norm in front exist in the exact-product family only (whatever strict_reference says:
+    // the caller asked for a fusion the per-element-rounding definition does not have)
     if (!gemvx_covers(d, m) || d.out_dtype != WQAA_F16) {
-      set_error(WQAA_ERR_UNSUPPORTED, "matmul_ex: the residual add needs float16 activations, 1/2/4-bit integer weights, "
+      set_error(WQAA_ERR_UNSUPPORTED, "matmul_ex: residual add / RMSNorm input need float16 activations, 1/2/4-bit integer weights, "
                                       "float16 output and m <= 2 (got m=%d)", m);
       return WQAA_ERR_UNSUPPORTED;
     }

@@ -78,7 +78,7 @@ static void gemvx_candidate(int N, int nsteps, int cus, int R, int* kw, double* 
 }
 
 // pro: 0 plain members, 1 residual add (WQAA_EPI_ADD_RESIDUAL), 2 gate / up pair (wqaa_matmul_gate_up: d.N = the rows the
-// launch streams, 2 x the projections' N; two rows per wave by construction)
+// launch streams, 2 x the projections' N; two rows per wave by construction), 3 RMSNorm in front (WQAA_EPI_RMSNORM_INPUT), 4 = 3 + 2
 static int gemvx_choose(const wqaa_matmul_desc& d, int m, GemvxChoice* c, int pro = 0, int force_kw = 0) {
   c->bits = d.w_bits;
   c->layout = d.w_layout == WQAA_LAYOUT_LOP3 ? LAYOUT_LOP3 : LAYOUT_PLAIN;
@@ -100,7 +100,7 @@ static int gemvx_choose(const wqaa_matmul_desc& d, int m, GemvxChoice* c, int pr
   gemvx_candidate(d.N, c->nsteps, cus, 1, &k1, &sc1);
   c->R = sc2 >= 0.9 * sc1 ? 2 : 1;
   if (const char* f = getenv("WQAA_GEMVX_R")) c->R = atoi(f) == 1 ? 1 : 2;
-  if (pro == 2) c->R = 2;
+  if (pro == 2 || pro == 4) c->R = 2;
   int kw = c->R == 2 ? k2 : k1;
   if (d.k_split_hint > 1) kw = d.k_split_hint;                                          // the caller's k_split
   if (const char* f = getenv("WQAA_GEMVX_KW")) kw = atoi(f) > 0 ? atoi(f) : 1;          // tuning aid
@@ -169,7 +169,20 @@ static int gemvx_choose(const wqaa_matmul_desc& d, int m, GemvxChoice* c, int pr
   if (pro) c->areg = 0;                                  // the fused post ops come with the LDS-staged members
   if (c->areg) c->lds = 64;
   const int rd = c->R * 10 + c->D + (c->areg ? 1 : 0);
-  if (pro) {
+  if (pro >= 3) {
+    // the norm takes sum x^2 over items held in registers: the whole activation tile must fit the items a workgroup loads ahead
+    const long items = (long)c->mb * ncp * 256;
+    const int nai = c->R == 1 ? 3 : 2;                     // GemvxPolicy::NAI of the NORM members
+    if (items > (long)nai * c->nw * 64) {
+      set_error(WQAA_ERR_UNSUPPORTED, "gemvx: RMSNorm input needs the activation rows within %d items per thread (K = %d, %d threads)", nai,
+                d.K, c->nw * 64);
+      return WQAA_ERR_UNSUPPORTED;
+    }
+    const int prd = pro * 1000 + rd;
+    c->fn = c->bits == 4 ? pick_gemvx_norm4(c->layout, c->mode, c->mb, prd)
+            : c->bits == 2 ? pick_gemvx_norm2(c->layout, c->mode, c->mb, prd)
+                           : pick_gemvx_norm1(c->layout, c->mode, c->mb, prd);
+  } else if (pro) {
     const int prd = pro == 2 ? 1000 + rd : rd;
     c->fn = c->bits == 4 ? pick_gemvx_pro4(c->layout, c->mode, c->mb, prd)
             : c->bits == 2 ? pick_gemvx_pro2(c->layout, c->mode, c->mb, prd)
@@ -239,6 +252,14 @@ static void gemvx_fill(const wqaa_matmul_desc& d, const GemvxChoice& c, const vo
   a.slots = slots;
   a.kw_magic = (65536u + (uint32_t)c.kw - 1u) / (uint32_t)c.kw;
   a.residual = nullptr;
+  a.norm_weight = nullptr;
+  a.norm_eps = 0.f;
+  a.norm_inv_k = 1.f / (float)d.K;
+}
+
+static void gemvx_set_norm(GemvxArgs& a, const wqaa_epilogue* epi) {
+  a.norm_weight = epi->norm_weight;
+  a.norm_eps = epi->norm_eps;
 }
 
 static int gemvx_dispatch(const GemvxChoice& c, GemvxGroupArgs& ga, int grid_x, int count, hipStream_t stream, hipEvent_t start,
@@ -257,11 +278,12 @@ static int gemvx_dispatch(const GemvxChoice& c, GemvxGroupArgs& ga, int grid_x, 
 
 int gemvx_launch(const wqaa_matmul_desc& d, const void* A, const void* B, const void* Scale, const void* Zeros,
                  const void* Bias, void* C, int m, hipStream_t stream, hipEvent_t start, hipEvent_t stop, const wqaa_epilogue* epi) {
-  const int pro = epi != nullptr ? 1 : 0;                // WQAA_EPI_ADD_RESIDUAL (checked by the caller)
+  // WQAA_EPI_ADD_RESIDUAL or WQAA_EPI_RMSNORM_INPUT (one of them: checked by the caller)
+  const int pro = epi == nullptr ? 0 : (epi->flags & WQAA_EPI_RMSNORM_INPUT) ? 3 : 1;
   GemvxChoice c;
   {
     static thread_local ChoiceMemo<GemvxChoice> memo;
-    const int q = pro ? 8 : 7;
+    const int q = pro == 3 ? 10 : pro ? 8 : 7;
     if (const GemvxChoice* hit = memo.find(d, m, q)) {
       c = *hit;
     } else {
@@ -272,14 +294,15 @@ int gemvx_launch(const wqaa_matmul_desc& d, const void* A, const void* B, const 
   }
   GemvxGroupArgs ga;
   gemvx_fill(d, c, A, B, Scale, Zeros, Bias, C, m, &ga.p[0]);
-  if (pro) ga.p[0].residual = epi->residual;
+  if (pro == 1) ga.p[0].residual = epi->residual;
+  if (pro == 3) gemvx_set_norm(ga.p[0], epi);
   return gemvx_dispatch(c, ga, c.grid, 1, stream, start, stop);
 }
 
 // ---- gate_proj + up_proj + the gated activation in one launch (wqaa_matmul_gate_up) ---------------------------------------
 // Tile configuration: what the selector gives the two projections concatenated (2 N rows, two rows per wave); a wave's
 // two rows are row n of each.  args.N stays the projections' N: a row group IS an output element.
-static int gemvx_pair_choose(const wqaa_matmul_desc& d, int m, GemvxChoice* c) {
+static int gemvx_pair_choose(const wqaa_matmul_desc& d, int m, GemvxChoice* c, bool norm) {
   if (!gemvx_covers(d, m) || d.out_dtype != WQAA_F16) {
     set_error(WQAA_ERR_UNSUPPORTED, "matmul_gate_up: needs float16 activations, 1/2/4-bit integer weights, float16 output and m <= 2 (got m=%d)", m);
     return WQAA_ERR_UNSUPPORTED;
@@ -287,7 +310,8 @@ static int gemvx_pair_choose(const wqaa_matmul_desc& d, int m, GemvxChoice* c) {
   wqaa_matmul_desc merged = d;
   merged.N = 2 * d.N;
   static thread_local ChoiceMemo<GemvxChoice> memo;
-  if (const GemvxChoice* hit = memo.find(merged, m, 9)) {
+  const int q = norm ? 11 : 9;
+  if (const GemvxChoice* hit = memo.find(merged, m, q)) {
     *c = *hit;
     return WQAA_OK;
   }
@@ -296,14 +320,14 @@ static int gemvx_pair_choose(const wqaa_matmul_desc& d, int m, GemvxChoice* c) {
   GemvxChoice alone;
   int st = gemvx_choose(d, m, &alone, 1);
   if (st != WQAA_OK) return st;
-  st = gemvx_choose(merged, m, c, 2, alone.kw);
-  if (st == WQAA_OK) memo.put(merged, m, 9, *c);
+  st = gemvx_choose(merged, m, c, norm ? 4 : 2, alone.kw);
+  if (st == WQAA_OK) memo.put(merged, m, q, *c);
   return st;
 }
 
-int gemvx_pair_plan(const wqaa_matmul_desc& d, int m, wqaa_plan* plan) {
+int gemvx_pair_plan(const wqaa_matmul_desc& d, int m, wqaa_plan* plan, bool norm) {
   GemvxChoice c;
-  int st = gemvx_pair_choose(d, m, &c);
+  int st = gemvx_pair_choose(d, m, &c, norm);
   if (st != WQAA_OK || !plan) return st;
   wqaa_matmul_desc merged = d;
   merged.N = 2 * d.N;
@@ -321,15 +345,15 @@ int gemvx_pair_plan(const wqaa_matmul_desc& d, int m, wqaa_plan* plan) {
   plan->lds_bytes = c.lds;
   char wd[24];
   short_wdtype(d, wd, sizeof(wd));
-  snprintf(plan->name, sizeof(plan->name), "matmul_m%dn%dk%d_%sx%s_gemvx_b%dr%dd%dk%d_pair", m, d.N, d.K, short_dtype(d.a_dtype), wd, c.mb,
-           c.R, c.D, c.kw);
+  snprintf(plan->name, sizeof(plan->name), "matmul_m%dn%dk%d_%sx%s_gemvx_b%dr%dd%dk%d_pair%s", m, d.N, d.K, short_dtype(d.a_dtype), wd, c.mb,
+           c.R, c.D, c.kw, norm ? "_norm" : "");
   return WQAA_OK;
 }
 
 int gemvx_pair_launch(const wqaa_matmul_desc& d, const wqaa_group_item* gate, const wqaa_group_item* up, void* act, int m,
-                      hipStream_t stream) {
+                      hipStream_t stream, const wqaa_epilogue* norm) {
   GemvxChoice c;
-  int st = gemvx_pair_choose(d, m, &c);
+  int st = gemvx_pair_choose(d, m, &c, norm != nullptr);
   if (st != WQAA_OK) return st;
   GemvxGroupArgs ga;
   // filled as the 2 N-row operator (row-group blocks, K split), then N put back: rows of a pair are indexed by output element
@@ -340,6 +364,7 @@ int gemvx_pair_launch(const wqaa_matmul_desc& d, const wqaa_group_item* gate, co
   for (int i = 0; i < 2; ++i) {
     ga.p[i].N = d.N;
     ga.p[i].zq_row_bytes = d.N * c.bits / 8;
+    if (norm) gemvx_set_norm(ga.p[i], norm);
   }
   return gemvx_dispatch(c, ga, c.grid, 1, stream, nullptr, nullptr);
 }
@@ -347,15 +372,16 @@ int gemvx_pair_launch(const wqaa_matmul_desc& d, const wqaa_group_item* gate, co
 // ---- a group of independent operators in one launch (wqaa_matmul_group) -------------------------------------------------
 // The tile configuration is the one the selector gives the MERGED operator (N = sum of the members' rows: what a caller
 // that concatenates q/k/v or gate/up into one Linear would get); every member then takes gridDim.x workgroups of it.
-static int gemvx_group_choose(const wqaa_matmul_desc& merged, const int* Ns, int count, int m, GemvxChoice* c, int* grid_x) {
+static int gemvx_group_choose(const wqaa_matmul_desc& merged, const int* Ns, int count, int m, GemvxChoice* c, int* grid_x, bool norm = false) {
   {
     static thread_local ChoiceMemo<GemvxChoice> memo;
-    if (const GemvxChoice* hit = memo.find(merged, m, 16 + count)) {
+    const int q = (norm ? 48 : 16) + count;
+    if (const GemvxChoice* hit = memo.find(merged, m, q)) {
       *c = *hit;
     } else {
-      int st = gemvx_choose(merged, m, c);
+      int st = gemvx_choose(merged, m, c, norm ? 3 : 0);
       if (st != WQAA_OK) return st;
-      memo.put(merged, m, 16 + count, *c);
+      memo.put(merged, m, q, *c);
     }
   }
   const int slots = c->nw / c->kw;
@@ -379,13 +405,15 @@ static int gemvx_group_choose(const wqaa_matmul_desc& merged, const int* Ns, int
 // and the K split across waves (the fp32 summation order of a row) are chosen from N, so each member ALONE has to land on
 // the merged operator's choice - otherwise the group runs as separate launches.  (Rows per wave, workgroup width, grid and
 // register-resident vs LDS-staged activations do not change a row's arithmetic: tests/test_group_gpu.py.)
-bool gemvx_group_eligible(const wqaa_matmul_desc& merged, const wqaa_matmul_desc* const* descs, int count, int m) {
-  if (count < 1 || count > kGemvxGroupMax || !gemvx_eligible(merged, m)) return false;
+bool gemvx_group_eligible(const wqaa_matmul_desc& merged, const wqaa_matmul_desc* const* descs, int count, int m, bool norm) {
+  // (the norm in front exists in this family only: what it covers counts, not where it is the faster one)
+  auto takes = [&](const wqaa_matmul_desc& d) { return norm ? gemvx_covers(d, m) : gemvx_eligible(d, m); };
+  if (count < 1 || count > kGemvxGroupMax || !takes(merged)) return false;
   GemvxChoice cm;
-  if (gemvx_choose(merged, m, &cm) != WQAA_OK) return false;
+  if (gemvx_choose(merged, m, &cm, norm ? 3 : 0) != WQAA_OK) return false;
   for (int i = 0; descs && i < count; ++i) {
     GemvxChoice ci;
-    if (!gemvx_eligible(*descs[i], m) || gemvx_choose(*descs[i], m, &ci) != WQAA_OK) return false;
+    if (!takes(*descs[i]) || gemvx_choose(*descs[i], m, &ci, norm ? 3 : 0) != WQAA_OK) return false;
     if (ci.kw != cm.kw || ci.D != cm.D) return false;
   }
   return true;
@@ -406,16 +434,19 @@ int gemvx_group_plan(const wqaa_matmul_desc& merged, const int* Ns, int count, i
   return st;
 }
 
-int gemvx_group_launch(const wqaa_matmul_desc& merged, const wqaa_group_item* items, int count, int m, hipStream_t stream) {
+int gemvx_group_launch(const wqaa_matmul_desc& merged, const wqaa_group_item* items, int count, int m, hipStream_t stream,
+                       const wqaa_epilogue* norm) {
   int Ns[kGemvxGroupMax];
   for (int i = 0; i < count; ++i) Ns[i] = items[i].desc->N;
   GemvxChoice c;
   int gx = 0;
-  int st = gemvx_group_choose(merged, Ns, count, m, &c, &gx);
+  int st = gemvx_group_choose(merged, Ns, count, m, &c, &gx, norm != nullptr);
   if (st != WQAA_OK) return st;
   GemvxGroupArgs ga;
-  for (int i = 0; i < count; ++i)
+  for (int i = 0; i < count; ++i) {
     gemvx_fill(*items[i].desc, c, items[i].A, items[i].B, items[i].Scale, items[i].Zeros, items[i].Bias, items[i].C, m, &ga.p[i]);
+    if (norm) gemvx_set_norm(ga.p[i], norm);          // one norm for the group: its members read the same hidden state
+  }
   return gemvx_dispatch(c, ga, gx, count, stream, nullptr, nullptr);
 }
 
@@ -431,6 +462,11 @@ void gemvx_init() {
             for (int prd : {rd, 1000 + rd}) {
               fn = bits == 4 ? pick_gemvx_pro4(layout, mode, mb, prd) : bits == 2 ? pick_gemvx_pro2(layout, mode, mb, prd)
                                                                                 : pick_gemvx_pro1(layout, mode, mb, prd);
+              if (fn) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            }
+            for (int prd : {3000 + rd, 4000 + rd}) {
+              fn = bits == 4 ? pick_gemvx_norm4(layout, mode, mb, prd) : bits == 2 ? pick_gemvx_norm2(layout, mode, mb, prd)
+                                                                                 : pick_gemvx_norm1(layout, mode, mb, prd);
               if (fn) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             }
           }

@@ -59,6 +59,8 @@ struct GemvxArgs {
   int slots;          // waves / kw: row groups a workgroup works on at a time
   uint32_t kw_magic;  // ceil(2^16 / kw): x / kw == (x * kw_magic) >> 16 for x < 4096 (no integer division in the prologue)
   const void* residual;  // PRO members (WQAA_EPI_ADD_RESIDUAL): (m, N) float16 added to the float16 result; NULL: none
+  const void* norm_weight;   // NORM members (WQAA_EPI_RMSNORM_INPUT): (K,) float16 weight of the RMSNorm in front of the operator
+  float norm_eps, norm_inv_k;
 };
 
 // One launch serves up to kGemvxGroupMax INDEPENDENT operators of one tile configuration (wqaa_matmul_group: the q/k/v
@@ -85,18 +87,23 @@ struct GemvxGroupArgs {
 //   2  gate / up pair (wqaa_matmul_gate_up): the wave's two rows are row n of TWO operators (grp.p[0] = gate_proj,
 //      grp.p[1] = up_proj: same shape and format, own pointers); it stores half(silu(gate_out)) * up_out - the gated
 //      activation, evaluated once per output element by the lane that holds both sums
+//   3  RMSNorm in front (WQAA_EPI_RMSNORM_INPUT): A is the layer's hidden state; the workgroup takes sum x^2 of every row over
+//      the items it has just loaded, and stages weight * half(x * rsqrt(mean + eps)) - the reference's BitnetRMSNorm
+//      (= LlamaRMSNorm) - as its activations.  One extra barrier and K / threads multiplies per thread in front of the stream.
+//   4  3 + 2: the norm in front of a gate / up pair
 template <int BITS_, int LAYOUT_, int MODE_, int MB_, int R_, int D_, int ABL_ = 0, bool AREG_ = false, int PRO_ = 0>
 struct GemvxPolicy {
   static constexpr int BITS = BITS_, LAYOUT = LAYOUT_, MODE = MODE_, MB = MB_, R = R_, D = D_, ABL = ABL_;
   static constexpr bool AREG = AREG_;
-  static constexpr bool PRO = PRO_ == 1, PAIR = PRO_ == 2;
+  static constexpr bool PRO = PRO_ == 1, PAIR = PRO_ == 2 || PRO_ == 4, NORM = PRO_ >= 3;
   static_assert(!(AREG_ && PRO_ != 0), "the fused post ops come with the LDS-staged members");
-  static_assert(PRO_ != 2 || R_ == 2, "a gate / up pair is the two rows of a wave");
+  static_assert(!PAIR || R_ == 2, "a gate / up pair is the two rows of a wave");
   static_assert(!AREG_ || (BITS_ == 4 && LAYOUT_ == LAYOUT_LOP3 && MB_ == 1), "register-resident activations: 4-bit LOP3 weights, M = 1");
   // activation items per thread in flight ahead of the weight stream: 8 waves x 3 cover K = 12288 at 4 bit (rounds past
   // the tile are skipped wave-uniformly; 4096x11008 8.5 -> 7.76 us against one item).  The two-row members serve the
   // many-row shapes, where K is short and the extra registers cost 4 % (11008x4096 6.7 -> 7.0 us): they keep one.
-  static constexpr int NAI = R_ == 1 ? 3 : 1;
+  // (the norm needs the whole row in registers before it can stage anything: two items for the two-row members, K <= 8192 at 4 bit)
+  static constexpr int NAI = R_ == 1 ? 3 : NORM ? 2 : 1;
   static constexpr int KIND = BITS_ == 4 ? DK_INT4 : BITS_ == 2 ? DK_INT2 : DK_INT1;
   using T = KindTraits<KIND, AT_F16>;
   static constexpr int EPW = 32 / BITS_;       // fields per 32-bit word
@@ -269,6 +276,7 @@ __global__ void __launch_bounds__(1024) wq_gemvx_kernel(const GemvxGroupArgs grp
     sa_lds[((mi * ncp + c) * 64 + l) * 4 + u] = valid ? sum : 0.f;          // the chunk's sum arrives as four partials
   };
   bool avalid[NAI];
+  u32x4 nraw[P::NORM ? NAI : 1][IVW];             // NORM: the norm weight's halves of the same items
   // register-resident activations (AREG): word u of lane chunk d pairs with areg[d][u]; sa_reg[d] = the chunk's sum
   u32x4 areg[D][4];
   float sa_reg[D];
@@ -293,6 +301,17 @@ __global__ void __launch_bounds__(1024) wq_gemvx_kernel(const GemvxGroupArgs grp
       if (j * nthreads < items) {                  // wave-uniform: whole rounds beyond the tile are skipped
 #pragma unroll
         for (int v = 0; v < IVW; ++v) araw[j][v] = src[v];
+        if constexpr (P::NORM) {
+          // same elements of the (K,) weight: the item's address without its row offset
+          const int idx = j * nthreads + tid;
+          int c = idx >> 8;
+          if (MB > 1 && c >= ncp) c -= ncp;
+          const int chunk = c * 64 + (idx & 63);
+          const u32x4* wsrc = reinterpret_cast<const u32x4*>(reinterpret_cast<const uint8_t*>(a.norm_weight) +
+                                                             ((long)(avalid[j] ? chunk : 0) * E + ((idx >> 6) & 3) * EPW) * 2);
+#pragma unroll
+          for (int v = 0; v < IVW; ++v) nraw[j][v] = wsrc[v];
+        }
       }
     }
   }
@@ -316,6 +335,55 @@ __global__ void __launch_bounds__(1024) wq_gemvx_kernel(const GemvxGroupArgs grp
         for (int e = 0; e < 4; ++e) part[u] = __builtin_amdgcn_fdot2(as_h2(areg[d][u][e]), half2_t{(half_t)1.f, (half_t)1.f}, part[u], false);
       }
       sa_reg[d] = (part[0] + part[1]) + (part[2] + part[3]);
+    }
+  }
+  if constexpr (P::NORM) {
+    // sum x^2 of every activation row: per thread over its items (fp32; the squares of float16 values are exact), per wave by
+    // the DPP ladder, across the waves through LDS in wave order - every thread ends up with the same bits
+    float ssq[MB];
+#pragma unroll
+    for (int mi = 0; mi < MB; ++mi) ssq[mi] = 0.f;
+#pragma unroll
+    for (int j = 0; j < NAI; ++j) {
+      const int idx = j * nthreads + tid;
+      float part = 0.f;
+      if (idx < items && avalid[j]) {
+#pragma unroll
+        for (int v = 0; v < IVW; ++v)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) part = __builtin_amdgcn_fdot2(as_h2(araw[j][v][e]), as_h2(araw[j][v][e]), part, false);
+      }
+      const bool second = MB > 1 && (idx >> 8) >= ncp;          // the item belongs to activation row 1
+#pragma unroll
+      for (int mi = 0; mi < MB; ++mi) ssq[mi] += (second == (mi == 1)) ? part : 0.f;
+    }
+    float* nred = red_lds;                                      // free until the first `finish` (behind the staging barrier)
+#pragma unroll
+    for (int mi = 0; mi < MB; ++mi) {
+      const float w = wave_sum_l63(ssq[mi]);
+      if (lane == 63) nred[mi * NW + wave] = w;
+    }
+    __syncthreads();
+    float rinv[MB];
+#pragma unroll
+    for (int mi = 0; mi < MB; ++mi) {
+      float tot = nred[mi * NW];
+      for (int w = 1; w < NW; ++w) tot += nred[mi * NW + w];
+      rinv[mi] = rsqrtf(tot * a.norm_inv_k + a.norm_eps);
+    }
+    // x -> weight * half(x * r): the two roundings of `self.weight * (x.float() * rsqrt(var + eps)).to(half)`
+#pragma unroll
+    for (int j = 0; j < NAI; ++j) {
+      const int idx = j * nthreads + tid;
+      const float r = (MB > 1 && (idx >> 8) >= ncp) ? rinv[MB - 1] : rinv[0];
+#pragma unroll
+      for (int v = 0; v < IVW; ++v)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const half2_t x = as_h2(araw[j][v][e]);
+          const half2_t h = {(half_t)((float)x[0] * r), (half_t)((float)x[1] * r)};
+          araw[j][v][e] = as_u32(as_h2(nraw[j][v][e]) * h);
+        }
     }
   }
   if constexpr (!(P::ABL & 2) && !P::AREG) {
@@ -669,6 +737,28 @@ static gemvx_fn pick_gemvx_pro_mode(int mode, int mb, int rd) {
   return nullptr;
 }
 template <int BITS, int LAYOUT, int MODE, int MB>
+static gemvx_fn pick_gemvx_norm_rd(int rd) {
+  switch (rd) {
+    case 3012: return wq_gemvx_kernel<GemvxPolicy<BITS, LAYOUT, MODE, MB, 1, 2, 0, false, 3>>;
+    case 3022: return wq_gemvx_kernel<GemvxPolicy<BITS, LAYOUT, MODE, MB, 2, 2, 0, false, 3>>;
+    case 4022: return wq_gemvx_kernel<GemvxPolicy<BITS, LAYOUT, MODE, MB, 2, 2, 0, false, 4>>;     // norm + gate / up pair
+  }
+  return nullptr;
+}
+template <int BITS, int LAYOUT>
+static gemvx_fn pick_gemvx_norm_mode(int mode, int mb, int rd) {
+#define WQAA_GXN(MODE) (mb == 1 ? pick_gemvx_norm_rd<BITS, LAYOUT, MODE, 1>(rd) : mb == 2 ? pick_gemvx_norm_rd<BITS, LAYOUT, MODE, 2>(rd) : nullptr)
+  switch (mode) {
+    case MD_NONE: return WQAA_GXN(MD_NONE);
+    case MD_S: return WQAA_GXN(MD_S);
+    case MD_ZO: return WQAA_GXN(MD_ZO);
+    case MD_ZR: return WQAA_GXN(MD_ZR);
+    case MD_ZQ: return WQAA_GXN(MD_ZQ);
+  }
+#undef WQAA_GXN
+  return nullptr;
+}
+template <int BITS, int LAYOUT, int MODE, int MB>
 static gemvx_fn pick_gemvx_rd(int rd) {
   switch (rd) {
     case 12: return wq_gemvx_kernel<GemvxPolicy<BITS, LAYOUT, MODE, MB, 1, 2>>;
@@ -702,6 +792,9 @@ gemvx_fn pick_gemvx_int1(int layout, int mode, int mb, int rd);
 gemvx_fn pick_gemvx_pro4(int layout, int mode, int mb, int rd);
 gemvx_fn pick_gemvx_pro2(int layout, int mode, int mb, int rd);
 gemvx_fn pick_gemvx_pro1(int layout, int mode, int mb, int rd);
+gemvx_fn pick_gemvx_norm4(int layout, int mode, int mb, int rd);    // RMSNorm in front (wqaa_gemvx_inst_norm*.hip)
+gemvx_fn pick_gemvx_norm2(int layout, int mode, int mb, int rd);
+gemvx_fn pick_gemvx_norm1(int layout, int mode, int mb, int rd);
 gemvx_fn pick_gemvx_lab(int abl);     // ablation members of the int4 / LOP3 / scale / M = 1 / R = 2 configuration (tools only)
 
 }  // namespace wqaa

@@ -19,7 +19,7 @@ from typing import List, Optional, Sequence, Union
 import torch
 
 from . import lib as _lib
-from .matmul import Matmul
+from .matmul import Matmul, check_norm, rms_norm_reference
 
 GROUP_MAX = 8
 
@@ -44,9 +44,10 @@ def _library():
         lib.wqaa_matmul_group_ex.argtypes = [ctypes.POINTER(GroupItem), ctypes.POINTER(ctypes.POINTER(_lib.Epilogue)), ctypes.c_int,
                                              ctypes.c_int, ctypes.c_void_p]
         lib.wqaa_matmul_gate_up.restype = ctypes.c_int
-        lib.wqaa_matmul_gate_up.argtypes = [ctypes.POINTER(GroupItem), ctypes.POINTER(GroupItem), ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+        lib.wqaa_matmul_gate_up.argtypes = [ctypes.POINTER(GroupItem), ctypes.POINTER(GroupItem), ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
+                                            ctypes.POINTER(_lib.Epilogue)]
         lib.wqaa_gate_up_plan.restype = ctypes.c_int
-        lib.wqaa_gate_up_plan.argtypes = [ctypes.POINTER(_lib.MatmulDesc), ctypes.c_int, ctypes.POINTER(_lib.Plan)]
+        lib.wqaa_gate_up_plan.argtypes = [ctypes.POINTER(_lib.MatmulDesc), ctypes.c_int, ctypes.c_int, ctypes.POINTER(_lib.Plan)]
         lib.wqaa_group_plan.restype = ctypes.c_int
         lib.wqaa_group_plan.argtypes = [ctypes.POINTER(ctypes.POINTER(_lib.MatmulDesc)), ctypes.c_int, ctypes.c_int,
                                         ctypes.POINTER(ctypes.c_int), ctypes.POINTER(_lib.Plan)]
@@ -95,17 +96,28 @@ def _as_list(x, n, what):
 
 
 def matmul_group(ops: Sequence[Matmul], A: Union[torch.Tensor, Sequence[torch.Tensor]], weights: Sequence,
-                 outputs: Optional[Sequence[Optional[torch.Tensor]]] = None) -> List[torch.Tensor]:
+                 outputs: Optional[Sequence[Optional[torch.Tensor]]] = None, norm=None) -> List[torch.Tensor]:
     """`[op(A_i, *weights_i) for op in ops]` with as few launches as the library can do it in.
 
     ops      the operators (every member must have been built for the row count of its A);
     A        one tensor shared by all members, or one per member (all with the same row count);
     weights  per member the arguments of `Matmul.forward` after A: `W` or `(W, scale, zeros, bias)` (trailing ones optional);
-    outputs  optional preallocated outputs (contiguous, on A's device); they must not overlap.
+    outputs  optional preallocated outputs (contiguous, on A's device); they must not overlap;
+    norm     (weight, eps): A (ONE tensor) is the hidden state in front of the layer's RMSNorm, every member computes
+             `op(rms_norm(A), ...)` (include/wqaa.h WQAA_EPI_RMSNORM_INPUT) - inside the group's launch where
+             `Matmul.norm_supported`, by torch's kernels in front of it elsewhere.
     Asynchronous on the current stream of A's device, like `Matmul.forward`."""
     n = len(ops)
     if n == 0:
         return []
+    if norm is not None:
+        if not isinstance(A, torch.Tensor):
+            raise ValueError("a norm in front of a group reads ONE hidden state")
+        m_rows = ops[0].check_activation(A)
+        check_norm(norm, A, ops[0].K)
+        # (members the library cannot fuse into one launch still run one by one, each with the norm in its own staging pass)
+        if not all(op.norm_supported(m_rows) and op.K == ops[0].K for op in ops) or m_rows == 0:
+            A, norm = rms_norm_reference(A, *norm), None
     if len(weights) != n:
         raise ValueError(f"weights: expected {n} entries, got {len(weights)}")
     As = _as_list(A, n, "A")
@@ -158,30 +170,43 @@ def matmul_group(ops: Sequence[Matmul], A: Union[torch.Tensor, Sequence[torch.Te
         return outs
     if _lib._PLAN_LOG:
         _log_group([op.lib.desc for op in ops], m)
-    status = _library().wqaa_matmul_group(items, n, m, stream)
+    if norm is not None:
+        epi = _lib.norm_epilogue(norm[0].data_ptr(), norm[1])
+        epis = (ctypes.POINTER(_lib.Epilogue) * n)(*[ctypes.pointer(epi)] * n)
+        status = _library().wqaa_matmul_group_ex(items, epis, n, m, stream)
+        if status == _lib.ERR_UNSUPPORTED:        # the selector's word is final: torch's norm in front of the plain group
+            normed = rms_norm_reference(As[0], *norm)
+            return matmul_group(ops, normed, weights, outputs=outs)
+    else:
+        status = _library().wqaa_matmul_group(items, n, m, stream)
     if status != _lib.OK:
         _lib.check(status)
     return outs
 
 
-def gate_up_plan(op: Matmul, m: int = 1):
-    """plan of the one-launch `matmul_gate_up` of two operators like `op` at `m` rows, or None where it does not exist
-    (then the group launch + torch's `silu`, `mul` run).  Needs no device."""
+def gate_up_plan(op: Matmul, m: int = 1, norm: bool = False):
+    """plan of the one-launch `matmul_gate_up` of two operators like `op` at `m` rows (`norm`: with the RMSNorm in front), or
+    None where it does not exist (then the group launch + torch's `silu`, `mul` run).  Needs no device."""
     plan = _lib.Plan()
-    if _library().wqaa_gate_up_plan(ctypes.byref(op.lib.desc), int(m), ctypes.byref(plan)) != _lib.OK:
+    if _library().wqaa_gate_up_plan(ctypes.byref(op.lib.desc), int(m), 1 if norm else 0, ctypes.byref(plan)) != _lib.OK:
         return None
     return plan.as_dict()
 
 
 def matmul_gate_up(gate_op: Matmul, up_op: Matmul, A: torch.Tensor, gate_weights, up_weights,
-                   output: Optional[torch.Tensor] = None) -> torch.Tensor:
+                   output: Optional[torch.Tensor] = None, norm=None) -> torch.Tensor:
     """`F.silu(gate_op(A, *gate_weights)) * up_op(A, *up_weights)` - the gated activation of a Llama-style MLP (the reference's
     callers: integration/BitNet/modeling_bitnet.py:240-244, :281-287) with both projections in ONE launch that stores only the
     activation (wqaa_matmul_gate_up: float16 x 1 / 2 / 4-bit integer weights at m <= 2); elsewhere the group launch followed
-    by torch's two elementwise kernels.  weights: `W` or `(W, scale, zeros, bias)` per projection, as `matmul_group`."""
+    by torch's two elementwise kernels.  weights: `W` or `(W, scale, zeros, bias)` per projection, as `matmul_group`.
+    norm = (weight, eps): A is the hidden state in front of the MLP's RMSNorm (`post_attention_layernorm`, :858), folded in too."""
     m = gate_op.check_activation(A)
     if up_op.check_activation(A) != m or bytes(gate_op.lib.desc) != bytes(up_op.lib.desc):
         raise ValueError("gate and up must be operators of one configuration (same N, K, formats, group size)")
+    if norm is not None:
+        check_norm(norm, A, gate_op.K)
+        if not gate_op.fused_ops_supported(m) or gate_up_plan(gate_op, m, norm=True) is None:     # the selector's word
+            A, norm = rms_norm_reference(A, *norm), None
     if not gate_op.fused_ops_supported(m) or m == 0:
         g, u = matmul_group([gate_op, up_op], A, [gate_weights, up_weights])
         return torch.mul(torch.nn.functional.silu(g), u, out=output)
@@ -206,15 +231,16 @@ def matmul_gate_up(gate_op: Matmul, up_op: Matmul, A: torch.Tensor, gate_weights
         it.Zeros = zeros.data_ptr() if zeros is not None else None
         it.Bias = bias.data_ptr() if bias is not None else None
     if _lib._PLAN_LOG:
-        key = (bytes(gate_op.lib.desc), int(m), "pair")
+        key = (bytes(gate_op.lib.desc), int(m), "pair", norm is not None)
         if key not in _lib._plan_logged:
             _lib._plan_logged.add(key)
-            plan = gate_up_plan(gate_op, m)
+            plan = gate_up_plan(gate_op, m, norm=norm is not None)
             if plan is not None:
                 with open(_lib._PLAN_LOG, "a") as f:
                     f.write(f"{int(m)}\t{plan['name']}\n")
+    epi = _lib.norm_epilogue(norm[0].data_ptr(), norm[1]) if norm is not None else None
     status = _library().wqaa_matmul_gate_up(ctypes.byref(items[0]), ctypes.byref(items[1]), output.data_ptr(), m,
-                                            _lib.current_stream_handle(A.device))
+                                            _lib.current_stream_handle(A.device), ctypes.byref(epi) if epi is not None else None)
     if status != _lib.OK:
         _lib.check(status)
     return output
@@ -239,9 +265,10 @@ class GatedMLP(torch.nn.Module):
         return (lin.qweight, lin.scales if cfg.with_scaling else None, lin.zeros if cfg.with_zeros else None,
                 lin.bias if cfg.with_bias else None)
 
-    def forward(self, x, residual=None):
+    def forward(self, x, residual=None, norm=None):
+        """norm = (weight, eps): x is the hidden state in front of the MLP's RMSNorm (`post_attention_layernorm`)"""
         act = matmul_gate_up(self.gate_proj.bitblas_matmul, self.up_proj.bitblas_matmul, x, self._weights(self.gate_proj),
-                             self._weights(self.up_proj))
+                             self._weights(self.up_proj), norm=norm)
         return self.down_proj.forward_ex(act, residual=residual)
 
 

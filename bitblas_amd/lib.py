@@ -28,6 +28,7 @@ LAYOUT_PLAIN, LAYOUT_LOP3 = 0, 1
 OK, ERR_BAD_DESC, ERR_UNSUPPORTED, ERR_LAUNCH, ERR_NO_DEVICE = range(5)
 EPI_QUANTIZE_INPUT = 1
 EPI_ADD_RESIDUAL = 2
+EPI_RMSNORM_INPUT = 4
 
 DTYPE_CODE = {
     "float16": F16, "bfloat16": BF16, "float32": F32, "int8": I8, "int32": I32,
@@ -78,7 +79,19 @@ class Epilogue(ctypes.Structure):
     """struct wqaa_epilogue (include/wqaa.h): fused `out / si / sw -> half` of BitNet-style callers."""
     _fields_ = [("struct_size", ctypes.c_int32), ("flags", ctypes.c_int32),
                 ("row_scale", ctypes.c_void_p), ("tensor_scale", ctypes.c_float),
-                ("reserved2", ctypes.c_int32), ("residual", ctypes.c_void_p)]
+                ("reserved2", ctypes.c_int32), ("residual", ctypes.c_void_p), ("norm_weight", ctypes.c_void_p),
+                ("norm_eps", ctypes.c_float), ("reserved3", ctypes.c_int32)]
+
+
+def norm_epilogue(weight_ptr, eps) -> Epilogue:
+    """wqaa_epilogue with WQAA_EPI_RMSNORM_INPUT: the RMSNorm (weight (K,) float16, variance_epsilon) in front of the operator"""
+    epi = Epilogue()
+    epi.struct_size = ctypes.sizeof(Epilogue)
+    epi.flags = EPI_RMSNORM_INPUT
+    epi.tensor_scale = 1.0
+    epi.norm_weight = weight_ptr
+    epi.norm_eps = float(eps)
+    return epi
 
 
 class CallOpts(ctypes.Structure):
@@ -389,14 +402,15 @@ class BoundLib:
         if status != OK:
             check(status)
 
-    def run_residual(self, A, B, scale, zeros, bias, C, m, stream, residual):
-        """float16 decode path with the caller's residual add folded in (wqaa_matmul_ex, WQAA_EPI_ADD_RESIDUAL):
-        C = residual + matmul(...).  Raises WqaaError(UNSUPPORTED) where no exact-product GEMV member exists."""
+    def run_residual(self, A, B, scale, zeros, bias, C, m, stream, residual=None, norm=None):
+        """float16 decode path with one of the caller's elementwise ops folded in (wqaa_matmul_ex): `residual` (pointer) -
+        C = residual + matmul(...) (WQAA_EPI_ADD_RESIDUAL); `norm` = (weight pointer, eps) - A is the hidden state in front of
+        the layer's RMSNorm (WQAA_EPI_RMSNORM_INPUT).  Raises WqaaError(UNSUPPORTED) where no exact-product GEMV member exists."""
         if _PLAN_LOG:
-            _log_plan(self.desc, m, "+residual")
-        epi = Epilogue()
+            _log_plan(self.desc, m, "+norm" if norm else "+residual")
+        epi = norm_epilogue(*norm) if norm else Epilogue()
         epi.struct_size = ctypes.sizeof(Epilogue)
-        epi.flags = EPI_ADD_RESIDUAL
+        epi.flags = EPI_RMSNORM_INPUT if norm else EPI_ADD_RESIDUAL
         epi.tensor_scale = 1.0
         epi.residual = residual
         status = self._lib.wqaa_matmul_ex(self._desc_ref, A, B, None, scale, zeros, bias, C, m, stream, ctypes.byref(epi))

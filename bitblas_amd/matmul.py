@@ -335,6 +335,24 @@ class OPExecutorCPU:
         return len(self.operators)
 
 
+def rms_norm_reference(x: torch.Tensor, weight: torch.Tensor, eps: float) -> torch.Tensor:
+    """the reference's BitnetRMSNorm.forward (= LlamaRMSNorm; integration/BitNet/modeling_bitnet.py:99-104) as torch ops: what
+    the fused launches compute in front of the operator, and what runs where they do not exist"""
+    h = x.to(torch.float32)
+    variance = h.pow(2).mean(-1, keepdim=True)
+    h = h * torch.rsqrt(variance + eps)
+    return weight * h.to(x.dtype)
+
+
+def check_norm(norm, A: torch.Tensor, K: int) -> None:
+    """`norm` = (weight, eps): the kernels read K float16 weights through a raw pointer"""
+    weight, eps = norm
+    if weight.dtype != A.dtype or weight.numel() != K or weight.device != A.device or not weight.is_contiguous():
+        raise ValueError(f"the norm weight must hold {K} contiguous {A.dtype} elements on A's device")
+    if not float(eps) >= 0.0:
+        raise ValueError("the norm's eps must be a non-negative number")
+
+
 class Operator:
     """`bitblas.ops.Operator` (ops/operator.py:92-527): the type callers annotate and check against, and the calls they make
     on any operator - `op(*tensors)`, `hardware_aware_finetune`, `profile_latency`, `get_source`, `cleanup`.  Upstream's
@@ -680,16 +698,31 @@ class Matmul(Operator):
         return (1 <= m <= 2 and cfg.A_dtype == "float16" and cfg.out_dtype == "float16" and self.source_format in ("int", "uint")
                 and elems > 0 and cfg.K % elems == 0 and cfg.K % group == 0 and (not cfg.with_scaling or group % elems == 0))
 
-    def forward_ex(self, A, W, scale=None, zeros=None, bias=None, output=None, residual=None) -> Any:
-        """`residual + forward(A, W, ...)` - the residual add a decoder layer runs behind o_proj / down_proj (the reference's
-        callers: integration/BitNet/modeling_bitnet.py:839-860); `residual` may be `output` itself.  One launch where
-        `fused_ops_supported(m)`; elsewhere torch's add behind `forward`."""
-        if residual is None:
+    def norm_supported(self, m: int) -> bool:
+        """whether the RMSNorm in front of this operator folds into its launch at this row count (`forward_ex(norm=...)`,
+        `matmul_group(norm=...)`, `matmul_gate_up(norm=...)`): `fused_ops_supported` and the activation rows within the registers
+        a workgroup loads ahead (include/wqaa.h WQAA_EPI_RMSNORM_INPUT).  A quick necessary condition (K <= 12288 at 4 bit: three
+        items per thread of a 16-wave workgroup); the selector has the last word and the entries fall back on its refusal."""
+        return self.fused_ops_supported(m) and m * self.config.K * self.bit <= 12288 * 4
+
+    def forward_ex(self, A, W, scale=None, zeros=None, bias=None, output=None, residual=None, norm=None) -> Any:
+        """`forward` with one of the elementwise ops a decoder layer runs next to it (the reference's callers:
+        integration/BitNet/modeling_bitnet.py:839-860): `residual` - `residual + forward(A, ...)` (may be `output` itself);
+        `norm` = (weight, eps) - `forward(rms_norm(A), ...)`, A the hidden state in front of the layer's RMSNorm (:89-104).
+        One launch where `fused_ops_supported(m)` / `norm_supported(m)`; elsewhere torch's kernels around `forward`."""
+        if residual is None and norm is None:
             return self.forward(A, W, scale, zeros, bias, output)
+        if residual is not None and norm is not None:
+            raise ValueError("residual add and RMSNorm input on one projection: no layer has both")
         m = self.check_activation(A)
-        if residual.dtype != self.torch_output_dtype or residual.numel() != m * self.N or residual.device != A.device:
+        if residual is not None and (residual.dtype != self.torch_output_dtype or residual.numel() != m * self.N or residual.device != A.device):
             raise ValueError(f"`residual` must hold {m} x {self.N} {self.torch_output_dtype} elements on A's device")
-        if not self.fused_ops_supported(m):
+        if norm is not None:
+            check_norm(norm, A, self.K)
+        fused = self.norm_supported(m) if norm is not None else self.fused_ops_supported(m)
+        if not fused:
+            if norm is not None:
+                return self.forward(rms_norm_reference(A, *norm), W, scale, zeros, bias, output)
             if output is not None and output.data_ptr() == residual.data_ptr():
                 residual = residual.clone()
             out = self.forward(A, W, scale, zeros, bias, output)
@@ -705,11 +738,20 @@ class Matmul(Operator):
             raise ValueError(f"W holds {W.numel() * W.element_size()} bytes, the operator expects {self._w_bytes} "
                              f"(shape {self.retrieve_weight_shape()}: run transform_weight first)")
         A = A if A.is_contiguous() else A.contiguous()
-        residual = residual if residual.is_contiguous() else residual.contiguous()
-        self.lib.run_residual(
-            A.data_ptr(), W.data_ptr(), scale.data_ptr() if scale is not None else None,
-            zeros.data_ptr() if zeros is not None else None, bias.data_ptr() if bias is not None else None,
-            output.data_ptr(), m, _lib.current_stream_handle(A.device), residual.data_ptr())
+        residual = residual if residual is None or residual.is_contiguous() else residual.contiguous()
+        try:
+            self.lib.run_residual(
+                A.data_ptr(), W.data_ptr(), scale.data_ptr() if scale is not None else None,
+                zeros.data_ptr() if zeros is not None else None, bias.data_ptr() if bias is not None else None,
+                output.data_ptr(), m, _lib.current_stream_handle(A.device),
+                residual=residual.data_ptr() if residual is not None else None,
+                norm=(norm[0].data_ptr(), norm[1]) if norm is not None else None)
+        except _lib.WqaaError as exc:
+            # the selector's word is final (e.g. two activation rows of K = 8192 do not fit the registers a narrower workgroup loads
+            # ahead): nothing was launched - the reference's norm as torch kernels in front of the plain launch
+            if norm is None or exc.code != _lib.ERR_UNSUPPORTED:
+                raise
+            return self.forward(rms_norm_reference(A, *norm), W, scale, zeros, bias, output)
         return output
 
     def _forward_from_prebuild_lib(self, *args, stream=0):

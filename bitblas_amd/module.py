@@ -238,10 +238,10 @@ class Linear(nn.Module):
                    output.data_ptr(), m, current_stream_handle(A.device), A.device)
         return output
 
-    def forward_ex(self, A, residual=None, output=None):
+    def forward_ex(self, A, residual=None, output=None, norm=None):
         """`residual + forward(A)` - one launch at decode row counts (`Matmul.forward_ex`): what a decoder layer writes as
-        `hidden = residual + o_proj(attn)` / `residual + down_proj(act)`."""
-        if residual is None:
+        `hidden = residual + o_proj(attn)` / `residual + down_proj(act)`; or, `norm` = (weight, eps), `forward(rms_norm(A))`."""
+        if residual is None and norm is None:
             return self.forward(A, output=output)
         if not self._params_current():
             self.init_params()
@@ -250,7 +250,7 @@ class Linear(nn.Module):
         return self.bitblas_matmul.forward_ex(A, self.qweight if quantised else self.weight,
                                               self.scales if quantised and cfg.with_scaling else None,
                                               self.zeros if quantised and cfg.with_zeros else None,
-                                              self.bias if cfg.with_bias else None, output, residual=residual)
+                                              self.bias if cfg.with_bias else None, output, residual=residual, norm=norm)
 
     def load_and_transform_weight(self, weight: torch.Tensor, scales: torch.Tensor = None,
                                   zeros: torch.Tensor = None, bias: torch.Tensor = None):

@@ -177,10 +177,18 @@ int wqaa_matmul_timed(const wqaa_matmul_desc* desc, const void* A, const void* B
  *                          is read before it is written, by the same wave)
  *   wqaa_matmul_gate_up    (below)           act[m, n] = half(silu(gate_out[m, n])) * up_out[m, n]: gate_proj and up_proj
  *                          in ONE launch whose waves hold row n of both
+ * and the norm in front of q/k/v and gate/up (BitnetRMSNorm = LlamaRMSNorm, modeling_bitnet.py:89-104; decoder layer
+ * :841, :858) into the GEMV that CONSUMES the vector - a reduction over K, which every workgroup holds anyway:
+ *   WQAA_EPI_RMSNORM_INPUT (wqaa_matmul_ex, wqaa_matmul_group_ex, wqaa_matmul_gate_up)  A is the hidden state x (m, K) float16;
+ *                          the kernel stages norm_weight[k] * half(float(x[k]) * rsqrt(mean_k(x^2) + norm_eps)) - the
+ *                          reference's two roundings; the fp32 sum of squares is taken in the kernel's own order (the
+ *                          result is inside 1e-3 of torch's, not bit-identical).  Needs K <= 8192 at 4 bit (the rows
+ *                          of x within the registers a workgroup loads ahead); not together with WQAA_EPI_ADD_RESIDUAL
  * For float16 activations x 1 / 2 / 4-bit integer weights, float16 output, m <= 2 (the exact-product GEMV members,
  * whatever desc.strict_reference says); WQAA_ERR_UNSUPPORTED otherwise - the caller then runs its own elementwise ops.
  * row_scale / tensor_scale are not used by WQAA_EPI_ADD_RESIDUAL. */
 #define WQAA_EPI_ADD_RESIDUAL 2
+#define WQAA_EPI_RMSNORM_INPUT 4
 typedef struct wqaa_epilogue {
   int32_t struct_size;      /* = sizeof(wqaa_epilogue); the 24-byte prefix (up to reserved2) of earlier callers is accepted */
   int32_t flags;            /* 0 or an OR of WQAA_EPI_* */
@@ -188,6 +196,9 @@ typedef struct wqaa_epilogue {
   float tensor_scale;       /* sw = 1 / mean|W| */
   int32_t reserved2;
   const void* residual;     /* WQAA_EPI_ADD_RESIDUAL: (m, N) float16 */
+  const void* norm_weight;  /* WQAA_EPI_RMSNORM_INPUT: (K,) float16 */
+  float norm_eps;           /* WQAA_EPI_RMSNORM_INPUT: variance_epsilon */
+  int32_t reserved3;
 } wqaa_epilogue;
 
 int wqaa_matmul_ex(const wqaa_matmul_desc* desc, const void* A, const void* B, const void* LUT,
@@ -252,9 +263,11 @@ int wqaa_group_plan(const wqaa_matmul_desc* const* descs, int count, int m, int*
  * `F.silu(gate) * up`).  One launch: every wave streams row n of BOTH weights against the shared input and the lane holding
  * the two sums stores one value - neither projection's output goes to memory.  gate->C / up->C are ignored (may be NULL);
  * gate->A == up->A; the two descriptors must agree in everything (N, K, format, group size, flags).
- * wqaa_gate_up_plan: the plan of that launch (name suffix "_pair") or WQAA_ERR_UNSUPPORTED, without a device. */
-int wqaa_matmul_gate_up(const wqaa_group_item* gate, const wqaa_group_item* up, void* act, int m, void* stream);
-int wqaa_gate_up_plan(const wqaa_matmul_desc* desc, int m, wqaa_plan* plan);
+ * `norm`: NULL, or an epilogue with WQAA_EPI_RMSNORM_INPUT - A is then the hidden state in front of the MLP's norm.
+ * wqaa_gate_up_plan: the plan of that launch (name suffix "_pair" / "_pair_norm") or WQAA_ERR_UNSUPPORTED, without a device. */
+int wqaa_matmul_gate_up(const wqaa_group_item* gate, const wqaa_group_item* up, void* act, int m, void* stream,
+                        const wqaa_epilogue* norm);
+int wqaa_gate_up_plan(const wqaa_matmul_desc* desc, int m, int with_norm, wqaa_plan* plan);
 
 /* measured tuning of the vendor-library GEMM behind (desc, m) - the plain dense pairs, or the second pass of the two-pass
  * member: the heuristic's top candidates are timed on the device (temporary buffers, synchronises `stream`) and the

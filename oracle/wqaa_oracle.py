@@ -579,6 +579,15 @@ def silu_mul_f16(gate: np.ndarray, up: np.ndarray) -> np.ndarray:
     return f16(act.astype(np.float32) * np.asarray(up, dtype=np.float16).astype(np.float32))
 
 
+def rms_norm_f16(x: np.ndarray, weight: np.ndarray, eps: float) -> np.ndarray:
+    """BitnetRMSNorm.forward (= LlamaRMSNorm; integration/BitNet/modeling_bitnet.py:99-104) on float16 tensors: the variance and
+    the scaling in fp32, rounded to float16, then the float16 product with the weight."""
+    h = np.asarray(x, dtype=np.float16).astype(np.float32)
+    variance = np.mean(h * h, axis=-1, keepdims=True, dtype=np.float32)
+    h = f16(h * (np.float32(1.0) / np.sqrt(variance + np.float32(eps), dtype=np.float32)))
+    return f16(np.asarray(weight, dtype=np.float16).astype(np.float32) * h.astype(np.float32))
+
+
 def add_residual_f16(out: np.ndarray, residual: np.ndarray) -> np.ndarray:
     """`residual + linear(x)` on float16 tensors (modeling_bitnet.py:839-860): fp32 add of the two float16 values, one rounding"""
     return f16(np.asarray(out, dtype=np.float16).astype(np.float32) + np.asarray(residual, dtype=np.float16).astype(np.float32))

@@ -131,6 +131,96 @@ def test_residual_add_bit_for_bit(N, K, wd, g, zm, M, alias):
     assert_fp_parity(plain.cpu().numpy(), exact(case, case["A"]), rtol=2e-3 if case["bias"] is not None else 1e-3, atol_frac=6e-4)
 
 
+NORM = [  # (N, K, W_dtype, group, zeros_mode or None)
+    (4096, 4096, "int4", 128, None),             # Llama-2-7B q / k / v
+    (11008, 4096, "uint4", 128, "original"),     # gate / up
+    (1024, 8192, "uint4", 128, "quantized"),     # Llama-3-70B hidden size: two items per thread; K split across the waves
+    (2050, 2048, "int2", -1, None),
+    (515, 1024, "uint1", 128, None),
+]
+
+
+def _hidden_and_norm(M, K, seed):
+    rng = np.random.default_rng(seed)
+    x = ((rng.random((M, K), dtype=np.float32) - 0.5) * 6).astype(np.float16)
+    w = (1.0 + (rng.random(K, dtype=np.float32) - 0.5) * 0.5).astype(np.float16)
+    return x, w
+
+
+@pytest.mark.parametrize("M", [1, 2])
+@pytest.mark.parametrize("N,K,wd,g,zm", NORM)
+def test_rmsnorm_in_front_single_and_group(N, K, wd, g, zm, M):
+    """WQAA_EPI_RMSNORM_INPUT: the operator (and a q/k/v-style group of three) fed the hidden state computes what it computes fed
+    with the reference's RMSNorm output.  The fp32 sum of squares is taken in the kernel's own order: 1e-3, not bit identity."""
+    case = make_case(M, N, K, W_dtype=wd, group_size=g, with_scaling=True, with_zeros=zm is not None, zeros_mode=zm or "original",
+                     scale_mul=0.05, seed=N + K + M)
+    mm, W, args = build(case)
+    assert mm.norm_supported(M) or M * K > 12288          # (two rows of K = 8192: the selector may refuse - the entry then falls back)
+    x, w = _hidden_and_norm(M, K, seed=K + M)
+    xd, wd_ = torch.from_numpy(x).cuda(), torch.from_numpy(w).cuda()
+    eps = 1e-5
+    normed = bitblas.matmul.rms_norm_reference(xd, wd_, eps)
+    zero = torch.zeros(M, N, dtype=torch.float16, device="cuda")
+    want = mm.forward_ex(normed, W, residual=zero, **args)                      # the same family on torch's norm output
+    got = mm.forward_ex(xd, W, norm=(wd_, eps), **args)
+    outs = bitblas.matmul_group([mm] * 3, xd, [(W, args["scale"], args["zeros"], args["bias"])] * 3, norm=(wd_, eps))
+    torch.cuda.synchronize()
+    try:        # did the selector take the norm into the launch?  (two rows of K = 8192 do not fit an 8-wave workgroup's items)
+        mm.lib.run_residual(xd.data_ptr(), W.data_ptr(), args["scale"].data_ptr(), args["zeros"].data_ptr() if args["zeros"] is not None else None,
+                            None, torch.empty_like(got).data_ptr(), M, torch.cuda.current_stream().cuda_stream, norm=(wd_.data_ptr(), eps))
+        fused = True
+    except WqaaError:
+        fused = False
+    assert fused or K != 4096            # the Llama-2-7B shapes take it; small workgroups (few rows) or two long rows may not
+    if fused:
+        # the staged vector differs from torch's in a handful of float16 last bits at most (rsqrt of sums taken in different orders)
+        assert_fp_parity(got.cpu().numpy(), want.cpu().numpy(), rtol=1e-3, atol_frac=3e-4)
+        for o in outs:
+            assert torch.equal(o, got)                                          # a group member = the single launch, bit for bit
+    else:
+        assert torch.equal(got, mm(normed, W, **args))                          # torch's norm in front of the operator's plain launch
+    restated = oracle.rms_norm_f16(x, w, eps)
+    assert_fp_parity(normed.cpu().numpy(), restated, rtol=1e-3, atol_frac=1e-5)  # the oracle's norm = the reference's ops in torch
+    assert_fp_parity(got.cpu().numpy(), exact(case, restated), rtol=1e-3, atol_frac=6e-4)
+
+
+@pytest.mark.parametrize("M", [1, 2])
+def test_rmsnorm_in_front_of_the_gate_up_pair(M):
+    N, K = 11008, 4096
+    kw = dict(W_dtype="uint4", group_size=128, with_scaling=True, with_zeros=True, zeros_mode="original", scale_mul=0.08)
+    cg, cu = make_case(M, N, K, seed=3 + M, **kw), make_case(M, N, K, seed=11 + M, **kw)
+    gate_op, Wg, ag = build(cg)
+    up_op, Wu, au = build(cu)
+    assert bitblas.gate_up_plan(gate_op, M, norm=True)["name"].endswith("_pair_norm")
+    x, w = _hidden_and_norm(M, K, seed=5)
+    xd, wd_ = torch.from_numpy(x).cuda(), torch.from_numpy(w).cuda()
+    wg, wu = (Wg, ag["scale"], ag["zeros"], ag["bias"]), (Wu, au["scale"], au["zeros"], au["bias"])
+    got = bitblas.matmul_gate_up(gate_op, up_op, xd, wg, wu, norm=(wd_, 1e-6))
+    want = bitblas.matmul_gate_up(gate_op, up_op, bitblas.matmul.rms_norm_reference(xd, wd_, 1e-6), wg, wu)
+    torch.cuda.synchronize()
+    assert_fp_parity(got.cpu().numpy(), want.cpu().numpy(), rtol=2e-3, atol_frac=5e-4)
+    restated = oracle.rms_norm_f16(x, w, 1e-6)
+    assert_fp_parity(got.cpu().numpy(), oracle.silu_mul_f16(exact(cg, restated), exact(cu, restated)).astype(np.float32), rtol=4e-3, atol_frac=2e-3)
+
+
+def test_rmsnorm_where_no_fused_member_exists():
+    """long K (the rows do not fit the registers a workgroup loads ahead) and formats outside the family: the Python entries run the
+    reference's norm as torch kernels in front; the C entry refuses"""
+    M, N, K = 1, 1024, 28672
+    case = make_case(M, N, K, W_dtype="uint4", group_size=128, with_scaling=True, seed=2)
+    mm, W, args = build(case)
+    assert mm.fused_ops_supported(1) and not mm.norm_supported(1)
+    x, w = _hidden_and_norm(M, K, seed=9)
+    xd, wd_ = torch.from_numpy(x).cuda(), torch.from_numpy(w).cuda()
+    want = mm(bitblas.matmul.rms_norm_reference(xd, wd_, 1e-5), W, **args)
+    assert torch.equal(mm.forward_ex(xd, W, norm=(wd_, 1e-5), **args), want)
+    assert torch.equal(bitblas.matmul_group([mm, mm], xd, [(W, args["scale"])] * 2, norm=(wd_, 1e-5))[1], want)
+    out = torch.empty(M, N, dtype=torch.float16, device="cuda")
+    with pytest.raises(WqaaError):
+        mm.lib.run_residual(xd.data_ptr(), W.data_ptr(), args["scale"].data_ptr(), None, None, out.data_ptr(), 1,
+                            torch.cuda.current_stream().cuda_stream, norm=(wd_.data_ptr(), 1e-5))
+
+
 def test_mlp_in_two_launches():
     """x + down_proj(silu(gate_proj(h)) * up_proj(h)) of a Llama-style MLP: `matmul_gate_up` + `Linear.forward_ex` = two launches,
     against the layers' plain forwards with torch's silu, mul and add between them"""
@@ -172,7 +262,7 @@ def test_formats_without_a_fused_member():
     assert torch.equal(mm.forward_ex(A, W, residual=out, output=out, **args), res + mm(A, W, **args))
     with pytest.raises(WqaaError):
         mm.lib.run_residual(A.data_ptr(), W.data_ptr(), args["scale"].data_ptr(), None, None, out.data_ptr(), 1,
-                            torch.cuda.current_stream().cuda_stream, res.data_ptr())
+                            torch.cuda.current_stream().cuda_stream, residual=res.data_ptr())
     w = (W, args["scale"])
     assert torch.equal(bitblas.matmul_gate_up(mm, mm, A, w, w), torch.nn.functional.silu(mm(A, W, **args)) * mm(A, W, **args))
     # and M = 4 of a covered format: torch kernels around the MFMA member

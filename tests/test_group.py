@@ -160,22 +160,29 @@ def test_gate_up_pair_plan_and_argument_checks():
     assert wgroup.gate_up_plan(op(4096, W_dtype="nf4"), 1) is None
     L = wgroup._library()
     items = (wgroup.GroupItem * 2)()
-    assert L.wqaa_matmul_gate_up(None, None, None, 1, None) == wlib.ERR_BAD_DESC
+    assert L.wqaa_matmul_gate_up(None, None, None, 1, None, None) == wlib.ERR_BAD_DESC
     d = gate.lib.desc
     for it in items:
         it.desc = ctypes.pointer(d)
-    assert L.wqaa_matmul_gate_up(ctypes.byref(items[0]), ctypes.byref(items[1]), None, 0, None) == wlib.OK        # m == 0
-    assert L.wqaa_matmul_gate_up(ctypes.byref(items[0]), ctypes.byref(items[1]), None, 1, None) == wlib.ERR_BAD_DESC
+    assert L.wqaa_matmul_gate_up(ctypes.byref(items[0]), ctypes.byref(items[1]), None, 0, None, None) == wlib.OK        # m == 0
+    assert L.wqaa_matmul_gate_up(ctypes.byref(items[0]), ctypes.byref(items[1]), None, 1, None, None) == wlib.ERR_BAD_DESC
     other = op(4096).lib.desc
     items[1].desc = ctypes.pointer(other)
-    assert L.wqaa_matmul_gate_up(ctypes.byref(items[0]), ctypes.byref(items[1]), None, 1, None) == wlib.ERR_BAD_DESC
+    assert L.wqaa_matmul_gate_up(ctypes.byref(items[0]), ctypes.byref(items[1]), None, 1, None, None) == wlib.ERR_BAD_DESC
     assert b"agree" in L.wqaa_last_error_string()
 
 
 def test_epilogue_descriptor_layout():
-    """struct wqaa_epilogue grew by the residual pointer; its 24-byte prefix is what callers built before that pass"""
-    assert ctypes.sizeof(wlib.Epilogue) == 32 and wlib.Epilogue.residual.offset == 24
-    assert wlib.EPI_QUANTIZE_INPUT == 1 and wlib.EPI_ADD_RESIDUAL == 2
+    """struct wqaa_epilogue grew by the residual and norm fields; its 24-byte prefix is what callers built before that pass"""
+    assert ctypes.sizeof(wlib.Epilogue) == 48 and wlib.Epilogue.residual.offset == 24 and wlib.Epilogue.norm_weight.offset == 32
+    assert wlib.Epilogue.norm_eps.offset == 40
+    assert wlib.EPI_QUANTIZE_INPUT == 1 and wlib.EPI_ADD_RESIDUAL == 2 and wlib.EPI_RMSNORM_INPUT == 4
+    # the norm in front: plans without a device; K beyond the registers a workgroup loads ahead is refused
+    assert wgroup.gate_up_plan(op(11008), 1, norm=True)["name"].endswith("_pair_norm")
+    assert wgroup.gate_up_plan(op(4096, K=28672), 1, norm=True) is None and wgroup.gate_up_plan(op(4096, K=28672), 1) is not None
+    two_rows = op(4096, K=8192, M=[1, 2])      # two rows of K = 8192 against an 8-wave workgroup's two items per thread
+    assert wgroup.gate_up_plan(two_rows, 1, norm=True) is not None and wgroup.gate_up_plan(two_rows, 2, norm=True) is None
+    assert op(4096).norm_supported(1) and not op(4096, K=28672).norm_supported(1) and not op(4096, W_dtype="nf4").norm_supported(1)
     mm = op(4096)
     assert mm.fused_ops_supported(1) and mm.fused_ops_supported(2) and not mm.fused_ops_supported(3)
     assert not op(4096, W_dtype="nf4").fused_ops_supported(1)
