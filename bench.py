@@ -247,10 +247,11 @@ def time_step_int2_int8(device, gen, n_layers=4, grouped=True):
 def time_step_chained(device, gen, n_layers=4):
     """The headline step with the data dependencies of a decoder layer honoured and the caller's elementwise ops between the
     projections INCLUDED (the reference's layer: integration/BitNet/modeling_bitnet.py:839-860, MLP :240-244): per layer
-    {q,k,v}(x) -> o_proj(v) + x -> silu(gate(h)) * up(h) -> down_proj(act) + h -> next layer's x (the v projection stands in for
-    the attention output: attention and the norms are the caller's kernels either way).  `fused`: the residual adds ride in
-    the GEMVs' stores (`Matmul.forward_ex`) and gate / up / activation are one launch (`matmul_gate_up`) - 4 launches per layer,
-    nothing between them; `composed`: the same projections with torch's own elementwise kernels around them (8 launches per
+    {q,k,v}(norm1(x)) -> o_proj(v) + x -> silu(gate(norm2(h))) * up(norm2(h)) -> down_proj(act) + h -> next layer's x (the v
+    projection stands in for the attention output: attention and rope are the caller's kernels either way).  `fused`: the
+    RMSNorms ride in the activation staging of the group / pair launches, the residual adds in the GEMVs' stores
+    (`Matmul.forward_ex`), gate / up / activation are one launch (`matmul_gate_up`) - 4 launches per layer, nothing between
+    them; `composed`: the same projections with torch's own kernels around them (`F.rms_norm`, add, silu, mul: 10 launches per
     layer).  One hipGraph replay each, same weights."""
     layers = [[make_linear(N, K, device, gen) for (_, N, K) in LLAMA2_7B_LINEARS] for _ in range(n_layers)]
     for layer in layers:
@@ -261,21 +262,28 @@ def time_step_chained(device, gen, n_layers=4):
     x0 = (torch.rand((1, 4096), device=device, generator=gen) - 0.5).to(torch.float16)
     hid = [torch.empty((1, 4096), dtype=torch.float16, device=device) for _ in range(2 * n_layers)]
     act = torch.empty((1, 11008), dtype=torch.float16, device=device)
+    norms = [((1.0 + (torch.rand(4096, device=device, generator=gen) - 0.5) * 0.2).to(torch.float16),
+              (1.0 + (torch.rand(4096, device=device, generator=gen) - 0.5) * 0.2).to(torch.float16)) for _ in range(n_layers)]
+    eps = 1e-5
 
     def run(fused):
         x = x0
         for li, layer in enumerate(layers):
             h, x_next = hid[2 * li], hid[2 * li + 1]
             q, k, v, o, gate, up, down = layer
-            bitblas.matmul_group([q[0], k[0], v[0]], x, [(t[1], t[2]) for t in (q, k, v)], outputs=[t[3] for t in (q, k, v)])
+            w1, w2 = norms[li]
             if fused:
+                bitblas.matmul_group([q[0], k[0], v[0]], x, [(t[1], t[2]) for t in (q, k, v)], outputs=[t[3] for t in (q, k, v)], norm=(w1, eps))
                 o[0].forward_ex(v[3], o[1], scale=o[2], residual=x, output=h)
-                bitblas.matmul_gate_up(gate[0], up[0], h, (gate[1], gate[2]), (up[1], up[2]), output=act)
+                bitblas.matmul_gate_up(gate[0], up[0], h, (gate[1], gate[2]), (up[1], up[2]), output=act, norm=(w2, eps))
                 down[0].forward_ex(act, down[1], scale=down[2], residual=h, output=x_next)
             else:
+                xn = torch.nn.functional.rms_norm(x, (4096,), w1, eps)
+                bitblas.matmul_group([q[0], k[0], v[0]], xn, [(t[1], t[2]) for t in (q, k, v)], outputs=[t[3] for t in (q, k, v)])
                 o[0].forward(v[3], o[1], scale=o[2], output=h)
                 h += x
-                bitblas.matmul_group([gate[0], up[0]], h, [(t[1], t[2]) for t in (gate, up)], outputs=[gate[3], up[3]])
+                hn = torch.nn.functional.rms_norm(h, (4096,), w2, eps)
+                bitblas.matmul_group([gate[0], up[0]], hn, [(t[1], t[2]) for t in (gate, up)], outputs=[gate[3], up[3]])
                 torch.mul(torch.nn.functional.silu(gate[3]), up[3], out=act)
                 down[0].forward(act, down[1], scale=down[2], output=x_next)
                 x_next += h
@@ -289,7 +297,7 @@ def time_step_chained(device, gen, n_layers=4):
     for name, fused in (("fused", True), ("composed", False)):
         t = graph_time(device, lambda: run(fused), 1)
         outs[name] = run(fused).float().clone()
-        launches = n_layers * (4 if fused else 8)
+        launches = n_layers * (4 if fused else 10)
         res[name] = {"us_per_step": t * 1e6, "launches_per_step": launches, "GBps": nbytes / t / 1e9, "frac": nbytes / t / 1e9 / HBM_PEAK_GBS}
     torch.cuda.synchronize(device)
     ref = outs["composed"]
@@ -297,8 +305,8 @@ def time_step_chained(device, gen, n_layers=4):
     from bitblas_amd import gate_up_plan
     return {"workload": f"W_int4 A_fp16 M=1 decode, Llama-2-7B linears, {n_layers} layers CHAINED through their data (o_proj reads v, "
                         "gate/up read o_proj + residual, down_proj reads silu(gate) * up, the next layer reads down_proj + residual), "
-                        "the layer's elementwise ops included; weights as in the headline step",
-            "gate_up_launch": (gate_up_plan(layers[0][4][0], 1) or {}).get("name"),
+                        "the layer's RMSNorms and elementwise ops included; weights as in the headline step",
+            "gate_up_launch": (gate_up_plan(layers[0][4][0], 1, norm=True) or {}).get("name"),
             "bytes_per_step": nbytes, **res, "fused_vs_composed_max_rel_err": err,
             "bit_identical": bool(torch.equal(outs["fused"], ref)),
             "roofline": {"bound": "hbm", "achieved": res["fused"]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": res["fused"]["frac"]}}

@@ -77,6 +77,9 @@ def snapshot():
                                              ("N", "K", "A_dtype", "W_dtype", "out_dtype", "accum_dtype", "group_size", "with_scaling")}),
                                              enable_tuning=False, strict_reference=False), m)
                     snap[f"pair_gateup/m{m}"] = {k: p[k] for k in KEEP}
+                    pn = bitblas.gate_up_plan(ops[0], m, norm=True) if m == 1 else None      # ... with the RMSNorm in front
+                    if pn is not None:
+                        snap[f"pair_gateup_norm/m{m}"] = {k: pn[k] for k in KEEP}
         return snap
     finally:
         os.environ.update(keep_env)
