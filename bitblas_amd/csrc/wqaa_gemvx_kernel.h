@@ -168,6 +168,8 @@ __global__ void __launch_bounds__(1024) wq_gemvx_kernel(const GemvxGroupArgs grp
   asm volatile("" ::"s"(a.A), "s"(a.B), "s"(a.scale), "s"(a.zeros), "s"(a.N), "s"(a.K), "s"(a.kg), "s"(a.gq_shift), "s"(a.cpr),
                "s"(a.nsteps), "s"(a.kw), "s"(a.row_bytes), "s"(a.n_rgb), "s"(a.slots), "s"(a.kw_magic), "s"(a.m));
   if constexpr (P::PAIR) asm volatile("" ::"s"(grp.p[1].B), "s"(grp.p[1].scale), "s"(grp.p[1].zeros));
+  if constexpr (P::NORM) asm volatile("" ::"s"(a.norm_weight), "s"(a.norm_eps), "s"(a.norm_inv_k));
+  if constexpr (P::PRO) asm volatile("" ::"s"(a.residual));
   const int kw = a.kw;
   const int slots = a.slots;                     // row groups the workgroup works on at a time
   const int rgl = (int)(((uint32_t)wave * a.kw_magic) >> 16), kpart = wave - rgl * kw;

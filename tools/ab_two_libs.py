@@ -14,7 +14,10 @@ import bench
 dev = torch.device("cuda", 0); gen = torch.Generator(device=dev); gen.manual_seed(1)
 out = {}
 which = os.environ.get("AB_SET", "gemv")
-if which == "midm":
+if which == "head":
+    for (N, K) in ((4096, 4096), (4096, 11008), (11008, 4096)):
+        out[f"i4 exact {N}x{K}"] = bench.time_member_gemv(dev, gen, N, K)["us_per_launch"]
+elif which == "midm":
     for M in (16, 32, 64, 128, 256, 512, 4096):
         out[f"u4 M={M}"] = bench.time_member_gemm(dev, gen, M, 4096, 4096)["us_per_launch"]
     out["u4 M=128 11008x4096"] = bench.time_member_gemm(dev, gen, 128, 11008, 4096)["us_per_launch"]
