@@ -1,3 +1,4 @@
+"""bench.py's live HBM-traffic pass alone (rocprofv3 --pmc child runs of the headline step): python tools/run_live_pmc.py"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
