@@ -413,7 +413,9 @@ bool gemvx_group_eligible(const wqaa_matmul_desc& merged, const wqaa_matmul_desc
   if (gemvx_choose(merged, m, &cm, norm ? 3 : 0) != WQAA_OK) return false;
   for (int i = 0; descs && i < count; ++i) {
     GemvxChoice ci;
-    if (!takes(*descs[i]) || gemvx_choose(*descs[i], m, &ci, norm ? 3 : 0) != WQAA_OK) return false;
+    // (the norm's capacity - the rows within the items a workgroup loads ahead - is the MERGED configuration's: a narrow member,
+    // the k / v of grouped-query attention, runs in the group's workgroups; what has to agree is the summation order)
+    if (!takes(*descs[i]) || gemvx_choose(*descs[i], m, &ci, 0) != WQAA_OK) return false;
     if (ci.kw != cm.kw || ci.D != cm.D) return false;
   }
   return true;
