@@ -75,7 +75,8 @@ struct GemvxGroupArgs {
 
 // ABL_: ablation bits for tools/ (lab members only, never selected by the library): 1 = loads consumed by one XOR
 // instead of the decode + dot, 2 = no activation staging / barrier, 4 = no wave reduction / store, 8 = no store,
-// 64 = time line: s_memrealtime stamps per wave written through a.bias ([workgroup][wave][8]; tools/gemv_lab.hip)
+// 64 = time line: s_memrealtime stamps per wave written through a.bias ([workgroup][wave][8]; tools/gemv_lab.hip; slot 7 = the
+//      norm's sum known, NORM members)
 // AREG_: the lane keeps the activations of its own lane chunks in registers (4-bit LOP3 weights, M = 1, K within one
 // step): the LOP3 interleave puts consecutive elements 2j, 2j + 1 into the two halves of field j, so the natural-order
 // activation dword j IS the partner of masked field j - no LDS tile, no staging pass, no barrier; the chunk's
@@ -373,6 +374,7 @@ __global__ void __launch_bounds__(1024) wq_gemvx_kernel(const GemvxGroupArgs grp
       for (int w = 1; w < NW; ++w) tot += nred[mi * NW + w];
       rinv[mi] = rsqrtf(tot * a.norm_inv_k + a.norm_eps);
     }
+    stamp(7);                                                   // (lab time line: the norm's sum is known)
     // x -> weight * half(x * r): the two roundings of `self.weight * (x.float() * rsqrt(var + eps)).to(half)`
 #pragma unroll
     for (int j = 0; j < NAI; ++j) {

@@ -3,7 +3,9 @@
 // --rotate-mb: how many MB of weight sets the launches rotate over (cache-residency experiment).
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -I bitblas_amd/csrc -I include tools/gemv_lab.hip \
 //         -L bitblas_amd -lwqaa_hip -Wl,-rpath,'$ORIGIN/../bitblas_amd' -o tools/gemv_lab
-//   tools/gemv_lab N K [--group G] [--iters I] [--rounds R]
+//   tools/gemv_lab N K [--group G] [--iters I] [--rounds R] [--pro P]
+// --pro 3: the time line of the member with the RMSNorm in front (GemvxPolicy PRO = 3) next to the plain one; --pro 2 / 4: the gate / up
+// pair (two operators of N rows each, without / with the norm) - lab launches only, the library's launch stays the plain operator
 // int4 (signed, LOP3 layout), fp16 activations, scale per group of 128, M = 1: the headline configuration.
 #include <hip/hip_runtime.h>
 
@@ -41,7 +43,7 @@ static inline float frand() { return (float)(rng() & 0xFFFFFF) / 16777216.f; }
 
 
 int main(int argc, char** argv) {
-  int N = 4096, K = 4096, G = 128, iters = 200, rounds = 7, count = 1, rotate_mb = 600;
+  int N = 4096, K = 4096, G = 128, iters = 200, rounds = 7, count = 1, rotate_mb = 600, pro = 0;
   std::vector<int> pos;
   for (int i = 1; i < argc; ++i) {
     std::string s = argv[i];
@@ -50,6 +52,7 @@ int main(int argc, char** argv) {
     else if (s == "--rounds" && i + 1 < argc) rounds = atoi(argv[++i]);
     else if (s == "--rotate-mb" && i + 1 < argc) rotate_mb = atoi(argv[++i]);   // weight sets rotate over this many MB (600: HBM-cold; 120: memory-side cache; 0: one set)
     else if (s == "--count" && i + 1 < argc) count = atoi(argv[++i]);     // operators of a group launch (q/k/v: 3 x 4096)
+    else if (s == "--pro" && i + 1 < argc) pro = atoi(argv[++i]);         // 2 pair, 3 norm, 4 norm + pair (time line of that member)
     else pos.push_back(atoi(argv[i]));
   }
   if (pos.size() >= 2) { N = pos[0]; K = pos[1]; }
@@ -148,6 +151,19 @@ int main(int argc, char** argv) {
   const int gx = count == 1 ? plan.grid : plan.grid / count;
   gemvx_fn fn_plain = R == 2 ? wq_gemvx_kernel<GemvxPolicy<4, LAYOUT_LOP3, MD_S, 1, 2, 2>> : wq_gemvx_kernel<GemvxPolicy<4, LAYOUT_LOP3, MD_S, 1, 1, 2>>;
   gemvx_fn fn_trace = R == 2 ? wq_gemvx_kernel<GemvxPolicy<4, LAYOUT_LOP3, MD_S, 1, 2, 2, 64>> : wq_gemvx_kernel<GemvxPolicy<4, LAYOUT_LOP3, MD_S, 1, 1, 2, 64>>;
+  // members with the caller's ops folded in (R = 2 only: what the q/k/v group and the gate / up pair run): same geometry, their
+  // own kernels; a pair streams operator `set` and `set + 1` of the rotation as gate and up
+  void* dNW = nullptr;
+  if (pro >= 3) {
+    std::vector<_Float16> hN(K);
+    for (auto& x : hN) x = (_Float16)(0.75f + 0.5f * frand());
+    CK(hipMalloc(&dNW, K * 2));
+    CK(hipMemcpy(dNW, hN.data(), K * 2, hipMemcpyHostToDevice));
+  }
+  gemvx_fn fn_pro_plain = nullptr, fn_pro_trace = nullptr;
+  if (pro == 2) { fn_pro_plain = wq_gemvx_kernel<GemvxPolicy<4, LAYOUT_LOP3, MD_S, 1, 2, 2, 0, false, 2>>; fn_pro_trace = wq_gemvx_kernel<GemvxPolicy<4, LAYOUT_LOP3, MD_S, 1, 2, 2, 64, false, 2>>; }
+  if (pro == 3) { fn_pro_plain = wq_gemvx_kernel<GemvxPolicy<4, LAYOUT_LOP3, MD_S, 1, 2, 2, 0, false, 3>>; fn_pro_trace = wq_gemvx_kernel<GemvxPolicy<4, LAYOUT_LOP3, MD_S, 1, 2, 2, 64, false, 3>>; }
+  if (pro == 4) { fn_pro_plain = wq_gemvx_kernel<GemvxPolicy<4, LAYOUT_LOP3, MD_S, 1, 2, 2, 0, false, 4>>; fn_pro_trace = wq_gemvx_kernel<GemvxPolicy<4, LAYOUT_LOP3, MD_S, 1, 2, 2, 64, false, 4>>; }
   unsigned long long* dT;
   const size_t tr_words = (size_t)gx * count * nw * 8;
   CK(hipMalloc(&dT, tr_words * 8));
@@ -157,6 +173,49 @@ int main(int argc, char** argv) {
     void* params[] = {&ga};
     CK(hipLaunchKernel(reinterpret_cast<const void*>(fn), dim3(gx, count, 1), dim3(nw * 64), params, plan.lds_bytes, st));
   };
+  auto pro_launch = [&](gemvx_fn fn, int set, const void* bias) {
+    GemvxGroupArgs ga;
+    const bool pair = pro == 2 || pro == 4;
+    for (int i = 0; i < (pair ? 2 : count); ++i) {
+      fill(ga.p[i], dW[(set * count + i) % (int)dW.size()], (char*)dC2 + (size_t)(pair ? 0 : i) * N * 2, bias);
+      ga.p[i].norm_weight = dNW;
+      ga.p[i].norm_eps = 1e-5f;
+      ga.p[i].norm_inv_k = 1.f / (float)K;
+      if (pair) {               // a row group is ONE output element: N pairs
+        const int slots = nw / kw;
+        ga.p[i].n_rgb = (N + slots - 1) / slots;
+      }
+    }
+    void* params[] = {&ga};
+    CK(hipLaunchKernel(reinterpret_cast<const void*>(fn), dim3(pair ? 2 * gx : gx, pair ? 1 : count, 1), dim3(nw * 64), params, plan.lds_bytes, st));
+  };
+  if (pro >= 2 && R == 2 && !strstr(plan.name, "areg") && (size_t)count * NSETS >= 2) {
+    const char* what = pro == 2 ? "gate / up pair" : pro == 3 ? "RMSNorm in front" : "RMSNorm + gate / up pair";
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn_pro_plain), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn_pro_trace), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    const double t_pro = time_it([&](int set) { pro_launch(fn_pro_plain, set, nullptr); });
+    printf("%-44s %8.2f us  (%s; a pair streams two operators)\n", "member with the fused op, lab launch", t_pro, what);
+    const size_t words = (size_t)gx * ((pro == 2 || pro == 4) ? 2 : count) * nw * 8;
+    unsigned long long* dTp;
+    CK(hipMalloc(&dTp, words * 8));
+    CK(hipMemset(dTp, 0, words * 8));
+    for (int rep = 0; rep < 4; ++rep) pro_launch(fn_pro_trace, rep % NSETS, dTp);
+    CK(hipStreamSynchronize(st));
+    std::vector<unsigned long long> hT(words);
+    CK(hipMemcpy(hT.data(), dTp, words * 8, hipMemcpyDeviceToHost));
+    unsigned long long t0 = ~0ull;
+    for (size_t i = 0; i < hT.size(); i += 8) if (hT[i]) t0 = std::min(t0, hT[i]);
+    const char* nm[8] = {"wave start", "first weight loads issued", "activations staged + barrier", "first weights landed", "first position consumed",
+                         "last position consumed", "stored", "norm: sum of squares known"};
+    printf("time line of the member with the fused op (%s), last of 4 launches (us after the first wave's start; median [min .. p90 .. max]):\n", what);
+    for (int j : {0, 1, 7, 2, 3, 4, 5, 6}) {
+      std::vector<double> v;
+      for (size_t i = 0; i < hT.size(); i += 8) if (hT[i + j] && hT[i]) v.push_back((double)(hT[i + j] - t0) * 0.01);
+      if (v.empty()) continue;
+      std::sort(v.begin(), v.end());
+      printf("  %-30s %7.2f [%7.2f .. %7.2f .. %7.2f]   (%zu waves)\n", nm[j], v[v.size() / 2], v.front(), v[v.size() * 9 / 10], v.back(), v.size());
+    }
+  }
   if (!strstr(plan.name, "areg")) {
     lib_launch(0);
     lab_launch(fn_plain, 0, nullptr);
