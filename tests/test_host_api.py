@@ -290,3 +290,45 @@ def test_operator_workspace_is_retired_not_freed_when_a_taller_batch_needs_more(
     assert second is not first and second.numel() >= 2 * first.numel()
     assert wlib._shared_ws_retired == [first] and seen[2] == (second.data_ptr(), 6000)
     del wlib._shared_ws_retired[:]
+
+
+@pytest.mark.parametrize("bits", [1, 2, 4])
+def test_packer_word_paths_match_the_definition(bits):
+    """csrc/wqaa_pack.hip gathers a word's fields with 64-bit SWAR shifts and changes layout through byte tables; the definition is
+    the reference's `general_compress` + `interleave_weight` (run as the oracle's restatement, itself pinned by
+    tests/golden/packing_golden.npz): whole words, row tails, one row and many (threads), source bytes with garbage above the field"""
+    import ctypes
+    import wqaa_oracle as oracle
+    from bitblas_amd import lib as wlib
+    L = wlib.load_library()
+    for f in (L.wqaa_pack_weight, L.wqaa_unpack_weight):
+        f.restype = ctypes.c_int
+        f.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    L.wqaa_relayout_weight.restype = ctypes.c_int
+    L.wqaa_relayout_weight.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64] + [ctypes.c_int] * 4 + [ctypes.c_void_p]
+    rng = np.random.default_rng(bits)
+    mask = (1 << bits) - 1
+    for cols in (32, 96, 40, 24, 200, 8192):
+        if cols % (8 // bits):
+            continue
+        for rows in (1, 5, 700):
+            src = rng.integers(-128, 128, size=(rows, cols)).astype(np.int8)
+            fields = (src.astype(np.int16) & mask).astype(np.int8)
+            plain = oracle.general_compress(fields, bits)
+            out = np.empty((rows, cols * bits // 8), dtype=np.int8)
+            assert L.wqaa_pack_weight(src.ctypes.data, rows, cols, bits, wlib.LAYOUT_PLAIN, wlib.DTYPE_CODE["float16"], out.ctypes.data) == wlib.OK
+            assert np.array_equal(out.view(np.uint8), plain.view(np.uint8))
+            if (cols * bits // 8) % 4:
+                continue
+            for target in ("float16", "int8"):
+                want = np.asarray(oracle.interleave_weight(plain.copy(), bits, target)).view(np.uint8).reshape(out.shape)
+                lop3 = np.empty_like(out)
+                assert L.wqaa_pack_weight(src.ctypes.data, rows, cols, bits, wlib.LAYOUT_LOP3, wlib.DTYPE_CODE[target], lop3.ctypes.data) == wlib.OK
+                assert np.array_equal(lop3.view(np.uint8), want)
+                back = np.empty_like(src)
+                assert L.wqaa_unpack_weight(lop3.ctypes.data, rows, cols, bits, wlib.LAYOUT_LOP3, wlib.DTYPE_CODE[target], back.ctypes.data) == wlib.OK
+                assert np.array_equal(back, fields)
+                moved = np.empty_like(out)
+                assert L.wqaa_relayout_weight(out.ctypes.data, rows, out.shape[1], bits, wlib.LAYOUT_PLAIN, wlib.LAYOUT_LOP3, wlib.DTYPE_CODE[target],
+                                              moved.ctypes.data) == wlib.OK
+                assert np.array_equal(moved.view(np.uint8), want)
