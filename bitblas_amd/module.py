@@ -276,7 +276,7 @@ class Linear(nn.Module):
             if ops and ops[0] is mm.weight_compress and self.bits in (1, 2, 4):
                 # a transposed GPTQ word holds its fields lowest first, which IS the general_compress order: the reference's
                 # unpack -> compress round trip (:315-338, ops/quant_compress) returns these bytes - only the later stages (the
-                # LOP3 interleave) have anything to do.  (11008 x 4096: 65 -> 20 ms per layer on 8 host cores.)
+                # LOP3 interleave) have anything to do.  (11008 x 4096: ~250 -> ~20 ms per layer on 8 host cores; the unpack alone was 226 ms.)
                 out = qweight.cpu()
                 for op in ops[1:]:
                     out = op.forward(out)
