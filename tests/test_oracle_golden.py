@@ -172,3 +172,20 @@ def test_oracle_properties_exact():
     y0 = oracle.matmul_dequant(A, flat, source_format="uint", bit=4, scale=scale, zeros=np.full((N, K // g), 8, np.float16),
                                zeros_mode="original", group_size=g, bias=bias, out_dtype="float16")
     assert np.array_equal(y0, np.broadcast_to(bias, y0.shape))
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c", "d"])
+def test_layer_elementwise_ops_against_reference_run_vectors(tag):
+    """The decoder layer's RMSNorm, gated activation and residual add (the ops that ride in the GEMV launches): the oracle's
+    restatements against vectors produced by RUNNING the reference's `BitnetRMSNorm` class and its layer expressions
+    (oracle/gen_layer_ops_golden.py -> tests/golden/layer_ops_golden.npz).  Norm and add: bit for bit.  silu * up: numpy's exp and
+    torch's round the last fp32 bit differently on a few inputs in ten thousand - those land one float16 ulp away, nothing more."""
+    g = np.load(os.path.join(GOLDEN_DIR, "layer_ops_golden.npz"))
+    y = oracle.rms_norm_f16(g[f"norm_{tag}_x"], g[f"norm_{tag}_w"], float(g[f"norm_{tag}_eps"]))
+    assert np.array_equal(y.view(np.uint16), g[f"norm_{tag}_y"].view(np.uint16))
+    r = oracle.add_residual_f16(g[f"add_{tag}_hidden"], g[f"add_{tag}_residual"])
+    assert np.array_equal(r.view(np.uint16), g[f"add_{tag}_y"].view(np.uint16))
+    a, want = oracle.silu_mul_f16(g[f"act_{tag}_gate"], g[f"act_{tag}_up"]), g[f"act_{tag}_y"]
+    off = a.view(np.uint16) != want.view(np.uint16)
+    assert off.sum() <= max(1, a.size // 2000)
+    assert np.all(np.abs(a[off].astype(np.float64) - want[off].astype(np.float64)) <= np.abs(want[off].astype(np.float64)) * 2.0 ** -9)
