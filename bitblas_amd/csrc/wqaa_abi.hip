@@ -68,6 +68,7 @@ static void ensure_device(int dev) {
       di.ok = 1;
       gemv_init();
       gemm_init();
+      chain_init();
     } else {
       (void)hipGetLastError();
     }
@@ -528,6 +529,36 @@ int wqaa_gate_up_plan(const wqaa_matmul_desc* desc, int m, int with_norm, wqaa_p
 
 int wqaa_matmul_group_ex(const wqaa_group_item* items, const wqaa_epilogue* const* epilogues, int count, int m, void* stream) {
   return group_impl(items, epilogues, count, m, stream);
+}
+
+int wqaa_matmul_chain(const wqaa_chain_item* items, int count, int m, void* stream) {
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const void* anchor = (items && count > 0) ? (items[0].A ? items[0].A : items[0].B) : nullptr;
+  StreamDeviceScope scope(s, anchor);
+  if (!device_info().ok) {
+    set_error(WQAA_ERR_NO_DEVICE, "no HIP device visible");
+    return WQAA_ERR_NO_DEVICE;
+  }
+  int st = chain_launch(items, count, m, s);
+  if (st == WQAA_OK) g_last_error = WQAA_OK;
+  return st;
+}
+
+int wqaa_chain_plan(const wqaa_chain_item* items, int count, int m, int* launches, wqaa_plan* plan) {
+  return chain_plan(items, count, m <= 0 ? 1 : m, launches, plan);
+}
+
+int wqaa_debug_chain_status(void* stream, uint32_t* out4) {
+  if (!out4) return WQAA_ERR_BAD_DESC;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  StreamDeviceScope scope(s);
+  return chain_status(s, out4);
+}
+
+int64_t wqaa_debug_chain_trace(void* stream, uint64_t* out, int64_t max_words) {
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  StreamDeviceScope scope(s);
+  return chain_trace(s, out, max_words);
 }
 
 int wqaa_tune(const wqaa_matmul_desc* desc, int m, void* stream) {

@@ -1,0 +1,813 @@
+// wqaa_chain_kernel.h - ONE persistent launch for a chain of dependent M = 1 GEMVs (wqaa_matmul_chain): the post-attention
+// half of a decoder layer, o_proj (+ residual) -> RMSNorm -> gate / up * silu -> down_proj (+ residual), or any chain of
+// exact-product GEMV operators whose inputs are earlier operators' outputs.
+//
+// What it replaces: one launch per operator (reference: bitblas/ops/general_matmul/tilelang/dequantize/
+// gemv_dequantize_simt.py:116-262, called once per nn.Linear by integration/BitNet/modeling_bitnet.py:240-244, :839-860).
+// On MI355X every dependent launch pays ~2.85 us around a weight stream that itself runs at the memory's rate (DESIGN 3.1:
+// dispatch 0.85 + first byte 0.9 + last byte -> last store 1.1), and the WEIGHTS of the next operator do not depend on this
+// one's result - only a few KB of activations do.  So (MI355X_MICROARCH.md, rows prefetch-credit / allgather / ldsdma-fill /
+// engine-vs-launches):
+//   * one workgroup per CU, four waves: wave 0 is the LOADER.  It streams this CU's share of every operator's packed weights,
+//     operator after operator, into an LDS ring with LDS-DMA (global_load_lds_dwordx4 ... nt: 1 KiB per instruction, no
+//     VGPR, no VALU) and never waits on a dependency: when the consumers stall on an edge the ring fills up with the next
+//     operator's weights;
+//   * waves 1-3 are CONSUMERS: the exact-product decode / dot of wqaa_gemvx_kernel.h on 16-byte lane chunks read back from
+//     the ring (same lane <-> weight bytes map, same per-lane order over the chunks of a row, same wave reduction: a row's
+//     bits are the single launch's with kw = 1);
+//   * an operator's output vector crosses to every CU as 8-byte {tag, 2 x float16} granules: one write-through (sc1) store
+//     by the lane that holds the two rounded results, swept by ONE consumer wave per CU with relaxed agent-scope loads
+//     until every tag matches (cdna_hip_programming.md Guideline 16, recipe R2) and staged into the LDS layout the dots read
+//     (the RMSNorm and the residual stash ride in that pass).  No grid barrier, no fence: the data is the flag;
+//   * tags are (generation, stage): the generation lives in device memory and is bumped once per launch by workgroup 0,
+//     so a replayed hipGraph needs no memset node and stale granules of the previous launch never match.
+// Work split: tasks = pairs of output rows (one granule), a contiguous range of tasks per CU, round-robin over the three
+// consumers.  Every spin is bounded (s_memrealtime) and ends in an error code in ctl[1] + abort of the workgroup.
+#pragma once
+#include "wqaa_gemvx_kernel.h"
+
+namespace wqaa {
+
+constexpr int kChainMaxStages = 8;
+constexpr int kChainFill = 8;          // DMA instructions (1 KiB units) per fill
+constexpr int kChainLag = 6;           // fills left in flight behind the issue point: s_waitcnt vmcnt(48)
+constexpr int kChainConsumers = 3;
+constexpr int kChainStashMaxRows = 128;
+
+// LDS control block (dwords)
+enum : int {
+  CL_LANDED = 0,      // units (of the issue sequence) known to have landed
+  CL_ABORT = 1,
+  CL_GEN = 2,         // this launch's generation, CL_GEN_READY = 1 once valid
+  CL_GEN_READY = 3,
+  CL_NEXT0 = 4,       // [3] ring sequence number of each consumer's next unfinished task
+  CL_SWEEPING = 7,    // a consumer of this CU is sweeping granules: the loader thins itself
+  CL_CSTAGE0 = 8,     // [3] stage each consumer has reached
+  CL_ACT_READY = 12,  // [8] staged input of stage s is complete
+  CL_TICKET = 20,     // [8] who stages the input of stage s
+  CL_WORDS = 32
+};
+
+// error codes (ctl[1] = code | stage << 8 | wave << 16)
+enum : int { CE_LOADER_SPACE = 1, CE_LOADER_SC = 2, CE_WAIT_LANDED = 3, CE_WAIT_ACT = 4, CE_SWEEP = 5, CE_WAIT_GEN = 6, CE_WAIT_STAGE = 7 };
+
+struct ChainStage {
+  const void* A;            // in_kind 0: (K,) float16
+  const void* B[2];         // [1]: the `up` operator of a gate / up pair
+  const void* scale[2];
+  const void* zeros[2];
+  const void* bias[2];
+  const void* residual;     // (N,) float16 from the caller, or NULL
+  const void* norm_weight;  // (K,) float16: RMSNorm in front, or NULL
+  void* C;                  // (N,) float16, or NULL (only later stages read it)
+  float norm_eps, norm_inv_k;
+  int N, K, kg, gq_shift;
+  uint32_t gq_magic;
+  int nc, cpr, row_bytes;
+  int zint;
+  uint32_t flip;
+  int has_bias;
+  int in_kind;              // 0 caller's A, 1 granules of stage `src`, 2 the staged input of the previous stage
+  int src;
+  int pair;
+  int publish;              // granules: a later stage reads this output
+  int res_stage;            // -1, or j: residual = output of stage j, stashed while stage `stash_at` swept it
+  int stash_for;            // -1, or s2: while sweeping my input keep the rows stage s2 of this CU adds as its residual
+  int norm_nwv, norm_nai;   // the single launch's geometry (waves, items per thread): the order of its sum of squares
+  int gran_off;             // output granules in the workspace
+  int tasks;                // ceil(N / 2)
+  int un;                   // ring units per task: (pair ? 4 : 2) * nc
+  int sc_units;             // 1 KiB units per (operator, scale | zeros) block
+  int nsc;                  // scale / zeros units at the head of the stage's stream
+  int wait_stage;           // the stager waits until every consumer has reached this stage (its LDS input buffer is free)
+  int a_off, sa_off, sc_off, stash_off;   // LDS byte offsets
+};
+
+struct ChainArgs {
+  ChainStage st[kChainMaxStages];
+  int nstages;
+  int ring_off, ring_units;
+  int raw_off, raw_passes, parts_off;
+  int bump_stage;           // the stage after whose sweep workgroup 0 bumps the generation (-1: no edge)
+  int thin;                 // 1: one fill outstanding while a consumer of this CU sweeps
+  int sweep_depth;          // 1 or 2 passes of granule loads in flight
+  unsigned timeout_ticks;   // s_memrealtime ticks (100 MHz) a wait may take
+  unsigned long long* gran;
+  uint32_t* ctl;            // [0] generation, [1] first error
+  unsigned long long* trace;  // lab: [workgroup][wave][32] time stamps, or NULL
+};
+
+typedef __attribute__((address_space(1))) unsigned long long chain_gu64;
+typedef __attribute__((address_space(1))) unsigned int chain_gu32;
+
+// control words: volatile accesses through LDS-address-space pointers (a volatile access through a generic pointer is a FLAT
+// instruction, which counts on vmcnt - the loader's DMA counter)
+typedef __attribute__((address_space(3))) uint32_t chain_lds_u32;
+typedef __attribute__((address_space(3))) unsigned char chain_lds_u8;
+__device__ __forceinline__ uint32_t chain_lds_ld(const unsigned char* smem, int word) {
+  return *reinterpret_cast<const volatile chain_lds_u32*>((const chain_lds_u8*)smem + word * 4);
+}
+__device__ __forceinline__ void chain_lds_st(unsigned char* smem, int word, uint32_t v) {
+  *reinterpret_cast<volatile chain_lds_u32*>((chain_lds_u8*)smem + word * 4) = v;
+}
+// order this wave's LDS accesses against a control word (LDS only: a workgroup fence over every address space would wait
+// for the wave's outstanding global stores, a memory round trip per task)
+#define CHAIN_LDS_RELEASE() __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local")
+#define CHAIN_LDS_ACQUIRE() __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local")
+
+// one 1 KiB LDS-DMA unit: lane l's 16 bytes at sbase + voff land at LDS byte lds_dst + 16 * l.  M0 is saved and restored
+// (the compiler owns it); the s_nop 4 covers v_readfirstlane -> SGPR -> VMEM base, the s_nop 0 M0 -> LDS-DMA.
+__device__ __forceinline__ void chain_dma(unsigned lds_dst, unsigned voff, unsigned long long sbase) {
+  unsigned keep;
+  asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3 nt\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(voff), "s"(lds_dst), "s"(sbase)
+               : "memory");
+}
+
+__device__ __forceinline__ unsigned long long chain_uniform64(unsigned long long x) {
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)x), hi = __builtin_amdgcn_readfirstlane((unsigned)(x >> 32));
+  return ((unsigned long long)hi << 32) | lo;
+}
+
+struct ChainWave {
+  unsigned char* smem;
+  const ChainArgs* args;
+  int lane, wave, b, G;
+  unsigned timeout;
+  __device__ __forceinline__ void stamp(int i) const {
+    if (args->trace && lane == 0) args->trace[((long)b * 4 + wave) * 32 + i] = __builtin_amdgcn_s_memrealtime();
+  }
+  __device__ __forceinline__ void fail(int code, int stage) const {
+    if (lane == 0) {
+      unsigned expected = 0;
+      __hip_atomic_compare_exchange_strong((chain_gu32*)(args->ctl + 1), &expected, (unsigned)(code | (stage << 8) | (wave << 16) | (b << 20)),
+                                           __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    chain_lds_st(smem, CL_ABORT, 1u);
+  }
+  // every 32 polls: give up when the workgroup has aborted or the wait has lasted longer than the limit
+  __device__ __forceinline__ bool expired(unsigned& n, unsigned long long& t0) const {
+    __builtin_amdgcn_s_sleep(2);
+    if ((++n & 31u) != 0) return false;
+    if (chain_lds_ld(smem, CL_ABORT) != 0) return true;
+    const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+    if (t0 == 0) {
+      t0 = now;
+      return false;
+    }
+    return now - t0 > (unsigned long long)timeout;
+  }
+  // LDS word >= value
+  __device__ __forceinline__ bool wait_ge(int word, uint32_t value, int code, int stage) const {
+    unsigned n = 0;
+    unsigned long long t0 = 0;
+    while ((int)chain_lds_ld(smem, word) < (int)value) {
+      if (expired(n, t0)) {
+        fail(code, stage);
+        return false;
+      }
+    }
+    return true;
+  }
+  __device__ __forceinline__ int min_cstage() const {
+    const int a = (int)chain_lds_ld(smem, CL_CSTAGE0), c = (int)chain_lds_ld(smem, CL_CSTAGE0 + 1), d = (int)chain_lds_ld(smem, CL_CSTAGE0 + 2);
+    const int m = a < c ? a : c;
+    return m < d ? m : d;
+  }
+  __device__ __forceinline__ bool wait_cstage(int stage, int code, int at) const {
+    unsigned n = 0;
+    unsigned long long t0 = 0;
+    while (min_cstage() < stage) {
+      if (expired(n, t0)) {
+        fail(code, at);
+        return false;
+      }
+    }
+    return true;
+  }
+  __device__ __forceinline__ void task_range(const ChainStage& S, int& t0, int& t1) const {
+    t0 = (int)(((uint32_t)b * (uint32_t)S.tasks) / (uint32_t)G);            // tasks * G < 2^32 (host)
+    t1 = (int)(((uint32_t)(b + 1) * (uint32_t)S.tasks) / (uint32_t)G);
+  }
+};
+
+// ---- the loader wave ------------------------------------------------------------------------------------------------------
+template <class P>
+__device__ void chain_loader(const ChainWave& cw) {
+  const ChainArgs& args = *cw.args;
+  unsigned char* smem = cw.smem;
+  const int lane = cw.lane;
+  const int RING = args.ring_units;
+  int issued = 0;         // units issued so far (scale blocks + ring units)
+  int rseq = 0;           // ring units issued so far
+  int rpos = 0;           // rseq % RING
+  int in_fill = 0;
+  int frontier = 0;       // cached min(next task's ring sequence) over the consumers
+  int landed_pub = 0;
+  const unsigned voff_full = (unsigned)lane * 16u;
+  cw.stamp(1);
+
+  auto publish = [&](int landed) {
+    if (landed > landed_pub) {
+      landed_pub = landed;
+      chain_lds_st(smem, CL_LANDED, (uint32_t)landed);
+    }
+  };
+  auto drain = [&]() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    publish(issued);
+  };
+  auto read_frontier = [&]() {
+    const int a = (int)chain_lds_ld(smem, CL_NEXT0), c = (int)chain_lds_ld(smem, CL_NEXT0 + 1), d = (int)chain_lds_ld(smem, CL_NEXT0 + 2);
+    const int m = a < c ? a : c;
+    frontier = m < d ? m : d;
+  };
+  // after a unit: at a fill boundary leave kChainLag fills (one while a consumer sweeps) in flight and publish the rest
+  auto after_unit = [&]() {
+    ++issued;
+    if (++in_fill == kChainFill) {
+      in_fill = 0;
+      if (args.thin && chain_lds_ld(smem, CL_SWEEPING) != 0) {
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        publish(issued - kChainFill);
+      } else {
+        asm volatile("s_waitcnt vmcnt(48)" ::: "memory");
+        publish(issued - kChainFill * kChainLag);
+      }
+      static_assert(kChainFill == 8 && kChainLag == 6, "the vmcnt immediates above");
+    }
+  };
+
+  for (int s = 0; s < args.nstages; ++s) {
+    const ChainStage& S = args.st[s];
+    int t0, t1;
+    cw.task_range(S, t0, t1);
+    const int nt = t1 - t0;
+    const int n0 = 2 * t0;
+    const int nops = S.pair ? 2 : 1;
+    // ---- scale / zeros blocks of this CU's rows: contiguous in the (N, K / g) tensors, 16-byte windows aligned in
+    // absolute address (a window never straddles a page), lanes past the block re-read its first window ----
+    if (S.nsc > 0) {
+      if (s >= 2 && cw.min_cstage() < s - 1) {     // the block of stage s - 2 lives in the same LDS area
+        drain();
+        if (!cw.wait_cstage(s - 1, CE_LOADER_SC, s)) return;
+      }
+      int nr = 2 * nt;
+      if (n0 + nr > S.N) nr = S.N - n0;
+      if (nr < 0) nr = 0;
+      int blk = 0;
+      constexpr int NTENS = (P::MODE == MD_ZO || P::MODE == MD_ZR) ? 2 : 1;
+      for (int op = 0; op < nops; ++op) {
+#pragma unroll
+        for (int tn = 0; tn < NTENS; ++tn) {
+          const unsigned char* base = reinterpret_cast<const unsigned char*>(tn == 0 ? S.scale[op] : S.zeros[op]);
+          const unsigned long long beg = (unsigned long long)(base) + (unsigned long long)((long)n0 * S.kg * 2);
+          const unsigned long long a16 = chain_uniform64(beg & ~15ull);
+          const unsigned span = (unsigned)(beg - a16) + (unsigned)nr * (unsigned)S.kg * 2u;     // bytes from a16 to the block's end
+          for (int u = 0; u < S.sc_units; ++u) {
+            unsigned off = (unsigned)u * 1024u + voff_full;
+            off = off < span ? off : 0u;
+            chain_dma((unsigned)(S.sc_off + (blk * S.sc_units + u) * 1024), off, a16);
+            after_unit();
+          }
+          ++blk;
+        }
+      }
+    }
+    // ---- the weight rows of this CU's tasks, in the order the consumers read them back: one flat loop over the 1 KiB
+    // units, everything it needs in registers (the stage descriptor lives in the kernel-argument segment) ----
+    int nc = S.nc, rows_per_task = S.pair ? 4 : 2, pair = S.pair, Nrows = S.N, row_bytes = S.row_bytes;
+    unsigned long long B0 = (unsigned long long)S.B[0], B1 = (unsigned long long)S.B[S.pair ? 1 : 0];
+    unsigned voff_tail = voff_full;
+    {
+      const int chunk = (nc - 1) * 64 + lane;
+      if (chunk >= S.cpr) voff_tail = 0u;        // lanes past the row re-read the unit's first 16 bytes: they meet zero activations
+    }
+    asm volatile("" : "+s"(nc), "+s"(rows_per_task), "+s"(pair), "+s"(Nrows), "+s"(row_bytes), "+s"(B0), "+s"(B1));
+    auto row_addr = [&](int t, int r) -> unsigned long long {
+      int n = 2 * t + (pair ? (r >> 1) : r);
+      n = n < Nrows ? n : Nrows - 1;
+      const unsigned long long base = (pair && (r & 1)) ? B1 : B0;
+      return chain_uniform64(base + (unsigned long long)((long)n * row_bytes));
+    };
+    int c = 0, r = 0, t = t0;
+    unsigned long long src = row_addr(t, 0);
+    const int total_units = nt * rows_per_task * nc;
+    for (int ui = 0; ui < total_units; ++ui) {
+      if (in_fill == 0 && rseq + kChainFill > frontier + RING) {
+        read_frontier();
+        if (rseq + kChainFill > frontier + RING) {
+          drain();       // what is in flight must be published before blocking: the consumers may be waiting for it
+          unsigned n_ = 0;
+          unsigned long long t_ = 0;
+          for (;;) {
+            read_frontier();
+            if (rseq + kChainFill <= frontier + RING) break;
+            if (cw.expired(n_, t_)) {
+              cw.fail(CE_LOADER_SPACE, s);
+              return;
+            }
+          }
+        }
+      }
+      chain_dma((unsigned)(args.ring_off + rpos * 1024), c == nc - 1 ? voff_tail : voff_full, src);
+      src += 1024ull;
+      ++rseq;
+      if (++rpos == RING) rpos = 0;
+      after_unit();
+      if (++c == nc) {
+        c = 0;
+        if (++r == rows_per_task) {
+          r = 0;
+          ++t;
+        }
+        src = row_addr(t < t1 ? t : t1 - 1, r);
+      }
+    }
+  }
+  drain();
+  cw.stamp(2);
+}
+
+// ---- one lane chunk of one weight row against the staged activations: the arithmetic of wq_gemvx_kernel's `consume`,
+// MB = 1, to the letter (class accumulators over the four words, Horner, zero point through the chunk's activation sum,
+// group scale on the fp32 partial) ----
+template <class P>
+__device__ __forceinline__ void chain_chunk(const u32x4 w, const u32x4 (&av)[4 * P::PPW], const float sa, const uint32_t sbits,
+                                            const uint32_t zbits, const float zint, const uint32_t flip, float& acc) {
+  constexpr int BITS = P::BITS, NPAIR = P::NPAIR, NCLS = P::NCLS, PPW = P::PPW, MODE = P::MODE;
+  float cls[NCLS];
+#pragma unroll
+  for (int k = 0; k < NCLS; ++k) cls[k] = 0.f;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    uint32_t f[NPAIR];
+    const uint32_t ww = BITS == 1 ? (w[u] ^ flip) : w[u];
+    const uint32_t w8 = ww >> 8;
+#pragma unroll
+    for (int i = 0; i < NPAIR; ++i) {
+      constexpr uint32_t fmask = ((1u << BITS) - 1u) * 0x00010001u;
+      const int bit = BITS * i;
+      f[i] = (bit >= 8 ? w8 : ww) & (fmask << (bit & 7));
+    }
+#pragma unroll
+    for (int pp = 0; pp < PPW; ++pp) {
+      const u32x4 a = av[u * PPW + pp];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int i = pp * 4 + e;
+        const int k = ((BITS * i) & 7) / BITS;
+        cls[k] = __builtin_amdgcn_fdot2(as_h2(f[i]), as_h2(a[e]), cls[k], false);
+      }
+    }
+  }
+  float t = cls[NCLS - 1];
+#pragma unroll
+  for (int k = NCLS - 2; k >= 0; --k) t = __builtin_fmaf(t, 1.f / (float)(1 << BITS), cls[k]);
+  t *= 16777216.f;
+  float z = zint;
+  if constexpr (MODE == MD_ZO) z += (float)bits_to_half(zbits);
+  t = __builtin_fmaf(-z, sa, t);
+  if constexpr (MODE == MD_NONE) {
+    acc += t;
+  } else {
+    acc = __builtin_fmaf(t, (float)bits_to_half(sbits), acc);
+    if constexpr (MODE == MD_ZR) acc = __builtin_fmaf(-(float)bits_to_half(zbits), sa, acc);
+  }
+}
+
+// ---- staging: EPW activations (one item = the partner of one weight word of one lane chunk) -> the LDS tile in the order
+// the unpack produces + the chunk's activation sum; wq_gemvx_kernel's `item_store`, with the four partial sums of a lane
+// chunk combined here ((p0 + p1) + (p2 + p3), the order `consume` adds them in) by the four lanes that hold them ----
+template <class P>
+__device__ __forceinline__ void chain_item_store(unsigned char* smem, const ChainStage& S, int c, int u, int l, const u32x4 (&raw)[P::EPW / 8],
+                                                 bool valid, int lane) {
+  using T = typename P::T;
+  constexpr int EPW = P::EPW, PPW = P::PPW, PIECES = P::PIECES;
+  u32x4* a_lds = reinterpret_cast<u32x4*>(smem + S.a_off);
+  float* sa_lds = reinterpret_cast<float*>(smem + S.sa_off);
+  float sum = 0.f;
+  half_t el[EPW];
+#pragma unroll
+  for (int e = 0; e < EPW / 2; ++e) {
+    const half2_t h = as_h2(raw[e / 4][e % 4]);
+    el[2 * e] = h[0];
+    el[2 * e + 1] = h[1];
+    sum = __builtin_amdgcn_fdot2(h, half2_t{(half_t)1.f, (half_t)1.f}, sum, false);
+  }
+#pragma unroll
+  for (int pp = 0; pp < PPW; ++pp) {
+    u32x4 out;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const half2_t h = {el[T::src_elem(P::LAYOUT, pp * 8 + 2 * e)], el[T::src_elem(P::LAYOUT, pp * 8 + 2 * e + 1)]};
+      out[e] = valid ? as_u32(h) : 0u;
+    }
+    a_lds[((long)c * PIECES + u * PPW + pp) * 64 + l] = out;
+  }
+  // lanes 4j .. 4j + 3 hold the partials u = 0 .. 3 of one lane chunk (the callers' item order)
+  float p = valid ? sum : 0.f;
+  const float q = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, p), 0xB1, 0xF, 0xF, true));     // quad_perm [1,0,3,2]
+  p = p + q;                                                                                                                       // u even: p_u + p_(u+1)
+  const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, p), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+  p = p + r2;                                                                                                                      // lane u = 0: (p0 + p1) + (p2 + p3)
+  if ((lane & 3) == 0) sa_lds[c * 64 + l] = p;
+}
+
+// stage the items [first, first + count) (natural memory order: item i = EPW elements at element offset i * EPW) from
+// `src` (LDS raw scratch, item first at src) - `norm_r` != 0: x -> weight * half(x * r) first (the norm's two roundings)
+template <class P, bool NORM>
+__device__ __forceinline__ void chain_stage_items(unsigned char* smem, const ChainStage& S, const unsigned char* src, int first, int count, int lane,
+                                                  float norm_r) {
+  constexpr int EPW = P::EPW, IVW = EPW / 8;
+  for (int q = 0; q < count; q += 64) {
+    const int i = first + q + lane;                // count is a multiple of 64
+    const int cl = i >> 2, u = i & 3;
+    const int c = cl >> 6, l = cl & 63;
+    const bool valid = cl < S.cpr;
+    u32x4 raw[IVW];
+#pragma unroll
+    for (int v = 0; v < IVW; ++v) raw[v] = reinterpret_cast<const u32x4*>(src + (long)(q + lane) * (EPW * 2))[v];
+    if constexpr (NORM) {
+      u32x4 nw[IVW];
+#pragma unroll
+      for (int v = 0; v < IVW; ++v)
+        nw[v] = reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(S.norm_weight) + (long)(valid ? i : 0) * (EPW * 2))[v];
+#pragma unroll
+      for (int v = 0; v < IVW; ++v)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const half2_t x = as_h2(raw[v][e]);
+          const half2_t h = {(half_t)((float)x[0] * norm_r), (half_t)((float)x[1] * norm_r)};
+          raw[v][e] = as_u32(as_h2(nw[v][e]) * h);
+        }
+    }
+    chain_item_store<P>(smem, S, c, u, l, raw, valid, lane);
+  }
+}
+
+// sum x^2 of the raw vector in LDS in the order the single launch takes it (NWV waves x NAI items per thread: item idx =
+// j * threads + tid; per thread over j, per wave by the DPP ladder, across the waves in wave order)
+template <class P>
+__device__ __forceinline__ float chain_norm_rinv(unsigned char* smem, const ChainArgs& args, const ChainStage& S, int lane) {
+  constexpr int EPW = P::EPW, IVW = EPW / 8;
+  float* parts = reinterpret_cast<float*>(smem + args.parts_off);      // [slot = idx >> 6][lane]
+  const unsigned char* raw = smem + args.raw_off;
+  const int nitems = S.cpr * 4;                                        // K / EPW
+  const int nslots = (nitems + 63) >> 6;
+  for (int sl = 0; sl < nslots; ++sl) {
+    // launch-path item idx = c * 256 + u * 64 + l  <->  natural item (c * 64 + l) * 4 + u
+    const int idx = sl * 64 + lane;
+    const int c = idx >> 8, u = (idx >> 6) & 3;
+    const int cl = c * 64 + lane;
+    float part = 0.f;
+    if (cl < S.cpr) {
+      const u32x4* src = reinterpret_cast<const u32x4*>(raw + ((long)cl * 4 + u) * (EPW * 2));
+#pragma unroll
+      for (int v = 0; v < IVW; ++v) {
+        const u32x4 x = src[v];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) part = __builtin_amdgcn_fdot2(as_h2(x[e]), as_h2(x[e]), part, false);
+      }
+    }
+    parts[sl * 64 + lane] = part;
+  }
+  float tot = 0.f;
+  for (int w = 0; w < S.norm_nwv; ++w) {
+    float ssq = 0.f;
+    for (int j = 0; j < S.norm_nai; ++j) {
+      const int sl = j * S.norm_nwv + w;
+      ssq += sl < nslots ? parts[sl * 64 + lane] : 0.f;
+    }
+    const float ws = wave_sum_l63(ssq);
+    const float wsum = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ws), 63));
+    tot = w == 0 ? wsum : tot + wsum;
+  }
+  return rsqrtf(tot * S.norm_inv_k + S.norm_eps);
+}
+
+// ---- the consumer waves ---------------------------------------------------------------------------------------------------
+template <class P, int ROWS>
+__device__ __forceinline__ void chain_task(const ChainWave& cw, const ChainStage& S, int s, int t, int n0, int rseq, uint32_t tag) {
+  constexpr int PPW = P::PPW, PIECES = P::PIECES, MODE = P::MODE;
+  constexpr bool PAIR = ROWS == 4;
+  constexpr int NTENS = (MODE == MD_ZO || MODE == MD_ZR) ? 2 : 1;
+  const ChainArgs& args = *cw.args;
+  unsigned char* smem = cw.smem;
+  const int lane = cw.lane;
+  const int RING = args.ring_units;
+  const u32x4* a_lds = reinterpret_cast<const u32x4*>(smem + S.a_off);
+  const float* sa_lds = reinterpret_cast<const float*>(smem + S.sa_off);
+  // output elements of the task, the operator and scale block of each streamed row
+  int elem[ROWS], op[ROWS];
+  int sc_base[ROWS], z_base[ROWS];
+#pragma unroll
+  for (int r = 0; r < ROWS; ++r) {
+    int e = 2 * t + (PAIR ? (r >> 1) : r);
+    e = e < S.N ? e : S.N - 1;
+    elem[r] = e;
+    op[r] = PAIR ? (r & 1) : 0;
+    if constexpr (MODE != MD_NONE) {
+      const unsigned long long sb = (unsigned long long)(S.scale[op[r]]) + (unsigned long long)((long)n0 * S.kg * 2);
+      sc_base[r] = S.sc_off + (op[r] * NTENS) * S.sc_units * 1024 + (int)(sb & 15ull) + (e - n0) * S.kg * 2;
+      if constexpr (NTENS == 2) {
+        const unsigned long long zb = (unsigned long long)(S.zeros[op[r]]) + (unsigned long long)((long)n0 * S.kg * 2);
+        z_base[r] = S.sc_off + (op[r] * NTENS + 1) * S.sc_units * 1024 + (int)(zb & 15ull) + (e - n0) * S.kg * 2;
+      }
+    }
+  }
+  // bias / the caller's residual: asked for before the dots (every lane the same address: one request)
+  float resv[ROWS];
+  half_t biasv[ROWS];
+#pragma unroll
+  for (int r = 0; r < ROWS; ++r) {
+    resv[r] = 0.f;
+    biasv[r] = (half_t)0.f;
+    if (S.has_bias) biasv[r] = reinterpret_cast<const half_t*>(S.bias[op[r]])[elem[r]];
+    if constexpr (!PAIR) {
+      if (S.residual) resv[r] = (float)reinterpret_cast<const half_t*>(S.residual)[elem[r]];
+      else if (S.res_stage >= 0) resv[r] = (float)reinterpret_cast<const half_t*>(smem + S.stash_off)[elem[r] - n0];
+    }
+  }
+  const float zint = (float)S.zint;
+  float acc[ROWS];
+#pragma unroll
+  for (int r = 0; r < ROWS; ++r) acc[r] = 0.f;
+  int upos = rseq % RING;                          // ring slot of (row 0, chunk 0)
+  int rp[ROWS];
+#pragma unroll
+  for (int r = 0; r < ROWS; ++r) {
+    rp[r] = upos + r * S.nc;
+    while (rp[r] >= RING) rp[r] -= RING;
+  }
+  for (int c = 0; c < S.nc; ++c) {
+    const int chunk = c * 64 + lane;
+    const bool cvalid = chunk < S.cpr;
+    int gi = 0;
+    if constexpr (MODE != MD_NONE) {
+      const int ch = cvalid ? chunk : 0;           // (the single launch clamps the chunk before it takes the group)
+      gi = S.gq_shift >= 0 ? (ch >> S.gq_shift) : (int)__umulhi((uint32_t)ch, S.gq_magic);
+    }
+    u32x4 av[4 * PPW];
+#pragma unroll
+    for (int j = 0; j < 4 * PPW; ++j) av[j] = a_lds[((long)c * PIECES + j) * 64 + lane];
+    const float sa = sa_lds[c * 64 + lane];
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+      const u32x4 w = *reinterpret_cast<const u32x4*>(smem + args.ring_off + rp[r] * 1024 + lane * 16);
+      uint32_t sb = 0, zb = 0;
+      if constexpr (MODE != MD_NONE) sb = *reinterpret_cast<const uint16_t*>(smem + sc_base[r] + gi * 2);
+      if constexpr (NTENS == 2) zb = *reinterpret_cast<const uint16_t*>(smem + z_base[r] + gi * 2);
+      chain_chunk<P>(w, av, sa, sb, zb, zint, S.flip, acc[r]);
+      if (++rp[r] == RING) rp[r] = 0;
+    }
+  }
+  float tot[ROWS];
+#pragma unroll
+  for (int r = 0; r < ROWS; ++r) tot[r] = wave_sum_l63(acc[r]);
+  if (lane == 63) {
+    half_t out[2];
+    const int e0 = 2 * t;
+    const bool two = e0 + 1 < S.N;
+    if constexpr (PAIR) {
+      // both projections' results (+ their biases) rounded to float16 as their own launches would store them, then
+      // torch's F.silu(gate) * up (wq_gemvx_kernel, PAIR members)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        half_t h[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          h[q] = (half_t)tot[2 * j + q];
+          if (S.has_bias) h[q] = h[q] + biasv[2 * j + q];
+        }
+        out[j] = silu_mul_h(h[0], h[1]);
+      }
+    } else {
+      // result (+ bias) rounded to float16, then + residual in fp32, rounded again (wq_gemvx_kernel, PRO members)
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        half_t h = (half_t)tot[r];
+        if (S.has_bias) h = h + biasv[r];
+        if (S.residual || S.res_stage >= 0) h = (half_t)((float)h + resv[r]);
+        out[r] = h;
+      }
+    }
+    if (!two) out[1] = (half_t)0.f;
+    const uint32_t bits = as_u32(half2_t{out[0], out[1]});
+    if (S.C) {
+      if (two) *reinterpret_cast<uint32_t*>(reinterpret_cast<half_t*>(S.C) + e0) = bits;
+      else reinterpret_cast<half_t*>(S.C)[e0] = out[0];
+    }
+    if (S.publish)
+      __hip_atomic_store((chain_gu64*)(args.gran + S.gran_off + t), ((unsigned long long)tag << 32) | bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+template <class P>
+__device__ void chain_consumer(const ChainWave& cw) {
+  constexpr int EPW = P::EPW, IVW = EPW / 8, E = P::E;
+  constexpr int IPP = 2048 / EPW;                 // items per sweep pass (1024 granules = 2048 elements)
+  const ChainArgs& args = *cw.args;
+  unsigned char* smem = cw.smem;
+  const int lane = cw.lane;
+  const int cons = cw.wave - 1;
+  int rseq_base = 0, useq_base = 0, gt_base = 0;  // of the current stage, for this CU
+  uint32_t gen = 0;
+  bool have_gen = false;
+  auto need_gen = [&](int s) -> bool {
+    if (have_gen) return true;
+    if (!cw.wait_ge(CL_GEN_READY, 1u, CE_WAIT_GEN, s)) return false;
+    gen = chain_lds_ld(smem, CL_GEN);
+    have_gen = true;
+    return true;
+  };
+  if (cons == 0) {
+    // the workgroup's generation: ONE agent-scope load, shared through LDS (every tag of this launch derives from it)
+    const uint32_t g = __hip_atomic_load((chain_gu32*)args.ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    chain_lds_st(smem, CL_GEN, g);
+    CHAIN_LDS_RELEASE();
+    chain_lds_st(smem, CL_GEN_READY, 1u);
+    gen = g;
+    have_gen = true;
+  }
+
+  for (int s = 0; s < args.nstages; ++s) {
+    const ChainStage& S = args.st[s];
+    int t0, t1;
+    cw.task_range(S, t0, t1);
+    const int nt = t1 - t0;
+    const int n0 = 2 * t0;
+    chain_lds_st(smem, CL_CSTAGE0 + cons, (uint32_t)s);
+    // ---- the stage's input: staged once per CU, by the first consumer to get here ----
+    if (S.in_kind != 2) {
+      unsigned ticket = 0;
+      if (lane == 0) ticket = __hip_atomic_fetch_add(reinterpret_cast<uint32_t*>(smem) + CL_TICKET + s, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      ticket = __builtin_amdgcn_readfirstlane(ticket);
+      if (ticket == 0) {
+        cw.stamp(4 + 3 * s);
+        // the LDS tile of this input generation was read by the stages two generations back
+        if (S.wait_stage > 0 && !cw.wait_cstage(S.wait_stage, CE_WAIT_STAGE, s)) return;
+        const int npass = (S.nc * 64 * E + 2047) / 2048;          // passes that cover the nc lane chunks (zero beyond K)
+        const bool norm = S.norm_weight != nullptr;
+        if (S.in_kind == 0) {
+          // the caller's vector: plain loads, through the raw scratch only when the norm needs the whole row first
+          const unsigned char* A = reinterpret_cast<const unsigned char*>(S.A);
+          constexpr int IPL = IPP / 64;                            // items per lane and pass
+          for (int p = 0; p < npass; p += 2) {                     // two passes per memory round trip
+            u32x4 x[2][IPL][IVW];
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+              for (int q = 0; q < IPL; ++q) {
+                const int i = (p + h) * IPP + q * 64 + lane;
+                const bool valid = (i >> 2) < S.cpr;                 // (also false for the whole pass p + 1 == npass)
+#pragma unroll
+                for (int v = 0; v < IVW; ++v) x[h][q][v] = reinterpret_cast<const u32x4*>(A + (long)(valid ? i : 0) * (EPW * 2))[v];
+              }
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              if (p + h >= npass) break;
+              unsigned char* rawp = smem + args.raw_off + (norm ? p + h : 0) * 4096;
+#pragma unroll
+              for (int q = 0; q < IPL; ++q)
+#pragma unroll
+                for (int v = 0; v < IVW; ++v) reinterpret_cast<u32x4*>(rawp + (long)(q * 64 + lane) * (EPW * 2))[v] = x[h][q][v];
+              if (!norm) chain_stage_items<P, false>(smem, S, rawp, (p + h) * IPP, IPP, lane, 0.f);
+            }
+          }
+        } else {
+          // granules of stage S.src: 16 relaxed agent-scope 8-byte loads per lane and pass, re-read until every tag matches
+          if (!need_gen(s)) return;
+          const uint32_t tag = gen * 16u + (uint32_t)S.src + 1u;
+          const int ng = S.K / 2;
+          const chain_gu64* g = (const chain_gu64*)(args.gran + args.st[S.src].gran_off);
+          if (args.thin) chain_lds_st(smem, CL_SWEEPING, 1u);
+          // the rows a later stage of this CU adds as its residual (the output of stage S.src): kept as they pass
+          int stash_n0 = 0, stash_nr = 0, stash_off = 0;
+          if (S.stash_for >= 0) {
+            const ChainStage& S2 = args.st[S.stash_for];
+            int u0, u1;
+            cw.task_range(S2, u0, u1);
+            stash_n0 = 2 * u0;
+            stash_nr = 2 * (u1 - u0);
+            if (stash_n0 + stash_nr > S2.N) stash_nr = S2.N - stash_n0;
+            stash_off = S2.stash_off;
+          }
+          unsigned long long x0[16], x1[16];
+          auto load_pass = [&](int p, unsigned long long (&x)[16]) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+              const int gi = p * 1024 + k * 64 + lane;
+              x[k] = gi < ng ? __hip_atomic_load(g + gi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ((unsigned long long)tag << 32);
+            }
+          };
+          const int npl = (ng + 1023) / 1024;                      // passes that have granules to load
+          if (npl > 0) load_pass(0, x0);
+          for (int p = 0; p < npass; ++p) {
+            unsigned char* rawp = smem + args.raw_off + (norm ? p : 0) * 4096;
+            if (p < npl) {
+              if (args.sweep_depth > 1 && p + 1 < npl) load_pass(p + 1, x1);
+              unsigned n_ = 0;
+              unsigned long long t_ = 0;
+              for (;;) {
+                bool ok = true;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) ok &= (uint32_t)(x0[k] >> 32) == tag;
+                if (__all(ok)) break;
+                if (cw.expired(n_, t_)) {
+                  cw.fail(CE_SWEEP, s);
+                  return;
+                }
+                load_pass(p, x0);
+              }
+#pragma unroll
+              for (int k = 0; k < 16; ++k) reinterpret_cast<uint32_t*>(rawp)[k * 64 + lane] = (uint32_t)x0[k];
+              for (int i = lane; i < stash_nr; i += 64) {
+                const int n = stash_n0 + i - p * 2048;
+                if (n >= 0 && n < 2048) reinterpret_cast<uint16_t*>(smem + stash_off)[i] = reinterpret_cast<const uint16_t*>(rawp)[n];
+              }
+              if (args.sweep_depth > 1 && p + 1 < npl) {
+#pragma unroll
+                for (int k = 0; k < 16; ++k) x0[k] = x1[k];
+              } else if (p + 1 < npl) {
+                load_pass(p + 1, x0);
+              }
+            }
+            if (!norm) chain_stage_items<P, false>(smem, S, rawp, p * IPP, IPP, lane, 0.f);
+          }
+          if (args.thin) chain_lds_st(smem, CL_SWEEPING, 0u);
+          // every workgroup of this launch has read the generation by now (its granules are here): the next launch's
+          if (s == args.bump_stage && cw.b == 0 && lane == 0)
+            __hip_atomic_store((chain_gu32*)args.ctl, gen + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (norm) {
+          const float r = chain_norm_rinv<P>(smem, args, S, lane);
+          for (int p = 0; p < npass; ++p) chain_stage_items<P, true>(smem, S, smem + args.raw_off + p * 4096, p * IPP, IPP, lane, r);
+        }
+        CHAIN_LDS_RELEASE();
+        chain_lds_st(smem, CL_ACT_READY + s, 1u);
+        cw.stamp(5 + 3 * s);
+      } else {
+        if (!cw.wait_ge(CL_ACT_READY + s, 1u, CE_WAIT_ACT, s)) return;
+      }
+      CHAIN_LDS_ACQUIRE();
+    }
+    // ---- this consumer's tasks of the stage ----
+    uint32_t tag = 0;
+    if (S.publish) {
+      if (!need_gen(s)) return;
+      tag = gen * 16u + (uint32_t)s + 1u;
+    }
+    int k = cons - gt_base % kChainConsumers;
+    if (k < 0) k += kChainConsumers;
+    const int need_base = useq_base + S.nsc;
+    for (; k < nt; k += kChainConsumers) {
+      const int rseq = rseq_base + k * S.un;
+      if (!cw.wait_ge(CL_LANDED, (uint32_t)(need_base + (k + 1) * S.un), CE_WAIT_LANDED, s)) return;
+      CHAIN_LDS_ACQUIRE();
+      if (S.pair) chain_task<P, 4>(cw, S, s, t0 + k, n0, rseq, tag);
+      else chain_task<P, 2>(cw, S, s, t0 + k, n0, rseq, tag);
+      // the ring slots of this task are free: the next unfinished task of this consumer starts here (a later stage's
+      // first one is not known yet - the end of this stage's units is a safe lower bound)
+      int next = rseq + kChainConsumers * S.un;
+      if (k + kChainConsumers >= nt) next = rseq_base + nt * S.un;
+      CHAIN_LDS_RELEASE();
+      chain_lds_st(smem, CL_NEXT0 + cons, (uint32_t)next);
+    }
+    // (also when no task of this stage fell to this consumer: its frontier still moves past the stage)
+    chain_lds_st(smem, CL_NEXT0 + cons, (uint32_t)(rseq_base + nt * S.un));
+    cw.stamp(6 + 3 * s);
+    gt_base += nt;
+    rseq_base += nt * S.un;
+    useq_base += S.nsc + nt * S.un;
+  }
+  chain_lds_st(smem, CL_NEXT0 + cons, 0x7fffffffu);
+  chain_lds_st(smem, CL_CSTAGE0 + cons, (uint32_t)(args.nstages + 1));
+}
+
+template <int BITS, int LAYOUT, int MODE>
+__global__ void __launch_bounds__(256) wq_chain_kernel(const ChainArgs args) {
+  using P = GemvxPolicy<BITS, LAYOUT, MODE, 1, 2, 2>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int tid = threadIdx.x;
+  ChainWave cw;
+  cw.smem = smem_raw;
+  cw.args = &args;
+  cw.lane = tid & 63;
+  cw.wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  cw.b = (int)blockIdx.x;
+  cw.G = (int)gridDim.x;
+  cw.timeout = args.timeout_ticks;
+  if (tid < CL_WORDS) reinterpret_cast<uint32_t*>(smem_raw)[tid] = 0u;
+  __syncthreads();
+  cw.stamp(0);
+  if (cw.wave == 0) chain_loader<P>(cw);
+  else chain_consumer<P>(cw);
+  cw.stamp(3);
+}
+
+typedef void (*chain_fn)(const ChainArgs);
+chain_fn pick_chain(int bits, int layout, int mode);
+
+}  // namespace wqaa

@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def declared_functions():
     text = open(os.path.join(ROOT, "include", "wqaa.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    names = re.findall(r"^\s*(?:const\s+)?(?:void|int|uint64_t|char\s*\*|const char\s*\*)\s*\*?\s*(\w+)\s*\(", text, flags=re.M)
+    names = re.findall(r"^\s*(?:const\s+)?(?:void|int|int64_t|uint64_t|char\s*\*|const char\s*\*)\s*\*?\s*(\w+)\s*\(", text, flags=re.M)
     return sorted(set(names))
 
 
@@ -39,7 +39,7 @@ def test_init_is_idempotent_and_error_channel_works():
     L = wlib.load_library()
     L.init()
     L.init()
-    assert L.wqaa_abi_version() == 2
+    assert L.wqaa_abi_version() == 3
     d = wlib.make_desc(N=64, K=64, a_dtype=wlib.F16, w_format=wlib.W_UINT, w_bits=4, out_dtype=wlib.F16)
     d.struct_size = 4  # wrong ABI size must be refused
     assert L.wqaa_matmul(ctypes.byref(d), 1, 1, None, None, None, None, 1, 1, None) == wlib.ERR_BAD_DESC

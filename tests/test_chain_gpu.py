@@ -1,0 +1,196 @@
+"""wqaa_matmul_chain (include/wqaa.h; csrc/wqaa_chain_kernel.h): a chain of dependent M = 1 GEMVs - the post-attention half of
+a decoder layer, o_proj (+ residual) -> RMSNorm -> gate / up * silu -> down_proj (+ residual), the reference's
+integration/BitNet/modeling_bitnet.py:240-244, :839-860 - as ONE persistent launch.
+
+The chain is DEFINED as the launches it stands for (`Matmul.forward_ex`, `matmul_gate_up`), so every stage's output is
+checked bit for bit against those launches fed the same inputs (a whole-chain tolerance would hide a wrong sub-stage), over
+formats, ragged shapes, repeated launches (the generation counter that replaces a memset between replays), a captured
+hipGraph, and against the oracle's restatement of the layer at the exact-product members' tolerance."""
+import numpy as np
+import pytest
+import torch
+
+import bitblas_amd as bitblas
+import wqaa_oracle as oracle
+from bitblas_amd.chain import ChainStep, chain_plan, chain_status, matmul_chain
+from helpers import _to_dev, assert_fp_parity, make_case
+
+pytestmark = pytest.mark.gpu
+
+
+def build(case):
+    mm = bitblas.Matmul(case["config"], enable_tuning=False)
+    W = mm.weight_transform(torch.from_numpy(case["codes"])).cuda()
+    w = (W, _to_dev(case["scale"], "cuda"), _to_dev(case["zeros"], "cuda"), _to_dev(case["bias"], "cuda"))
+    return mm, w
+
+
+def layer(H, I, wd="int4", g=128, zm=None, bias=False, seed=0, scale_mul=0.03):
+    kw = dict(W_dtype=wd, group_size=g, with_scaling=True, with_zeros=zm is not None, zeros_mode=zm or "original", with_bias=bias,
+              scale_mul=scale_mul)
+    cases = dict(o=make_case(1, H, H, seed=seed + 1, **kw), gate=make_case(1, I, H, seed=seed + 2, **kw),
+                 up=make_case(1, I, H, seed=seed + 3, **kw), down=make_case(1, H, I, seed=seed + 4, **kw))
+    ops = {k: build(c) for k, c in cases.items()}
+    rng = np.random.default_rng(seed)
+    attn = torch.from_numpy((rng.random((1, H), dtype=np.float32) - 0.5).astype(np.float16)).cuda()
+    x = torch.from_numpy((rng.random((1, H), dtype=np.float32) - 0.5).astype(np.float16)).cuda()
+    nw = torch.from_numpy((1.0 + (rng.random(H, dtype=np.float32) - 0.5) * 0.2).astype(np.float16)).cuda()
+    return cases, ops, attn, x, nw
+
+
+def by_launches(ops, attn, x, nw, eps):
+    (o, wo), (g, wg), (u, wu), (d, wd) = ops["o"], ops["gate"], ops["up"], ops["down"]
+    h = o.forward_ex(attn, wo[0], scale=wo[1], zeros=wo[2], bias=wo[3], residual=x)
+    act = bitblas.matmul_gate_up(g, u, h, wg, wu, norm=(nw, eps))
+    out = d.forward_ex(act, wd[0], scale=wd[1], zeros=wd[2], bias=wd[3], residual=h)
+    return h, act, out
+
+
+def tail_steps(ops, attn, x, nw, eps, keep=True):
+    (o, wo), (g, wg), (u, wu), (d, wd) = ops["o"], ops["gate"], ops["up"], ops["down"]
+    return [ChainStep(o, wo, attn, residual=x, output=None if keep else False),
+            ChainStep(g, wg, 0, norm=(nw, eps), up_op=u, up_weights=wu, output=None if keep else False),
+            ChainStep(d, wd, 1, residual=0)]
+
+
+def assert_clean():
+    st = chain_status()
+    assert st["error"] == 0, f"a fused chain launch gave up: {st}"
+
+
+LAYERS = [  # (hidden, intermediate, W_dtype, group, zeros_mode, bias)
+    (4096, 11008, "int4", 128, None, False),          # Llama-2-7B, BASELINE c2's format
+    (1024, 2048, "int4", 128, None, False),
+    (2048, 5632, "uint4", 128, "original", True),     # K = 5632: a ragged last lane chunk
+    (1536, 4096, "uint4", 64, "rescale", False),
+    (1024, 3072, "int2", 128, None, True),
+    (1056, 2048, "int4", -1, None, False),            # 528 tasks over 256 CUs: uneven ranges; one group per row
+]
+
+
+@pytest.mark.parametrize("H,I,wd,g,zm,bias", LAYERS)
+def test_decoder_tail_bit_for_bit(H, I, wd, g, zm, bias):
+    if H % (128 // int(wd[-1])) or I % (128 // int(wd[-1])):
+        pytest.skip("K must be a multiple of the lane chunk")
+    cases, ops, attn, x, nw = layer(H, I, wd, g, zm, bias, seed=H + I)
+    eps = 1e-5
+    steps = tail_steps(ops, attn, x, nw, eps)
+    plan = chain_plan(steps)
+    assert plan["launches"] == 1 and plan["plan"]["name"].startswith("chain_m1_"), plan
+    want = by_launches(ops, attn, x, nw, eps)
+    got = matmul_chain(steps)
+    torch.cuda.synchronize()
+    assert_clean()
+    for name, a, b in zip(("o_proj + x", "silu(gate) * up", "down_proj + h"), got, want):
+        assert torch.equal(a, b), f"{name}: {int((a != b).sum())} of {a.numel()} elements differ from the launch's"
+    # intermediate outputs not stored: the same final bits
+    got2 = matmul_chain(tail_steps(ops, attn, x, nw, eps, keep=False))
+    torch.cuda.synchronize()
+    assert_clean()
+    assert got2[0] is None and got2[1] is None and torch.equal(got2[2], want[2])
+
+
+def test_decoder_tail_against_the_oracle():
+    H, I = 1024, 2048
+    cases, ops, attn, x, nw = layer(H, I, seed=5)
+    eps = 1e-5
+    got = matmul_chain(tail_steps(ops, attn, x, nw, eps))
+    torch.cuda.synchronize()
+    assert_clean()
+
+    def exact(c, A):
+        return oracle.matmul_dequant_exact(A, c["codes"], source_format=c["source_format"], bit=c["bit"], scale=c["scale"], zeros=c["zeros"],
+                                           zeros_mode=c["zeros_mode"], group_size=c["g"], bias=c["bias"], out_dtype="float16")
+    h = oracle.add_residual_f16(exact(cases["o"], attn.cpu().numpy()), x.cpu().numpy())
+    assert_fp_parity(got[0].cpu().numpy(), h, rtol=1e-3, atol_frac=6e-4)
+    hn = oracle.rms_norm_f16(got[0].cpu().numpy(), nw.cpu().numpy(), eps)
+    act = oracle.silu_mul_f16(exact(cases["gate"], hn), exact(cases["up"], hn))
+    assert_fp_parity(got[1].cpu().numpy(), act.astype(np.float32), rtol=4e-3, atol_frac=2e-3)
+    out = oracle.add_residual_f16(exact(cases["down"], got[1].cpu().numpy()), got[0].cpu().numpy())
+    assert_fp_parity(got[2].cpu().numpy(), out, rtol=1e-3, atol_frac=6e-4)
+
+
+def test_repeated_launches_and_graph_replay():
+    """no memset between launches: the generation counter in the stream's scratch makes every launch's tags new"""
+    cases, ops, attn, x, nw = layer(1024, 2048, seed=11)
+    eps = 1e-5
+    want = by_launches(ops, attn, x, nw, eps)
+    steps = tail_steps(ops, attn, x, nw, eps, keep=False)
+    out = torch.empty_like(want[2])
+    steps[2].output = out
+    gen0 = None
+    for i in range(5):
+        out.zero_()
+        matmul_chain(steps)
+        torch.cuda.synchronize()
+        st = chain_status()
+        assert st["error"] == 0, st
+        gen0 = st["generation"] if gen0 is None else gen0
+        assert st["generation"] == gen0 + i
+        assert torch.equal(out, want[2])
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        matmul_chain(steps)                      # the stream's scratch is allocated outside capture
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            matmul_chain(steps)
+            matmul_chain(steps)                  # two chains back to back in one graph
+        for _ in range(4):
+            out.zero_()
+            g.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(out, want[2])
+        assert chain_status()["error"] == 0
+    # new inputs through the same chain
+    x2 = (x * 0.5).contiguous()
+    want2 = by_launches(ops, attn, x2, nw, eps)
+    steps2 = tail_steps(ops, attn, x2, nw, eps)
+    got2 = matmul_chain(steps2)
+    torch.cuda.synchronize()
+    assert all(torch.equal(a, b) for a, b in zip(got2, want2))
+
+
+def test_shared_input_and_longer_chains():
+    """q / k / v-like steps that read ONE vector through one norm share the staged tile; a chain may continue into the next
+    layer's projections (4+ stages: the LDS tiles and scale areas rotate)"""
+    H, I = 1024, 2048
+    cases, ops, attn, x, nw = layer(H, I, seed=21)
+    eps = 1e-5
+    h, act, out = by_launches(ops, attn, x, nw, eps)
+    qkv = [build(make_case(1, n, H, W_dtype="int4", group_size=128, with_scaling=True, seed=100 + i, scale_mul=0.03)) for i, n in enumerate((1024, 512, 512))]
+    nw2 = (nw * 1.1).to(torch.float16).contiguous()
+    want_qkv = [op.forward_ex(out, w[0], scale=w[1], norm=(nw2, eps)) for op, w in qkv]
+    steps = tail_steps(ops, attn, x, nw, eps) + [ChainStep(op, w, 2, norm=(nw2, eps)) for op, w in qkv]
+    plan = chain_plan(steps)
+    assert plan["launches"] == 1, plan
+    got = matmul_chain(steps)
+    torch.cuda.synchronize()
+    assert_clean()
+    for a, b in zip(got, [h, act, out] + want_qkv):
+        assert torch.equal(a, b)
+    # a chain that starts with the norm on the caller's vector, three operators on one staged tile
+    steps = [ChainStep(op, w, out, norm=(nw2, eps)) for op, w in qkv]
+    got = matmul_chain(steps)
+    torch.cuda.synchronize()
+    assert_clean()
+    for a, b in zip(got, want_qkv):
+        assert torch.equal(a, b)
+
+
+def test_unfused_chains_run_as_launches():
+    """m = 2, or a chain the persistent member refuses: the same call, the launches' results"""
+    H, I = 1024, 2048
+    kw = dict(W_dtype="int4", group_size=128, with_scaling=True, scale_mul=0.03)
+    o = build(make_case(2, H, H, seed=1, **kw))
+    d = build(make_case(2, H, H, seed=2, **kw))
+    rng = np.random.default_rng(0)
+    a = torch.from_numpy((rng.random((2, H), dtype=np.float32) - 0.5).astype(np.float16)).cuda()
+    steps = [ChainStep(o[0], o[1], a, residual=a), ChainStep(d[0], d[1], 0, residual=0, output=None)]
+    assert chain_plan(steps)["launches"] == 2
+    got = matmul_chain(steps)
+    h = o[0].forward_ex(a, o[1][0], scale=o[1][1], residual=a)
+    want = d[0].forward_ex(h, d[1][0], scale=d[1][1], residual=h)
+    torch.cuda.synchronize()
+    assert torch.equal(got[0], h) and torch.equal(got[1], want)

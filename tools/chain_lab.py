@@ -1,0 +1,127 @@
+"""Lab for wqaa_matmul_chain (csrc/wqaa_chain_kernel.h): the post-attention half of a Llama-2-7B decoder layer at M = 1,
+o_proj (+ x) -> RMSNorm -> gate / up * silu -> down_proj (+ h), as ONE persistent launch against the three launches it stands
+for (forward_ex, matmul_gate_up, forward_ex), hipGraph replays over rotating weight sets; bit-compared; with the in-kernel
+time line of one traced launch (s_memrealtime stamps per wave: loader first DMA / stream done, per stage stager start / tile
+ready / tasks done).
+    python tools/chain_lab.py [--layers 6] [--reps 5]      # one JSON line per variant + the time line table"""
+import argparse, json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+import bitblas_amd as bitblas
+from bitblas_amd.chain import ChainStep, chain_plan, chain_status, chain_trace, matmul_chain
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--layers", type=int, default=6)
+ap.add_argument("--reps", type=int, default=5)
+ap.add_argument("--hidden", type=int, default=4096)
+ap.add_argument("--inter", type=int, default=11008)
+ap.add_argument("--no-trace", action="store_true")
+args = ap.parse_args()
+dev = torch.device("cuda", 0)
+gen = torch.Generator(device=dev); gen.manual_seed(1)
+H, I, G = args.hidden, args.inter, 128
+
+
+def op(N, K):
+    return bitblas.Matmul(bitblas.MatmulConfig(M=1, N=N, K=K, A_dtype="float16", W_dtype="int4", out_dtype="float16", accum_dtype="float16",
+                                               group_size=G, with_scaling=True), enable_tuning=False)
+
+
+def lin(o):
+    return (torch.randint(-128, 128, (o.N, o.K // 2), dtype=torch.int8, device=dev, generator=gen),
+            (torch.rand((o.N, o.K // G), device=dev, generator=gen) * 0.02 * 0.04).to(torch.float16))
+
+
+o_op, g_op, d_op = op(H, H), op(I, H), op(H, I)
+layers = [dict(o=lin(o_op), g=lin(g_op), u=lin(g_op), d=lin(d_op),
+               nw=(1.0 + (torch.rand(H, device=dev, generator=gen) - 0.5) * 0.2).to(torch.float16)) for _ in range(args.layers)]
+attn = (torch.rand((1, H), device=dev, generator=gen) - 0.5).to(torch.float16)
+x0 = (torch.rand((1, H), device=dev, generator=gen) - 0.5).to(torch.float16)
+eps = 1e-5
+hs = [torch.empty((1, H), dtype=torch.float16, device=dev) for _ in range(args.layers)]
+acts = [torch.empty((1, I), dtype=torch.float16, device=dev) for _ in range(args.layers)]
+outs = [torch.empty((1, H), dtype=torch.float16, device=dev) for _ in range(args.layers)]
+
+
+def run_launches():
+    x = x0
+    for L, h, a, o in zip(layers, hs, acts, outs):
+        o_op.forward_ex(attn, L["o"][0], scale=L["o"][1], residual=x, output=h)
+        bitblas.matmul_gate_up(g_op, g_op, h, L["g"], L["u"], output=a, norm=(L["nw"], eps))
+        d_op.forward_ex(a, L["d"][0], scale=L["d"][1], residual=h, output=o)
+        x = o
+    return x
+
+
+def steps_of(L, x, h=None, a=None, o=None):
+    return [ChainStep(o_op, L["o"], attn, residual=x, output=h if h is not None else False),
+            ChainStep(g_op, L["g"], 0, norm=(L["nw"], eps), up_op=g_op, up_weights=L["u"], output=a if a is not None else False),
+            ChainStep(d_op, L["d"], 1, residual=0, output=o)]
+
+
+chs, cas, cos = [torch.empty_like(t) for t in hs], [torch.empty_like(t) for t in acts], [torch.empty_like(t) for t in outs]
+
+
+def run_chain(keep):
+    x = x0
+    for i, L in enumerate(layers):
+        matmul_chain(steps_of(L, x, chs[i] if keep else None, cas[i] if keep else None, cos[i]))
+        x = cos[i]
+    return x
+
+
+def graph_us(fn):
+    fn(); torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        fn()
+    g.replay(); torch.cuda.synchronize()
+    per = []
+    for _ in range(args.reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); g.replay(); e1.record(); e1.synchronize()
+        per.append(e0.elapsed_time(e1) * 1e3 / args.layers)
+    return per
+
+
+print(json.dumps({"plan": chain_plan(steps_of(layers[0], x0, chs[0], cas[0], cos[0]))}), flush=True)
+run_launches(); torch.cuda.synchronize()
+run_chain(True); torch.cuda.synchronize()
+st = chain_status()
+same = [bool(torch.equal(a, b)) for a, b in zip(hs + acts + outs, chs + cas + cos)]
+print(json.dumps({"status": st, "bit_identical_stages": f"{sum(same)}/{len(same)}",
+                  "first_diffs": [int((a != b).sum()) for a, b in zip(hs + acts + outs, chs + cas + cos)][:3 * args.layers]}), flush=True)
+nbytes = sum(2 * t.numel() if t.dtype == torch.float16 else t.numel() for L in layers[:1] for k in "ogud" for t in L[k])
+res = {}
+for name, fn in (("launches_3_per_layer", run_launches), ("chain_keep_intermediates", lambda: run_chain(True)),
+                 ("chain", lambda: run_chain(False)), ("launches_again", run_launches), ("chain_again", lambda: run_chain(False))):
+    per = graph_us(fn)
+    res[name] = {"us_per_layer_tail": [round(p, 2) for p in per], "median": round(float(np.median(per)), 2),
+                 "GBps": round(nbytes / np.median(per) / 1e3, 1)}
+    print(json.dumps({name: res[name]}), flush=True)
+print(json.dumps({"status_after": chain_status(), "weight_bytes_per_tail": nbytes}), flush=True)
+
+if not args.no_trace:
+    os.environ["WQAA_CHAIN_TRACE"] = "1"
+    x = x0
+    matmul_chain(steps_of(layers[0], x0, None, None, cos[0]))
+    torch.cuda.synchronize()
+    matmul_chain(steps_of(layers[1], x0, None, None, cos[1]))       # cold weights for the traced launch
+    torch.cuda.synchronize()
+    tr = chain_trace().astype(np.int64)
+    os.environ.pop("WQAA_CHAIN_TRACE")
+    if tr.size:
+        t0 = tr[:, :, 0][tr[:, :, 0] > 0].min()
+        names = {0: "wave start", 1: "loader: first DMA issued", 2: "loader: stream drained", 3: "wave end"}
+        for s in range(3):
+            names[4 + 3 * s] = f"stage {s}: stager starts"
+            names[5 + 3 * s] = f"stage {s}: input tile ready"
+            names[6 + 3 * s] = f"stage {s}: this wave's tasks done"
+        print("time line of one launch, microseconds after the first wave's start (100 MHz clock): min / median / max over the waves that stamped")
+        for i in sorted(names):
+            v = tr[:, :, i]
+            v = v[v > 0]
+            if v.size:
+                u = (v - t0) / 100.0
+                print(f"  {names[i]:44s} n={v.size:4d}  {u.min():7.2f} {np.median(u):7.2f} {u.max():7.2f}")
