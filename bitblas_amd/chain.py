@@ -184,7 +184,10 @@ def chain_plan(steps: Sequence[ChainStep], m: Optional[int] = None) -> dict:
     launches = ctypes.c_int(0)
     plan = _lib.Plan()
     _lib.check(_library().wqaa_chain_plan(items, len(steps), int(m if m is not None else mm), ctypes.byref(launches), ctypes.byref(plan)))
-    return {"launches": launches.value, "plan": plan.as_dict() if launches.value == 1 and plan.kernel_family else None}
+    fused = launches.value == 1 and plan.kernel_family != 0
+    # (where the persistent member refuses, the library's error string says why; the call itself succeeded)
+    return {"launches": launches.value, "plan": plan.as_dict() if fused else None,
+            "reason": None if fused else _library().wqaa_last_error_string().decode(errors="replace")}
 
 
 def matmul_chain(steps: Sequence[ChainStep]) -> List[Optional[torch.Tensor]]:

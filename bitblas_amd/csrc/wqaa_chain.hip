@@ -51,6 +51,16 @@ static std::vector<void*> g_chain_retired;
 static std::mutex g_chain_mu;
 constexpr size_t kChainCtlBytes = 256;
 
+// streams first seen DURING capture (torch captures on a side stream of its own) take a spare slab: allocated and cleared
+// next to the device's first slab, outside capture
+constexpr int kChainSpares = 8;
+constexpr size_t kChainSlabBytes = 1u << 20;
+struct ChainSpare {
+  int dev;
+  unsigned char* ptr;
+};
+static std::vector<ChainSpare> g_chain_spares;
+
 static ChainSlab* chain_slab(hipStream_t stream, size_t bytes, bool create) {
   const int dev = current_device();
   if (dev < 0) return nullptr;
@@ -62,32 +72,46 @@ static ChainSlab* chain_slab(hipStream_t stream, size_t bytes, bool create) {
   hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
   if (hipStreamIsCapturing(stream, &cs) != hipSuccess) (void)hipGetLastError();
   if (cs != hipStreamCaptureStatusNone) {
+    if (!slab && bytes <= kChainSlabBytes) {
+      for (size_t i = 0; i < g_chain_spares.size(); ++i)
+        if (g_chain_spares[i].dev == dev) {
+          g_chain_ws.push_back(ChainSlab{dev, stream, g_chain_spares[i].ptr, kChainSlabBytes, 0, 0});
+          g_chain_spares.erase(g_chain_spares.begin() + (long)i);
+          return &g_chain_ws.back();
+        }
+    }
     set_error(WQAA_ERR_LAUNCH, "matmul_chain: the hand-off scratch of this stream has to be allocated (%zu B), which cannot happen during "
-              "stream capture: run the chain once outside capture first", bytes);
+              "stream capture: run a chain once outside capture first (that also sets %d spare slabs aside for capturing streams)", bytes, kChainSpares);
     return nullptr;
   }
-  size_t want = bytes < (1u << 20) ? (1u << 20) : bytes;
+  size_t want = bytes < kChainSlabBytes ? kChainSlabBytes : bytes;
   if (slab && want < 2 * slab->bytes) want = 2 * slab->bytes;
-  void* p = nullptr;
-  if (hipMalloc(&p, want) != hipSuccess) {
-    (void)hipGetLastError();
-    set_error(WQAA_ERR_LAUNCH, "matmul_chain: cannot allocate %zu B of hand-off scratch", want);
-    return nullptr;
+  bool have_spares = false;
+  for (auto& sp : g_chain_spares) have_spares = have_spares || sp.dev == dev;
+  bool first_of_dev = !have_spares;
+  for (auto& w : g_chain_ws) first_of_dev = first_of_dev && w.dev != dev;
+  const int nalloc = 1 + (first_of_dev ? kChainSpares : 0);
+  void* got[1 + kChainSpares] = {};
+  for (int i = 0; i < nalloc; ++i) {
+    const size_t sz = i == 0 ? want : kChainSlabBytes;
+    // stream-ordered clear, then one wait: a spare is used by ANOTHER stream later
+    if (hipMalloc(&got[i], sz) != hipSuccess || hipMemsetAsync(got[i], 0, sz, stream) != hipSuccess) {
+      (void)hipGetLastError();
+      for (int j = 0; j <= i; ++j)
+        if (got[j]) (void)hipFree(got[j]);
+      set_error(WQAA_ERR_LAUNCH, "matmul_chain: cannot allocate %zu B of hand-off scratch", sz);
+      return nullptr;
+    }
   }
-  // stream-ordered: launches of this stream that still use the old slab are ahead of the memset's successors
-  if (hipMemsetAsync(p, 0, want, stream) != hipSuccess) {
-    (void)hipGetLastError();
-    (void)hipFree(p);
-    set_error(WQAA_ERR_LAUNCH, "matmul_chain: cannot clear the hand-off scratch");
-    return nullptr;
-  }
+  if (nalloc > 1 && hipStreamSynchronize(stream) != hipSuccess) (void)hipGetLastError();
+  for (int i = 1; i < nalloc; ++i) g_chain_spares.push_back(ChainSpare{dev, reinterpret_cast<unsigned char*>(got[i])});
   if (slab) {
     g_chain_retired.push_back(slab->ptr);
-    slab->ptr = reinterpret_cast<unsigned char*>(p);
+    slab->ptr = reinterpret_cast<unsigned char*>(got[0]);
     slab->bytes = want;
     slab->trace_words = 0;
   } else {
-    g_chain_ws.push_back(ChainSlab{dev, stream, reinterpret_cast<unsigned char*>(p), want, 0, 0});
+    g_chain_ws.push_back(ChainSlab{dev, stream, reinterpret_cast<unsigned char*>(got[0]), want, 0, 0});
     slab = &g_chain_ws.back();
   }
   return slab;
@@ -312,7 +336,7 @@ static int chain_build(const wqaa_chain_item* items, int count, int m, ChainBuil
     if (S.in_kind == 2 || !S.norm_weight) continue;
     const int npass = (S.nc * 64 * E + 2047) / 2048;
     if (npass > raw_passes) raw_passes = npass;
-    const int nslots = (S.cpr * 4 + 63) / 64;
+    const int nslots = S.nc * 4;
     if (nslots * 256 > parts_bytes) parts_bytes = nslots * 256;
   }
   A.raw_off = off; A.raw_passes = raw_passes;

@@ -454,8 +454,7 @@ __device__ __forceinline__ float chain_norm_rinv(unsigned char* smem, const Chai
   constexpr int EPW = P::EPW, IVW = EPW / 8;
   float* parts = reinterpret_cast<float*>(smem + args.parts_off);      // [slot = idx >> 6][lane]
   const unsigned char* raw = smem + args.raw_off;
-  const int nitems = S.cpr * 4;                                        // K / EPW
-  const int nslots = (nitems + 63) >> 6;
+  const int nslots = S.nc * 4;                                         // launch-path items idx = c * 256 + u * 64 + l: slot = idx >> 6
   for (int sl = 0; sl < nslots; ++sl) {
     // launch-path item idx = c * 256 + u * 64 + l  <->  natural item (c * 64 + l) * 4 + u
     const int idx = sl * 64 + lane;

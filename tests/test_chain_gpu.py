@@ -61,7 +61,7 @@ def assert_clean():
 LAYERS = [  # (hidden, intermediate, W_dtype, group, zeros_mode, bias)
     (4096, 11008, "int4", 128, None, False),          # Llama-2-7B, BASELINE c2's format
     (1024, 2048, "int4", 128, None, False),
-    (2048, 5632, "uint4", 128, "original", True),     # K = 5632: a ragged last lane chunk
+    (4096, 9728, "uint4", 128, "original", True),     # K = 9728: a ragged last lane chunk (4.75), zeros, bias
     (1536, 4096, "uint4", 64, "rescale", False),
     (1024, 3072, "int2", 128, None, True),
     (1056, 2048, "int4", -1, None, False),            # 528 tasks over 256 CUs: uneven ranges; one group per row
@@ -76,7 +76,7 @@ def test_decoder_tail_bit_for_bit(H, I, wd, g, zm, bias):
     eps = 1e-5
     steps = tail_steps(ops, attn, x, nw, eps)
     plan = chain_plan(steps)
-    assert plan["launches"] == 1 and plan["plan"]["name"].startswith("chain_m1_"), plan
+    assert plan["launches"] == 1 and plan["plan"]["name"].startswith("chain_m1_") and plan["reason"] is None, plan
     want = by_launches(ops, attn, x, nw, eps)
     got = matmul_chain(steps)
     torch.cuda.synchronize()
@@ -159,7 +159,7 @@ def test_shared_input_and_longer_chains():
     cases, ops, attn, x, nw = layer(H, I, seed=21)
     eps = 1e-5
     h, act, out = by_launches(ops, attn, x, nw, eps)
-    qkv = [build(make_case(1, n, H, W_dtype="int4", group_size=128, with_scaling=True, seed=100 + i, scale_mul=0.03)) for i, n in enumerate((1024, 512, 512))]
+    qkv = [build(make_case(1, n, H, W_dtype="int4", group_size=128, with_scaling=True, seed=100 + i, scale_mul=0.03)) for i, n in enumerate((4096, 2048, 2048))]
     nw2 = (nw * 1.1).to(torch.float16).contiguous()
     want_qkv = [op.forward_ex(out, w[0], scale=w[1], norm=(nw2, eps)) for op, w in qkv]
     steps = tail_steps(ops, attn, x, nw, eps) + [ChainStep(op, w, 2, norm=(nw2, eps)) for op, w in qkv]
@@ -177,6 +177,21 @@ def test_shared_input_and_longer_chains():
     assert_clean()
     for a, b in zip(got, want_qkv):
         assert torch.equal(a, b)
+
+
+def test_k_split_chain_runs_as_launches():
+    """a stage whose single launch splits K across waves sums its rows in another order than the persistent member's
+    consumers: refused (with the reason), run as its launches - the same call, the launches' bits"""
+    cases, ops, attn, x, nw = layer(2048, 5632, "uint4", 128, "original", True, seed=3)
+    eps = 1e-5
+    steps = tail_steps(ops, attn, x, nw, eps)
+    plan = chain_plan(steps)
+    assert plan["launches"] == 3 and "splits K" in plan["reason"], plan
+    want = by_launches(ops, attn, x, nw, eps)
+    got = matmul_chain(steps)
+    got2 = matmul_chain(tail_steps(ops, attn, x, nw, eps, keep=False))      # intermediates in the library's scratch
+    torch.cuda.synchronize()
+    assert all(torch.equal(a, b) for a, b in zip(got, want)) and torch.equal(got2[2], want[2])
 
 
 def test_unfused_chains_run_as_launches():
