@@ -9,19 +9,23 @@
 namespace wqaa {
 
 // member table: one kernel per (bits, layout, scale / zeros mode) - every stage of a chain shares the format
-chain_fn pick_chain(int bits, int layout, int mode) {
-#define WQAA_CH(B, L)                                                   \
+chain_fn pick_chain(int bits, int layout, int mode, int waves) {
+#define WQAA_CH(B, L, W)                                                \
   switch (mode) {                                                       \
-    case MD_NONE: return wq_chain_kernel<B, L, MD_NONE>;                \
-    case MD_S: return wq_chain_kernel<B, L, MD_S>;                      \
-    case MD_ZO: return wq_chain_kernel<B, L, MD_ZO>;                    \
-    case MD_ZR: return wq_chain_kernel<B, L, MD_ZR>;                    \
+    case MD_NONE: return wq_chain_kernel<B, L, MD_NONE, W>;             \
+    case MD_S: return wq_chain_kernel<B, L, MD_S, W>;                   \
+    case MD_ZO: return wq_chain_kernel<B, L, MD_ZO, W>;                 \
+    case MD_ZR: return wq_chain_kernel<B, L, MD_ZR, W>;                 \
   }                                                                     \
   return nullptr;
-  if (bits == 4 && layout == LAYOUT_LOP3) { WQAA_CH(4, LAYOUT_LOP3) }
-  if (bits == 4 && layout == LAYOUT_PLAIN) { WQAA_CH(4, LAYOUT_PLAIN) }
-  if (bits == 2 && layout == LAYOUT_LOP3) { WQAA_CH(2, LAYOUT_LOP3) }
-  if (bits == 2 && layout == LAYOUT_PLAIN) { WQAA_CH(2, LAYOUT_PLAIN) }
+  if (waves == 8) {   // lab member: the loader + 7 consumers (two waves per SIMD), the headline format only
+    if (bits == 4 && layout == LAYOUT_LOP3 && mode == MD_S) return wq_chain_kernel<4, LAYOUT_LOP3, MD_S, 8>;
+    return nullptr;
+  }
+  if (bits == 4 && layout == LAYOUT_LOP3) { WQAA_CH(4, LAYOUT_LOP3, 4) }
+  if (bits == 4 && layout == LAYOUT_PLAIN) { WQAA_CH(4, LAYOUT_PLAIN, 4) }
+  if (bits == 2 && layout == LAYOUT_LOP3) { WQAA_CH(2, LAYOUT_LOP3, 4) }
+  if (bits == 2 && layout == LAYOUT_PLAIN) { WQAA_CH(2, LAYOUT_PLAIN, 4) }
 #undef WQAA_CH
   return nullptr;
 }
@@ -117,9 +121,37 @@ static ChainSlab* chain_slab(hipStream_t stream, size_t bytes, bool create) {
   return slab;
 }
 
+// switches (A/B and lab aids; all plan-time like every WQAA_* variable: read again when wqaa_select / wqaa_chain_plan bump the epoch)
+struct ChainKnobs {
+  int fuse, waves, ring, thin, sweep_sleep, trace;
+  unsigned timeout_ticks;
+};
+static const ChainKnobs& chain_knobs() {
+  static thread_local ChainKnobs k;
+  static thread_local unsigned seen = ~0u;
+  const unsigned ep = g_plan_epoch.load(std::memory_order_relaxed);
+  if (ep != seen) {
+    auto geti = [](const char* name, int dflt) {
+      const char* f = getenv(name);
+      return f ? atoi(f) : dflt;
+    };
+    k.fuse = geti("WQAA_CHAIN_FUSE", 1) != 0;
+    k.waves = geti("WQAA_CHAIN_WAVES", 4);
+    k.ring = geti("WQAA_CHAIN_RING", 0);
+    k.thin = geti("WQAA_CHAIN_THIN", 1) != 0;
+    k.sweep_sleep = geti("WQAA_CHAIN_SWEEP_SLEEP", 2);
+    if (k.sweep_sleep < 0) k.sweep_sleep = 0;
+    k.trace = geti("WQAA_CHAIN_TRACE", 0);
+    const int ms = geti("WQAA_CHAIN_TIMEOUT_MS", 250);
+    k.timeout_ticks = (unsigned)(ms > 0 ? ms : 1) * 100000u;          // s_memrealtime runs at 100 MHz
+    seen = ep;
+  }
+  return k;
+}
+
 struct ChainBuild {
   ChainArgs args;
-  int bits, layout, mode;
+  int bits, layout, mode, waves;
   int lds_bytes;
   int grid;
   size_t gran_count;        // granules
@@ -190,11 +222,10 @@ static int chain_build(const wqaa_chain_item* items, int count, int m, ChainBuil
     set_error(WQAA_ERR_UNSUPPORTED, "matmul_chain: the persistent member takes m = 1 (got %d)", m);
     return WQAA_ERR_UNSUPPORTED;
   }
-  if (const char* f = getenv("WQAA_CHAIN_FUSE")) {
-    if (atoi(f) == 0) {
-      set_error(WQAA_ERR_UNSUPPORTED, "matmul_chain: WQAA_CHAIN_FUSE=0");
-      return WQAA_ERR_UNSUPPORTED;
-    }
+  const ChainKnobs& knobs = chain_knobs();
+  if (!knobs.fuse) {
+    set_error(WQAA_ERR_UNSUPPORTED, "matmul_chain: WQAA_CHAIN_FUSE=0");
+    return WQAA_ERR_UNSUPPORTED;
   }
   const int cus = device_info().ok ? device_info().cus : 256;
   const wqaa_matmul_desc& d0 = *items[0].desc;
@@ -202,7 +233,8 @@ static int chain_build(const wqaa_chain_item* items, int count, int m, ChainBuil
   out->layout = d0.w_layout == WQAA_LAYOUT_LOP3 ? LAYOUT_LOP3 : LAYOUT_PLAIN;
   out->mode = desc_mode(d0);
   out->grid = cus;
-  if (!pick_chain(out->bits, out->layout, out->mode)) {
+  out->waves = (knobs.waves == 8 && pick_chain(out->bits, out->layout, out->mode, 8)) ? 8 : 4;
+  if (!pick_chain(out->bits, out->layout, out->mode, out->waves)) {
     set_error(WQAA_ERR_UNSUPPORTED, "matmul_chain: no persistent member for %d-bit weights, layout %d, scale / zeros mode %d", out->bits, out->layout, out->mode);
     return WQAA_ERR_UNSUPPORTED;
   }
@@ -271,7 +303,7 @@ static int chain_build(const wqaa_chain_item* items, int count, int m, ChainBuil
     if (it.norm_weight) {
       // (the single launch's own limit - the row within the items its workgroup loads ahead - was checked by its selector)
       const int npass = (S.nc * 64 * E + 2047) / 2048;
-      if (npass > 8) {
+      if (npass > 4) {
         set_error(WQAA_ERR_UNSUPPORTED, "matmul_chain: item %d: RMSNorm input of K = %d", i, d.K);
         return WQAA_ERR_UNSUPPORTED;
       }
@@ -378,10 +410,7 @@ static int chain_build(const wqaa_chain_item* items, int count, int m, ChainBuil
   const int lds_total = 160 * 1024;
   int ring_units = (lds_total - off) / 1024;
   ring_units -= ring_units % kChainFill;
-  if (const char* f = getenv("WQAA_CHAIN_RING")) {          // lab aid: a smaller ring
-    const int r = atoi(f);
-    if (r >= 2 * kChainFill && r < ring_units) ring_units = r - r % kChainFill;
-  }
+  if (knobs.ring >= 2 * kChainFill && knobs.ring < ring_units) ring_units = knobs.ring - knobs.ring % kChainFill;   // lab aid: a smaller ring
   int un_max = 0;
   for (int i = 0; i < count; ++i) un_max = A.st[i].un > un_max ? A.st[i].un : un_max;
   if (ring_units < un_max + 2 * kChainFill || ring_units < 4 * kChainFill) {
@@ -391,12 +420,10 @@ static int chain_build(const wqaa_chain_item* items, int count, int m, ChainBuil
   A.ring_units = ring_units;
   out->lds_bytes = A.ring_off + ring_units * 1024;
   A.nstages = count;
-  A.thin = 1;
-  A.sweep_depth = 2;
-  if (const char* f = getenv("WQAA_CHAIN_THIN")) A.thin = atoi(f) != 0;
-  if (const char* f = getenv("WQAA_CHAIN_SWEEP_DEPTH")) A.sweep_depth = atoi(f) > 1 ? 2 : 1;
-  A.timeout_ticks = 25000000u;                              // 0.25 s of s_memrealtime
-  if (const char* f = getenv("WQAA_CHAIN_TIMEOUT_MS")) A.timeout_ticks = (unsigned)(atoi(f) > 0 ? atoi(f) : 1) * 100000u;
+  A.nconsumers = out->waves - 1;
+  A.thin = knobs.thin;
+  A.sweep_sleep = knobs.sweep_sleep;
+  A.timeout_ticks = knobs.timeout_ticks;
   out->gran_count = gran;
   return WQAA_OK;
 }
@@ -408,7 +435,7 @@ static void chain_plan_fill(const ChainBuild& b, const wqaa_chain_item* items, i
   plan->block_m = 1;
   plan->block_n = 2;
   plan->block_k = 64 * (128 / b.bits);
-  plan->threads = 256;
+  plan->threads = 64 * b.waves;
   plan->grid = b.grid;
   plan->rows_per_wave = 2;
   plan->batch_tile = 1;
@@ -509,9 +536,9 @@ int chain_launch(const wqaa_chain_item* items, int count, int m, hipStream_t str
   ChainBuild b;
   // (the plan is rebuilt per call: a few hundred nanoseconds per stage next to a 15-20 us launch; pointers differ per call)
   if (chain_build(items, count, m, &b) != WQAA_OK) return chain_by_launches(items, count, m, stream);
-  const bool trace = getenv("WQAA_CHAIN_TRACE") != nullptr && atoi(getenv("WQAA_CHAIN_TRACE")) != 0;
+  const bool trace = chain_knobs().trace != 0;
   const size_t gran_bytes = (b.gran_count * 8 + 255) & ~(size_t)255;
-  const size_t trace_words = trace ? (size_t)b.grid * 4 * 32 : 0;
+  const size_t trace_words = trace ? (size_t)b.grid * 8 * 32 : 0;
   const size_t need = kChainCtlBytes + (1u << 19) + (1u << 18) + trace_words * 8;
   if (gran_bytes > (1u << 19)) {
     set_error(WQAA_ERR_UNSUPPORTED, "matmul_chain: %zu B of granules", gran_bytes);
@@ -529,9 +556,9 @@ int chain_launch(const wqaa_chain_item* items, int count, int m, hipStream_t str
   b.args.ctl = reinterpret_cast<uint32_t*>(base);
   b.args.gran = reinterpret_cast<unsigned long long*>(base + kChainCtlBytes);
   b.args.trace = trace ? reinterpret_cast<unsigned long long*>(base + kChainCtlBytes + (1u << 19) + (1u << 18)) : nullptr;
-  chain_fn fn = pick_chain(b.bits, b.layout, b.mode);
+  chain_fn fn = pick_chain(b.bits, b.layout, b.mode, b.waves);
   void* params[] = {&b.args};
-  dim3 grid(b.grid, 1, 1), block(256, 1, 1);
+  dim3 grid(b.grid, 1, 1), block(64 * b.waves, 1, 1);
   hipError_t e = hipLaunchKernel(reinterpret_cast<const void*>(fn), grid, block, params, b.lds_bytes, stream);
   if (e != hipSuccess) {
     set_error(WQAA_ERR_LAUNCH, "matmul_chain launch failed: %s", hipGetErrorString(e));
@@ -576,10 +603,11 @@ int64_t chain_trace(hipStream_t stream, uint64_t* out, int64_t max_words) {
 void chain_init() {
   for (int bits : {4, 2})
     for (int layout = 0; layout < 2; ++layout)
-      for (int mode = 0; mode <= MD_ZR; ++mode) {
-        chain_fn fn = pick_chain(bits, layout, mode);
-        if (fn) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      }
+      for (int mode = 0; mode <= MD_ZR; ++mode)
+        for (int waves : {4, 8}) {
+          chain_fn fn = pick_chain(bits, layout, mode, waves);
+          if (fn) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        }
   (void)hipGetLastError();
 }
 

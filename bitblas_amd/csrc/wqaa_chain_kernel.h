@@ -31,7 +31,7 @@ namespace wqaa {
 constexpr int kChainMaxStages = 8;
 constexpr int kChainFill = 8;          // DMA instructions (1 KiB units) per fill
 constexpr int kChainLag = 6;           // fills left in flight behind the issue point: s_waitcnt vmcnt(48)
-constexpr int kChainConsumers = 3;
+constexpr int kChainMaxConsumers = 7;  // consumer waves per workgroup (3: one wave per SIMD with the loader; 7: two)
 constexpr int kChainStashMaxRows = 128;
 
 // LDS control block (dwords)
@@ -40,15 +40,15 @@ enum : int {
   CL_ABORT = 1,
   CL_GEN = 2,         // this launch's generation, CL_GEN_READY = 1 once valid
   CL_GEN_READY = 3,
-  CL_NEXT0 = 4,       // [3] ring sequence number of each consumer's next unfinished task
-  CL_SWEEPING = 7,    // a consumer of this CU is sweeping granules: the loader thins itself
-  CL_CSTAGE0 = 8,     // [3] stage each consumer has reached
-  CL_ACT_READY = 12,  // [8] staged input of stage s is complete
-  CL_TICKET = 20,     // [8] who stages the input of stage s
-  CL_WORDS = 32
+  CL_SWEEPING = 4,    // a consumer of this CU is sweeping granules: the loader thins itself
+  CL_NEXT0 = 8,       // [8] ring sequence number of each consumer's next unfinished task (unused slots: INT_MAX)
+  CL_CSTAGE0 = 16,    // [8] stage each consumer has reached
+  CL_ACT_READY = 24,  // [8] staged input of stage s is complete
+  CL_TICKET = 32,     // [8] who stages the input of stage s
+  CL_WORDS = 40
 };
 
-// error codes (ctl[1] = code | stage << 8 | wave << 16)
+// error codes (ctl[1] = code | stage << 8 | wave << 16 | workgroup << 20)
 enum : int { CE_LOADER_SPACE = 1, CE_LOADER_SC = 2, CE_WAIT_LANDED = 3, CE_WAIT_ACT = 4, CE_SWEEP = 5, CE_WAIT_GEN = 6, CE_WAIT_STAGE = 7 };
 
 struct ChainStage {
@@ -71,7 +71,7 @@ struct ChainStage {
   int src;
   int pair;
   int publish;              // granules: a later stage reads this output
-  int res_stage;            // -1, or j: residual = output of stage j, stashed while stage `stash_at` swept it
+  int res_stage;            // -1, or j: residual = output of stage j, stashed while a stage up to this one swept it
   int stash_for;            // -1, or s2: while sweeping my input keep the rows stage s2 of this CU adds as its residual
   int norm_nwv, norm_nai;   // the single launch's geometry (waves, items per thread): the order of its sum of squares
   int gran_off;             // output granules in the workspace
@@ -86,11 +86,12 @@ struct ChainStage {
 struct ChainArgs {
   ChainStage st[kChainMaxStages];
   int nstages;
+  int nconsumers;           // consumer waves (blockDim = 64 * (1 + nconsumers))
   int ring_off, ring_units;
   int raw_off, raw_passes, parts_off;
   int bump_stage;           // the stage after whose sweep workgroup 0 bumps the generation (-1: no edge)
   int thin;                 // 1: one fill outstanding while a consumer of this CU sweeps
-  int sweep_depth;          // 1 or 2 passes of granule loads in flight
+  int sweep_sleep;          // naps of ~0.2 us between two reads of an incomplete sweep
   unsigned timeout_ticks;   // s_memrealtime ticks (100 MHz) a wait may take
   unsigned long long* gran;
   uint32_t* ctl;            // [0] generation, [1] first error
@@ -99,16 +100,35 @@ struct ChainArgs {
 
 typedef __attribute__((address_space(1))) unsigned long long chain_gu64;
 typedef __attribute__((address_space(1))) unsigned int chain_gu32;
+// every global operand the consumers touch goes through a GLOBAL-address-space pointer: a generic pointer makes a FLAT
+// instruction, which also counts on lgkmcnt - an LDS wait would then sit out a memory round trip
+#define CHAIN_G(T, p) (reinterpret_cast<const __attribute__((address_space(1))) T*>((const __attribute__((address_space(1))) void*)(p)))
+#define CHAIN_GW(T, p) (reinterpret_cast<__attribute__((address_space(1))) T*>((__attribute__((address_space(1))) void*)(p)))
 
 // control words: volatile accesses through LDS-address-space pointers (a volatile access through a generic pointer is a FLAT
 // instruction, which counts on vmcnt - the loader's DMA counter)
 typedef __attribute__((address_space(3))) uint32_t chain_lds_u32;
 typedef __attribute__((address_space(3))) unsigned char chain_lds_u8;
+typedef __attribute__((address_space(3))) u32x4 chain_lds_u32x4;
 __device__ __forceinline__ uint32_t chain_lds_ld(const unsigned char* smem, int word) {
   return *reinterpret_cast<const volatile chain_lds_u32*>((const chain_lds_u8*)smem + word * 4);
 }
 __device__ __forceinline__ void chain_lds_st(unsigned char* smem, int word, uint32_t v) {
   *reinterpret_cast<volatile chain_lds_u32*>((chain_lds_u8*)smem + word * 4) = v;
+}
+// min of the eight control words at `word` (one value per consumer slot)
+__device__ __forceinline__ int chain_lds_min8(const unsigned char* smem, int word) {
+  const u32x4 a = *reinterpret_cast<const volatile chain_lds_u32x4*>((const chain_lds_u8*)smem + word * 4);
+  const u32x4 c = *reinterpret_cast<const volatile chain_lds_u32x4*>((const chain_lds_u8*)smem + word * 4 + 16);
+  int m = (int)a[0];
+  m = (int)a[1] < m ? (int)a[1] : m;
+  m = (int)a[2] < m ? (int)a[2] : m;
+  m = (int)a[3] < m ? (int)a[3] : m;
+  m = (int)c[0] < m ? (int)c[0] : m;
+  m = (int)c[1] < m ? (int)c[1] : m;
+  m = (int)c[2] < m ? (int)c[2] : m;
+  m = (int)c[3] < m ? (int)c[3] : m;
+  return __builtin_amdgcn_readfirstlane(m);
 }
 // order this wave's LDS accesses against a control word (LDS only: a workgroup fence over every address space would wait
 // for the wave's outstanding global stores, a memory round trip per task)
@@ -136,7 +156,7 @@ struct ChainWave {
   int lane, wave, b, G;
   unsigned timeout;
   __device__ __forceinline__ void stamp(int i) const {
-    if (args->trace && lane == 0) args->trace[((long)b * 4 + wave) * 32 + i] = __builtin_amdgcn_s_memrealtime();
+    if (args->trace && lane == 0) args->trace[((long)b * 8 + wave) * 32 + i] = __builtin_amdgcn_s_memrealtime();
   }
   __device__ __forceinline__ void fail(int code, int stage) const {
     if (lane == 0) {
@@ -148,7 +168,7 @@ struct ChainWave {
   }
   // every 32 polls: give up when the workgroup has aborted or the wait has lasted longer than the limit
   __device__ __forceinline__ bool expired(unsigned& n, unsigned long long& t0) const {
-    __builtin_amdgcn_s_sleep(2);
+    __builtin_amdgcn_s_sleep(1);
     if ((++n & 31u) != 0) return false;
     if (chain_lds_ld(smem, CL_ABORT) != 0) return true;
     const unsigned long long now = __builtin_amdgcn_s_memrealtime();
@@ -170,15 +190,10 @@ struct ChainWave {
     }
     return true;
   }
-  __device__ __forceinline__ int min_cstage() const {
-    const int a = (int)chain_lds_ld(smem, CL_CSTAGE0), c = (int)chain_lds_ld(smem, CL_CSTAGE0 + 1), d = (int)chain_lds_ld(smem, CL_CSTAGE0 + 2);
-    const int m = a < c ? a : c;
-    return m < d ? m : d;
-  }
   __device__ __forceinline__ bool wait_cstage(int stage, int code, int at) const {
     unsigned n = 0;
     unsigned long long t0 = 0;
-    while (min_cstage() < stage) {
+    while (chain_lds_min8(smem, CL_CSTAGE0) < stage) {
       if (expired(n, t0)) {
         fail(code, at);
         return false;
@@ -186,9 +201,9 @@ struct ChainWave {
     }
     return true;
   }
-  __device__ __forceinline__ void task_range(const ChainStage& S, int& t0, int& t1) const {
-    t0 = (int)(((uint32_t)b * (uint32_t)S.tasks) / (uint32_t)G);            // tasks * G < 2^32 (host)
-    t1 = (int)(((uint32_t)(b + 1) * (uint32_t)S.tasks) / (uint32_t)G);
+  __device__ __forceinline__ void task_range(int tasks, int& t0, int& t1) const {
+    t0 = (int)(((uint32_t)b * (uint32_t)tasks) / (uint32_t)G);            // tasks * G < 2^32 (host)
+    t1 = (int)(((uint32_t)(b + 1) * (uint32_t)tasks) / (uint32_t)G);
   }
 };
 
@@ -198,13 +213,16 @@ __device__ void chain_loader(const ChainWave& cw) {
   const ChainArgs& args = *cw.args;
   unsigned char* smem = cw.smem;
   const int lane = cw.lane;
-  const int RING = args.ring_units;
+  int RING = args.ring_units, ring_off = args.ring_off, thin = args.thin;
+  asm volatile("" : "+s"(RING), "+s"(ring_off), "+s"(thin));
+  const unsigned ring_end = (unsigned)(ring_off + RING * 1024);
   int issued = 0;         // units issued so far (scale blocks + ring units)
   int rseq = 0;           // ring units issued so far
-  int rpos = 0;           // rseq % RING
+  unsigned dst = (unsigned)ring_off;   // LDS byte address of ring slot rseq % RING
   int in_fill = 0;
   int frontier = 0;       // cached min(next task's ring sequence) over the consumers
   int landed_pub = 0;
+  bool dead = false;
   const unsigned voff_full = (unsigned)lane * 16u;
   cw.stamp(1);
 
@@ -214,43 +232,65 @@ __device__ void chain_loader(const ChainWave& cw) {
       chain_lds_st(smem, CL_LANDED, (uint32_t)landed);
     }
   };
-  auto drain = [&]() {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    publish(issued);
-  };
-  auto read_frontier = [&]() {
-    const int a = (int)chain_lds_ld(smem, CL_NEXT0), c = (int)chain_lds_ld(smem, CL_NEXT0 + 1), d = (int)chain_lds_ld(smem, CL_NEXT0 + 2);
-    const int m = a < c ? a : c;
-    frontier = m < d ? m : d;
-  };
-  // after a unit: at a fill boundary leave kChainLag fills (one while a consumer sweeps) in flight and publish the rest
-  auto after_unit = [&]() {
-    ++issued;
-    if (++in_fill == kChainFill) {
-      in_fill = 0;
-      if (args.thin && chain_lds_ld(smem, CL_SWEEPING) != 0) {
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        publish(issued - kChainFill);
-      } else {
-        asm volatile("s_waitcnt vmcnt(48)" ::: "memory");
-        publish(issued - kChainFill * kChainLag);
+  auto has_space = [&]() { return rseq + kChainFill <= frontier + RING; };
+  // the ring is full: publish what is in flight as it lands (the consumers may be waiting for exactly that), fill by fill,
+  // and go on as soon as a fill's worth of slots is free
+  auto wait_space = [&](int stage) {
+#define CHAIN_DRAIN_STEP(N)                                   \
+  asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory");       \
+  publish(issued - N);                                        \
+  frontier = chain_lds_min8(smem, CL_NEXT0);                  \
+  if (has_space()) return;
+    CHAIN_DRAIN_STEP(40)
+    CHAIN_DRAIN_STEP(32)
+    CHAIN_DRAIN_STEP(24)
+    CHAIN_DRAIN_STEP(16)
+    CHAIN_DRAIN_STEP(8)
+    CHAIN_DRAIN_STEP(0)
+#undef CHAIN_DRAIN_STEP
+    unsigned n_ = 0;
+    unsigned long long t_ = 0;
+    for (;;) {
+      frontier = chain_lds_min8(smem, CL_NEXT0);
+      if (has_space()) return;
+      if (cw.expired(n_, t_)) {
+        cw.fail(CE_LOADER_SPACE, stage);
+        dead = true;
+        return;
       }
-      static_assert(kChainFill == 8 && kChainLag == 6, "the vmcnt immediates above");
+    }
+  };
+  // a fill is complete: leave kChainLag fills (one while a consumer of this CU sweeps) in flight, publish the rest, and make
+  // sure the next fill's ring slots are free
+  auto boundary = [&](int stage) {
+    in_fill = 0;
+    if (thin && chain_lds_ld(smem, CL_SWEEPING) != 0) {
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      publish(issued - kChainFill);
+    } else {
+      asm volatile("s_waitcnt vmcnt(48)" ::: "memory");
+      publish(issued - kChainFill * kChainLag);
+    }
+    static_assert(kChainFill == 8 && kChainLag == 6, "the vmcnt immediates above");
+    if (!has_space()) {
+      frontier = chain_lds_min8(smem, CL_NEXT0);
+      if (!has_space()) wait_space(stage);
     }
   };
 
-  for (int s = 0; s < args.nstages; ++s) {
+  for (int s = 0; s < args.nstages && !dead; ++s) {
     const ChainStage& S = args.st[s];
     int t0, t1;
-    cw.task_range(S, t0, t1);
+    cw.task_range(S.tasks, t0, t1);
     const int nt = t1 - t0;
     const int n0 = 2 * t0;
     const int nops = S.pair ? 2 : 1;
     // ---- scale / zeros blocks of this CU's rows: contiguous in the (N, K / g) tensors, 16-byte windows aligned in
     // absolute address (a window never straddles a page), lanes past the block re-read its first window ----
     if (S.nsc > 0) {
-      if (s >= 2 && cw.min_cstage() < s - 1) {     // the block of stage s - 2 lives in the same LDS area
-        drain();
+      if (s >= 2 && chain_lds_min8(smem, CL_CSTAGE0) < s - 1) {     // the block of stage s - 2 lives in the same LDS area
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        publish(issued);
         if (!cw.wait_cstage(s - 1, CE_LOADER_SC, s)) return;
       }
       int nr = 2 * nt;
@@ -269,64 +309,62 @@ __device__ void chain_loader(const ChainWave& cw) {
             unsigned off = (unsigned)u * 1024u + voff_full;
             off = off < span ? off : 0u;
             chain_dma((unsigned)(S.sc_off + (blk * S.sc_units + u) * 1024), off, a16);
-            after_unit();
+            ++issued;
+            if (++in_fill == kChainFill) {
+              boundary(s);
+              if (dead) return;
+            }
           }
           ++blk;
         }
       }
     }
-    // ---- the weight rows of this CU's tasks, in the order the consumers read them back: one flat loop over the 1 KiB
-    // units, everything it needs in registers (the stage descriptor lives in the kernel-argument segment) ----
+    // ---- the weight rows of this CU's tasks, in the order the consumers read them back: the stage descriptor lives in the
+    // kernel-argument segment, what the loop needs is pinned in registers; per unit: M0, the DMA, two adds, a compare ----
     int nc = S.nc, rows_per_task = S.pair ? 4 : 2, pair = S.pair, Nrows = S.N, row_bytes = S.row_bytes;
     unsigned long long B0 = (unsigned long long)S.B[0], B1 = (unsigned long long)S.B[S.pair ? 1 : 0];
+    const bool tail_partial = (S.cpr & 63) != 0;
     unsigned voff_tail = voff_full;
     {
       const int chunk = (nc - 1) * 64 + lane;
       if (chunk >= S.cpr) voff_tail = 0u;        // lanes past the row re-read the unit's first 16 bytes: they meet zero activations
     }
-    asm volatile("" : "+s"(nc), "+s"(rows_per_task), "+s"(pair), "+s"(Nrows), "+s"(row_bytes), "+s"(B0), "+s"(B1));
-    auto row_addr = [&](int t, int r) -> unsigned long long {
-      int n = 2 * t + (pair ? (r >> 1) : r);
-      n = n < Nrows ? n : Nrows - 1;
-      const unsigned long long base = (pair && (r & 1)) ? B1 : B0;
-      return chain_uniform64(base + (unsigned long long)((long)n * row_bytes));
-    };
-    int c = 0, r = 0, t = t0;
-    unsigned long long src = row_addr(t, 0);
-    const int total_units = nt * rows_per_task * nc;
-    for (int ui = 0; ui < total_units; ++ui) {
-      if (in_fill == 0 && rseq + kChainFill > frontier + RING) {
-        read_frontier();
-        if (rseq + kChainFill > frontier + RING) {
-          drain();       // what is in flight must be published before blocking: the consumers may be waiting for it
-          unsigned n_ = 0;
-          unsigned long long t_ = 0;
-          for (;;) {
-            read_frontier();
-            if (rseq + kChainFill <= frontier + RING) break;
-            if (cw.expired(n_, t_)) {
-              cw.fail(CE_LOADER_SPACE, s);
-              return;
-            }
+    int nfull = tail_partial ? nc - 1 : nc;
+    asm volatile("" : "+s"(nc), "+s"(rows_per_task), "+s"(pair), "+s"(Nrows), "+s"(row_bytes), "+s"(B0), "+s"(B1), "+s"(nfull));
+    for (int t = t0; t < t1; ++t) {
+      for (int r = 0; r < rows_per_task; ++r) {
+        int n = 2 * t + (pair ? (r >> 1) : r);
+        n = n < Nrows ? n : Nrows - 1;
+        const unsigned long long base = (pair && (r & 1)) ? B1 : B0;
+        unsigned long long src = chain_uniform64(base + (unsigned long long)((long)n * row_bytes));
+        for (int c = 0; c < nfull; ++c) {
+          chain_dma(dst, voff_full, src);
+          src += 1024ull;
+          dst += 1024u;
+          if (dst == ring_end) dst = (unsigned)ring_off;
+          ++rseq;
+          ++issued;
+          if (++in_fill == kChainFill) {
+            boundary(s);
+            if (dead) return;
+          }
+        }
+        if (tail_partial) {
+          chain_dma(dst, voff_tail, src);
+          dst += 1024u;
+          if (dst == ring_end) dst = (unsigned)ring_off;
+          ++rseq;
+          ++issued;
+          if (++in_fill == kChainFill) {
+            boundary(s);
+            if (dead) return;
           }
         }
       }
-      chain_dma((unsigned)(args.ring_off + rpos * 1024), c == nc - 1 ? voff_tail : voff_full, src);
-      src += 1024ull;
-      ++rseq;
-      if (++rpos == RING) rpos = 0;
-      after_unit();
-      if (++c == nc) {
-        c = 0;
-        if (++r == rows_per_task) {
-          r = 0;
-          ++t;
-        }
-        src = row_addr(t < t1 ? t : t1 - 1, r);
-      }
     }
   }
-  drain();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  publish(issued);
   cw.stamp(2);
 }
 
@@ -381,12 +419,12 @@ __device__ __forceinline__ void chain_chunk(const u32x4 w, const u32x4 (&av)[4 *
 // the unpack produces + the chunk's activation sum; wq_gemvx_kernel's `item_store`, with the four partial sums of a lane
 // chunk combined here ((p0 + p1) + (p2 + p3), the order `consume` adds them in) by the four lanes that hold them ----
 template <class P>
-__device__ __forceinline__ void chain_item_store(unsigned char* smem, const ChainStage& S, int c, int u, int l, const u32x4 (&raw)[P::EPW / 8],
+__device__ __forceinline__ void chain_item_store(unsigned char* smem, int a_off, int sa_off, int c, int u, int l, const u32x4 (&raw)[P::EPW / 8],
                                                  bool valid, int lane) {
   using T = typename P::T;
   constexpr int EPW = P::EPW, PPW = P::PPW, PIECES = P::PIECES;
-  u32x4* a_lds = reinterpret_cast<u32x4*>(smem + S.a_off);
-  float* sa_lds = reinterpret_cast<float*>(smem + S.sa_off);
+  u32x4* a_lds = reinterpret_cast<u32x4*>(smem + a_off);
+  float* sa_lds = reinterpret_cast<float*>(smem + sa_off);
   float sum = 0.f;
   half_t el[EPW];
 #pragma unroll
@@ -415,35 +453,32 @@ __device__ __forceinline__ void chain_item_store(unsigned char* smem, const Chai
   if ((lane & 3) == 0) sa_lds[c * 64 + l] = p;
 }
 
-// stage the items [first, first + count) (natural memory order: item i = EPW elements at element offset i * EPW) from
-// `src` (LDS raw scratch, item first at src) - `norm_r` != 0: x -> weight * half(x * r) first (the norm's two roundings)
+// stage one pass (IPP items in natural memory order, item i = EPW elements at element offset i * EPW) from `src` (LDS raw
+// scratch).  NORM: x -> weight * half(x * r) first (the norm's two roundings), weight = nw[q] of item first + q * 64 + lane
 template <class P, bool NORM>
-__device__ __forceinline__ void chain_stage_items(unsigned char* smem, const ChainStage& S, const unsigned char* src, int first, int count, int lane,
-                                                  float norm_r) {
-  constexpr int EPW = P::EPW, IVW = EPW / 8;
-  for (int q = 0; q < count; q += 64) {
-    const int i = first + q + lane;                // count is a multiple of 64
+__device__ __forceinline__ void chain_stage_pass(unsigned char* smem, int a_off, int sa_off, int cpr, const unsigned char* src, int first, int lane,
+                                                 float norm_r, const u32x4 (*nw)[P::EPW / 8]) {
+  constexpr int EPW = P::EPW, IVW = EPW / 8, IPL = 2048 / EPW / 64;
+#pragma unroll
+  for (int q = 0; q < IPL; ++q) {
+    const int i = first + q * 64 + lane;
     const int cl = i >> 2, u = i & 3;
     const int c = cl >> 6, l = cl & 63;
-    const bool valid = cl < S.cpr;
+    const bool valid = cl < cpr;
     u32x4 raw[IVW];
 #pragma unroll
-    for (int v = 0; v < IVW; ++v) raw[v] = reinterpret_cast<const u32x4*>(src + (long)(q + lane) * (EPW * 2))[v];
+    for (int v = 0; v < IVW; ++v) raw[v] = reinterpret_cast<const u32x4*>(src + (long)(q * 64 + lane) * (EPW * 2))[v];
     if constexpr (NORM) {
-      u32x4 nw[IVW];
-#pragma unroll
-      for (int v = 0; v < IVW; ++v)
-        nw[v] = reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned char*>(S.norm_weight) + (long)(valid ? i : 0) * (EPW * 2))[v];
 #pragma unroll
       for (int v = 0; v < IVW; ++v)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const half2_t x = as_h2(raw[v][e]);
           const half2_t h = {(half_t)((float)x[0] * norm_r), (half_t)((float)x[1] * norm_r)};
-          raw[v][e] = as_u32(as_h2(nw[v][e]) * h);
+          raw[v][e] = as_u32(as_h2(nw[q][v][e]) * h);
         }
     }
-    chain_item_store<P>(smem, S, c, u, l, raw, valid, lane);
+    chain_item_store<P>(smem, a_off, sa_off, c, u, l, raw, valid, lane);
   }
 }
 
@@ -455,13 +490,13 @@ __device__ __forceinline__ float chain_norm_rinv(unsigned char* smem, const Chai
   float* parts = reinterpret_cast<float*>(smem + args.parts_off);      // [slot = idx >> 6][lane]
   const unsigned char* raw = smem + args.raw_off;
   const int nslots = S.nc * 4;                                         // launch-path items idx = c * 256 + u * 64 + l: slot = idx >> 6
+  const int cpr = S.cpr;
   for (int sl = 0; sl < nslots; ++sl) {
     // launch-path item idx = c * 256 + u * 64 + l  <->  natural item (c * 64 + l) * 4 + u
-    const int idx = sl * 64 + lane;
-    const int c = idx >> 8, u = (idx >> 6) & 3;
+    const int c = sl >> 2, u = sl & 3;
     const int cl = c * 64 + lane;
     float part = 0.f;
-    if (cl < S.cpr) {
+    if (cl < cpr) {
       const u32x4* src = reinterpret_cast<const u32x4*>(raw + ((long)cl * 4 + u) * (EPW * 2));
 #pragma unroll
       for (int v = 0; v < IVW; ++v) {
@@ -472,11 +507,12 @@ __device__ __forceinline__ float chain_norm_rinv(unsigned char* smem, const Chai
     }
     parts[sl * 64 + lane] = part;
   }
+  const int nwv = S.norm_nwv, nai = S.norm_nai;
   float tot = 0.f;
-  for (int w = 0; w < S.norm_nwv; ++w) {
+  for (int w = 0; w < nwv; ++w) {
     float ssq = 0.f;
-    for (int j = 0; j < S.norm_nai; ++j) {
-      const int sl = j * S.norm_nwv + w;
+    for (int j = 0; j < nai; ++j) {
+      const int sl = j * nwv + w;
       ssq += sl < nslots ? parts[sl * 64 + lane] : 0.f;
     }
     const float ws = wave_sum_l63(ssq);
@@ -487,79 +523,102 @@ __device__ __forceinline__ float chain_norm_rinv(unsigned char* smem, const Chai
 }
 
 // ---- the consumer waves ---------------------------------------------------------------------------------------------------
+// what a stage's tasks need, fetched from the kernel-argument segment once per stage
+struct ChainTaskCtx {
+  int nc, cpr, kg, gq_shift, N, n0;
+  uint32_t gq_magic, flip;
+  int a_off, sa_off, ring_off, ring_units;
+  int sc_rel[2], z_rel[2];      // LDS byte address of (row n0, group 0) in the scale / zeros block of operator 0 / 1
+  float zint;
+  int has_bias, has_res, stash_off;
+  const void* bias[2];
+  const void* residual;
+  void* C;
+  unsigned long long* gran;     // this stage's granules, or NULL
+  uint32_t tag;
+};
+
 template <class P, int ROWS>
-__device__ __forceinline__ void chain_task(const ChainWave& cw, const ChainStage& S, int s, int t, int n0, int rseq, uint32_t tag) {
+__device__ __forceinline__ void chain_task(unsigned char* smem, const ChainTaskCtx& X, int t, int rpos, int lane) {
   constexpr int PPW = P::PPW, PIECES = P::PIECES, MODE = P::MODE;
   constexpr bool PAIR = ROWS == 4;
-  constexpr int NTENS = (MODE == MD_ZO || MODE == MD_ZR) ? 2 : 1;
-  const ChainArgs& args = *cw.args;
-  unsigned char* smem = cw.smem;
-  const int lane = cw.lane;
-  const int RING = args.ring_units;
-  const u32x4* a_lds = reinterpret_cast<const u32x4*>(smem + S.a_off);
-  const float* sa_lds = reinterpret_cast<const float*>(smem + S.sa_off);
-  // output elements of the task, the operator and scale block of each streamed row
-  int elem[ROWS], op[ROWS];
-  int sc_base[ROWS], z_base[ROWS];
+  constexpr bool ZT = MODE == MD_ZO || MODE == MD_ZR;
+  const int RING = X.ring_units;
+  const u32x4* a_lds = reinterpret_cast<const u32x4*>(smem + X.a_off);
+  const float* sa_lds = reinterpret_cast<const float*>(smem + X.sa_off);
+  // output elements of the task, the operator and scale block of each streamed row, its first ring slot
+  int elem[ROWS], sc_base[ROWS], z_base[ROWS], rp[ROWS];
 #pragma unroll
   for (int r = 0; r < ROWS; ++r) {
     int e = 2 * t + (PAIR ? (r >> 1) : r);
-    e = e < S.N ? e : S.N - 1;
+    e = e < X.N ? e : X.N - 1;
     elem[r] = e;
-    op[r] = PAIR ? (r & 1) : 0;
-    if constexpr (MODE != MD_NONE) {
-      const unsigned long long sb = (unsigned long long)(S.scale[op[r]]) + (unsigned long long)((long)n0 * S.kg * 2);
-      sc_base[r] = S.sc_off + (op[r] * NTENS) * S.sc_units * 1024 + (int)(sb & 15ull) + (e - n0) * S.kg * 2;
-      if constexpr (NTENS == 2) {
-        const unsigned long long zb = (unsigned long long)(S.zeros[op[r]]) + (unsigned long long)((long)n0 * S.kg * 2);
-        z_base[r] = S.sc_off + (op[r] * NTENS + 1) * S.sc_units * 1024 + (int)(zb & 15ull) + (e - n0) * S.kg * 2;
-      }
-    }
+    const int op = PAIR ? (r & 1) : 0;
+    sc_base[r] = X.sc_rel[op] + (e - X.n0) * X.kg * 2;
+    z_base[r] = X.z_rel[op] + (e - X.n0) * X.kg * 2;
+    rp[r] = rpos + r * X.nc;
+    while (rp[r] >= RING) rp[r] -= RING;
   }
-  // bias / the caller's residual: asked for before the dots (every lane the same address: one request)
-  float resv[ROWS];
-  half_t biasv[ROWS];
+  // bias / the caller's residual: asked for before the dots (every lane the same address: one request), used behind them
+  uint16_t res_bits[ROWS], bias_bits[ROWS];
 #pragma unroll
   for (int r = 0; r < ROWS; ++r) {
-    resv[r] = 0.f;
-    biasv[r] = (half_t)0.f;
-    if (S.has_bias) biasv[r] = reinterpret_cast<const half_t*>(S.bias[op[r]])[elem[r]];
+    res_bits[r] = 0;
+    bias_bits[r] = 0;
+    if (X.has_bias) bias_bits[r] = CHAIN_G(uint16_t, X.bias[PAIR ? (r & 1) : 0])[elem[r]];
     if constexpr (!PAIR) {
-      if (S.residual) resv[r] = (float)reinterpret_cast<const half_t*>(S.residual)[elem[r]];
-      else if (S.res_stage >= 0) resv[r] = (float)reinterpret_cast<const half_t*>(smem + S.stash_off)[elem[r] - n0];
+      if (X.residual) res_bits[r] = CHAIN_G(uint16_t, X.residual)[elem[r]];
     }
   }
-  const float zint = (float)S.zint;
+  struct Ops {
+    u32x4 av[4 * PPW];
+    float sa;
+    u32x4 w[ROWS];
+    uint32_t sb[ROWS], zb[ROWS];
+  };
+  // every LDS operand of lane chunk c, asked for in one go (one wave per SIMD: nothing else hides an LDS round trip);
+  // the next chunk's are in flight while this one's dots run
+  auto load = [&](Ops& o, int c) {
+    const int chunk = c * 64 + lane;
+    int gi = 0;
+    if constexpr (MODE != MD_NONE) {
+      const int ch = chunk < X.cpr ? chunk : 0;           // (the single launch clamps the chunk before it takes the group)
+      gi = X.gq_shift >= 0 ? (ch >> X.gq_shift) : (int)__umulhi((uint32_t)ch, X.gq_magic);
+    }
+#pragma unroll
+    for (int j = 0; j < 4 * PPW; ++j) o.av[j] = a_lds[((long)c * PIECES + j) * 64 + lane];
+    o.sa = sa_lds[c * 64 + lane];
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+      o.w[r] = *reinterpret_cast<const u32x4*>(smem + X.ring_off + rp[r] * 1024 + lane * 16);
+      o.sb[r] = 0;
+      o.zb[r] = 0;
+      if constexpr (MODE != MD_NONE) o.sb[r] = *reinterpret_cast<const uint16_t*>(smem + sc_base[r] + gi * 2);
+      if constexpr (ZT) o.zb[r] = *reinterpret_cast<const uint16_t*>(smem + z_base[r] + gi * 2);
+      if (++rp[r] == RING) rp[r] = 0;
+    }
+  };
   float acc[ROWS];
 #pragma unroll
   for (int r = 0; r < ROWS; ++r) acc[r] = 0.f;
-  int upos = rseq % RING;                          // ring slot of (row 0, chunk 0)
-  int rp[ROWS];
+  auto compute = [&](const Ops& o) {
 #pragma unroll
-  for (int r = 0; r < ROWS; ++r) {
-    rp[r] = upos + r * S.nc;
-    while (rp[r] >= RING) rp[r] -= RING;
-  }
-  for (int c = 0; c < S.nc; ++c) {
-    const int chunk = c * 64 + lane;
-    const bool cvalid = chunk < S.cpr;
-    int gi = 0;
-    if constexpr (MODE != MD_NONE) {
-      const int ch = cvalid ? chunk : 0;           // (the single launch clamps the chunk before it takes the group)
-      gi = S.gq_shift >= 0 ? (ch >> S.gq_shift) : (int)__umulhi((uint32_t)ch, S.gq_magic);
-    }
-    u32x4 av[4 * PPW];
-#pragma unroll
-    for (int j = 0; j < 4 * PPW; ++j) av[j] = a_lds[((long)c * PIECES + j) * 64 + lane];
-    const float sa = sa_lds[c * 64 + lane];
-#pragma unroll
-    for (int r = 0; r < ROWS; ++r) {
-      const u32x4 w = *reinterpret_cast<const u32x4*>(smem + args.ring_off + rp[r] * 1024 + lane * 16);
-      uint32_t sb = 0, zb = 0;
-      if constexpr (MODE != MD_NONE) sb = *reinterpret_cast<const uint16_t*>(smem + sc_base[r] + gi * 2);
-      if constexpr (NTENS == 2) zb = *reinterpret_cast<const uint16_t*>(smem + z_base[r] + gi * 2);
-      chain_chunk<P>(w, av, sa, sb, zb, zint, S.flip, acc[r]);
-      if (++rp[r] == RING) rp[r] = 0;
+    for (int r = 0; r < ROWS; ++r) chain_chunk<P>(o.w[r], o.av, o.sa, o.sb[r], o.zb[r], X.zint, X.flip, acc[r]);
+  };
+  {
+    Ops oa, ob;
+    const int nc = X.nc;
+    load(oa, 0);
+    int c = 0;
+    for (;;) {
+      if (c + 1 < nc) load(ob, c + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      compute(oa);
+      if (++c >= nc) break;
+      if (c + 1 < nc) load(oa, c + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      compute(ob);
+      if (++c >= nc) break;
     }
   }
   float tot[ROWS];
@@ -568,7 +627,7 @@ __device__ __forceinline__ void chain_task(const ChainWave& cw, const ChainStage
   if (lane == 63) {
     half_t out[2];
     const int e0 = 2 * t;
-    const bool two = e0 + 1 < S.N;
+    const bool two = e0 + 1 < X.N;
     if constexpr (PAIR) {
       // both projections' results (+ their biases) rounded to float16 as their own launches would store them, then
       // torch's F.silu(gate) * up (wq_gemvx_kernel, PAIR members)
@@ -578,7 +637,7 @@ __device__ __forceinline__ void chain_task(const ChainWave& cw, const ChainStage
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
           h[q] = (half_t)tot[2 * j + q];
-          if (S.has_bias) h[q] = h[q] + biasv[2 * j + q];
+          if (X.has_bias) h[q] = h[q] + bits_to_half(bias_bits[2 * j + q]);
         }
         out[j] = silu_mul_h(h[0], h[1]);
       }
@@ -587,31 +646,39 @@ __device__ __forceinline__ void chain_task(const ChainWave& cw, const ChainStage
 #pragma unroll
       for (int r = 0; r < 2; ++r) {
         half_t h = (half_t)tot[r];
-        if (S.has_bias) h = h + biasv[r];
-        if (S.residual || S.res_stage >= 0) h = (half_t)((float)h + resv[r]);
+        if (X.has_bias) h = h + bits_to_half(bias_bits[r]);
+        if (X.has_res) {
+          const half_t rv = X.residual ? bits_to_half(res_bits[r]) : reinterpret_cast<const half_t*>(smem + X.stash_off)[elem[r] - X.n0];
+          h = (half_t)((float)h + (float)rv);
+        }
         out[r] = h;
       }
     }
     if (!two) out[1] = (half_t)0.f;
     const uint32_t bits = as_u32(half2_t{out[0], out[1]});
-    if (S.C) {
-      if (two) *reinterpret_cast<uint32_t*>(reinterpret_cast<half_t*>(S.C) + e0) = bits;
-      else reinterpret_cast<half_t*>(S.C)[e0] = out[0];
+    if (X.C) {
+      if (two) CHAIN_GW(uint32_t, X.C)[t] = bits;                 // elements 2t, 2t + 1: one aligned 4-byte store
+      else CHAIN_GW(uint16_t, X.C)[e0] = (uint16_t)(bits & 0xFFFFu);
     }
-    if (S.publish)
-      __hip_atomic_store((chain_gu64*)(args.gran + S.gran_off + t), ((unsigned long long)tag << 32) | bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (X.gran) __hip_atomic_store((chain_gu64*)(X.gran + t), ((unsigned long long)X.tag << 32) | bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
-template <class P>
+template <class P, int kChainSweepPasses>      // granule passes (1024 granules each) one sweep keeps in flight
 __device__ void chain_consumer(const ChainWave& cw) {
-  constexpr int EPW = P::EPW, IVW = EPW / 8, E = P::E;
+  constexpr int EPW = P::EPW, IVW = EPW / 8, E = P::E, MODE = P::MODE;
   constexpr int IPP = 2048 / EPW;                 // items per sweep pass (1024 granules = 2048 elements)
+  constexpr int IPL = IPP / 64;                   // ... per lane
+  constexpr int NTENS = (MODE == MD_ZO || MODE == MD_ZR) ? 2 : 1;
   const ChainArgs& args = *cw.args;
   unsigned char* smem = cw.smem;
   const int lane = cw.lane;
   const int cons = cw.wave - 1;
-  int rseq_base = 0, useq_base = 0, gt_base = 0;  // of the current stage, for this CU
+  const int NC = args.nconsumers;
+  const int RING = args.ring_units;
+  int rseq_base = 0, useq_base = 0;               // of the current stage, for this CU
+  int turn = cons;                                // tasks of a stage before this consumer's first one (round-robin across stages)
+  int rpos_base = 0;                              // rseq_base % RING
   uint32_t gen = 0;
   bool have_gen = false;
   auto need_gen = [&](int s) -> bool {
@@ -634,7 +701,7 @@ __device__ void chain_consumer(const ChainWave& cw) {
   for (int s = 0; s < args.nstages; ++s) {
     const ChainStage& S = args.st[s];
     int t0, t1;
-    cw.task_range(S, t0, t1);
+    cw.task_range(S.tasks, t0, t1);
     const int nt = t1 - t0;
     const int n0 = 2 * t0;
     chain_lds_st(smem, CL_CSTAGE0 + cons, (uint32_t)s);
@@ -647,22 +714,34 @@ __device__ void chain_consumer(const ChainWave& cw) {
         cw.stamp(4 + 3 * s);
         // the LDS tile of this input generation was read by the stages two generations back
         if (S.wait_stage > 0 && !cw.wait_cstage(S.wait_stage, CE_WAIT_STAGE, s)) return;
+        const int a_off = S.a_off, sa_off = S.sa_off, cpr = S.cpr;
         const int npass = (S.nc * 64 * E + 2047) / 2048;          // passes that cover the nc lane chunks (zero beyond K)
         const bool norm = S.norm_weight != nullptr;
+        // the norm's weight: asked for now, used when the whole row is here (4 passes: K <= 8192 at 4 bit, host-checked)
+        u32x4 nwr[4][IPL][IVW];
+        if (norm) {
+#pragma unroll
+          for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int q = 0; q < IPL; ++q) {
+              const int i = p * IPP + q * 64 + lane;
+              const bool valid = p < npass && (i >> 2) < cpr;
+#pragma unroll
+              for (int v = 0; v < IVW; ++v) nwr[p][q][v] = CHAIN_G(u32x4, S.norm_weight)[(long)(valid ? i : 0) * IVW + v];
+            }
+        }
         if (S.in_kind == 0) {
-          // the caller's vector: plain loads, through the raw scratch only when the norm needs the whole row first
-          const unsigned char* A = reinterpret_cast<const unsigned char*>(S.A);
-          constexpr int IPL = IPP / 64;                            // items per lane and pass
-          for (int p = 0; p < npass; p += 2) {                     // two passes per memory round trip
+          // the caller's vector: plain loads, two passes per memory round trip
+          for (int p = 0; p < npass; p += 2) {
             u32x4 x[2][IPL][IVW];
 #pragma unroll
             for (int h = 0; h < 2; ++h)
 #pragma unroll
               for (int q = 0; q < IPL; ++q) {
                 const int i = (p + h) * IPP + q * 64 + lane;
-                const bool valid = (i >> 2) < S.cpr;                 // (also false for the whole pass p + 1 == npass)
+                const bool valid = (i >> 2) < cpr;                   // (also false for the whole pass p + 1 == npass)
 #pragma unroll
-                for (int v = 0; v < IVW; ++v) x[h][q][v] = reinterpret_cast<const u32x4*>(A + (long)(valid ? i : 0) * (EPW * 2))[v];
+                for (int v = 0; v < IVW; ++v) x[h][q][v] = CHAIN_G(u32x4, S.A)[(long)(valid ? i : 0) * IVW + v];
               }
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
@@ -672,11 +751,12 @@ __device__ void chain_consumer(const ChainWave& cw) {
               for (int q = 0; q < IPL; ++q)
 #pragma unroll
                 for (int v = 0; v < IVW; ++v) reinterpret_cast<u32x4*>(rawp + (long)(q * 64 + lane) * (EPW * 2))[v] = x[h][q][v];
-              if (!norm) chain_stage_items<P, false>(smem, S, rawp, (p + h) * IPP, IPP, lane, 0.f);
+              if (!norm) chain_stage_pass<P, false>(smem, a_off, sa_off, cpr, rawp, (p + h) * IPP, lane, 0.f, nullptr);
             }
           }
         } else {
-          // granules of stage S.src: 16 relaxed agent-scope 8-byte loads per lane and pass, re-read until every tag matches
+          // granules of stage S.src: relaxed agent-scope 8-byte loads, 16 per lane and pass, up to kChainSweepPasses passes in
+          // flight; a pass is staged when every one of its tags matches, the incomplete ones are read again after a nap
           if (!need_gen(s)) return;
           const uint32_t tag = gen * 16u + (uint32_t)S.src + 1u;
           const int ng = S.K / 2;
@@ -687,54 +767,60 @@ __device__ void chain_consumer(const ChainWave& cw) {
           if (S.stash_for >= 0) {
             const ChainStage& S2 = args.st[S.stash_for];
             int u0, u1;
-            cw.task_range(S2, u0, u1);
+            cw.task_range(S2.tasks, u0, u1);
             stash_n0 = 2 * u0;
             stash_nr = 2 * (u1 - u0);
             if (stash_n0 + stash_nr > S2.N) stash_nr = S2.N - stash_n0;
             stash_off = S2.stash_off;
           }
-          unsigned long long x0[16], x1[16];
-          auto load_pass = [&](int p, unsigned long long (&x)[16]) {
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-              const int gi = p * 1024 + k * 64 + lane;
-              x[k] = gi < ng ? __hip_atomic_load(g + gi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ((unsigned long long)tag << 32);
-            }
-          };
           const int npl = (ng + 1023) / 1024;                      // passes that have granules to load
-          if (npl > 0) load_pass(0, x0);
-          for (int p = 0; p < npass; ++p) {
-            unsigned char* rawp = smem + args.raw_off + (norm ? p : 0) * 4096;
-            if (p < npl) {
-              if (args.sweep_depth > 1 && p + 1 < npl) load_pass(p + 1, x1);
-              unsigned n_ = 0;
-              unsigned long long t_ = 0;
-              for (;;) {
+          for (int base = 0; base < npl; base += kChainSweepPasses) {
+            unsigned long long x[kChainSweepPasses][16];
+            unsigned pending = 0;
+#pragma unroll
+            for (int j = 0; j < kChainSweepPasses; ++j)
+              if (base + j < npl) pending |= 1u << j;
+            unsigned n_ = 0;
+            unsigned long long t_ = 0;
+            for (;;) {
+#pragma unroll
+              for (int j = 0; j < kChainSweepPasses; ++j) {
+                if (!((pending >> j) & 1u)) continue;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                  const int gi = (base + j) * 1024 + k * 64 + lane;
+                  x[j][k] = gi < ng ? __hip_atomic_load(g + gi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ((unsigned long long)tag << 32);
+                }
+              }
+#pragma unroll
+              for (int j = 0; j < kChainSweepPasses; ++j) {
+                if (!((pending >> j) & 1u)) continue;
                 bool ok = true;
 #pragma unroll
-                for (int k = 0; k < 16; ++k) ok &= (uint32_t)(x0[k] >> 32) == tag;
-                if (__all(ok)) break;
-                if (cw.expired(n_, t_)) {
-                  cw.fail(CE_SWEEP, s);
-                  return;
+                for (int k = 0; k < 16; ++k) ok &= (uint32_t)(x[j][k] >> 32) == tag;
+                if (!__all(ok)) continue;
+                pending &= ~(1u << j);
+                const int p = base + j;
+                unsigned char* rawp = smem + args.raw_off + (norm ? p : 0) * 4096;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) reinterpret_cast<uint32_t*>(rawp)[k * 64 + lane] = (uint32_t)x[j][k];
+                for (int i = lane; i < stash_nr; i += 64) {
+                  const int n = stash_n0 + i - p * 2048;
+                  if (n >= 0 && n < 2048) reinterpret_cast<uint16_t*>(smem + stash_off)[i] = reinterpret_cast<const uint16_t*>(rawp)[n];
                 }
-                load_pass(p, x0);
+                if (!norm) chain_stage_pass<P, false>(smem, a_off, sa_off, cpr, rawp, p * IPP, lane, 0.f, nullptr);
               }
-#pragma unroll
-              for (int k = 0; k < 16; ++k) reinterpret_cast<uint32_t*>(rawp)[k * 64 + lane] = (uint32_t)x0[k];
-              for (int i = lane; i < stash_nr; i += 64) {
-                const int n = stash_n0 + i - p * 2048;
-                if (n >= 0 && n < 2048) reinterpret_cast<uint16_t*>(smem + stash_off)[i] = reinterpret_cast<const uint16_t*>(rawp)[n];
-              }
-              if (args.sweep_depth > 1 && p + 1 < npl) {
-#pragma unroll
-                for (int k = 0; k < 16; ++k) x0[k] = x1[k];
-              } else if (p + 1 < npl) {
-                load_pass(p + 1, x0);
+              if (!pending) break;
+              for (int i = 0; i < args.sweep_sleep; ++i) __builtin_amdgcn_s_sleep(8);       // ~0.2 us each
+              if (cw.expired(n_, t_)) {
+                cw.fail(CE_SWEEP, s);
+                return;
               }
             }
-            if (!norm) chain_stage_items<P, false>(smem, S, rawp, p * IPP, IPP, lane, 0.f);
           }
+          // lane chunks past the last granule (partial coverage of the last pass pair at 1 / 2 bit): zeros
+          if (!norm)
+            for (int p = npl; p < npass; ++p) chain_stage_pass<P, false>(smem, a_off, sa_off, cpr, smem + args.raw_off, p * IPP, lane, 0.f, nullptr);
           if (args.thin) chain_lds_st(smem, CL_SWEEPING, 0u);
           // every workgroup of this launch has read the generation by now (its granules are here): the next launch's
           if (s == args.bump_stage && cw.b == 0 && lane == 0)
@@ -742,7 +828,9 @@ __device__ void chain_consumer(const ChainWave& cw) {
         }
         if (norm) {
           const float r = chain_norm_rinv<P>(smem, args, S, lane);
-          for (int p = 0; p < npass; ++p) chain_stage_items<P, true>(smem, S, smem + args.raw_off + p * 4096, p * IPP, IPP, lane, r);
+#pragma unroll
+          for (int p = 0; p < 4; ++p)
+            if (p < npass) chain_stage_pass<P, true>(smem, a_off, sa_off, cpr, smem + args.raw_off + p * 4096, p * IPP, lane, r, nwr[p]);
         }
         CHAIN_LDS_RELEASE();
         chain_lds_st(smem, CL_ACT_READY + s, 1u);
@@ -753,40 +841,75 @@ __device__ void chain_consumer(const ChainWave& cw) {
       CHAIN_LDS_ACQUIRE();
     }
     // ---- this consumer's tasks of the stage ----
-    uint32_t tag = 0;
+    ChainTaskCtx X;
+    X.nc = S.nc; X.cpr = S.cpr; X.kg = S.kg; X.gq_shift = S.gq_shift; X.N = S.N; X.n0 = n0;
+    X.gq_magic = S.gq_magic; X.flip = S.flip;
+    X.a_off = S.a_off; X.sa_off = S.sa_off; X.ring_off = args.ring_off; X.ring_units = RING;
+#pragma unroll
+    for (int op = 0; op < 2; ++op) {
+      X.sc_rel[op] = 0;
+      X.z_rel[op] = 0;
+      if (MODE != MD_NONE && (op == 0 || S.pair)) {
+        const unsigned long long sb = (unsigned long long)(S.scale[op]) + (unsigned long long)((long)n0 * S.kg * 2);
+        X.sc_rel[op] = S.sc_off + (op * NTENS) * S.sc_units * 1024 + (int)(sb & 15ull);
+        if (NTENS == 2) {
+          const unsigned long long zb = (unsigned long long)(S.zeros[op]) + (unsigned long long)((long)n0 * S.kg * 2);
+          X.z_rel[op] = S.sc_off + (op * NTENS + 1) * S.sc_units * 1024 + (int)(zb & 15ull);
+        }
+      }
+    }
+    X.zint = (float)S.zint;
+    X.has_bias = S.has_bias;
+    X.has_res = (S.residual != nullptr || S.res_stage >= 0) ? 1 : 0;
+    X.stash_off = S.stash_off;
+    X.bias[0] = S.bias[0]; X.bias[1] = S.bias[1];
+    X.residual = S.residual;
+    X.C = S.C;
+    X.gran = nullptr;
+    X.tag = 0;
     if (S.publish) {
       if (!need_gen(s)) return;
-      tag = gen * 16u + (uint32_t)s + 1u;
+      X.tag = gen * 16u + (uint32_t)s + 1u;
+      X.gran = args.gran + S.gran_off;
     }
-    int k = cons - gt_base % kChainConsumers;
-    if (k < 0) k += kChainConsumers;
+    const int un = S.un, pair = S.pair;
     const int need_base = useq_base + S.nsc;
-    for (; k < nt; k += kChainConsumers) {
-      const int rseq = rseq_base + k * S.un;
-      if (!cw.wait_ge(CL_LANDED, (uint32_t)(need_base + (k + 1) * S.un), CE_WAIT_LANDED, s)) return;
+    // ring slot of this consumer's first task, then + NC tasks per step
+    int step = NC * un;
+    while (step >= RING) step -= RING;
+    int rpos = rpos_base + turn * un;
+    while (rpos >= RING) rpos -= RING;
+    int k = turn;
+    for (; k < nt; k += NC) {
+      if (!cw.wait_ge(CL_LANDED, (uint32_t)(need_base + (k + 1) * un), CE_WAIT_LANDED, s)) return;
       CHAIN_LDS_ACQUIRE();
-      if (S.pair) chain_task<P, 4>(cw, S, s, t0 + k, n0, rseq, tag);
-      else chain_task<P, 2>(cw, S, s, t0 + k, n0, rseq, tag);
+      if (pair) chain_task<P, 4>(smem, X, t0 + k, rpos, lane);
+      else chain_task<P, 2>(smem, X, t0 + k, rpos, lane);
       // the ring slots of this task are free: the next unfinished task of this consumer starts here (a later stage's
       // first one is not known yet - the end of this stage's units is a safe lower bound)
-      int next = rseq + kChainConsumers * S.un;
-      if (k + kChainConsumers >= nt) next = rseq_base + nt * S.un;
+      int next = rseq_base + (k + NC) * un;
+      if (k + NC >= nt) next = rseq_base + nt * un;
       CHAIN_LDS_RELEASE();
       chain_lds_st(smem, CL_NEXT0 + cons, (uint32_t)next);
+      rpos += step;
+      if (rpos >= RING) rpos -= RING;
     }
     // (also when no task of this stage fell to this consumer: its frontier still moves past the stage)
-    chain_lds_st(smem, CL_NEXT0 + cons, (uint32_t)(rseq_base + nt * S.un));
+    chain_lds_st(smem, CL_NEXT0 + cons, (uint32_t)(rseq_base + nt * un));
     cw.stamp(6 + 3 * s);
-    gt_base += nt;
-    rseq_base += nt * S.un;
-    useq_base += S.nsc + nt * S.un;
+    turn = k - nt;                                  // tasks of the next stage in front of this consumer's first
+    rseq_base += nt * un;
+    useq_base += S.nsc + nt * un;
+    rpos_base = rseq_base % RING;
   }
   chain_lds_st(smem, CL_NEXT0 + cons, 0x7fffffffu);
-  chain_lds_st(smem, CL_CSTAGE0 + cons, (uint32_t)(args.nstages + 1));
+  chain_lds_st(smem, CL_CSTAGE0 + cons, 0x7fffffffu);
 }
 
-template <int BITS, int LAYOUT, int MODE>
-__global__ void __launch_bounds__(256) wq_chain_kernel(const ChainArgs args) {
+// WAVES = 4: the loader + 3 consumers, one wave per SIMD (512 registers each: six sweep passes in flight);
+// WAVES = 8: the loader + 7 consumers, two per SIMD (256 registers: two passes)
+template <int BITS, int LAYOUT, int MODE, int WAVES>
+__global__ void __launch_bounds__(64 * WAVES) wq_chain_kernel(const ChainArgs args) {
   using P = GemvxPolicy<BITS, LAYOUT, MODE, 1, 2, 2>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int tid = threadIdx.x;
@@ -798,15 +921,19 @@ __global__ void __launch_bounds__(256) wq_chain_kernel(const ChainArgs args) {
   cw.b = (int)blockIdx.x;
   cw.G = (int)gridDim.x;
   cw.timeout = args.timeout_ticks;
-  if (tid < CL_WORDS) reinterpret_cast<uint32_t*>(smem_raw)[tid] = 0u;
+  if (tid < CL_WORDS) {
+    const int slot = tid & 7;
+    const bool unused = (tid >= CL_NEXT0 && tid < CL_CSTAGE0 + 8) && slot >= args.nconsumers;
+    reinterpret_cast<uint32_t*>(smem_raw)[tid] = unused ? 0x7fffffffu : 0u;
+  }
   __syncthreads();
   cw.stamp(0);
   if (cw.wave == 0) chain_loader<P>(cw);
-  else chain_consumer<P>(cw);
+  else chain_consumer<P, (WAVES == 4 ? 4 : 2)>(cw);
   cw.stamp(3);
 }
 
 typedef void (*chain_fn)(const ChainArgs);
-chain_fn pick_chain(int bits, int layout, int mode);
+chain_fn pick_chain(int bits, int layout, int mode, int waves);
 
 }  // namespace wqaa

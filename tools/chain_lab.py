@@ -85,43 +85,68 @@ def graph_us(fn):
     return per
 
 
-print(json.dumps({"plan": chain_plan(steps_of(layers[0], x0, chs[0], cas[0], cos[0]))}), flush=True)
-run_launches(); torch.cuda.synchronize()
-run_chain(True); torch.cuda.synchronize()
-st = chain_status()
-same = [bool(torch.equal(a, b)) for a, b in zip(hs + acts + outs, chs + cas + cos)]
-print(json.dumps({"status": st, "bit_identical_stages": f"{sum(same)}/{len(same)}",
-                  "first_diffs": [int((a != b).sum()) for a, b in zip(hs + acts + outs, chs + cas + cos)][:3 * args.layers]}), flush=True)
-nbytes = sum(2 * t.numel() if t.dtype == torch.float16 else t.numel() for L in layers[:1] for k in "ogud" for t in L[k])
-res = {}
-for name, fn in (("launches_3_per_layer", run_launches), ("chain_keep_intermediates", lambda: run_chain(True)),
-                 ("chain", lambda: run_chain(False)), ("launches_again", run_launches), ("chain_again", lambda: run_chain(False))):
-    per = graph_us(fn)
-    res[name] = {"us_per_layer_tail": [round(p, 2) for p in per], "median": round(float(np.median(per)), 2),
-                 "GBps": round(nbytes / np.median(per) / 1e3, 1)}
-    print(json.dumps({name: res[name]}), flush=True)
-print(json.dumps({"status_after": chain_status(), "weight_bytes_per_tail": nbytes}), flush=True)
+def variant(name, env):
+    """one configuration of the persistent member (plan-time switches: chain_plan re-reads them)"""
+    for k in ("WQAA_CHAIN_WAVES", "WQAA_CHAIN_THIN", "WQAA_CHAIN_SWEEP_SLEEP", "WQAA_CHAIN_RING", "WQAA_CHAIN_TRACE"):
+        os.environ.pop(k, None)
+    os.environ.update(env)
+    plan = chain_plan(steps_of(layers[0], x0, chs[0], cas[0], cos[0]))
+    for t in chs + cas + cos:
+        t.zero_()
+    run_chain(True); torch.cuda.synchronize()
+    st = chain_status()
+    same = [bool(torch.equal(a, b)) for a, b in zip(hs + acts + outs, chs + cas + cos)]
+    per = graph_us(lambda: run_chain(False))
+    rec = {"variant": name, "env": env, "plan": (plan["plan"] or {}).get("name"), "threads": (plan["plan"] or {}).get("threads"),
+           "error": st["error"], "bit_identical_stages": f"{sum(same)}/{len(same)}",
+           "us_per_layer_tail": [round(p, 2) for p in per], "median": round(float(np.median(per)), 2),
+           "GBps": round(nbytes / np.median(per) / 1e3, 1)}
+    print(json.dumps(rec), flush=True)
+    return rec
 
-if not args.no_trace:
+
+def timeline(name, env):
+    os.environ.update(env)
     os.environ["WQAA_CHAIN_TRACE"] = "1"
-    x = x0
+    chain_plan(steps_of(layers[0], x0, None, None, cos[0]))
     matmul_chain(steps_of(layers[0], x0, None, None, cos[0]))
     torch.cuda.synchronize()
     matmul_chain(steps_of(layers[1], x0, None, None, cos[1]))       # cold weights for the traced launch
     torch.cuda.synchronize()
     tr = chain_trace().astype(np.int64)
     os.environ.pop("WQAA_CHAIN_TRACE")
-    if tr.size:
-        t0 = tr[:, :, 0][tr[:, :, 0] > 0].min()
-        names = {0: "wave start", 1: "loader: first DMA issued", 2: "loader: stream drained", 3: "wave end"}
-        for s in range(3):
-            names[4 + 3 * s] = f"stage {s}: stager starts"
-            names[5 + 3 * s] = f"stage {s}: input tile ready"
-            names[6 + 3 * s] = f"stage {s}: this wave's tasks done"
-        print("time line of one launch, microseconds after the first wave's start (100 MHz clock): min / median / max over the waves that stamped")
-        for i in sorted(names):
-            v = tr[:, :, i]
-            v = v[v > 0]
-            if v.size:
-                u = (v - t0) / 100.0
-                print(f"  {names[i]:44s} n={v.size:4d}  {u.min():7.2f} {np.median(u):7.2f} {u.max():7.2f}")
+    for k in env:
+        os.environ.pop(k, None)
+    chain_plan(steps_of(layers[0], x0, None, None, cos[0]))
+    if not tr.size:
+        return
+    t0 = tr[:, :, 0][tr[:, :, 0] > 0].min()
+    names = {0: "wave start", 1: "loader: first DMA issued", 2: "loader: stream drained", 3: "wave end"}
+    for s in range(3):
+        names[4 + 3 * s] = f"stage {s}: stager starts"
+        names[5 + 3 * s] = f"stage {s}: input tile ready"
+        names[6 + 3 * s] = f"stage {s}: this wave's tasks done"
+    print(f"time line of one launch [{name}], microseconds after the first wave's start (100 MHz clock): min / median / max over the waves that stamped")
+    for i in sorted(names):
+        v = tr[:, :, i]
+        v = v[v > t0 - 100000]
+        if v.size:
+            u = (v - t0) / 100.0
+            print(f"  {names[i]:44s} n={v.size:4d}  {u.min():7.2f} {np.median(u):7.2f} {u.max():7.2f}")
+
+
+run_launches(); torch.cuda.synchronize()
+nbytes = sum(2 * t.numel() if t.dtype == torch.float16 else t.numel() for L in layers[:1] for k in "ogud" for t in L[k])
+per = graph_us(run_launches)
+print(json.dumps({"variant": "launches_3_per_layer", "us_per_layer_tail": [round(p, 2) for p in per], "median": round(float(np.median(per)), 2),
+                  "GBps": round(nbytes / np.median(per) / 1e3, 1), "weight_bytes_per_tail": nbytes}), flush=True)
+VARIANTS = [("w4", {}), ("w8", {"WQAA_CHAIN_WAVES": "8"}), ("w4_nothin", {"WQAA_CHAIN_THIN": "0"}), ("w4_sleep0", {"WQAA_CHAIN_SWEEP_SLEEP": "0"}),
+            ("w4_sleep5", {"WQAA_CHAIN_SWEEP_SLEEP": "5"}), ("w8_nothin", {"WQAA_CHAIN_WAVES": "8", "WQAA_CHAIN_THIN": "0"}),
+            ("w4_ring64", {"WQAA_CHAIN_RING": "64"})]
+for name, env in VARIANTS:
+    variant(name, env)
+per = graph_us(run_launches)
+print(json.dumps({"variant": "launches_again", "median": round(float(np.median(per)), 2)}), flush=True)
+if not args.no_trace:
+    timeline("w4", {})
+    timeline("w8", {"WQAA_CHAIN_WAVES": "8"})
