@@ -123,7 +123,7 @@ static ChainSlab* chain_slab(hipStream_t stream, size_t bytes, bool create) {
 
 // switches (A/B and lab aids; all plan-time like every WQAA_* variable: read again when wqaa_select / wqaa_chain_plan bump the epoch)
 struct ChainKnobs {
-  int fuse, waves, ring, thin, sweep_sleep, trace;
+  int fuse, waves, ring, thin, sweep_sleep, trace, lab;
   unsigned timeout_ticks;
 };
 static const ChainKnobs& chain_knobs() {
@@ -142,6 +142,7 @@ static const ChainKnobs& chain_knobs() {
     k.sweep_sleep = geti("WQAA_CHAIN_SWEEP_SLEEP", 2);
     if (k.sweep_sleep < 0) k.sweep_sleep = 0;
     k.trace = geti("WQAA_CHAIN_TRACE", 0);
+    k.lab = geti("WQAA_CHAIN_LAB", 0);
     const int ms = geti("WQAA_CHAIN_TIMEOUT_MS", 250);
     k.timeout_ticks = (unsigned)(ms > 0 ? ms : 1) * 100000u;          // s_memrealtime runs at 100 MHz
     seen = ep;
@@ -424,6 +425,7 @@ static int chain_build(const wqaa_chain_item* items, int count, int m, ChainBuil
   A.thin = knobs.thin;
   A.sweep_sleep = knobs.sweep_sleep;
   A.timeout_ticks = knobs.timeout_ticks;
+  A.lab = knobs.lab;
   out->gran_count = gran;
   return WQAA_OK;
 }

@@ -93,6 +93,7 @@ struct ChainArgs {
   int thin;                 // 1: one fill outstanding while a consumer of this CU sweeps
   int sweep_sleep;          // naps of ~0.2 us between two reads of an incomplete sweep
   unsigned timeout_ticks;   // s_memrealtime ticks (100 MHz) a wait may take
+  int lab;                  // tools only, results wrong by construction: 1 no dots, 2 consumers do not wait for the weights, 4 no sweeps (tiles "ready" at once), 8 default-policy DMA
   unsigned long long* gran;
   uint32_t* ctl;            // [0] generation, [1] first error
   unsigned long long* trace;  // lab: [workgroup][wave][32] time stamps, or NULL
@@ -137,8 +138,15 @@ __device__ __forceinline__ int chain_lds_min8(const unsigned char* smem, int wor
 
 // one 1 KiB LDS-DMA unit: lane l's 16 bytes at sbase + voff land at LDS byte lds_dst + 16 * l.  M0 is saved and restored
 // (the compiler owns it); the s_nop 4 covers v_readfirstlane -> SGPR -> VMEM base, the s_nop 0 M0 -> LDS-DMA.
-__device__ __forceinline__ void chain_dma(unsigned lds_dst, unsigned voff, unsigned long long sbase) {
+__device__ __forceinline__ void chain_dma(unsigned lds_dst, unsigned voff, unsigned long long sbase, bool default_policy = false) {
   unsigned keep;
+  if (default_policy) {      // (lab: the weight stream without the non-temporal hint)
+    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(lds_dst), "s"(sbase)
+                 : "memory");
+    return;
+  }
   asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3 nt\n\ts_mov_b32 m0, %0"
                : "=&s"(keep)
                : "v"(voff), "s"(lds_dst), "s"(sbase)
@@ -223,6 +231,7 @@ __device__ void chain_loader(const ChainWave& cw) {
   int frontier = 0;       // cached min(next task's ring sequence) over the consumers
   int landed_pub = 0;
   bool dead = false;
+  const bool dflt = (args.lab & 8) != 0;
   const unsigned voff_full = (unsigned)lane * 16u;
   cw.stamp(1);
 
@@ -338,19 +347,20 @@ __device__ void chain_loader(const ChainWave& cw) {
         const unsigned long long base = (pair && (r & 1)) ? B1 : B0;
         unsigned long long src = chain_uniform64(base + (unsigned long long)((long)n * row_bytes));
         for (int c = 0; c < nfull; ++c) {
-          chain_dma(dst, voff_full, src);
+          chain_dma(dst, voff_full, src, dflt);
           src += 1024ull;
           dst += 1024u;
           if (dst == ring_end) dst = (unsigned)ring_off;
           ++rseq;
           ++issued;
           if (++in_fill == kChainFill) {
+            if ((issued & 63) == 0 && issued <= 256) cw.stamp(27 + (issued >> 6));      // lab: 64 / 128 / 192 / 256 units issued
             boundary(s);
             if (dead) return;
           }
         }
         if (tail_partial) {
-          chain_dma(dst, voff_tail, src);
+          chain_dma(dst, voff_tail, src, dflt);
           dst += 1024u;
           if (dst == ring_end) dst = (unsigned)ring_off;
           ++rseq;
@@ -773,7 +783,7 @@ __device__ void chain_consumer(const ChainWave& cw) {
             if (stash_n0 + stash_nr > S2.N) stash_nr = S2.N - stash_n0;
             stash_off = S2.stash_off;
           }
-          const int npl = (ng + 1023) / 1024;                      // passes that have granules to load
+          const int npl = (args.lab & 4) ? 0 : (ng + 1023) / 1024;     // passes that have granules to load
           for (int base = 0; base < npl; base += kChainSweepPasses) {
             unsigned long long x[kChainSweepPasses][16];
             unsigned pending = 0;
@@ -881,9 +891,11 @@ __device__ void chain_consumer(const ChainWave& cw) {
     while (rpos >= RING) rpos -= RING;
     int k = turn;
     for (; k < nt; k += NC) {
-      if (!cw.wait_ge(CL_LANDED, (uint32_t)(need_base + (k + 1) * un), CE_WAIT_LANDED, s)) return;
+      if (!(args.lab & 2) && !cw.wait_ge(CL_LANDED, (uint32_t)(need_base + (k + 1) * un), CE_WAIT_LANDED, s)) return;
       CHAIN_LDS_ACQUIRE();
-      if (pair) chain_task<P, 4>(smem, X, t0 + k, rpos, lane);
+      if (args.lab & 1) {
+        if (X.gran && lane == 63) __hip_atomic_store((chain_gu64*)(X.gran + t0 + k), (unsigned long long)X.tag << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else if (pair) chain_task<P, 4>(smem, X, t0 + k, rpos, lane);
       else chain_task<P, 2>(smem, X, t0 + k, rpos, lane);
       // the ring slots of this task are free: the next unfinished task of this consumer starts here (a later stage's
       // first one is not known yet - the end of this stage's units is a safe lower bound)

@@ -87,7 +87,7 @@ def graph_us(fn):
 
 def variant(name, env):
     """one configuration of the persistent member (plan-time switches: chain_plan re-reads them)"""
-    for k in ("WQAA_CHAIN_WAVES", "WQAA_CHAIN_THIN", "WQAA_CHAIN_SWEEP_SLEEP", "WQAA_CHAIN_RING", "WQAA_CHAIN_TRACE"):
+    for k in ("WQAA_CHAIN_WAVES", "WQAA_CHAIN_THIN", "WQAA_CHAIN_SWEEP_SLEEP", "WQAA_CHAIN_RING", "WQAA_CHAIN_TRACE", "WQAA_CHAIN_LAB"):
         os.environ.pop(k, None)
     os.environ.update(env)
     plan = chain_plan(steps_of(layers[0], x0, chs[0], cas[0], cos[0]))
@@ -121,7 +121,8 @@ def timeline(name, env):
     if not tr.size:
         return
     t0 = tr[:, :, 0][tr[:, :, 0] > 0].min()
-    names = {0: "wave start", 1: "loader: first DMA issued", 2: "loader: stream drained", 3: "wave end"}
+    names = {0: "wave start", 1: "loader: first DMA issued", 2: "loader: stream drained", 3: "wave end", 28: "loader: 64 units issued",
+             29: "loader: 128 units issued", 30: "loader: 192 units issued", 31: "loader: 256 units issued"}
     for s in range(3):
         names[4 + 3 * s] = f"stage {s}: stager starts"
         names[5 + 3 * s] = f"stage {s}: input tile ready"
@@ -140,13 +141,16 @@ nbytes = sum(2 * t.numel() if t.dtype == torch.float16 else t.numel() for L in l
 per = graph_us(run_launches)
 print(json.dumps({"variant": "launches_3_per_layer", "us_per_layer_tail": [round(p, 2) for p in per], "median": round(float(np.median(per)), 2),
                   "GBps": round(nbytes / np.median(per) / 1e3, 1), "weight_bytes_per_tail": nbytes}), flush=True)
-VARIANTS = [("w4", {}), ("w8", {"WQAA_CHAIN_WAVES": "8"}), ("w4_nothin", {"WQAA_CHAIN_THIN": "0"}), ("w4_sleep0", {"WQAA_CHAIN_SWEEP_SLEEP": "0"}),
-            ("w4_sleep5", {"WQAA_CHAIN_SWEEP_SLEEP": "5"}), ("w8_nothin", {"WQAA_CHAIN_WAVES": "8", "WQAA_CHAIN_THIN": "0"}),
-            ("w4_ring64", {"WQAA_CHAIN_RING": "64"})]
+# lab bits (results wrong by construction): 1 no dots, 2 consumers do not wait for the weights, 4 no sweeps, 8 default-policy DMA
+VARIANTS = [("w4", {}), ("w8", {"WQAA_CHAIN_WAVES": "8"}),
+            ("lab7_loader_free_running", {"WQAA_CHAIN_LAB": "7"}), ("lab15_same_default_policy", {"WQAA_CHAIN_LAB": "15"}),
+            ("lab5_no_dots_no_sweeps", {"WQAA_CHAIN_LAB": "5"}), ("lab4_no_sweeps", {"WQAA_CHAIN_LAB": "4"}), ("lab1_no_dots", {"WQAA_CHAIN_LAB": "1"}),
+            ("lab8_default_policy", {"WQAA_CHAIN_LAB": "8"})]
 for name, env in VARIANTS:
     variant(name, env)
 per = graph_us(run_launches)
 print(json.dumps({"variant": "launches_again", "median": round(float(np.median(per)), 2)}), flush=True)
 if not args.no_trace:
     timeline("w4", {})
-    timeline("w8", {"WQAA_CHAIN_WAVES": "8"})
+    timeline("lab7_loader_free_running", {"WQAA_CHAIN_LAB": "7"})
+    timeline("lab5_no_dots_no_sweeps", {"WQAA_CHAIN_LAB": "5"})
