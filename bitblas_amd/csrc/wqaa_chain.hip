@@ -9,23 +9,19 @@
 namespace wqaa {
 
 // member table: one kernel per (bits, layout, scale / zeros mode) - every stage of a chain shares the format
-chain_fn pick_chain(int bits, int layout, int mode, int waves) {
-#define WQAA_CH(B, L, W)                                                \
+chain_fn pick_chain(int bits, int layout, int mode) {
+#define WQAA_CH(B, L)                                                   \
   switch (mode) {                                                       \
-    case MD_NONE: return wq_chain_kernel<B, L, MD_NONE, W>;             \
-    case MD_S: return wq_chain_kernel<B, L, MD_S, W>;                   \
-    case MD_ZO: return wq_chain_kernel<B, L, MD_ZO, W>;                 \
-    case MD_ZR: return wq_chain_kernel<B, L, MD_ZR, W>;                 \
+    case MD_NONE: return wq_chain_kernel<B, L, MD_NONE>;                \
+    case MD_S: return wq_chain_kernel<B, L, MD_S>;                      \
+    case MD_ZO: return wq_chain_kernel<B, L, MD_ZO>;                    \
+    case MD_ZR: return wq_chain_kernel<B, L, MD_ZR>;                    \
   }                                                                     \
   return nullptr;
-  if (waves == 8) {   // lab member: the loader + 7 consumers (two waves per SIMD), the headline format only
-    if (bits == 4 && layout == LAYOUT_LOP3 && mode == MD_S) return wq_chain_kernel<4, LAYOUT_LOP3, MD_S, 8>;
-    return nullptr;
-  }
-  if (bits == 4 && layout == LAYOUT_LOP3) { WQAA_CH(4, LAYOUT_LOP3, 4) }
-  if (bits == 4 && layout == LAYOUT_PLAIN) { WQAA_CH(4, LAYOUT_PLAIN, 4) }
-  if (bits == 2 && layout == LAYOUT_LOP3) { WQAA_CH(2, LAYOUT_LOP3, 4) }
-  if (bits == 2 && layout == LAYOUT_PLAIN) { WQAA_CH(2, LAYOUT_PLAIN, 4) }
+  if (bits == 4 && layout == LAYOUT_LOP3) { WQAA_CH(4, LAYOUT_LOP3) }
+  if (bits == 4 && layout == LAYOUT_PLAIN) { WQAA_CH(4, LAYOUT_PLAIN) }
+  if (bits == 2 && layout == LAYOUT_LOP3) { WQAA_CH(2, LAYOUT_LOP3) }
+  if (bits == 2 && layout == LAYOUT_PLAIN) { WQAA_CH(2, LAYOUT_PLAIN) }
 #undef WQAA_CH
   return nullptr;
 }
@@ -123,7 +119,7 @@ static ChainSlab* chain_slab(hipStream_t stream, size_t bytes, bool create) {
 
 // switches (A/B and lab aids; all plan-time like every WQAA_* variable: read again when wqaa_select / wqaa_chain_plan bump the epoch)
 struct ChainKnobs {
-  int fuse, waves, ring, thin, sweep_sleep, trace, lab;
+  int fuse, lanes, ring, thin, sweep_sleep, trace, lab;
   unsigned timeout_ticks;
 };
 static const ChainKnobs& chain_knobs() {
@@ -136,7 +132,7 @@ static const ChainKnobs& chain_knobs() {
       return f ? atoi(f) : dflt;
     };
     k.fuse = geti("WQAA_CHAIN_FUSE", 1) != 0;
-    k.waves = geti("WQAA_CHAIN_WAVES", 4);
+    k.lanes = geti("WQAA_CHAIN_LANES", 0);
     k.ring = geti("WQAA_CHAIN_RING", 0);
     k.thin = geti("WQAA_CHAIN_THIN", 1) != 0;
     k.sweep_sleep = geti("WQAA_CHAIN_SWEEP_SLEEP", 2);
@@ -152,7 +148,7 @@ static const ChainKnobs& chain_knobs() {
 
 struct ChainBuild {
   ChainArgs args;
-  int bits, layout, mode, waves;
+  int bits, layout, mode, lanes;
   int lds_bytes;
   int grid;
   size_t gran_count;        // granules
@@ -234,8 +230,7 @@ static int chain_build(const wqaa_chain_item* items, int count, int m, ChainBuil
   out->layout = d0.w_layout == WQAA_LAYOUT_LOP3 ? LAYOUT_LOP3 : LAYOUT_PLAIN;
   out->mode = desc_mode(d0);
   out->grid = cus;
-  out->waves = (knobs.waves == 8 && pick_chain(out->bits, out->layout, out->mode, 8)) ? 8 : 4;
-  if (!pick_chain(out->bits, out->layout, out->mode, out->waves)) {
+  if (!pick_chain(out->bits, out->layout, out->mode)) {
     set_error(WQAA_ERR_UNSUPPORTED, "matmul_chain: no persistent member for %d-bit weights, layout %d, scale / zeros mode %d", out->bits, out->layout, out->mode);
     return WQAA_ERR_UNSUPPORTED;
   }
@@ -409,19 +404,29 @@ static int chain_build(const wqaa_chain_item* items, int count, int m, ChainBuil
   off = (off + 1023) & ~1023;
   A.ring_off = off;
   const int lds_total = 160 * 1024;
-  int ring_units = (lds_total - off) / 1024;
-  ring_units -= ring_units % kChainFill;
-  if (knobs.ring >= 2 * kChainFill && knobs.ring < ring_units) ring_units = knobs.ring - knobs.ring % kChainFill;   // lab aid: a smaller ring
   int un_max = 0;
   for (int i = 0; i < count; ++i) un_max = A.st[i].un > un_max ? A.st[i].un : un_max;
-  if (ring_units < un_max + 2 * kChainFill || ring_units < 4 * kChainFill) {
-    set_error(WQAA_ERR_UNSUPPORTED, "matmul_chain: %d KiB of LDS left for the weight ring (a task needs %d)", ring_units, un_max);
+  // lanes (loader + consumer + ring slice each): four feed the memory's rate (one loader wave issues ~8.4 GB/s of LDS-DMA); fewer
+  // when a task's rows would not fit a quarter of the ring beside a fill in flight each way
+  const int total_units = (lds_total - off) / 1024;
+  int lanes = kChainMaxLanes, ring_units = 0;
+  if (knobs.lanes >= 1 && knobs.lanes <= kChainMaxLanes) lanes = knobs.lanes;         // lab aid
+  for (; lanes >= 1; lanes >>= 1) {
+    ring_units = total_units / lanes;
+    ring_units -= ring_units % kChainFill;
+    if (knobs.ring >= 2 * kChainFill && knobs.ring < ring_units) ring_units = knobs.ring - knobs.ring % kChainFill;   // lab aid: a smaller ring
+    if (ring_units >= un_max + 2 * kChainFill && ring_units >= 4 * kChainFill) break;
+    if (knobs.lanes >= 1) { lanes = 0; break; }
+  }
+  if (lanes < 1) {
+    set_error(WQAA_ERR_UNSUPPORTED, "matmul_chain: %d KiB of LDS left for the weight rings (a task needs %d)", total_units, un_max);
     return WQAA_ERR_UNSUPPORTED;
   }
+  out->lanes = lanes;
+  A.nlanes = lanes;
   A.ring_units = ring_units;
-  out->lds_bytes = A.ring_off + ring_units * 1024;
+  out->lds_bytes = A.ring_off + lanes * ring_units * 1024;
   A.nstages = count;
-  A.nconsumers = out->waves - 1;
   A.thin = knobs.thin;
   A.sweep_sleep = knobs.sweep_sleep;
   A.timeout_ticks = knobs.timeout_ticks;
@@ -437,7 +442,7 @@ static void chain_plan_fill(const ChainBuild& b, const wqaa_chain_item* items, i
   plan->block_m = 1;
   plan->block_n = 2;
   plan->block_k = 64 * (128 / b.bits);
-  plan->threads = 64 * b.waves;
+  plan->threads = 128 * b.lanes;
   plan->grid = b.grid;
   plan->rows_per_wave = 2;
   plan->batch_tile = 1;
@@ -452,7 +457,7 @@ static void chain_plan_fill(const ChainBuild& b, const wqaa_chain_item* items, i
     n += snprintf(plan->name + n, sizeof(plan->name) - n, "_%s%s%dx%d%s", S.norm_weight ? "n" : "", S.pair ? "p" : "", S.N, S.K,
                   (S.residual || S.res_stage >= 0) ? "r" : "");
   }
-  if (n > 0 && n < (int)sizeof(plan->name) - 1) snprintf(plan->name + n, sizeof(plan->name) - n, "_ring%d", b.args.ring_units);
+  if (n > 0 && n < (int)sizeof(plan->name) - 1) snprintf(plan->name + n, sizeof(plan->name) - n, "_l%dring%d", b.lanes, b.args.ring_units);
 }
 
 // ---- launch by launch: the definition of the chain, and its form wherever the persistent member does not cover it ----
@@ -558,9 +563,9 @@ int chain_launch(const wqaa_chain_item* items, int count, int m, hipStream_t str
   b.args.ctl = reinterpret_cast<uint32_t*>(base);
   b.args.gran = reinterpret_cast<unsigned long long*>(base + kChainCtlBytes);
   b.args.trace = trace ? reinterpret_cast<unsigned long long*>(base + kChainCtlBytes + (1u << 19) + (1u << 18)) : nullptr;
-  chain_fn fn = pick_chain(b.bits, b.layout, b.mode, b.waves);
+  chain_fn fn = pick_chain(b.bits, b.layout, b.mode);
   void* params[] = {&b.args};
-  dim3 grid(b.grid, 1, 1), block(64 * b.waves, 1, 1);
+  dim3 grid(b.grid, 1, 1), block(128 * b.lanes, 1, 1);
   hipError_t e = hipLaunchKernel(reinterpret_cast<const void*>(fn), grid, block, params, b.lds_bytes, stream);
   if (e != hipSuccess) {
     set_error(WQAA_ERR_LAUNCH, "matmul_chain launch failed: %s", hipGetErrorString(e));
@@ -606,10 +611,10 @@ void chain_init() {
   for (int bits : {4, 2})
     for (int layout = 0; layout < 2; ++layout)
       for (int mode = 0; mode <= MD_ZR; ++mode)
-        for (int waves : {4, 8}) {
-          chain_fn fn = pick_chain(bits, layout, mode, waves);
-          if (fn) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        }
+      {
+        chain_fn fn = pick_chain(bits, layout, mode);
+        if (fn) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      }
   (void)hipGetLastError();
 }
 

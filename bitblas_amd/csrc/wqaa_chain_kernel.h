@@ -8,44 +8,46 @@
 // dispatch 0.85 + first byte 0.9 + last byte -> last store 1.1), and the WEIGHTS of the next operator do not depend on this
 // one's result - only a few KB of activations do.  So (MI355X_MICROARCH.md, rows prefetch-credit / allgather / ldsdma-fill /
 // engine-vs-launches):
-//   * one workgroup per CU, four waves: wave 0 is the LOADER.  It streams this CU's share of every operator's packed weights,
-//     operator after operator, into an LDS ring with LDS-DMA (global_load_lds_dwordx4 ... nt: 1 KiB per instruction, no
-//     VGPR, no VALU) and never waits on a dependency: when the consumers stall on an edge the ring fills up with the next
-//     operator's weights;
-//   * waves 1-3 are CONSUMERS: the exact-product decode / dot of wqaa_gemvx_kernel.h on 16-byte lane chunks read back from
-//     the ring (same lane <-> weight bytes map, same per-lane order over the chunks of a row, same wave reduction: a row's
-//     bits are the single launch's with kw = 1);
+//   * one workgroup per CU of NL LANES (4), a lane = one LOADER wave + one CONSUMER wave + its slice of an LDS ring.  The
+//     loader streams the packed weights of its lane's tasks, operator after operator, into the ring with LDS-DMA
+//     (global_load_lds_dwordx4 ... nt: 1 KiB per instruction, no VGPR, no VALU) and never waits on a dependency: when the
+//     consumers stall on an edge the rings fill up with the next operator's weights.  Four loaders because ONE wave issues
+//     only ~8.4 GB/s of LDS-DMA (tools/dma_lab.hip, profiles/r04_lab_dma_stream.txt: 1 / 2 / 4 loader waves per CU = 2.1 /
+//     4.0 / 5.8-6.1 TB/s over the chip, whatever the address pattern, cache policy or queue depth);
+//   * the CONSUMER: the exact-product decode / dot of wqaa_gemvx_kernel.h on 16-byte lane chunks read back from the ring
+//     (same lane <-> weight bytes map, same per-lane order over the chunks of a row, same wave reduction: a row's bits are
+//     the single launch's with kw = 1).  Loaders are waves 0 .. NL-1, consumers NL .. 2NL-1: a workgroup's waves go to the
+//     SIMDs round-robin, so every SIMD hosts one loader (SALU + VMEM issue) and one consumer (VALU + LDS);
 //   * an operator's output vector crosses to every CU as 8-byte {tag, 2 x float16} granules: one write-through (sc1) store
 //     by the lane that holds the two rounded results, swept by ONE consumer wave per CU with relaxed agent-scope loads
 //     until every tag matches (cdna_hip_programming.md Guideline 16, recipe R2) and staged into the LDS layout the dots read
 //     (the RMSNorm and the residual stash ride in that pass).  No grid barrier, no fence: the data is the flag;
 //   * tags are (generation, stage): the generation lives in device memory and is bumped once per launch by workgroup 0,
 //     so a replayed hipGraph needs no memset node and stale granules of the previous launch never match.
-// Work split: tasks = pairs of output rows (one granule), a contiguous range of tasks per CU, round-robin over the three
-// consumers.  Every spin is bounded (s_memrealtime) and ends in an error code in ctl[1] + abort of the workgroup.
+// Work split: tasks = pairs of output rows (one granule), a contiguous range of tasks per CU, task k of a stage to lane k % NL.  Every spin is bounded (s_memrealtime) and ends in an error code in ctl[1] + abort of the workgroup.
 #pragma once
 #include "wqaa_gemvx_kernel.h"
 
 namespace wqaa {
 
 constexpr int kChainMaxStages = 8;
-constexpr int kChainFill = 8;          // DMA instructions (1 KiB units) per fill
-constexpr int kChainLag = 6;           // fills left in flight behind the issue point: s_waitcnt vmcnt(48)
-constexpr int kChainMaxConsumers = 7;  // consumer waves per workgroup (3: one wave per SIMD with the loader; 7: two)
+constexpr int kChainFill = 4;          // DMA instructions (1 KiB units) per fill
+constexpr int kChainLag = 3;           // fills a loader leaves in flight behind its issue point: s_waitcnt vmcnt(12)
+constexpr int kChainMaxLanes = 4;      // loader / consumer pairs per workgroup
 constexpr int kChainStashMaxRows = 128;
 
 // LDS control block (dwords)
 enum : int {
-  CL_LANDED = 0,      // units (of the issue sequence) known to have landed
   CL_ABORT = 1,
   CL_GEN = 2,         // this launch's generation, CL_GEN_READY = 1 once valid
   CL_GEN_READY = 3,
-  CL_SWEEPING = 4,    // a consumer of this CU is sweeping granules: the loader thins itself
-  CL_NEXT0 = 8,       // [8] ring sequence number of each consumer's next unfinished task (unused slots: INT_MAX)
-  CL_CSTAGE0 = 16,    // [8] stage each consumer has reached
+  CL_SWEEPING = 4,    // a consumer of this CU is sweeping granules: the loaders thin themselves
+  CL_NEXT0 = 8,       // [8] per lane: ring sequence number (of the lane's own unit stream) of the consumer's next unfinished task
+  CL_CSTAGE0 = 16,    // [8] stage each consumer has reached (unused slots: INT_MAX)
   CL_ACT_READY = 24,  // [8] staged input of stage s is complete
   CL_TICKET = 32,     // [8] who stages the input of stage s
-  CL_WORDS = 40
+  CL_LANDED0 = 40,    // [8] per lane: units of the lane's issue sequence known to have landed
+  CL_WORDS = 48
 };
 
 // error codes (ctl[1] = code | stage << 8 | wave << 16 | workgroup << 20)
@@ -86,8 +88,8 @@ struct ChainStage {
 struct ChainArgs {
   ChainStage st[kChainMaxStages];
   int nstages;
-  int nconsumers;           // consumer waves (blockDim = 64 * (1 + nconsumers))
-  int ring_off, ring_units;
+  int nlanes;               // loader / consumer pairs (blockDim = 128 * nlanes)
+  int ring_off, ring_units; // ring_units: per lane; lane l's slice starts at ring_off + l * ring_units KiB
   int raw_off, raw_passes, parts_off;
   int bump_stage;           // the stage after whose sweep workgroup 0 bumps the generation (-1: no edge)
   int thin;                 // 1: one fill outstanding while a consumer of this CU sweeps
@@ -215,20 +217,22 @@ struct ChainWave {
   }
 };
 
-// ---- the loader wave ------------------------------------------------------------------------------------------------------
+// ---- a loader wave (lane L of NL) -------------------------------------------------------------------------------------------
 template <class P>
 __device__ void chain_loader(const ChainWave& cw) {
   const ChainArgs& args = *cw.args;
   unsigned char* smem = cw.smem;
   const int lane = cw.lane;
-  int RING = args.ring_units, ring_off = args.ring_off, thin = args.thin;
-  asm volatile("" : "+s"(RING), "+s"(ring_off), "+s"(thin));
-  const unsigned ring_end = (unsigned)(ring_off + RING * 1024);
-  int issued = 0;         // units issued so far (scale blocks + ring units)
-  int rseq = 0;           // ring units issued so far
-  unsigned dst = (unsigned)ring_off;   // LDS byte address of ring slot rseq % RING
+  const int L = cw.wave, NL = args.nlanes;
+  int RING = args.ring_units, thin = args.thin;
+  int ring_base = args.ring_off + L * RING * 1024;
+  asm volatile("" : "+s"(RING), "+s"(ring_base), "+s"(thin));
+  const unsigned ring_end = (unsigned)(ring_base + RING * 1024);
+  int issued = 0;         // units this loader has issued (lane 0: the scale blocks too)
+  int rseq = 0;           // ring units this loader has issued
+  unsigned dst = (unsigned)ring_base;   // LDS byte address of ring slot rseq % RING
   int in_fill = 0;
-  int frontier = 0;       // cached min(next task's ring sequence) over the consumers
+  int frontier = 0;       // cached: ring sequence number of the lane's consumer's next unfinished task
   int landed_pub = 0;
   bool dead = false;
   const bool dflt = (args.lab & 8) != 0;
@@ -238,29 +242,26 @@ __device__ void chain_loader(const ChainWave& cw) {
   auto publish = [&](int landed) {
     if (landed > landed_pub) {
       landed_pub = landed;
-      chain_lds_st(smem, CL_LANDED, (uint32_t)landed);
+      chain_lds_st(smem, CL_LANDED0 + L, (uint32_t)landed);
     }
   };
   auto has_space = [&]() { return rseq + kChainFill <= frontier + RING; };
-  // the ring is full: publish what is in flight as it lands (the consumers may be waiting for exactly that), fill by fill,
-  // and go on as soon as a fill's worth of slots is free
+  // the ring slice is full: publish what is in flight as it lands (the consumer may be waiting for exactly that), fill by
+  // fill, and go on as soon as a fill's worth of slots is free
   auto wait_space = [&](int stage) {
 #define CHAIN_DRAIN_STEP(N)                                   \
   asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory");       \
   publish(issued - N);                                        \
-  frontier = chain_lds_min8(smem, CL_NEXT0);                  \
+  frontier = (int)chain_lds_ld(smem, CL_NEXT0 + L);           \
   if (has_space()) return;
-    CHAIN_DRAIN_STEP(40)
-    CHAIN_DRAIN_STEP(32)
-    CHAIN_DRAIN_STEP(24)
-    CHAIN_DRAIN_STEP(16)
     CHAIN_DRAIN_STEP(8)
+    CHAIN_DRAIN_STEP(4)
     CHAIN_DRAIN_STEP(0)
 #undef CHAIN_DRAIN_STEP
     unsigned n_ = 0;
     unsigned long long t_ = 0;
     for (;;) {
-      frontier = chain_lds_min8(smem, CL_NEXT0);
+      frontier = (int)chain_lds_ld(smem, CL_NEXT0 + L);
       if (has_space()) return;
       if (cw.expired(n_, t_)) {
         cw.fail(CE_LOADER_SPACE, stage);
@@ -274,15 +275,15 @@ __device__ void chain_loader(const ChainWave& cw) {
   auto boundary = [&](int stage) {
     in_fill = 0;
     if (thin && chain_lds_ld(smem, CL_SWEEPING) != 0) {
-      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
       publish(issued - kChainFill);
     } else {
-      asm volatile("s_waitcnt vmcnt(48)" ::: "memory");
+      asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
       publish(issued - kChainFill * kChainLag);
     }
-    static_assert(kChainFill == 8 && kChainLag == 6, "the vmcnt immediates above");
+    static_assert(kChainFill == 4 && kChainLag == 3, "the vmcnt immediates above");
     if (!has_space()) {
-      frontier = chain_lds_min8(smem, CL_NEXT0);
+      frontier = (int)chain_lds_ld(smem, CL_NEXT0 + L);
       if (!has_space()) wait_space(stage);
     }
   };
@@ -294,9 +295,9 @@ __device__ void chain_loader(const ChainWave& cw) {
     const int nt = t1 - t0;
     const int n0 = 2 * t0;
     const int nops = S.pair ? 2 : 1;
-    // ---- scale / zeros blocks of this CU's rows: contiguous in the (N, K / g) tensors, 16-byte windows aligned in
+    // ---- scale / zeros blocks of this CU's rows (lane 0): contiguous in the (N, K / g) tensors, 16-byte windows aligned in
     // absolute address (a window never straddles a page), lanes past the block re-read its first window ----
-    if (S.nsc > 0) {
+    if (L == 0 && S.nsc > 0) {
       if (s >= 2 && chain_lds_min8(smem, CL_CSTAGE0) < s - 1) {     // the block of stage s - 2 lives in the same LDS area
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         publish(issued);
@@ -328,8 +329,7 @@ __device__ void chain_loader(const ChainWave& cw) {
         }
       }
     }
-    // ---- the weight rows of this CU's tasks, in the order the consumers read them back: the stage descriptor lives in the
-    // kernel-argument segment, what the loop needs is pinned in registers; per unit: M0, the DMA, two adds, a compare ----
+    // ---- the weight rows of this lane's tasks (t0 + L, t0 + L + NL, ...), in the order its consumer reads them back ----
     int nc = S.nc, rows_per_task = S.pair ? 4 : 2, pair = S.pair, Nrows = S.N, row_bytes = S.row_bytes;
     unsigned long long B0 = (unsigned long long)S.B[0], B1 = (unsigned long long)S.B[S.pair ? 1 : 0];
     const bool tail_partial = (S.cpr & 63) != 0;
@@ -340,32 +340,21 @@ __device__ void chain_loader(const ChainWave& cw) {
     }
     int nfull = tail_partial ? nc - 1 : nc;
     asm volatile("" : "+s"(nc), "+s"(rows_per_task), "+s"(pair), "+s"(Nrows), "+s"(row_bytes), "+s"(B0), "+s"(B1), "+s"(nfull));
-    for (int t = t0; t < t1; ++t) {
+    for (int t = t0 + L; t < t1; t += NL) {
       for (int r = 0; r < rows_per_task; ++r) {
         int n = 2 * t + (pair ? (r >> 1) : r);
         n = n < Nrows ? n : Nrows - 1;
         const unsigned long long base = (pair && (r & 1)) ? B1 : B0;
         unsigned long long src = chain_uniform64(base + (unsigned long long)((long)n * row_bytes));
-        for (int c = 0; c < nfull; ++c) {
-          chain_dma(dst, voff_full, src, dflt);
+        for (int c = 0; c < nc; ++c) {
+          chain_dma(dst, c < nfull ? voff_full : voff_tail, src, dflt);
           src += 1024ull;
           dst += 1024u;
-          if (dst == ring_end) dst = (unsigned)ring_off;
+          if (dst == ring_end) dst = (unsigned)ring_base;
           ++rseq;
           ++issued;
           if (++in_fill == kChainFill) {
-            if ((issued & 63) == 0 && issued <= 256) cw.stamp(27 + (issued >> 6));      // lab: 64 / 128 / 192 / 256 units issued
-            boundary(s);
-            if (dead) return;
-          }
-        }
-        if (tail_partial) {
-          chain_dma(dst, voff_tail, src, dflt);
-          dst += 1024u;
-          if (dst == ring_end) dst = (unsigned)ring_off;
-          ++rseq;
-          ++issued;
-          if (++in_fill == kChainFill) {
+            if (L == 0 && (issued & 15) == 0 && issued <= 64) cw.stamp(27 + (issued >> 4));      // lab: lane 0 has issued 16 / 32 / 48 / 64 units
             boundary(s);
             if (dead) return;
           }
@@ -683,12 +672,11 @@ __device__ void chain_consumer(const ChainWave& cw) {
   const ChainArgs& args = *cw.args;
   unsigned char* smem = cw.smem;
   const int lane = cw.lane;
-  const int cons = cw.wave - 1;
-  const int NC = args.nconsumers;
+  const int NL = args.nlanes;
+  const int cons = cw.wave - NL;                  // this consumer's lane
   const int RING = args.ring_units;
-  int rseq_base = 0, useq_base = 0;               // of the current stage, for this CU
-  int turn = cons;                                // tasks of a stage before this consumer's first one (round-robin across stages)
-  int rpos_base = 0;                              // rseq_base % RING
+  int rseq_base = 0, useq_base = 0;               // of the current stage, in this lane's own unit stream
+  int useq0_base = 0;                             // ... in lane 0's (which also carries every stage's scale blocks)
   uint32_t gen = 0;
   bool have_gen = false;
   auto need_gen = [&](int s) -> bool {
@@ -883,45 +871,40 @@ __device__ void chain_consumer(const ChainWave& cw) {
       X.gran = args.gran + S.gran_off;
     }
     const int un = S.un, pair = S.pair;
-    const int need_base = useq_base + S.nsc;
-    // ring slot of this consumer's first task, then + NC tasks per step
-    int step = NC * un;
-    while (step >= RING) step -= RING;
-    int rpos = rpos_base + turn * un;
-    while (rpos >= RING) rpos -= RING;
-    int k = turn;
-    for (; k < nt; k += NC) {
-      if (!(args.lab & 2) && !cw.wait_ge(CL_LANDED, (uint32_t)(need_base + (k + 1) * un), CE_WAIT_LANDED, s)) return;
+    X.ring_off = args.ring_off + cons * RING * 1024;
+    // the stage's scale / zeros blocks ride at the head of lane 0's stream
+    if (S.nsc > 0 && !(args.lab & 2) && !cw.wait_ge(CL_LANDED0, (uint32_t)(useq0_base + S.nsc), CE_WAIT_LANDED, s)) return;
+    const int need_base = useq_base + (cons == 0 ? S.nsc : 0);
+    const int ntl = nt > cons ? (nt - cons + NL - 1) / NL : 0;      // tasks of this stage that fall to this lane: cons, cons + NL, ...
+    int rpos = rseq_base % RING;
+    int ustep = un;
+    while (ustep >= RING) ustep -= RING;
+    for (int j = 0; j < ntl; ++j) {
+      const int k = cons + j * NL;
+      if (!(args.lab & 2) && !cw.wait_ge(CL_LANDED0 + cons, (uint32_t)(need_base + (j + 1) * un), CE_WAIT_LANDED, s)) return;
       CHAIN_LDS_ACQUIRE();
       if (args.lab & 1) {
         if (X.gran && lane == 63) __hip_atomic_store((chain_gu64*)(X.gran + t0 + k), (unsigned long long)X.tag << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       } else if (pair) chain_task<P, 4>(smem, X, t0 + k, rpos, lane);
       else chain_task<P, 2>(smem, X, t0 + k, rpos, lane);
-      // the ring slots of this task are free: the next unfinished task of this consumer starts here (a later stage's
-      // first one is not known yet - the end of this stage's units is a safe lower bound)
-      int next = rseq_base + (k + NC) * un;
-      if (k + NC >= nt) next = rseq_base + nt * un;
+      // the ring slots of this task are free
       CHAIN_LDS_RELEASE();
-      chain_lds_st(smem, CL_NEXT0 + cons, (uint32_t)next);
-      rpos += step;
+      chain_lds_st(smem, CL_NEXT0 + cons, (uint32_t)(rseq_base + (j + 1) * un));
+      rpos += ustep;
       if (rpos >= RING) rpos -= RING;
     }
-    // (also when no task of this stage fell to this consumer: its frontier still moves past the stage)
-    chain_lds_st(smem, CL_NEXT0 + cons, (uint32_t)(rseq_base + nt * un));
     cw.stamp(6 + 3 * s);
-    turn = k - nt;                                  // tasks of the next stage in front of this consumer's first
-    rseq_base += nt * un;
-    useq_base += S.nsc + nt * un;
-    rpos_base = rseq_base % RING;
+    rseq_base += ntl * un;
+    useq_base += (cons == 0 ? S.nsc : 0) + ntl * un;
+    useq0_base += S.nsc + (nt > 0 ? (nt + NL - 1) / NL : 0) * un;
   }
   chain_lds_st(smem, CL_NEXT0 + cons, 0x7fffffffu);
   chain_lds_st(smem, CL_CSTAGE0 + cons, 0x7fffffffu);
 }
 
-// WAVES = 4: the loader + 3 consumers, one wave per SIMD (512 registers each: six sweep passes in flight);
-// WAVES = 8: the loader + 7 consumers, two per SIMD (256 registers: two passes)
-template <int BITS, int LAYOUT, int MODE, int WAVES>
-__global__ void __launch_bounds__(64 * WAVES) wq_chain_kernel(const ChainArgs args) {
+// 2 x nlanes waves (at most 8: two per SIMD, 256 registers each)
+template <int BITS, int LAYOUT, int MODE>
+__global__ void __launch_bounds__(512) wq_chain_kernel(const ChainArgs args) {
   using P = GemvxPolicy<BITS, LAYOUT, MODE, 1, 2, 2>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int tid = threadIdx.x;
@@ -935,17 +918,17 @@ __global__ void __launch_bounds__(64 * WAVES) wq_chain_kernel(const ChainArgs ar
   cw.timeout = args.timeout_ticks;
   if (tid < CL_WORDS) {
     const int slot = tid & 7;
-    const bool unused = (tid >= CL_NEXT0 && tid < CL_CSTAGE0 + 8) && slot >= args.nconsumers;
+    const bool unused = (tid >= CL_CSTAGE0 && tid < CL_CSTAGE0 + 8) && slot >= args.nlanes;
     reinterpret_cast<uint32_t*>(smem_raw)[tid] = unused ? 0x7fffffffu : 0u;
   }
   __syncthreads();
   cw.stamp(0);
-  if (cw.wave == 0) chain_loader<P>(cw);
-  else chain_consumer<P, (WAVES == 4 ? 4 : 2)>(cw);
+  if (cw.wave < args.nlanes) chain_loader<P>(cw);
+  else chain_consumer<P, 2>(cw);
   cw.stamp(3);
 }
 
 typedef void (*chain_fn)(const ChainArgs);
-chain_fn pick_chain(int bits, int layout, int mode, int waves);
+chain_fn pick_chain(int bits, int layout, int mode);
 
 }  // namespace wqaa

@@ -87,7 +87,7 @@ def graph_us(fn):
 
 def variant(name, env):
     """one configuration of the persistent member (plan-time switches: chain_plan re-reads them)"""
-    for k in ("WQAA_CHAIN_WAVES", "WQAA_CHAIN_THIN", "WQAA_CHAIN_SWEEP_SLEEP", "WQAA_CHAIN_RING", "WQAA_CHAIN_TRACE", "WQAA_CHAIN_LAB"):
+    for k in ("WQAA_CHAIN_LANES", "WQAA_CHAIN_THIN", "WQAA_CHAIN_SWEEP_SLEEP", "WQAA_CHAIN_RING", "WQAA_CHAIN_TRACE", "WQAA_CHAIN_LAB"):
         os.environ.pop(k, None)
     os.environ.update(env)
     plan = chain_plan(steps_of(layers[0], x0, chs[0], cas[0], cos[0]))
@@ -121,8 +121,8 @@ def timeline(name, env):
     if not tr.size:
         return
     t0 = tr[:, :, 0][tr[:, :, 0] > 0].min()
-    names = {0: "wave start", 1: "loader: first DMA issued", 2: "loader: stream drained", 3: "wave end", 28: "loader: 64 units issued",
-             29: "loader: 128 units issued", 30: "loader: 192 units issued", 31: "loader: 256 units issued"}
+    names = {0: "wave start", 1: "loader: first DMA issued", 2: "loader: stream drained", 3: "wave end", 28: "loader 0: 16 units issued",
+             29: "loader 0: 32 units issued", 30: "loader 0: 48 units issued", 31: "loader 0: 64 units issued"}
     for s in range(3):
         names[4 + 3 * s] = f"stage {s}: stager starts"
         names[5 + 3 * s] = f"stage {s}: input tile ready"
@@ -142,8 +142,8 @@ per = graph_us(run_launches)
 print(json.dumps({"variant": "launches_3_per_layer", "us_per_layer_tail": [round(p, 2) for p in per], "median": round(float(np.median(per)), 2),
                   "GBps": round(nbytes / np.median(per) / 1e3, 1), "weight_bytes_per_tail": nbytes}), flush=True)
 # lab bits (results wrong by construction): 1 no dots, 2 consumers do not wait for the weights, 4 no sweeps, 8 default-policy DMA
-VARIANTS = [("w4", {}), ("w8", {"WQAA_CHAIN_WAVES": "8"}),
-            ("lab7_loader_free_running", {"WQAA_CHAIN_LAB": "7"}), ("lab15_same_default_policy", {"WQAA_CHAIN_LAB": "15"}),
+VARIANTS = [("l4", {}), ("l2", {"WQAA_CHAIN_LANES": "2"}), ("l1", {"WQAA_CHAIN_LANES": "1"}), ("l4_nothin", {"WQAA_CHAIN_THIN": "0"}),
+            ("l4_sleep0", {"WQAA_CHAIN_SWEEP_SLEEP": "0"}), ("l4_sleep5", {"WQAA_CHAIN_SWEEP_SLEEP": "5"}),
             ("lab5_no_dots_no_sweeps", {"WQAA_CHAIN_LAB": "5"}), ("lab4_no_sweeps", {"WQAA_CHAIN_LAB": "4"}), ("lab1_no_dots", {"WQAA_CHAIN_LAB": "1"}),
             ("lab8_default_policy", {"WQAA_CHAIN_LAB": "8"})]
 for name, env in VARIANTS:
@@ -151,6 +151,6 @@ for name, env in VARIANTS:
 per = graph_us(run_launches)
 print(json.dumps({"variant": "launches_again", "median": round(float(np.median(per)), 2)}), flush=True)
 if not args.no_trace:
-    timeline("w4", {})
-    timeline("lab7_loader_free_running", {"WQAA_CHAIN_LAB": "7"})
+    timeline("l4", {})
     timeline("lab5_no_dots_no_sweeps", {"WQAA_CHAIN_LAB": "5"})
+    timeline("lab4_no_sweeps", {"WQAA_CHAIN_LAB": "4"})
