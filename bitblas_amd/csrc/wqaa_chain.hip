@@ -299,7 +299,7 @@ static int chain_build(const wqaa_chain_item* items, int count, int m, ChainBuil
     if (it.norm_weight) {
       // (the single launch's own limit - the row within the items its workgroup loads ahead - was checked by its selector)
       const int npass = (S.nc * 64 * E + 2047) / 2048;
-      if (npass > 4) {
+      if (npass > 2 * kChainMaxLanes || nw > 16) {
         set_error(WQAA_ERR_UNSUPPORTED, "matmul_chain: item %d: RMSNorm input of K = %d", i, d.K);
         return WQAA_ERR_UNSUPPORTED;
       }
@@ -358,12 +358,14 @@ static int chain_build(const wqaa_chain_item* items, int count, int m, ChainBuil
       A.st[i].stash_off = off;
       off += kChainStashMaxRows * 2;
     }
-  int raw_passes = 1, parts_bytes = 0;
+  // raw scratch: a 4 KiB pass slot per consumer, or the whole row under a norm (its sum of squares needs every element first)
+  int raw_passes = kChainMaxLanes, parts_bytes = 0, norm_npass_max = 0;
   for (int i = 0; i < count; ++i) {
     const ChainStage& S = A.st[i];
     if (S.in_kind == 2 || !S.norm_weight) continue;
     const int npass = (S.nc * 64 * E + 2047) / 2048;
     if (npass > raw_passes) raw_passes = npass;
+    if (npass > norm_npass_max) norm_npass_max = npass;
     const int nslots = S.nc * 4;
     if (nslots * 256 > parts_bytes) parts_bytes = nslots * 256;
   }
@@ -415,7 +417,7 @@ static int chain_build(const wqaa_chain_item* items, int count, int m, ChainBuil
     ring_units = total_units / lanes;
     ring_units -= ring_units % kChainFill;
     if (knobs.ring >= 2 * kChainFill && knobs.ring < ring_units) ring_units = knobs.ring - knobs.ring % kChainFill;   // lab aid: a smaller ring
-    if (ring_units >= un_max + 2 * kChainFill && ring_units >= 4 * kChainFill) break;
+    if (ring_units >= un_max + 2 * kChainFill && ring_units >= 4 * kChainFill && norm_npass_max <= 2 * lanes) break;
     if (knobs.lanes >= 1) { lanes = 0; break; }
   }
   if (lanes < 1) {

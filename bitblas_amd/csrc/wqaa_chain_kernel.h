@@ -44,10 +44,10 @@ enum : int {
   CL_SWEEPING = 4,    // a consumer of this CU is sweeping granules: the loaders thin themselves
   CL_NEXT0 = 8,       // [8] per lane: ring sequence number (of the lane's own unit stream) of the consumer's next unfinished task
   CL_CSTAGE0 = 16,    // [8] stage each consumer has reached (unused slots: INT_MAX)
-  CL_ACT_READY = 24,  // [8] staged input of stage s is complete
-  CL_TICKET = 32,     // [8] who stages the input of stage s
-  CL_LANDED0 = 40,    // [8] per lane: units of the lane's issue sequence known to have landed
-  CL_WORDS = 48
+  CL_LANDED0 = 24,    // [8] per lane: units of the lane's issue sequence known to have landed
+  CL_SYNC0 = 32,      // [8 stages][4]: arrival counters of the consumers while they stage a stage's input together
+  CL_WSUM = 64,       // [16] the norm's per-(virtual)-wave sums of squares
+  CL_WORDS = 80
 };
 
 // error codes (ctl[1] = code | stage << 8 | wave << 16 | workgroup << 20)
@@ -367,26 +367,32 @@ __device__ void chain_loader(const ChainWave& cw) {
   cw.stamp(2);
 }
 
-// ---- one lane chunk of one weight row against the staged activations: the arithmetic of wq_gemvx_kernel's `consume`,
-// MB = 1, to the letter (class accumulators over the four words, Horner, zero point through the chunk's activation sum,
-// group scale on the fp32 partial) ----
-template <class P>
-__device__ __forceinline__ void chain_chunk(const u32x4 w, const u32x4 (&av)[4 * P::PPW], const float sa, const uint32_t sbits,
-                                            const uint32_t zbits, const float zint, const uint32_t flip, float& acc) {
+// ---- one lane chunk of ROWS weight rows against the staged activations: per row the arithmetic of wq_gemvx_kernel's
+// `consume`, MB = 1, to the letter (class accumulators over the four words, Horner, zero point through the chunk's
+// activation sum, group scale on the fp32 partial).  The rows advance together, innermost: one consumer wave per SIMD has no
+// other wave to cover the latency of a dependent V_DOT2C chain, the 2 x ROWS independent chains of a task do ----
+template <class P, int ROWS>
+__device__ __forceinline__ void chain_chunk(const u32x4 (&w)[ROWS], const u32x4 (&av)[4 * P::PPW], const float sa, const uint32_t (&sbits)[ROWS],
+                                            const uint32_t (&zbits)[ROWS], const float zint, const uint32_t flip, float (&acc)[ROWS]) {
   constexpr int BITS = P::BITS, NPAIR = P::NPAIR, NCLS = P::NCLS, PPW = P::PPW, MODE = P::MODE;
-  float cls[NCLS];
+  float cls[ROWS][NCLS];
 #pragma unroll
-  for (int k = 0; k < NCLS; ++k) cls[k] = 0.f;
+  for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+    for (int k = 0; k < NCLS; ++k) cls[r][k] = 0.f;
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
-    uint32_t f[NPAIR];
-    const uint32_t ww = BITS == 1 ? (w[u] ^ flip) : w[u];
-    const uint32_t w8 = ww >> 8;
+    uint32_t f[ROWS][NPAIR];
 #pragma unroll
-    for (int i = 0; i < NPAIR; ++i) {
-      constexpr uint32_t fmask = ((1u << BITS) - 1u) * 0x00010001u;
-      const int bit = BITS * i;
-      f[i] = (bit >= 8 ? w8 : ww) & (fmask << (bit & 7));
+    for (int r = 0; r < ROWS; ++r) {
+      const uint32_t ww = BITS == 1 ? (w[r][u] ^ flip) : w[r][u];
+      const uint32_t w8 = ww >> 8;
+#pragma unroll
+      for (int i = 0; i < NPAIR; ++i) {
+        constexpr uint32_t fmask = ((1u << BITS) - 1u) * 0x00010001u;
+        const int bit = BITS * i;
+        f[r][i] = (bit >= 8 ? w8 : ww) & (fmask << (bit & 7));
+      }
     }
 #pragma unroll
     for (int pp = 0; pp < PPW; ++pp) {
@@ -395,22 +401,26 @@ __device__ __forceinline__ void chain_chunk(const u32x4 w, const u32x4 (&av)[4 *
       for (int e = 0; e < 4; ++e) {
         const int i = pp * 4 + e;
         const int k = ((BITS * i) & 7) / BITS;
-        cls[k] = __builtin_amdgcn_fdot2(as_h2(f[i]), as_h2(a[e]), cls[k], false);
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) cls[r][k] = __builtin_amdgcn_fdot2(as_h2(f[r][i]), as_h2(a[e]), cls[r][k], false);
       }
     }
   }
-  float t = cls[NCLS - 1];
 #pragma unroll
-  for (int k = NCLS - 2; k >= 0; --k) t = __builtin_fmaf(t, 1.f / (float)(1 << BITS), cls[k]);
-  t *= 16777216.f;
-  float z = zint;
-  if constexpr (MODE == MD_ZO) z += (float)bits_to_half(zbits);
-  t = __builtin_fmaf(-z, sa, t);
-  if constexpr (MODE == MD_NONE) {
-    acc += t;
-  } else {
-    acc = __builtin_fmaf(t, (float)bits_to_half(sbits), acc);
-    if constexpr (MODE == MD_ZR) acc = __builtin_fmaf(-(float)bits_to_half(zbits), sa, acc);
+  for (int r = 0; r < ROWS; ++r) {
+    float t = cls[r][NCLS - 1];
+#pragma unroll
+    for (int k = NCLS - 2; k >= 0; --k) t = __builtin_fmaf(t, 1.f / (float)(1 << BITS), cls[r][k]);
+    t *= 16777216.f;
+    float z = zint;
+    if constexpr (MODE == MD_ZO) z += (float)bits_to_half(zbits[r]);
+    t = __builtin_fmaf(-z, sa, t);
+    if constexpr (MODE == MD_NONE) {
+      acc[r] += t;
+    } else {
+      acc[r] = __builtin_fmaf(t, (float)bits_to_half(sbits[r]), acc[r]);
+      if constexpr (MODE == MD_ZR) acc[r] = __builtin_fmaf(-(float)bits_to_half(zbits[r]), sa, acc[r]);
+    }
   }
 }
 
@@ -482,15 +492,17 @@ __device__ __forceinline__ void chain_stage_pass(unsigned char* smem, int a_off,
 }
 
 // sum x^2 of the raw vector in LDS in the order the single launch takes it (NWV waves x NAI items per thread: item idx =
-// j * threads + tid; per thread over j, per wave by the DPP ladder, across the waves in wave order)
+// j * threads + tid; per thread over j, per wave by the DPP ladder, across the waves in wave order).  The consumers share
+// the work: (1) per-item partial sums for the slots idx >> 6 == cons (mod NL); (2) the (virtual) waves w == cons (mod NL);
+// (3) everyone adds the wave sums in wave order - the same bits in every consumer.
 template <class P>
-__device__ __forceinline__ float chain_norm_rinv(unsigned char* smem, const ChainArgs& args, const ChainStage& S, int lane) {
+__device__ __forceinline__ void chain_norm_parts(unsigned char* smem, const ChainArgs& args, const ChainStage& S, int lane, int cons, int NL) {
   constexpr int EPW = P::EPW, IVW = EPW / 8;
   float* parts = reinterpret_cast<float*>(smem + args.parts_off);      // [slot = idx >> 6][lane]
   const unsigned char* raw = smem + args.raw_off;
   const int nslots = S.nc * 4;                                         // launch-path items idx = c * 256 + u * 64 + l: slot = idx >> 6
   const int cpr = S.cpr;
-  for (int sl = 0; sl < nslots; ++sl) {
+  for (int sl = cons; sl < nslots; sl += NL) {
     // launch-path item idx = c * 256 + u * 64 + l  <->  natural item (c * 64 + l) * 4 + u
     const int c = sl >> 2, u = sl & 3;
     const int cl = c * 64 + lane;
@@ -506,18 +518,25 @@ __device__ __forceinline__ float chain_norm_rinv(unsigned char* smem, const Chai
     }
     parts[sl * 64 + lane] = part;
   }
+}
+__device__ __forceinline__ void chain_norm_wsums(unsigned char* smem, const ChainArgs& args, const ChainStage& S, int lane, int cons, int NL) {
+  const float* parts = reinterpret_cast<const float*>(smem + args.parts_off);
+  const int nslots = S.nc * 4;
   const int nwv = S.norm_nwv, nai = S.norm_nai;
-  float tot = 0.f;
-  for (int w = 0; w < nwv; ++w) {
+  for (int w = cons; w < nwv; w += NL) {
     float ssq = 0.f;
     for (int j = 0; j < nai; ++j) {
       const int sl = j * nwv + w;
       ssq += sl < nslots ? parts[sl * 64 + lane] : 0.f;
     }
     const float ws = wave_sum_l63(ssq);
-    const float wsum = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ws), 63));
-    tot = w == 0 ? wsum : tot + wsum;
+    if (lane == 63) reinterpret_cast<float*>(smem)[CL_WSUM + w] = ws;
   }
+}
+__device__ __forceinline__ float chain_norm_rinv(const unsigned char* smem, const ChainStage& S) {
+  const float* wsum = reinterpret_cast<const float*>(smem) + CL_WSUM;
+  float tot = wsum[0];
+  for (int w = 1; w < S.norm_nwv; ++w) tot += wsum[w];
   return rsqrtf(tot * S.norm_inv_k + S.norm_eps);
 }
 
@@ -600,10 +619,7 @@ __device__ __forceinline__ void chain_task(unsigned char* smem, const ChainTaskC
   float acc[ROWS];
 #pragma unroll
   for (int r = 0; r < ROWS; ++r) acc[r] = 0.f;
-  auto compute = [&](const Ops& o) {
-#pragma unroll
-    for (int r = 0; r < ROWS; ++r) chain_chunk<P>(o.w[r], o.av, o.sa, o.sb[r], o.zb[r], X.zint, X.flip, acc[r]);
-  };
+  auto compute = [&](const Ops& o) { chain_chunk<P, ROWS>(o.w, o.av, o.sa, o.sb, o.zb, X.zint, X.flip, acc); };
   {
     Ops oa, ob;
     const int nc = X.nc;
@@ -703,140 +719,142 @@ __device__ void chain_consumer(const ChainWave& cw) {
     const int nt = t1 - t0;
     const int n0 = 2 * t0;
     chain_lds_st(smem, CL_CSTAGE0 + cons, (uint32_t)s);
-    // ---- the stage's input: staged once per CU, by the first consumer to get here ----
+    // ---- the stage's input: staged once per CU by its consumers TOGETHER, pass p (1024 granules = 2048 elements) by consumer
+    // p % NL - a pass costs one wave ~1500 issue slots of LDS / VALU work, and every consumer waits for the tile anyway ----
     if (S.in_kind != 2) {
-      unsigned ticket = 0;
-      if (lane == 0) ticket = __hip_atomic_fetch_add(reinterpret_cast<uint32_t*>(smem) + CL_TICKET + s, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      ticket = __builtin_amdgcn_readfirstlane(ticket);
-      if (ticket == 0) {
-        cw.stamp(4 + 3 * s);
-        // the LDS tile of this input generation was read by the stages two generations back
-        if (S.wait_stage > 0 && !cw.wait_cstage(S.wait_stage, CE_WAIT_STAGE, s)) return;
-        const int a_off = S.a_off, sa_off = S.sa_off, cpr = S.cpr;
-        const int npass = (S.nc * 64 * E + 2047) / 2048;          // passes that cover the nc lane chunks (zero beyond K)
-        const bool norm = S.norm_weight != nullptr;
-        // the norm's weight: asked for now, used when the whole row is here (4 passes: K <= 8192 at 4 bit, host-checked)
-        u32x4 nwr[4][IPL][IVW];
-        if (norm) {
+      cw.stamp(4 + 3 * s);
+      // the LDS tile of this input generation was read by the stages two generations back
+      if (S.wait_stage > 0 && !cw.wait_cstage(S.wait_stage, CE_WAIT_STAGE, s)) return;
+      const int a_off = S.a_off, sa_off = S.sa_off, cpr = S.cpr;
+      const int npass = (S.nc * 64 * E + 2047) / 2048;          // passes that cover the nc lane chunks (zero beyond K)
+      const bool norm = S.norm_weight != nullptr;
+      auto sync = [&](int which) -> bool {
+        CHAIN_LDS_RELEASE();
+        if (lane == 0) __hip_atomic_fetch_add(reinterpret_cast<uint32_t*>(smem) + CL_SYNC0 + s * 4 + which, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (!cw.wait_ge(CL_SYNC0 + s * 4 + which, (uint32_t)NL, CE_WAIT_ACT, s)) return false;
+        CHAIN_LDS_ACQUIRE();
+        return true;
+      };
+      auto raw_of = [&](int p) { return smem + args.raw_off + (norm ? p : cons) * 4096; };
+      if (S.in_kind == 0) {
+        // the caller's vector: plain loads, this consumer's passes two per memory round trip
+        for (int p = cons; p < npass; p += 2 * NL) {
+          u32x4 x[2][IPL][IVW];
 #pragma unroll
-          for (int p = 0; p < 4; ++p)
+          for (int h = 0; h < 2; ++h)
 #pragma unroll
             for (int q = 0; q < IPL; ++q) {
-              const int i = p * IPP + q * 64 + lane;
-              const bool valid = p < npass && (i >> 2) < cpr;
+              const int i = (p + h * NL) * IPP + q * 64 + lane;
+              const bool valid = (i >> 2) < cpr;                   // (also false for a whole pass >= npass)
 #pragma unroll
-              for (int v = 0; v < IVW; ++v) nwr[p][q][v] = CHAIN_G(u32x4, S.norm_weight)[(long)(valid ? i : 0) * IVW + v];
+              for (int v = 0; v < IVW; ++v) x[h][q][v] = CHAIN_G(u32x4, S.A)[(long)(valid ? i : 0) * IVW + v];
             }
-        }
-        if (S.in_kind == 0) {
-          // the caller's vector: plain loads, two passes per memory round trip
-          for (int p = 0; p < npass; p += 2) {
-            u32x4 x[2][IPL][IVW];
 #pragma unroll
-            for (int h = 0; h < 2; ++h)
+          for (int h = 0; h < 2; ++h) {
+            const int pp = p + h * NL;
+            if (pp >= npass) break;
+            unsigned char* rawp = raw_of(pp);
 #pragma unroll
-              for (int q = 0; q < IPL; ++q) {
-                const int i = (p + h) * IPP + q * 64 + lane;
-                const bool valid = (i >> 2) < cpr;                   // (also false for the whole pass p + 1 == npass)
+            for (int q = 0; q < IPL; ++q)
 #pragma unroll
-                for (int v = 0; v < IVW; ++v) x[h][q][v] = CHAIN_G(u32x4, S.A)[(long)(valid ? i : 0) * IVW + v];
-              }
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-              if (p + h >= npass) break;
-              unsigned char* rawp = smem + args.raw_off + (norm ? p + h : 0) * 4096;
-#pragma unroll
-              for (int q = 0; q < IPL; ++q)
-#pragma unroll
-                for (int v = 0; v < IVW; ++v) reinterpret_cast<u32x4*>(rawp + (long)(q * 64 + lane) * (EPW * 2))[v] = x[h][q][v];
-              if (!norm) chain_stage_pass<P, false>(smem, a_off, sa_off, cpr, rawp, (p + h) * IPP, lane, 0.f, nullptr);
-            }
+              for (int v = 0; v < IVW; ++v) reinterpret_cast<u32x4*>(rawp + (long)(q * 64 + lane) * (EPW * 2))[v] = x[h][q][v];
+            if (!norm) chain_stage_pass<P, false>(smem, a_off, sa_off, cpr, rawp, pp * IPP, lane, 0.f, nullptr);
           }
-        } else {
-          // granules of stage S.src: relaxed agent-scope 8-byte loads, 16 per lane and pass, up to kChainSweepPasses passes in
-          // flight; a pass is staged when every one of its tags matches, the incomplete ones are read again after a nap
-          if (!need_gen(s)) return;
-          const uint32_t tag = gen * 16u + (uint32_t)S.src + 1u;
-          const int ng = S.K / 2;
-          const chain_gu64* g = (const chain_gu64*)(args.gran + args.st[S.src].gran_off);
-          if (args.thin) chain_lds_st(smem, CL_SWEEPING, 1u);
-          // the rows a later stage of this CU adds as its residual (the output of stage S.src): kept as they pass
-          int stash_n0 = 0, stash_nr = 0, stash_off = 0;
-          if (S.stash_for >= 0) {
-            const ChainStage& S2 = args.st[S.stash_for];
-            int u0, u1;
-            cw.task_range(S2.tasks, u0, u1);
-            stash_n0 = 2 * u0;
-            stash_nr = 2 * (u1 - u0);
-            if (stash_n0 + stash_nr > S2.N) stash_nr = S2.N - stash_n0;
-            stash_off = S2.stash_off;
-          }
-          const int npl = (args.lab & 4) ? 0 : (ng + 1023) / 1024;     // passes that have granules to load
-          for (int base = 0; base < npl; base += kChainSweepPasses) {
-            unsigned long long x[kChainSweepPasses][16];
-            unsigned pending = 0;
-#pragma unroll
-            for (int j = 0; j < kChainSweepPasses; ++j)
-              if (base + j < npl) pending |= 1u << j;
-            unsigned n_ = 0;
-            unsigned long long t_ = 0;
-            for (;;) {
-#pragma unroll
-              for (int j = 0; j < kChainSweepPasses; ++j) {
-                if (!((pending >> j) & 1u)) continue;
-#pragma unroll
-                for (int k = 0; k < 16; ++k) {
-                  const int gi = (base + j) * 1024 + k * 64 + lane;
-                  x[j][k] = gi < ng ? __hip_atomic_load(g + gi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ((unsigned long long)tag << 32);
-                }
-              }
-#pragma unroll
-              for (int j = 0; j < kChainSweepPasses; ++j) {
-                if (!((pending >> j) & 1u)) continue;
-                bool ok = true;
-#pragma unroll
-                for (int k = 0; k < 16; ++k) ok &= (uint32_t)(x[j][k] >> 32) == tag;
-                if (!__all(ok)) continue;
-                pending &= ~(1u << j);
-                const int p = base + j;
-                unsigned char* rawp = smem + args.raw_off + (norm ? p : 0) * 4096;
-#pragma unroll
-                for (int k = 0; k < 16; ++k) reinterpret_cast<uint32_t*>(rawp)[k * 64 + lane] = (uint32_t)x[j][k];
-                for (int i = lane; i < stash_nr; i += 64) {
-                  const int n = stash_n0 + i - p * 2048;
-                  if (n >= 0 && n < 2048) reinterpret_cast<uint16_t*>(smem + stash_off)[i] = reinterpret_cast<const uint16_t*>(rawp)[n];
-                }
-                if (!norm) chain_stage_pass<P, false>(smem, a_off, sa_off, cpr, rawp, p * IPP, lane, 0.f, nullptr);
-              }
-              if (!pending) break;
-              for (int i = 0; i < args.sweep_sleep; ++i) __builtin_amdgcn_s_sleep(8);       // ~0.2 us each
-              if (cw.expired(n_, t_)) {
-                cw.fail(CE_SWEEP, s);
-                return;
-              }
-            }
-          }
-          // lane chunks past the last granule (partial coverage of the last pass pair at 1 / 2 bit): zeros
-          if (!norm)
-            for (int p = npl; p < npass; ++p) chain_stage_pass<P, false>(smem, a_off, sa_off, cpr, smem + args.raw_off, p * IPP, lane, 0.f, nullptr);
-          if (args.thin) chain_lds_st(smem, CL_SWEEPING, 0u);
-          // every workgroup of this launch has read the generation by now (its granules are here): the next launch's
-          if (s == args.bump_stage && cw.b == 0 && lane == 0)
-            __hip_atomic_store((chain_gu32*)args.ctl, gen + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        if (norm) {
-          const float r = chain_norm_rinv<P>(smem, args, S, lane);
-#pragma unroll
-          for (int p = 0; p < 4; ++p)
-            if (p < npass) chain_stage_pass<P, true>(smem, a_off, sa_off, cpr, smem + args.raw_off + p * 4096, p * IPP, lane, r, nwr[p]);
-        }
-        CHAIN_LDS_RELEASE();
-        chain_lds_st(smem, CL_ACT_READY + s, 1u);
-        cw.stamp(5 + 3 * s);
       } else {
-        if (!cw.wait_ge(CL_ACT_READY + s, 1u, CE_WAIT_ACT, s)) return;
+        // granules of stage S.src: relaxed agent-scope 8-byte loads, 16 per lane and pass, this consumer's passes two at a time
+        // in flight; a pass is staged when every one of its tags matches, an incomplete one is read again after a nap
+        if (!need_gen(s)) return;
+        const uint32_t tag = gen * 16u + (uint32_t)S.src + 1u;
+        const int ng = (args.lab & 4) ? 0 : S.K / 2;
+        const chain_gu64* g = (const chain_gu64*)(args.gran + args.st[S.src].gran_off);
+        if (args.thin && lane == 0) __hip_atomic_fetch_add(reinterpret_cast<uint32_t*>(smem) + CL_SWEEPING, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        // the rows a later stage of this CU adds as its residual (the output of stage S.src): kept as they pass
+        int stash_n0 = 0, stash_nr = 0, stash_off = 0;
+        if (S.stash_for >= 0) {
+          const ChainStage& S2 = args.st[S.stash_for];
+          int u0, u1;
+          cw.task_range(S2.tasks, u0, u1);
+          stash_n0 = 2 * u0;
+          stash_nr = 2 * (u1 - u0);
+          if (stash_n0 + stash_nr > S2.N) stash_nr = S2.N - stash_n0;
+          stash_off = S2.stash_off;
+        }
+        for (int base = cons; base < npass; base += kChainSweepPasses * NL) {
+          unsigned long long x[kChainSweepPasses][16];
+          unsigned pending = 0;
+#pragma unroll
+          for (int j = 0; j < kChainSweepPasses; ++j)
+            if (base + j * NL < npass) pending |= 1u << j;
+          unsigned n_ = 0;
+          unsigned long long t_ = 0;
+          for (;;) {
+#pragma unroll
+            for (int j = 0; j < kChainSweepPasses; ++j) {
+              if (!((pending >> j) & 1u)) continue;
+#pragma unroll
+              for (int k = 0; k < 16; ++k) {
+                const int gi = (base + j * NL) * 1024 + k * 64 + lane;
+                x[j][k] = gi < ng ? __hip_atomic_load(g + gi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ((unsigned long long)tag << 32);
+              }
+            }
+#pragma unroll
+            for (int j = 0; j < kChainSweepPasses; ++j) {
+              if (!((pending >> j) & 1u)) continue;
+              bool ok = true;
+#pragma unroll
+              for (int k = 0; k < 16; ++k) ok &= (uint32_t)(x[j][k] >> 32) == tag;
+              if (!__all(ok)) continue;
+              pending &= ~(1u << j);
+              const int p = base + j * NL;
+              unsigned char* rawp = raw_of(p);
+#pragma unroll
+              for (int k = 0; k < 16; ++k) reinterpret_cast<uint32_t*>(rawp)[k * 64 + lane] = (uint32_t)x[j][k];
+              for (int i = lane; i < stash_nr; i += 64) {
+                const int n = stash_n0 + i - p * 2048;
+                if (n >= 0 && n < 2048) reinterpret_cast<uint16_t*>(smem + stash_off)[i] = reinterpret_cast<const uint16_t*>(rawp)[n];
+              }
+              if (!norm) chain_stage_pass<P, false>(smem, a_off, sa_off, cpr, rawp, p * IPP, lane, 0.f, nullptr);
+            }
+            if (!pending) break;
+            for (int i = 0; i < args.sweep_sleep; ++i) __builtin_amdgcn_s_sleep(8);       // ~0.2 us each
+            if (cw.expired(n_, t_)) {
+              cw.fail(CE_SWEEP, s);
+              return;
+            }
+          }
+        }
+        if (args.thin && lane == 0) __hip_atomic_fetch_sub(reinterpret_cast<uint32_t*>(smem) + CL_SWEEPING, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
-      CHAIN_LDS_ACQUIRE();
+      if (norm) {
+        // the norm's weight for this consumer's passes: asked for now, used behind the three meetings
+        u32x4 nwr[2][IPL][IVW];
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int q = 0; q < IPL; ++q) {
+            const int i = (cons + h * NL) * IPP + q * 64 + lane;
+            const bool valid = cons + h * NL < npass && (i >> 2) < cpr;
+#pragma unroll
+            for (int v = 0; v < IVW; ++v) nwr[h][q][v] = CHAIN_G(u32x4, S.norm_weight)[(long)(valid ? i : 0) * IVW + v];
+          }
+        if (!sync(0)) return;                       // the whole row is in the raw scratch
+        chain_norm_parts<P>(smem, args, S, lane, cons, NL);
+        if (!sync(1)) return;
+        chain_norm_wsums(smem, args, S, lane, cons, NL);
+        if (!sync(2)) return;
+        const float r = chain_norm_rinv(smem, S);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int p = cons + h * NL;              // (host: at most 2 * NL passes under a norm)
+          if (p < npass) chain_stage_pass<P, true>(smem, a_off, sa_off, cpr, smem + args.raw_off + p * 4096, p * IPP, lane, r, nwr[h]);
+        }
+      }
+      if (!sync(3)) return;                         // the tile is complete
+      // every workgroup of this launch has read the generation by now (its granules are here): the next launch's
+      if (S.in_kind == 1 && s == args.bump_stage && cw.b == 0 && cons == 0 && lane == 0)
+        __hip_atomic_store((chain_gu32*)args.ctl, gen + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      cw.stamp(5 + 3 * s);
     }
     // ---- this consumer's tasks of the stage ----
     ChainTaskCtx X;
