@@ -95,7 +95,7 @@ struct ChainArgs {
   int thin;                 // 1: one fill outstanding while a consumer of this CU sweeps
   int sweep_sleep;          // naps of ~0.2 us between two reads of an incomplete sweep
   unsigned timeout_ticks;   // s_memrealtime ticks (100 MHz) a wait may take
-  int lab;                  // tools only, results wrong by construction: 1 no dots, 2 consumers do not wait for the weights, 4 no sweeps (tiles "ready" at once), 8 default-policy DMA
+  int lab;                  // tools only: 1 no dots, 2 consumers do not wait for the weights, 4 no sweeps (tiles "ready" at once), 8 default-policy DMA, 16 no weight stream, 32 consumers at s_setprio 3 (1 - 16: results wrong by construction)
   unsigned long long* gran;
   uint32_t* ctl;            // [0] generation, [1] first error
   unsigned long long* trace;  // lab: [workgroup][wave][32] time stamps, or NULL
@@ -166,7 +166,10 @@ struct ChainWave {
   int lane, wave, b, G;
   unsigned timeout;
   __device__ __forceinline__ void stamp(int i) const {
-    if (args->trace && lane == 0) args->trace[((long)b * 8 + wave) * 32 + i] = __builtin_amdgcn_s_memrealtime();
+    if (args->trace && lane == 0) {
+      args->trace[((long)b * 8 + wave) * 32 + i] = __builtin_amdgcn_s_memrealtime();
+      if (i == 0 || i == 3) args->trace[((long)b * 8 + wave) * 32 + 24 + (i ? 1 : 0)] = __builtin_amdgcn_s_memtime();      // shader clock at wave start / end
+    }
   }
   __device__ __forceinline__ void fail(int code, int stage) const {
     if (lane == 0) {
@@ -238,6 +241,10 @@ __device__ void chain_loader(const ChainWave& cw) {
   const bool dflt = (args.lab & 8) != 0;
   const unsigned voff_full = (unsigned)lane * 16u;
   cw.stamp(1);
+  if (args.lab & 16) {          // lab: no weight stream at all - the consumers run on whatever the ring holds
+    chain_lds_st(smem, CL_LANDED0 + L, 0x7ffffff0u);
+    return;
+  }
 
   auto publish = [&](int landed) {
     if (landed > landed_pub) {
@@ -725,6 +732,11 @@ __device__ void chain_consumer(const ChainWave& cw) {
       cw.stamp(4 + 3 * s);
       // the LDS tile of this input generation was read by the stages two generations back
       if (S.wait_stage > 0 && !cw.wait_cstage(S.wait_stage, CE_WAIT_STAGE, s)) return;
+      auto lab_stamp = [&](int i) {                 // lab time line of the staging of stages 1 and 2 (slots 13 .. 23)
+        if (s == 1) cw.stamp(13 + i);
+        if (s == 2 && i < 4) cw.stamp(20 + i);
+      };
+      lab_stamp(0);
       const int a_off = S.a_off, sa_off = S.sa_off, cpr = S.cpr;
       const int npass = (S.nc * 64 * E + 2047) / 2048;          // passes that cover the nc lane chunks (zero beyond K)
       const bool norm = S.norm_weight != nullptr;
@@ -826,6 +838,7 @@ __device__ void chain_consumer(const ChainWave& cw) {
         }
         if (args.thin && lane == 0) __hip_atomic_fetch_sub(reinterpret_cast<uint32_t*>(smem) + CL_SWEEPING, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
+      lab_stamp(1);
       if (norm) {
         // the norm's weight for this consumer's passes: asked for now, used behind the three meetings
         u32x4 nwr[2][IPL][IVW];
@@ -839,10 +852,13 @@ __device__ void chain_consumer(const ChainWave& cw) {
             for (int v = 0; v < IVW; ++v) nwr[h][q][v] = CHAIN_G(u32x4, S.norm_weight)[(long)(valid ? i : 0) * IVW + v];
           }
         if (!sync(0)) return;                       // the whole row is in the raw scratch
+        lab_stamp(3);
         chain_norm_parts<P>(smem, args, S, lane, cons, NL);
         if (!sync(1)) return;
+        lab_stamp(4);
         chain_norm_wsums(smem, args, S, lane, cons, NL);
         if (!sync(2)) return;
+        lab_stamp(5);
         const float r = chain_norm_rinv(smem, S);
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -850,6 +866,7 @@ __device__ void chain_consumer(const ChainWave& cw) {
           if (p < npass) chain_stage_pass<P, true>(smem, a_off, sa_off, cpr, smem + args.raw_off + p * 4096, p * IPP, lane, r, nwr[h]);
         }
       }
+      lab_stamp(2);
       if (!sync(3)) return;                         // the tile is complete
       // every workgroup of this launch has read the generation by now (its granules are here): the next launch's
       if (S.in_kind == 1 && s == args.bump_stage && cw.b == 0 && cons == 0 && lane == 0)
@@ -942,7 +959,10 @@ __global__ void __launch_bounds__(512) wq_chain_kernel(const ChainArgs args) {
   __syncthreads();
   cw.stamp(0);
   if (cw.wave < args.nlanes) chain_loader<P>(cw);
-  else chain_consumer<P, 2>(cw);
+  else {
+    if (args.lab & 32) __builtin_amdgcn_s_setprio(3);      // lab: the consumers above the loaders in issue priority
+    chain_consumer<P, 2>(cw);
+  }
   cw.stamp(3);
 }
 

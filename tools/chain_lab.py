@@ -127,6 +127,14 @@ def timeline(name, env):
         names[4 + 3 * s] = f"stage {s}: stager starts"
         names[5 + 3 * s] = f"stage {s}: input tile ready"
         names[6 + 3 * s] = f"stage {s}: this wave's tasks done"
+    ok = (tr[:, :, 24] > 0) & (tr[:, :, 25] > tr[:, :, 24]) & (tr[:, :, 3] > tr[:, :, 0])
+    if ok.any():
+        mhz = (tr[:, :, 25] - tr[:, :, 24])[ok] / ((tr[:, :, 3] - tr[:, :, 0])[ok] / 100.0)
+        print(f"shader clock over the launch [{name}] (s_memtime ticks per s_memrealtime microsecond): min {mhz.min():.0f} median {np.median(mhz):.0f} max {mhz.max():.0f} MHz")
+    for i, nm in ((13, "st1 staging: tile free"), (14, "st1 staging: my passes swept"), (16, "st1 staging: sync0 passed"), (17, "st1 staging: sync1 passed"),
+                  (18, "st1 staging: sync2 passed"), (15, "st1 staging: my passes staged"), (20, "st2 staging: tile free"), (21, "st2 staging: my passes swept+staged"),
+                  (22, "st2 staging: before last sync")):
+        names[i] = nm
     print(f"time line of one launch [{name}], microseconds after the first wave's start (100 MHz clock): min / median / max over the waves that stamped")
     for i in sorted(names):
         v = tr[:, :, i]
@@ -142,15 +150,11 @@ per = graph_us(run_launches)
 print(json.dumps({"variant": "launches_3_per_layer", "us_per_layer_tail": [round(p, 2) for p in per], "median": round(float(np.median(per)), 2),
                   "GBps": round(nbytes / np.median(per) / 1e3, 1), "weight_bytes_per_tail": nbytes}), flush=True)
 # lab bits (results wrong by construction): 1 no dots, 2 consumers do not wait for the weights, 4 no sweeps, 8 default-policy DMA
-VARIANTS = [("l4", {}), ("l2", {"WQAA_CHAIN_LANES": "2"}), ("l1", {"WQAA_CHAIN_LANES": "1"}), ("l4_nothin", {"WQAA_CHAIN_THIN": "0"}),
-            ("l4_sleep0", {"WQAA_CHAIN_SWEEP_SLEEP": "0"}), ("l4_sleep5", {"WQAA_CHAIN_SWEEP_SLEEP": "5"}),
-            ("lab5_no_dots_no_sweeps", {"WQAA_CHAIN_LAB": "5"}), ("lab4_no_sweeps", {"WQAA_CHAIN_LAB": "4"}), ("lab1_no_dots", {"WQAA_CHAIN_LAB": "1"}),
-            ("lab8_default_policy", {"WQAA_CHAIN_LAB": "8"})]
+VARIANTS = [("l4", {})]
 for name, env in VARIANTS:
     variant(name, env)
 per = graph_us(run_launches)
 print(json.dumps({"variant": "launches_again", "median": round(float(np.median(per)), 2)}), flush=True)
 if not args.no_trace:
     timeline("l4", {})
-    timeline("lab5_no_dots_no_sweeps", {"WQAA_CHAIN_LAB": "5"})
-    timeline("lab4_no_sweeps", {"WQAA_CHAIN_LAB": "4"})
+    timeline("lab21_no_stream_no_sweeps_no_dots", {"WQAA_CHAIN_LAB": "21"})
