@@ -212,13 +212,13 @@ def chain_status(device=None) -> dict:
 
 
 def chain_trace(device=None):
-    """lab aid: the [workgroup][wave (8 slots)][32] s_memrealtime stamps (100 MHz) of the last fused launch planned with WQAA_CHAIN_TRACE=1"""
+    """lab aid: the [workgroup][wave (16 slots)][32] s_memrealtime stamps (100 MHz) of the last fused launch planned with WQAA_CHAIN_TRACE=1"""
     import numpy as np
     dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
-    buf = np.zeros(1024 * 8 * 32, dtype=np.uint64)
+    buf = np.zeros(1024 * 16 * 32, dtype=np.uint64)
     with torch.cuda.device(dev):
         n = _library().wqaa_debug_chain_trace(_lib.current_stream_handle(dev), buf.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)), buf.size)
-    return buf[:n].reshape(-1, 8, 32)
+    return buf[:n].reshape(-1, 16, 32)
 
 
 def _lin_weights(lin):

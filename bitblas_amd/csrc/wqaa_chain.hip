@@ -119,7 +119,7 @@ static ChainSlab* chain_slab(hipStream_t stream, size_t bytes, bool create) {
 
 // switches (A/B and lab aids; all plan-time like every WQAA_* variable: read again when wqaa_select / wqaa_chain_plan bump the epoch)
 struct ChainKnobs {
-  int fuse, lanes, ring, thin, sweep_sleep, trace, lab;
+  int fuse, lanes, cpl, ring, thin, sweep_sleep, trace, lab;
   unsigned timeout_ticks;
 };
 static const ChainKnobs& chain_knobs() {
@@ -133,6 +133,7 @@ static const ChainKnobs& chain_knobs() {
     };
     k.fuse = geti("WQAA_CHAIN_FUSE", 1) != 0;
     k.lanes = geti("WQAA_CHAIN_LANES", 0);
+    k.cpl = geti("WQAA_CHAIN_CPL", 0);
     k.ring = geti("WQAA_CHAIN_RING", 0);
     k.thin = geti("WQAA_CHAIN_THIN", 1) != 0;
     k.sweep_sleep = geti("WQAA_CHAIN_SWEEP_SLEEP", 2);
@@ -148,7 +149,7 @@ static const ChainKnobs& chain_knobs() {
 
 struct ChainBuild {
   ChainArgs args;
-  int bits, layout, mode, lanes;
+  int bits, layout, mode, lanes, cpl;
   int lds_bytes;
   int grid;
   size_t gran_count;        // granules
@@ -298,8 +299,7 @@ static int chain_build(const wqaa_chain_item* items, int count, int m, ChainBuil
     }
     if (it.norm_weight) {
       // (the single launch's own limit - the row within the items its workgroup loads ahead - was checked by its selector)
-      const int npass = (S.nc * 64 * E + 2047) / 2048;
-      if (npass > 2 * kChainMaxLanes || nw > 16) {
+      if (S.nc > kChainMaxLanes * kChainMaxCpl || nw > 16) {
         set_error(WQAA_ERR_UNSUPPORTED, "matmul_chain: item %d: RMSNorm input of K = %d", i, d.K);
         return WQAA_ERR_UNSUPPORTED;
       }
@@ -358,19 +358,14 @@ static int chain_build(const wqaa_chain_item* items, int count, int m, ChainBuil
       A.st[i].stash_off = off;
       off += kChainStashMaxRows * 2;
     }
-  // raw scratch: a 4 KiB pass slot per consumer, or the whole row under a norm (its sum of squares needs every element first)
-  int raw_passes = kChainMaxLanes, parts_bytes = 0, norm_npass_max = 0;
+  // the norm's per-item partial sums (its raw row sits in the tile's own region until it is staged in place)
+  int parts_bytes = 0, norm_nc_max = 0;
   for (int i = 0; i < count; ++i) {
     const ChainStage& S = A.st[i];
     if (S.in_kind == 2 || !S.norm_weight) continue;
-    const int npass = (S.nc * 64 * E + 2047) / 2048;
-    if (npass > raw_passes) raw_passes = npass;
-    if (npass > norm_npass_max) norm_npass_max = npass;
-    const int nslots = S.nc * 4;
-    if (nslots * 256 > parts_bytes) parts_bytes = nslots * 256;
+    if (S.nc > norm_nc_max) norm_nc_max = S.nc;
+    if (S.nc * 4 * 256 > parts_bytes) parts_bytes = S.nc * 4 * 256;
   }
-  A.raw_off = off; A.raw_passes = raw_passes;
-  off += raw_passes * 4096;
   A.parts_off = off;
   off += parts_bytes;
   // scale / zeros blocks: two areas by stage parity
@@ -412,20 +407,25 @@ static int chain_build(const wqaa_chain_item* items, int count, int m, ChainBuil
   // when a task's rows would not fit a quarter of the ring beside a fill in flight each way
   const int total_units = (lds_total - off) / 1024;
   int lanes = kChainMaxLanes, ring_units = 0;
+  int cpl = kChainMaxCpl;
+  if (knobs.cpl >= 1 && knobs.cpl <= kChainMaxCpl) cpl = knobs.cpl;                   // lab aid
   if (knobs.lanes >= 1 && knobs.lanes <= kChainMaxLanes) lanes = knobs.lanes;         // lab aid
   for (; lanes >= 1; lanes >>= 1) {
     ring_units = total_units / lanes;
     ring_units -= ring_units % kChainFill;
     if (knobs.ring >= 2 * kChainFill && knobs.ring < ring_units) ring_units = knobs.ring - knobs.ring % kChainFill;   // lab aid: a smaller ring
-    if (ring_units >= un_max + 2 * kChainFill && ring_units >= 4 * kChainFill && norm_npass_max <= 2 * lanes) break;
+    if (ring_units >= un_max + 2 * kChainFill && ring_units >= 4 * kChainFill && norm_nc_max <= lanes * cpl) break;
     if (knobs.lanes >= 1) { lanes = 0; break; }
   }
   if (lanes < 1) {
-    set_error(WQAA_ERR_UNSUPPORTED, "matmul_chain: %d KiB of LDS left for the weight rings (a task needs %d)", total_units, un_max);
+    set_error(WQAA_ERR_UNSUPPORTED, "matmul_chain: %d KiB of LDS left for the weight rings (a task needs %d), %d lane chunks under a norm", total_units,
+              un_max, norm_nc_max);
     return WQAA_ERR_UNSUPPORTED;
   }
   out->lanes = lanes;
+  out->cpl = cpl;
   A.nlanes = lanes;
+  A.cpl = cpl;
   A.ring_units = ring_units;
   out->lds_bytes = A.ring_off + lanes * ring_units * 1024;
   A.nstages = count;
@@ -444,7 +444,7 @@ static void chain_plan_fill(const ChainBuild& b, const wqaa_chain_item* items, i
   plan->block_m = 1;
   plan->block_n = 2;
   plan->block_k = 64 * (128 / b.bits);
-  plan->threads = 128 * b.lanes;
+  plan->threads = 64 * b.lanes * (1 + b.cpl);
   plan->grid = b.grid;
   plan->rows_per_wave = 2;
   plan->batch_tile = 1;
@@ -459,7 +459,7 @@ static void chain_plan_fill(const ChainBuild& b, const wqaa_chain_item* items, i
     n += snprintf(plan->name + n, sizeof(plan->name) - n, "_%s%s%dx%d%s", S.norm_weight ? "n" : "", S.pair ? "p" : "", S.N, S.K,
                   (S.residual || S.res_stage >= 0) ? "r" : "");
   }
-  if (n > 0 && n < (int)sizeof(plan->name) - 1) snprintf(plan->name + n, sizeof(plan->name) - n, "_l%dring%d", b.lanes, b.args.ring_units);
+  if (n > 0 && n < (int)sizeof(plan->name) - 1) snprintf(plan->name + n, sizeof(plan->name) - n, "_l%dc%dring%d", b.lanes, b.cpl, b.args.ring_units);
 }
 
 // ---- launch by launch: the definition of the chain, and its form wherever the persistent member does not cover it ----
@@ -547,7 +547,7 @@ int chain_launch(const wqaa_chain_item* items, int count, int m, hipStream_t str
   if (chain_build(items, count, m, &b) != WQAA_OK) return chain_by_launches(items, count, m, stream);
   const bool trace = chain_knobs().trace != 0;
   const size_t gran_bytes = (b.gran_count * 8 + 255) & ~(size_t)255;
-  const size_t trace_words = trace ? (size_t)b.grid * 8 * 32 : 0;
+  const size_t trace_words = trace ? (size_t)b.grid * 16 * 32 : 0;
   const size_t need = kChainCtlBytes + (1u << 19) + (1u << 18) + trace_words * 8;
   if (gran_bytes > (1u << 19)) {
     set_error(WQAA_ERR_UNSUPPORTED, "matmul_chain: %zu B of granules", gran_bytes);
@@ -567,7 +567,7 @@ int chain_launch(const wqaa_chain_item* items, int count, int m, hipStream_t str
   b.args.trace = trace ? reinterpret_cast<unsigned long long*>(base + kChainCtlBytes + (1u << 19) + (1u << 18)) : nullptr;
   chain_fn fn = pick_chain(b.bits, b.layout, b.mode);
   void* params[] = {&b.args};
-  dim3 grid(b.grid, 1, 1), block(128 * b.lanes, 1, 1);
+  dim3 grid(b.grid, 1, 1), block(64 * b.lanes * (1 + b.cpl), 1, 1);
   hipError_t e = hipLaunchKernel(reinterpret_cast<const void*>(fn), grid, block, params, b.lds_bytes, stream);
   if (e != hipSuccess) {
     set_error(WQAA_ERR_LAUNCH, "matmul_chain launch failed: %s", hipGetErrorString(e));

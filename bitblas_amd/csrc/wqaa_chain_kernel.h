@@ -33,7 +33,9 @@ namespace wqaa {
 constexpr int kChainMaxStages = 8;
 constexpr int kChainFill = 4;          // DMA instructions (1 KiB units) per fill
 constexpr int kChainLag = 3;           // fills a loader leaves in flight behind its issue point: s_waitcnt vmcnt(12)
-constexpr int kChainMaxLanes = 4;      // loader / consumer pairs per workgroup
+constexpr int kChainMaxLanes = 4;      // lanes per workgroup: a loader wave, its slice of the ring, kChainMaxCpl consumer waves at most
+constexpr int kChainMaxCpl = 3;        // consumers per lane (tools/chain_task_lab.hip: 4 / 8 / 12 / 16 consumer waves per CU sustain
+                                       // 25 / 39 / 49 / 56 GB/s of 4-bit lane chunks - the stream wants 25 and a consumer shares its SIMD)
 constexpr int kChainStashMaxRows = 128;
 
 // LDS control block (dwords)
@@ -41,13 +43,13 @@ enum : int {
   CL_ABORT = 1,
   CL_GEN = 2,         // this launch's generation, CL_GEN_READY = 1 once valid
   CL_GEN_READY = 3,
-  CL_SWEEPING = 4,    // a consumer of this CU is sweeping granules: the loaders thin themselves
-  CL_NEXT0 = 8,       // [8] per lane: ring sequence number (of the lane's own unit stream) of the consumer's next unfinished task
-  CL_CSTAGE0 = 16,    // [8] stage each consumer has reached (unused slots: INT_MAX)
-  CL_LANDED0 = 24,    // [8] per lane: units of the lane's issue sequence known to have landed
-  CL_SYNC0 = 32,      // [8 stages][4]: arrival counters of the consumers while they stage a stage's input together
-  CL_WSUM = 64,       // [16] the norm's per-(virtual)-wave sums of squares
-  CL_WORDS = 80
+  CL_SWEEPING = 4,    // consumers of this CU that are sweeping granules: the loaders thin themselves
+  CL_LANDED0 = 8,     // [4] per lane: units of the lane's issue sequence known to have landed
+  CL_NEXT0 = 16,      // [4 lanes][4]: ring sequence number (of the lane's unit stream) of each consumer's next unfinished task
+  CL_CSTAGE0 = 32,    // [16] stage each consumer has reached (unused slots: INT_MAX)
+  CL_SYNC0 = 48,      // [8 stages][4]: arrival counters of the consumers while they stage a stage's input together
+  CL_WSUM = 80,       // [16] the norm's per-(virtual)-wave sums of squares
+  CL_WORDS = 96
 };
 
 // error codes (ctl[1] = code | stage << 8 | wave << 16 | workgroup << 20)
@@ -88,9 +90,9 @@ struct ChainStage {
 struct ChainArgs {
   ChainStage st[kChainMaxStages];
   int nstages;
-  int nlanes;               // loader / consumer pairs (blockDim = 128 * nlanes)
+  int nlanes, cpl;          // lanes and consumers per lane (blockDim = 64 * nlanes * (1 + cpl))
   int ring_off, ring_units; // ring_units: per lane; lane l's slice starts at ring_off + l * ring_units KiB
-  int raw_off, raw_passes, parts_off;
+  int parts_off;
   int bump_stage;           // the stage after whose sweep workgroup 0 bumps the generation (-1: no edge)
   int thin;                 // 1: one fill outstanding while a consumer of this CU sweeps
   int sweep_sleep;          // naps of ~0.2 us between two reads of an incomplete sweep
@@ -119,19 +121,19 @@ __device__ __forceinline__ uint32_t chain_lds_ld(const unsigned char* smem, int 
 __device__ __forceinline__ void chain_lds_st(unsigned char* smem, int word, uint32_t v) {
   *reinterpret_cast<volatile chain_lds_u32*>((chain_lds_u8*)smem + word * 4) = v;
 }
-// min of the eight control words at `word` (one value per consumer slot)
-__device__ __forceinline__ int chain_lds_min8(const unsigned char* smem, int word) {
+// min of the four / sixteen control words at `word` (one value per consumer slot; unused slots hold INT_MAX)
+__device__ __forceinline__ int chain_lds_min4(const unsigned char* smem, int word) {
   const u32x4 a = *reinterpret_cast<const volatile chain_lds_u32x4*>((const chain_lds_u8*)smem + word * 4);
-  const u32x4 c = *reinterpret_cast<const volatile chain_lds_u32x4*>((const chain_lds_u8*)smem + word * 4 + 16);
   int m = (int)a[0];
   m = (int)a[1] < m ? (int)a[1] : m;
   m = (int)a[2] < m ? (int)a[2] : m;
   m = (int)a[3] < m ? (int)a[3] : m;
-  m = (int)c[0] < m ? (int)c[0] : m;
-  m = (int)c[1] < m ? (int)c[1] : m;
-  m = (int)c[2] < m ? (int)c[2] : m;
-  m = (int)c[3] < m ? (int)c[3] : m;
   return __builtin_amdgcn_readfirstlane(m);
+}
+__device__ __forceinline__ int chain_lds_min16(const unsigned char* smem, int word) {
+  const int a = chain_lds_min4(smem, word), b = chain_lds_min4(smem, word + 4), c = chain_lds_min4(smem, word + 8), d = chain_lds_min4(smem, word + 12);
+  const int m = a < b ? a : b, n = c < d ? c : d;
+  return m < n ? m : n;
 }
 // order this wave's LDS accesses against a control word (LDS only: a workgroup fence over every address space would wait
 // for the wave's outstanding global stores, a memory round trip per task)
@@ -167,8 +169,8 @@ struct ChainWave {
   unsigned timeout;
   __device__ __forceinline__ void stamp(int i) const {
     if (args->trace && lane == 0) {
-      args->trace[((long)b * 8 + wave) * 32 + i] = __builtin_amdgcn_s_memrealtime();
-      if (i == 0 || i == 3) args->trace[((long)b * 8 + wave) * 32 + 24 + (i ? 1 : 0)] = __builtin_amdgcn_s_memtime();      // shader clock at wave start / end
+      args->trace[((long)b * 16 + wave) * 32 + i] = __builtin_amdgcn_s_memrealtime();
+      if (i == 0 || i == 3) args->trace[((long)b * 16 + wave) * 32 + 24 + (i ? 1 : 0)] = __builtin_amdgcn_s_memtime();      // shader clock at wave start / end
     }
   }
   __device__ __forceinline__ void fail(int code, int stage) const {
@@ -206,7 +208,7 @@ struct ChainWave {
   __device__ __forceinline__ bool wait_cstage(int stage, int code, int at) const {
     unsigned n = 0;
     unsigned long long t0 = 0;
-    while (chain_lds_min8(smem, CL_CSTAGE0) < stage) {
+    while (chain_lds_min16(smem, CL_CSTAGE0) < stage) {
       if (expired(n, t0)) {
         fail(code, at);
         return false;
@@ -235,7 +237,7 @@ __device__ void chain_loader(const ChainWave& cw) {
   int rseq = 0;           // ring units this loader has issued
   unsigned dst = (unsigned)ring_base;   // LDS byte address of ring slot rseq % RING
   int in_fill = 0;
-  int frontier = 0;       // cached: ring sequence number of the lane's consumer's next unfinished task
+  int frontier = 0;       // cached: min over the lane's consumers of the ring sequence number of their next unfinished task
   int landed_pub = 0;
   bool dead = false;
   const bool dflt = (args.lab & 8) != 0;
@@ -259,7 +261,7 @@ __device__ void chain_loader(const ChainWave& cw) {
 #define CHAIN_DRAIN_STEP(N)                                   \
   asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory");       \
   publish(issued - N);                                        \
-  frontier = (int)chain_lds_ld(smem, CL_NEXT0 + L);           \
+  frontier = chain_lds_min4(smem, CL_NEXT0 + 4 * L);          \
   if (has_space()) return;
     CHAIN_DRAIN_STEP(8)
     CHAIN_DRAIN_STEP(4)
@@ -268,7 +270,7 @@ __device__ void chain_loader(const ChainWave& cw) {
     unsigned n_ = 0;
     unsigned long long t_ = 0;
     for (;;) {
-      frontier = (int)chain_lds_ld(smem, CL_NEXT0 + L);
+      frontier = chain_lds_min4(smem, CL_NEXT0 + 4 * L);
       if (has_space()) return;
       if (cw.expired(n_, t_)) {
         cw.fail(CE_LOADER_SPACE, stage);
@@ -290,7 +292,7 @@ __device__ void chain_loader(const ChainWave& cw) {
     }
     static_assert(kChainFill == 4 && kChainLag == 3, "the vmcnt immediates above");
     if (!has_space()) {
-      frontier = (int)chain_lds_ld(smem, CL_NEXT0 + L);
+      frontier = chain_lds_min4(smem, CL_NEXT0 + 4 * L);
       if (!has_space()) wait_space(stage);
     }
   };
@@ -305,7 +307,7 @@ __device__ void chain_loader(const ChainWave& cw) {
     // ---- scale / zeros blocks of this CU's rows (lane 0): contiguous in the (N, K / g) tensors, 16-byte windows aligned in
     // absolute address (a window never straddles a page), lanes past the block re-read its first window ----
     if (L == 0 && S.nsc > 0) {
-      if (s >= 2 && chain_lds_min8(smem, CL_CSTAGE0) < s - 1) {     // the block of stage s - 2 lives in the same LDS area
+      if (s >= 2 && chain_lds_min16(smem, CL_CSTAGE0) < s - 1) {     // the block of stage s - 2 lives in the same LDS area
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         publish(issued);
         if (!cw.wait_cstage(s - 1, CE_LOADER_SC, s)) return;
@@ -469,47 +471,52 @@ __device__ __forceinline__ void chain_item_store(unsigned char* smem, int a_off,
   if ((lane & 3) == 0) sa_lds[c * 64 + l] = p;
 }
 
-// stage one pass (IPP items in natural memory order, item i = EPW elements at element offset i * EPW) from `src` (LDS raw
-// scratch).  NORM: x -> weight * half(x * r) first (the norm's two roundings), weight = nw[q] of item first + q * 64 + lane
+// stage lane chunk c IN PLACE: its 64 * E activations sit in the chunk's own region of the tile in natural memory order
+// (item t of the chunk = EPW elements at byte t * EPW * 2; the permuted tile of a chunk fills exactly the same bytes); this wave
+// reads all four of its items per lane, then writes them back in the order the unpack produces (+ the chunk's activation sums).
+// One wave per chunk: its LDS reads are in the queue ahead of its writes.  NORM: x -> weight * half(x * r) first (the norm's two
+// roundings), weight = nw[q] of item q * 64 + lane of the chunk.
 template <class P, bool NORM>
-__device__ __forceinline__ void chain_stage_pass(unsigned char* smem, int a_off, int sa_off, int cpr, const unsigned char* src, int first, int lane,
-                                                 float norm_r, const u32x4 (*nw)[P::EPW / 8]) {
-  constexpr int EPW = P::EPW, IVW = EPW / 8, IPL = 2048 / EPW / 64;
+__device__ __forceinline__ void chain_stage_chunk(unsigned char* smem, int a_off, int sa_off, int cpr, int c, int lane, float norm_r,
+                                                  const u32x4 (*nw)[P::EPW / 8]) {
+  constexpr int EPW = P::EPW, IVW = EPW / 8, E = P::E;
+  const unsigned char* src = smem + a_off + (long)c * (64 * E * 2);
+  u32x4 raw[4][IVW];
 #pragma unroll
-  for (int q = 0; q < IPL; ++q) {
-    const int i = first + q * 64 + lane;
-    const int cl = i >> 2, u = i & 3;
-    const int c = cl >> 6, l = cl & 63;
-    const bool valid = cl < cpr;
-    u32x4 raw[IVW];
+  for (int q = 0; q < 4; ++q)
 #pragma unroll
-    for (int v = 0; v < IVW; ++v) raw[v] = reinterpret_cast<const u32x4*>(src + (long)(q * 64 + lane) * (EPW * 2))[v];
+    for (int v = 0; v < IVW; ++v) raw[q][v] = reinterpret_cast<const u32x4*>(src + (long)(q * 64 + lane) * (EPW * 2))[v];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int t = q * 64 + lane;               // item of the chunk: lane chunk position t >> 2, weight word t & 3
+    const int l = t >> 2, u = t & 3;
+    const bool valid = c * 64 + l < cpr;
     if constexpr (NORM) {
 #pragma unroll
       for (int v = 0; v < IVW; ++v)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const half2_t x = as_h2(raw[v][e]);
+          const half2_t x = as_h2(raw[q][v][e]);
           const half2_t h = {(half_t)((float)x[0] * norm_r), (half_t)((float)x[1] * norm_r)};
-          raw[v][e] = as_u32(as_h2(nw[q][v][e]) * h);
+          raw[q][v][e] = as_u32(as_h2(nw[q][v][e]) * h);
         }
     }
-    chain_item_store<P>(smem, a_off, sa_off, c, u, l, raw, valid, lane);
+    chain_item_store<P>(smem, a_off, sa_off, c, u, l, raw[q], valid, lane);
   }
 }
 
-// sum x^2 of the raw vector in LDS in the order the single launch takes it (NWV waves x NAI items per thread: item idx =
-// j * threads + tid; per thread over j, per wave by the DPP ladder, across the waves in wave order).  The consumers share
-// the work: (1) per-item partial sums for the slots idx >> 6 == cons (mod NL); (2) the (virtual) waves w == cons (mod NL);
-// (3) everyone adds the wave sums in wave order - the same bits in every consumer.
+// sum x^2 of the raw vector (natural order, in the tile's region) in the order the single launch takes it (NWV waves x NAI
+// items per thread: item idx = j * threads + tid; per thread over j, per wave by the DPP ladder, across the waves in wave
+// order).  The consumers share the work: (1) per-item partial sums for the slots idx >> 6 == ci (mod NCONS); (2) the (virtual)
+// waves w == ci (mod NCONS); (3) everyone adds the wave sums in wave order - the same bits in every consumer.
 template <class P>
-__device__ __forceinline__ void chain_norm_parts(unsigned char* smem, const ChainArgs& args, const ChainStage& S, int lane, int cons, int NL) {
+__device__ __forceinline__ void chain_norm_parts(unsigned char* smem, const ChainArgs& args, const ChainStage& S, int lane, int ci, int ncons) {
   constexpr int EPW = P::EPW, IVW = EPW / 8;
   float* parts = reinterpret_cast<float*>(smem + args.parts_off);      // [slot = idx >> 6][lane]
-  const unsigned char* raw = smem + args.raw_off;
+  const unsigned char* raw = smem + S.a_off;
   const int nslots = S.nc * 4;                                         // launch-path items idx = c * 256 + u * 64 + l: slot = idx >> 6
   const int cpr = S.cpr;
-  for (int sl = cons; sl < nslots; sl += NL) {
+  for (int sl = ci; sl < nslots; sl += ncons) {
     // launch-path item idx = c * 256 + u * 64 + l  <->  natural item (c * 64 + l) * 4 + u
     const int c = sl >> 2, u = sl & 3;
     const int cl = c * 64 + lane;
@@ -526,11 +533,11 @@ __device__ __forceinline__ void chain_norm_parts(unsigned char* smem, const Chai
     parts[sl * 64 + lane] = part;
   }
 }
-__device__ __forceinline__ void chain_norm_wsums(unsigned char* smem, const ChainArgs& args, const ChainStage& S, int lane, int cons, int NL) {
+__device__ __forceinline__ void chain_norm_wsums(unsigned char* smem, const ChainArgs& args, const ChainStage& S, int lane, int ci, int ncons) {
   const float* parts = reinterpret_cast<const float*>(smem + args.parts_off);
   const int nslots = S.nc * 4;
   const int nwv = S.norm_nwv, nai = S.norm_nai;
-  for (int w = cons; w < nwv; w += NL) {
+  for (int w = ci; w < nwv; w += ncons) {
     float ssq = 0.f;
     for (int j = 0; j < nai; ++j) {
       const int sl = j * nwv + w;
@@ -627,7 +634,8 @@ __device__ __forceinline__ void chain_task(unsigned char* smem, const ChainTaskC
 #pragma unroll
   for (int r = 0; r < ROWS; ++r) acc[r] = 0.f;
   auto compute = [&](const Ops& o) { chain_chunk<P, ROWS>(o.w, o.av, o.sa, o.sb, o.zb, X.zint, X.flip, acc); };
-  {
+  if constexpr (ROWS <= 2) {
+    // two rows: the next chunk's operands are in flight while this one's dots run
     Ops oa, ob;
     const int nc = X.nc;
     load(oa, 0);
@@ -641,6 +649,15 @@ __device__ __forceinline__ void chain_task(unsigned char* smem, const ChainTaskC
       __builtin_amdgcn_sched_barrier(0);
       compute(ob);
       if (++c >= nc) break;
+    }
+  } else {
+    // four rows (a gate / up task): one set of operands (the kernel runs four waves per SIMD in 128 registers: the other
+    // waves cover the LDS round trip)
+    Ops oa;
+    for (int c = 0; c < X.nc; ++c) {
+      load(oa, c);
+      __builtin_amdgcn_sched_barrier(0);
+      compute(oa);
     }
   }
   float tot[ROWS];
@@ -686,17 +703,17 @@ __device__ __forceinline__ void chain_task(unsigned char* smem, const ChainTaskC
   }
 }
 
-template <class P, int kChainSweepPasses>      // granule passes (1024 granules each) one sweep keeps in flight
+template <class P>
 __device__ void chain_consumer(const ChainWave& cw) {
   constexpr int EPW = P::EPW, IVW = EPW / 8, E = P::E, MODE = P::MODE;
-  constexpr int IPP = 2048 / EPW;                 // items per sweep pass (1024 granules = 2048 elements)
-  constexpr int IPL = IPP / 64;                   // ... per lane
+  constexpr int PPC = E / 32;                     // sweep passes (1024 granules = 2048 elements) per lane chunk
   constexpr int NTENS = (MODE == MD_ZO || MODE == MD_ZR) ? 2 : 1;
   const ChainArgs& args = *cw.args;
   unsigned char* smem = cw.smem;
   const int lane = cw.lane;
-  const int NL = args.nlanes;
-  const int cons = cw.wave - NL;                  // this consumer's lane
+  const int NL = args.nlanes, CPL = args.cpl, NCONS = NL * CPL;
+  const int ci = cw.wave - NL;                    // consumer index: lane ci % NL (on that lane's loader's SIMD), position ci / NL in it
+  const int ln = ci % NL, sub = ci / NL;
   const int RING = args.ring_units;
   int rseq_base = 0, useq_base = 0;               // of the current stage, in this lane's own unit stream
   int useq0_base = 0;                             // ... in lane 0's (which also carries every stage's scale blocks)
@@ -709,7 +726,7 @@ __device__ void chain_consumer(const ChainWave& cw) {
     have_gen = true;
     return true;
   };
-  if (cons == 0) {
+  if (ci == 0) {
     // the workgroup's generation: ONE agent-scope load, shared through LDS (every tag of this launch derives from it)
     const uint32_t g = __hip_atomic_load((chain_gu32*)args.ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     chain_lds_st(smem, CL_GEN, g);
@@ -725,65 +742,52 @@ __device__ void chain_consumer(const ChainWave& cw) {
     cw.task_range(S.tasks, t0, t1);
     const int nt = t1 - t0;
     const int n0 = 2 * t0;
-    chain_lds_st(smem, CL_CSTAGE0 + cons, (uint32_t)s);
-    // ---- the stage's input: staged once per CU by its consumers TOGETHER, pass p (1024 granules = 2048 elements) by consumer
-    // p % NL - a pass costs one wave ~1500 issue slots of LDS / VALU work, and every consumer waits for the tile anyway ----
+    chain_lds_st(smem, CL_CSTAGE0 + ci, (uint32_t)s);
+    // ---- the stage's input: staged once per CU by its consumers TOGETHER, lane chunk c (64 * E elements) by consumer c % NCONS,
+    // in place in the chunk's region of the tile ----
     if (S.in_kind != 2) {
       cw.stamp(4 + 3 * s);
       // the LDS tile of this input generation was read by the stages two generations back
       if (S.wait_stage > 0 && !cw.wait_cstage(S.wait_stage, CE_WAIT_STAGE, s)) return;
-      auto lab_stamp = [&](int i) {                 // lab time line of the staging of stages 1 and 2 (slots 13 .. 23)
-        if (s == 1) cw.stamp(13 + i);
-        if (s == 2 && i < 4) cw.stamp(20 + i);
-      };
-      lab_stamp(0);
-      const int a_off = S.a_off, sa_off = S.sa_off, cpr = S.cpr;
-      const int npass = (S.nc * 64 * E + 2047) / 2048;          // passes that cover the nc lane chunks (zero beyond K)
+      const int a_off = S.a_off, sa_off = S.sa_off, cpr = S.cpr, nc = S.nc;
       const bool norm = S.norm_weight != nullptr;
       auto sync = [&](int which) -> bool {
         CHAIN_LDS_RELEASE();
         if (lane == 0) __hip_atomic_fetch_add(reinterpret_cast<uint32_t*>(smem) + CL_SYNC0 + s * 4 + which, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (!cw.wait_ge(CL_SYNC0 + s * 4 + which, (uint32_t)NL, CE_WAIT_ACT, s)) return false;
+        if (!cw.wait_ge(CL_SYNC0 + s * 4 + which, (uint32_t)NCONS, CE_WAIT_ACT, s)) return false;
         CHAIN_LDS_ACQUIRE();
         return true;
       };
-      auto raw_of = [&](int p) { return smem + args.raw_off + (norm ? p : cons) * 4096; };
       if (S.in_kind == 0) {
-        // the caller's vector: plain loads, this consumer's passes two per memory round trip
-        for (int p = cons; p < npass; p += 2 * NL) {
-          u32x4 x[2][IPL][IVW];
+        // the caller's vector: plain loads of this consumer's chunks into their regions (natural order)
+        for (int c = ci; c < nc; c += NCONS) {
+          u32x4 x[4][IVW];
 #pragma unroll
-          for (int h = 0; h < 2; ++h)
+          for (int q = 0; q < 4; ++q) {
+            const int i = c * 256 + q * 64 + lane;
+            const bool valid = (i >> 2) < cpr;
 #pragma unroll
-            for (int q = 0; q < IPL; ++q) {
-              const int i = (p + h * NL) * IPP + q * 64 + lane;
-              const bool valid = (i >> 2) < cpr;                   // (also false for a whole pass >= npass)
-#pragma unroll
-              for (int v = 0; v < IVW; ++v) x[h][q][v] = CHAIN_G(u32x4, S.A)[(long)(valid ? i : 0) * IVW + v];
-            }
-#pragma unroll
-          for (int h = 0; h < 2; ++h) {
-            const int pp = p + h * NL;
-            if (pp >= npass) break;
-            unsigned char* rawp = raw_of(pp);
-#pragma unroll
-            for (int q = 0; q < IPL; ++q)
-#pragma unroll
-              for (int v = 0; v < IVW; ++v) reinterpret_cast<u32x4*>(rawp + (long)(q * 64 + lane) * (EPW * 2))[v] = x[h][q][v];
-            if (!norm) chain_stage_pass<P, false>(smem, a_off, sa_off, cpr, rawp, pp * IPP, lane, 0.f, nullptr);
+            for (int v = 0; v < IVW; ++v) x[q][v] = CHAIN_G(u32x4, S.A)[(long)(valid ? i : 0) * IVW + v];
           }
+          unsigned char* dstp = smem + a_off + (long)c * (64 * E * 2);
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int v = 0; v < IVW; ++v) reinterpret_cast<u32x4*>(dstp + (long)(q * 64 + lane) * (EPW * 2))[v] = x[q][v];
+          if (!norm) chain_stage_chunk<P, false>(smem, a_off, sa_off, cpr, c, lane, 0.f, nullptr);
         }
       } else {
-        // granules of stage S.src: relaxed agent-scope 8-byte loads, 16 per lane and pass, this consumer's passes two at a time
-        // in flight; a pass is staged when every one of its tags matches, an incomplete one is read again after a nap
+        // granules of stage S.src: relaxed agent-scope 8-byte loads, 16 per lane and pass; a pass is kept when every one of its
+        // tags matches, an incomplete one is read again after a nap; a chunk is staged when its passes are in
         if (!need_gen(s)) return;
         const uint32_t tag = gen * 16u + (uint32_t)S.src + 1u;
         const int ng = (args.lab & 4) ? 0 : S.K / 2;
         const chain_gu64* g = (const chain_gu64*)(args.gran + args.st[S.src].gran_off);
-        if (args.thin && lane == 0) __hip_atomic_fetch_add(reinterpret_cast<uint32_t*>(smem) + CL_SWEEPING, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const bool mine = ci < nc;
+        if (mine && args.thin && lane == 0) __hip_atomic_fetch_add(reinterpret_cast<uint32_t*>(smem) + CL_SWEEPING, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         // the rows a later stage of this CU adds as its residual (the output of stage S.src): kept as they pass
         int stash_n0 = 0, stash_nr = 0, stash_off = 0;
-        if (S.stash_for >= 0) {
+        if (mine && S.stash_for >= 0) {
           const ChainStage& S2 = args.st[S.stash_for];
           int u0, u1;
           cw.task_range(S2.tasks, u0, u1);
@@ -792,92 +796,73 @@ __device__ void chain_consumer(const ChainWave& cw) {
           if (stash_n0 + stash_nr > S2.N) stash_nr = S2.N - stash_n0;
           stash_off = S2.stash_off;
         }
-        for (int base = cons; base < npass; base += kChainSweepPasses * NL) {
-          unsigned long long x[kChainSweepPasses][16];
-          unsigned pending = 0;
-#pragma unroll
-          for (int j = 0; j < kChainSweepPasses; ++j)
-            if (base + j * NL < npass) pending |= 1u << j;
-          unsigned n_ = 0;
-          unsigned long long t_ = 0;
-          for (;;) {
-#pragma unroll
-            for (int j = 0; j < kChainSweepPasses; ++j) {
-              if (!((pending >> j) & 1u)) continue;
+        for (int c = ci; c < nc; c += NCONS) {
+          unsigned char* dstp = smem + a_off + (long)c * (64 * E * 2);
+          for (int h = 0; h < PPC; ++h) {
+            const int p = c * PPC + h;
+            unsigned n_ = 0;
+            unsigned long long t_ = 0;
+            for (;;) {
+              unsigned long long x[16];
 #pragma unroll
               for (int k = 0; k < 16; ++k) {
-                const int gi = (base + j * NL) * 1024 + k * 64 + lane;
-                x[j][k] = gi < ng ? __hip_atomic_load(g + gi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ((unsigned long long)tag << 32);
+                const int gi = p * 1024 + k * 64 + lane;
+                x[k] = gi < ng ? __hip_atomic_load(g + gi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ((unsigned long long)tag << 32);
               }
-            }
-#pragma unroll
-            for (int j = 0; j < kChainSweepPasses; ++j) {
-              if (!((pending >> j) & 1u)) continue;
               bool ok = true;
 #pragma unroll
-              for (int k = 0; k < 16; ++k) ok &= (uint32_t)(x[j][k] >> 32) == tag;
-              if (!__all(ok)) continue;
-              pending &= ~(1u << j);
-              const int p = base + j * NL;
-              unsigned char* rawp = raw_of(p);
+              for (int k = 0; k < 16; ++k) ok &= (uint32_t)(x[k] >> 32) == tag;
+              if (__all(ok)) {
 #pragma unroll
-              for (int k = 0; k < 16; ++k) reinterpret_cast<uint32_t*>(rawp)[k * 64 + lane] = (uint32_t)x[j][k];
-              for (int i = lane; i < stash_nr; i += 64) {
-                const int n = stash_n0 + i - p * 2048;
-                if (n >= 0 && n < 2048) reinterpret_cast<uint16_t*>(smem + stash_off)[i] = reinterpret_cast<const uint16_t*>(rawp)[n];
+                for (int k = 0; k < 16; ++k) reinterpret_cast<uint32_t*>(dstp + h * 4096)[k * 64 + lane] = (uint32_t)x[k];
+                break;
               }
-              if (!norm) chain_stage_pass<P, false>(smem, a_off, sa_off, cpr, rawp, p * IPP, lane, 0.f, nullptr);
+              for (int i = 0; i < args.sweep_sleep; ++i) __builtin_amdgcn_s_sleep(8);       // ~0.2 us each
+              if (cw.expired(n_, t_)) {
+                cw.fail(CE_SWEEP, s);
+                return;
+              }
             }
-            if (!pending) break;
-            for (int i = 0; i < args.sweep_sleep; ++i) __builtin_amdgcn_s_sleep(8);       // ~0.2 us each
-            if (cw.expired(n_, t_)) {
-              cw.fail(CE_SWEEP, s);
-              return;
+            for (int i = lane; i < stash_nr; i += 64) {
+              const int n = stash_n0 + i - p * 2048;
+              if (n >= 0 && n < 2048) reinterpret_cast<uint16_t*>(smem + stash_off)[i] = reinterpret_cast<const uint16_t*>(dstp + h * 4096)[n];
             }
           }
+          if (!norm) chain_stage_chunk<P, false>(smem, a_off, sa_off, cpr, c, lane, 0.f, nullptr);
         }
-        if (args.thin && lane == 0) __hip_atomic_fetch_sub(reinterpret_cast<uint32_t*>(smem) + CL_SWEEPING, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (mine && args.thin && lane == 0) __hip_atomic_fetch_sub(reinterpret_cast<uint32_t*>(smem) + CL_SWEEPING, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
-      lab_stamp(1);
       if (norm) {
-        // the norm's weight for this consumer's passes: asked for now, used behind the three meetings
-        u32x4 nwr[2][IPL][IVW];
+        // (host: at most NCONS lane chunks under a norm - one per consumer)
+        // the norm's weight for this consumer's chunk: asked for now, used behind the three meetings
+        u32x4 nwr[4][IVW];
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
+        for (int q = 0; q < 4; ++q) {
+          const int i = ci * 256 + q * 64 + lane;
+          const bool valid = ci < nc && (i >> 2) < cpr;
 #pragma unroll
-          for (int q = 0; q < IPL; ++q) {
-            const int i = (cons + h * NL) * IPP + q * 64 + lane;
-            const bool valid = cons + h * NL < npass && (i >> 2) < cpr;
-#pragma unroll
-            for (int v = 0; v < IVW; ++v) nwr[h][q][v] = CHAIN_G(u32x4, S.norm_weight)[(long)(valid ? i : 0) * IVW + v];
-          }
-        if (!sync(0)) return;                       // the whole row is in the raw scratch
-        lab_stamp(3);
-        chain_norm_parts<P>(smem, args, S, lane, cons, NL);
-        if (!sync(1)) return;
-        lab_stamp(4);
-        chain_norm_wsums(smem, args, S, lane, cons, NL);
-        if (!sync(2)) return;
-        lab_stamp(5);
-        const float r = chain_norm_rinv(smem, S);
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const int p = cons + h * NL;              // (host: at most 2 * NL passes under a norm)
-          if (p < npass) chain_stage_pass<P, true>(smem, a_off, sa_off, cpr, smem + args.raw_off + p * 4096, p * IPP, lane, r, nwr[h]);
+          for (int v = 0; v < IVW; ++v) nwr[q][v] = CHAIN_G(u32x4, S.norm_weight)[(long)(valid ? i : 0) * IVW + v];
         }
+        if (!sync(0)) return;                       // the whole row is in the tile's region, natural order
+        chain_norm_parts<P>(smem, args, S, lane, ci, NCONS);
+        if (!sync(1)) return;
+        chain_norm_wsums(smem, args, S, lane, ci, NCONS);
+        if (!sync(2)) return;
+        const float r = chain_norm_rinv(smem, S);
+        if (ci < nc) chain_stage_chunk<P, true>(smem, a_off, sa_off, cpr, ci, lane, r, nwr);
       }
-      lab_stamp(2);
       if (!sync(3)) return;                         // the tile is complete
       // every workgroup of this launch has read the generation by now (its granules are here): the next launch's
-      if (S.in_kind == 1 && s == args.bump_stage && cw.b == 0 && cons == 0 && lane == 0)
+      if (S.in_kind == 1 && s == args.bump_stage && cw.b == 0 && ci == 0 && lane == 0)
         __hip_atomic_store((chain_gu32*)args.ctl, gen + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       cw.stamp(5 + 3 * s);
     }
-    // ---- this consumer's tasks of the stage ----
+    // ---- this consumer's tasks of the stage: task k of the CU's range belongs to lane k % NL, the lane's j-th task to its
+    // consumer j % CPL ----
     ChainTaskCtx X;
     X.nc = S.nc; X.cpr = S.cpr; X.kg = S.kg; X.gq_shift = S.gq_shift; X.N = S.N; X.n0 = n0;
     X.gq_magic = S.gq_magic; X.flip = S.flip;
-    X.a_off = S.a_off; X.sa_off = S.sa_off; X.ring_off = args.ring_off; X.ring_units = RING;
+    X.a_off = S.a_off; X.sa_off = S.sa_off; X.ring_off = args.ring_off + ln * RING * 1024; X.ring_units = RING;
 #pragma unroll
     for (int op = 0; op < 2; ++op) {
       X.sc_rel[op] = 0;
@@ -906,40 +891,43 @@ __device__ void chain_consumer(const ChainWave& cw) {
       X.gran = args.gran + S.gran_off;
     }
     const int un = S.un, pair = S.pair;
-    X.ring_off = args.ring_off + cons * RING * 1024;
     // the stage's scale / zeros blocks ride at the head of lane 0's stream
     if (S.nsc > 0 && !(args.lab & 2) && !cw.wait_ge(CL_LANDED0, (uint32_t)(useq0_base + S.nsc), CE_WAIT_LANDED, s)) return;
-    const int need_base = useq_base + (cons == 0 ? S.nsc : 0);
-    const int ntl = nt > cons ? (nt - cons + NL - 1) / NL : 0;      // tasks of this stage that fall to this lane: cons, cons + NL, ...
-    int rpos = rseq_base % RING;
-    int ustep = un;
-    while (ustep >= RING) ustep -= RING;
-    for (int j = 0; j < ntl; ++j) {
-      const int k = cons + j * NL;
-      if (!(args.lab & 2) && !cw.wait_ge(CL_LANDED0 + cons, (uint32_t)(need_base + (j + 1) * un), CE_WAIT_LANDED, s)) return;
+    const int need_base = useq_base + (ln == 0 ? S.nsc : 0);
+    const int ntl = nt > ln ? (nt - ln + NL - 1) / NL : 0;      // tasks of this stage that fall to this lane: ln, ln + NL, ...
+    int jstep = CPL * un;
+    while (jstep >= RING) jstep -= RING;
+    int rpos = (rseq_base + sub * un) % RING;
+    for (int j = sub; j < ntl; j += CPL) {
+      const int k = ln + j * NL;
+      if (!(args.lab & 2) && !cw.wait_ge(CL_LANDED0 + ln, (uint32_t)(need_base + (j + 1) * un), CE_WAIT_LANDED, s)) return;
       CHAIN_LDS_ACQUIRE();
       if (args.lab & 1) {
         if (X.gran && lane == 63) __hip_atomic_store((chain_gu64*)(X.gran + t0 + k), (unsigned long long)X.tag << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       } else if (pair) chain_task<P, 4>(smem, X, t0 + k, rpos, lane);
       else chain_task<P, 2>(smem, X, t0 + k, rpos, lane);
-      // the ring slots of this task are free
+      // the ring slots of this task are free: this consumer's next unfinished task of the lane
+      int next = rseq_base + (j + CPL) * un;
+      if (j + CPL >= ntl) next = rseq_base + ntl * un;
       CHAIN_LDS_RELEASE();
-      chain_lds_st(smem, CL_NEXT0 + cons, (uint32_t)(rseq_base + (j + 1) * un));
-      rpos += ustep;
+      chain_lds_st(smem, CL_NEXT0 + 4 * ln + sub, (uint32_t)next);
+      rpos += jstep;
       if (rpos >= RING) rpos -= RING;
     }
+    // (also when no task of this stage fell to this consumer: its frontier still moves past the stage)
+    chain_lds_st(smem, CL_NEXT0 + 4 * ln + sub, (uint32_t)(rseq_base + ntl * un));
     cw.stamp(6 + 3 * s);
     rseq_base += ntl * un;
-    useq_base += (cons == 0 ? S.nsc : 0) + ntl * un;
+    useq_base += (ln == 0 ? S.nsc : 0) + ntl * un;
     useq0_base += S.nsc + (nt > 0 ? (nt + NL - 1) / NL : 0) * un;
   }
-  chain_lds_st(smem, CL_NEXT0 + cons, 0x7fffffffu);
-  chain_lds_st(smem, CL_CSTAGE0 + cons, 0x7fffffffu);
+  chain_lds_st(smem, CL_NEXT0 + 4 * ln + sub, 0x7fffffffu);
+  chain_lds_st(smem, CL_CSTAGE0 + ci, 0x7fffffffu);
 }
 
-// 2 x nlanes waves (at most 8: two per SIMD, 256 registers each)
+// nlanes loaders (waves 0 .. NL-1: one per SIMD) + nlanes * cpl consumers: at most 16 waves, 128 registers each
 template <int BITS, int LAYOUT, int MODE>
-__global__ void __launch_bounds__(512) wq_chain_kernel(const ChainArgs args) {
+__global__ void __launch_bounds__(1024) wq_chain_kernel(const ChainArgs args) {
   using P = GemvxPolicy<BITS, LAYOUT, MODE, 1, 2, 2>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int tid = threadIdx.x;
@@ -952,16 +940,18 @@ __global__ void __launch_bounds__(512) wq_chain_kernel(const ChainArgs args) {
   cw.G = (int)gridDim.x;
   cw.timeout = args.timeout_ticks;
   if (tid < CL_WORDS) {
-    const int slot = tid & 7;
-    const bool unused = (tid >= CL_CSTAGE0 && tid < CL_CSTAGE0 + 8) && slot >= args.nlanes;
-    reinterpret_cast<uint32_t*>(smem_raw)[tid] = unused ? 0x7fffffffu : 0u;
+    uint32_t v = 0u;
+    const int ncons = args.nlanes * args.cpl;
+    if (tid >= CL_NEXT0 && tid < CL_NEXT0 + 16 && ((tid - CL_NEXT0) >> 2 >= args.nlanes || ((tid - CL_NEXT0) & 3) >= args.cpl)) v = 0x7fffffffu;
+    if (tid >= CL_CSTAGE0 && tid < CL_CSTAGE0 + 16 && tid - CL_CSTAGE0 >= ncons) v = 0x7fffffffu;
+    reinterpret_cast<uint32_t*>(smem_raw)[tid] = v;
   }
   __syncthreads();
   cw.stamp(0);
   if (cw.wave < args.nlanes) chain_loader<P>(cw);
   else {
     if (args.lab & 32) __builtin_amdgcn_s_setprio(3);      // lab: the consumers above the loaders in issue priority
-    chain_consumer<P, 2>(cw);
+    chain_consumer<P>(cw);
   }
   cw.stamp(3);
 }

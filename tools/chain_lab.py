@@ -87,7 +87,7 @@ def graph_us(fn):
 
 def variant(name, env):
     """one configuration of the persistent member (plan-time switches: chain_plan re-reads them)"""
-    for k in ("WQAA_CHAIN_LANES", "WQAA_CHAIN_THIN", "WQAA_CHAIN_SWEEP_SLEEP", "WQAA_CHAIN_RING", "WQAA_CHAIN_TRACE", "WQAA_CHAIN_LAB"):
+    for k in ("WQAA_CHAIN_LANES", "WQAA_CHAIN_CPL", "WQAA_CHAIN_THIN", "WQAA_CHAIN_SWEEP_SLEEP", "WQAA_CHAIN_RING", "WQAA_CHAIN_TRACE", "WQAA_CHAIN_LAB"):
         os.environ.pop(k, None)
     os.environ.update(env)
     plan = chain_plan(steps_of(layers[0], x0, chs[0], cas[0], cos[0]))
@@ -150,11 +150,14 @@ per = graph_us(run_launches)
 print(json.dumps({"variant": "launches_3_per_layer", "us_per_layer_tail": [round(p, 2) for p in per], "median": round(float(np.median(per)), 2),
                   "GBps": round(nbytes / np.median(per) / 1e3, 1), "weight_bytes_per_tail": nbytes}), flush=True)
 # lab bits (results wrong by construction): 1 no dots, 2 consumers do not wait for the weights, 4 no sweeps, 8 default-policy DMA
-VARIANTS = [("l4", {})]
+VARIANTS = [("l4c3", {}), ("l4c2", {"WQAA_CHAIN_CPL": "2"}), ("l4c1", {"WQAA_CHAIN_CPL": "1"}), ("l2c3", {"WQAA_CHAIN_LANES": "2"}),
+            ("l4c3_nothin", {"WQAA_CHAIN_THIN": "0"}), ("l4c3_prio", {"WQAA_CHAIN_LAB": "32"}),
+            ("lab5_no_dots_no_sweeps", {"WQAA_CHAIN_LAB": "5"}), ("lab4_no_sweeps", {"WQAA_CHAIN_LAB": "4"}), ("lab1_no_dots", {"WQAA_CHAIN_LAB": "1"}),
+            ("lab21_no_stream_no_sweeps_no_dots", {"WQAA_CHAIN_LAB": "21"})]
 for name, env in VARIANTS:
     variant(name, env)
 per = graph_us(run_launches)
 print(json.dumps({"variant": "launches_again", "median": round(float(np.median(per)), 2)}), flush=True)
 if not args.no_trace:
-    timeline("l4", {})
+    timeline("l4c3", {})
     timeline("lab21_no_stream_no_sweeps_no_dots", {"WQAA_CHAIN_LAB": "21"})
