@@ -363,7 +363,7 @@ __device__ void chain_loader(const ChainWave& cw) {
           ++rseq;
           ++issued;
           if (++in_fill == kChainFill) {
-            if (L == 0 && (issued & 15) == 0 && issued <= 64) cw.stamp(27 + (issued >> 4));      // lab: lane 0 has issued 16 / 32 / 48 / 64 units
+            if (L == 0 && (issued & 15) == 0 && issued <= 64) cw.stamp(19 + (issued >> 4));      // lab: lane 0 has issued 16 / 32 / 48 / 64 units
             boundary(s);
             if (dead) return;
           }
@@ -717,6 +717,10 @@ __device__ void chain_consumer(const ChainWave& cw) {
   const int RING = args.ring_units;
   int rseq_base = 0, useq_base = 0;               // of the current stage, in this lane's own unit stream
   int useq0_base = 0;                             // ... in lane 0's (which also carries every stage's scale blocks)
+  // lab: shader cycles this wave spent waiting for weights / in the dots / staging inputs / in the staging's meetings / waiting for granules
+  unsigned long long acc_t[5] = {0, 0, 0, 0, 0};
+  const bool timing = args.trace != nullptr;
+  auto now = [&]() -> unsigned long long { return timing ? __builtin_amdgcn_s_memtime() : 0ull; };
   uint32_t gen = 0;
   bool have_gen = false;
   auto need_gen = [&](int s) -> bool {
@@ -747,15 +751,18 @@ __device__ void chain_consumer(const ChainWave& cw) {
     // in place in the chunk's region of the tile ----
     if (S.in_kind != 2) {
       cw.stamp(4 + 3 * s);
+      const unsigned long long tst0 = now();
       // the LDS tile of this input generation was read by the stages two generations back
       if (S.wait_stage > 0 && !cw.wait_cstage(S.wait_stage, CE_WAIT_STAGE, s)) return;
       const int a_off = S.a_off, sa_off = S.sa_off, cpr = S.cpr, nc = S.nc;
       const bool norm = S.norm_weight != nullptr;
       auto sync = [&](int which) -> bool {
+        const unsigned long long ts0 = now();
         CHAIN_LDS_RELEASE();
         if (lane == 0) __hip_atomic_fetch_add(reinterpret_cast<uint32_t*>(smem) + CL_SYNC0 + s * 4 + which, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         if (!cw.wait_ge(CL_SYNC0 + s * 4 + which, (uint32_t)NCONS, CE_WAIT_ACT, s)) return false;
         CHAIN_LDS_ACQUIRE();
+        acc_t[3] += now() - ts0;
         return true;
       };
       if (S.in_kind == 0) {
@@ -802,6 +809,7 @@ __device__ void chain_consumer(const ChainWave& cw) {
             const int p = c * PPC + h;
             unsigned n_ = 0;
             unsigned long long t_ = 0;
+            const unsigned long long tg0 = now();
             for (;;) {
               unsigned long long x[16];
 #pragma unroll
@@ -823,6 +831,7 @@ __device__ void chain_consumer(const ChainWave& cw) {
                 return;
               }
             }
+            acc_t[4] += now() - tg0;
             for (int i = lane; i < stash_nr; i += 64) {
               const int n = stash_n0 + i - p * 2048;
               if (n >= 0 && n < 2048) reinterpret_cast<uint16_t*>(smem + stash_off)[i] = reinterpret_cast<const uint16_t*>(dstp + h * 4096)[n];
@@ -856,6 +865,7 @@ __device__ void chain_consumer(const ChainWave& cw) {
       if (S.in_kind == 1 && s == args.bump_stage && cw.b == 0 && ci == 0 && lane == 0)
         __hip_atomic_store((chain_gu32*)args.ctl, gen + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       cw.stamp(5 + 3 * s);
+      acc_t[2] += now() - tst0;
     }
     // ---- this consumer's tasks of the stage: task k of the CU's range belongs to lane k % NL, the lane's j-th task to its
     // consumer j % CPL ----
@@ -900,8 +910,11 @@ __device__ void chain_consumer(const ChainWave& cw) {
     int rpos = (rseq_base + sub * un) % RING;
     for (int j = sub; j < ntl; j += CPL) {
       const int k = ln + j * NL;
+      const unsigned long long tw0 = now();
       if (!(args.lab & 2) && !cw.wait_ge(CL_LANDED0 + ln, (uint32_t)(need_base + (j + 1) * un), CE_WAIT_LANDED, s)) return;
       CHAIN_LDS_ACQUIRE();
+      const unsigned long long tw1 = now();
+      acc_t[0] += tw1 - tw0;
       if (args.lab & 1) {
         if (X.gran && lane == 63) __hip_atomic_store((chain_gu64*)(X.gran + t0 + k), (unsigned long long)X.tag << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       } else if (pair) chain_task<P, 4>(smem, X, t0 + k, rpos, lane);
@@ -911,6 +924,7 @@ __device__ void chain_consumer(const ChainWave& cw) {
       if (j + CPL >= ntl) next = rseq_base + ntl * un;
       CHAIN_LDS_RELEASE();
       chain_lds_st(smem, CL_NEXT0 + 4 * ln + sub, (uint32_t)next);
+      acc_t[1] += now() - tw1;
       rpos += jstep;
       if (rpos >= RING) rpos -= RING;
     }
@@ -923,6 +937,10 @@ __device__ void chain_consumer(const ChainWave& cw) {
   }
   chain_lds_st(smem, CL_NEXT0 + 4 * ln + sub, 0x7fffffffu);
   chain_lds_st(smem, CL_CSTAGE0 + ci, 0x7fffffffu);
+  if (timing && lane == 0) {
+#pragma unroll
+    for (int i = 0; i < 5; ++i) args.trace[((long)cw.b * 16 + cw.wave) * 32 + 26 + i] = acc_t[i];
+  }
 }
 
 // nlanes loaders (waves 0 .. NL-1: one per SIMD) + nlanes * cpl consumers: at most 16 waves, 128 registers each
@@ -945,6 +963,16 @@ __global__ void __launch_bounds__(1024) wq_chain_kernel(const ChainArgs args) {
     if (tid >= CL_NEXT0 && tid < CL_NEXT0 + 16 && ((tid - CL_NEXT0) >> 2 >= args.nlanes || ((tid - CL_NEXT0) & 3) >= args.cpl)) v = 0x7fffffffu;
     if (tid >= CL_CSTAGE0 && tid < CL_CSTAGE0 + 16 && tid - CL_CSTAGE0 >= ncons) v = 0x7fffffffu;
     reinterpret_cast<uint32_t*>(smem_raw)[tid] = v;
+  }
+  // The descriptors live in the kernel-argument segment, which the device reads through the scalar cache a 64-byte line at a
+  // time - and a first touch is a trip to memory (host-visible memory for an eager launch): 0.5 - 1.5 us EACH where the
+  // stages' fields are fetched one by one as they are first used.  Every wave asks for every line now, in one go.
+  {
+    const uint32_t* ap = reinterpret_cast<const uint32_t*>(&args);
+    uint32_t touch = 0;
+#pragma unroll
+    for (int i = 0; i < (int)(sizeof(ChainArgs) / 4); i += 16) touch |= ap[i];
+    asm volatile("" ::"s"(touch));
   }
   __syncthreads();
   cw.stamp(0);

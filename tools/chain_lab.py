@@ -106,9 +106,11 @@ def variant(name, env):
 
 
 def timeline(name, env):
+    for k in ("WQAA_CHAIN_LANES", "WQAA_CHAIN_CPL", "WQAA_CHAIN_THIN", "WQAA_CHAIN_SWEEP_SLEEP", "WQAA_CHAIN_RING", "WQAA_CHAIN_TRACE", "WQAA_CHAIN_LAB"):
+        os.environ.pop(k, None)
     os.environ.update(env)
     os.environ["WQAA_CHAIN_TRACE"] = "1"
-    chain_plan(steps_of(layers[0], x0, None, None, cos[0]))
+    plan = chain_plan(steps_of(layers[0], x0, None, None, cos[0]))
     matmul_chain(steps_of(layers[0], x0, None, None, cos[0]))
     torch.cuda.synchronize()
     matmul_chain(steps_of(layers[1], x0, None, None, cos[1]))       # cold weights for the traced launch
@@ -120,21 +122,20 @@ def timeline(name, env):
     chain_plan(steps_of(layers[0], x0, None, None, cos[0]))
     if not tr.size:
         return
+    nl = 4 if not env.get("WQAA_CHAIN_LANES") else int(env["WQAA_CHAIN_LANES"])
     t0 = tr[:, :, 0][tr[:, :, 0] > 0].min()
-    names = {0: "wave start", 1: "loader: first DMA issued", 2: "loader: stream drained", 3: "wave end", 28: "loader 0: 16 units issued",
-             29: "loader 0: 32 units issued", 30: "loader 0: 48 units issued", 31: "loader 0: 64 units issued"}
+    names = {0: "wave start", 1: "loader: first DMA issued", 2: "loader: stream drained", 3: "wave end", 20: "loader 0: 16 units issued",
+             21: "loader 0: 32 units issued", 22: "loader 0: 48 units issued", 23: "loader 0: 64 units issued"}
     for s in range(3):
-        names[4 + 3 * s] = f"stage {s}: stager starts"
+        names[4 + 3 * s] = f"stage {s}: staging starts"
         names[5 + 3 * s] = f"stage {s}: input tile ready"
         names[6 + 3 * s] = f"stage {s}: this wave's tasks done"
     ok = (tr[:, :, 24] > 0) & (tr[:, :, 25] > tr[:, :, 24]) & (tr[:, :, 3] > tr[:, :, 0])
+    mhz = 2350.0
     if ok.any():
-        mhz = (tr[:, :, 25] - tr[:, :, 24])[ok] / ((tr[:, :, 3] - tr[:, :, 0])[ok] / 100.0)
-        print(f"shader clock over the launch [{name}] (s_memtime ticks per s_memrealtime microsecond): min {mhz.min():.0f} median {np.median(mhz):.0f} max {mhz.max():.0f} MHz")
-    for i, nm in ((13, "st1 staging: tile free"), (14, "st1 staging: my passes swept"), (16, "st1 staging: sync0 passed"), (17, "st1 staging: sync1 passed"),
-                  (18, "st1 staging: sync2 passed"), (15, "st1 staging: my passes staged"), (20, "st2 staging: tile free"), (21, "st2 staging: my passes swept+staged"),
-                  (22, "st2 staging: before last sync")):
-        names[i] = nm
+        m = (tr[:, :, 25] - tr[:, :, 24])[ok] / ((tr[:, :, 3] - tr[:, :, 0])[ok] / 100.0)
+        mhz = float(np.median(m))
+        print(f"[{name}] {(plan['plan'] or {}).get('name')}: shader clock over the launch: min {m.min():.0f} median {mhz:.0f} max {m.max():.0f} MHz")
     print(f"time line of one launch [{name}], microseconds after the first wave's start (100 MHz clock): min / median / max over the waves that stamped")
     for i in sorted(names):
         v = tr[:, :, i]
@@ -142,6 +143,13 @@ def timeline(name, env):
         if v.size:
             u = (v - t0) / 100.0
             print(f"  {names[i]:44s} n={v.size:4d}  {u.min():7.2f} {np.median(u):7.2f} {u.max():7.2f}")
+    cons = tr[:, nl:, :]
+    live = cons[:, :, 3] > 0
+    print("  per consumer wave, microseconds of shader time (min / median / max): ")
+    for i, nm in enumerate(("waiting for weights to land", "in the tasks (dots, store, publish)", "staging inputs (all of it)", "... of which in the meetings",
+                            "... of which waiting for granules")):
+        v = cons[:, :, 26 + i][live] / mhz
+        print(f"    {nm:40s} {v.min():7.2f} {np.median(v):7.2f} {v.max():7.2f}")
 
 
 run_launches(); torch.cuda.synchronize()
@@ -150,8 +158,7 @@ per = graph_us(run_launches)
 print(json.dumps({"variant": "launches_3_per_layer", "us_per_layer_tail": [round(p, 2) for p in per], "median": round(float(np.median(per)), 2),
                   "GBps": round(nbytes / np.median(per) / 1e3, 1), "weight_bytes_per_tail": nbytes}), flush=True)
 # lab bits (results wrong by construction): 1 no dots, 2 consumers do not wait for the weights, 4 no sweeps, 8 default-policy DMA
-VARIANTS = [("l4c3", {}), ("l4c2", {"WQAA_CHAIN_CPL": "2"}), ("l4c1", {"WQAA_CHAIN_CPL": "1"}), ("l2c3", {"WQAA_CHAIN_LANES": "2"}),
-            ("l4c3_nothin", {"WQAA_CHAIN_THIN": "0"}), ("l4c3_prio", {"WQAA_CHAIN_LAB": "32"}),
+VARIANTS = [("l4c3", {}), ("l4c2", {"WQAA_CHAIN_CPL": "2"}), ("l4c1", {"WQAA_CHAIN_CPL": "1"}),
             ("lab5_no_dots_no_sweeps", {"WQAA_CHAIN_LAB": "5"}), ("lab4_no_sweeps", {"WQAA_CHAIN_LAB": "4"}), ("lab1_no_dots", {"WQAA_CHAIN_LAB": "1"}),
             ("lab21_no_stream_no_sweeps_no_dots", {"WQAA_CHAIN_LAB": "21"})]
 for name, env in VARIANTS:
