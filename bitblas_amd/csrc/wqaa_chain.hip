@@ -426,6 +426,7 @@ static int chain_build(const wqaa_chain_item* items, int count, int m, ChainBuil
   out->cpl = cpl;
   A.nlanes = lanes;
   A.cpl = cpl;
+  A.g_shift = (out->grid & (out->grid - 1)) == 0 ? ilog2_exact(out->grid) : -1;
   A.ring_units = ring_units;
   out->lds_bytes = A.ring_off + lanes * ring_units * 1024;
   A.nstages = count;

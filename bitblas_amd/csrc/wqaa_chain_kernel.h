@@ -91,6 +91,7 @@ struct ChainArgs {
   ChainStage st[kChainMaxStages];
   int nstages;
   int nlanes, cpl;          // lanes and consumers per lane (blockDim = 64 * nlanes * (1 + cpl))
+  int g_shift;              // log2(grid) when the grid is a power of two (256 CUs), else -1
   int ring_off, ring_units; // ring_units: per lane; lane l's slice starts at ring_off + l * ring_units KiB
   int parts_off;
   int bump_stage;           // the stage after whose sweep workgroup 0 bumps the generation (-1: no edge)
@@ -217,8 +218,14 @@ struct ChainWave {
     return true;
   }
   __device__ __forceinline__ void task_range(int tasks, int& t0, int& t1) const {
-    t0 = (int)(((uint32_t)b * (uint32_t)tasks) / (uint32_t)G);            // tasks * G < 2^32 (host)
-    t1 = (int)(((uint32_t)(b + 1) * (uint32_t)tasks) / (uint32_t)G);
+    const int gs = args->g_shift;
+    if (gs >= 0) {                                                        // tasks * G < 2^32 (host)
+      t0 = (int)(((uint32_t)b * (uint32_t)tasks) >> gs);
+      t1 = (int)(((uint32_t)(b + 1) * (uint32_t)tasks) >> gs);
+    } else {
+      t0 = (int)(((uint32_t)b * (uint32_t)tasks) / (uint32_t)G);
+      t1 = (int)(((uint32_t)(b + 1) * (uint32_t)tasks) / (uint32_t)G);
+    }
   }
 };
 
@@ -350,14 +357,22 @@ __device__ void chain_loader(const ChainWave& cw) {
     int nfull = tail_partial ? nc - 1 : nc;
     asm volatile("" : "+s"(nc), "+s"(rows_per_task), "+s"(pair), "+s"(Nrows), "+s"(row_bytes), "+s"(B0), "+s"(B1), "+s"(nfull));
     for (int t = t0 + L; t < t1; t += NL) {
-      for (int r = 0; r < rows_per_task; ++r) {
-        int n = 2 * t + (pair ? (r >> 1) : r);
+      // the task's rows, lane chunk by lane chunk (chunk c of every row, then chunk c + 1): its consumer starts on chunk 0 while
+      // the rest is still in flight, and hands the ring slots back chunk by chunk
+      unsigned long long rowb[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int n = 2 * t + (pair ? (r >> 1) : (r & 1));
         n = n < Nrows ? n : Nrows - 1;
         const unsigned long long base = (pair && (r & 1)) ? B1 : B0;
-        unsigned long long src = chain_uniform64(base + (unsigned long long)((long)n * row_bytes));
-        for (int c = 0; c < nc; ++c) {
-          chain_dma(dst, c < nfull ? voff_full : voff_tail, src, dflt);
-          src += 1024ull;
+        rowb[r] = chain_uniform64(base + (unsigned long long)((long)n * row_bytes));
+      }
+      for (int c = 0; c < nc; ++c) {
+        const unsigned voff = c < nfull ? voff_full : voff_tail;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (r >= rows_per_task) break;
+          chain_dma(dst, voff, rowb[r] + (unsigned long long)c * 1024ull, dflt);
           dst += 1024u;
           if (dst == ring_end) dst = (unsigned)ring_base;
           ++rseq;
@@ -507,21 +522,20 @@ __device__ __forceinline__ void chain_stage_chunk(unsigned char* smem, int a_off
 
 // sum x^2 of the raw vector (natural order, in the tile's region) in the order the single launch takes it (NWV waves x NAI
 // items per thread: item idx = j * threads + tid; per thread over j, per wave by the DPP ladder, across the waves in wave
-// order).  The consumers share the work: (1) per-item partial sums for the slots idx >> 6 == ci (mod NCONS); (2) the (virtual)
-// waves w == ci (mod NCONS); (3) everyone adds the wave sums in wave order - the same bits in every consumer.
+// order).  (1) the consumer that brought lane chunk c in takes the per-item partial sums of the chunk's four slots
+// (launch-path item idx = c * 256 + u * 64 + l, slot = idx >> 6 = 4c + u); (2) after ONE meeting every staging consumer
+// runs the wave ladders and the sum over the waves itself - the same bits in every wave, no second hand-off.
 template <class P>
-__device__ __forceinline__ void chain_norm_parts(unsigned char* smem, const ChainArgs& args, const ChainStage& S, int lane, int ci, int ncons) {
+__device__ __forceinline__ void chain_norm_parts(unsigned char* smem, const ChainArgs& args, const ChainStage& S, int lane, int c) {
   constexpr int EPW = P::EPW, IVW = EPW / 8;
-  float* parts = reinterpret_cast<float*>(smem + args.parts_off);      // [slot = idx >> 6][lane]
+  float* parts = reinterpret_cast<float*>(smem + args.parts_off);      // [slot][lane]
   const unsigned char* raw = smem + S.a_off;
-  const int nslots = S.nc * 4;                                         // launch-path items idx = c * 256 + u * 64 + l: slot = idx >> 6
-  const int cpr = S.cpr;
-  for (int sl = ci; sl < nslots; sl += ncons) {
-    // launch-path item idx = c * 256 + u * 64 + l  <->  natural item (c * 64 + l) * 4 + u
-    const int c = sl >> 2, u = sl & 3;
-    const int cl = c * 64 + lane;
+  const int cl = c * 64 + lane;
+  const bool valid = cl < S.cpr;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
     float part = 0.f;
-    if (cl < cpr) {
+    if (valid) {
       const u32x4* src = reinterpret_cast<const u32x4*>(raw + ((long)cl * 4 + u) * (EPW * 2));
 #pragma unroll
       for (int v = 0; v < IVW; ++v) {
@@ -530,27 +544,24 @@ __device__ __forceinline__ void chain_norm_parts(unsigned char* smem, const Chai
         for (int e = 0; e < 4; ++e) part = __builtin_amdgcn_fdot2(as_h2(x[e]), as_h2(x[e]), part, false);
       }
     }
-    parts[sl * 64 + lane] = part;
+    parts[(c * 4 + u) * 64 + lane] = part;
   }
 }
-__device__ __forceinline__ void chain_norm_wsums(unsigned char* smem, const ChainArgs& args, const ChainStage& S, int lane, int ci, int ncons) {
+__device__ __forceinline__ float chain_norm_rinv(const unsigned char* smem, const ChainArgs& args, const ChainStage& S, int lane) {
   const float* parts = reinterpret_cast<const float*>(smem + args.parts_off);
   const int nslots = S.nc * 4;
   const int nwv = S.norm_nwv, nai = S.norm_nai;
-  for (int w = ci; w < nwv; w += ncons) {
+  float tot = 0.f;
+  for (int w = 0; w < nwv; ++w) {
     float ssq = 0.f;
     for (int j = 0; j < nai; ++j) {
       const int sl = j * nwv + w;
       ssq += sl < nslots ? parts[sl * 64 + lane] : 0.f;
     }
     const float ws = wave_sum_l63(ssq);
-    if (lane == 63) reinterpret_cast<float*>(smem)[CL_WSUM + w] = ws;
+    const float wsum = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ws), 63));
+    tot = w == 0 ? wsum : tot + wsum;
   }
-}
-__device__ __forceinline__ float chain_norm_rinv(const unsigned char* smem, const ChainStage& S) {
-  const float* wsum = reinterpret_cast<const float*>(smem) + CL_WSUM;
-  float tot = wsum[0];
-  for (int w = 1; w < S.norm_nwv; ++w) tot += wsum[w];
   return rsqrtf(tot * S.norm_inv_k + S.norm_eps);
 }
 
@@ -570,16 +581,23 @@ struct ChainTaskCtx {
   uint32_t tag;
 };
 
+// one task: ROWS weight rows (two output elements) against the staged input.  The rows sit in the lane's ring lane chunk by
+// lane chunk (slot rpos + c * ROWS + r); chunk c is awaited on its own (the loader's landed count `need0 + (c + 1) * ROWS`) and
+// its slots are handed back as soon as its dots are done (`next_word` = the ring sequence number of this consumer's first
+// unit still in use).  false: the wait gave up.
 template <class P, int ROWS>
-__device__ __forceinline__ void chain_task(unsigned char* smem, const ChainTaskCtx& X, int t, int rpos, int lane) {
+__device__ __forceinline__ bool chain_task(const ChainWave& cw, const ChainTaskCtx& X, int t, int rpos, int landed_word, int need0, int next_word,
+                                           int rseq0, int stage, bool free_run) {
   constexpr int PPW = P::PPW, PIECES = P::PIECES, MODE = P::MODE;
   constexpr bool PAIR = ROWS == 4;
   constexpr bool ZT = MODE == MD_ZO || MODE == MD_ZR;
+  unsigned char* smem = cw.smem;
+  const int lane = cw.lane;
   const int RING = X.ring_units;
   const u32x4* a_lds = reinterpret_cast<const u32x4*>(smem + X.a_off);
   const float* sa_lds = reinterpret_cast<const float*>(smem + X.sa_off);
-  // output elements of the task, the operator and scale block of each streamed row, its first ring slot
-  int elem[ROWS], sc_base[ROWS], z_base[ROWS], rp[ROWS];
+  // output elements of the task, the operator and scale block of each streamed row
+  int elem[ROWS], sc_base[ROWS], z_base[ROWS];
 #pragma unroll
   for (int r = 0; r < ROWS; ++r) {
     int e = 2 * t + (PAIR ? (r >> 1) : r);
@@ -588,8 +606,6 @@ __device__ __forceinline__ void chain_task(unsigned char* smem, const ChainTaskC
     const int op = PAIR ? (r & 1) : 0;
     sc_base[r] = X.sc_rel[op] + (e - X.n0) * X.kg * 2;
     z_base[r] = X.z_rel[op] + (e - X.n0) * X.kg * 2;
-    rp[r] = rpos + r * X.nc;
-    while (rp[r] >= RING) rp[r] -= RING;
   }
   // bias / the caller's residual: asked for before the dots (every lane the same address: one request), used behind them
   uint16_t res_bits[ROWS], bias_bits[ROWS];
@@ -608,9 +624,24 @@ __device__ __forceinline__ void chain_task(unsigned char* smem, const ChainTaskC
     u32x4 w[ROWS];
     uint32_t sb[ROWS], zb[ROWS];
   };
-  // every LDS operand of lane chunk c, asked for in one go (one wave per SIMD: nothing else hides an LDS round trip);
-  // the next chunk's are in flight while this one's dots run
-  auto load = [&](Ops& o, int c) {
+  int slot = rpos;                                  // ring slot of (chunk c, row 0), c = the next chunk to load
+  int landed = (int)chain_lds_ld(smem, landed_word);
+  // every LDS operand of lane chunk c, asked for in one go, once the loader says the chunk has landed
+  auto load = [&](Ops& o, int c) -> bool {
+    const int need = need0 + (c + 1) * ROWS;
+    if (!free_run && landed < need) {
+      unsigned n_ = 0;
+      unsigned long long t_ = 0;
+      for (;;) {
+        landed = (int)chain_lds_ld(smem, landed_word);
+        if (landed >= need) break;
+        if (cw.expired(n_, t_)) {
+          cw.fail(CE_WAIT_LANDED, stage);
+          return false;
+        }
+      }
+      CHAIN_LDS_ACQUIRE();
+    }
     const int chunk = c * 64 + lane;
     int gi = 0;
     if constexpr (MODE != MD_NONE) {
@@ -622,32 +653,37 @@ __device__ __forceinline__ void chain_task(unsigned char* smem, const ChainTaskC
     o.sa = sa_lds[c * 64 + lane];
 #pragma unroll
     for (int r = 0; r < ROWS; ++r) {
-      o.w[r] = *reinterpret_cast<const u32x4*>(smem + X.ring_off + rp[r] * 1024 + lane * 16);
+      o.w[r] = *reinterpret_cast<const u32x4*>(smem + X.ring_off + slot * 1024 + lane * 16);
+      if (++slot == RING) slot = 0;
       o.sb[r] = 0;
       o.zb[r] = 0;
       if constexpr (MODE != MD_NONE) o.sb[r] = *reinterpret_cast<const uint16_t*>(smem + sc_base[r] + gi * 2);
       if constexpr (ZT) o.zb[r] = *reinterpret_cast<const uint16_t*>(smem + z_base[r] + gi * 2);
-      if (++rp[r] == RING) rp[r] = 0;
     }
+    return true;
   };
   float acc[ROWS];
 #pragma unroll
   for (int r = 0; r < ROWS; ++r) acc[r] = 0.f;
-  auto compute = [&](const Ops& o) { chain_chunk<P, ROWS>(o.w, o.av, o.sa, o.sb, o.zb, X.zint, X.flip, acc); };
+  // the dots of chunk c; its ring slots go back to the loader (the operands are in registers)
+  auto compute = [&](const Ops& o, int c) {
+    chain_lds_st(smem, next_word, (uint32_t)(rseq0 + (c + 1) * ROWS));
+    chain_chunk<P, ROWS>(o.w, o.av, o.sa, o.sb, o.zb, X.zint, X.flip, acc);
+  };
   if constexpr (ROWS <= 2) {
     // two rows: the next chunk's operands are in flight while this one's dots run
     Ops oa, ob;
     const int nc = X.nc;
-    load(oa, 0);
+    if (!load(oa, 0)) return false;
     int c = 0;
     for (;;) {
-      if (c + 1 < nc) load(ob, c + 1);
+      if (c + 1 < nc && !load(ob, c + 1)) return false;
       __builtin_amdgcn_sched_barrier(0);
-      compute(oa);
+      compute(oa, c);
       if (++c >= nc) break;
-      if (c + 1 < nc) load(oa, c + 1);
+      if (c + 1 < nc && !load(oa, c + 1)) return false;
       __builtin_amdgcn_sched_barrier(0);
-      compute(ob);
+      compute(ob, c);
       if (++c >= nc) break;
     }
   } else {
@@ -655,9 +691,9 @@ __device__ __forceinline__ void chain_task(unsigned char* smem, const ChainTaskC
     // waves cover the LDS round trip)
     Ops oa;
     for (int c = 0; c < X.nc; ++c) {
-      load(oa, c);
+      if (!load(oa, c)) return false;
       __builtin_amdgcn_sched_barrier(0);
-      compute(oa);
+      compute(oa, c);
     }
   }
   float tot[ROWS];
@@ -701,6 +737,7 @@ __device__ __forceinline__ void chain_task(unsigned char* smem, const ChainTaskC
     }
     if (X.gran) __hip_atomic_store((chain_gu64*)(X.gran + t), ((unsigned long long)X.tag << 32) | bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
+  return true;
 }
 
 template <class P>
@@ -781,7 +818,8 @@ __device__ void chain_consumer(const ChainWave& cw) {
           for (int q = 0; q < 4; ++q)
 #pragma unroll
             for (int v = 0; v < IVW; ++v) reinterpret_cast<u32x4*>(dstp + (long)(q * 64 + lane) * (EPW * 2))[v] = x[q][v];
-          if (!norm) chain_stage_chunk<P, false>(smem, a_off, sa_off, cpr, c, lane, 0.f, nullptr);
+          if (norm) chain_norm_parts<P>(smem, args, S, lane, c);
+          else chain_stage_chunk<P, false>(smem, a_off, sa_off, cpr, c, lane, 0.f, nullptr);
         }
       } else {
         // granules of stage S.src: relaxed agent-scope 8-byte loads, 16 per lane and pass; a pass is kept when every one of its
@@ -837,13 +875,14 @@ __device__ void chain_consumer(const ChainWave& cw) {
               if (n >= 0 && n < 2048) reinterpret_cast<uint16_t*>(smem + stash_off)[i] = reinterpret_cast<const uint16_t*>(dstp + h * 4096)[n];
             }
           }
-          if (!norm) chain_stage_chunk<P, false>(smem, a_off, sa_off, cpr, c, lane, 0.f, nullptr);
+          if (norm) chain_norm_parts<P>(smem, args, S, lane, c);
+          else chain_stage_chunk<P, false>(smem, a_off, sa_off, cpr, c, lane, 0.f, nullptr);
         }
         if (mine && args.thin && lane == 0) __hip_atomic_fetch_sub(reinterpret_cast<uint32_t*>(smem) + CL_SWEEPING, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
       if (norm) {
-        // (host: at most NCONS lane chunks under a norm - one per consumer)
-        // the norm's weight for this consumer's chunk: asked for now, used behind the three meetings
+        // the norm's weight for this consumer's chunk (host: at most NCONS lane chunks under a norm - one per consumer): asked
+        // for now, used behind the meeting and the wave ladders
         u32x4 nwr[4][IVW];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -852,13 +891,11 @@ __device__ void chain_consumer(const ChainWave& cw) {
 #pragma unroll
           for (int v = 0; v < IVW; ++v) nwr[q][v] = CHAIN_G(u32x4, S.norm_weight)[(long)(valid ? i : 0) * IVW + v];
         }
-        if (!sync(0)) return;                       // the whole row is in the tile's region, natural order
-        chain_norm_parts<P>(smem, args, S, lane, ci, NCONS);
-        if (!sync(1)) return;
-        chain_norm_wsums(smem, args, S, lane, ci, NCONS);
-        if (!sync(2)) return;
-        const float r = chain_norm_rinv(smem, S);
-        if (ci < nc) chain_stage_chunk<P, true>(smem, a_off, sa_off, cpr, ci, lane, r, nwr);
+        if (!sync(0)) return;                       // the whole row and its per-item sums of squares are in LDS
+        if (ci < nc) {
+          const float r = chain_norm_rinv(smem, args, S, lane);
+          chain_stage_chunk<P, true>(smem, a_off, sa_off, cpr, ci, lane, r, nwr);
+        }
       }
       if (!sync(3)) return;                         // the tile is complete
       // every workgroup of this launch has read the generation by now (its granules are here): the next launch's
@@ -910,19 +947,19 @@ __device__ void chain_consumer(const ChainWave& cw) {
     int rpos = (rseq_base + sub * un) % RING;
     for (int j = sub; j < ntl; j += CPL) {
       const int k = ln + j * NL;
-      const unsigned long long tw0 = now();
-      if (!(args.lab & 2) && !cw.wait_ge(CL_LANDED0 + ln, (uint32_t)(need_base + (j + 1) * un), CE_WAIT_LANDED, s)) return;
-      CHAIN_LDS_ACQUIRE();
       const unsigned long long tw1 = now();
-      acc_t[0] += tw1 - tw0;
+      const int need0 = need_base + j * un, rseq0 = rseq_base + j * un;
       if (args.lab & 1) {
+        if (!(args.lab & 2) && !cw.wait_ge(CL_LANDED0 + ln, (uint32_t)(need0 + un), CE_WAIT_LANDED, s)) return;
         if (X.gran && lane == 63) __hip_atomic_store((chain_gu64*)(X.gran + t0 + k), (unsigned long long)X.tag << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      } else if (pair) chain_task<P, 4>(smem, X, t0 + k, rpos, lane);
-      else chain_task<P, 2>(smem, X, t0 + k, rpos, lane);
-      // the ring slots of this task are free: this consumer's next unfinished task of the lane
+      } else if (pair) {
+        if (!chain_task<P, 4>(cw, X, t0 + k, rpos, CL_LANDED0 + ln, need0, CL_NEXT0 + 4 * ln + sub, rseq0, s, (args.lab & 2) != 0)) return;
+      } else {
+        if (!chain_task<P, 2>(cw, X, t0 + k, rpos, CL_LANDED0 + ln, need0, CL_NEXT0 + 4 * ln + sub, rseq0, s, (args.lab & 2) != 0)) return;
+      }
+      // this consumer's next unfinished task of the lane (its ring slots went back chunk by chunk)
       int next = rseq_base + (j + CPL) * un;
       if (j + CPL >= ntl) next = rseq_base + ntl * un;
-      CHAIN_LDS_RELEASE();
       chain_lds_st(smem, CL_NEXT0 + 4 * ln + sub, (uint32_t)next);
       acc_t[1] += now() - tw1;
       rpos += jstep;
@@ -963,16 +1000,6 @@ __global__ void __launch_bounds__(1024) wq_chain_kernel(const ChainArgs args) {
     if (tid >= CL_NEXT0 && tid < CL_NEXT0 + 16 && ((tid - CL_NEXT0) >> 2 >= args.nlanes || ((tid - CL_NEXT0) & 3) >= args.cpl)) v = 0x7fffffffu;
     if (tid >= CL_CSTAGE0 && tid < CL_CSTAGE0 + 16 && tid - CL_CSTAGE0 >= ncons) v = 0x7fffffffu;
     reinterpret_cast<uint32_t*>(smem_raw)[tid] = v;
-  }
-  // The descriptors live in the kernel-argument segment, which the device reads through the scalar cache a 64-byte line at a
-  // time - and a first touch is a trip to memory (host-visible memory for an eager launch): 0.5 - 1.5 us EACH where the
-  // stages' fields are fetched one by one as they are first used.  Every wave asks for every line now, in one go.
-  {
-    const uint32_t* ap = reinterpret_cast<const uint32_t*>(&args);
-    uint32_t touch = 0;
-#pragma unroll
-    for (int i = 0; i < (int)(sizeof(ChainArgs) / 4); i += 16) touch |= ap[i];
-    asm volatile("" ::"s"(touch));
   }
   __syncthreads();
   cw.stamp(0);
