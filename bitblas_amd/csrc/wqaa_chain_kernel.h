@@ -391,6 +391,19 @@ __device__ void chain_loader(const ChainWave& cw) {
   cw.stamp(2);
 }
 
+// 4-bit LOP3 weights (`fast_decoding`, the default of W_int4 x A_fp16): the interleave puts consecutive elements 2j, 2j + 1
+// into the two halves of field j, so the order the unpack produces IS memory order (KindTraits::src_elem is the identity).
+// The chain then keeps an operator's input in LDS as it is: nothing to permute when it arrives, and the chunk sums are
+// taken by the consumer from the activations it loads anyway.
+template <class P>
+constexpr bool chain_natural_layout() {
+  for (int x = 0; x < P::EPW; ++x)
+    if (P::T::src_elem(P::LAYOUT, x) != x) return false;
+  return true;
+}
+template <class P>
+constexpr bool kChainNatural = chain_natural_layout<P>();
+
 // ---- one lane chunk of ROWS weight rows against the staged activations: per row the arithmetic of wq_gemvx_kernel's
 // `consume`, MB = 1, to the letter (class accumulators over the four words, Horner, zero point through the chunk's
 // activation sum, group scale on the fp32 partial).  The rows advance together, innermost: one consumer wave per SIMD has no
@@ -648,9 +661,25 @@ __device__ __forceinline__ bool chain_task(const ChainWave& cw, const ChainTaskC
       const int ch = chunk < X.cpr ? chunk : 0;           // (the single launch clamps the chunk before it takes the group)
       gi = X.gq_shift >= 0 ? (ch >> X.gq_shift) : (int)__umulhi((uint32_t)ch, X.gq_magic);
     }
+    if constexpr (kChainNatural<P>) {
+      // the tile is the input vector itself (natural order: the unpack's order IS memory order for this layout): the lane's
+      // four items are 64 contiguous bytes; the chunk's activation sum is taken here, by the additions the staged tile's is
+      // (one partial per weight word, then (p0 + p1) + (p2 + p3))
 #pragma unroll
-    for (int j = 0; j < 4 * PPW; ++j) o.av[j] = a_lds[((long)c * PIECES + j) * 64 + lane];
-    o.sa = sa_lds[c * 64 + lane];
+      for (int j = 0; j < 4; ++j) o.av[j] = a_lds[(long)chunk * 4 + j];
+      float part[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        part[u] = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) part[u] = __builtin_amdgcn_fdot2(as_h2(o.av[u][e]), half2_t{(half_t)1.f, (half_t)1.f}, part[u], false);
+      }
+      o.sa = (part[0] + part[1]) + (part[2] + part[3]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4 * PPW; ++j) o.av[j] = a_lds[((long)c * PIECES + j) * 64 + lane];
+      o.sa = sa_lds[c * 64 + lane];
+    }
 #pragma unroll
     for (int r = 0; r < ROWS; ++r) {
       o.w[r] = *reinterpret_cast<const u32x4*>(smem + X.ring_off + slot * 1024 + lane * 16);
@@ -793,6 +822,10 @@ __device__ void chain_consumer(const ChainWave& cw) {
       if (S.wait_stage > 0 && !cw.wait_cstage(S.wait_stage, CE_WAIT_STAGE, s)) return;
       const int a_off = S.a_off, sa_off = S.sa_off, cpr = S.cpr, nc = S.nc;
       const bool norm = S.norm_weight != nullptr;
+      auto mark = [&](int i) {                     // lab: shader cycles since this wave entered the staging of stage 1
+        if (timing && s == 1 && lane == 0) args.trace[((long)cw.b * 16 + cw.wave) * 32 + 13 + i] = __builtin_amdgcn_s_memtime() - tst0;
+      };
+      mark(0);
       auto sync = [&](int which) -> bool {
         const unsigned long long ts0 = now();
         CHAIN_LDS_RELEASE();
@@ -802,7 +835,160 @@ __device__ void chain_consumer(const ChainWave& cw) {
         acc_t[3] += now() - ts0;
         return true;
       };
-      if (S.in_kind == 0) {
+      if constexpr (kChainNatural<P>) {
+        // ---- natural-order tile: a unit of work is one WEIGHT-WORD SLOT sl = 4c + u of the vector - per lane l the item
+        // (8 activations, 16 bytes, four granules) of lane chunk position c * 64 + l, word u: exactly the items ONE thread
+        // of the single launch loads (item idx = sl * 64 + l).  Without a norm the items go straight to the tile.  With one,
+        // a consumer takes every slot of ONE (virtual) wave w of the launch (slots w, w + nwv, ...): it owns that wave's
+        // whole sum of squares - per thread over its items, the DPP ladder - and only the wave sums meet. ----
+        const bool from_gran = S.in_kind == 1;
+        uint32_t tag = 0;
+        const chain_gu64* g = nullptr;
+        if (from_gran) {
+          if (!need_gen(s)) return;
+          tag = gen * 16u + (uint32_t)S.src + 1u;
+          g = (const chain_gu64*)(args.gran + args.st[S.src].gran_off);
+        }
+        const bool lab_nosweep = (args.lab & 4) != 0;
+        const int nslots = nc * 4;
+        const int nwv = norm ? S.norm_nwv : 1, nai = norm ? S.norm_nai : 1;
+        // the rows a later stage of this CU adds as its residual (the output of stage S.src): kept as they pass
+        int stash_n0 = 0, stash_nr = 0, stash_off = 0;
+        if (from_gran && S.stash_for >= 0) {
+          const ChainStage& S2 = args.st[S.stash_for];
+          int u0, u1;
+          cw.task_range(S2.tasks, u0, u1);
+          stash_n0 = 2 * u0;
+          stash_nr = 2 * (u1 - u0);
+          if (stash_n0 + stash_nr > S2.N) stash_nr = S2.N - stash_n0;
+          stash_off = S2.stash_off;
+        }
+        const int nunits = norm ? nwv : nslots;      // norm: a unit = a virtual wave's slots (at most 3); else one slot
+        bool swept_any = false;
+        for (int unit = ci; unit < nunits; unit += NCONS) {
+          constexpr int NS = 3;
+          u32x4 item[NS];
+          int slot_of[NS];
+          bool have[NS];
+#pragma unroll
+          for (int j = 0; j < NS; ++j) {
+            slot_of[j] = norm ? unit + j * nwv : unit;
+            have[j] = j < (norm ? nai : 1) && slot_of[j] < nslots;
+            item[j] = u32x4{0u, 0u, 0u, 0u};
+          }
+          if (from_gran && args.thin && !swept_any && lane == 0)
+            __hip_atomic_fetch_add(reinterpret_cast<uint32_t*>(smem) + CL_SWEEPING, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          swept_any = true;
+          unsigned n_ = 0;
+          unsigned long long t_ = 0;
+          const unsigned long long tg0 = now();
+          for (;;) {
+            bool ok = true;
+#pragma unroll
+            for (int j = 0; j < NS; ++j) {
+              if (!have[j]) continue;
+              const int cl = (slot_of[j] >> 2) * 64 + lane;
+              const long it = (long)cl * 4 + (slot_of[j] & 3);               // item index: 8 elements, 4 granules
+              if (cl >= cpr) continue;                                        // past K: zeros
+              if (from_gran) {
+                if (lab_nosweep) continue;
+                unsigned long long x[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) x[k] = __hip_atomic_load(g + it * 4 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                  ok &= (uint32_t)(x[k] >> 32) == tag;
+                  item[j][k] = (uint32_t)x[k];
+                }
+              } else {
+                item[j] = CHAIN_G(u32x4, S.A)[it];
+              }
+            }
+            if (__all(ok)) break;
+            for (int i = 0; i < args.sweep_sleep; ++i) __builtin_amdgcn_s_sleep(8);       // ~0.2 us each
+            if (cw.expired(n_, t_)) {
+              cw.fail(CE_SWEEP, s);
+              return;
+            }
+          }
+          acc_t[4] += now() - tg0;
+          if (stash_nr > 0) {
+#pragma unroll
+            for (int j = 0; j < NS; ++j) {
+              if (!have[j]) continue;
+              const int e0 = (((slot_of[j] >> 2) * 64 + lane) * 4 + (slot_of[j] & 3)) * 8 - stash_n0;
+              if (e0 + 8 > 0 && e0 < stash_nr) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                  if (e0 + k >= 0 && e0 + k < stash_nr)
+                    reinterpret_cast<uint16_t*>(smem + stash_off)[e0 + k] = (uint16_t)(item[j][k >> 1] >> ((k & 1) * 16));
+              }
+            }
+          }
+          u32x4* tile = reinterpret_cast<u32x4*>(smem + a_off);
+          if (!norm) {
+            const int cl = (slot_of[0] >> 2) * 64 + lane;
+            tile[(long)cl * 4 + (slot_of[0] & 3)] = item[0];               // (zeros past K)
+            continue;
+          }
+          // the launch's thread (wave `unit`, lane): sum of squares over its items in item order, the wave's DPP ladder
+          float ssq = 0.f;
+          u32x4 nwv_item[NS];
+#pragma unroll
+          for (int j = 0; j < NS; ++j) {
+            float part = 0.f;
+            nwv_item[j] = u32x4{0u, 0u, 0u, 0u};
+            const int cl = (slot_of[j] >> 2) * 64 + lane;
+            if (have[j] && cl < cpr) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) part = __builtin_amdgcn_fdot2(as_h2(item[j][e]), as_h2(item[j][e]), part, false);
+              nwv_item[j] = CHAIN_G(u32x4, S.norm_weight)[(long)cl * 4 + (slot_of[j] & 3)];
+            }
+            if (j < nai) ssq += part;
+          }
+          const float ws = wave_sum_l63(ssq);
+          if (lane == 63) reinterpret_cast<float*>(smem)[CL_WSUM + unit] = ws;
+          if (unit + NCONS < nunits) {
+            // (more than NCONS virtual waves: this consumer has a second one - park this one's items in the tile, unscaled,
+            // and scale them in place behind the meeting)
+#pragma unroll
+            for (int j = 0; j < NS; ++j)
+              if (have[j]) tile[(long)((slot_of[j] >> 2) * 64 + lane) * 4 + (slot_of[j] & 3)] = item[j];
+            continue;
+          }
+          if (!sync(0)) return;                     // every wave's sum of squares is in LDS
+          float tot = reinterpret_cast<const float*>(smem)[CL_WSUM];
+          for (int w = 1; w < nwv; ++w) tot += reinterpret_cast<const float*>(smem)[CL_WSUM + w];
+          const float r = rsqrtf(tot * S.norm_inv_k + S.norm_eps);
+          for (int un2 = ci; un2 <= unit; un2 += NCONS) {
+#pragma unroll
+            for (int j = 0; j < NS; ++j) {
+              const int sl2 = un2 + j * nwv;
+              if (!(j < nai && sl2 < nslots)) continue;
+              const int cl = (sl2 >> 2) * 64 + lane;
+              const long it = (long)cl * 4 + (sl2 & 3);
+              u32x4 x = item[j], wgt = nwv_item[j];
+              if (un2 != unit) {                     // a parked unit: its items and weights again
+                x = tile[it];
+                wgt = cl < cpr ? CHAIN_G(u32x4, S.norm_weight)[it] : u32x4{0u, 0u, 0u, 0u};
+              }
+              u32x4 o;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const half2_t xx = as_h2(x[e]);
+                const half2_t h = {(half_t)((float)xx[0] * r), (half_t)((float)xx[1] * r)};
+                o[e] = cl < cpr ? as_u32(as_h2(wgt[e]) * h) : 0u;
+              }
+              tile[it] = o;
+            }
+          }
+        }
+        if (norm && ci >= nunits) {
+          if (!sync(0)) return;                     // (a consumer without a unit still attends the meeting)
+        }
+        if (from_gran && args.thin && swept_any && lane == 0)
+          __hip_atomic_fetch_sub(reinterpret_cast<uint32_t*>(smem) + CL_SWEEPING, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      } else if (S.in_kind == 0) {
         // the caller's vector: plain loads of this consumer's chunks into their regions (natural order)
         for (int c = ci; c < nc; c += NCONS) {
           u32x4 x[4][IVW];
@@ -880,7 +1066,8 @@ __device__ void chain_consumer(const ChainWave& cw) {
         }
         if (mine && args.thin && lane == 0) __hip_atomic_fetch_sub(reinterpret_cast<uint32_t*>(smem) + CL_SWEEPING, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
-      if (norm) {
+      mark(1);
+      if (!kChainNatural<P> && norm) {
         // the norm's weight for this consumer's chunk (host: at most NCONS lane chunks under a norm - one per consumer): asked
         // for now, used behind the meeting and the wave ladders
         u32x4 nwr[4][IVW];
@@ -892,12 +1079,17 @@ __device__ void chain_consumer(const ChainWave& cw) {
           for (int v = 0; v < IVW; ++v) nwr[q][v] = CHAIN_G(u32x4, S.norm_weight)[(long)(valid ? i : 0) * IVW + v];
         }
         if (!sync(0)) return;                       // the whole row and its per-item sums of squares are in LDS
+        mark(2);
         if (ci < nc) {
           const float r = chain_norm_rinv(smem, args, S, lane);
+          mark(3);
           chain_stage_chunk<P, true>(smem, a_off, sa_off, cpr, ci, lane, r, nwr);
+          mark(4);
         }
       }
+      mark(5);
       if (!sync(3)) return;                         // the tile is complete
+      mark(6);
       // every workgroup of this launch has read the generation by now (its granules are here): the next launch's
       if (S.in_kind == 1 && s == args.bump_stage && cw.b == 0 && ci == 0 && lane == 0)
         __hip_atomic_store((chain_gu32*)args.ctl, gen + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

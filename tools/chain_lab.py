@@ -145,6 +145,14 @@ def timeline(name, env):
             print(f"  {names[i]:44s} n={v.size:4d}  {u.min():7.2f} {np.median(u):7.2f} {u.max():7.2f}")
     cons = tr[:, nl:, :]
     live = cons[:, :, 3] > 0
+    print("  inside the staging of stage 1, microseconds of shader time since the wave entered it (min / median / max), stagers (chunk owners) | others:")
+    for i, nm in enumerate(("tile free", "my chunks swept (+ partial sums)", "meeting 0 passed", "wave ladders done (rinv)", "my chunk staged", "before the last meeting",
+                            "after the last meeting")):
+        v = cons[:, :, 13 + i]
+        a, b = v[:, :2][v[:, :2] > 0] / mhz, v[:, 2:][v[:, 2:] > 0] / mhz
+        fa = f"{a.min():6.2f} {np.median(a):6.2f} {a.max():6.2f}" if a.size else "     -      -      -"
+        fb = f"{b.min():6.2f} {np.median(b):6.2f} {b.max():6.2f}" if b.size else "     -      -      -"
+        print(f"    {nm:36s} {fa}  |  {fb}")
     print("  per consumer wave, microseconds of shader time (min / median / max): ")
     for i, nm in enumerate(("waiting for weights to land", "in the tasks (dots, store, publish)", "staging inputs (all of it)", "... of which in the meetings",
                             "... of which waiting for granules")):
@@ -158,7 +166,7 @@ per = graph_us(run_launches)
 print(json.dumps({"variant": "launches_3_per_layer", "us_per_layer_tail": [round(p, 2) for p in per], "median": round(float(np.median(per)), 2),
                   "GBps": round(nbytes / np.median(per) / 1e3, 1), "weight_bytes_per_tail": nbytes}), flush=True)
 # lab bits (results wrong by construction): 1 no dots, 2 consumers do not wait for the weights, 4 no sweeps, 8 default-policy DMA
-VARIANTS = [("l4c3", {}), ("l4c2", {"WQAA_CHAIN_CPL": "2"}), ("l4c1", {"WQAA_CHAIN_CPL": "1"}),
+VARIANTS = [("l4c3", {}), ("l4c2", {"WQAA_CHAIN_CPL": "2"}), ("l4c3_nothin", {"WQAA_CHAIN_THIN": "0"}),
             ("lab5_no_dots_no_sweeps", {"WQAA_CHAIN_LAB": "5"}), ("lab4_no_sweeps", {"WQAA_CHAIN_LAB": "4"}), ("lab1_no_dots", {"WQAA_CHAIN_LAB": "1"}),
             ("lab21_no_stream_no_sweeps_no_dots", {"WQAA_CHAIN_LAB": "21"})]
 for name, env in VARIANTS:

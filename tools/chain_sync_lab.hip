@@ -49,8 +49,10 @@ int main() {
   CK(hipFuncSetAttribute((const void*)k_sync, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   const char* names[] = {"meeting of the waves (LDS counter)", "chunk staged in place", "time stamp (s_memrealtime + store)", "agent-scope load of one word", "poll of a ready LDS word"};
   for (int mode = 0; mode < 5; ++mode)
+    for (int rounds : {64, 1})
     for (int waves : {4, 12, 16}) {
-      const int rounds = 64, G = 256;
+      const int G = 256;
+      if (mode == 2) continue;
       for (int w = 0; w < 2; ++w) hipLaunchKernelGGL(k_sync, dim3(G), dim3(64 * waves), 100 * 1024, 0, rounds, mode, dout, ctl);
       CK(hipDeviceSynchronize());
       std::vector<unsigned long long> h(G * 16);
@@ -59,7 +61,7 @@ int main() {
       int cnt = 0;
       for (int b = 0; b < G; ++b)
         for (int w = 0; w < waves; ++w) { sum += (double)h[b * 16 + w]; ++cnt; }
-      printf("%-40s %2d waves/CU: %8.1f cycles per round per wave\n", names[mode], waves, sum / cnt / rounds);
+      printf("%-40s %2d waves/CU, %2d round(s) per launch: %8.1f cycles per round per wave\n", names[mode], waves, rounds, sum / cnt / rounds);
     }
   return 0;
 }
