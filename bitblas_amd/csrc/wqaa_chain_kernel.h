@@ -863,8 +863,55 @@ __device__ void chain_consumer(const ChainWave& cw) {
           if (stash_n0 + stash_nr > S2.N) stash_nr = S2.N - stash_n0;
           stash_off = S2.stash_off;
         }
-        const int nunits = norm ? nwv : nslots;      // norm: a unit = a virtual wave's slots (at most 3); else one slot
+        u32x4* tile = reinterpret_cast<u32x4*>(smem + a_off);
         bool swept_any = false;
+        if (from_gran) {
+          // granules -> the tile, pass by pass (1024 granules: 16 coalesced relaxed agent-scope 8-byte loads per lane, pass p by
+          // consumer p % NCONS; kept when every tag matches, read again after a nap otherwise): one ds_write_b32 per granule,
+          // and without a norm that IS the staged input
+          const int ng = lab_nosweep ? 0 : S.K / 2;
+          const int npass = (S.K / 2 + 1023) / 1024;
+          for (int p = ci; p < npass; p += NCONS) {
+            if (args.thin && !swept_any && lane == 0)
+              __hip_atomic_fetch_add(reinterpret_cast<uint32_t*>(smem) + CL_SWEEPING, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            swept_any = true;
+            unsigned n_ = 0;
+            unsigned long long t_ = 0;
+            const unsigned long long tg0 = now();
+            for (;;) {
+              unsigned long long x[16];
+#pragma unroll
+              for (int k = 0; k < 16; ++k) {
+                const int gi = p * 1024 + k * 64 + lane;
+                x[k] = gi < ng ? __hip_atomic_load(g + gi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ((unsigned long long)tag << 32);
+              }
+              bool ok = true;
+#pragma unroll
+              for (int k = 0; k < 16; ++k) ok &= (uint32_t)(x[k] >> 32) == tag;
+              if (__all(ok)) {
+#pragma unroll
+                for (int k = 0; k < 16; ++k) reinterpret_cast<uint32_t*>(smem + a_off + p * 4096)[k * 64 + lane] = (uint32_t)x[k];
+                break;
+              }
+              for (int i = 0; i < args.sweep_sleep; ++i) __builtin_amdgcn_s_sleep(8);       // ~0.2 us each
+              if (cw.expired(n_, t_)) {
+                cw.fail(CE_SWEEP, s);
+                return;
+              }
+            }
+            acc_t[4] += now() - tg0;
+            for (int i = lane; i < stash_nr; i += 64) {
+              const int n = stash_n0 + i - p * 2048;
+              if (n >= 0 && n < 2048) reinterpret_cast<uint16_t*>(smem + stash_off)[i] = reinterpret_cast<const uint16_t*>(smem + a_off + p * 4096)[n];
+            }
+          }
+          if (args.thin && swept_any && lane == 0)
+            __hip_atomic_fetch_sub(reinterpret_cast<uint32_t*>(smem) + CL_SWEEPING, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          // lane chunks past the last granule (K not a multiple of 2048): zeros
+          for (int i = (S.K / 8) + ci * 64 + lane; i < nslots * 64; i += NCONS * 64) tile[i] = u32x4{0u, 0u, 0u, 0u};
+          if (norm && !sync(1)) return;             // the whole row is in the tile
+        }
+        const int nunits = (from_gran && !norm) ? 0 : norm ? nwv : nslots;      // norm: a unit = a virtual wave's slots (at most 3); else one slot
         for (int unit = ci; unit < nunits; unit += NCONS) {
           constexpr int NS = 3;
           u32x4 item[NS];
@@ -876,56 +923,14 @@ __device__ void chain_consumer(const ChainWave& cw) {
             have[j] = j < (norm ? nai : 1) && slot_of[j] < nslots;
             item[j] = u32x4{0u, 0u, 0u, 0u};
           }
-          if (from_gran && args.thin && !swept_any && lane == 0)
-            __hip_atomic_fetch_add(reinterpret_cast<uint32_t*>(smem) + CL_SWEEPING, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          swept_any = true;
-          unsigned n_ = 0;
-          unsigned long long t_ = 0;
-          const unsigned long long tg0 = now();
-          for (;;) {
-            bool ok = true;
 #pragma unroll
-            for (int j = 0; j < NS; ++j) {
-              if (!have[j]) continue;
-              const int cl = (slot_of[j] >> 2) * 64 + lane;
-              const long it = (long)cl * 4 + (slot_of[j] & 3);               // item index: 8 elements, 4 granules
-              if (cl >= cpr) continue;                                        // past K: zeros
-              if (from_gran) {
-                if (lab_nosweep) continue;
-                unsigned long long x[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) x[k] = __hip_atomic_load(g + it * 4 + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                  ok &= (uint32_t)(x[k] >> 32) == tag;
-                  item[j][k] = (uint32_t)x[k];
-                }
-              } else {
-                item[j] = CHAIN_G(u32x4, S.A)[it];
-              }
-            }
-            if (__all(ok)) break;
-            for (int i = 0; i < args.sweep_sleep; ++i) __builtin_amdgcn_s_sleep(8);       // ~0.2 us each
-            if (cw.expired(n_, t_)) {
-              cw.fail(CE_SWEEP, s);
-              return;
-            }
+          for (int j = 0; j < NS; ++j) {
+            if (!have[j]) continue;
+            const int cl = (slot_of[j] >> 2) * 64 + lane;
+            const long it = (long)cl * 4 + (slot_of[j] & 3);               // item index: 8 elements
+            if (cl >= cpr) continue;                                        // past K: zeros
+            item[j] = from_gran ? tile[it] : CHAIN_G(u32x4, S.A)[it];
           }
-          acc_t[4] += now() - tg0;
-          if (stash_nr > 0) {
-#pragma unroll
-            for (int j = 0; j < NS; ++j) {
-              if (!have[j]) continue;
-              const int e0 = (((slot_of[j] >> 2) * 64 + lane) * 4 + (slot_of[j] & 3)) * 8 - stash_n0;
-              if (e0 + 8 > 0 && e0 < stash_nr) {
-#pragma unroll
-                for (int k = 0; k < 8; ++k)
-                  if (e0 + k >= 0 && e0 + k < stash_nr)
-                    reinterpret_cast<uint16_t*>(smem + stash_off)[e0 + k] = (uint16_t)(item[j][k >> 1] >> ((k & 1) * 16));
-              }
-            }
-          }
-          u32x4* tile = reinterpret_cast<u32x4*>(smem + a_off);
           if (!norm) {
             const int cl = (slot_of[0] >> 2) * 64 + lane;
             tile[(long)cl * 4 + (slot_of[0] & 3)] = item[0];               // (zeros past K)
@@ -986,8 +991,6 @@ __device__ void chain_consumer(const ChainWave& cw) {
         if (norm && ci >= nunits) {
           if (!sync(0)) return;                     // (a consumer without a unit still attends the meeting)
         }
-        if (from_gran && args.thin && swept_any && lane == 0)
-          __hip_atomic_fetch_sub(reinterpret_cast<uint32_t*>(smem) + CL_SWEEPING, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       } else if (S.in_kind == 0) {
         // the caller's vector: plain loads of this consumer's chunks into their regions (natural order)
         for (int c = ci; c < nc; c += NCONS) {
