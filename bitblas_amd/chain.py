@@ -212,13 +212,13 @@ def chain_status(device=None) -> dict:
 
 
 def chain_trace(device=None):
-    """lab aid: the [workgroup][wave (16 slots)][32] s_memrealtime stamps (100 MHz) of the last fused launch planned with WQAA_CHAIN_TRACE=1"""
+    """lab aid: the [workgroup][wave (16 slots)][64] s_memrealtime stamps (100 MHz) of the last fused launch planned with WQAA_CHAIN_TRACE=1"""
     import numpy as np
     dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
-    buf = np.zeros(1024 * 16 * 32, dtype=np.uint64)
+    buf = np.zeros(1024 * 16 * 64, dtype=np.uint64)
     with torch.cuda.device(dev):
         n = _library().wqaa_debug_chain_trace(_lib.current_stream_handle(dev), buf.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)), buf.size)
-    return buf[:n].reshape(-1, 16, 32)
+    return buf[:n].reshape(-1, 16, 64)
 
 
 def _lin_weights(lin):
@@ -235,15 +235,18 @@ class DecoderTail(torch.nn.Module):
         h   = x + o_proj(attn)
         out = h + down_proj(silu(gate_proj(norm(h))) * up_proj(norm(h)))
 
-    (integration/BitNet/modeling_bitnet.py:839-860 with the MLP of :240-244) as ONE launch at decode row counts
-    (`matmul_chain`), as the layers' launches with torch's elementwise kernels elsewhere.  The layers keep their own
-    buffers and state_dict keys."""
+    (integration/BitNet/modeling_bitnet.py:839-860 with the MLP of :240-244).  At decode row counts: three launches with the
+    elementwise ops folded in (`forward_ex`, `matmul_gate_up`) - or, `persistent=True`, ONE launch (`matmul_chain`; same bits,
+    measured SLOWER on MI355X for the int4 layers of BASELINE c2: 38.5 vs 25.9 us, profiles/r04_chain_lab.txt, DESIGN.md
+    section 3.3c - hence not the default); the layers' plain launches with torch's elementwise kernels elsewhere.  The layers keep
+    their own buffers and state_dict keys."""
 
-    def __init__(self, o_proj, gate_proj, up_proj, down_proj, norm_weight: torch.Tensor, eps: float = 1e-6):
+    def __init__(self, o_proj, gate_proj, up_proj, down_proj, norm_weight: torch.Tensor, eps: float = 1e-6, persistent: bool = False):
         super().__init__()
         self.o_proj, self.gate_proj, self.up_proj, self.down_proj = o_proj, gate_proj, up_proj, down_proj
         self.norm_weight = norm_weight
         self.eps = float(eps)
+        self.persistent = bool(persistent)
 
     def steps(self, attn, x, h_out=None, out=None):
         mm = lambda lin: lin.bitblas_matmul  # noqa: E731
@@ -255,13 +258,17 @@ class DecoderTail(torch.nn.Module):
         ]
 
     def forward(self, attn, x):
+        from .group import matmul_gate_up
         m = attn.numel() // attn.shape[-1]
         ops = [lin.bitblas_matmul for lin in (self.o_proj, self.gate_proj, self.up_proj, self.down_proj)]
         if m >= 1 and all(op.fused_ops_supported(m) for op in ops):
             a2 = attn.reshape(m, attn.shape[-1])
             x2 = x.reshape(m, x.shape[-1]).contiguous()
-            res = matmul_chain(self.steps(a2, x2))
-            return res[2].reshape(x.shape)
+            if self.persistent:
+                return matmul_chain(self.steps(a2, x2))[2].reshape(x.shape)
+            h = self.o_proj.forward_ex(a2, residual=x2)
+            act = matmul_gate_up(ops[1], ops[2], h, _lin_weights(self.gate_proj), _lin_weights(self.up_proj), norm=(self.norm_weight, self.eps))
+            return self.down_proj.forward_ex(act, residual=h).reshape(x.shape)
         h = x + self.o_proj(attn)
         hn = torch.nn.functional.rms_norm(h, (h.shape[-1],), self.norm_weight, self.eps)
         act = torch.nn.functional.silu(self.gate_proj(hn)) * self.up_proj(hn)

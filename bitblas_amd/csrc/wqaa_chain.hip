@@ -407,7 +407,9 @@ static int chain_build(const wqaa_chain_item* items, int count, int m, ChainBuil
   // when a task's rows would not fit a quarter of the ring beside a fill in flight each way
   const int total_units = (lds_total - off) / 1024;
   int lanes = kChainMaxLanes, ring_units = 0;
-  int cpl = kChainMaxCpl;
+  // two consumers per lane: same-call A/B on the Llama-2-7B decoder tail (tools/chain_lab.py, profiles/r04_chain_lab.txt): 1 / 2 / 3
+  // consumers per lane 48.7 / 37.2 / 40.9 us
+  int cpl = 2;
   if (knobs.cpl >= 1 && knobs.cpl <= kChainMaxCpl) cpl = knobs.cpl;                   // lab aid
   if (knobs.lanes >= 1 && knobs.lanes <= kChainMaxLanes) lanes = knobs.lanes;         // lab aid
   for (; lanes >= 1; lanes >>= 1) {
@@ -548,8 +550,8 @@ int chain_launch(const wqaa_chain_item* items, int count, int m, hipStream_t str
   if (chain_build(items, count, m, &b) != WQAA_OK) return chain_by_launches(items, count, m, stream);
   const bool trace = chain_knobs().trace != 0;
   const size_t gran_bytes = (b.gran_count * 8 + 255) & ~(size_t)255;
-  const size_t trace_words = trace ? (size_t)b.grid * 16 * 32 : 0;
-  const size_t need = kChainCtlBytes + (1u << 19) + (1u << 18) + trace_words * 8;
+  const size_t trace_words = trace ? (size_t)b.grid * 16 * 64 : 0;
+  const size_t need = kChainCtlBytes + (1u << 19) + (1u << 18) + trace_words * 8;   // (a traced launch: 2 MiB more)
   if (gran_bytes > (1u << 19)) {
     set_error(WQAA_ERR_UNSUPPORTED, "matmul_chain: %zu B of granules", gran_bytes);
     return chain_by_launches(items, count, m, stream);

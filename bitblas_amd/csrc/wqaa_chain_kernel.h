@@ -116,8 +116,10 @@ typedef __attribute__((address_space(1))) unsigned int chain_gu32;
 typedef __attribute__((address_space(3))) uint32_t chain_lds_u32;
 typedef __attribute__((address_space(3))) unsigned char chain_lds_u8;
 typedef __attribute__((address_space(3))) u32x4 chain_lds_u32x4;
+// (every lane reads the same word: handed back as a SCALAR - control flow that hangs on a vector value is compiled into
+// exec-masked regions, and every wait loop of this kernel hangs on one of these)
 __device__ __forceinline__ uint32_t chain_lds_ld(const unsigned char* smem, int word) {
-  return *reinterpret_cast<const volatile chain_lds_u32*>((const chain_lds_u8*)smem + word * 4);
+  return __builtin_amdgcn_readfirstlane(*reinterpret_cast<const volatile chain_lds_u32*>((const chain_lds_u8*)smem + word * 4));
 }
 __device__ __forceinline__ void chain_lds_st(unsigned char* smem, int word, uint32_t v) {
   *reinterpret_cast<volatile chain_lds_u32*>((chain_lds_u8*)smem + word * 4) = v;
@@ -170,8 +172,8 @@ struct ChainWave {
   unsigned timeout;
   __device__ __forceinline__ void stamp(int i) const {
     if (args->trace && lane == 0) {
-      args->trace[((long)b * 16 + wave) * 32 + i] = __builtin_amdgcn_s_memrealtime();
-      if (i == 0 || i == 3) args->trace[((long)b * 16 + wave) * 32 + 24 + (i ? 1 : 0)] = __builtin_amdgcn_s_memtime();      // shader clock at wave start / end
+      args->trace[((long)b * 16 + wave) * 64 + i] = __builtin_amdgcn_s_memrealtime();
+      if (i == 0 || i == 3) args->trace[((long)b * 16 + wave) * 64 + 24 + (i ? 1 : 0)] = __builtin_amdgcn_s_memtime();      // shader clock at wave start / end
     }
   }
   __device__ __forceinline__ void fail(int code, int stage) const {
@@ -787,6 +789,10 @@ __device__ void chain_consumer(const ChainWave& cw) {
   unsigned long long acc_t[5] = {0, 0, 0, 0, 0};
   const bool timing = args.trace != nullptr;
   auto now = [&]() -> unsigned long long { return timing ? __builtin_amdgcn_s_memtime() : 0ull; };
+  // lab: shader-clock marks of this wave, ten per stage (slots 32 + 10 * stage + i), first three stages
+  auto cyc = [&](int stage, int i) {
+    if (timing && stage < 3 && lane == 0) args.trace[((long)cw.b * 16 + cw.wave) * 64 + 32 + 10 * stage + i] = __builtin_amdgcn_s_memtime();
+  };
   uint32_t gen = 0;
   bool have_gen = false;
   auto need_gen = [&](int s) -> bool {
@@ -813,6 +819,7 @@ __device__ void chain_consumer(const ChainWave& cw) {
     const int nt = t1 - t0;
     const int n0 = 2 * t0;
     chain_lds_st(smem, CL_CSTAGE0 + ci, (uint32_t)s);
+    cyc(s, 9);
     // ---- the stage's input: staged once per CU by its consumers TOGETHER, lane chunk c (64 * E elements) by consumer c % NCONS,
     // in place in the chunk's region of the tile ----
     if (S.in_kind != 2) {
@@ -822,9 +829,7 @@ __device__ void chain_consumer(const ChainWave& cw) {
       if (S.wait_stage > 0 && !cw.wait_cstage(S.wait_stage, CE_WAIT_STAGE, s)) return;
       const int a_off = S.a_off, sa_off = S.sa_off, cpr = S.cpr, nc = S.nc;
       const bool norm = S.norm_weight != nullptr;
-      auto mark = [&](int i) {                     // lab: shader cycles since this wave entered the staging of stage 1
-        if (timing && s == 1 && lane == 0) args.trace[((long)cw.b * 16 + cw.wave) * 32 + 13 + i] = __builtin_amdgcn_s_memtime() - tst0;
-      };
+      auto mark = [&](int i) { cyc(s, i); };
       mark(0);
       auto sync = [&](int which) -> bool {
         const unsigned long long ts0 = now();
@@ -909,7 +914,9 @@ __device__ void chain_consumer(const ChainWave& cw) {
             __hip_atomic_fetch_sub(reinterpret_cast<uint32_t*>(smem) + CL_SWEEPING, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
           // lane chunks past the last granule (K not a multiple of 2048): zeros
           for (int i = (S.K / 8) + ci * 64 + lane; i < nslots * 64; i += NCONS * 64) tile[i] = u32x4{0u, 0u, 0u, 0u};
+          mark(1);
           if (norm && !sync(1)) return;             // the whole row is in the tile
+          mark(2);
         }
         const int nunits = (from_gran && !norm) ? 0 : norm ? nwv : nslots;      // norm: a unit = a virtual wave's slots (at most 3); else one slot
         for (int unit = ci; unit < nunits; unit += NCONS) {
@@ -961,7 +968,9 @@ __device__ void chain_consumer(const ChainWave& cw) {
               if (have[j]) tile[(long)((slot_of[j] >> 2) * 64 + lane) * 4 + (slot_of[j] & 3)] = item[j];
             continue;
           }
+          mark(3);
           if (!sync(0)) return;                     // every wave's sum of squares is in LDS
+          mark(4);
           float tot = reinterpret_cast<const float*>(smem)[CL_WSUM];
           for (int w = 1; w < nwv; ++w) tot += reinterpret_cast<const float*>(smem)[CL_WSUM + w];
           const float r = rsqrtf(tot * S.norm_inv_k + S.norm_eps);
@@ -1069,7 +1078,6 @@ __device__ void chain_consumer(const ChainWave& cw) {
         }
         if (mine && args.thin && lane == 0) __hip_atomic_fetch_sub(reinterpret_cast<uint32_t*>(smem) + CL_SWEEPING, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       }
-      mark(1);
       if (!kChainNatural<P> && norm) {
         // the norm's weight for this consumer's chunk (host: at most NCONS lane chunks under a norm - one per consumer): asked
         // for now, used behind the meeting and the wave ladders
@@ -1082,7 +1090,6 @@ __device__ void chain_consumer(const ChainWave& cw) {
           for (int v = 0; v < IVW; ++v) nwr[q][v] = CHAIN_G(u32x4, S.norm_weight)[(long)(valid ? i : 0) * IVW + v];
         }
         if (!sync(0)) return;                       // the whole row and its per-item sums of squares are in LDS
-        mark(2);
         if (ci < nc) {
           const float r = chain_norm_rinv(smem, args, S, lane);
           mark(3);
@@ -1132,6 +1139,7 @@ __device__ void chain_consumer(const ChainWave& cw) {
       X.tag = gen * 16u + (uint32_t)s + 1u;
       X.gran = args.gran + S.gran_off;
     }
+    cyc(s, 7);
     const int un = S.un, pair = S.pair;
     // the stage's scale / zeros blocks ride at the head of lane 0's stream
     if (S.nsc > 0 && !(args.lab & 2) && !cw.wait_ge(CL_LANDED0, (uint32_t)(useq0_base + S.nsc), CE_WAIT_LANDED, s)) return;
@@ -1162,6 +1170,7 @@ __device__ void chain_consumer(const ChainWave& cw) {
     }
     // (also when no task of this stage fell to this consumer: its frontier still moves past the stage)
     chain_lds_st(smem, CL_NEXT0 + 4 * ln + sub, (uint32_t)(rseq_base + ntl * un));
+    cyc(s, 8);
     cw.stamp(6 + 3 * s);
     rseq_base += ntl * un;
     useq_base += (ln == 0 ? S.nsc : 0) + ntl * un;
@@ -1171,7 +1180,7 @@ __device__ void chain_consumer(const ChainWave& cw) {
   chain_lds_st(smem, CL_CSTAGE0 + ci, 0x7fffffffu);
   if (timing && lane == 0) {
 #pragma unroll
-    for (int i = 0; i < 5; ++i) args.trace[((long)cw.b * 16 + cw.wave) * 32 + 26 + i] = acc_t[i];
+    for (int i = 0; i < 5; ++i) args.trace[((long)cw.b * 16 + cw.wave) * 64 + 26 + i] = acc_t[i];
   }
 }
 

@@ -209,3 +209,34 @@ def test_unfused_chains_run_as_launches():
     want = d[0].forward_ex(h, d[1][0], scale=d[1][1], residual=h)
     torch.cuda.synchronize()
     assert torch.equal(got[0], h) and torch.equal(got[1], want)
+
+
+def test_decoder_tail_module_both_forms():
+    """`bitblas_amd.DecoderTail` over four `Linear` layers: the persistent launch and the three launches give the same bits, and
+    both are the reference's layer (torch's elementwise kernels around the layers' own forwards) within the members' tolerance"""
+    H, I = 1024, 2048
+    rng = np.random.default_rng(7)
+
+    def linear(n_in, n_out):
+        lin = bitblas.Linear(n_in, n_out, bias=False, A_dtype="float16", W_dtype="uint4", accum_dtype="float16", out_dtype="float16",
+                             group_size=128, with_scaling=True, with_zeros=True, zeros_mode="original", opt_M=[1], enable_tuning=False)
+        lin.load_and_transform_weight(torch.from_numpy(rng.integers(0, 16, size=(n_out, n_in)).astype(np.int8)),
+                                      scales=torch.from_numpy((rng.random((n_out, n_in // 128), dtype=np.float32) * 0.01).astype(np.float16)),
+                                      zeros=torch.from_numpy(rng.integers(6, 10, size=(n_out, n_in // 128)).astype(np.float16)))
+        return lin.cuda()
+
+    o, gate, up, down = linear(H, H), linear(H, I), linear(H, I), linear(I, H)
+    nw = torch.from_numpy((1.0 + (rng.random(H, dtype=np.float32) - 0.5) * 0.2).astype(np.float16)).cuda()
+    attn = torch.from_numpy((rng.random((1, H), dtype=np.float32) - 0.5).astype(np.float16)).cuda()
+    x = torch.from_numpy((rng.random((1, H), dtype=np.float32) - 0.5).astype(np.float16)).cuda()
+    launches = bitblas.DecoderTail(o, gate, up, down, nw, eps=1e-5)
+    one = bitblas.DecoderTail(o, gate, up, down, nw, eps=1e-5, persistent=True)
+    assert chain_plan(one.steps(attn, x))["launches"] == 1
+    a, b = launches(attn, x), one(attn, x)
+    torch.cuda.synchronize()
+    assert_clean()
+    assert torch.equal(a, b)
+    h = x + o(attn)
+    hn = torch.nn.functional.rms_norm(h, (H,), nw, 1e-5)
+    want = h + down(torch.nn.functional.silu(gate(hn)) * up(hn))
+    assert_fp_parity(b.cpu().numpy(), want.float().cpu().numpy(), rtol=4e-3, atol_frac=2e-3)

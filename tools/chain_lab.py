@@ -145,14 +145,19 @@ def timeline(name, env):
             print(f"  {names[i]:44s} n={v.size:4d}  {u.min():7.2f} {np.median(u):7.2f} {u.max():7.2f}")
     cons = tr[:, nl:, :]
     live = cons[:, :, 3] > 0
-    print("  inside the staging of stage 1, microseconds of shader time since the wave entered it (min / median / max), stagers (chunk owners) | others:")
-    for i, nm in enumerate(("tile free", "my chunks swept (+ partial sums)", "meeting 0 passed", "wave ladders done (rinv)", "my chunk staged", "before the last meeting",
-                            "after the last meeting")):
-        v = cons[:, :, 13 + i]
-        a, b = v[:, :2][v[:, :2] > 0] / mhz, v[:, 2:][v[:, 2:] > 0] / mhz
-        fa = f"{a.min():6.2f} {np.median(a):6.2f} {a.max():6.2f}" if a.size else "     -      -      -"
-        fb = f"{b.min():6.2f} {np.median(b):6.2f} {b.max():6.2f}" if b.size else "     -      -      -"
-        print(f"    {nm:36s} {fa}  |  {fb}")
+    print("  shader-clock marks per consumer wave, microseconds since the wave's stage-loop entry of the stage (median over waves; '-' = not passed):")
+    mk = ("9 stage entered", "0 tile free", "1 my passes gathered", "2 meeting A passed", "3 my ladder done", "4 meeting B passed", "5 scaled, before last meeting",
+          "6 after last meeting", "7 task context ready", "8 tasks done")
+    order = (9, 0, 1, 2, 3, 4, 5, 6, 7, 8)
+    for st in range(3):
+        base = cons[:, :, 32 + 10 * st + 9].astype(np.float64)
+        row = []
+        for i in order:
+            v = cons[:, :, 32 + 10 * st + i].astype(np.float64)
+            okm = (v > 0) & (base > 0)
+            row.append(f"{np.median((v - base)[okm]) / mhz:6.2f}" if okm.any() else "     -")
+        print(f"    stage {st}: " + "  ".join(f"{n.split(' ')[0]}:{r}" for n, r in zip([mk[i if i != 9 else 0] if False else str(i) for i in order], row)))
+    print("    (marks: 9 stage entered, 0 tile free, 1 my passes gathered, 2 meeting A passed, 3 my ladder done, 4 meeting B passed, 5 before the last meeting, 6 after it, 7 task context ready, 8 tasks done)")
     print("  per consumer wave, microseconds of shader time (min / median / max): ")
     for i, nm in enumerate(("waiting for weights to land", "in the tasks (dots, store, publish)", "staging inputs (all of it)", "... of which in the meetings",
                             "... of which waiting for granules")):
@@ -166,13 +171,14 @@ per = graph_us(run_launches)
 print(json.dumps({"variant": "launches_3_per_layer", "us_per_layer_tail": [round(p, 2) for p in per], "median": round(float(np.median(per)), 2),
                   "GBps": round(nbytes / np.median(per) / 1e3, 1), "weight_bytes_per_tail": nbytes}), flush=True)
 # lab bits (results wrong by construction): 1 no dots, 2 consumers do not wait for the weights, 4 no sweeps, 8 default-policy DMA
-VARIANTS = [("l4c3", {}), ("l4c2", {"WQAA_CHAIN_CPL": "2"}), ("l4c3_nothin", {"WQAA_CHAIN_THIN": "0"}),
-            ("lab5_no_dots_no_sweeps", {"WQAA_CHAIN_LAB": "5"}), ("lab4_no_sweeps", {"WQAA_CHAIN_LAB": "4"}), ("lab1_no_dots", {"WQAA_CHAIN_LAB": "1"}),
+VARIANTS = [("l4c2 (default)", {}), ("l4c3", {"WQAA_CHAIN_CPL": "3"}), ("l4c1", {"WQAA_CHAIN_CPL": "1"}), ("l2c2", {"WQAA_CHAIN_LANES": "2"}),
+            ("l4c2_nothin", {"WQAA_CHAIN_THIN": "0"}),
+            ("lab1_no_dots", {"WQAA_CHAIN_LAB": "1"}), ("lab4_no_sweeps", {"WQAA_CHAIN_LAB": "4"}), ("lab5_no_dots_no_sweeps", {"WQAA_CHAIN_LAB": "5"}),
             ("lab21_no_stream_no_sweeps_no_dots", {"WQAA_CHAIN_LAB": "21"})]
 for name, env in VARIANTS:
     variant(name, env)
 per = graph_us(run_launches)
 print(json.dumps({"variant": "launches_again", "median": round(float(np.median(per)), 2)}), flush=True)
 if not args.no_trace:
-    timeline("l4c3", {})
+    timeline("l4c2 (default)", {})
     timeline("lab21_no_stream_no_sweeps_no_dots", {"WQAA_CHAIN_LAB": "21"})
