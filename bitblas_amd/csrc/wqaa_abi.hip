@@ -169,6 +169,19 @@ static int dispatch(const wqaa_matmul_desc& d, int m, bool* use_gemm) {
   return WQAA_OK;
 }
 
+// WQAA_TWO_PASS (A/B aid: the two-pass member wherever it exists) is a plan-time switch like every WQAA_* variable: read when
+// wqaa_select / a plan query bumps the epoch, not on every launch
+static bool two_pass_forced() {
+  static thread_local unsigned seen_epoch = ~0u;
+  static thread_local bool on = false;
+  const unsigned ep = g_plan_epoch.load(std::memory_order_relaxed);
+  if (ep != seen_epoch) {
+    on = getenv("WQAA_TWO_PASS") != nullptr;
+    seen_epoch = ep;
+  }
+  return on;
+}
+
 constexpr int32_t kEpilogueV1Bytes = 24;   // wqaa_epilogue up to `reserved2`: callers built before the float16 pre/post ops
 
 static int matmul_impl(const wqaa_matmul_desc* desc, const void* A, const void* B, const void* LUT,
@@ -232,7 +245,7 @@ static int matmul_impl(const wqaa_matmul_desc* desc, const void* A, const void* 
       return st;
     }
     // the tuned two-pass member (desc.two_pass_min_m): B_decode to a scratch, then the plain GEMM through the library
-    if (desc->two_pass_min_m > 0 || getenv("WQAA_TWO_PASS")) {
+    if (desc->two_pass_min_m > 0 || two_pass_forced()) {
       static thread_local ChoiceMemo<int> tp_memo;
       bool tp;
       if (const int* hit = tp_memo.find(*desc, m, 5)) {
@@ -459,12 +472,18 @@ static int group_impl(const wqaa_group_item* items, const wqaa_epilogue* const* 
         total += descs[i]->N;
       }
       key.N = (int32_t)(total & 0x7fffffff);
+      // fusability depends on every member's OWN N (each alone must land on the merged K split / family): two groups of one
+      // total and count but other splits (3 x 4096 vs 8192 + 2 x 2048) must not share a verdict - the split goes into the key
+      uint32_t nhash = 2166136261u;
+      for (int i = 0; i < count; ++i) nhash = (nhash ^ (uint32_t)descs[i]->N) * 16777619u;
+      key.reserved[0] = (int32_t)nhash;
       const int q = 32 + count + 16 * epi_mode;
       const Fuse* hit = same ? memo.find(key, m, q) : nullptr;
       if (hit) {
         ok = hit->ok != 0;
         fx = hit->fx;
         merged = key;
+        merged.reserved[0] = 0;
       } else {
         ok = group_fusable(descs, count, m, &merged, &fx, epi_mode);
         if (same) memo.put(key, m, q, Fuse{ok ? 1 : 0, fx});

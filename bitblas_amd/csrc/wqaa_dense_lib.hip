@@ -16,11 +16,67 @@
 // fp8 kernels want.  Workspace: caller-owned through wqaa_matmul_opts (wqaa_workspace_bytes reports the selected
 // algorithm's need) or the per-(device, stream) pool of wqaa_gemm.hip - the same ownership rules as the split-K scratch.
 #include <hipblaslt/hipblaslt.h>
+#include <dlfcn.h>
 
 #include <deque>
 #include <mutex>
 
 #include "wqaa_common.h"
+
+// The vendor library is an OPT-IN yardstick (WQAA_DENSE_LIB=1) and the second pass of the opt-in two-pass member: it is loaded
+// when first asked for, not linked - a box without libhipblaslt.so still loads libwqaa_hip.so and runs every kernel of its own.
+namespace {
+struct LtApi {
+  decltype(&hipblasLtCreate) Create;
+  decltype(&hipblasLtMatmul) Matmul;
+  decltype(&hipblasLtMatmulAlgoGetHeuristic) MatmulAlgoGetHeuristic;
+  decltype(&hipblasLtMatmulDescCreate) MatmulDescCreate;
+  decltype(&hipblasLtMatmulDescSetAttribute) MatmulDescSetAttribute;
+  decltype(&hipblasLtMatmulPreferenceCreate) MatmulPreferenceCreate;
+  decltype(&hipblasLtMatmulPreferenceDestroy) MatmulPreferenceDestroy;
+  decltype(&hipblasLtMatmulPreferenceSetAttribute) MatmulPreferenceSetAttribute;
+  decltype(&hipblasLtMatrixLayoutCreate) MatrixLayoutCreate;
+  bool ok;
+};
+const LtApi& lt_api() {
+  static const LtApi api = [] {
+    LtApi a;
+    memset(&a, 0, sizeof(a));
+    void* h = nullptr;
+    for (const char* name : {"libhipblaslt.so", "libhipblaslt.so.1", "libhipblaslt.so.0", "/opt/rocm/lib/libhipblaslt.so"}) {
+      h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+      if (h) break;
+    }
+    if (!h) return a;
+    bool ok = true;
+#define WQAA_LT_SYM(field, sym)                                              \
+  a.field = reinterpret_cast<decltype(a.field)>(dlsym(h, #sym));           \
+  ok = ok && a.field != nullptr;
+    WQAA_LT_SYM(Create, hipblasLtCreate)
+    WQAA_LT_SYM(Matmul, hipblasLtMatmul)
+    WQAA_LT_SYM(MatmulAlgoGetHeuristic, hipblasLtMatmulAlgoGetHeuristic)
+    WQAA_LT_SYM(MatmulDescCreate, hipblasLtMatmulDescCreate)
+    WQAA_LT_SYM(MatmulDescSetAttribute, hipblasLtMatmulDescSetAttribute)
+    WQAA_LT_SYM(MatmulPreferenceCreate, hipblasLtMatmulPreferenceCreate)
+    WQAA_LT_SYM(MatmulPreferenceDestroy, hipblasLtMatmulPreferenceDestroy)
+    WQAA_LT_SYM(MatmulPreferenceSetAttribute, hipblasLtMatmulPreferenceSetAttribute)
+    WQAA_LT_SYM(MatrixLayoutCreate, hipblasLtMatrixLayoutCreate)
+#undef WQAA_LT_SYM
+    a.ok = ok;
+    return a;
+  }();
+  return api;
+}
+}  // namespace
+#define hipblasLtCreate lt_api().Create
+#define hipblasLtMatmul lt_api().Matmul
+#define hipblasLtMatmulAlgoGetHeuristic lt_api().MatmulAlgoGetHeuristic
+#define hipblasLtMatmulDescCreate lt_api().MatmulDescCreate
+#define hipblasLtMatmulDescSetAttribute lt_api().MatmulDescSetAttribute
+#define hipblasLtMatmulPreferenceCreate lt_api().MatmulPreferenceCreate
+#define hipblasLtMatmulPreferenceDestroy lt_api().MatmulPreferenceDestroy
+#define hipblasLtMatmulPreferenceSetAttribute lt_api().MatmulPreferenceSetAttribute
+#define hipblasLtMatrixLayoutCreate lt_api().MatrixLayoutCreate
 
 namespace wqaa {
 
@@ -105,7 +161,7 @@ const LtPlan* get_plan(const wqaa_matmul_desc& d, int m) {
   memset(&p, 0, sizeof(p));
   p.d = d; p.m = m; p.dev = dev; p.ok = false;
   hipDataType ta, tc;
-  bool good = to_hip_type(d.a_dtype, &ta) && to_hip_type(d.out_dtype, &tc);
+  bool good = lt_api().ok && to_hip_type(d.a_dtype, &ta) && to_hip_type(d.out_dtype, &tc);
   if (good && !g_handle[dev]) good = hipblasLtCreate(&g_handle[dev]) == HIPBLAS_STATUS_SUCCESS;
   hipblasLtMatmulPreference_t pref = nullptr;
   if (good) {

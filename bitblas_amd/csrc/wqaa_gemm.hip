@@ -213,7 +213,7 @@ static int gemm_choose(const wqaa_matmul_desc& d, int m, GemmChoice* c, bool fus
     } else if (getenv("WQAA_GEMM_MF") != nullptr) {
       bm = (c->mf == 16 && fn256) ? 256 : 0;                       // a forced tile height keeps its round-2 meaning
     } else {
-      double best = 0.97 * tlock;
+      double best = k_ok ? 0.97 * tlock : 1e30;      // (K off the lockstep members' grid: any ping-pong member that takes it)
       if (fn256 && t256 < best) { bm = 256; best = t256; }
       if (fn128 && t128 < best) { bm = 128; best = t128; }
       if (fns && ts < best) { bm = 128; bn = 128; best = ts; }

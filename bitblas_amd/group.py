@@ -207,7 +207,10 @@ def matmul_gate_up(gate_op: Matmul, up_op: Matmul, A: torch.Tensor, gate_weights
         check_norm(norm, A, gate_op.K)
         if not gate_op.fused_ops_supported(m) or gate_up_plan(gate_op, m, norm=True) is None:     # the selector's word
             A, norm = rms_norm_reference(A, *norm), None
-    if not gate_op.fused_ops_supported(m) or m == 0:
+    # the selector's word is final: where it refuses the pair (no member, the LDS limit) the group launch + torch's two kernels run
+    if not gate_op.fused_ops_supported(m) or m == 0 or gate_up_plan(gate_op, m, norm=norm is not None) is None:
+        if norm is not None:
+            A, norm = rms_norm_reference(A, *norm), None
         g, u = matmul_group([gate_op, up_op], A, [gate_weights, up_weights])
         return torch.mul(torch.nn.functional.silu(g), u, out=output)
     if output is None:

@@ -736,8 +736,8 @@ class Matmul(Operator):
             return out
         if output is None:
             output = torch.empty(A.shape[:-1] + (self.N,), dtype=self.torch_output_dtype, device=A.device)
-        elif not output.is_contiguous():
-            raise ValueError("output must be a contiguous tensor")
+        elif not output.is_contiguous() or output.device != A.device:
+            raise ValueError("output must be a contiguous tensor on A's device")      # (handed to the kernel as a raw pointer)
         else:
             self.check_output(output, m)
         if W.numel() * W.element_size() != self._w_bytes:

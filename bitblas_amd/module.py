@@ -247,6 +247,7 @@ class Linear(nn.Module):
             self.init_params()
         cfg = self.bitblas_matmul.config
         quantised = not self.consistent
+        A = self.bitblas_matmul.transform_input(A)          # as `forward` does (module/__init__.py:271-276)
         return self.bitblas_matmul.forward_ex(A, self.qweight if quantised else self.weight,
                                               self.scales if quantised and cfg.with_scaling else None,
                                               self.zeros if quantised and cfg.with_zeros else None,

@@ -260,8 +260,10 @@ int wqaa_matmul_group_ex(const wqaa_group_item* items, const wqaa_epilogue* cons
 int wqaa_group_plan(const wqaa_matmul_desc* const* descs, int count, int m, int* launches, wqaa_plan* plan);
 
 /* gate_proj and up_proj of a gated MLP with the activation between them and down_proj folded in (see "callers' elementwise
- * ops" above): act[m, n] = half(silu(g)) * u with g, u = the float16 values wqaa_matmul would have stored for `gate` and
- * `up` (silu in fp32: g / (1 + exp(-g)), rounded to float16; then the float16 product - the roundings of torch's
+ * ops" above): act[m, n] = half(silu(g)) * u with g, u = the float16 values the exact-product GEMV family stores for `gate` and
+ * `up` - what wqaa_matmul gives wherever it takes that family itself (strict_reference = 0 at m = 1, and the m = 2 shapes its
+ * selector keeps there), what wqaa_matmul_ex with a zero residual gives everywhere; a descriptor with strict_reference = 1 runs
+ * the per-element-rounding members under wqaa_matmul and differs from g, u by that rounding (silu in fp32: g / (1 + exp(-g)), rounded to float16; then the float16 product - the roundings of torch's
  * `F.silu(gate) * up`).  One launch: every wave streams row n of BOTH weights against the shared input and the lane holding
  * the two sums stores one value - neither projection's output goes to memory.  gate->C / up->C are ignored (may be NULL);
  * gate->A == up->A; the two descriptors must agree in everything (N, K, format, group size, flags).

@@ -281,3 +281,12 @@ def test_tune_and_dequantize_entries_without_a_device():
     assert p["kernel_family"] in (2, 4)
     if L.wqaa_device_count() == 0:
         assert p["kernel_family"] == 2
+
+
+def test_vendor_library_is_not_a_link_dependency():
+    """hipBLASLt is an opt-in yardstick: libwqaa_hip.so must load on a box without it (dlopen on first use, never DT_NEEDED)"""
+    import subprocess
+    out = subprocess.run(["readelf", "-d", wlib.LIB_PATH], capture_output=True, text=True).stdout
+    needed = [ln for ln in out.splitlines() if "NEEDED" in ln]
+    assert needed, "readelf gave no dynamic section"
+    assert not any("hipblaslt" in ln.lower() for ln in needed), needed
