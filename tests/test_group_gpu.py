@@ -264,3 +264,21 @@ def test_groups_whose_members_alone_would_run_differently_stay_bit_identical():
             c["A"] = longk8[0]["A"]
         ops = [build(c, strict)[0] for c in longk8]
         run_both(longk8, strict, expect_launches=wgroup.group_plan(ops, 1)["launches"])
+
+
+def test_same_total_other_split_do_not_share_a_verdict():
+    """two groups of one total N and member count but different splits, one after the other in one process (the
+    fusability memo was keyed by the total only): each must give its members the single calls' bits, whatever the other group's
+    verdict was.  Few-row members (1024 x 8192: K split across waves alone) next to many-row ones make the splits differ."""
+    K = 8192
+    for Ns in ((4096, 4096, 4096), (10240, 1024, 1024), (4096, 4096, 4096), (8192, 2048, 2048)):
+        cases = [int4_case(n, K=K, seed=n + i) for i, n in enumerate(Ns)]
+        for c in cases[1:]:
+            c["A"] = cases[0]["A"]
+        ops, weights = zip(*[build(c, False) for c in cases])
+        A = _to_dev(cases[0]["A"], DEV)
+        single = [op(A, *w) for op, w in zip(ops, weights)]
+        grouped = bitblas.matmul_group(ops, A, weights)
+        torch.cuda.synchronize()
+        for i, (s_, g_) in enumerate(zip(single, grouped)):
+            assert torch.equal(s_, g_), f"split {Ns}, member {i}: grouped launch differs from the single call"
