@@ -14,6 +14,13 @@ import torch
 
 from helpers import assert_fp_parity, hip_output, make_case, oracle_output
 
+# this file covers the per-element-rounding GEMV members (`strict_reference=True`: the reference's definition to the letter);
+# the library's default members at M <= 2 - the exact-product family - have tests/test_gemvx_gpu.py, test_group_gpu.py,
+# test_float_ops_gpu.py and the reference-held fixtures (test_optest_golden.py, test_te_golden.py, both families)
+import functools  # noqa: E402
+import helpers as _helpers  # noqa: E402
+hip_output = functools.partial(_helpers.hip_output, strict_reference=True)
+
 pytestmark = pytest.mark.gpu
 
 REF_GEMV_CASES = [

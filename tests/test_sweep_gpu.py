@@ -48,8 +48,11 @@ def draw(rng):
     return M, N, K, kw
 
 
+@pytest.mark.parametrize("strict", [None, True], ids=["default_members", "strict_reference"])
 @pytest.mark.parametrize("chunk", range(int(os.environ.get("WQAA_SWEEP_CHUNKS", "8"))))   # 40 draws each
-def test_random_configurations(chunk):
+def test_random_configurations(chunk, strict):
+    """strict=None: the operator as a caller constructs it (the library's default members: at M <= 2 the exact-product GEMV
+    family, IEEE e4m3); True: the reference's definition to the letter"""
     rng = np.random.default_rng(1000 + chunk)
     ran = refused = 0
     for _ in range(40):
@@ -64,7 +67,7 @@ def test_random_configurations(chunk):
             print("draw", M, N, K, kw, flush=True)
         try:
             case = make_case(M, N, K, seed=int(rng.integers(1 << 30)), **kw)
-            got, mm = hip_output(case)
+            got, mm = hip_output(case, strict_reference=strict)
         except (ValueError, RuntimeError, AssertionError) as e:
             msg = str(e)
             # a refusal must come from the selector / config legalisation, with a reason
@@ -77,7 +80,8 @@ def test_random_configurations(chunk):
             assert np.array_equal(got, want), (M, N, K, kw, mm.plans[M]["name"])
         else:
             try:
-                assert_fp_parity(got, want)
+                # (the default members' exact products differ from the reference's per-element rounding by that rounding: DESIGN 4)
+                assert_fp_parity(got, want, atol_frac=1e-3 if strict else 1.5e-3)
             except AssertionError as e:
                 raise AssertionError(f"{(M, N, K, kw, mm.plans[M]['name'])}: {e}")
         ran += 1

@@ -157,9 +157,10 @@ _W_DTYPE = {("uint", 4): "uint4", ("uint", 2): "uint2", ("uint", 1): "uint1", ("
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("members", ["strict_reference", "default"])
 @pytest.mark.parametrize("fast_decoding", [False, True])
 @pytest.mark.parametrize("c", DEQUANT, ids=[c["tag"] for c in DEQUANT])
-def test_hip_matmul_meets_the_executed_te_graph(c, fast_decoding):
+def test_hip_matmul_meets_the_executed_te_graph(c, fast_decoding, members):
     import torch
     import bitblas_amd as bitblas
     from helpers import assert_fp_parity
@@ -179,7 +180,10 @@ def test_hip_matmul_meets_the_executed_te_graph(c, fast_decoding):
                                with_scaling=kw.get("with_scaling", False), with_zeros=kw.get("with_zeros", False),
                                zeros_mode=kw.get("zeros_mode", "original"), with_bias=kw.get("with_bias", False),
                                fast_decoding=fast_decoding if (fmt in ("int", "uint") and bit < 8) else None)
-    mm = bitblas.Matmul(cfg, enable_tuning=False, strict_reference=True)
+    if members == "default" and (fmt == "fp_e4m3" or (fmt == "uint" and bit == 8)):
+        pytest.skip("the default members decode e4m3 per IEEE and uint8 as unsigned: the executed TE graph holds the reference's "
+                    "quirks (bit trick, signed storage read) - compared with the oracle's IEEE restatement in test_gemm_gpu.py")
+    mm = bitblas.Matmul(cfg, enable_tuning=False, strict_reference=True) if members == "strict_reference" else bitblas.Matmul(cfg, enable_tuning=False)
     codes = torch.from_numpy(G[f"{tag}__codes"].view(np.int8))
     if kw["in_dtype"] == "int8" and bit == 8:
         W = codes.cuda()
@@ -197,7 +201,10 @@ def test_hip_matmul_meets_the_executed_te_graph(c, fast_decoding):
     if kw["in_dtype"] == "int8":
         assert np.array_equal(got, want)
     else:
-        assert_fp_parity(got, want)
+        from helpers import record_margin
+        record_margin(f"te/{tag}/fd{int(fast_decoding)}/{members}/{mm.plans[c['M']]['name']}", got, want)
+        # (default members at M <= 2: exact products - they differ from the graph's per-element rounding by that rounding)
+        assert_fp_parity(got, want, atol_frac=1e-3 if members == "strict_reference" else 1.5e-3)
 
 
 @pytest.mark.gpu

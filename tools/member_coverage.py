@@ -26,7 +26,8 @@ def member_class(name: str) -> str:
     return re.sub(r"_x\d+$", "_xG", cls)            # group launches: one class whatever the member count
 
 
-def reachable():
+def reachable(with_args=False):
+    """class -> a one-line example (or, with_args, the example's arguments: tests/test_member_coverage_gpu.py runs it)"""
     f16 = [("float16", w) for w in ("uint4", "int4", "uint2", "int2", "uint1", "int1", "uint8", "int8", "nf4", "fp4_e2m1", "e4m3_float8", "float16")]
     bf16 = [("bfloat16", w) for w in ("uint4", "int4", "uint2", "uint1", "int8", "nf4", "fp4_e2m1", "e4m3_float8", "bfloat16")]
     i8 = [("int8", w) for w in ("int8", "int4", "uint4", "int2", "uint2", "int1")]
@@ -48,13 +49,16 @@ def reachable():
                 continue
             out = "int32" if a in ("int8", "int4") else ("bfloat16" if a == "bfloat16" else "float16")
             acc = "int32" if a in ("int8", "int4") else "float32"
+            cfg = dict(M=ms, N=N, K=K, A_dtype=a, W_dtype=w, out_dtype=out, accum_dtype=acc, fast_decoding=fd, **mode)
             try:
-                op = bitblas.Matmul(bitblas.MatmulConfig(M=ms, N=N, K=K, A_dtype=a, W_dtype=w, out_dtype=out, accum_dtype=acc,
-                                                         fast_decoding=fd, **mode), enable_tuning=False, strict_reference=strict)
+                op = bitblas.Matmul(bitblas.MatmulConfig(**cfg), enable_tuning=False, strict_reference=strict)
             except Exception:  # noqa: BLE001 - a refused configuration reaches no member
                 continue
             for m in ms:
-                seen.setdefault(member_class(op.plans[m]["name"]), f"M={m} N={N} K={K} {a} x {w} {mode} fd={fd} strict={strict}")
+                if with_args:
+                    seen.setdefault(member_class(op.plans[m]["name"]), dict(M=m, N=N, K=K, a=a, w=w, mode=mode, fd=fd, strict=strict, cfg=cfg))
+                else:
+                    seen.setdefault(member_class(op.plans[m]["name"]), f"M={m} N={N} K={K} {a} x {w} {mode} fd={fd} strict={strict}")
     return seen
 
 
