@@ -323,8 +323,14 @@ static bool group_fusable(const wqaa_matmul_desc* const* descs, int count, int m
     if (gemvx_group_eligible(*merged, descs, count, m, true)) *fused_x = 1;
     else ok = false;
   } else if (epi_mode == 0 && gemvx_group_eligible(*merged, descs, count, m)) *fused_x = 1;
-  else if (gemv_group_eligible(*merged, descs, count, m, epi_mode != 0, epi_mode == 2)) *fused_x = 0;
-  else ok = false;
+  else if (gemv_group_eligible(*merged, descs, count, m, epi_mode != 0, epi_mode == 2)) {
+    *fused_x = 0;
+    // a member whose OWN call takes the exact-product family (refused above because its K split alone differs from the merged
+    // operator's: 4096 x 8192 alone splits K in two, 3 x 4096 merged does not) must not be fused into the rounding family's
+    // launch: other arithmetic, other bits than `wqaa_matmul` on it (found by tests/test_group_gpu.py, round 4)
+    for (int i = 0; epi_mode == 0 && descs && i < count; ++i)
+      if (gemvx_eligible(*descs[i], m)) ok = false;
+  } else ok = false;
   g_last_error = saved;
   memcpy(g_last_error_msg, saved_msg, sizeof(saved_msg));
   return ok;

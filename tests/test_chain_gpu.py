@@ -239,4 +239,5 @@ def test_decoder_tail_module_both_forms():
     h = x + o(attn)
     hn = torch.nn.functional.rms_norm(h, (H,), nw, 1e-5)
     want = h + down(torch.nn.functional.silu(gate(hn)) * up(hn))
-    assert_fp_parity(b.cpu().numpy(), want.float().cpu().numpy(), rtol=4e-3, atol_frac=2e-3)
+    # (torch's norm sums x^2 in another order, its layers round where the fused ops do not: a last float16 bit here and there)
+    assert_fp_parity(b.cpu().numpy(), want.float().cpu().numpy(), rtol=4e-3, atol_frac=4e-3)

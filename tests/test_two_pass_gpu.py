@@ -100,7 +100,7 @@ def test_two_pass_member_against_the_oracle_and_the_fused_member(kw, M):
     assert plan["kernel_family"] == 4 and plan["name"].endswith("_dq_hipblaslt"), plan
     two = mm(A, *w)
     torch.cuda.synchronize()
-    want = oracle_output(case)
+    want = oracle_output(case, strict_reference=True)
     assert_fp_parity(two.cpu().numpy(), want, rtol=1e-3, atol_frac=1e-3)
     assert_fp_parity(two.cpu().numpy(), fused.cpu().numpy(), rtol=1e-3, atol_frac=1e-3)
     # below the threshold the fused member stays
@@ -120,7 +120,7 @@ def test_two_pass_int8_is_bit_exact():
         pytest.skip("the vendor library offers no int8 x int8 -> int32 algorithm for this shape")
     out = mm(_to_dev(case["A"], DEV), *w)
     torch.cuda.synchronize()
-    assert np.array_equal(out.cpu().numpy(), oracle_output(case))
+    assert np.array_equal(out.cpu().numpy(), oracle_output(case, strict_reference=True))
 
 
 @pytest.mark.dense_lib
