@@ -141,11 +141,13 @@ def time_member_gemv(device, gen, N, K, n_buf=64, strict=False):
             "frac_of_hbm_peak": nbytes / t / 1e9 / HBM_PEAK_GBS, "buffers": n_buf}
 
 
-def time_member_gemm(device, gen, M=4096, N=4096, K=4096, W_dtype="uint4", A_dtype="float16", n_buf=8, tuned=False):
-    """MFMA GEMM members (BASELINE configs c3 / c4): TFLOP/s from graph-replayed launches."""
+def time_member_gemm(device, gen, M=4096, N=4096, K=4096, W_dtype="uint4", A_dtype="float16", n_buf=8, tuned=False, bitnet=False):
+    """MFMA GEMM members (BASELINE configs c3 / c4): TFLOP/s from graph-replayed launches.
+    bitnet: the int8 member as a BitNet layer calls it (integration/BitNet/utils_quant.py:205-216) - float16 output through the fused
+    `out / si / sw` epilogue (wqaa_matmul_ex) instead of the int32 sums."""
     int8 = A_dtype == "int8"
     try:
-        op = get_op(M, N, K, W_dtype=W_dtype, A_dtype=A_dtype, out_dtype="int32" if int8 else "float16",
+        op = get_op(M, N, K, W_dtype=W_dtype, A_dtype=A_dtype, out_dtype="float16" if (bitnet or not int8) else "int32",
                     zeros=not int8, scaling=not int8, accum="int32" if int8 else "float16")
         if op.plans[M]["kernel_family"] != 2:
             return None
@@ -166,7 +168,8 @@ def time_member_gemm(device, gen, M=4096, N=4096, K=4096, W_dtype="uint4", A_dty
         A = torch.randint(-128, 128, (M, K), device=device, dtype=torch.int8, generator=gen)
     else:
         A = (torch.rand((M, K), device=device, generator=gen) - 0.5).to(torch.float16)
-    out = torch.empty((M, N), dtype=torch.int32 if int8 else torch.float16, device=device)
+    out = torch.empty((M, N), dtype=torch.int32 if (int8 and not bitnet) else torch.float16, device=device)
+    row_scale = (torch.rand((M,), device=device, generator=gen) * 50.0 + 50.0).to(torch.float32) if bitnet else None
     sets = []
     for _ in range(n_buf):
         qw = torch.randint(-128, 128, (N, K * bits // 8), dtype=torch.int8, device=device, generator=gen)
@@ -177,8 +180,11 @@ def time_member_gemm(device, gen, M=4096, N=4096, K=4096, W_dtype="uint4", A_dty
     def launch_all():
         stream = torch.cuda.current_stream(device).cuda_stream
         for qw, sc, zr in sets:
-            op.lib.run(A.data_ptr(), qw.data_ptr(), None, None if int8 else sc.data_ptr(),
-                       None if int8 else zr.data_ptr(), None, out.data_ptr(), M, stream)
+            if bitnet:
+                op.lib.run_fused(A.data_ptr(), qw.data_ptr(), None, out.data_ptr(), M, stream, row_scale.data_ptr(), 37.5)
+            else:
+                op.lib.run(A.data_ptr(), qw.data_ptr(), None, None if int8 else sc.data_ptr(),
+                           None if int8 else zr.data_ptr(), None, out.data_ptr(), M, stream)
 
     try:
         t = graph_time(device, launch_all, n_buf)
@@ -187,7 +193,7 @@ def time_member_gemm(device, gen, M=4096, N=4096, K=4096, W_dtype="uint4", A_dty
             os.environ.pop("WQAA_DENSE_LIB", None)
     peak = MFMA_I8_PEAK_TOPS if int8 else MFMA_F16_PEAK_TF
     tf = 2.0 * M * N * K / t / 1e12
-    nbytes = algorithmic_bytes(M, N, K, bits=bits, zeros=not int8, scale=not int8, out_bytes=4 if int8 else 2, a_bytes=1 if int8 else 2)
+    nbytes = algorithmic_bytes(M, N, K, bits=bits, zeros=not int8, scale=not int8, out_bytes=4 if (int8 and not bitnet) else 2, a_bytes=1 if int8 else 2)
     # the roof that binds this shape: decode batches sit left of the ridge (4-bit weights: 2 M N K flops over ~N K / 2
     # bytes = 4 M flop/B against 2500 / 8 = 312), where the weight stream, not the matrix pipe, sets the floor
     t_mfma, t_hbm = 2.0 * M * N * K / (peak * 1e12), nbytes / (HBM_PEAK_GBS * 1e9)
@@ -198,7 +204,7 @@ def time_member_gemm(device, gen, M=4096, N=4096, K=4096, W_dtype="uint4", A_dty
         roof = {"bound": "mfma", "achieved": tf, "peak": peak, "unit": "TFLOP/s" if not int8 else "TOP/s", "frac": tf / peak,
                 "flops_per_launch": 2.0 * M * N * K}
     return {"workload": f"W_{W_dtype} A_{A_dtype} GEMM M={M} N={N} K={K}" + ("" if int8 else " g=128 zeros=original"),
-            "kernel": op.plans[M]["name"], **({"tuning": getattr(op, "_tuned", {}).get(M, "fused member kept")} if tuned else {}),
+            "kernel": op.lib.plan_ex(M, 0)["name"] if bitnet else op.plans[M]["name"], **({"tuning": getattr(op, "_tuned", {}).get(M, "fused member kept")} if tuned else {}),
             "us_per_launch": t * 1e6, "TFLOPs": tf, "roofline": roof,
             "GBps_algorithmic": nbytes / t / 1e9, "frac_of_mfma_peak": tf / peak, "mfma_peak": peak}
 
@@ -880,6 +886,7 @@ def main():
             member("gemm_uint4_m128", time_member_gemm, device, gen, 128)
             member("gemm_uint4_m16", time_member_gemm, device, gen, 16)
             member("gemm_int2_int8_m4096", time_member_gemm, device, gen, 4096, W_dtype="int2", A_dtype="int8")
+            member("gemm_int2_int8_m4096_bitnet", time_member_gemm, device, gen, 4096, W_dtype="int2", A_dtype="int8", bitnet=True)
             member("gemv_int2_int8_m1", time_member_dense, device, gen, 1, 4096, 4096, kind="int2", n_buf=64)
             member("step_chained", time_step_chained, device, gen)
             member("step_int2_int8", time_step_int2_int8, device, gen)

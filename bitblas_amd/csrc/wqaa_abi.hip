@@ -643,6 +643,29 @@ int wqaa_select(const wqaa_matmul_desc* desc, int m, wqaa_plan* plan) {
 
 // wqaa_pack_weight / wqaa_unpack_weight / wqaa_relayout_weight: csrc/wqaa_pack.hip (host only)
 
+int wqaa_select_ex(const wqaa_matmul_desc* desc, int m, int epilogue_flags, wqaa_plan* plan) {
+  if (!valid_desc(desc)) return WQAA_ERR_BAD_DESC;
+  if (plan) memset(plan, 0, sizeof(*plan));
+  if (m <= 0) m = 1;
+  if (epilogue_flags < 0) return wqaa_select(desc, m, plan);
+  g_plan_epoch.fetch_add(1, std::memory_order_relaxed);
+  if (epilogue_flags & (WQAA_EPI_ADD_RESIDUAL | WQAA_EPI_RMSNORM_INPUT)) {
+    // the float16 path's fused ops exist in the exact-product GEMV family only
+    wqaa_epilogue e;
+    memset(&e, 0, sizeof(e));
+    e.flags = epilogue_flags;
+    if (!gemvx_covers(*desc, m) || desc->out_dtype != WQAA_F16) {
+      set_error(WQAA_ERR_UNSUPPORTED, "select_ex: residual add / RMSNorm input need float16 x 1/2/4-bit integer weights, float16 output, m <= 2");
+      return WQAA_ERR_UNSUPPORTED;
+    }
+    return gemvx_plan(*desc, m, plan);
+  }
+  bool use_gemm = false;
+  dispatch(*desc, m, &use_gemm);
+  if ((epilogue_flags & WQAA_EPI_QUANTIZE_INPUT) && m <= 4) use_gemm = false;
+  return use_gemm ? gemm_plan(*desc, m, plan, true) : gemv_plan(*desc, m, plan);
+}
+
 int wqaa_debug_decode(const void* packed_dev, int64_t nwords, int w_format, int bits, int layout,
                       int a_dtype, int strict_reference, const void* lut_dev, void* out_dev,
                       void* stream) {

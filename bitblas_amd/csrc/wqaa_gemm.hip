@@ -180,11 +180,13 @@ static int gemm_choose(const wqaa_matmul_desc& d, int m, GemmChoice* c, bool fus
     const bool one_group = d.K / g == 1;
     const bool meta_ok = c->mode == MD_NONE || (g % (kb / 2) == 0 && (one_group || (ilog2_exact(gb) >= 0 && ((d.K / g) & 1) == 0)) &&
                                                 (long)d.N * (d.K / g) >= 8 && (c->mode != MD_ZQ || (d.N % 32 == 0 && c->bits == 4)));
-    const bool out_ok = c->at == AT_I8 ? d.out_dtype == WQAA_I32
+    // (the caller's fused epilogue - int32 sums / row scale / tensor scale -> float16 - rides in the integer members' output stage)
+    const bool epi_ok = !fused_epilogue || (c->at == AT_I8 && d.out_dtype == WQAA_F16 && d.a_dtype == WQAA_I8);
+    const bool out_ok = c->at == AT_I8 ? (fused_epilogue ? d.out_dtype == WQAA_F16 : d.out_dtype == WQAA_I32)
                         : c->at == AT_F8 ? d.out_dtype == WQAA_F16
                         : (d.out_dtype == WQAA_F32 || d.out_dtype == ((c->flags & FL_BF16) ? WQAA_BF16 : WQAA_F16));
     const long a_bytes = (long)m * d.K * (c->at == AT_F16 ? 2 : 1), w_bytes = (long)d.N * d.K * c->bits / 8;
-    const bool shape_ok = !fused_epilogue && d.K % kb == 0 && meta_ok && out_ok && d.N % 8 == 0 && a_bytes + 256L * d.K * 2 < (1L << 31) &&
+    const bool shape_ok = epi_ok && d.K % kb == 0 && meta_ok && out_ok && d.N % 8 == 0 && a_bytes + 256L * d.K * 2 < (1L << 31) &&
                           w_bytes < (1L << 31) && d.k_split_hint <= 1 && getenv("WQAA_GEMM_KSPLIT") == nullptr && (!pf || atoi(pf) != 0);
     auto rounds_time = [&](long tiles, double base, double slope) {
       const long full = tiles / cus_, rem = tiles % cus_;
@@ -334,9 +336,9 @@ static int gemm_choose(const wqaa_matmul_desc& d, int m, GemmChoice* c, bool fus
   return WQAA_OK;
 }
 
-int gemm_plan(const wqaa_matmul_desc& d, int m, wqaa_plan* plan) {
+int gemm_plan(const wqaa_matmul_desc& d, int m, wqaa_plan* plan, bool fused_epilogue) {
   GemmChoice c;
-  int st = gemm_choose(d, m, &c);
+  int st = gemm_choose(d, m, &c, fused_epilogue);
   if (st != WQAA_OK) return st;
   if (plan) {
     plan->kernel_family = 2;
@@ -397,7 +399,7 @@ int gemm_launch(const wqaa_matmul_desc& d, const void* A, const void* B, const v
   GemmChoice c;
   {
     static thread_local ChoiceMemo<GemmChoice> memo;
-    const int q = epi ? 1 : 0;            // the callers' fused epilogue lives in wq_gemm_kernel only
+    const int q = epi ? 1 : 0;            // (with the callers' fused epilogue: another output type, another tile choice)
     if (const GemmChoice* hit = memo.find(d, m, q)) {
       c = *hit;
     } else {

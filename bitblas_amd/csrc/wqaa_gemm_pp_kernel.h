@@ -639,9 +639,12 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_pp_kernel(const GemmArgs a
   PP_BARRIER();
   const int el = pp_opaque(lane);          // (lane roles recomputed: nothing of the epilogue stays live across the loop)
   const int e_fr = el & 15, e_kb = el >> 4, e_ln = el & 31, e_h = el >> 5;
-  const bool wide_out = !F16 || a.out_dtype == WQAA_F32;       // 4-byte output elements: int32, or float32 out of the float members
+  // 4-byte output elements: float32 out of the float members; int32 out of the integer ones - unless the caller's epilogue
+  // (wqaa_matmul_ex: out / row_scale[m] / tensor_scale -> float16, integration/BitNet/utils_quant.py:205-216) turns the int32
+  // sums into float16 on their way out: then the tile leaves as the float members' does, half the bytes and one pass
+  const bool wide_out = F16 ? a.out_dtype == WQAA_F32 : a.epi_row == nullptr;
   if (!wide_out) {
-   if constexpr (F16) {
+   {
     // unit = 4 consecutive n (8 bytes); unit u of row m lives at pair ((u >> 1) ^ (m & 7)), half ((u & 1) ^ ((m >> 3) & 1)):
     // the 16 lanes of a ds_write_b64 group (16 consecutive m, one u) hit 16 distinct 8-byte slots of a 128-byte window
     half_t bias_h[2][4];
@@ -659,10 +662,25 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_pp_kernel(const GemmArgs a
 #pragma unroll
     for (int f = 0; f < NMF; ++f) {
       const int m = f * 16 + e_fr;
+      double rs = 1.0;                     // (integer members: the row's activation scale, one load per 8 outputs)
+      if constexpr (!F16) rs = (double)a.epi_row[m0 + m < a.M ? m0 + m : a.M - 1];
 #pragma unroll
       for (int nf = 0; nf < 2; ++nf) {
         uint32_t lo_u, hi_u;
-        if constexpr (BF) {
+        if constexpr (!F16) {
+          // store_out_fused (wqaa_kinds.h) to the letter: two IEEE-exact fp32 divisions taken in fp64, cast, + bias in float16
+          half_t v[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            float x = (float)((double)(float)acc[f][nf][i] / rs);
+            x = (float)((double)x / (double)a.epi_tensor);
+            v[i] = (half_t)x;
+            if (a.has_bias) v[i] = v[i] + bias_h[nf][i];
+          }
+          const half2_t lo = {v[0], v[1]}, hi = {v[2], v[3]};
+          lo_u = as_u32(lo);
+          hi_u = as_u32(hi);
+        } else if constexpr (BF) {
           float x[4];
 #pragma unroll
           for (int i = 0; i < 4; ++i) {

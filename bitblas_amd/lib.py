@@ -41,7 +41,7 @@ ZEROS_CODE = {"original": Z_ORIGINAL, "rescale": Z_RESCALE, "quantized": Z_QUANT
 
 EXPORTED_SYMBOLS = (
     "init", "wqaa_abi_version", "wqaa_device_count", "wqaa_matmul", "wqaa_matmul_timed",
-    "wqaa_matmul_ex", "wqaa_matmul_opts", "wqaa_workspace_bytes", "wqaa_matmul_group", "wqaa_matmul_group_ex", "wqaa_group_plan", "wqaa_matmul_gate_up", "wqaa_gate_up_plan", "wqaa_matmul_chain", "wqaa_chain_plan", "wqaa_debug_chain_status", "wqaa_debug_chain_trace", "wqaa_dequantize", "wqaa_tune", "wqaa_act_quant_int8", "wqaa_select", "wqaa_pack_weight", "wqaa_unpack_weight", "wqaa_relayout_weight", "wqaa_debug_decode", "wqaa_debug_row_blocks", "wqaa_debug_tile_of_block",
+    "wqaa_matmul_ex", "wqaa_matmul_opts", "wqaa_workspace_bytes", "wqaa_matmul_group", "wqaa_matmul_group_ex", "wqaa_group_plan", "wqaa_matmul_gate_up", "wqaa_gate_up_plan", "wqaa_matmul_chain", "wqaa_chain_plan", "wqaa_debug_chain_status", "wqaa_debug_chain_trace", "wqaa_dequantize", "wqaa_tune", "wqaa_act_quant_int8", "wqaa_select", "wqaa_select_ex", "wqaa_pack_weight", "wqaa_unpack_weight", "wqaa_relayout_weight", "wqaa_debug_decode", "wqaa_debug_row_blocks", "wqaa_debug_tile_of_block",
     "wqaa_last_error", "wqaa_last_error_string",
 )
 
@@ -167,6 +167,8 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
         lib.wqaa_dequantize.argtypes = [dp, vp, vp, vp, vp, vp, vp]
         lib.wqaa_select.restype = ci
         lib.wqaa_select.argtypes = [dp, ci, ctypes.POINTER(Plan)]
+        lib.wqaa_select_ex.restype = ci
+        lib.wqaa_select_ex.argtypes = [dp, ci, ci, ctypes.POINTER(Plan)]
         lib.wqaa_pack_weight.restype = ci
         lib.wqaa_pack_weight.argtypes = [vp, i64, i64, ci, ci, ci, vp]
         lib.wqaa_unpack_weight.restype = ci
@@ -425,6 +427,13 @@ class BoundLib:
     def plan(self, m: int) -> dict:
         self._ws_need.clear()      # planning re-reads the tuning variables: the scratch a member needs may change with them
         return select(self.desc, m)
+
+    def plan_ex(self, m: int, epilogue_flags: int = 0) -> dict:
+        """the member `run_fused` / `run_residual` take (wqaa_select_ex): 0 = the caller's row / tensor scales alone"""
+        self._ws_need.clear()
+        plan = Plan()
+        check(load_library().wqaa_select_ex(ctypes.byref(self.desc), int(m), int(epilogue_flags), ctypes.byref(plan)))
+        return plan.as_dict()
 
 
 def act_quant_int8(x, q, s, stream):

@@ -343,6 +343,9 @@ int wqaa_act_quant_int8(const void* X, int64_t rows, int K, void* Q, float* S, v
  * The WQAA_GEMM_* / WQAA_GEMV_* tuning environment variables are read here and at the first wqaa_matmul of a
  * (desc, m) pair per thread; a later change takes effect at the next wqaa_select call. */
 int wqaa_select(const wqaa_matmul_desc* desc, int m, wqaa_plan* plan);
+/* the member wqaa_matmul_ex takes for (desc, m) with an epilogue of these WQAA_EPI_* flags (0: the caller's row / tensor scales
+ * alone - the output type and with it the tile choice differ from the plain call's; < 0: as wqaa_select) */
+int wqaa_select_ex(const wqaa_matmul_desc* desc, int m, int epilogue_flags, wqaa_plan* plan);
 
 /* ---- weight pre-processing (CPU; replaces the TVM-llvm ops of Matmul.transform_weight,
  * bitblas/ops/general_matmul/__init__.py:662-711: QuantCompress + LOP3Permutate) ---------------

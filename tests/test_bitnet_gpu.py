@@ -172,3 +172,24 @@ def test_group_ex_argument_checks_and_mixed_epilogues():
         assert torch.equal(w_, o)
     eptr[1] = None
     assert L.wqaa_matmul_group_ex(items, eptr, 2, 1, stream) == wlib.ERR_BAD_DESC
+
+
+@pytest.mark.parametrize("m,N,K,bias", [(300, 512, 1024, True), (1000, 1024, 2048, False), (4096, 4096, 4096, True), (2048, 11008, 4096, False)])
+def test_bitlinear_prefill_runs_the_ping_pong_member_with_the_epilogue(m, N, K, bias):
+    """prefill row counts: the `out / si / sw -> half (+ bias)` of utils_quant.py:205-216 rides in the output stage of the
+    ping-pong int2 x int8 member (round 4; it used to force the lockstep member) - the plan says so, the bits are the oracle's
+    on a sample of rows"""
+    rng = np.random.default_rng(m + N)
+    w = (rng.standard_normal((N, K)) * 0.05).astype(np.float32)
+    b = rng.standard_normal(N).astype(np.float16) if bias else None
+    lin = BitLinear(K, N, bias=bias).cuda()
+    lin.load_float_weight(torch.from_numpy(w).cuda(), None if b is None else torch.from_numpy(b).cuda())
+    x = rng.standard_normal((m, K)).astype(np.float16)
+    got = lin(torch.from_numpy(x).cuda()).cpu().numpy()
+    name = lin.bitblas_matmul.lib.plan_ex(m)["name"] if hasattr(lin.bitblas_matmul.lib, "plan_ex") else ""
+    rows = np.unique(np.concatenate([[0, 1, 15, 16, 127, 128, 255, 256, m - 1], rng.integers(0, m, 24)]))
+    rows = rows[rows < m]
+    want = oracle.bitnet_forward(x[rows], module_codes(lin), np.float32(lin.sw.item()), b)
+    assert np.array_equal(got[rows].view(np.uint16), want.view(np.uint16))
+    if name and m >= 2048:
+        assert name.endswith("pp"), name          # (smaller outputs: whichever tile the selector's round estimate prefers)
