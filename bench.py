@@ -96,16 +96,29 @@ def make_linear(N, K, device, gen):
     return op, qweight, scale, out
 
 
-def graph_time(device, launch_all, n_launches, replays=5):
+GRAPH_WARM_MS = float(os.environ.get("WQAA_BENCH_WARM_MS", "25"))
+
+
+def graph_time(device, launch_all, n_launches, replays=5, warm_ms=None):
     """Capture `launch_all` (a sequence of kernel launches on the current stream) into one hipGraph,
     replay it, return the average duration of one launch in seconds (median over replays), measured
-    with events on the stream the graph runs on."""
+    with events on the stream the graph runs on.  Untimed replays first, `warm_ms` of them (default 25 ms, WQAA_BENCH_WARM_MS):
+    a member is timed at the clocks the chip settles at under its load, not on the ramp out of the idle state the
+    host-side set-up left it in (same-box A/B of the M = 4096 GEMM: 117.7 us timed cold against 105.3 sustained,
+    profiles/r04_ab_bench_warm.txt)."""
     launch_all()
     torch.cuda.synchronize(device)
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g):
         launch_all()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
     g.replay()
+    e1.record()
+    e1.synchronize()
+    first_ms = max(e0.elapsed_time(e1), 1e-3)
+    for _ in range(min(2000, int((GRAPH_WARM_MS if warm_ms is None else warm_ms) / first_ms))):
+        g.replay()
     torch.cuda.synchronize(device)
     per = []
     for _ in range(replays):
@@ -316,6 +329,66 @@ def time_step_chained(device, gen, n_layers=4):
             "bytes_per_step": nbytes, **res, "fused_vs_composed_max_rel_err": err,
             "bit_identical": bool(torch.equal(outs["fused"], ref)),
             "roofline": {"bound": "hbm", "achieved": res["fused"]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": res["fused"]["frac"]}}
+
+
+def time_chain_tail(device, gen, n_layers=6, reps=5):
+    """the post-attention half of a decoder layer - o_proj (+ x) -> RMSNorm -> gate / up * silu -> down_proj
+    (+ h) - as ONE persistent run-ahead launch (`wqaa_matmul_chain`, csrc/wqaa_chain_kernel.h) against the three launches it
+    stands for (`forward_ex`, `matmul_gate_up`, `forward_ex`): one hipGraph replay over `n_layers` tails with distinct weights
+    each, every stage's output compared bit for bit.  The launches are what the headline step and `step_chained` use (the
+    chain loses: DESIGN.md section 3.3c)."""
+    from bitblas_amd.chain import ChainStep, chain_plan, matmul_chain
+    H, I = 4096, 11008
+    o_op, g_op, d_op = get_op(1, H, H), get_op(1, I, H), get_op(1, H, I)
+
+    def lin(op):
+        return (torch.randint(-128, 128, (op.N, op.K // 2), dtype=torch.int8, device=device, generator=gen),
+                (torch.rand((op.N, op.K // GROUP), device=device, generator=gen) * 0.02 * 0.04).to(torch.float16))
+
+    layers = [dict(o=lin(o_op), g=lin(g_op), u=lin(g_op), d=lin(d_op),
+                   nw=(1.0 + (torch.rand(H, device=device, generator=gen) - 0.5) * 0.2).to(torch.float16)) for _ in range(n_layers)]
+    attn = (torch.rand((1, H), device=device, generator=gen) - 0.5).to(torch.float16)
+    x0 = (torch.rand((1, H), device=device, generator=gen) - 0.5).to(torch.float16)
+    eps = 1e-5
+    mk = lambda n: [torch.empty((1, n), dtype=torch.float16, device=device) for _ in range(n_layers)]   # noqa: E731
+    hs, acts, outs, chs, cas, cos = mk(H), mk(I), mk(H), mk(H), mk(I), mk(H)
+
+    def run_launches():
+        x = x0
+        for L, h, a, o in zip(layers, hs, acts, outs):
+            o_op.forward_ex(attn, L["o"][0], scale=L["o"][1], residual=x, output=h)
+            bitblas.matmul_gate_up(g_op, g_op, h, L["g"], L["u"], output=a, norm=(L["nw"], eps))
+            d_op.forward_ex(a, L["d"][0], scale=L["d"][1], residual=h, output=o)
+            x = o
+
+    def steps_of(L, x, h, a, o):
+        return [ChainStep(o_op, L["o"], attn, residual=x, output=h),
+                ChainStep(g_op, L["g"], 0, norm=(L["nw"], eps), up_op=g_op, up_weights=L["u"], output=a),
+                ChainStep(d_op, L["d"], 1, residual=0, output=o)]
+
+    def run_chain():
+        x = x0
+        for i, L in enumerate(layers):
+            matmul_chain(steps_of(L, x, chs[i], cas[i], cos[i]))
+            x = cos[i]
+
+    plan = chain_plan(steps_of(layers[0], x0, chs[0], cas[0], cos[0]))
+    run_launches()
+    run_chain()
+    torch.cuda.synchronize(device)
+    same = [bool(torch.equal(a, b)) for a, b in zip(hs + acts + outs, chs + cas + cos)]
+    tail_bytes = sum(algorithmic_bytes(1, N, K) for (N, K) in ((H, H), (I, H), (I, H), (H, I))) - I * 2 * 2 + I * 2 + 2 * H * 2
+    res = {}
+    for name, fn in (("launches", run_launches), ("chain", run_chain)):
+        t = min(graph_time(device, fn, n_layers) for _ in range(reps))
+        res[name] = {"us_per_tail": t * 1e6, "launches_per_tail": 3 if name == "launches" else (plan.get("launches") or 1),
+                     "GBps": tail_bytes / t / 1e9, "frac": tail_bytes / t / 1e9 / HBM_PEAK_GBS}
+    return {"workload": f"W_int4 A_fp16 M=1: o_proj(+x) -> RMSNorm -> gate/up*silu -> down_proj(+h) of a Llama-2-7B layer, {n_layers} tails "
+                        "with distinct weights per hipGraph replay",
+            "chain_plan": (plan.get("plan") or {}).get("name"), "chain_fused": plan.get("launches") == 1, "chain_reason": plan.get("reason"),
+            "bytes_per_tail": tail_bytes, **res, "bit_identical_stages": f"{sum(same)}/{len(same)}", "bit_identical": all(same),
+            "chain_over_launches": res["chain"]["us_per_tail"] / res["launches"]["us_per_tail"],
+            "roofline": {"bound": "hbm", "achieved": res["launches"]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": res["launches"]["frac"]}}
 
 
 def time_member_f16_gemv(device, gen, N, K, int4_us=None):
@@ -889,6 +962,7 @@ def main():
             member("gemm_int2_int8_m4096_bitnet", time_member_gemm, device, gen, 4096, W_dtype="int2", A_dtype="int8", bitnet=True)
             member("gemv_int2_int8_m1", time_member_dense, device, gen, 1, 4096, 4096, kind="int2", n_buf=64)
             member("step_chained", time_step_chained, device, gen)
+            member("chain_tail", time_chain_tail, device, gen)
             member("step_int2_int8", time_step_int2_int8, device, gen)
             member("step_int2_int8_ungrouped", time_step_int2_int8, device, gen, grouped=False)
             # c5: dense e4m3 x e4m3 on every Llama-3-70B linear of one (unsharded) GPU, M = 4096 and M = 1

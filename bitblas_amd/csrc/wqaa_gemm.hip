@@ -75,11 +75,16 @@ struct GemmChoice {
   int mf, ks, kl, nwaves, bn, ksplit, skinny, decode, wide, pp, pp_shift, pp_bm;
   int tiles_m, tiles_n, lds;
   int fp4_table;
+  // the remainder of a partial round of 256 x 256 tiles as a second launch of the 128 x 256 member over the last N-tiles
+  gemm_fn tail_fn;
+  int tail_lds, tail_tiles_m, tail_tiles_n;
 };
 
 static int gemm_choose(const wqaa_matmul_desc& d, int m, GemmChoice* c, bool fused_epilogue = false) {
   const int a = d.a_dtype;
   c->fp4_table = 0;
+  c->tail_fn = nullptr;
+  c->tail_lds = c->tail_tiles_m = c->tail_tiles_n = 0;
   c->flags = 0;
   c->layout = d.w_layout == WQAA_LAYOUT_LOP3 ? LAYOUT_LOP3 : LAYOUT_PLAIN;
   if (a == WQAA_F16) c->at = AT_F16;
@@ -206,6 +211,25 @@ static int gemm_choose(const wqaa_matmul_desc& d, int m, GemmChoice* c, bool fus
     gemm_fn fns = shape_ok ? pick_gemm_pp(c->kind, c->layout, c->at, c->mode, c->flags, 128, 128, &ldss) : nullptr;
     // (a round of x 128 x 128 fp8 tiles: 30 + 0.035 x in the units of the estimates above; profiles/r03_ab_pp_tile_f8_128.txt)
     const double ts = rounds_time(tiles_l, 30.0, 0.035);
+    // A shape that leaves the last round of 256 x 256 tiles mostly empty (2048 x 11008: 344 tiles = one round + 88) pays a whole
+    // tile's latency for it (80 + 0.113 x).  The columns of that remainder go out as a SECOND launch of the 128-row tile - twice
+    // the workgroups, 55 + 0.052 x - behind a launch of whole rounds: N-tiles [0, n_main) by the first, the rest by the second
+    // (GemmArgs::tile_n_off); + ~3 us of boundary.  WQAA_GEMM_PP_TAIL=0: never.
+    int hy_n_main = 0;
+    double thy = 1e30;
+    {
+      const char* tf = getenv("WQAA_GEMM_PP_TAIL");
+      const long tm256 = (m + 255) / 256, tm128 = (m + 127) / 128;
+      const long T = tm256 * tiles_n256;
+      if (fn256 && fn128 && (!tf || atoi(tf) != 0) && T > cus_ && T % cus_ != 0 && tiles_n256 >= 2) {
+        const long n_fit = ((T / cus_) * cus_) / tm256;
+        for (long nm = n_fit; nm >= n_fit - 1 && nm >= 1; --nm) {
+          if (nm >= tiles_n256) continue;
+          const double t = rounds_time(tm256 * nm, 80.0, 0.113) + rounds_time(tm128 * (tiles_n256 - nm), 55.0, 0.052) + 3.0;
+          if (t < (nm == n_fit ? thy : 0.99 * thy)) { thy = t; hy_n_main = (int)nm; }      // (ties: the whole rounds to the first launch)
+        }
+      }
+    }
     int bm = 0, bn = 256;
     if (const char* f = getenv("WQAA_GEMM_PP_BM")) {               // tuning aid: force a tile (0: the lockstep members; 128 with
       bm = atoi(f);                                                // WQAA_GEMM_PP_BN=128: the 128 x 128 tile)
@@ -219,7 +243,10 @@ static int gemm_choose(const wqaa_matmul_desc& d, int m, GemmChoice* c, bool fus
       if (fn256 && t256 < best) { bm = 256; best = t256; }
       if (fn128 && t128 < best) { bm = 128; best = t128; }
       if (fns && ts < best) { bm = 128; bn = 128; best = ts; }
+      if (hy_n_main > 0 && thy < 0.97 * best) { bm = 256; bn = 256; best = thy; }
+      else hy_n_main = 0;
     }
+    if (bm != 256 || bn != 256) hy_n_main = 0;       // (a forced tile stays what it says)
     if (bm) {
       c->pp = 1;
       c->pp_bm = bm;
@@ -236,6 +263,13 @@ static int gemm_choose(const wqaa_matmul_desc& d, int m, GemmChoice* c, bool fus
       c->tiles_n = (d.N + bn - 1) / bn;
       c->lds = bn == 128 ? ldss : bm == 256 ? lds256 : lds128;
       c->ksplit = 1;
+      if (hy_n_main > 0) {
+        c->tail_fn = fn128;
+        c->tail_lds = lds128;
+        c->tail_tiles_m = (m + 127) / 128;
+        c->tail_tiles_n = c->tiles_n - hy_n_main;
+        c->tiles_n = hy_n_main;
+      }
       return WQAA_OK;
     }
   }
@@ -352,11 +386,13 @@ int gemm_plan(const wqaa_matmul_desc& d, int m, wqaa_plan* plan, bool fused_epil
     plan->pipeline_depth = 2;
     plan->split_k = c.ksplit;
     plan->lds_bytes = c.lds;
-    plan->grid = c.tiles_m * c.tiles_n * c.ksplit;
+    plan->grid = c.tiles_m * c.tiles_n * c.ksplit + (c.tail_fn ? c.tail_tiles_m * c.tail_tiles_n : 0);
     char wd[24];
     short_wdtype(d, wd, sizeof(wd));
-    snprintf(plan->name, sizeof(plan->name), "matmul_m%dn%dk%d_%sx%s_tcx%dx%dx%d%s%s", m, d.N, d.K, short_dtype(d.a_dtype),
-             wd, 16 * c.mf, c.bn, c.ks, c.ksplit > 1 ? "xr" : "", c.pp ? "pp" : c.skinny ? "xs" : c.decode == 2 ? "xdl" : c.decode ? "xd" : c.wide ? "xw" : "");
+    char tail[16] = "";
+    if (c.tail_fn) snprintf(tail, sizeof(tail), "t%d", c.tail_tiles_n);      // "ppt11": the last 11 N-tiles as a launch of the 128-row tile
+    snprintf(plan->name, sizeof(plan->name), "matmul_m%dn%dk%d_%sx%s_tcx%dx%dx%d%s%s%s", m, d.N, d.K, short_dtype(d.a_dtype),
+             wd, 16 * c.mf, c.bn, c.ks, c.ksplit > 1 ? "xr" : "", c.pp ? "pp" : c.skinny ? "xs" : c.decode == 2 ? "xdl" : c.decode ? "xd" : c.wide ? "xw" : "", tail);
   }
   return WQAA_OK;
 }
@@ -483,9 +519,22 @@ int gemm_launch(const wqaa_matmul_desc& d, const void* A, const void* B, const v
   hipError_t e;
   if (start || stop) {
     e = hipExtLaunchKernel(reinterpret_cast<const void*>(c.fn), grid, block, params, c.lds, stream, start,
-                           c.ksplit > 1 ? nullptr : stop, 0);
+                           (c.ksplit > 1 || c.tail_fn) ? nullptr : stop, 0);
   } else {
     e = hipLaunchKernel(reinterpret_cast<const void*>(c.fn), grid, block, params, c.lds, stream);
+  }
+  if (e == hipSuccess && c.tail_fn) {
+    // the remainder's columns, by the 128-row tile (same operands; the tile map counts from the first N-tile of the band)
+    GemmArgs t = a;
+    t.tiles_m = c.tail_tiles_m;
+    t.tiles_n = c.tail_tiles_n;
+    t.tile_n_off = c.tiles_n;
+    t.group_m = a.group_m;
+    fill_tile_magics(t, 1, d.K);
+    void* tparams[] = {&t};
+    const dim3 tgrid(c.tail_tiles_m * c.tail_tiles_n, 1, 1);
+    if (start || stop) e = hipExtLaunchKernel(reinterpret_cast<const void*>(c.tail_fn), tgrid, block, tparams, c.tail_lds, stream, nullptr, stop, 0);
+    else e = hipLaunchKernel(reinterpret_cast<const void*>(c.tail_fn), tgrid, block, tparams, c.tail_lds, stream);
   }
   if (e == hipSuccess && c.ksplit > 1) {
     const long quads = (long)m * d.N / 4;

@@ -68,6 +68,8 @@ struct GemmArgs {
   // reciprocals of the tile map's divisors (tile_magic; 0 = divide): a uniform integer division is ~25 instructions of
   // float reciprocal + fix-up on this ISA (a 64-bit one ~150) and the tile map had five of them in front of the first load
   uint32_t mg_ntiles = 0, mg_per_group = 0, mg_group_m = 0, mg_tail_m = 0, mg_ksplit = 0;
+  int tile_n_off = 0;  // ping-pong members: first N-tile of this launch (a launch may cover a band of the output's columns: the
+                       // remainder of a partial round goes out as a second launch of the 128-row tile, csrc/wqaa_gemm.hip)
 };
 
 // floor(2^32 / d) + 1: __umulhi(x, magic) == x / d whenever x * d < 2^32 (the host checks the largest x it can meet)

@@ -32,6 +32,8 @@ typedef int i32x16 __attribute__((ext_vector_type(16)));
 
 enum : int {
   PPO_ZINT_OFF = 1,      // never take the integer-zero-point decode (A/B aid)
+  PPO_RW64 = 2,          // lab: the packed words come back by conflict-free 8-byte reads + a lane select (4-byte reads: 2-way conflicts)
+  PPO_META_SLOW = 4,     // lab: the general Scale / Zeros window arithmetic even where the rows' windows are aligned
   PPO_TRACE = 32,        // lab: s_memtime stamps of the four phases of k-tile 16, written through a.lut ([block][wave][20])
   PPO_ABL_NODMA = 64,    // lab ablations (timing only, results wrong): no LDS-DMA inside the loop,
   PPO_ABL_NOREAD = 128,  //   no operand reads from LDS,
@@ -215,7 +217,7 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_pp_kernel(const GemmArgs a
   const TileOfBlock tob = tile_of_block(a, (int)blockIdx.x, (int)gridDim.x);
   const int tile_m = tob.tile_m, tile_n = tob.tile_n;
   const int m0 = tile_m * P::BM;
-  const int n0 = tile_n * P::BN;
+  const int n0 = (tile_n + a.tile_n_off) * P::BN;
   const int nw0 = n0 + wave * 32;       // first weight row of this wave
 
   const int ntiles = a.K / P::KT;       // a multiple of 4 (K is a multiple of KB)
@@ -354,10 +356,19 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_pp_kernel(const GemmArgs a
       const int gi = group_of_body(b);
       const int q8 = gi & ~7;
       const unsigned char* p = meta + ((gi >> 3) & 1) * 1024 + (pp_opaque(lane) & 15) * 16;
+      // e = gi - min(8 q - parity, mlim_f) = max((gi & 7) + parity, gi - mlim_f): the scalar part of each term stays scalar
+      // (every vector operation of this loop shows in its time: the ~120 that Scale + Zeros add per trip are its 15 us)
+      const int c1 = (gi & 7) + (mlim_f[0] & 1);    // (mlim is even: the parity of mlim - rowbase is the row's; both fragments' rows share it - 16 rows apart)
 #pragma unroll
       for (int nf = 0; nf < 2; ++nf) {
-        const int q8o = q8 - (mlim_f[nf] & 1);      // (mlim is even: the parity of mlim - rowbase is the row's)
-        const int e = gi - (q8o < mlim_f[nf] ? q8o : mlim_f[nf]);
+        int e;
+        if constexpr (P::OPT & PPO_META_SLOW) {
+          const int q8o = q8 - (mlim_f[nf] & 1);
+          e = gi - (q8o < mlim_f[nf] ? q8o : mlim_f[nf]);
+        } else {
+          const int t = gi - mlim_f[nf];
+          e = t > c1 ? t : c1;
+        }
         m_s[nf] = *reinterpret_cast<const uint16_t*>(p + nf * 256 + e * 2);
         if constexpr (ZP) m_z[nf] = *reinterpret_cast<const uint16_t*>(p + 512 + nf * 256 + e * 2);
         if constexpr (ZQ) {
@@ -408,8 +419,26 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_pp_kernel(const GemmArgs a
   };
   auto read_words = [&](int half, int buf) {        // k-tiles 2 * half, 2 * half + 1 of the landed chunk (in buffer buf) -> registers
     const int l = pp_opaque(lane);
-    const uint32_t w_rd0 = (uint32_t)((l & 15) * 128 + (l >> 4) * 4);
     const int swl = ((l & 15) >> 1) & 7;
+    if constexpr (P::OPT & PPO_RW64) {
+      // a 4-byte read is banked modulo 32 dwords over lanes 0-31 / 32-63: rows 2j and 2j + 1 share a swizzle and meet on a bank
+      // (2-way: the 8 % of LDS cycles SQ_LDS_BANK_CONFLICT counts for this member).  8-byte reads are banked modulo 64: the
+      // 16 rows of a lane half fall on 16 different slots.  A lane reads the 8-byte half that holds its word and keeps one.
+      typedef __attribute__((address_space(3))) const volatile uint64_t lds_u64;
+      const uint32_t base = (uint32_t)(uintptr_t)(w_buf + buf * 4096) + (uint32_t)((l & 15) * 128 + (l >> 5) * 8);
+      const bool hi = (l & 16) != 0;
+#pragma unroll
+      for (int tp = 0; tp < 2; ++tp)
+#pragma unroll
+        for (int nf = 0; nf < 2; ++nf)
+#pragma unroll
+          for (int jj = 0; jj < 2; ++jj) {
+            const uint64_t v = *reinterpret_cast<lds_u64*>(base + (uint32_t)(nf * 2048) + (uint32_t)(((2 * (2 * half + tp) + jj) ^ swl) * 16));
+            rawc[2 * half + tp][nf][jj] = hi ? (uint32_t)(v >> 32) : (uint32_t)v;
+          }
+      return;
+    }
+    const uint32_t w_rd0 = (uint32_t)((l & 15) * 128 + (l >> 4) * 4);
 #pragma unroll
     for (int tp = 0; tp < 2; ++tp)
 #pragma unroll
@@ -659,23 +688,43 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_pp_kernel(const GemmArgs a
           else bias_h[nf][i] = reinterpret_cast<const half_t*>(a.bias)[n < a.N ? n : a.N - 1];
         }
     }
+    // integer members: out / row_scale[m] / tensor_scale by the shared-divisor form of the IEEE division (ExactDiv, wqaa_kinds.h)
+    // when every divisor this wave meets is in its range (always, for scales that come from a quantiser), `a / b` otherwise
+    bool div_safe = false;
+    ExactDiv dts{1.f, 1.f};
+    if constexpr (!F16) {
+      bool ok = ExactDiv::safe(a.epi_tensor);
+#pragma unroll
+      for (int f = 0; f < NMF; ++f) ok = ok && ExactDiv::safe(a.epi_row[m0 + f * 16 + e_fr < a.M ? m0 + f * 16 + e_fr : a.M - 1]);
+      div_safe = __all(ok);
+      dts = ExactDiv::prepare(a.epi_tensor);
+    }
 #pragma unroll
     for (int f = 0; f < NMF; ++f) {
       const int m = f * 16 + e_fr;
-      double rs = 1.0;                     // (integer members: the row's activation scale, one load per 8 outputs)
-      if constexpr (!F16) rs = (double)a.epi_row[m0 + m < a.M ? m0 + m : a.M - 1];
+      float rs = 1.f;                      // (integer members: the row's activation scale, one load per 8 outputs)
+      if constexpr (!F16) rs = a.epi_row[m0 + m < a.M ? m0 + m : a.M - 1];
+      const ExactDiv drs = ExactDiv::prepare(rs);
 #pragma unroll
       for (int nf = 0; nf < 2; ++nf) {
         uint32_t lo_u, hi_u;
         if constexpr (!F16) {
-          // store_out_fused (wqaa_kinds.h) to the letter: two IEEE-exact fp32 divisions taken in fp64, cast, + bias in float16
+          // store_out_fused (wqaa_kinds.h) to the letter: two IEEE fp32 divisions, cast, + bias in float16
           half_t v[4];
+          if (div_safe) {
 #pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            float x = (float)((double)(float)acc[f][nf][i] / rs);
-            x = (float)((double)x / (double)a.epi_tensor);
-            v[i] = (half_t)x;
-            if (a.has_bias) v[i] = v[i] + bias_h[nf][i];
+            for (int i = 0; i < 4; i += 2) {
+              const ExactDiv::f32x2 x = dts(drs(ExactDiv::f32x2{(float)acc[f][nf][i], (float)acc[f][nf][i + 1]}));
+              v[i] = (half_t)x[0];
+              v[i + 1] = (half_t)x[1];
+            }
+          } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = (half_t)(((float)acc[f][nf][i] / rs) / a.epi_tensor);
+          }
+          if (a.has_bias) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = v[i] + bias_h[nf][i];
           }
           const half2_t lo = {v[0], v[1]}, hi = {v[2], v[3]};
           lo_u = as_u32(lo);
@@ -810,7 +859,7 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_pp8_kernel(const GemmArgs 
 
   const TileOfBlock tob = tile_of_block(a, (int)blockIdx.x, (int)gridDim.x);
   const int tile_m = tob.tile_m, tile_n = tob.tile_n;
-  const int m0 = tile_m * P::BM, n0 = tile_n * P::BN, nw0 = n0 + wave * 32;
+  const int m0 = tile_m * P::BM, n0 = (tile_n + a.tile_n_off) * P::BN, nw0 = n0 + wave * 32;
   const int ntiles = a.K / P::KT;
 
   const auto a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.A), 0, (int)((long)a.M * a.K), 0x00020000);
@@ -1014,7 +1063,7 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_pp8s_kernel(const GemmArgs
 
   const TileOfBlock tob = tile_of_block(a, (int)blockIdx.x, (int)gridDim.x);
   const int tile_m = tob.tile_m, tile_n = tob.tile_n;
-  const int m0 = tile_m * P::BM, n0 = tile_n * P::BN;
+  const int m0 = tile_m * P::BM, n0 = (tile_n + a.tile_n_off) * P::BN;
   const int ntiles = a.K / P::KT;
 
   const auto a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.A), 0, (int)((long)a.M * a.K), 0x00020000);

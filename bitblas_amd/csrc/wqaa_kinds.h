@@ -115,12 +115,49 @@ __device__ __forceinline__ void store_out(void* C, long idx, int acc, int out_dt
 }
 
 // caller epilogue of the int8 path (utils_quant.py:170-176): out = input / si; out = out / sw; half; + bias
+// IEEE division by a divisor many quotients share (a row's activation scale, the tensor's weight scale).  The compiler's own
+// fp32 `a / b` IS correctly rounded here (v_div_scale x 2, v_rcp, the Newton step, two quotient corrections, v_div_fmas,
+// v_div_fixup: 11 operations, checked in the ISA) - and when neither operand needs scaling (v_div_scale passes them
+// through and clears VCC) and none is special, that sequence is exactly: r = rcp(b) refined once; q = a r; two rounds of
+// e = fma(-b, q, a), q = fma(e, r, q).  `safe()` states the operand range in which that holds for quotients taken one after
+// the other (a an integer's float or 0, divisors in [2^-30, 2^30]: every exponent difference stays under 96, nothing comes
+// near a denormal); outside it the callers take `a / b`.  Bit for bit the same result, 5 operations per quotient.
+struct ExactDiv {
+  float b, r;
+  __device__ __forceinline__ static ExactDiv prepare(float b) {
+    float r = __builtin_amdgcn_rcpf(b);
+    const float e = __builtin_fmaf(-b, r, 1.0f);
+    r = __builtin_fmaf(e, r, r);
+    return ExactDiv{b, r};
+  }
+  __device__ __forceinline__ static bool safe(float b) {
+    const float m = __builtin_fabsf(b);
+    return m >= 0x1p-30f && m <= 0x1p30f;          // (false for NaN)
+  }
+  __device__ __forceinline__ float operator()(float a) const {
+    float q = a * r;
+    float e = __builtin_fmaf(-b, q, a);
+    q = __builtin_fmaf(e, r, q);
+    e = __builtin_fmaf(-b, q, a);
+    return __builtin_fmaf(e, r, q);
+  }
+  // two quotients at a time: the same five operations as packed fp32 (v_pk_mul_f32 / v_pk_fma_f32: two lanes' worth per issue)
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  __device__ __forceinline__ f32x2 operator()(f32x2 a) const {
+    const f32x2 nb = {-b, -b}, rr = {r, r};
+    f32x2 q = a * rr;
+    f32x2 e = __builtin_elementwise_fma(nb, q, a);
+    q = __builtin_elementwise_fma(e, rr, q);
+    e = __builtin_elementwise_fma(nb, q, a);
+    return __builtin_elementwise_fma(e, rr, q);
+  }
+};
+
 __device__ __forceinline__ void store_out_fused(void* C, long idx, int acc, float row_scale, float tensor_scale,
                                                 bool has_bias, const void* bias, int n) {
-  // two IEEE-exact fp32 divisions, like torch's: the quotient is taken in fp64 and rounded once to fp32
-  // (innocuous double rounding for p = 24), since the default fp32 division here is not correctly rounded
-  float v = (float)((double)(float)acc / (double)row_scale);
-  v = (float)((double)v / (double)tensor_scale);
+  // two IEEE fp32 divisions, like torch's `out / si / sw` (integration/BitNet/utils_quant.py:205-216)
+  float v = (float)acc / row_scale;
+  v = v / tensor_scale;
   half_t h = (half_t)v;
   if (has_bias) h = h + reinterpret_cast<const half_t*>(bias)[n];
   reinterpret_cast<half_t*>(C)[idx] = h;

@@ -42,6 +42,7 @@ ZEROS_CODE = {"original": Z_ORIGINAL, "rescale": Z_RESCALE, "quantized": Z_QUANT
 EXPORTED_SYMBOLS = (
     "init", "wqaa_abi_version", "wqaa_device_count", "wqaa_matmul", "wqaa_matmul_timed",
     "wqaa_matmul_ex", "wqaa_matmul_opts", "wqaa_workspace_bytes", "wqaa_matmul_group", "wqaa_matmul_group_ex", "wqaa_group_plan", "wqaa_matmul_gate_up", "wqaa_gate_up_plan", "wqaa_matmul_chain", "wqaa_chain_plan", "wqaa_debug_chain_status", "wqaa_debug_chain_trace", "wqaa_dequantize", "wqaa_tune", "wqaa_act_quant_int8", "wqaa_select", "wqaa_select_ex", "wqaa_pack_weight", "wqaa_unpack_weight", "wqaa_relayout_weight", "wqaa_debug_decode", "wqaa_debug_row_blocks", "wqaa_debug_tile_of_block",
+    "wqaa_peer_alloc", "wqaa_peer_free", "wqaa_peer_export", "wqaa_peer_open", "wqaa_peer_close", "wqaa_peer_exchange",
     "wqaa_last_error", "wqaa_last_error_string",
 )
 
@@ -98,6 +99,18 @@ class CallOpts(ctypes.Structure):
     """struct wqaa_call_opts (include/wqaa.h): caller-owned split-K workspace (+ optional fused epilogue)."""
     _fields_ = [("struct_size", ctypes.c_int32), ("flags", ctypes.c_int32), ("workspace", ctypes.c_void_p),
                 ("workspace_bytes", ctypes.c_uint64), ("epilogue", ctypes.POINTER(Epilogue))]
+
+
+PEER_MAX = 16
+PEER_HANDLE_BYTES = 64
+
+
+class PeerExchangeDesc(ctypes.Structure):
+    """struct wqaa_peer_exchange_desc (include/wqaa.h)."""
+    _fields_ = [("src", ctypes.c_void_p), ("bytes", ctypes.c_size_t), ("world", ctypes.c_int32), ("rank", ctypes.c_int32),
+                ("step", ctypes.c_uint32), ("timeout_ms", ctypes.c_uint32),
+                ("dst", ctypes.c_void_p * PEER_MAX), ("post", ctypes.c_void_p * PEER_MAX),
+                ("flags", ctypes.c_void_p), ("status", ctypes.c_void_p)]
 
 
 class WqaaError(RuntimeError):
@@ -177,6 +190,18 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
         lib.wqaa_relayout_weight.argtypes = [vp, i64, i64, ci, ci, ci, ci, vp]
         lib.wqaa_debug_decode.restype = ci
         lib.wqaa_debug_decode.argtypes = [vp, i64, ci, ci, ci, ci, ci, vp, vp, vp]
+        lib.wqaa_peer_alloc.restype = ci
+        lib.wqaa_peer_alloc.argtypes = [ctypes.c_size_t, ctypes.POINTER(vp)]
+        lib.wqaa_peer_free.restype = ci
+        lib.wqaa_peer_free.argtypes = [vp]
+        lib.wqaa_peer_export.restype = ci
+        lib.wqaa_peer_export.argtypes = [vp, vp]
+        lib.wqaa_peer_open.restype = ci
+        lib.wqaa_peer_open.argtypes = [vp, ctypes.POINTER(vp)]
+        lib.wqaa_peer_close.restype = ci
+        lib.wqaa_peer_close.argtypes = [vp]
+        lib.wqaa_peer_exchange.restype = ci
+        lib.wqaa_peer_exchange.argtypes = [ctypes.POINTER(PeerExchangeDesc), vp]
         lib.wqaa_last_error.restype = ci
         lib.wqaa_last_error_string.restype = ctypes.c_char_p
         if lib.wqaa_abi_version() != 3:

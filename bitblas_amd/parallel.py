@@ -103,7 +103,12 @@ class ColumnParallelMatmul:
         return int(rows)
 
     def __init__(self, config: MatmulConfig, group=None, compute: Optional[Callable] = None, row_block: Optional[int] = None,
-                 **matmul_kwargs):
+                 direct_store: bool = False, window_slots: int = 2, window_timeout_ms: int = 2000, **matmul_kwargs):
+        """`direct_store=True`: a single row (decode, M = 1) skips the collective - the kernel writes this rank's slice into its
+        own PEER WINDOW row, one exchange launch stores it into every peer's row and waits for theirs (bitblas_amd/peer.py;
+        hipIpc-mapped device memory on GPUs, a shared mapping in the CPU tests).  The returned `[.., N]` row is a view of the
+        window: valid until `window_slots - 1` more single-row calls have been enqueued (pass `out=` to get a copy).  Rows > 1 and
+        world = 1 take the all-gather path as before.  Not for hipGraph capture (the step number is a launch argument)."""
         self.group = group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
@@ -120,6 +125,9 @@ class ColumnParallelMatmul:
         self.op = None if compute is not None else self._op_for(config.M if isinstance(config.M, int) else None)
         self._comm_stream = None
         self._staging = [None, None]
+        self.direct_store = bool(direct_store)
+        self._window = None
+        self._window_args = (int(window_slots), int(window_timeout_ms))
 
     def _op_for(self, rows):
         """operator for a block of `rows` rows (static-M configs get one operator per block height)"""
@@ -142,8 +150,37 @@ class ColumnParallelMatmul:
             return r
         return self._op_for(A.shape[0] if A.dim() == 2 else None)(A, W, scale=scale, zeros=zeros, bias=bias, output=output)
 
+    def _forward_direct(self, A, W, scale, zeros, bias, out):
+        """one row, no collective: GEMV into the own window row, exchange, the window row is the result"""
+        from .peer import make_window
+        per = self.local_config.N
+        dtype = torch_dtype(self.full_config.out_dtype)
+        item = torch.empty((), dtype=dtype).element_size()
+        if self._window is None:
+            self._window = make_window(self.group, self.world * per * item, A.device, *self._window_args)
+        win = self._window
+        step = win.next_step()
+        row = win.row(win.slot_of(step), dtype)                     # [N]
+        own = row[self.rank * per:(self.rank + 1) * per].view(1, per)
+        self._local(A.reshape(1, A.shape[-1]), W, scale, zeros, bias, output=own)
+        win.exchange(step, self.rank * per * item, per * item)
+        res = row.view(*A.shape[:-1], self.world * per)
+        if out is not None:
+            if tuple(out.shape) != tuple(res.shape) or out.dtype != res.dtype:
+                raise ValueError(f"out must be a {tuple(res.shape)} {res.dtype} tensor")
+            out.copy_(res)
+            return out
+        return res
+
+    def check_peers(self):
+        """raise `peer.PeerTimeout` if an exchange of the direct-store path gave up waiting (synchronises on GPUs)"""
+        if self._window is not None:
+            self._window.check()
+
     def forward(self, A, W, scale=None, zeros=None, bias=None, out=None):
         rows = A.numel() // A.shape[-1]
+        if self.direct_store and rows == 1 and self.world > 1:
+            return self._forward_direct(A, W, scale, zeros, bias, out)
         blocked = A.dim() == 2 and rows > self.row_block and self.world > 1
         if not blocked:
             return gather_columns(self._local(A, W, scale, zeros, bias), self.group, out=out)

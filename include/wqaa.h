@@ -376,6 +376,35 @@ void wqaa_debug_row_blocks(int b, int grid, int n_blocks, int* out3);
  * in use) for a grid of tiles_m * tiles_n * ksplit workgroups: every tile of every k-slice is taken exactly once (test aid) */
 void wqaa_debug_tile_of_block(int tiles_m, int tiles_n, int ksplit, int group_m, int block, int* out4);
 
+/* ---- M = 1 output exchange of the column-parallel operator without a collective (bitblas_amd/parallel.py,
+ * ColumnParallelMatmul(direct_store=True); the reference has no multi-GPU path: SURVEY.md section 5) ----------------------
+ * A rank owns a WINDOW (wqaa_peer_alloc: uncached device memory; offset 0 holds `world` 32-bit flag words, the [1, N] output
+ * rows follow), exports it (64-byte hipIpc handle, exchanged by the host over torch.distributed), opens its peers' windows
+ * and, after the GEMV that wrote its [1, N/P] slice into its own window, calls wqaa_peer_exchange: ONE launch stores the
+ * slice into every peer's row at this rank's columns, posts `step` into the peer's flag word for this rank (system-scope
+ * release) and waits until every peer's post of `step` has arrived in this rank's flag words (bounded: on a timeout
+ * `*status` = 1 + the late peer, the launch ends).  Steps count up by one per exchange; a row slot may be reused once the
+ * exchange after next has been enqueued (the host alternates two slots).  Not for stream capture (step is an argument). */
+#define WQAA_PEER_MAX 16
+#define WQAA_PEER_HANDLE_BYTES 64
+typedef struct wqaa_peer_exchange_desc {
+  const void* src;                  /* this rank's slice inside its own window, 16-byte aligned */
+  size_t bytes;                     /* of the slice; a multiple of 16 */
+  int world, rank;
+  uint32_t step;
+  uint32_t timeout_ms;              /* 0: 2000 */
+  void* dst[WQAA_PEER_MAX];         /* peer p's row at this rank's columns (mapped by wqaa_peer_open); [rank] unused */
+  uint32_t* post[WQAA_PEER_MAX];    /* peer p's flag word for this rank (inside p's mapped window) */
+  const uint32_t* flags;            /* own flag words [world] */
+  uint32_t* status;                 /* own device word, zero before the first exchange */
+} wqaa_peer_exchange_desc;
+int wqaa_peer_alloc(size_t bytes, void** ptr);
+int wqaa_peer_free(void* ptr);
+int wqaa_peer_export(const void* ptr, void* handle64);
+int wqaa_peer_open(const void* handle64, void** ptr);
+int wqaa_peer_close(void* ptr);
+int wqaa_peer_exchange(const wqaa_peer_exchange_desc* desc, void* stream);
+
 /* ---- error side channel ---------------------------------------------------------------------- */
 int wqaa_last_error(void);
 const char* wqaa_last_error_string(void);

@@ -35,6 +35,22 @@ def test_struct_sizes_match_header():
     assert ctypes.sizeof(wlib.Plan) == 11 * 4 + 96
 
 
+def test_peer_exchange_descriptor_and_argument_checks():
+    """struct wqaa_peer_exchange_desc as the binding lays it out; a malformed exchange is refused before any launch"""
+    assert ctypes.sizeof(wlib.PeerExchangeDesc) == 8 + 8 + 4 * 4 + 2 * wlib.PEER_MAX * 8 + 8 + 8
+    L = wlib.load_library()
+    assert L.wqaa_peer_exchange(None, None) == wlib.ERR_BAD_DESC
+    d = wlib.PeerExchangeDesc()
+    d.world, d.rank, d.bytes, d.src, d.flags, d.status = 1, 0, 64, 256, 256, 256       # a world of one has nothing to exchange
+    assert L.wqaa_peer_exchange(ctypes.byref(d), None) == wlib.ERR_BAD_DESC
+    d.world, d.bytes = 2, 24                                                              # not whole 16-byte pieces
+    assert L.wqaa_peer_exchange(ctypes.byref(d), None) == wlib.ERR_BAD_DESC
+    d.bytes = 64                                                                          # peer 1 has no destination
+    assert L.wqaa_peer_exchange(ctypes.byref(d), None) == wlib.ERR_BAD_DESC
+    assert b"peer 1" in L.wqaa_last_error_string()
+    assert L.wqaa_peer_export(None, None) == wlib.ERR_BAD_DESC and L.wqaa_peer_open(None, None) == wlib.ERR_BAD_DESC
+
+
 def test_init_is_idempotent_and_error_channel_works():
     L = wlib.load_library()
     L.init()
@@ -163,7 +179,7 @@ def test_selector_invariants_over_a_random_configuration_sweep():
     kernel-name style (general_matmul/__init__.py:240-318) - and a refusal must carry a message."""
     import re
     rng = np.random.default_rng(7)
-    name_re = re.compile(r"^matmul_m\d+n\d+k\d+_[a-z0-9]+x[a-z0-9_]+_(gemv_b\d+r\d+d\d+(k\d+)?(_areg)?|gemvx_b\d+r\d+d\d+k\d+(_areg)?|tcx\d+x\d+x\d+(xr)?(pp|xs|xdl|xd|xw)?)$")
+    name_re = re.compile(r"^matmul_m\d+n\d+k\d+_[a-z0-9]+x[a-z0-9_]+_(gemv_b\d+r\d+d\d+(k\d+)?(_areg)?|gemvx_b\d+r\d+d\d+k\d+(_areg)?|tcx\d+x\d+x\d+(xr)?(pp(t\d+)?|xs|xdl|xd|xw)?)$")
     pairs = [(wlib.F16, wlib.W_UINT, b) for b in (1, 2, 4, 8)] + [(wlib.F16, wlib.W_INT, b) for b in (1, 2, 4, 8)] + \
             [(wlib.F16, wlib.W_NF, 4), (wlib.F16, wlib.W_FP4, 4), (wlib.F16, wlib.W_E4M3, 8),
              (wlib.BF16, wlib.W_UINT, 4), (wlib.BF16, wlib.W_NF, 4),

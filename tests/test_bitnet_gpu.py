@@ -192,4 +192,5 @@ def test_bitlinear_prefill_runs_the_ping_pong_member_with_the_epilogue(m, N, K, 
     want = oracle.bitnet_forward(x[rows], module_codes(lin), np.float32(lin.sw.item()), b)
     assert np.array_equal(got[rows].view(np.uint16), want.view(np.uint16))
     if name and m >= 2048:
-        assert name.endswith("pp"), name          # (smaller outputs: whichever tile the selector's round estimate prefers)
+        import re
+        assert re.search(r"pp(t\d+)?$", name), name    # (a partial last round's columns may go out as a second launch: "ppt<n>")

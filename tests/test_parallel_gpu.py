@@ -144,3 +144,74 @@ def test_column_parallel_group_with_real_kernels():
     if any(isinstance(v, str) and v.startswith("skip") for v in vals):
         pytest.skip(str(vals))
     assert all(v is True for v in vals), vals
+
+
+def _worker_direct_store(rank, world, port, ret):
+    """ColumnParallelMatmul(direct_store=True) with the real kernels and the hipIpc transport: two ranks on cuda:0 map each
+    other's window (csrc/wqaa_peer.hip), the M = 1 GEMV writes its slice into the own window row, ONE exchange launch per
+    step stores it into the peer's row and waits for the peer's - no collective after the set-up"""
+    for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import bitblas_amd as bitblas
+        import wqaa_oracle as oracle
+        from bitblas_amd import parallel
+        from bitblas_amd.lib import WqaaError
+        from bitblas_amd.parallel import ColumnParallelMatmul, shard_operands
+        torch.cuda.set_device(0)
+        rng = np.random.default_rng(13)
+        N, K, g, bit = 4096, 4096, 128, 4
+        codes = rng.integers(0, 16, size=(N, K)).astype(np.int8)
+        scale = (rng.random((N, K // g), dtype=np.float32) * 0.05).astype(np.float16)
+        cfg = bitblas.MatmulConfig(M=1, N=N, K=K, A_dtype="float16", W_dtype="uint4", group_size=g, with_scaling=True)
+        full = bitblas.Matmul(cfg, enable_tuning=False)
+        sh = shard_operands(rank, world, W=full.weight_transform(torch.from_numpy(codes)), bits=bit, scale=torch.from_numpy(scale))
+        Wl, Sl = sh["W"].cuda(), sh["scale"].cuda()
+        op = ColumnParallelMatmul(cfg, direct_store=True)
+        calls = []
+        real = dist.all_gather_into_tensor
+        ok = True
+        try:
+            for step in range(1, 7):
+                A = (rng.random((1, K), dtype=np.float32) - 0.5).astype(np.float16)
+                want = oracle.matmul_dequant(A, codes, source_format="uint", bit=bit, scale=scale, group_size=g)
+                try:
+                    got = op(torch.from_numpy(A).cuda(), Wl, Sl)
+                except WqaaError as e:
+                    ret[rank] = f"skip: no IPC mapping between two processes here ({e})"
+                    return
+                if step == 1:
+                    parallel.dist.all_gather_into_tensor = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+                g_ = got.float().cpu().numpy()                     # (stream-ordered read of the window row: before the next call)
+                err = np.abs(g_ - want)
+                ok = ok and tuple(got.shape) == (1, N)
+                ok = ok and bool((err <= 1e-3 * np.abs(want) + 1.5e-3 * np.sqrt(np.mean(want.astype(np.float64) ** 2))).all())
+            op.check_peers()
+        finally:
+            parallel.dist.all_gather_into_tensor = real
+        ret[rank] = (ok and not calls) or f"ok={ok} gathers={len(calls)}"
+        dist.barrier()
+        op._window.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_single_row_direct_store_through_ipc_windows():
+    world = 2
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_direct_store, args=(r, world, port, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    vals = [ret.get(r) for r in range(world)]
+    if any(isinstance(v, str) and v.startswith("skip") for v in vals):
+        pytest.skip(str(vals))
+    assert all(v is True for v in vals), vals
