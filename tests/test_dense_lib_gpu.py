@@ -159,7 +159,9 @@ def test_measured_tuning_keeps_results_and_never_a_slower_algorithm():
 
     before, ref = ms()
     op.hardware_aware_finetune()
-    assert op.plans[M]["kernel_family"] == 3
+    # (the vendor library's tuned algorithm - family 3 - or, since the partial-round tail of round 4 made this library's own
+    # member the faster one on this shape, the own member: the tuner keeps whichever it timed fastest)
+    assert op.plans[M]["kernel_family"] in (2, 3)
     after, out = ms()
     assert after <= 1.25 * before, (before, after)
     rows = np.arange(0, M, 37)
