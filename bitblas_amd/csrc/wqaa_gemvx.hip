@@ -255,8 +255,6 @@ static void gemvx_fill(const wqaa_matmul_desc& d, const GemvxChoice& c, const vo
   a.norm_weight = nullptr;
   a.norm_eps = 0.f;
   a.norm_inv_k = 1.f / (float)d.K;
-  a.nthreads = c.nw * 64;
-  a.grid_x = c.grid;         // (gemvx_dispatch overwrites it with the launch's own: a group's grid is not a member's)
 }
 
 static void gemvx_set_norm(GemvxArgs& a, const wqaa_epilogue* epi) {
@@ -266,10 +264,6 @@ static void gemvx_set_norm(GemvxArgs& a, const wqaa_epilogue* epi) {
 
 static int gemvx_dispatch(const GemvxChoice& c, GemvxGroupArgs& ga, int grid_x, int count, hipStream_t stream, hipEvent_t start,
                           hipEvent_t stop) {
-  for (int i = 0; i < count; ++i) {
-    ga.p[i].grid_x = grid_x;
-    ga.p[i].nthreads = c.nw * 64;
-  }
   void* params[] = {&ga};
   dim3 grid(grid_x, count, 1), block(c.nw * 64, 1, 1);
   hipError_t e;

@@ -61,8 +61,6 @@ struct GemvxArgs {
   const void* residual;  // PRO members (WQAA_EPI_ADD_RESIDUAL): (m, N) float16 added to the float16 result; NULL: none
   const void* norm_weight;   // NORM members (WQAA_EPI_RMSNORM_INPUT): (K,) float16 weight of the RMSNorm in front of the operator
   float norm_eps, norm_inv_k;
-  int nthreads, grid_x;      // the launch's own blockDim.x / gridDim.x: in the argument block they arrive with the first scalar
-                             // batch (the implicit arguments sit 1.2 KB further on: a second round trip in front of the weight loads)
 };
 
 // One launch serves up to kGemvxGroupMax INDEPENDENT operators of one tile configuration (wqaa_matmul_group: the q/k/v
@@ -147,7 +145,7 @@ __global__ void __launch_bounds__(1024) wq_gemvx_kernel(const GemvxGroupArgs grp
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int nthreads = a.nthreads;
+  const int nthreads = blockDim.x;
   const int NW = nthreads >> 6;
   unsigned long long tr_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   auto stamp = [&](int i) {
@@ -157,7 +155,7 @@ __global__ void __launch_bounds__(1024) wq_gemvx_kernel(const GemvxGroupArgs grp
     if constexpr ((P::ABL & 64) != 0) {
       if (lane == 0 && a.bias) {
         unsigned long long* dst = reinterpret_cast<unsigned long long*>(const_cast<void*>(a.bias)) +
-                                  (((long)blockIdx.y * a.grid_x + blockIdx.x) * NW + wave) * 8;
+                                  (((long)blockIdx.y * gridDim.x + blockIdx.x) * NW + wave) * 8;
 #pragma unroll
         for (int i = 0; i < 8; ++i) dst[i] = tr_[i];
       }
@@ -169,7 +167,7 @@ __global__ void __launch_bounds__(1024) wq_gemvx_kernel(const GemvxGroupArgs grp
   // them where first used, three dependent s_load waits before the weight loads), and keep integer divisions out of
   // it (the host passes slots and a reciprocal of kw).
   asm volatile("" ::"s"(a.A), "s"(a.B), "s"(a.scale), "s"(a.zeros), "s"(a.N), "s"(a.K), "s"(a.kg), "s"(a.gq_shift), "s"(a.cpr),
-               "s"(a.nsteps), "s"(a.kw), "s"(a.row_bytes), "s"(a.n_rgb), "s"(a.slots), "s"(a.kw_magic), "s"(a.m), "s"(a.nthreads), "s"(a.grid_x));
+               "s"(a.nsteps), "s"(a.kw), "s"(a.row_bytes), "s"(a.n_rgb), "s"(a.slots), "s"(a.kw_magic), "s"(a.m));
   if constexpr (P::PAIR) asm volatile("" ::"s"(grp.p[1].B), "s"(grp.p[1].scale), "s"(grp.p[1].zeros));
   if constexpr (P::NORM) asm volatile("" ::"s"(a.norm_weight), "s"(a.norm_eps), "s"(a.norm_inv_k));
   if constexpr (P::PRO) asm volatile("" ::"s"(a.residual));
@@ -205,7 +203,7 @@ __global__ void __launch_bounds__(1024) wq_gemvx_kernel(const GemvxGroupArgs grp
 
   // this workgroup's row-group blocks rb.first, rb.first + rb.stride, ... < rb.end (XCD-aware, wqaa_kinds.h; many small
   // workgroups and the hardware dispatcher balance better than one persistent workgroup per CU: measured)
-  const RowBlocks rb = xcd_row_blocks((int)blockIdx.x, a.grid_x, a.n_rgb);
+  const RowBlocks rb = xcd_row_blocks((int)blockIdx.x, (int)gridDim.x, a.n_rgb);
   if (rb.first >= rb.end) return;                              // grid padding / a shorter operator of a group: nothing to load
   int iters = 1;                                               // uniform over the workgroup; the usual case: one block, no division
   if (rb.first + rb.stride < rb.end) iters = (rb.end - rb.first + rb.stride - 1) / rb.stride;
@@ -302,9 +300,8 @@ __global__ void __launch_bounds__(1024) wq_gemvx_kernel(const GemvxGroupArgs grp
   if constexpr (!(P::ABL & 2) && !P::AREG) {
 #pragma unroll
     for (int j = 0; j < NAI; ++j) {
-      avalid[j] = false;
-      if (j * nthreads < items) {                  // wave-uniform: whole rounds beyond the tile are skipped, their index math too
-        const u32x4* src = item_src(j * nthreads + tid, avalid[j]);
+      const u32x4* src = item_src(j * nthreads + tid, avalid[j]);
+      if (j * nthreads < items) {                  // wave-uniform: whole rounds beyond the tile are skipped
 #pragma unroll
         for (int v = 0; v < IVW; ++v) araw[j][v] = src[v];
         if constexpr (P::NORM) {

@@ -147,8 +147,6 @@ int main(int argc, char** argv) {
     a.n_rgb = ((N + R - 1) / R + slots - 1) / slots;
     a.slots = slots;
     a.kw_magic = (65536u + (uint32_t)kw - 1u) / (uint32_t)kw;
-    a.nthreads = nw * 64;
-    a.grid_x = count == 1 ? plan.grid : plan.grid / count;
   };
   const int gx = count == 1 ? plan.grid : plan.grid / count;
   gemvx_fn fn_plain = R == 2 ? wq_gemvx_kernel<GemvxPolicy<4, LAYOUT_LOP3, MD_S, 1, 2, 2>> : wq_gemvx_kernel<GemvxPolicy<4, LAYOUT_LOP3, MD_S, 1, 1, 2>>;
@@ -186,7 +184,6 @@ int main(int argc, char** argv) {
       if (pair) {               // a row group is ONE output element: N pairs
         const int slots = nw / kw;
         ga.p[i].n_rgb = (N + slots - 1) / slots;
-        ga.p[i].grid_x = 2 * gx;
       }
     }
     void* params[] = {&ga};
