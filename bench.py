@@ -1019,6 +1019,9 @@ def main():
                 if t is None and isinstance(v.get("fused"), dict):
                     return {"fused_us": round(v["fused"]["us_per_step"], 1), "composed_us": round(v["composed"]["us_per_step"], 1),
                             "frac": round(v["fused"]["frac"], 3)}
+                if t is None and isinstance(v.get("chain"), dict) and isinstance(v.get("launches"), dict):
+                    return {"launches_us_per_tail": round(v["launches"]["us_per_tail"], 2), "chain_us_per_tail": round(v["chain"]["us_per_tail"], 2),
+                            "bit_identical": v.get("bit_identical"), "frac": round(v["launches"]["frac"], 3)}
                 if t is None and "own_us_per_launch" in v:
                     return {"own_f16_us": round(v["own_us_per_launch"], 2), "vendor_f16_us": round(v["vendor_us_per_launch"], 2),
                             "int4_speedup_vs_vendor_f16": round(v.get("int4_speedup_vs_vendor_f16") or 0.0, 2)}
