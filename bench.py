@@ -474,6 +474,8 @@ def time_member_dense(device, gen, M, N, K, kind="fp8", n_buf=4, vendor=False, t
         if kind == "fp8":
             cfg = bitblas.MatmulConfig(M=M, N=N, K=K, A_dtype="e4m3_float8", W_dtype="e4m3_float8", accum_dtype="float32",
                                        out_dtype="float16")
+        elif kind == "f16":
+            cfg = bitblas.MatmulConfig(M=M, N=N, K=K, A_dtype="float16", W_dtype="float16", accum_dtype="float32", out_dtype="float16")
         else:
             cfg = bitblas.MatmulConfig(M=M, N=N, K=K, A_dtype="int8", W_dtype="int2", accum_dtype="int32", out_dtype="int32")
         op = bitblas.Matmul(cfg, enable_tuning=False)
@@ -495,6 +497,11 @@ def _time_member_dense(device, gen, op, M, N, K, kind, n_buf):
         Ws = [(torch.rand((N, K), device=device, generator=gen) * 2 - 1).to(torch.float8_e4m3fn) for _ in range(n_buf)]
         out = torch.empty((M, N), dtype=torch.float16, device=device)
         wbytes = N * K
+    elif kind == "f16":
+        A = (torch.rand((M, K), device=device, generator=gen) - 0.5).to(torch.float16)
+        Ws = [(torch.rand((N, K), device=device, generator=gen) - 0.5).to(torch.float16) for _ in range(n_buf)]
+        out = torch.empty((M, N), dtype=torch.float16, device=device)
+        wbytes = N * K * 2
     else:
         A = torch.randint(-128, 128, (M, K), device=device, dtype=torch.int8, generator=gen)
         Ws = [torch.randint(-128, 128, (N, K // 4), dtype=torch.int8, device=device, generator=gen) for _ in range(n_buf)]
@@ -507,7 +514,8 @@ def _time_member_dense(device, gen, op, M, N, K, kind, n_buf):
             op.lib.run(A.data_ptr(), W.data_ptr(), None, None, None, None, out.data_ptr(), M, stream)
 
     t = graph_time(device, launch_all, n_buf)
-    res = {"workload": f"{'e4m3 x e4m3' if kind == 'fp8' else 'W_int2 A_int8'} M={M} N={N} K={K}",
+    peak = MFMA_F16_PEAK_TF if kind == "f16" else MFMA_I8_PEAK_TOPS
+    res = {"workload": f"{'e4m3 x e4m3' if kind == 'fp8' else 'float16 x float16' if kind == 'f16' else 'W_int2 A_int8'} M={M} N={N} K={K}",
            "kernel": op.plans[M]["name"], "us_per_launch": t * 1e6}
     if M == 1:
         nbytes = M * K + wbytes + M * N * out.element_size()
@@ -516,8 +524,8 @@ def _time_member_dense(device, gen, op, M, N, K, kind, n_buf):
                              "frac": nbytes / t / 1e9 / HBM_PEAK_GBS})
     else:
         tf = 2.0 * M * N * K / t / 1e12
-        res.update(TFLOPs=tf, frac_of_mfma_peak=tf / MFMA_I8_PEAK_TOPS, mfma_peak=MFMA_I8_PEAK_TOPS,
-                   roofline={"bound": "mfma", "achieved": tf, "peak": MFMA_I8_PEAK_TOPS, "unit": "TFLOP/s", "frac": tf / MFMA_I8_PEAK_TOPS,
+        res.update(TFLOPs=tf, frac_of_mfma_peak=tf / peak, mfma_peak=peak,
+                   roofline={"bound": "mfma", "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak,
                              "flops_per_launch": 2.0 * M * N * K})
     return res
 
@@ -960,6 +968,10 @@ def main():
             member("gemm_uint4_m16", time_member_gemm, device, gen, 16)
             member("gemm_int2_int8_m4096", time_member_gemm, device, gen, 4096, W_dtype="int2", A_dtype="int8")
             member("gemm_int2_int8_m4096_bitnet", time_member_gemm, device, gen, 4096, W_dtype="int2", A_dtype="int8", bitnet=True)
+            # the reference's plain matmul (float16 x float16, README.md support matrix): this library's dense member on the ping-pong
+            # skeleton (round 4) and, as a yardstick, the vendor library on the same operands
+            member("gemm_f16_dense_m4096", time_member_dense, device, gen, 4096, 4096, 4096, kind="f16", n_buf=4)
+            member("gemm_f16_dense_m4096_vendor", time_member_dense, device, gen, 4096, 4096, 4096, kind="f16", n_buf=4, vendor=True, tuned=True)
             member("gemv_int2_int8_m1", time_member_dense, device, gen, 1, 4096, 4096, kind="int2", n_buf=64)
             member("step_chained", time_step_chained, device, gen)
             member("chain_tail", time_chain_tail, device, gen)

@@ -177,7 +177,8 @@ static int gemm_choose(const wqaa_matmul_desc& d, int m, GemmChoice* c, bool fus
   c->pp_bm = 0;
   if (m > 128 && d.N >= 128) {
     const char* pf = getenv("WQAA_GEMM_PP");
-    const int kb = c->at == AT_F16 ? 256 : c->at == AT_F8 ? 128 : 512;   // k per trip of the main loop
+    const bool dense16 = c->kind == DK_NATIVE && c->at == AT_F16;        // float16 / bfloat16 x the same type: the dense fp8 skeleton on 16-bit lines
+    const int kb = dense16 ? 64 : c->at == AT_F16 ? 256 : c->at == AT_F8 ? 128 : 512;   // k per trip of the main loop
     const int gb = c->at == AT_F8 ? 1 : g / (kb / 2);                   // k-bodies (two k-tiles) per group
     // (packed integer zero points - GPTQ checkpoints: a wave fetches the 16 bytes of its 32 rows per group, so N in whole waves)
     // (one group per row - per-channel scales, the reference's default group_size = -1 - is the one odd K / g the members take:
@@ -189,6 +190,7 @@ static int gemm_choose(const wqaa_matmul_desc& d, int m, GemmChoice* c, bool fus
     const bool epi_ok = !fused_epilogue || (c->at == AT_I8 && d.out_dtype == WQAA_F16 && d.a_dtype == WQAA_I8);
     const bool out_ok = c->at == AT_I8 ? (fused_epilogue ? d.out_dtype == WQAA_F16 : d.out_dtype == WQAA_I32)
                         : c->at == AT_F8 ? d.out_dtype == WQAA_F16
+                        : dense16 ? (!d.with_bias && d.out_dtype == ((c->flags & FL_BF16) ? WQAA_BF16 : WQAA_F16))      // (its output pass: 2-byte elements, no bias)
                         : (d.out_dtype == WQAA_F32 || d.out_dtype == ((c->flags & FL_BF16) ? WQAA_BF16 : WQAA_F16));
     const long a_bytes = (long)m * d.K * (c->at == AT_F16 ? 2 : 1), w_bytes = (long)d.N * d.K * c->bits / 8;
     const bool shape_ok = epi_ok && d.K % kb == 0 && meta_ok && out_ok && d.N % 8 == 0 && a_bytes + 256L * d.K * 2 < (1L << 31) &&

@@ -70,6 +70,17 @@ gemm_fn pick_gemm_pp(int kind, int layout, int at, int mode, int flags, int bm, 
     }
     return fn;
   }
+  if (at == AT_F16 && kind == DK_NATIVE && mode == MD_NONE && (flags & ~(int)FL_BF16) == 0) {   // dense float16 / bfloat16 x the same type
+    const bool bf = (flags & FL_BF16) != 0;
+    if (bm == 256) {
+      fn = bf ? wq_gemm_pp8_kernel<PP8Policy<3, 3>> : wq_gemm_pp8_kernel<PP8Policy<2, 2>>;
+      *lds_bytes = PP8Policy<2, 2>::LDS_BYTES;
+    } else {
+      fn = bf ? wq_gemm_pp8_kernel<PP8Policy<3, 3, 0, 128>> : wq_gemm_pp8_kernel<PP8Policy<2, 2, 0, 128>>;
+      *lds_bytes = PP8Policy<2, 2, 0, 128>::LDS_BYTES;
+    }
+    return fn;
+  }
   if (flags == (int)FL_BF16 && at == AT_F16 && kind == DK_LUT4 && layout == LAYOUT_PLAIN && (mode == MD_NONE || mode == MD_S)) {   // bfloat16 x nf4 / fp4
     if (mode == MD_NONE) {
       fn = bm == 256 ? wq_gemm_pp_kernel<PPPolicy<DK_LUT4, LAYOUT_PLAIN, AT_F16, MD_NONE, FL_BF16, 3, 0, 256>>

@@ -827,10 +827,17 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_pp_kernel(const GemmArgs a
 // BM_ = 128: the same loop on half the activation rows (two phases per k-tile) for shapes whose 256-row tiles leave the chip
 // short of whole rounds - the N / 8 column shards of BASELINE c5 first of all (4096 x 1024 x 8192 is 64 tiles of 256 x 256).
 // A k-tile then lasts half as long: activation ring of 4 (16 KiB slots), weight ring of 3 per wave, asked for three tiles ahead.
+// WFMT_ / AFMT_ 2, 3 (round 4): dense float16 / bfloat16 x the same type - W "stored in A_dtype" (the reference's plain matmul,
+// tilelang/dense/matmul_mma.py, and the second pass of the two-pass member: B_decode, then this).  Same skeleton, same bytes per
+// k-tile (64 k = one 128-byte line of every row of both operands); a fragment pair is two v_mfma_f32_16x16x32_f16 / _bf16
+// (granule kb = k [8 kb, +8) of the tile's first 32, granule 4 + kb the same of its second 32: ascending k, the order of the
+// fused members).
 template <int WFMT_, int AFMT_, int OPT_ = 0, int BM_ = 256>
 struct PP8Policy {
-  static constexpr int WFMT = WFMT_, AFMT = AFMT_, OPT = OPT_;   // 0 e4m3, 1 e5m2
-  static constexpr int BM = BM_, BN = 256, THREADS = 512, KT = 128, TILE_ROW = 128;
+  static constexpr int WFMT = WFMT_, AFMT = AFMT_, OPT = OPT_;   // 0 e4m3, 1 e5m2; 2 float16, 3 bfloat16 (both operands)
+  static constexpr int ESZ = WFMT_ >= 2 ? 2 : 1;                 // bytes per element
+  static_assert(WFMT_ < 2 || WFMT_ == AFMT_, "the 16-bit members take one type for both operands");
+  static constexpr int BM = BM_, BN = 256, THREADS = 512, KT = 128 / ESZ, TILE_ROW = 128;
   static constexpr int RING = BM_ == 128 ? 4 : 3, D = RING - 1;
   static constexpr int WS = BM_ == 128 ? 3 : 2;      // weight k-tile slots per wave (4 KiB each)
   static constexpr int NPH = BM_ / 64;               // phases (8 MFMAs per wave each) per k-tile
@@ -861,29 +868,30 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_pp8_kernel(const GemmArgs 
   const int tile_m = tob.tile_m, tile_n = tob.tile_n;
   const int m0 = tile_m * P::BM, n0 = (tile_n + a.tile_n_off) * P::BN, nw0 = n0 + wave * 32;
   const int ntiles = a.K / P::KT;
+  const uint32_t rowb = (uint32_t)a.K * (uint32_t)P::ESZ;     // bytes per row of either operand
 
-  const auto a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.A), 0, (int)((long)a.M * a.K), 0x00020000);
-  const auto w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.B), 0, (int)((long)a.N * a.K), 0x00020000);
+  const auto a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.A), 0, (int)((long)a.M * rowb), 0x00020000);
+  const auto w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.B), 0, (int)((long)a.N * rowb), 0x00020000);
   // piece j of either operand: 8 rows x one 128-byte line; rows beyond the matrix are out of the buffer's range (read as zero)
   const int g0_ = (lane & 7) ^ ((lane >> 4) & 7);
-  const uint32_t v0 = (uint32_t)(wave * 32 + (lane >> 3)) * (uint32_t)a.K + (uint32_t)(g0_ * 16);         // the wave's weight rows
-  const uint32_t v0a = (uint32_t)(wave * WROWS + (lane >> 3)) * (uint32_t)a.K + (uint32_t)(g0_ * 16);     // ... and its share of the activation rows
+  const uint32_t v0 = (uint32_t)(wave * 32 + (lane >> 3)) * rowb + (uint32_t)(g0_ * 16);         // the wave's weight rows
+  const uint32_t v0a = (uint32_t)(wave * WROWS + (lane >> 3)) * rowb + (uint32_t)(g0_ * 16);     // ... and its share of the activation rows
   const int vd = ((g0_ ^ 4) - g0_) * 16;
-  const uint32_t a_rows0 = (uint32_t)m0 * (uint32_t)a.K, w_rows0 = (uint32_t)n0 * (uint32_t)a.K;
+  const uint32_t a_rows0 = (uint32_t)m0 * rowb, w_rows0 = (uint32_t)n0 * rowb;
 
   unsigned char* const a_ring = smem;
   unsigned char* const w_ring = smem + P::W_OFF + wave * (WS * 4096);
   auto dma_a = [&](int tt, int slot, int j) {
     const int tc = tt < ntiles ? tt : ntiles - 1;
     unsigned char* dst = a_ring + slot * P::A_SLOT + (wave * WROWS + j * 8) * P::TILE_ROW;
-    const uint32_t rows = a_rows0 + (uint32_t)(j * 8) * (uint32_t)a.K;
+    const uint32_t rows = a_rows0 + (uint32_t)(j * 8) * rowb;
     const uint32_t voff = (j & 1) ? v0a + (uint32_t)vd + rows : v0a + rows;
     __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (lds_ptr_t)dst, 16, voff, tc * P::TILE_ROW, 0, 0);
   };
   auto dma_w = [&](int tt, int j, int ws) {          // piece j of the wave's 32 weight rows of k-tile tt -> weight slot ws
     const int tc = tt < ntiles ? tt : ntiles - 1;
     unsigned char* dst = w_ring + ws * 4096 + j * 1024;
-    const uint32_t rows = w_rows0 + (uint32_t)(j * 8) * (uint32_t)a.K;
+    const uint32_t rows = w_rows0 + (uint32_t)(j * 8) * rowb;
     const uint32_t voff = (j & 1) ? v0 + (uint32_t)vd + rows : v0 + rows;
     __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_ptr_t)dst, 16, voff, tc * P::TILE_ROW, 0, 0);
   };
@@ -970,15 +978,32 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_pp8_kernel(const GemmArgs 
   };
   auto compute_segment = [&](auto PH, int t) {
     constexpr int p = decltype(PH)::value;
+    if constexpr (P::ESZ == 2) {
+      // 16-bit operands: the tile's two 32-deep halves, in ascending k
 #pragma unroll
-    for (int f = 0; f < 4; ++f) {
-      const i32x8 av = {(int)afrag[f][0][0], (int)afrag[f][0][1], (int)afrag[f][0][2], (int)afrag[f][0][3],
-                        (int)afrag[f][1][0], (int)afrag[f][1][1], (int)afrag[f][1][2], (int)afrag[f][1][3]};
+      for (int f = 0; f < 4; ++f)
 #pragma unroll
-      for (int nf = 0; nf < 2; ++nf) {
-        const i32x8 wv = {(int)wfrag[nf][0][0], (int)wfrag[nf][0][1], (int)wfrag[nf][0][2], (int)wfrag[nf][0][3],
-                          (int)wfrag[nf][1][0], (int)wfrag[nf][1][1], (int)wfrag[nf][1][2], (int)wfrag[nf][1][3]};
-        acc[p * 4 + f][nf] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wv, av, acc[p * 4 + f][nf], P::WFMT, P::AFMT, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+        for (int nf = 0; nf < 2; ++nf)
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            if constexpr (P::WFMT == 3)
+              acc[p * 4 + f][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wfrag[nf][i]), __builtin_bit_cast(bf16x8_t, afrag[f][i]),
+                                                                          acc[p * 4 + f][nf], 0, 0, 0);
+            else
+              acc[p * 4 + f][nf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8_t, wfrag[nf][i]), __builtin_bit_cast(half8_t, afrag[f][i]),
+                                                                         acc[p * 4 + f][nf], 0, 0, 0);
+          }
+    } else {
+#pragma unroll
+      for (int f = 0; f < 4; ++f) {
+        const i32x8 av = {(int)afrag[f][0][0], (int)afrag[f][0][1], (int)afrag[f][0][2], (int)afrag[f][0][3],
+                          (int)afrag[f][1][0], (int)afrag[f][1][1], (int)afrag[f][1][2], (int)afrag[f][1][3]};
+#pragma unroll
+        for (int nf = 0; nf < 2; ++nf) {
+          const i32x8 wv = {(int)wfrag[nf][0][0], (int)wfrag[nf][0][1], (int)wfrag[nf][0][2], (int)wfrag[nf][0][3],
+                            (int)wfrag[nf][1][0], (int)wfrag[nf][1][1], (int)wfrag[nf][1][2], (int)wfrag[nf][1][3]};
+          acc[p * 4 + f][nf] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wv, av, acc[p * 4 + f][nf], P::WFMT, P::AFMT, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+        }
       }
     }
     PP_BARRIER();
@@ -1009,10 +1034,21 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_pp8_kernel(const GemmArgs 
     const int m = f * 16 + e_fr;
 #pragma unroll
     for (int nf = 0; nf < 2; ++nf) {
-      const half2_t lo = {(half_t)acc[f][nf][0], (half_t)acc[f][nf][1]}, hi = {(half_t)acc[f][nf][2], (half_t)acc[f][nf][3]};
+      uint32_t lo_u, hi_u;
+      if constexpr (P::WFMT == 3) {         // bfloat16 out: round to nearest even (bf16_round), packed pairs
+        float x[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) x[i] = bf16_round(acc[f][nf][i]);
+        lo_u = (__builtin_bit_cast(uint32_t, x[0]) >> 16) | (__builtin_bit_cast(uint32_t, x[1]) & 0xFFFF0000u);
+        hi_u = (__builtin_bit_cast(uint32_t, x[2]) >> 16) | (__builtin_bit_cast(uint32_t, x[3]) & 0xFFFF0000u);
+      } else {
+        const half2_t lo = {(half_t)acc[f][nf][0], (half_t)acc[f][nf][1]}, hi = {(half_t)acc[f][nf][2], (half_t)acc[f][nf][3]};
+        lo_u = as_u32(lo);
+        hi_u = as_u32(hi);
+      }
       const int u = wave * 8 + nf * 4 + e_kb;
       const int up = (((u >> 1) ^ (m & 7)) << 1) | ((u & 1) ^ ((m >> 3) & 1));
-      *reinterpret_cast<u32x2*>(smem + m * 512 + up * 8) = u32x2{as_u32(lo), as_u32(hi)};
+      *reinterpret_cast<u32x2*>(smem + m * 512 + up * 8) = u32x2{lo_u, hi_u};
     }
   }
   PP_FENCE();

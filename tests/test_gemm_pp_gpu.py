@@ -152,6 +152,30 @@ def test_dense_fp8_pairings_ragged(a_dt, w_dt, M, N, K, pin_the_tile):
     assert_fp_parity(out.float().cpu().numpy(), want.astype(np.float16).astype(np.float32), rtol=1e-3, atol_frac=1e-4)
 
 
+@pytest.mark.parametrize("dt", ["float16", "bfloat16"])
+@pytest.mark.parametrize("M,N,K", [(300, 520, 512), (256, 256, 64), (513, 264, 1152)])
+def test_dense_16bit_pairs_ragged(dt, M, N, K, pin_the_tile):
+    """the reference's plain matmul (W_dtype == A_dtype, float16 / bfloat16: README.md support matrix, first rows;
+    tilelang/dense/matmul_mma.py) on the dense skeleton with 16-bit lines (round 4) - also the second pass of the two-pass member:
+    every element against the oracle, ragged M / N, one k-tile, both tiles"""
+    import bitblas_amd as bitblas
+    import wqaa_oracle as oracle
+    tdt = {"float16": torch.float16, "bfloat16": torch.bfloat16}[dt]
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(M + K)
+    A = (torch.rand((M, K), device="cuda", generator=gen) - 0.5).to(tdt)
+    W = (torch.rand((N, K), device="cuda", generator=gen) - 0.5).to(tdt)
+    mm = bitblas.Matmul(bitblas.MatmulConfig(M=M, N=N, K=K, A_dtype=dt, W_dtype=dt, accum_dtype="float32", out_dtype=dt), enable_tuning=False)
+    assert mm.plans[M]["name"].endswith("pp") and f"_tcx{pin_the_tile}x256x64" in mm.plans[M]["name"], mm.plans[M]["name"]
+    out = mm(A, W)
+    torch.cuda.synchronize()
+    want = oracle.matmul_dense(A.float().cpu().numpy(), W.float().cpu().numpy(), a_dtype=dt, w_dtype=dt, out_dtype="float32")
+    if dt == "bfloat16":
+        assert_fp_parity(out.float().cpu().numpy(), want, rtol=8e-3, atol_frac=8e-3)       # the bfloat16 result itself is rounded to 2^-8 relative
+    else:
+        assert_fp_parity(out.float().cpu().numpy(), want.astype(np.float16).astype(np.float32), rtol=1e-3, atol_frac=1e-4)
+
+
 @pytest.mark.parametrize("a_dt,w_dt", [("e4m3_float8", "e4m3_float8"), ("e5m2_float8", "e4m3_float8"), ("e4m3_float8", "e5m2_float8"),
                                        ("e5m2_float8", "e5m2_float8")])
 @pytest.mark.parametrize("M,N,K", [(300, 520, 512), (129, 128, 128), (513, 264, 1152), (1000, 136, 2048)])
