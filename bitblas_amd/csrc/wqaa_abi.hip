@@ -245,7 +245,8 @@ static int matmul_impl(const wqaa_matmul_desc* desc, const void* A, const void* 
       return st;
     }
     // the tuned two-pass member (desc.two_pass_min_m): B_decode to a scratch, then the plain GEMM through the library
-    if (desc->two_pass_min_m > 0 || two_pass_forced()) {
+    // (m >= 256: the automatic form - own B_decode + own dense member where the fused member is still a lockstep one)
+    if (desc->two_pass_min_m > 0 || two_pass_forced() || m >= 256) {
       static thread_local ChoiceMemo<int> tp_memo;
       bool tp;
       if (const int* hit = tp_memo.find(*desc, m, 5)) {

@@ -620,17 +620,39 @@ static bool two_pass_dense_desc(const wqaa_matmul_desc& d, wqaa_matmul_desc* dd)
   return true;
 }
 
+// Round 4 - the second pass without the vendor library: this library's own dense 16-bit ping-pong member (PP8Policy<2, 2> / <3, 3>).
+// AUTOMATIC for the formats whose fused large-M member is still the lockstep one (float16 / bfloat16 activations x int8, e4m3,
+// 2-bit, 1-bit weights ...): B_decode (HBM-bound, ~11 us at 4096^2) + the dense member beats the lockstep fused member from
+// ~1024 rows on (profiles/r04_ab_two_pass_own.txt).  Never where a fused ping-pong member exists (it wins: DESIGN.md 3.2a').
+// WQAA_TWO_PASS_AUTO=0: off; =n: from n rows on.
+static bool own_dense_second_pass(const wqaa_matmul_desc& dd, int m) {
+  if (dd.a_dtype != WQAA_F16 && dd.a_dtype != WQAA_BF16) return false;
+  GemmChoice c;
+  return gemm_choose(dd, m, &c) == WQAA_OK && c.pp;
+}
+
+static bool two_pass_auto(const wqaa_matmul_desc& d, const wqaa_matmul_desc& dd, int m) {
+  int auto_m = 1024;
+  if (const char* f = getenv("WQAA_TWO_PASS_AUTO")) auto_m = atoi(f);          // (plan time: the callers memoise the verdict)
+  if (auto_m <= 0 || m < auto_m) return false;
+  if (d.K % 128 != 0 || !own_dense_second_pass(dd, m)) return false;
+  GemmChoice c;
+  return !(gemm_choose(d, m, &c) == WQAA_OK && c.pp);
+}
+
 bool gemm_two_pass_eligible(const wqaa_matmul_desc& d, int m) {
   int min_m = d.two_pass_min_m;
   if (const char* f = getenv("WQAA_TWO_PASS")) min_m = atoi(f);      // A/B aid (plan-time): 0 never, n > 0 from n rows on
-  if (min_m <= 0 || m < min_m || m < 16) return false;
+  if (getenv("WQAA_TWO_PASS") != nullptr && min_m <= 0) return false;
   wqaa_matmul_desc dd;
-  if (!two_pass_dense_desc(d, &dd)) return false;
+  if (m < 16 || !two_pass_dense_desc(d, &dd)) return false;
   GemmChoice c;
   GemmArgs a;
   gemm_fn fn = nullptr;
   if (dequant_setup(d, &c, &a, &fn, nullptr, nullptr, nullptr, nullptr) != WQAA_OK) return false;
-  return dense_lib_eligible(dd, m, true);
+  const bool asked = min_m > 0 && m >= min_m;
+  if (asked && (dense_lib_eligible(dd, m, true) || own_dense_second_pass(dd, m))) return true;
+  return two_pass_auto(d, dd, m);
 }
 
 // the vendor GEMM of the second pass, tuned (dense_lib_tune) - independent of two_pass_min_m, which the caller sets afterwards
@@ -648,7 +670,7 @@ static size_t two_pass_scratch(const wqaa_matmul_desc& d) {
 size_t gemm_two_pass_workspace_bytes(const wqaa_matmul_desc& d, int m) {
   wqaa_matmul_desc dd;
   if (!two_pass_dense_desc(d, &dd)) return 0;
-  return two_pass_scratch(d) + dense_lib_workspace_bytes(dd, m);
+  return two_pass_scratch(d) + (dense_lib_eligible(dd, m, true) ? dense_lib_workspace_bytes(dd, m) : 0);
 }
 
 int gemm_two_pass_plan(const wqaa_matmul_desc& d, int m, wqaa_plan* plan) {
@@ -657,12 +679,21 @@ int gemm_two_pass_plan(const wqaa_matmul_desc& d, int m, wqaa_plan* plan) {
     set_error(WQAA_ERR_UNSUPPORTED, "two-pass member: not defined for this configuration");
     return WQAA_ERR_UNSUPPORTED;
   }
-  int st = dense_lib_plan(dd, m, plan);
+  const bool vendor = dense_lib_eligible(dd, m, true);
+  int st = vendor ? dense_lib_plan(dd, m, plan) : gemm_plan(dd, m, plan);
   if (st == WQAA_OK && plan) {
     plan->kernel_family = 4;
     char wd[24];
     short_wdtype(d, wd, sizeof(wd));
-    snprintf(plan->name, sizeof(plan->name), "matmul_m%dn%dk%d_%sx%s_dq_hipblaslt", m, d.N, d.K, short_dtype(d.a_dtype), wd);
+    if (vendor) {
+      snprintf(plan->name, sizeof(plan->name), "matmul_m%dn%dk%d_%sx%s_dq_hipblaslt", m, d.N, d.K, short_dtype(d.a_dtype), wd);
+    } else {
+      // "..._dq_tcx256x256x64pp": B_decode, then the dense member of that tile
+      char tile[48];
+      const char* t = strstr(plan->name, "_tcx");
+      snprintf(tile, sizeof(tile), "%s", t ? t + 1 : "own");
+      snprintf(plan->name, sizeof(plan->name), "matmul_m%dn%dk%d_%sx%s_dq_%s", m, d.N, d.K, short_dtype(d.a_dtype), wd, tile);
+    }
   }
   return st;
 }
@@ -674,8 +705,9 @@ int gemm_two_pass_launch(const wqaa_matmul_desc& d, const void* A, const void* B
     set_error(WQAA_ERR_UNSUPPORTED, "two-pass member: not defined for this configuration");
     return WQAA_ERR_UNSUPPORTED;
   }
+  const bool vendor = dense_lib_eligible(dd, m, true);
   const size_t scratch = two_pass_scratch(d);
-  const size_t need = scratch + dense_lib_workspace_bytes(dd, m);
+  const size_t need = scratch + (vendor ? dense_lib_workspace_bytes(dd, m) : 0);
   uint8_t* ws = nullptr;
   if (opts && opts->workspace) {
     if (opts->workspace_bytes < need || (reinterpret_cast<uintptr_t>(opts->workspace) & 15)) {
@@ -690,6 +722,7 @@ int gemm_two_pass_launch(const wqaa_matmul_desc& d, const void* A, const void* B
   }
   int st = gemm_dequantize_launch(d, B, LUT, Scale, Zeros, ws, stream);
   if (st != WQAA_OK) return st;
+  if (!vendor) return gemm_launch(dd, A, ws, nullptr, nullptr, nullptr, nullptr, C, m, stream, nullptr, nullptr, nullptr, nullptr);
   wqaa_call_opts sub;
   memset(&sub, 0, sizeof(sub));
   sub.struct_size = (int32_t)sizeof(sub);

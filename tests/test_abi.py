@@ -179,7 +179,7 @@ def test_selector_invariants_over_a_random_configuration_sweep():
     kernel-name style (general_matmul/__init__.py:240-318) - and a refusal must carry a message."""
     import re
     rng = np.random.default_rng(7)
-    name_re = re.compile(r"^matmul_m\d+n\d+k\d+_[a-z0-9]+x[a-z0-9_]+_(gemv_b\d+r\d+d\d+(k\d+)?(_areg)?|gemvx_b\d+r\d+d\d+k\d+(_areg)?|tcx\d+x\d+x\d+(xr)?(pp(t\d+)?|xs|xdl|xd|xw)?)$")
+    name_re = re.compile(r"^matmul_m\d+n\d+k\d+_[a-z0-9]+x[a-z0-9_]+_(gemv_b\d+r\d+d\d+(k\d+)?(_areg)?|gemvx_b\d+r\d+d\d+k\d+(_areg)?|(dq_)?tcx\d+x\d+x\d+(xr)?(pp(t\d+)?|xs|xdl|xd|xw)?)$")
     pairs = [(wlib.F16, wlib.W_UINT, b) for b in (1, 2, 4, 8)] + [(wlib.F16, wlib.W_INT, b) for b in (1, 2, 4, 8)] + \
             [(wlib.F16, wlib.W_NF, 4), (wlib.F16, wlib.W_FP4, 4), (wlib.F16, wlib.W_E4M3, 8),
              (wlib.BF16, wlib.W_UINT, 4), (wlib.BF16, wlib.W_NF, 4),
@@ -210,7 +210,7 @@ def test_selector_invariants_over_a_random_configuration_sweep():
             continue
         ok += 1
         ctx = (N, K, M, a, wf, bits, g, scaling, zmode, layout, p)
-        assert p["kernel_family"] in (1, 2), ctx
+        assert p["kernel_family"] in (1, 2, 4), ctx           # (4: B_decode + this library's dense member, round 4's automatic two-pass form)
         assert p["threads"] % 64 == 0 and 64 <= p["threads"] <= 1024, ctx
         assert 0 <= p["lds_bytes"] <= 160 * 1024, ctx
         assert p["grid"] >= 1, ctx
@@ -291,12 +291,14 @@ def test_tune_and_dequantize_entries_without_a_device():
     if L.wqaa_device_count() == 0:
         assert L.wqaa_tune(ctypes.byref(d), 4096, None) == wlib.OK
     assert L.wqaa_dequantize(ctypes.byref(d), None, None, None, None, None, None) == wlib.ERR_BAD_DESC
-    # the tuned threshold is part of the descriptor: planning honours it only where the two-pass member exists (needs the device)
+    # the tuned threshold is part of the descriptor: planning honours it where a two-pass member exists - since round 4 that is
+    # B_decode + this library's own dense member (no device, no vendor library needed); below the threshold: the fused member
     d.two_pass_min_m = 1024
     p = wlib.select(d, 4096)
-    assert p["kernel_family"] in (2, 4)
-    if L.wqaa_device_count() == 0:
-        assert p["kernel_family"] == 2
+    assert p["kernel_family"] == 4 and "_dq_" in p["name"], p
+    assert wlib.select(d, 512)["kernel_family"] == 2
+    d.two_pass_min_m = 0
+    assert wlib.select(d, 4096)["kernel_family"] == 2          # a format with a fused ping-pong member never takes it unasked
 
 
 def test_vendor_library_is_not_a_link_dependency():
