@@ -476,6 +476,8 @@ def time_member_dense(device, gen, M, N, K, kind="fp8", n_buf=4, vendor=False, t
                                        out_dtype="float16")
         elif kind == "f16":
             cfg = bitblas.MatmulConfig(M=M, N=N, K=K, A_dtype="float16", W_dtype="float16", accum_dtype="float32", out_dtype="float16")
+        elif kind == "int8":
+            cfg = bitblas.MatmulConfig(M=M, N=N, K=K, A_dtype="int8", W_dtype="int8", accum_dtype="int32", out_dtype="int32")
         else:
             cfg = bitblas.MatmulConfig(M=M, N=N, K=K, A_dtype="int8", W_dtype="int2", accum_dtype="int32", out_dtype="int32")
         op = bitblas.Matmul(cfg, enable_tuning=False)
@@ -502,6 +504,11 @@ def _time_member_dense(device, gen, op, M, N, K, kind, n_buf):
         Ws = [(torch.rand((N, K), device=device, generator=gen) - 0.5).to(torch.float16) for _ in range(n_buf)]
         out = torch.empty((M, N), dtype=torch.float16, device=device)
         wbytes = N * K * 2
+    elif kind == "int8":
+        A = torch.randint(-128, 128, (M, K), device=device, dtype=torch.int8, generator=gen)
+        Ws = [torch.randint(-128, 128, (N, K), dtype=torch.int8, device=device, generator=gen) for _ in range(n_buf)]
+        out = torch.empty((M, N), dtype=torch.int32, device=device)
+        wbytes = N * K
     else:
         A = torch.randint(-128, 128, (M, K), device=device, dtype=torch.int8, generator=gen)
         Ws = [torch.randint(-128, 128, (N, K // 4), dtype=torch.int8, device=device, generator=gen) for _ in range(n_buf)]
@@ -515,7 +522,7 @@ def _time_member_dense(device, gen, op, M, N, K, kind, n_buf):
 
     t = graph_time(device, launch_all, n_buf)
     peak = MFMA_F16_PEAK_TF if kind == "f16" else MFMA_I8_PEAK_TOPS
-    res = {"workload": f"{'e4m3 x e4m3' if kind == 'fp8' else 'float16 x float16' if kind == 'f16' else 'W_int2 A_int8'} M={M} N={N} K={K}",
+    res = {"workload": f"{'e4m3 x e4m3' if kind == 'fp8' else 'float16 x float16' if kind == 'f16' else 'int8 x int8' if kind == 'int8' else 'W_int2 A_int8'} M={M} N={N} K={K}",
            "kernel": op.plans[M]["name"], "us_per_launch": t * 1e6}
     if M == 1:
         nbytes = M * K + wbytes + M * N * out.element_size()
@@ -972,6 +979,7 @@ def main():
             # skeleton (round 4) and, as a yardstick, the vendor library on the same operands
             member("gemm_f16_dense_m4096", time_member_dense, device, gen, 4096, 4096, 4096, kind="f16", n_buf=4)
             member("gemm_f16_dense_m4096_vendor", time_member_dense, device, gen, 4096, 4096, 4096, kind="f16", n_buf=4, vendor=True, tuned=True)
+            member("gemm_int8_dense_m4096", time_member_dense, device, gen, 4096, 4096, 4096, kind="int8", n_buf=4)
             member("gemv_int2_int8_m1", time_member_dense, device, gen, 1, 4096, 4096, kind="int2", n_buf=64)
             member("step_chained", time_step_chained, device, gen)
             member("chain_tail", time_chain_tail, device, gen)

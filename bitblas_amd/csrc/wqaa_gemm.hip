@@ -178,7 +178,8 @@ static int gemm_choose(const wqaa_matmul_desc& d, int m, GemmChoice* c, bool fus
   if (m > 128 && d.N >= 128) {
     const char* pf = getenv("WQAA_GEMM_PP");
     const bool dense16 = c->kind == DK_NATIVE && c->at == AT_F16;        // float16 / bfloat16 x the same type: the dense fp8 skeleton on 16-bit lines
-    const int kb = dense16 ? 64 : c->at == AT_F16 ? 256 : c->at == AT_F8 ? 128 : 512;   // k per trip of the main loop
+    const bool dense8 = c->kind == DK_NATIVE && c->at == AT_I8;          // int8 x int8: the same skeleton, 128 k per line
+    const int kb = dense16 ? 64 : c->at == AT_F16 ? 256 : (c->at == AT_F8 || dense8) ? 128 : 512;   // k per trip of the main loop
     const int gb = c->at == AT_F8 ? 1 : g / (kb / 2);                   // k-bodies (two k-tiles) per group
     // (packed integer zero points - GPTQ checkpoints: a wave fetches the 16 bytes of its 32 rows per group, so N in whole waves)
     // (one group per row - per-channel scales, the reference's default group_size = -1 - is the one odd K / g the members take:
@@ -187,7 +188,7 @@ static int gemm_choose(const wqaa_matmul_desc& d, int m, GemmChoice* c, bool fus
     const bool meta_ok = c->mode == MD_NONE || (g % (kb / 2) == 0 && (one_group || (ilog2_exact(gb) >= 0 && ((d.K / g) & 1) == 0)) &&
                                                 (long)d.N * (d.K / g) >= 8 && (c->mode != MD_ZQ || (d.N % 32 == 0 && c->bits == 4)));
     // (the caller's fused epilogue - int32 sums / row scale / tensor scale -> float16 - rides in the integer members' output stage)
-    const bool epi_ok = !fused_epilogue || (c->at == AT_I8 && d.out_dtype == WQAA_F16 && d.a_dtype == WQAA_I8);
+    const bool epi_ok = !fused_epilogue || (c->at == AT_I8 && d.out_dtype == WQAA_F16 && d.a_dtype == WQAA_I8 && c->kind != DK_NATIVE);
     const bool out_ok = c->at == AT_I8 ? (fused_epilogue ? d.out_dtype == WQAA_F16 : d.out_dtype == WQAA_I32)
                         : c->at == AT_F8 ? d.out_dtype == WQAA_F16
                         : dense16 ? (!d.with_bias && d.out_dtype == ((c->flags & FL_BF16) ? WQAA_BF16 : WQAA_F16))      // (its output pass: 2-byte elements, no bias)
@@ -626,7 +627,7 @@ static bool two_pass_dense_desc(const wqaa_matmul_desc& d, wqaa_matmul_desc* dd)
 // ~1024 rows on (profiles/r04_ab_two_pass_own.txt).  Never where a fused ping-pong member exists (it wins: DESIGN.md 3.2a').
 // WQAA_TWO_PASS_AUTO=0: off; =n: from n rows on.
 static bool own_dense_second_pass(const wqaa_matmul_desc& dd, int m) {
-  if (dd.a_dtype != WQAA_F16 && dd.a_dtype != WQAA_BF16) return false;
+  if (dd.a_dtype != WQAA_F16 && dd.a_dtype != WQAA_BF16 && dd.a_dtype != WQAA_I8) return false;
   GemmChoice c;
   return gemm_choose(dd, m, &c) == WQAA_OK && c.pp;
 }
@@ -635,7 +636,7 @@ static bool two_pass_auto(const wqaa_matmul_desc& d, const wqaa_matmul_desc& dd,
   int auto_m = 1024;
   if (const char* f = getenv("WQAA_TWO_PASS_AUTO")) auto_m = atoi(f);          // (plan time: the callers memoise the verdict)
   if (auto_m <= 0 || m < auto_m) return false;
-  if (d.K % 128 != 0 || !own_dense_second_pass(dd, m)) return false;
+  if (d.K % (d.a_dtype == WQAA_I8 ? 256 : 128) != 0 || !own_dense_second_pass(dd, m)) return false;
   GemmChoice c;
   return !(gemm_choose(d, m, &c) == WQAA_OK && c.pp);
 }

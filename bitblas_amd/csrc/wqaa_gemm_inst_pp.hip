@@ -70,6 +70,16 @@ gemm_fn pick_gemm_pp(int kind, int layout, int at, int mode, int flags, int bm, 
     }
     return fn;
   }
+  if (at == AT_I8 && kind == DK_NATIVE && mode == MD_NONE && flags == 0) {                      // dense int8 x int8 -> int32
+    if (bm == 256) {
+      fn = wq_gemm_pp8_kernel<PP8Policy<4, 4>>;
+      *lds_bytes = PP8Policy<4, 4>::LDS_BYTES;
+    } else {
+      fn = wq_gemm_pp8_kernel<PP8Policy<4, 4, 0, 128>>;
+      *lds_bytes = PP8Policy<4, 4, 0, 128>::LDS_BYTES;
+    }
+    return fn;
+  }
   if (at == AT_F16 && kind == DK_NATIVE && mode == MD_NONE && (flags & ~(int)FL_BF16) == 0) {   // dense float16 / bfloat16 x the same type
     const bool bf = (flags & FL_BF16) != 0;
     if (bm == 256) {

@@ -834,9 +834,11 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_pp_kernel(const GemmArgs a
 // fused members).
 template <int WFMT_, int AFMT_, int OPT_ = 0, int BM_ = 256>
 struct PP8Policy {
-  static constexpr int WFMT = WFMT_, AFMT = AFMT_, OPT = OPT_;   // 0 e4m3, 1 e5m2; 2 float16, 3 bfloat16 (both operands)
-  static constexpr int ESZ = WFMT_ >= 2 ? 2 : 1;                 // bytes per element
-  static_assert(WFMT_ < 2 || WFMT_ == AFMT_, "the 16-bit members take one type for both operands");
+  static constexpr int WFMT = WFMT_, AFMT = AFMT_, OPT = OPT_;   // 0 e4m3, 1 e5m2; 2 float16, 3 bfloat16, 4 int8 (both operands)
+  static constexpr int ESZ = (WFMT_ == 2 || WFMT_ == 3) ? 2 : 1; // bytes per element
+  static constexpr bool I8 = WFMT_ == 4;                         // int8 x int8 -> int32 (the reference's INT8 x INT8 row; two
+                                                                 // v_mfma_i32_16x16x64_i8 per fragment pair; int32 output in 128-row passes)
+  static_assert(WFMT_ < 2 || WFMT_ == AFMT_, "the 16-bit / int8 members take one type for both operands");
   static constexpr int BM = BM_, BN = 256, THREADS = 512, KT = 128 / ESZ, TILE_ROW = 128;
   static constexpr int RING = BM_ == 128 ? 4 : 3, D = RING - 1;
   static constexpr int WS = BM_ == 128 ? 3 : 2;      // weight k-tile slots per wave (4 KiB each)
@@ -901,11 +903,12 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_pp8_kernel(const GemmArgs 
   rd[0] = (uint32_t)(fr * P::TILE_ROW + ((kb ^ swl) * 16));
   rd[1] = (uint32_t)(fr * P::TILE_ROW + (((4 + kb) ^ swl) * 16));
 
-  f32x4 acc[NMF][2];
+  using acc_t = typename std::conditional<P::I8, i32x4, f32x4>::type;
+  acc_t acc[NMF][2];
 #pragma unroll
   for (int f = 0; f < NMF; ++f)
 #pragma unroll
-    for (int nf = 0; nf < 2; ++nf) acc[f][nf] = f32x4{0, 0, 0, 0};
+    for (int nf = 0; nf < 2; ++nf) acc[f][nf] = acc_t{0, 0, 0, 0};
   u32x4 afrag[4][2], wfrag[2][2];
 
   // ---- prologue ----
@@ -978,7 +981,17 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_pp8_kernel(const GemmArgs 
   };
   auto compute_segment = [&](auto PH, int t) {
     constexpr int p = decltype(PH)::value;
-    if constexpr (P::ESZ == 2) {
+    if constexpr (P::I8) {
+      // int8 operands: the tile's two 64-deep halves, in ascending k
+#pragma unroll
+      for (int f = 0; f < 4; ++f)
+#pragma unroll
+        for (int nf = 0; nf < 2; ++nf)
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+            acc[p * 4 + f][nf] = __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4, wfrag[nf][i]), __builtin_bit_cast(i32x4, afrag[f][i]),
+                                                                       acc[p * 4 + f][nf], 0, 0, 0);
+    } else if constexpr (P::ESZ == 2) {
       // 16-bit operands: the tile's two 32-deep halves, in ascending k
 #pragma unroll
       for (int f = 0; f < 4; ++f)
@@ -1029,6 +1042,44 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_pp8_kernel(const GemmArgs 
   PP_BARRIER();
   const int el = pp_opaque(lane);
   const int e_fr = el & 15, e_kb = el >> 4, e_ln = el & 31, e_h = el >> 5;
+  if constexpr (P::I8) {
+    // int32 output (+ int8 bias): wq_gemm_pp_kernel's wide pass - 16 bytes per (lane, fragment), passes of 128 rows; slot s = n / 4
+    // of row m lives at s ^ (m & 7)
+    int bias_i[2][4];
+#pragma unroll
+    for (int nf = 0; nf < 2; ++nf)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int n = nw0 + nf * 16 + e_kb * 4 + i;
+        bias_i[nf][i] = a.has_bias ? (int)reinterpret_cast<const int8_t*>(a.bias)[n < a.N ? n : a.N - 1] : 0;
+      }
+#pragma unroll
+    for (int pass = 0; pass < P::BM / 128; ++pass) {
+      if (pass) __syncthreads();
+#pragma unroll
+      for (int ff = 0; ff < 8; ++ff) {
+        const int f = pass * 8 + ff;
+        const int ml = ff * 16 + e_fr;
+#pragma unroll
+        for (int nf = 0; nf < 2; ++nf) {
+          const int sidx = wave * 8 + nf * 4 + e_kb;
+          const i32x4 v = {(int)acc[f][nf][0] + bias_i[nf][0], (int)acc[f][nf][1] + bias_i[nf][1], (int)acc[f][nf][2] + bias_i[nf][2],
+                           (int)acc[f][nf][3] + bias_i[nf][3]};
+          *reinterpret_cast<i32x4*>(smem + ml * 1024 + ((sidx ^ (ml & 7)) * 16)) = v;
+        }
+      }
+      PP_FENCE();
+      __syncthreads();
+#pragma unroll
+      for (int rr = 0; rr < 16; ++rr) {
+        const int ml = wave * 16 + rr;
+        const i32x4 x = *reinterpret_cast<const i32x4*>(smem + ml * 1024 + ((el ^ (ml & 7)) * 16));
+        const int m = m0 + pass * 128 + ml, n = n0 + el * 4;
+        if (m < a.M && n < a.N) pp_store_out(reinterpret_cast<i32x4*>(reinterpret_cast<int*>(a.C) + (long)m * a.N + n), x, a.ws_policy);
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int f = 0; f < NMF; ++f) {
     const int m = f * 16 + e_fr;

@@ -152,6 +152,28 @@ def test_dense_fp8_pairings_ragged(a_dt, w_dt, M, N, K, pin_the_tile):
     assert_fp_parity(out.float().cpu().numpy(), want.astype(np.float16).astype(np.float32), rtol=1e-3, atol_frac=1e-4)
 
 
+@pytest.mark.parametrize("with_bias", [False, True])
+@pytest.mark.parametrize("M,N,K", [(300, 520, 512), (256, 256, 128), (513, 264, 1152)])
+def test_dense_int8_bit_exact(M, N, K, with_bias, pin_the_tile):
+    """INT8 x INT8 -> INT32 (README.md support matrix; tilelang/dense/matmul_mma.py) on the dense skeleton (round 4): bit exact over
+    the full int8 range, ragged M / N, one k-tile, both tiles, int8 bias"""
+    import bitblas_amd as bitblas
+    import wqaa_oracle as oracle
+    rng = np.random.default_rng(M + K)
+    A = rng.integers(-128, 128, size=(M, K), dtype=np.int8)
+    W = rng.integers(-128, 128, size=(N, K), dtype=np.int8)
+    b = rng.integers(-8, 8, size=(N,), dtype=np.int8) if with_bias else None
+    mm = bitblas.Matmul(bitblas.MatmulConfig(M=M, N=N, K=K, A_dtype="int8", W_dtype="int8", accum_dtype="int32", out_dtype="int32", with_bias=with_bias),
+                        enable_tuning=False)
+    assert mm.plans[M]["name"].endswith("pp") and f"_tcx{pin_the_tile}x256x128" in mm.plans[M]["name"], mm.plans[M]["name"]
+    out = mm(torch.from_numpy(A).cuda(), torch.from_numpy(W).cuda(), bias=None if b is None else torch.from_numpy(b).cuda())
+    torch.cuda.synchronize()
+    want = A.astype(np.int64) @ W.astype(np.int64).T
+    if b is not None:
+        want = want + b.astype(np.int64)[None, :]
+    assert np.array_equal(out.cpu().numpy().astype(np.int64), want)
+
+
 @pytest.mark.parametrize("dt", ["float16", "bfloat16"])
 @pytest.mark.parametrize("M,N,K", [(300, 520, 512), (256, 256, 64), (513, 264, 1152)])
 def test_dense_16bit_pairs_ragged(dt, M, N, K, pin_the_tile):
