@@ -206,7 +206,8 @@ static int gemm_choose(const wqaa_matmul_desc& d, int m, GemmChoice* c, bool fus
     const long tiles_l = (long)((m + 127) / 128) * ((d.N + 127) / 128);
     // (the lockstep int8 / fp8 members are further behind their ping-pong counterparts than the fp16 one: tools/ab_pp_tile.py,
     // profiles/r03_ab_pp_tile_*.txt - int2 x int8 M = 1024 4096^2 39.6 vs 34.4 us on the 128-row tile, e4m3 1024 x 8192 x 8192 106 vs 84)
-    const double tlock = (12.0 + 40.0 * 0.5 * (double)((2 * tiles_l + cus_ - 1) / cus_)) * (c->at == AT_I8 ? 1.35 : c->at == AT_F8 ? 1.3 : 1.0);
+    // (and the dense 16-bit ones: float16 1024 x 4096^2 75.5 us on the lockstep member, 49.4 on the 128-row tile; profiles/r04_ab_pp_tile_dense.txt)
+    const double tlock = (12.0 + 40.0 * 0.5 * (double)((2 * tiles_l + cus_ - 1) / cus_)) * (c->at == AT_I8 ? 1.35 : c->at == AT_F8 ? 1.3 : dense16 ? 1.4 : 1.0);
     int lds256 = 0, lds128 = 0, ldss = 0;
     gemm_fn fn256 = shape_ok && m >= 256 && d.N >= 256 ? pick_gemm_pp(c->kind, c->layout, c->at, c->mode, c->flags, 256, 256, &lds256) : nullptr;
     gemm_fn fn128 = shape_ok && d.N >= 256 ? pick_gemm_pp(c->kind, c->layout, c->at, c->mode, c->flags, 128, 256, &lds128) : nullptr;

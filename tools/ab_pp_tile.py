@@ -1,7 +1,8 @@
 #!/usr/bin/env python
 """tools/ab_pp_tile.py [kind] "M N K" ...: the tile the selector picks for a large-M GEMM against each forced choice
 (WQAA_GEMM_PP_BM = 256 / 128 / 0: ping-pong 256 x 256, ping-pong 128 x 256, lockstep members), same process, hipGraph
-replays over rotating weights.  kind: u4 (uint4 g128 + zeros x fp16, default), i2 (int2 x int8), f8 (e4m3 x e4m3)."""
+replays over rotating weights.  kind: u4 (uint4 g128 + zeros x fp16, default), i2 (int2 x int8), f8 (e4m3 x e4m3), f16 / i8 (dense
+float16 x float16 / int8 x int8, round 4)."""
 import os
 import sys
 
@@ -16,6 +17,8 @@ def time_one(dev, gen, kind, M, N, K):
     bench._OPS.clear()                      # a fresh operator: planned (and named) under the variable just set
     if kind == "f8":
         r = bench.time_member_dense(dev, gen, M, N, K, kind="fp8")
+    elif kind in ("f16", "i8"):
+        r = bench.time_member_dense(dev, gen, M, N, K, kind="f16" if kind == "f16" else "int8", n_buf=4)
     elif kind == "i2":
         r = bench.time_member_gemm(dev, gen, M, N, K, W_dtype="int2", A_dtype="int8")
     else:
@@ -28,7 +31,7 @@ def time_one(dev, gen, kind, M, N, K):
 def main():
     argv = sys.argv[1:]
     kind = "u4"
-    if argv and argv[0] in ("u4", "i2", "f8"):
+    if argv and argv[0] in ("u4", "i2", "f8", "f16", "i8"):
         kind = argv.pop(0)
     shapes = [tuple(int(x) for x in a.split()) for a in argv]
     dev = torch.device("cuda", 0)
