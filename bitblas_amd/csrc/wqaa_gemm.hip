@@ -78,6 +78,7 @@ struct GemmChoice {
   // the remainder of a partial round of 256 x 256 tiles as a second launch of the 128 x 256 member over the last N-tiles
   gemm_fn tail_fn;
   int tail_lds, tail_tiles_m, tail_tiles_n;
+  int pp_avail;         // m > 128: a fused ping-pong member takes this descriptor (whether or not the round estimate chose it here)
 };
 
 static int gemm_choose(const wqaa_matmul_desc& d, int m, GemmChoice* c, bool fused_epilogue = false) {
@@ -85,6 +86,7 @@ static int gemm_choose(const wqaa_matmul_desc& d, int m, GemmChoice* c, bool fus
   c->fp4_table = 0;
   c->tail_fn = nullptr;
   c->tail_lds = c->tail_tiles_m = c->tail_tiles_n = 0;
+  c->pp_avail = 0;
   c->flags = 0;
   c->layout = d.w_layout == WQAA_LAYOUT_LOP3 ? LAYOUT_LOP3 : LAYOUT_PLAIN;
   if (a == WQAA_F16) c->at = AT_F16;
@@ -213,6 +215,7 @@ static int gemm_choose(const wqaa_matmul_desc& d, int m, GemmChoice* c, bool fus
     gemm_fn fn128 = shape_ok && d.N >= 256 ? pick_gemm_pp(c->kind, c->layout, c->at, c->mode, c->flags, 128, 256, &lds128) : nullptr;
     // dense fp8 also has a 128 x 128 tile, for outputs that give the CUs no wider one each (4096 x 1024: the c5 column shards)
     gemm_fn fns = shape_ok ? pick_gemm_pp(c->kind, c->layout, c->at, c->mode, c->flags, 128, 128, &ldss) : nullptr;
+    c->pp_avail = (fn256 || fn128 || fns) ? 1 : 0;
     // (a round of x 128 x 128 fp8 tiles: 30 + 0.035 x in the units of the estimates above; profiles/r03_ab_pp_tile_f8_128.txt)
     const double ts = rounds_time(tiles_l, 30.0, 0.035);
     // A shape that leaves the last round of 256 x 256 tiles mostly empty (2048 x 11008: 344 tiles = one round + 88) pays a whole
@@ -638,8 +641,10 @@ static bool two_pass_auto(const wqaa_matmul_desc& d, const wqaa_matmul_desc& dd,
   if (const char* f = getenv("WQAA_TWO_PASS_AUTO")) auto_m = atoi(f);          // (plan time: the callers memoise the verdict)
   if (auto_m <= 0 || m < auto_m) return false;
   if (d.K % (d.a_dtype == WQAA_I8 ? 256 : 128) != 0 || !own_dense_second_pass(dd, m)) return false;
+  // only for descriptors NO fused ping-pong member takes (a format with one keeps its fused members at every shape: where the round
+  // estimate prefers the lockstep member - uint4 1024 x 4096^2: 48.9 us - B_decode + dense would be 60)
   GemmChoice c;
-  return !(gemm_choose(d, m, &c) == WQAA_OK && c.pp);
+  return gemm_choose(d, m, &c) == WQAA_OK && !c.pp_avail;
 }
 
 bool gemm_two_pass_eligible(const wqaa_matmul_desc& d, int m) {

@@ -298,7 +298,11 @@ def test_tune_and_dequantize_entries_without_a_device():
     assert p["kernel_family"] == 4 and "_dq_" in p["name"], p
     assert wlib.select(d, 512)["kernel_family"] == 2
     d.two_pass_min_m = 0
-    assert wlib.select(d, 4096)["kernel_family"] == 2          # a format with a fused ping-pong member never takes it unasked
+    for m in (4096, 2048, 1024):                               # a format with a fused ping-pong member never takes it unasked - also where
+        assert wlib.select(d, m)["kernel_family"] == 2, m      # the round estimate prefers the lockstep member (1024 x 4096^2)
+    d8 = wlib.make_desc(N=4096, K=4096, a_dtype=wlib.F16, w_format=wlib.W_INT, w_bits=8, out_dtype=wlib.F16)
+    assert wlib.select(d8, 4096)["kernel_family"] == 4         # float16 x int8 has none: B_decode + the dense member
+    assert wlib.select(d8, 512)["kernel_family"] == 2
 
 
 def test_vendor_library_is_not_a_link_dependency():
