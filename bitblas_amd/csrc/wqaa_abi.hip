@@ -257,6 +257,11 @@ static int matmul_impl(const wqaa_matmul_desc* desc, const void* A, const void* 
         g_last_error = saved;
         tp_memo.put(*desc, m, 5, tp ? 1 : 0);
       }
+      // the AUTOMATIC form never turns a call that used to need no scratch into a refused one: while the stream is being captured
+      // and the library's scratch would have to grow (no caller workspace, no earlier call of this shape), the fused member runs
+      if (tp && desc->two_pass_min_m <= 0 && !two_pass_forced() && !(opts && opts->workspace) &&
+          !pool_workspace_ready(s, gemm_two_pass_workspace_bytes(*desc, m)))
+        tp = false;
       if (tp) {
         int st = gemm_two_pass_launch(*desc, A, B, LUT, Scale, Zeros, C, m, s, opts);
         if (st == WQAA_OK) g_last_error = WQAA_OK;

@@ -112,6 +112,7 @@ void gemvx_init();
 
 void gemm_debug_tile_of_block(int tiles_m, int tiles_n, int ksplit, int group_m, int block, int* out4);
 int gemm_plan(const wqaa_matmul_desc& d, int m, wqaa_plan* plan, bool fused_epilogue = false);
+bool pool_workspace_ready(hipStream_t stream, size_t bytes);
 int gemm_launch(const wqaa_matmul_desc& d, const void* A, const void* B, const void* LUT,
                 const void* Scale, const void* Zeros, const void* Bias, void* C, int m,
                 hipStream_t stream, hipEvent_t start, hipEvent_t stop, const wqaa_epilogue* epi = nullptr,

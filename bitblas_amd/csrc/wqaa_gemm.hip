@@ -33,7 +33,7 @@ void* pool_workspace(hipStream_t stream, size_t bytes) {
   hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
   if (hipStreamIsCapturing(stream, &cs) != hipSuccess) (void)hipGetLastError();
   if (cs != hipStreamCaptureStatusNone) {
-    set_error(WQAA_ERR_LAUNCH, "gemm: the split-K scratch of this stream has to grow to %zu B, which cannot happen during stream "
+    set_error(WQAA_ERR_LAUNCH, "gemm: the scratch of this stream (split-K partial sums / B_decode) has to grow to %zu B, which cannot happen during stream "
               "capture: run this shape once outside capture, or pass a workspace (wqaa_matmul_opts)", bytes);
     return nullptr;
   }
@@ -53,6 +53,20 @@ void* pool_workspace(hipStream_t stream, size_t bytes) {
     g_ws.push_back(WsSlab{dev, stream, p, want});
   }
   return p;
+}
+
+// true where pool_workspace(stream, bytes) would succeed: the slab is there, or the stream is not capturing (it can grow)
+bool pool_workspace_ready(hipStream_t stream, size_t bytes) {
+  const int dev = current_device();
+  if (dev < 0) return false;
+  {
+    std::lock_guard<std::mutex> lk(g_ws_mu);
+    for (auto& w : g_ws)
+      if (w.dev == dev && w.stream == stream && w.bytes >= bytes) return true;
+  }
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(stream, &cs) != hipSuccess) (void)hipGetLastError();
+  return cs == hipStreamCaptureStatusNone;
 }
 
 static gemm_fn pick_gemm(int kind, int layout, int at, int mode, int flags, int mf) {

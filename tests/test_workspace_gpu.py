@@ -159,3 +159,42 @@ def test_growth_during_capture_is_refused_and_a_caller_workspace_works():
     with pytest.raises(wl.WqaaError, match="workspace"):
         mm.lib.run_ws(ops["A"].data_ptr(), ops["W"].data_ptr(), None, ops["scale"].data_ptr(), ops["zeros"].data_ptr(),
                       None, out.data_ptr(), 48, torch.cuda.current_stream().cuda_stream, ws.data_ptr(), need - 16)
+
+
+def test_automatic_two_pass_does_not_refuse_a_capture_that_needed_no_scratch_before():
+    """round 4: float16 x int8 at >= 1024 rows runs B_decode + the dense member - which needs N K 2 bytes of scratch.  Through the
+    plain C entry on a fresh stream under capture (no caller workspace, no earlier call) the library's pool cannot grow: the call
+    must take the fused member instead of failing, and the same call outside capture afterwards takes the two-pass form; both
+    meet the oracle on sampled rows"""
+    import ctypes
+    import wqaa_oracle as oracle
+    M, N, K = 2048, 2048, 1024
+    rng = np.random.default_rng(5)
+    A = (rng.random((M, K), dtype=np.float32) - 0.5).astype(np.float16)
+    W = rng.integers(-128, 128, size=(N, K), dtype=np.int8)
+    mm = bitblas.Matmul(bitblas.MatmulConfig(M=M, N=N, K=K, A_dtype="float16", W_dtype="int8", accum_dtype="float32", out_dtype="float16"),
+                        enable_tuning=False)
+    assert "_dq_" in mm.plans[M]["name"] and mm.lib.workspace_bytes(M) >= N * K * 2, mm.plans[M]
+    Ad, Wd = torch.from_numpy(A).cuda(), torch.from_numpy(W).cuda()
+    lib = wl.load_library()
+    rows = np.arange(0, M, 61)
+    want = oracle.matmul_dequant(A[rows], W, source_format="int", bit=8, a_dtype="float16", out_dtype="float32")
+
+    def call(out, stream):
+        wl.check(lib.wqaa_matmul(ctypes.byref(mm.lib.desc), Ad.data_ptr(), Wd.data_ptr(), None, None, None, None, out.data_ptr(), M, stream.cuda_stream))
+
+    s = torch.cuda.Stream()                        # a fresh stream: no slab of the library's pool yet
+    out = torch.zeros((M, N), dtype=torch.float16, device="cuda")
+    with torch.cuda.stream(s):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            call(out, s)                           # must not raise
+        g.replay()
+        s.synchronize()
+        assert_fp_parity(out.float().cpu().numpy()[rows], want.astype(np.float16).astype(np.float32), rtol=1e-3, atol_frac=1e-3)
+        out2 = torch.zeros_like(out)
+        call(out2, s)                              # outside capture: the pool grows, B_decode + dense
+        s.synchronize()
+    assert_fp_parity(out2.float().cpu().numpy()[rows], want.astype(np.float16).astype(np.float32), rtol=1e-3, atol_frac=1e-3)
+    # (the fused member of this shape splits K: another summation order - the two forms agree to rounding, not bit for bit)
+    assert_fp_parity(out.float().cpu().numpy()[rows], out2.float().cpu().numpy()[rows], rtol=1e-3, atol_frac=1e-3)
