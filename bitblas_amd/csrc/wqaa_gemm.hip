@@ -92,6 +92,7 @@ struct GemmChoice {
   // the remainder of a partial round of 256 x 256 tiles as a second launch of the 128 x 256 member over the last N-tiles
   gemm_fn tail_fn;
   int tail_lds, tail_tiles_m, tail_tiles_n;
+  int decode_grid;      // > 0: the persistent form of the one-launch decode member (grid < number of 16-row fragments)
   int pp_avail;         // m > 128: a fused ping-pong member takes this descriptor (whether or not the round estimate chose it here)
 };
 
@@ -101,6 +102,7 @@ static int gemm_choose(const wqaa_matmul_desc& d, int m, GemmChoice* c, bool fus
   c->tail_fn = nullptr;
   c->tail_lds = c->tail_tiles_m = c->tail_tiles_n = 0;
   c->pp_avail = 0;
+  c->decode_grid = 0;
   c->flags = 0;
   c->layout = d.w_layout == WQAA_LAYOUT_LOP3 ? LAYOUT_LOP3 : LAYOUT_PLAIN;
   if (a == WQAA_F16) c->at = AT_F16;
@@ -319,6 +321,20 @@ static int gemm_choose(const wqaa_matmul_desc& d, int m, GemmChoice* c, bool fus
   // 0.75 and 1 round - the round-1 table above)
   bool decode_fits = c->at != AT_I4 ? (frags <= cus_ || frags == 2 * cus_ || (m <= 8 && frags <= 2 * cus_))
                                     : (m <= 8 ? frags <= cus_ + cus_ / 2 : (frags <= cus_ && 4 * frags >= 3 * cus_));
+  // round 4 - the PERSISTENT form of member 211: where every wave's k-range is one block of 4 k-steps (K <= 32 k-steps: 4096 for the
+  // float types, 8192 for int8) a workgroup stages the activations once and takes fragments blk, blk + grid, ... with the next
+  // fragments' weights in flight; the grid is capped at one workgroup per CU.  Partial rounds no longer cost a round:
+  // 11008 x 4096 M = 3 ... 16 13.3-15.1 us (skinny + reduce) -> 11.6-12.6; 8192 9.8-11.3 -> 8.6-9.7; 5120 9.2-10.6 -> 8.2-9.2
+  // (profiles/r04_ab_decode_persistent.txt).  WQAA_GEMM_DECODE_PERSIST=0: off.
+  bool persist = false;
+  {
+    const char* pf = getenv("WQAA_GEMM_DECODE_PERSIST");
+    // (float types, up to three rounds of fragments: 22016 x 4096 - 5.4 per workgroup - and int2 x int8 measured no better
+    // than the skinny member + reduce)
+    persist = (c->at == AT_F16 || c->at == AT_F8) && frags > cus_ && frags <= 3 * cus_ && nsteps <= 8 * 4 && (!pf || atoi(pf) != 0);
+  }
+  const bool fits_one_each = decode_fits;     // (the rule for one fragment per workgroup)
+  if (persist) decode_fits = true;
   if (const char* f = getenv("WQAA_GEMM_DECODE_FORCE")) decode_fits = atoi(f) != 0;   // tuning aid
   if (m <= decode_max_m && m <= 16 && c->mf == 1 && decode_fits) {
     const char* dflag = getenv("WQAA_GEMM_DECODE");
@@ -337,10 +353,13 @@ static int gemm_choose(const wqaa_matmul_desc& d, int m, GemmChoice* c, bool fus
       c->skinny = 0;
       c->tiles_m = 1;
       c->tiles_n = (d.N + 15) / 16;
-      c->lds = lds_member ? 8 * 4 * 16 * 256 + 8 * 64 * 16 : 8 * c->mf * 64 * 16;
+      c->lds = lds_member ? 8 * 4 * 16 * 256 + 2 * 8 * 64 * 16 : 8 * c->mf * 64 * 16;     // (two sets of meeting slots: the persistent form)
       c->ksplit = 1;
       c->decode = lds_member ? 2 : 1;
-      return WQAA_OK;
+      // persistent: a grid of one workgroup per CU (whole XCD rounds keep the block swizzle on); the direct-load member has no such form
+      c->decode_grid = (lds_member && persist) ? (cus_ / 8) * 8 : 0;
+      if (lds_member || fits_one_each) return WQAA_OK;
+      c->fn = nullptr;                       // (persistent asked for, but this format has only the direct-load member)
     }
     c->decode = 0;
   }
@@ -408,12 +427,13 @@ int gemm_plan(const wqaa_matmul_desc& d, int m, wqaa_plan* plan, bool fused_epil
     plan->split_k = c.ksplit;
     plan->lds_bytes = c.lds;
     plan->grid = c.tiles_m * c.tiles_n * c.ksplit + (c.tail_fn ? c.tail_tiles_m * c.tail_tiles_n : 0);
+    if (c.decode_grid > 0) plan->grid = c.decode_grid;
     char wd[24];
     short_wdtype(d, wd, sizeof(wd));
     char tail[16] = "";
     if (c.tail_fn) snprintf(tail, sizeof(tail), "t%d", c.tail_tiles_n);      // "ppt11": the last 11 N-tiles as a launch of the 128-row tile
     snprintf(plan->name, sizeof(plan->name), "matmul_m%dn%dk%d_%sx%s_tcx%dx%dx%d%s%s%s", m, d.N, d.K, short_dtype(d.a_dtype),
-             wd, 16 * c.mf, c.bn, c.ks, c.ksplit > 1 ? "xr" : "", c.pp ? "pp" : c.skinny ? "xs" : c.decode == 2 ? "xdl" : c.decode ? "xd" : c.wide ? "xw" : "", tail);
+             wd, 16 * c.mf, c.bn, c.ks, c.ksplit > 1 ? "xr" : "", c.pp ? "pp" : c.skinny ? "xs" : c.decode == 2 ? (c.decode_grid > 0 ? "xdlp" : "xdl") : c.decode ? "xd" : c.wide ? "xw" : "", tail);
   }
   return WQAA_OK;
 }
@@ -536,7 +556,7 @@ int gemm_launch(const wqaa_matmul_desc& d, const void* A, const void* B, const v
     }
   }
   void* params[] = {&a};
-  dim3 grid(c.tiles_m * c.tiles_n * c.ksplit, 1, 1), block(64 * c.nwaves, 1, 1);
+  dim3 grid(c.decode_grid > 0 ? c.decode_grid : c.tiles_m * c.tiles_n * c.ksplit, 1, 1), block(64 * c.nwaves, 1, 1);
   hipError_t e;
   if (start || stop) {
     e = hipExtLaunchKernel(reinterpret_cast<const void*>(c.fn), grid, block, params, c.lds, stream, start,

@@ -1232,7 +1232,14 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_decode_lds_kernel(const Ge
   const int fr = lane & 15, kb = lane >> 4;
   int blk = blockIdx.x;
   if ((gridDim.x & 7) == 0) blk = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
-  const int n0 = blk * 16;
+  // PERSISTENT form (round 4): a grid smaller than the number of 16-row weight fragments - the launcher caps it at one
+  // workgroup per CU when N / 16 exceeds the chip AND every wave's k-range is one block (K <= NW * PF k-steps) - makes a
+  // workgroup take fragments blk, blk + grid, ...: the activations are staged ONCE (a wave's whole k-range sits in its LDS
+  // region), the next fragment's weights are in flight while this one is multiplied and reduced.  11008 x 4096 at M = 3 ... 16
+  // was 2.7 rounds of one-fragment workgroups (or the split-K skinny member + its reduce launch: 13-15 us).
+  const int nfrags = (a.N + 15) >> 4;
+  const bool persistent = (int)gridDim.x < nfrags;
+  int n0 = blk * 16;
   int nrow = n0 + fr;
   nrow = nrow < a.N ? nrow : a.N - 1;
 
@@ -1242,7 +1249,14 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_decode_lds_kernel(const Ge
   const uint16_t* Zp = reinterpret_cast<const uint16_t*>(a.zeros);
   const uint8_t* Qp = reinterpret_cast<const uint8_t*>(a.zeros);
   const uint8_t* brow = Bp + (long)nrow * a.row_bytes + (long)kb * (WL * 4);
-  const long srow = (long)nrow * a.kg;
+  long srow = (long)nrow * a.kg;
+  auto set_fragment = [&](int frag) {                           // the weight fragment the loads / the store that follow refer to
+    n0 = frag * 16;
+    nrow = n0 + fr;
+    nrow = nrow < a.N ? nrow : a.N - 1;
+    brow = Bp + (long)nrow * a.row_bytes + (long)kb * (WL * 4);
+    srow = (long)nrow * a.kg;
+  };
   unsigned char* region = smem_raw + wave * REGION;
 
   // LDS-DMA source of this lane for instruction q (rows 4q .. 4q+3) of a k-step: the slot it fills is (row, p = lane & 15);
@@ -1295,12 +1309,13 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_decode_lds_kernel(const Ge
   }
 
   acc_t acc = acc_t{0, 0, 0, 0};
+  int zq_row = nrow;                                            // (packed zero points: the row the fragment in hand was loaded for)
   auto compute = [&](const BLane<P>& bl, int s) {
     uint32_t bfrag[NJ][4];
     if constexpr (F16) {
       half_t zf = cx.zf;
       if constexpr (MODE == MD_ZQ) {
-        const uint32_t zq = (bl.z[0] >> ((nrow % ZPB) * ZB)) & ((1u << ZB) - 1u);
+        const uint32_t zq = (bl.z[0] >> ((zq_row % ZPB) * ZB)) & ((1u << ZB) - 1u);
         zf = (half_t)(float)zq;
       }
       const half2_t s2 = MODE != MD_NONE ? splat(bits_to_half(bl.s[0])) : splat((half_t)1.0f);
@@ -1361,6 +1376,90 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_decode_lds_kernel(const Ge
   const int t_lo = wave * run;
   const int my_steps = t_lo >= nsteps ? 0 : (nsteps - t_lo < run ? nsteps - t_lo : run);   // wave-uniform
   acc_t* red = reinterpret_cast<acc_t*>(smem_raw + NW * REGION);
+  if (persistent) {
+    // (the launcher guarantees run <= PF: one block per wave)
+    struct FragLoad {
+      BLane<P> bs[PF];
+      u32x2 gs, gz;
+      int row;
+    };
+    auto load_fragment = [&](int frag, FragLoad& f) {
+      set_fragment(frag);
+      f.row = nrow;
+      f.gs = u32x2{0u, 0u};
+      f.gz = u32x2{0u, 0u};
+      if (wide) {
+        int base = t_lo < a.kg - 4 ? t_lo : a.kg - 4;
+        base = base < 0 ? 0 : base;
+        f.gs = *reinterpret_cast<const u32x2*>(Sp + srow + base);
+        if constexpr (MODE == MD_ZO || MODE == MD_ZR) f.gz = *reinterpret_cast<const u32x2*>(Zp + srow + base);
+      }
+#pragma unroll
+      for (int i = 0; i < PF; ++i) {
+        const int t = t_lo + i;
+        w_load(t < nsteps ? t : last, f.bs[i]);
+      }
+    };
+    auto finish_fragment = [&](int frag, FragLoad& f, int parity) {
+      acc = acc_t{0, 0, 0, 0};
+      zq_row = f.row;
+#pragma unroll
+      for (int i = 0; i < PF; ++i) {
+        if (wide) {
+          f.bs[i].s[0] = (f.gs[i >> 1] >> (16 * (i & 1))) & 0xFFFFu;
+          f.bs[i].z[0] = (f.gz[i >> 1] >> (16 * (i & 1))) & 0xFFFFu;
+        }
+        if (i < my_steps) compute(f.bs[i], i);
+      }
+      // two sets of meeting slots: the waves may be a fragment ahead of the one that sums
+      acc_t* r = red + parity * (NW * 64);
+      r[wave * 64 + lane] = acc;
+      __syncthreads();
+      if (wave == 0) {
+        acc_t sum = r[lane];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) sum += r[w * 64 + lane];
+        const int nb = frag * 16 + kb * 4;
+        if (nb < a.N && fr < a.M) store_quad<P>(a, sum, fr, nb);
+      }
+    };
+    // the activations, once
+#pragma unroll
+    for (int i = 0; i < PF; ++i) {
+      const int t = t_lo + i;
+      dma_step(t < nsteps ? t : last, i);
+    }
+    asm volatile("" ::: "memory");
+    // up to three fragments' weights asked for ahead (12.2 us with one ahead, 11.6 with three, 13.3 before: 11008 x 4096 M = 3;
+    // profiles/r04_ab_decode_persistent.txt).  The loads of a refill sit behind a test, and the copy at the join waits for
+    // everything in flight; the branch-free form (clamped fragment indices, every load unconditional) was built and measured
+    // WORSE - 18 us: the redundant fetches of the clamped fragment and a 6-way unrolled trip - and is not kept.
+    FragLoad f0, f1, f2;
+    const int G = (int)gridDim.x;
+    int g0 = blk, g1 = blk + G, g2 = blk + 2 * G;
+    load_fragment(g0, f0);
+    if (g1 < nfrags) load_fragment(g1, f1);
+    if (g2 < nfrags) load_fragment(g2, f2);
+    int parity = 0;
+    for (;;) {
+      finish_fragment(g0, f0, parity);
+      parity ^= 1;
+      if (g1 >= nfrags) break;
+      g0 += 3 * G;
+      if (g0 < nfrags) load_fragment(g0, f0);
+      finish_fragment(g1, f1, parity);
+      parity ^= 1;
+      if (g2 >= nfrags) break;
+      g1 += 3 * G;
+      if (g1 < nfrags) load_fragment(g1, f1);
+      finish_fragment(g2, f2, parity);
+      parity ^= 1;
+      if (g0 >= nfrags) break;
+      g2 += 3 * G;
+      if (g2 < nfrags) load_fragment(g2, f2);
+    }
+    return;
+  }
   for (int s0 = 0; s0 < my_steps; s0 += PF) {
     BLane<P> bs[PF];
     u32x2 gs = {0u, 0u}, gz = {0u, 0u};
