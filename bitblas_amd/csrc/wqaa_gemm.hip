@@ -353,7 +353,7 @@ static int gemm_choose(const wqaa_matmul_desc& d, int m, GemmChoice* c, bool fus
       c->skinny = 0;
       c->tiles_m = 1;
       c->tiles_n = (d.N + 15) / 16;
-      c->lds = lds_member ? 8 * 4 * 16 * 256 + 2 * 8 * 64 * 16 : 8 * c->mf * 64 * 16;     // (two sets of meeting slots: the persistent form)
+      c->lds = lds_member ? 8 * 4 * 16 * 256 + 3 * 8 * 64 * 16 : 8 * c->mf * 64 * 16;     // (three sets of meeting slots: the persistent form)
       c->ksplit = 1;
       c->decode = lds_member ? 2 : 1;
       // persistent: a grid of one workgroup per CU (whole XCD rounds keep the block swizzle on); the direct-load member has no such form

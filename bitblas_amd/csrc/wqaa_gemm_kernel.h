@@ -1377,7 +1377,115 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_decode_lds_kernel(const Ge
   const int my_steps = t_lo >= nsteps ? 0 : (nsteps - t_lo < run ? nsteps - t_lo : run);   // wave-uniform
   acc_t* red = reinterpret_cast<acc_t*>(smem_raw + NW * REGION);
   if (persistent) {
-    // (the launcher guarantees run <= PF: one block per wave)
+    // (the launcher guarantees run <= PF - one block per wave - and at most three fragments per workgroup)
+    // 4-bit weights with one Scale / Zeros group per k-step (the headline formats): the walk in straight line with every load an
+    // inline-assembly instruction and every wait counted by hand.  With compiler-tracked loads the first read of the staged tile
+    // waited for ALL loads in flight - LDS-DMA and register loads do not retire in one order, so the compiler assumes the worst -
+    // and a refill behind a test ended in a copy that did the same: 11.6 us at 11008 x 4096 where the weight stream needs ~6.
+    // Here the activations land first (one exposed L2 round trip, the s_waitcnt below tells the compiler's scoreboard so), then
+    // all the workgroup's fragments are asked for at once and fragment i is multiplied while i + 1, i + 2 are still arriving.
+    // A wave's own vmcnt retires in order for loads of ONE kind; wave 0's stores in between only make a wait stricter.
+    if constexpr (WL == 4 && WIDE_OK) {
+      if (wide) {
+        constexpr bool ZP = MODE == MD_ZO || MODE == MD_ZR;
+        constexpr int NOPS = PF + 1 + (ZP ? 1 : 0);        // loads per fragment and lane
+        struct AF {
+          u32x4 w[PF];
+          u32x2 gs, gz;
+          int row;
+        };
+        const int G = (int)gridDim.x;
+        const int n_own = (nfrags - 1 - blk) / G + 1;      // fragments of this workgroup: 1 .. 3
+#pragma unroll
+        for (int i = 0; i < PF; ++i) {
+          const int t = t_lo + i;
+          dma_step(t < nsteps ? t : last, i);
+        }
+        __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0): the tile has landed
+        auto issue = [&](int frag, AF& f) {
+          set_fragment(frag);
+          f.row = nrow;
+          int base = t_lo < a.kg - 4 ? t_lo : a.kg - 4;
+          base = base < 0 ? 0 : base;
+          const uint16_t* sp = Sp + srow + base;
+          asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(f.gs) : "v"(sp) : "memory");
+          if constexpr (ZP) {
+            const uint16_t* zp = Zp + srow + base;
+            asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(f.gz) : "v"(zp) : "memory");
+          } else {
+            f.gz = u32x2{0u, 0u};
+          }
+#pragma unroll
+          for (int i = 0; i < PF; ++i) {
+            int t = t_lo + i;
+            t = t < nsteps ? t : last;
+            const uint8_t* wp = brow + (long)t * (4 * WL * 4);
+            asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(f.w[i]) : "v"(wp) : "memory");
+          }
+        };
+        // the wait hands the fragment's registers on: nothing that reads them can be scheduled above it
+        auto landed = [&](auto NY, AF& f) {
+          constexpr int ny = decltype(NY)::value;          // loads issued after this fragment's
+          static_assert(PF == 4, "the operand list below");
+          if constexpr (ZP)
+            asm volatile("s_waitcnt vmcnt(%6)" : "+v"(f.w[0]), "+v"(f.w[1]), "+v"(f.w[2]), "+v"(f.w[3]), "+v"(f.gs), "+v"(f.gz) : "n"(ny) : "memory");
+          else
+            asm volatile("s_waitcnt vmcnt(%5)" : "+v"(f.w[0]), "+v"(f.w[1]), "+v"(f.w[2]), "+v"(f.w[3]), "+v"(f.gs) : "n"(ny) : "memory");
+        };
+        auto multiply = [&](const AF& f) -> acc_t {
+          acc = acc_t{0, 0, 0, 0};
+          zq_row = f.row;
+#pragma unroll
+          for (int i = 0; i < PF; ++i) {
+            BLane<P> bl;
+            bl.w[0][0] = f.w[i][0]; bl.w[0][1] = f.w[i][1]; bl.w[0][2] = f.w[i][2]; bl.w[0][3] = f.w[i][3];
+            bl.s[0] = (f.gs[i >> 1] >> (16 * (i & 1))) & 0xFFFFu;
+            bl.z[0] = (f.gz[i >> 1] >> (16 * (i & 1))) & 0xFFFFu;
+            if (i < my_steps) compute(bl, i);
+          }
+          return acc;
+        };
+        // the waves meet ONCE, with their partial sums of all the workgroup's fragments (three sets of slots), and waves 0, 1, 2 sum
+        // and store one fragment each - in wave order, as the one-fragment form does
+        AF f0, f1, f2;
+        acc_t p0 = acc_t{0, 0, 0, 0}, p1 = p0, p2 = p0;
+        if (n_own >= 3) {
+          issue(blk, f0);
+          issue(blk + G, f1);
+          issue(blk + 2 * G, f2);
+          landed(std::integral_constant<int, 2 * NOPS>{}, f0);
+          p0 = multiply(f0);
+          landed(std::integral_constant<int, NOPS>{}, f1);
+          p1 = multiply(f1);
+          landed(std::integral_constant<int, 0>{}, f2);
+          p2 = multiply(f2);
+        } else if (n_own == 2) {
+          issue(blk, f0);
+          issue(blk + G, f1);
+          landed(std::integral_constant<int, NOPS>{}, f0);
+          p0 = multiply(f0);
+          landed(std::integral_constant<int, 0>{}, f1);
+          p1 = multiply(f1);
+        } else {
+          issue(blk, f0);
+          landed(std::integral_constant<int, 0>{}, f0);
+          p0 = multiply(f0);
+        }
+        red[wave * 64 + lane] = p0;
+        red[(NW + wave) * 64 + lane] = p1;
+        red[(2 * NW + wave) * 64 + lane] = p2;
+        __syncthreads();
+        if (wave < n_own) {
+          const acc_t* r = red + wave * (NW * 64);
+          acc_t sum = r[lane];
+#pragma unroll
+          for (int w = 1; w < NW; ++w) sum += r[w * 64 + lane];
+          const int nb = (blk + wave * G) * 16 + kb * 4;
+          if (nb < a.N && fr < a.M) store_quad<P>(a, sum, fr, nb);
+        }
+        return;
+      }
+    }
     struct FragLoad {
       BLane<P> bs[PF];
       u32x2 gs, gz;
