@@ -331,7 +331,10 @@ static int gemm_choose(const wqaa_matmul_desc& d, int m, GemmChoice* c, bool fus
     const char* pf = getenv("WQAA_GEMM_DECODE_PERSIST");
     // (float types, up to three rounds of fragments: 22016 x 4096 - 5.4 per workgroup - and int2 x int8 measured no better
     // than the skinny member + reduce)
-    persist = (c->at == AT_F16 || c->at == AT_F8) && frags > cus_ && frags <= 3 * cus_ && nsteps <= 8 * 4 && (!pf || atoi(pf) != 0);
+    // (the hand-counted form - 4-bit weights, one Scale / Zeros group per k-step - takes up to six rounds of fragments, two batches)
+    const bool counted = c->at == AT_F16 && (c->kind == DK_INT4 || c->kind == DK_LUT4) && (c->mode == MD_S || c->mode == MD_ZO || c->mode == MD_ZR) &&
+                         g == c->ks && ((d.K / g) & 3) == 0;
+    persist = (c->at == AT_F16 || c->at == AT_F8) && frags > cus_ && frags <= (counted ? 6 : 3) * cus_ && nsteps <= 8 * 4 && (!pf || atoi(pf) != 0);
   }
   const bool fits_one_each = decode_fits;     // (the rule for one fragment per workgroup)
   if (persist) decode_fits = true;

@@ -1250,7 +1250,7 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_decode_lds_kernel(const Ge
   const uint8_t* Qp = reinterpret_cast<const uint8_t*>(a.zeros);
   const uint8_t* brow = Bp + (long)nrow * a.row_bytes + (long)kb * (WL * 4);
   long srow = (long)nrow * a.kg;
-  auto set_fragment = [&](int frag) {                           // the weight fragment the loads / the store that follow refer to
+  auto set_fragment = [&](int frag) __attribute__((always_inline)) {                           // the weight fragment the loads / the store that follow refer to
     n0 = frag * 16;
     nrow = n0 + fr;
     nrow = nrow < a.N ? nrow : a.N - 1;
@@ -1272,7 +1272,7 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_decode_lds_kernel(const Ge
   }
   constexpr int ASTEP = P::KS * ASZ;                            // bytes of one k-step in a row of A (= 256)
   const int nq = (a.M + 3) >> 2;                                // row groups that hold real rows (the rest of the fragment is never stored)
-  auto dma_step = [&](int t, int s) {                           // k-step t -> block slot s
+  auto dma_step = [&](int t, int s) __attribute__((always_inline)) {                           // k-step t -> block slot s
 #pragma unroll
     for (int q = 0; q < 4; ++q)
       if (q < nq)
@@ -1282,7 +1282,7 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_decode_lds_kernel(const Ge
 
   constexpr bool WIDE_OK = MODE == MD_S || MODE == MD_ZO || MODE == MD_ZR;
   const bool wide = WIDE_OK && a.gq_shift == 2 && (a.kg & 3) == 0;   // one group per k-step: 8-byte metadata loads per block
-  auto w_load = [&](int t, BLane<P>& b) {
+  auto w_load = [&](int t, BLane<P>& b) __attribute__((always_inline)) {
     const int kidx = t * 4 + kb;
     int gi = 0;
     if (MODE != MD_NONE) gi = a.gq_shift >= 0 ? (kidx >> a.gq_shift) : (int)__umulhi((uint32_t)kidx, a.gq_magic);
@@ -1310,7 +1310,7 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_decode_lds_kernel(const Ge
 
   acc_t acc = acc_t{0, 0, 0, 0};
   int zq_row = nrow;                                            // (packed zero points: the row the fragment in hand was loaded for)
-  auto compute = [&](const BLane<P>& bl, int s) {
+  auto compute = [&](const BLane<P>& bl, int s) __attribute__((always_inline)) {
     uint32_t bfrag[NJ][4];
     if constexpr (F16) {
       half_t zf = cx.zf;
@@ -1377,7 +1377,7 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_decode_lds_kernel(const Ge
   const int my_steps = t_lo >= nsteps ? 0 : (nsteps - t_lo < run ? nsteps - t_lo : run);   // wave-uniform
   acc_t* red = reinterpret_cast<acc_t*>(smem_raw + NW * REGION);
   if (persistent) {
-    // (the launcher guarantees run <= PF - one block per wave - and at most three fragments per workgroup)
+    // (the launcher guarantees run <= PF - one block per wave - and at most three fragments per workgroup; six for the form below)
     // 4-bit weights with one Scale / Zeros group per k-step (the headline formats): the walk in straight line with every load an
     // inline-assembly instruction and every wait counted by hand.  With compiler-tracked loads the first read of the staged tile
     // waited for ALL loads in flight - LDS-DMA and register loads do not retire in one order, so the compiler assumes the worst -
@@ -1402,7 +1402,7 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_decode_lds_kernel(const Ge
           dma_step(t < nsteps ? t : last, i);
         }
         __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0): the tile has landed
-        auto issue = [&](int frag, AF& f) {
+        auto issue = [&](int frag, AF& f) __attribute__((always_inline)) {
           set_fragment(frag);
           f.row = nrow;
           int base = t_lo < a.kg - 4 ? t_lo : a.kg - 4;
@@ -1423,8 +1423,14 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_decode_lds_kernel(const Ge
             asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(f.w[i]) : "v"(wp) : "memory");
           }
         };
-        // the wait hands the fragment's registers on: nothing that reads them can be scheduled above it
-        auto landed = [&](auto NY, AF& f) {
+        // the wait hands the fragment's registers on: nothing that reads them can be scheduled above it.
+        // CONTRACT with the compiler: between a load and its wait the destination registers must stay where they are - a spill
+        // or an out-of-line call (captures on the stack) would copy them before the data is there.  Hence every lambda of this
+        // kernel is always_inline, and tests/test_abi.py::test_counted_decode_members_keep_their_loads_in_registers reads the
+        // built library's metadata: no scratch, no stack in any instantiation that takes this path.  (The same walk with
+        // compiler-tracked loads needs no contract and was measured ~0.8 us slower at 11008 x 4096: where the one-, two- and
+        // three-fragment paths share their first loads the compiler's count falls back to vmcnt(0).)
+        auto landed = [&](auto NY, AF& f) __attribute__((always_inline)) {
           constexpr int ny = decltype(NY)::value;          // loads issued after this fragment's
           static_assert(PF == 4, "the operand list below");
           if constexpr (ZP)
@@ -1432,7 +1438,7 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_decode_lds_kernel(const Ge
           else
             asm volatile("s_waitcnt vmcnt(%5)" : "+v"(f.w[0]), "+v"(f.w[1]), "+v"(f.w[2]), "+v"(f.w[3]), "+v"(f.gs) : "n"(ny) : "memory");
         };
-        auto multiply = [&](const AF& f) -> acc_t {
+        auto multiply = [&](const AF& f) __attribute__((always_inline)) -> acc_t {
           acc = acc_t{0, 0, 0, 0};
           zq_row = f.row;
 #pragma unroll
@@ -1445,10 +1451,62 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_decode_lds_kernel(const Ge
           }
           return acc;
         };
-        // the waves meet ONCE, with their partial sums of all the workgroup's fragments (three sets of slots), and waves 0, 1, 2 sum
-        // and store one fragment each - in wave order, as the one-fragment form does
+        // the waves meet once per batch of (up to) three fragments, with their partial sums of the whole batch (three sets of
+        // slots), and waves 0, 1, 2 sum and store one fragment each - in wave order, as the one-fragment form does
+        auto meet = [&](const acc_t& p0, const acc_t& p1, const acc_t& p2, int first, int count) __attribute__((always_inline)) {
+          red[wave * 64 + lane] = p0;
+          red[(NW + wave) * 64 + lane] = p1;
+          red[(2 * NW + wave) * 64 + lane] = p2;
+          __syncthreads();
+          if (wave < count) {
+            const acc_t* r = red + wave * (NW * 64);
+            acc_t sum = r[lane];
+#pragma unroll
+            for (int w = 1; w < NW; ++w) sum += r[w * 64 + lane];
+            const int nb = (first + wave * G) * 16 + kb * 4;
+            if (nb < a.N && fr < a.M) store_quad<P>(a, sum, fr, nb);
+          }
+        };
         AF f0, f1, f2;
-        acc_t p0 = acc_t{0, 0, 0, 0}, p1 = p0, p2 = p0;
+        const acc_t zero = acc_t{0, 0, 0, 0};
+        acc_t p0 = zero, p1 = zero, p2 = zero;
+        if (n_own > 3) {
+          // four to six fragments: the second batch refills the first one's registers as they are consumed.  NB2 = fragments of the
+          // second batch; a wait counts the loads issued after the fragment it is for
+          auto two_batches = [&](auto NB2) __attribute__((always_inline)) {
+            constexpr int nb2 = decltype(NB2)::value;
+            issue(blk, f0);
+            issue(blk + G, f1);
+            issue(blk + 2 * G, f2);
+            landed(std::integral_constant<int, 2 * NOPS>{}, f0);
+            p0 = multiply(f0);
+            issue(blk + 3 * G, f0);
+            landed(std::integral_constant<int, 2 * NOPS>{}, f1);
+            p1 = multiply(f1);
+            if constexpr (nb2 >= 2) issue(blk + 4 * G, f1);
+            landed(std::integral_constant<int, (1 + (nb2 >= 2 ? 1 : 0)) * NOPS>{}, f2);
+            p2 = multiply(f2);
+            if constexpr (nb2 >= 3) issue(blk + 5 * G, f2);
+            meet(p0, p1, p2, blk, 3);
+            acc_t q0 = zero, q1 = zero, q2 = zero;
+            landed(std::integral_constant<int, (nb2 - 1) * NOPS>{}, f0);
+            q0 = multiply(f0);
+            if constexpr (nb2 >= 2) {
+              landed(std::integral_constant<int, (nb2 - 2) * NOPS>{}, f1);
+              q1 = multiply(f1);
+            }
+            if constexpr (nb2 >= 3) {
+              landed(std::integral_constant<int, 0>{}, f2);
+              q2 = multiply(f2);
+            }
+            __syncthreads();                               // the first batch's slots have been read
+            meet(q0, q1, q2, blk + 3 * G, nb2);
+          };
+          if (n_own == 4) two_batches(std::integral_constant<int, 1>{});
+          else if (n_own == 5) two_batches(std::integral_constant<int, 2>{});
+          else two_batches(std::integral_constant<int, 3>{});
+          return;
+        }
         if (n_own >= 3) {
           issue(blk, f0);
           issue(blk + G, f1);
@@ -1471,18 +1529,7 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_decode_lds_kernel(const Ge
           landed(std::integral_constant<int, 0>{}, f0);
           p0 = multiply(f0);
         }
-        red[wave * 64 + lane] = p0;
-        red[(NW + wave) * 64 + lane] = p1;
-        red[(2 * NW + wave) * 64 + lane] = p2;
-        __syncthreads();
-        if (wave < n_own) {
-          const acc_t* r = red + wave * (NW * 64);
-          acc_t sum = r[lane];
-#pragma unroll
-          for (int w = 1; w < NW; ++w) sum += r[w * 64 + lane];
-          const int nb = (blk + wave * G) * 16 + kb * 4;
-          if (nb < a.N && fr < a.M) store_quad<P>(a, sum, fr, nb);
-        }
+        meet(p0, p1, p2, blk, n_own);
         return;
       }
     }

@@ -312,3 +312,55 @@ def test_vendor_library_is_not_a_link_dependency():
     needed = [ln for ln in out.splitlines() if "NEEDED" in ln]
     assert needed, "readelf gave no dynamic section"
     assert not any("hipblaslt" in ln.lower() for ln in needed), needed
+
+
+def _gfx950_code_objects(path):
+    """the device ELFs inside the library's .hip_fatbin section (one clang offload bundle per translation unit)"""
+    import struct
+    import subprocess
+    blob = subprocess.run(["objcopy", "-O", "binary", "--only-section=.hip_fatbin", path, "/dev/stdout"], capture_output=True).stdout
+    magic, pos = b"__CLANG_OFFLOAD_BUNDLE__", 0
+    while True:
+        i = blob.find(magic, pos)
+        if i < 0:
+            return
+        n, = struct.unpack_from("<Q", blob, i + len(magic))
+        p = i + len(magic) + 8
+        for _ in range(n):
+            off, size, tl = struct.unpack_from("<QQQ", blob, p)
+            p += 24
+            triple = blob[p: p + tl].decode()
+            p += tl
+            if "gfx950" in triple and size:
+                yield blob[i + off: i + off + size]
+        pos = i + len(magic)
+
+
+def test_counted_decode_members_keep_their_loads_in_registers(tmp_path):
+    """The persistent decode member of the 4-bit Scale / Zeros formats issues its weight loads as inline assembly and counts the
+    waits by hand (csrc/wqaa_gemm_kernel.h, `issue` / `landed`): a register spill or an out-of-line call between a load and its
+    wait would copy registers the data has not reached yet - it did once (zeros-rescale, every output NaN).  The compiler's own
+    metadata of the BUILT library says whether that can happen: no scratch, no dynamic stack in any such instantiation."""
+    import re
+    import shutil
+    import subprocess
+    readelf = "/opt/rocm/lib/llvm/bin/llvm-readelf"
+    if not (os.path.exists(readelf) and shutil.which("objcopy")):
+        pytest.skip("no llvm-readelf / objcopy on this box")
+    seen = {}
+    for k, co in enumerate(_gfx950_code_objects(wlib.LIB_PATH)):
+        f = tmp_path / f"co{k}.elf"
+        f.write_bytes(co)
+        notes = subprocess.run([readelf, "--notes", str(f)], capture_output=True, text=True).stdout
+        for blk in re.split(r"\n\s+- \.agpr_count:", notes):
+            m = re.search(r"\.name:\s+(_ZN4wqaa25wq_gemm_decode_lds_kernelINS_10GemmPolicyILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)E\S*)", blk)
+            if not m:
+                continue
+            kind, _layout, at, mode = (int(m.group(j)) for j in (2, 3, 4, 5))
+            if kind in (0, 4) and at == 0 and mode in (1, 2, 3):                 # DK_INT4 / DK_LUT4, 16-bit float activations, MD_S / ZO / ZR
+                scratch = int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", blk).group(1))
+                dyn = re.search(r"\.uses_dynamic_stack:\s+(\w+)", blk)
+                seen[m.group(1)] = (scratch, dyn.group(1) if dyn else "false")
+    assert len(seen) >= 8, sorted(seen)                                          # {int4, lut4} x layouts x modes x {f16, bf16}, as instantiated
+    bad = {k: v for k, v in seen.items() if v != (0, "false")}
+    assert not bad, bad

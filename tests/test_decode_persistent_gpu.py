@@ -40,6 +40,14 @@ def test_uint4_scale_zeros(M, N, K, monkeypatch):
     _both(case, M, monkeypatch)
 
 
+@pytest.mark.parametrize("M", [4, 16])
+@pytest.mark.parametrize("N", [12928, 16544, 22016])
+def test_four_to_six_fragments_per_workgroup(M, N, monkeypatch):
+    """the hand-counted form's second batch (the first batch's registers refilled as they are consumed): 3.2 / 4.04 / 5.4 rounds of fragments"""
+    case = make_case(M, N, 4096, W_dtype="uint4", group_size=128, with_scaling=True, with_zeros=True, zeros_mode="original", scale_mul=0.05, seed=M + N)
+    _both(case, M, monkeypatch)
+
+
 @pytest.mark.parametrize("zeros_mode", ["rescale", "quantized"])
 def test_other_zero_point_forms_and_bias(zeros_mode, monkeypatch):
     case = make_case(9, 8192 + 32, 1024, W_dtype="uint4", group_size=128, with_scaling=True, with_zeros=True, zeros_mode=zeros_mode, with_bias=True,
@@ -57,8 +65,8 @@ def test_formats_and_widths_that_measured_no_better_keep_their_members():
     """int2 x int8 and outputs beyond three rounds of fragments (22016 x 4096): the skinny member + reduce stays (profiles/r04_ab_decode_persistent.txt)"""
     mm = bitblas.Matmul(bitblas.MatmulConfig(M=8, N=11008, K=4096, A_dtype="int8", W_dtype="int2", accum_dtype="int32", out_dtype="int32"), enable_tuning=False)
     assert not mm.plans[8]["name"].endswith("xdlp"), mm.plans[8]["name"]
-    mm = bitblas.Matmul(bitblas.MatmulConfig(M=8, N=22016, K=4096, A_dtype="float16", W_dtype="uint4", group_size=128, with_scaling=True), enable_tuning=False)
-    assert not mm.plans[8]["name"].endswith("xdlp"), mm.plans[8]["name"]
+    mm = bitblas.Matmul(bitblas.MatmulConfig(M=8, N=22016, K=4096, A_dtype="float16", W_dtype="uint4", group_size=-1, with_scaling=True), enable_tuning=False)
+    assert not mm.plans[8]["name"].endswith("xdlp"), mm.plans[8]["name"]       # (per-channel scales: the compiler-tracked form, three rounds at most)
 
 
 @pytest.mark.parametrize("M", [4, 16])
