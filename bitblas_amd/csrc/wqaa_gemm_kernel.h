@@ -1279,6 +1279,22 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_decode_lds_kernel(const Ge
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Ap + (long)t * ASTEP + dsrc[q]),
                                          (__attribute__((address_space(3))) void*)(region + s * STEP_BYTES + q * 1024), 16, 0, 0);
   };
+  // the same as instructions the compiler does NOT see (M0 = the LDS address, saved and put back).  With the builtin its scoreboard
+  // makes the first LDS read wait for EVERY load in flight - LDS-DMA and register loads do not retire in one order as far as it
+  // knows - so nothing could be asked for ahead of a tile.  Loads do return in order: whoever issues these counts the waits
+  // (an explicit s_waitcnt that leaves only loads YOUNGER than the tile outstanding) and keeps the LDS reads below that wait.
+  const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem_raw;
+  auto dma_step_unseen = [&](int t, int s) __attribute__((always_inline)) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (q < nq) {
+        const unsigned char* src = Ap + (long)t * ASTEP + dsrc[q];
+        const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_base + (uint32_t)(wave * REGION + s * STEP_BYTES + q * 1024));
+        uint32_t keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+      }
+  };
 
   constexpr bool WIDE_OK = MODE == MD_S || MODE == MD_ZO || MODE == MD_ZR;
   const bool wide = WIDE_OK && a.gq_shift == 2 && (a.kg & 3) == 0;   // one group per k-step: 8-byte metadata loads per block
@@ -1396,12 +1412,13 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_decode_lds_kernel(const Ge
         };
         const int G = (int)gridDim.x;
         const int n_own = (nfrags - 1 - blk) / G + 1;      // fragments of this workgroup: 1 .. 3
+        // the activations by LDS-DMA the compiler does not see: the tile need not land BEFORE the weights are asked for (it did with
+        // the builtin: one exposed L2 round trip) - loads return in order, the first fragment's wait covers the tile
 #pragma unroll
         for (int i = 0; i < PF; ++i) {
           const int t = t_lo + i;
-          dma_step(t < nsteps ? t : last, i);
+          dma_step_unseen(t < nsteps ? t : last, i);
         }
-        __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0): the tile has landed
         auto issue = [&](int frag, AF& f) __attribute__((always_inline)) {
           set_fragment(frag);
           f.row = nrow;
@@ -1615,6 +1632,11 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_decode_lds_kernel(const Ge
     }
     return;
   }
+  // (Round 4, measured and NOT kept - tools/r04_decode_longk_probe.py, profiles/r04_decode_longk.txt: asking for the NEXT block's weights
+  // before this block is multiplied, with the tile's DMA out of the compiler's sight and a marker load behind it so that the waits
+  // stay counted.  Bit-identical and slower, 10.98 -> 12.08 us at 4096 x 11008 M = 4: loads return in order, so the tile - which
+  // cannot be asked for before the previous block's LDS reads are done - returns behind every weight load asked for earlier;
+  // one block ahead hides one block's multiply (~0.3 us) of a ~2 us round trip and costs the marker.)
   for (int s0 = 0; s0 < my_steps; s0 += PF) {
     BLane<P> bs[PF];
     u32x2 gs = {0u, 0u}, gz = {0u, 0u};
