@@ -319,7 +319,10 @@ static int gemm_choose(const wqaa_matmul_desc& d, int m, GemmChoice* c, bool fus
   if (const char* f = getenv("WQAA_GEMM_DECODE_MAXM")) decode_max_m = atoi(f);   // tuning aid
   // (the direct-load member, which only packed-int4 activations still use: M <= 8 up to 1.5 rounds, M = 9..16 between
   // 0.75 and 1 round - the round-1 table above)
-  bool decode_fits = c->at != AT_I4 ? (frags <= cus_ || frags == 2 * cus_ || (m <= 8 && frags <= 2 * cus_))
+  // (two whole rounds of fragments at M = 9 ... 16: a tie with the split-K skinny member at K = 8192 - 19.2 vs 19.4 us at 8192^2 - and
+  // behind it on longer K, where the activations' L2 traffic of the second round costs more than the reduce launch: 8192 x 28672
+  // M = 16 59.4 vs 54.2 us, profiles/r04_decode_longk.txt; measured for 16-bit activations only: the rule is theirs)
+  bool decode_fits = c->at != AT_I4 ? (frags <= cus_ || (frags == 2 * cus_ && (m <= 8 || d.K <= 8192 || c->at != AT_F16)) || (m <= 8 && frags <= 2 * cus_))
                                     : (m <= 8 ? frags <= cus_ + cus_ / 2 : (frags <= cus_ && 4 * frags >= 3 * cus_));
   // round 4 - the PERSISTENT form of member 211: where every wave's k-range is one block of 4 k-steps (K <= 32 k-steps: 4096 for the
   // float types, 8192 for int8) a workgroup stages the activations once and takes fragments blk, blk + grid, ... with the next
