@@ -92,6 +92,7 @@ struct GemmChoice {
   // the remainder of a partial round of 256 x 256 tiles as a second launch of the 128 x 256 member over the last N-tiles
   gemm_fn tail_fn;
   int tail_lds, tail_tiles_m, tail_tiles_n;
+  int decode_long;      // the one-launch decode member stages the wave's whole k-range (M-sized slots) and walks units (fragment, k-block)
   int decode_grid;      // > 0: the persistent form of the one-launch decode member (grid < number of 16-row fragments)
   int pp_avail;         // m > 128: a fused ping-pong member takes this descriptor (whether or not the round estimate chose it here)
 };
@@ -103,6 +104,7 @@ static int gemm_choose(const wqaa_matmul_desc& d, int m, GemmChoice* c, bool fus
   c->tail_lds = c->tail_tiles_m = c->tail_tiles_n = 0;
   c->pp_avail = 0;
   c->decode_grid = 0;
+  c->decode_long = 0;
   c->flags = 0;
   c->layout = d.w_layout == WQAA_LAYOUT_LOP3 ? LAYOUT_LOP3 : LAYOUT_PLAIN;
   if (a == WQAA_F16) c->at = AT_F16;
@@ -336,11 +338,24 @@ static int gemm_choose(const wqaa_matmul_desc& d, int m, GemmChoice* c, bool fus
     // than the skinny member + reduce)
     // (the hand-counted form - 4-bit weights, one Scale / Zeros group per k-step - takes up to six rounds of fragments, two batches)
     const bool counted = c->at == AT_F16 && (c->kind == DK_INT4 || c->kind == DK_LUT4) && (c->mode == MD_S || c->mode == MD_ZO || c->mode == MD_ZR) &&
-                         g == c->ks && ((d.K / g) & 3) == 0;
+                         g == c->ks && ((d.K / g) & 1) == 0;     // (8-byte metadata loads as instructions: 4-byte alignment)
     persist = (c->at == AT_F16 || c->at == AT_F8) && frags > cus_ && frags <= (counted ? 6 : 3) * cus_ && nsteps <= 8 * 4 && (!pf || atoi(pf) != 0);
+    // round 4 - WHOLE TILE, K > 4096 (hand-counted formats): a wave's k-range is nbk = 2 or 3 blocks of 4 k-steps; with slots of
+    // nq = ceil(M / 4) KiB per k-step (only the row groups below M) it fits the wave's 16 KiB region for M <= 8 (nbk 2: K <= 8192)
+    // and M <= 4 (nbk 3: K <= 12288); units (fragment, block) <= 6 per workgroup.  WQAA_GEMM_DECODE_LONG=0: off.
+    const char* lf = getenv("WQAA_GEMM_DECODE_LONG");
+    const int run = (((nsteps + 7) / 8) + 3) & ~3, nbk = run / 4, nq = (m + 3) / 4;
+    // Taken where there is more than one fragment per workgroup (12288 x 8192 M = 3 / 8: 22.2 / 23.7 us on the skinny member -> 17.7 /
+    // 18.0, 8192^2 15.0 / 16.2 -> 12.7 / 13.4, 10240 x 8192 20.2 / 21.2 -> 17.4 / 17.8); with one fragment each (N <= 4096) asking for
+    // everything at once measured the same as block by block - 4096 x 11008 M = 4 10.8 vs 11.0 us - and the old form stays
+    // (profiles/r04_ab_decode_long.txt).
+    if (counted && nbk >= 2 && nbk <= 3 && run * nq <= 16 && frags > cus_ && frags <= (6 / nbk) * cus_ && (!lf || atoi(lf) != 0)) {
+      c->decode_long = 1;
+      persist = true;
+    }
   }
   const bool fits_one_each = decode_fits;     // (the rule for one fragment per workgroup)
-  if (persist) decode_fits = true;
+  if (persist || c->decode_long) decode_fits = true;
   if (const char* f = getenv("WQAA_GEMM_DECODE_FORCE")) decode_fits = atoi(f) != 0;   // tuning aid
   if (m <= decode_max_m && m <= 16 && c->mf == 1 && decode_fits) {
     const char* dflag = getenv("WQAA_GEMM_DECODE");
@@ -364,6 +379,7 @@ static int gemm_choose(const wqaa_matmul_desc& d, int m, GemmChoice* c, bool fus
       c->decode = lds_member ? 2 : 1;
       // persistent: a grid of one workgroup per CU (whole XCD rounds keep the block swizzle on); the direct-load member has no such form
       c->decode_grid = (lds_member && persist) ? (cus_ / 8) * 8 : 0;
+      if (!lds_member) c->decode_long = 0;
       if (lds_member || fits_one_each) return WQAA_OK;
       c->fn = nullptr;                       // (persistent asked for, but this format has only the direct-load member)
     }
@@ -439,7 +455,7 @@ int gemm_plan(const wqaa_matmul_desc& d, int m, wqaa_plan* plan, bool fused_epil
     char tail[16] = "";
     if (c.tail_fn) snprintf(tail, sizeof(tail), "t%d", c.tail_tiles_n);      // "ppt11": the last 11 N-tiles as a launch of the 128-row tile
     snprintf(plan->name, sizeof(plan->name), "matmul_m%dn%dk%d_%sx%s_tcx%dx%dx%d%s%s%s", m, d.N, d.K, short_dtype(d.a_dtype),
-             wd, 16 * c.mf, c.bn, c.ks, c.ksplit > 1 ? "xr" : "", c.pp ? "pp" : c.skinny ? "xs" : c.decode == 2 ? (c.decode_grid > 0 ? "xdlp" : "xdl") : c.decode ? "xd" : c.wide ? "xw" : "", tail);
+             wd, 16 * c.mf, c.bn, c.ks, c.ksplit > 1 ? "xr" : "", c.pp ? "pp" : c.skinny ? "xs" : c.decode == 2 ? (c.decode_long ? "xdlt" : c.decode_grid > 0 ? "xdlp" : "xdl") : c.decode ? "xd" : c.wide ? "xw" : "", tail);
   }
   return WQAA_OK;
 }
@@ -531,6 +547,7 @@ int gemm_launch(const wqaa_matmul_desc& d, const void* A, const void* B, const v
     a.ws_policy = policy >= 0 ? policy : (3 | (out_bytes >= (4L << 20) ? 16 : 0));
   }
   a.nsteps = d.K / c.ks;
+  a.decode_long = c.decode == 2 ? c.decode_long : 0;
   if (c.pp) {                               // the ping-pong member reads gq_shift as log2(k-bodies per group)
     a.gq_shift = c.pp_shift;
     a.gq_magic = 0u;

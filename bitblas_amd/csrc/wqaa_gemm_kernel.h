@@ -68,6 +68,7 @@ struct GemmArgs {
   // reciprocals of the tile map's divisors (tile_magic; 0 = divide): a uniform integer division is ~25 instructions of
   // float reciprocal + fix-up on this ISA (a 64-bit one ~150) and the tile map had five of them in front of the first load
   uint32_t mg_ntiles = 0, mg_per_group = 0, mg_group_m = 0, mg_tail_m = 0, mg_ksplit = 0;
+  int decode_long = 0; // one-launch decode member: the wave's WHOLE k-range of the activations fits its LDS region in M-sized slots (wq_gemm_decode_lds_kernel)
   int tile_n_off = 0;  // ping-pong members: first N-tile of this launch (a launch may cover a band of the output's columns: the
                        // remainder of a partial round goes out as a second launch of the 128-row tile, csrc/wqaa_gemm.hip)
 };
@@ -1284,12 +1285,12 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_decode_lds_kernel(const Ge
   // knows - so nothing could be asked for ahead of a tile.  Loads do return in order: whoever issues these counts the waits
   // (an explicit s_waitcnt that leaves only loads YOUNGER than the tile outstanding) and keeps the LDS reads below that wait.
   const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem_raw;
-  auto dma_step_unseen = [&](int t, int s) __attribute__((always_inline)) {
+  auto dma_step_unseen = [&](int t, int slot_off) __attribute__((always_inline)) {
 #pragma unroll
     for (int q = 0; q < 4; ++q)
       if (q < nq) {
         const unsigned char* src = Ap + (long)t * ASTEP + dsrc[q];
-        const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_base + (uint32_t)(wave * REGION + s * STEP_BYTES + q * 1024));
+        const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_base + (uint32_t)(wave * REGION + slot_off + q * 1024));
         uint32_t keep;
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                      : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
@@ -1326,7 +1327,7 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_decode_lds_kernel(const Ge
 
   acc_t acc = acc_t{0, 0, 0, 0};
   int zq_row = nrow;                                            // (packed zero points: the row the fragment in hand was loaded for)
-  auto compute = [&](const BLane<P>& bl, int s) __attribute__((always_inline)) {
+  auto compute = [&](const BLane<P>& bl, int slot_off) __attribute__((always_inline)) {     // slot_off: the k-step's slot in the wave's region, bytes
     uint32_t bfrag[NJ][4];
     if constexpr (F16) {
       half_t zf = cx.zf;
@@ -1354,7 +1355,7 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_decode_lds_kernel(const Ge
     // weight word is here the activations are too.  The compiler does not know the ds_reads depend on the DMA: tie
     // their address to the weight word (an empty asm that "rewrites" the offset after reading the word), so the
     // reads are ordered after the vmcnt wait it inserts for the weights.
-    uint32_t roff = (uint32_t)(s * STEP_BYTES + fr * P::ROW_BYTES);
+    uint32_t roff = (uint32_t)(slot_off + fr * P::ROW_BYTES);
     asm volatile("" : "+v"(roff) : "v"(bl.w[0][0]));
     const unsigned char* rowp = region + roff;
 #pragma unroll
@@ -1392,38 +1393,38 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_decode_lds_kernel(const Ge
   const int t_lo = wave * run;
   const int my_steps = t_lo >= nsteps ? 0 : (nsteps - t_lo < run ? nsteps - t_lo : run);   // wave-uniform
   acc_t* red = reinterpret_cast<acc_t*>(smem_raw + NW * REGION);
-  if (persistent) {
-    // (the launcher guarantees run <= PF - one block per wave - and at most three fragments per workgroup; six for the form below)
-    // 4-bit weights with one Scale / Zeros group per k-step (the headline formats): the walk in straight line with every load an
-    // inline-assembly instruction and every wait counted by hand.  With compiler-tracked loads the first read of the staged tile
-    // waited for ALL loads in flight - LDS-DMA and register loads do not retire in one order, so the compiler assumes the worst -
-    // and a refill behind a test ended in a copy that did the same: 11.6 us at 11008 x 4096 where the weight stream needs ~6.
-    // Here the activations land first (one exposed L2 round trip, the s_waitcnt below tells the compiler's scoreboard so), then
-    // all the workgroup's fragments are asked for at once and fragment i is multiplied while i + 1, i + 2 are still arriving.
-    // A wave's own vmcnt retires in order for loads of ONE kind; wave 0's stores in between only make a wait stricter.
-    if constexpr (WL == 4 && WIDE_OK) {
-      if (wide) {
+  // ---- the hand-counted forms: 4-bit weights with one Scale / Zeros group per k-step (the headline formats) --------------------------
+  // PERSISTENT (the launcher guarantees run <= PF - one block per wave - and at most six fragments per workgroup): the walk in
+  // straight line with every load an inline-assembly instruction and every wait counted by hand.  With compiler-tracked loads the
+  // first read of the staged tile waited for ALL loads in flight - LDS-DMA and register loads do not retire in one order, so the
+  // compiler assumes the worst - and a refill behind a test ended in a copy that did the same: 11.6 us at 11008 x 4096 where the
+  // weight stream needs ~6.  Here the tile and ALL the workgroup's fragments are asked for at once and fragment i is multiplied
+  // while i + 1, i + 2 are still arriving.  A wave's own vmcnt retires in order; wave 0's stores in between only make a wait stricter.
+  // WHOLE TILE (a.decode_long, K > 4096): the wave's k-range is NBK = 2 or 3 blocks; its activations fit the region when a k-step's
+  // slot holds only the row groups below M (nq KiB instead of 4: the MFMA's rows >= 4 nq read the slots behind - never stored), so
+  // the tile is staged once here too and the walk is over UNITS (fragment, block), three in flight, fragment-major - instead of
+  // blocks drained one by one at ~2 TB/s (profiles/r04_decode_longk.txt).  Same k order per wave, same meeting: bit-identical.
+  if constexpr (WL == 4 && WIDE_OK) {
+      // (8-byte metadata loads as instructions need 4-byte alignment only: K / g even.  Where K / g is not a multiple of 4 the last
+      // block's load is moved back to end inside the row and the halves are taken `sh` groups further on)
+      const bool wide_c = a.gq_shift == 2 && (a.kg & 1) == 0;
+      if (wide_c && (persistent || a.decode_long)) {
         constexpr bool ZP = MODE == MD_ZO || MODE == MD_ZR;
-        constexpr int NOPS = PF + 1 + (ZP ? 1 : 0);        // loads per fragment and lane
+        constexpr int NOPS = PF + 1 + (ZP ? 1 : 0);        // loads per unit and lane
         struct AF {
           u32x4 w[PF];
           u32x2 gs, gz;
-          int row;
+          int row, sh;
         };
         const int G = (int)gridDim.x;
-        const int n_own = (nfrags - 1 - blk) / G + 1;      // fragments of this workgroup: 1 .. 3
-        // the activations by LDS-DMA the compiler does not see: the tile need not land BEFORE the weights are asked for (it did with
-        // the builtin: one exposed L2 round trip) - loads return in order, the first fragment's wait covers the tile
-#pragma unroll
-        for (int i = 0; i < PF; ++i) {
-          const int t = t_lo + i;
-          dma_step_unseen(t < nsteps ? t : last, i);
-        }
-        auto issue = [&](int frag, AF& f) __attribute__((always_inline)) {
+        const int n_own = (nfrags - 1 - blk) / G + 1;      // fragments of this workgroup
+        auto issue_blk = [&](int frag, int j, AF& f) __attribute__((always_inline)) {          // block j of the wave's k-range
           set_fragment(frag);
           f.row = nrow;
-          int base = t_lo < a.kg - 4 ? t_lo : a.kg - 4;
+          const int t0 = t_lo + j * PF;
+          int base = t0 < a.kg - 4 ? t0 : a.kg - 4;
           base = base < 0 ? 0 : base;
+          f.sh = (t0 - base) & 3;
           const uint16_t* sp = Sp + srow + base;
           asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(f.gs) : "v"(sp) : "memory");
           if constexpr (ZP) {
@@ -1434,12 +1435,13 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_decode_lds_kernel(const Ge
           }
 #pragma unroll
           for (int i = 0; i < PF; ++i) {
-            int t = t_lo + i;
+            int t = t0 + i;
             t = t < nsteps ? t : last;
             const uint8_t* wp = brow + (long)t * (4 * WL * 4);
             asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(f.w[i]) : "v"(wp) : "memory");
           }
         };
+        auto issue = [&](int frag, AF& f) __attribute__((always_inline)) { issue_blk(frag, 0, f); };
         // the wait hands the fragment's registers on: nothing that reads them can be scheduled above it.
         // CONTRACT with the compiler: between a load and its wait the destination registers must stay where they are - a spill
         // or an out-of-line call (captures on the stack) would copy them before the data is there.  Hence every lambda of this
@@ -1455,17 +1457,22 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_decode_lds_kernel(const Ge
           else
             asm volatile("s_waitcnt vmcnt(%5)" : "+v"(f.w[0]), "+v"(f.w[1]), "+v"(f.w[2]), "+v"(f.w[3]), "+v"(f.gs) : "n"(ny) : "memory");
         };
-        auto multiply = [&](const AF& f) __attribute__((always_inline)) -> acc_t {
-          acc = acc_t{0, 0, 0, 0};
+        auto multiply_blk = [&](const AF& f, int j, int slot_bytes) __attribute__((always_inline)) {   // acc += block j (slots of slot_bytes)
           zq_row = f.row;
+          const uint64_t s64 = (((uint64_t)f.gs[1] << 32) | f.gs[0]) >> (16 * f.sh);
+          const uint64_t z64 = (((uint64_t)f.gz[1] << 32) | f.gz[0]) >> (16 * f.sh);
 #pragma unroll
           for (int i = 0; i < PF; ++i) {
             BLane<P> bl;
             bl.w[0][0] = f.w[i][0]; bl.w[0][1] = f.w[i][1]; bl.w[0][2] = f.w[i][2]; bl.w[0][3] = f.w[i][3];
-            bl.s[0] = (f.gs[i >> 1] >> (16 * (i & 1))) & 0xFFFFu;
-            bl.z[0] = (f.gz[i >> 1] >> (16 * (i & 1))) & 0xFFFFu;
-            if (i < my_steps) compute(bl, i);
+            bl.s[0] = (uint32_t)(s64 >> (16 * i)) & 0xFFFFu;
+            bl.z[0] = (uint32_t)(z64 >> (16 * i)) & 0xFFFFu;
+            if (j * PF + i < my_steps) compute(bl, (j * PF + i) * slot_bytes);
           }
+        };
+        auto multiply = [&](const AF& f) __attribute__((always_inline)) -> acc_t {
+          acc = acc_t{0, 0, 0, 0};
+          multiply_blk(f, 0, STEP_BYTES);
           return acc;
         };
         // the waves meet once per batch of (up to) three fragments, with their partial sums of the whole batch (three sets of
@@ -1487,6 +1494,71 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_decode_lds_kernel(const Ge
         AF f0, f1, f2;
         const acc_t zero = acc_t{0, 0, 0, 0};
         acc_t p0 = zero, p1 = zero, p2 = zero;
+        if (a.decode_long) {
+          const int slot_bytes = nq * 1024;
+          // units u = (fragment u / NBK, block u % NBK), registers u % 3; a wait counts the loads of the units issued after u
+          auto long_walk = [&](auto NOWN_, auto NBK_) __attribute__((always_inline)) {
+            constexpr int NOWN = decltype(NOWN_)::value, NBK = decltype(NBK_)::value, U = NOWN * NBK;
+            static_assert(U <= 6 && NOWN <= 3, "units");
+#pragma unroll
+            for (int sidx = 0; sidx < NBK * PF; ++sidx) {
+              const int t = t_lo + sidx;
+              dma_step_unseen(t < nsteps ? t : last, sidx * slot_bytes);
+            }
+            auto regs = [&](auto UC) __attribute__((always_inline)) -> AF& {
+              constexpr int r = decltype(UC)::value % 3;
+              if constexpr (r == 0) return f0;
+              else if constexpr (r == 1) return f1;
+              else return f2;
+            };
+            auto ask = [&](auto UC) __attribute__((always_inline)) {
+              constexpr int u = decltype(UC)::value;
+              if constexpr (u < U) issue_blk(blk + (u / NBK) * G, u % NBK, regs(UC));
+            };
+            auto unit = [&](auto UC) __attribute__((always_inline)) {
+              constexpr int u = decltype(UC)::value;
+              if constexpr (u < U) {
+                constexpr int after = (U - 1 < u + 2 ? U - 1 : u + 2) - u;
+                landed(std::integral_constant<int, after * NOPS>{}, regs(UC));
+                if constexpr (u % NBK == 0) acc = zero;
+                multiply_blk(regs(UC), u % NBK, slot_bytes);
+                if constexpr (u % NBK == NBK - 1) {
+                  if constexpr (u / NBK == 0) p0 = acc;
+                  else if constexpr (u / NBK == 1) p1 = acc;
+                  else p2 = acc;
+                }
+                ask(std::integral_constant<int, u + 3>{});
+              }
+            };
+            ask(std::integral_constant<int, 0>{});
+            ask(std::integral_constant<int, 1>{});
+            ask(std::integral_constant<int, 2>{});
+            unit(std::integral_constant<int, 0>{});
+            unit(std::integral_constant<int, 1>{});
+            unit(std::integral_constant<int, 2>{});
+            unit(std::integral_constant<int, 3>{});
+            unit(std::integral_constant<int, 4>{});
+            unit(std::integral_constant<int, 5>{});
+            meet(p0, p1, p2, blk, NOWN);
+          };
+          using std::integral_constant;
+          const int nbk = run / PF;                            // (the launcher: nbk = 2, 3; nbk * PF * nq <= 16 slots of 1 KiB; n_own * nbk <= 6)
+          if (nbk == 2) {
+            if (n_own == 1) long_walk(integral_constant<int, 1>{}, integral_constant<int, 2>{});
+            else if (n_own == 2) long_walk(integral_constant<int, 2>{}, integral_constant<int, 2>{});
+            else long_walk(integral_constant<int, 3>{}, integral_constant<int, 2>{});
+          } else {                                             // nbk == 3
+            if (n_own == 1) long_walk(integral_constant<int, 1>{}, integral_constant<int, 3>{});
+            else long_walk(integral_constant<int, 2>{}, integral_constant<int, 3>{});
+          }
+          return;
+        }
+        // (persistent) the tile: one block per wave
+#pragma unroll
+        for (int i = 0; i < PF; ++i) {
+          const int t = t_lo + i;
+          dma_step_unseen(t < nsteps ? t : last, i * STEP_BYTES);
+        }
         if (n_own > 3) {
           // four to six fragments: the second batch refills the first one's registers as they are consumed.  NB2 = fragments of the
           // second batch; a wait counts the loads issued after the fragment it is for
@@ -1549,7 +1621,8 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_decode_lds_kernel(const Ge
         meet(p0, p1, p2, blk, n_own);
         return;
       }
-    }
+  }
+  if (persistent) {
     struct FragLoad {
       BLane<P> bs[PF];
       u32x2 gs, gz;
@@ -1581,7 +1654,7 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_decode_lds_kernel(const Ge
           f.bs[i].s[0] = (f.gs[i >> 1] >> (16 * (i & 1))) & 0xFFFFu;
           f.bs[i].z[0] = (f.gz[i >> 1] >> (16 * (i & 1))) & 0xFFFFu;
         }
-        if (i < my_steps) compute(f.bs[i], i);
+        if (i < my_steps) compute(f.bs[i], i * STEP_BYTES);
       }
       // two sets of meeting slots: the waves may be a fragment ahead of the one that sums
       acc_t* r = red + parity * (NW * 64);
@@ -1665,7 +1738,7 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_decode_lds_kernel(const Ge
         bs[i].s[0] = (gs[i >> 1] >> (16 * (i & 1))) & 0xFFFFu;
         bs[i].z[0] = (gz[i >> 1] >> (16 * (i & 1))) & 0xFFFFu;
       }
-      if (s0 + i < my_steps) compute(bs[i], i);
+      if (s0 + i < my_steps) compute(bs[i], i * STEP_BYTES);
       WQ_TRACE_IF(s0 == 0 && i == 0, 2);
       WQ_TRACE_IF(s0 == 0 && i == PF - 2, 3);
     }

@@ -179,7 +179,7 @@ def test_selector_invariants_over_a_random_configuration_sweep():
     kernel-name style (general_matmul/__init__.py:240-318) - and a refusal must carry a message."""
     import re
     rng = np.random.default_rng(7)
-    name_re = re.compile(r"^matmul_m\d+n\d+k\d+_[a-z0-9]+x[a-z0-9_]+_(gemv_b\d+r\d+d\d+(k\d+)?(_areg)?|gemvx_b\d+r\d+d\d+k\d+(_areg)?|(dq_)?tcx\d+x\d+x\d+(xr)?(pp(t\d+)?|xs|xdlp?|xd|xw)?)$")
+    name_re = re.compile(r"^matmul_m\d+n\d+k\d+_[a-z0-9]+x[a-z0-9_]+_(gemv_b\d+r\d+d\d+(k\d+)?(_areg)?|gemvx_b\d+r\d+d\d+k\d+(_areg)?|(dq_)?tcx\d+x\d+x\d+(xr)?(pp(t\d+)?|xs|xdl[pt]?|xd|xw)?)$")
     pairs = [(wlib.F16, wlib.W_UINT, b) for b in (1, 2, 4, 8)] + [(wlib.F16, wlib.W_INT, b) for b in (1, 2, 4, 8)] + \
             [(wlib.F16, wlib.W_NF, 4), (wlib.F16, wlib.W_FP4, 4), (wlib.F16, wlib.W_E4M3, 8),
              (wlib.BF16, wlib.W_UINT, 4), (wlib.BF16, wlib.W_NF, 4),

@@ -97,3 +97,49 @@ def test_long_rows_keep_the_one_fragment_form():
     """K beyond one block per wave (4096 x 11008): the activations of a wave do not stay staged - one fragment per workgroup as before"""
     mm = bitblas.Matmul(bitblas.MatmulConfig(M=8, N=8192, K=11008, A_dtype="float16", W_dtype="uint4", group_size=128, with_scaling=True), enable_tuning=False)
     assert not mm.plans[8]["name"].endswith("xdlp"), mm.plans[8]["name"]
+
+
+def _long_both(case, M, monkeypatch, want_long=True):
+    """whole-tile form (`xdlt`) against the oracle and, bit for bit, against the block-by-block form of the same kernel"""
+    for k in ("WQAA_GEMM_DECODE_PERSIST", "WQAA_GEMM_DECODE_FORCE", "WQAA_GEMM_DECODE_LONG"):
+        monkeypatch.delenv(k, raising=False)
+    got, mm = hip_output(case)
+    assert mm.plans[M]["name"].endswith("xdlt") == want_long, mm.plans[M]["name"]
+    assert_fp_parity(got, oracle_output(case))
+    monkeypatch.setenv("WQAA_GEMM_DECODE_LONG", "0")
+    monkeypatch.setenv("WQAA_GEMM_DECODE_FORCE", "1")
+    one, mm1 = hip_output(case)
+    assert mm1.plans[M]["name"].endswith("xdl"), mm1.plans[M]["name"]
+    assert np.array_equal(got.view(np.uint16), one.view(np.uint16))
+
+
+@pytest.mark.parametrize("M,N,K", [(3, 8192, 11008), (4, 4096 + 48, 11008), (4, 8192 - 16, 12288),                      # three blocks per wave: M <= 4, two fragments
+                                   (5, 4096 + 16, 8192), (8, 8192, 8192), (7, 10240, 8192), (8, 3 * 4096, 8192), (3, 6144, 6144)])   # two: M <= 8, three fragments
+def test_whole_tile_form_on_long_k(M, N, K, monkeypatch):
+    """K > 4096: the wave's k-range is 2 ... 4 blocks, its activations fit in M-sized slots, units (fragment, block) are walked three
+    in flight (K / g = 86 at 11008 is even, not a multiple of 4: the last block's metadata load ends inside the row)"""
+    case = make_case(M, N, K, W_dtype="uint4", group_size=128, with_scaling=True, with_zeros=True, zeros_mode="original", scale_mul=0.05, seed=M + N + K)
+    _long_both(case, M, monkeypatch)
+
+
+@pytest.mark.parametrize("zeros_mode,wd", [("rescale", "uint4"), ("original", "int4"), (None, "nf4")])
+def test_whole_tile_form_other_formats(zeros_mode, wd, monkeypatch):
+    case = make_case(6, 8192 + 32, 8192, W_dtype=wd, group_size=128, with_scaling=True, with_zeros=zeros_mode is not None, zeros_mode=zeros_mode or "original",
+                     with_bias=True, scale_mul=0.05, seed=29)
+    _long_both(case, 6, monkeypatch)
+
+
+def test_whole_tile_form_keeps_to_what_fits(monkeypatch):
+    """M = 9 at K = 8192 (3 KiB slots x 8 k-steps), M = 5 at K = 11008 and seven blocks per wave (K = 28672) do not fit a 16 KiB region;
+    one fragment per workgroup measured no better than block by block and keeps the old form; four blocks allow one fragment only"""
+    for M, N, K in ((9, 8192, 8192), (5, 8192, 11008), (4, 8192, 28672), (4, 4096, 11008), (4, 4096 + 16, 14336)):        # (the last two: one fragment each / 4 x 2 units)
+        mm = bitblas.Matmul(bitblas.MatmulConfig(M=M, N=N, K=K, A_dtype="float16", W_dtype="uint4", group_size=128, with_scaling=True, with_zeros=True),
+                            enable_tuning=False)
+        assert not mm.plans[M]["name"].endswith("xdlt"), mm.plans[M]["name"]
+
+
+@pytest.mark.parametrize("M", [4, 16])
+def test_even_group_count_takes_the_counted_form(M, monkeypatch):
+    """K / g = 30: the hand-counted persistent form with 4-byte aligned metadata loads"""
+    case = make_case(M, 11008, 3840, W_dtype="uint4", group_size=128, with_scaling=True, with_zeros=True, zeros_mode="original", scale_mul=0.05, seed=M)
+    _both(case, M, monkeypatch)
