@@ -973,6 +973,11 @@ def main():
             member("gemm_uint4_m4096_two_pass_vendor", time_member_gemm, device, gen, 4096, tuned=True)
             member("gemm_uint4_m128", time_member_gemm, device, gen, 128)
             member("gemm_uint4_m16", time_member_gemm, device, gen, 16)
+            # decode batches on wide outputs (round 4): the persistent form of the one-launch decode member (a 7B model's gate / up and
+            # q/k/v widths, `...xdlp`) and its whole-tile form on long K (a 70B model's hidden size, `...xdlt`)
+            member("gemm_uint4_m8_n11008k4096", time_member_gemm, device, gen, 8, 11008, 4096)
+            member("gemm_uint4_m8_n22016k4096", time_member_gemm, device, gen, 8, 22016, 4096)
+            member("gemm_uint4_m8_n8192k8192", time_member_gemm, device, gen, 8, 8192, 8192)
             member("gemm_int2_int8_m4096", time_member_gemm, device, gen, 4096, W_dtype="int2", A_dtype="int8")
             member("gemm_int2_int8_m4096_bitnet", time_member_gemm, device, gen, 4096, W_dtype="int2", A_dtype="int8", bitnet=True)
             # the reference's plain matmul (float16 x float16, README.md support matrix): this library's dense member on the ping-pong
