@@ -364,3 +364,23 @@ def test_counted_decode_members_keep_their_loads_in_registers(tmp_path):
     assert len(seen) >= 8, sorted(seen)                                          # {int4, lut4} x layouts x modes x {f16, bf16}, as instantiated
     bad = {k: v for k, v in seen.items() if v != (0, "false")}
     assert not bad, bad
+
+
+def test_decode_batch_forms_are_chosen_where_they_were_measured(monkeypatch):
+    """one-launch decode member, round 4 (no device needed): persistent on wide outputs at K <= 4096 (`xdlp`, up to six rounds of
+    fragments for the hand-counted formats), whole tile on long K where M-sized slots fit (`xdlt`: M <= 8 at K <= 8192, M <= 4 at
+    K <= 12288, more than one fragment per workgroup), the block-by-block form otherwise"""
+    for k in ("WQAA_GEMM_DECODE_PERSIST", "WQAA_GEMM_DECODE_FORCE", "WQAA_GEMM_DECODE_LONG", "WQAA_GEMM_DECODE", "WQAA_GEMM_DECODE_LDS"):
+        monkeypatch.delenv(k, raising=False)
+
+    def name(m, N, K):
+        d = wlib.make_desc(N=N, K=K, a_dtype=wlib.F16, w_format=wlib.W_UINT, w_bits=4, out_dtype=wlib.F16, group_size=128, with_scaling=True,
+                           zeros_mode=wlib.Z_ORIGINAL, w_layout=wlib.LAYOUT_LOP3)
+        return wlib.select(d, m)["name"]
+
+    for m, N, K, suffix in ((8, 11008, 4096, "xdlp"), (16, 22016, 4096, "xdlp"), (3, 12288, 4096, "xdlp"), (8, 11008, 3840, "xdlp"),
+                            (8, 8192, 8192, "xdlt"), (3, 12288, 8192, "xdlt"), (4, 8192, 11008, "xdlt"), (4, 8176, 12288, "xdlt"),
+                            (9, 8192, 8192, "xdl"), (5, 8192, 11008, "xdl"), (4, 4096, 11008, "xdl"), (16, 4096, 4096, "xdl")):
+        assert name(m, N, K).endswith("_f16xu4_tcx16x16x128" + suffix), (m, N, K, name(m, N, K))
+    monkeypatch.setenv("WQAA_GEMM_DECODE_LONG", "0")
+    assert not name(8, 8192, 8192).endswith("xdlt")
