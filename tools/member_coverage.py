@@ -33,7 +33,7 @@ def reachable(with_args=False):
     i8 = [("int8", w) for w in ("int8", "int4", "uint4", "int2", "uint2", "int1")]
     f8 = [("e4m3_float8", "e4m3_float8"), ("e5m2_float8", "e5m2_float8")]
     i4 = [("int4", "int4"), ("int4", "int2")]
-    shapes = [(1024, 1024), (4096, 4096), (11008, 4096), (4096, 11008), (1024, 28672), (28672, 8192), (272, 2048), (5120, 4096), (2048, 8192)]
+    shapes = [(1024, 1024), (4096, 4096), (11008, 4096), (4096, 11008), (1024, 28672), (28672, 8192), (272, 2048), (5120, 4096), (2048, 8192), (4352, 8192)]
     ms = [1, 2, 3, 8, 16, 32, 64, 128, 256, 1024, 4096]
     seen = {}
     for (a, w) in f16 + bf16 + i8 + f8 + i4:
