@@ -1446,7 +1446,8 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_decode_lds_kernel(const Ge
         // CONTRACT with the compiler: between a load and its wait the destination registers must stay where they are - a spill
         // or an out-of-line call (captures on the stack) would copy them before the data is there.  Hence every lambda of this
         // kernel is always_inline, and tests/test_abi.py::test_counted_decode_members_keep_their_loads_in_registers reads the
-        // built library's metadata: no scratch, no stack in any instantiation that takes this path.  (The same walk with
+        // built library's metadata: no scratch, no stack in any instantiation that takes this path; tools/check_vmem_hazards.py
+        // (tests/test_vmem_hazard_checker.py) walks their disassembly: nothing touches a register a load is still to write.  (The same walk with
         // compiler-tracked loads needs no contract and was measured ~0.8 us slower at 11008 x 4096: where the one-, two- and
         // three-fragment paths share their first loads the compiler's count falls back to vmcnt(0).)
         auto landed = [&](auto NY, AF& f) __attribute__((always_inline)) {

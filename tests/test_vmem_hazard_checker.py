@@ -1,0 +1,79 @@
+"""tools/check_vmem_hazards.py: the static check that no instruction touches a VGPR an outstanding vector-memory load still has
+to write (in-order retirement, `s_waitcnt vmcnt(N)` = at most N outstanding).  It guards the hand-counted forms of the one-launch
+decode member (csrc/wqaa_gemm_kernel.h, DESIGN 3.2a''): their loads are inline assembly, invisible to the compiler's own wait
+insertion.  First the checker itself on hand-made instruction streams, then the built library."""
+import os
+import shutil
+import sys
+
+import pytest
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+import check_vmem_hazards as chk  # noqa: E402
+
+
+def _asm(*instrs):
+    """fake llvm-objdump lines: 4-byte instructions from address 0x1000 (an 8-byte one is written with a trailing '+')"""
+    lines, addr = [], 0x1000
+    for t in instrs:
+        wide = t.endswith("+")
+        t = t.rstrip("+")
+        lines.append(f"\t{t:<60}// {addr:012X}: 00000000")
+        addr += 8 if wide else 4
+    return lines
+
+
+def test_read_before_the_wait_is_found_and_the_wait_clears_it():
+    bad = _asm("global_load_dwordx4 v[4:7], v[0:1], off+", "v_add_u32_e32 v8, v4, v5", "s_endpgm")
+    assert [f[2] for f in chk.scan("k", bad)] == [[4, 5]]
+    good = _asm("global_load_dwordx4 v[4:7], v[0:1], off+", "s_waitcnt vmcnt(0)", "v_add_u32_e32 v8, v4, v5", "s_endpgm")
+    assert chk.scan("k", good) == []
+
+
+def test_counted_waits_follow_the_order_of_issue():
+    prog = ["global_load_dwordx4 v[4:7], v[0:1], off+", "global_load_dwordx4 v[8:11], v[0:1], off+", "global_load_lds_dwordx4 v[0:1], off+",
+            "global_store_dword v[2:3], v20, off+"]
+    # two operations younger than the second load: vmcnt(2) hands over both loads, vmcnt(3) only the first
+    assert chk.scan("k", _asm(*prog, "s_waitcnt vmcnt(2)", "v_mov_b32_e32 v30, v9", "s_endpgm")) == []
+    assert chk.scan("k", _asm(*prog, "s_waitcnt vmcnt(3)", "v_mov_b32_e32 v30, v5", "s_endpgm")) == []
+    assert len(chk.scan("k", _asm(*prog, "s_waitcnt vmcnt(3)", "v_mov_b32_e32 v30, v9", "s_endpgm"))) == 1
+    # overwriting a destination in flight (a spill reload, a copy) is a finding too
+    assert len(chk.scan("k", _asm(*prog, "v_mov_b32_e32 v10, 0", "s_waitcnt vmcnt(0)", "s_endpgm"))) == 1
+
+
+def test_paths_are_merged_by_age_and_exclusive_arms_do_not_alias():
+    # if / else: the load is in one arm, the constant in the other (what a linear scan would flag)
+    prog = _asm("s_cbranch_vccz 3",                                   # -> else arm
+                "global_load_dwordx2 v[96:97], v[0:1], off+",
+                "s_branch 1",                                         # -> join
+                "v_mov_b32_e32 v96, 0",
+                "s_waitcnt vmcnt(0)",
+                "v_add_u32_e32 v1, v96, v97",
+                "s_endpgm")
+    assert chk.scan("k", prog) == []
+    # a load issued before a loop and read inside it without a wait is found on the path around the back edge as well
+    loop = _asm("global_load_dword v5, v[0:1], off+",
+                "v_add_u32_e32 v6, 1, v6",
+                "s_cbranch_scc1 65534",                               # back to the add
+                "v_mov_b32_e32 v7, v5",
+                "s_endpgm")
+    assert [f[2] for f in chk.scan("k", loop)] == [[5]]
+
+
+def test_the_hand_counted_decode_kernels_of_the_built_library_are_clean():
+    from bitblas_amd import lib as wlib
+    if not (os.path.exists(chk.OBJDUMP) and shutil.which("objcopy")):
+        pytest.skip("no llvm-objdump / objcopy on this box")
+    import io
+    from contextlib import redirect_stdout
+    buf = io.StringIO()
+    old = sys.argv
+    sys.argv = ["check_vmem_hazards.py", "--lib", wlib.LIB_PATH]
+    try:
+        with redirect_stdout(buf):
+            rc = chk.main()
+    finally:
+        sys.argv = old
+    out = buf.getvalue()
+    assert rc == 0, out[-3000:]
+    assert "kernels checked, 0 with findings" in out and int(out.strip().split("\n")[-1].split()[0]) >= 8, out[-500:]

@@ -1,0 +1,233 @@
+#!/usr/bin/env python
+"""Static check of the built library: no instruction touches a VGPR that an OUTSTANDING vector-memory load still has to write.
+
+    python tools/check_vmem_hazards.py [--lib bitblas_amd/libwqaa_hip.so] [--match REGEX] [-v]
+
+Why: the hand-counted forms of `wq_gemm_decode_lds_kernel` (csrc/wqaa_gemm_kernel.h, DESIGN 3.2a'') issue their loads as inline
+assembly and count the `s_waitcnt vmcnt(N)` by hand - the compiler does not know the destination registers are in flight, so a
+spill, a copy or a re-use between a load and its wait would go unnoticed (it did once: every output NaN).  The model is the
+hardware's: vector-memory operations of a wave retire in order, `vmcnt(N)` waits until at most N are outstanding; loads AND
+stores count (gfx9 family).  Input: llvm-objdump of the code objects inside the library's .hip_fatbin.
+The analysis is a forward data flow over each kernel's control-flow graph (branch targets from the disassembly's addresses): the
+abstract state is the queue of outstanding operations' destination registers, youngest first; at a join the queues are merged
+position by position.  Compiler-tracked code passes by construction (the compiler's own waits satisfy the same model), so a
+finding is a place where hand-written loads and waits - or a future compiler - broke the contract."""
+from __future__ import annotations
+
+import argparse
+import os
+import re
+import struct
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+DEFAULT_MATCH = r"wq_gemm_decode_lds_kernelINS_10GemmPolicyILi[04]ELi\dELi0ELi[123]E"   # int4 / lut4, 16-bit activations, Scale (+ Zeros)
+
+
+def code_objects(path):
+    blob = subprocess.run(["objcopy", "-O", "binary", "--only-section=.hip_fatbin", path, "/dev/stdout"], capture_output=True).stdout
+    magic, pos = b"__CLANG_OFFLOAD_BUNDLE__", 0
+    while True:
+        i = blob.find(magic, pos)
+        if i < 0:
+            return
+        n, = struct.unpack_from("<Q", blob, i + len(magic))
+        p = i + len(magic) + 8
+        for _ in range(n):
+            off, size, tl = struct.unpack_from("<QQQ", blob, p)
+            p += 24
+            triple = blob[p: p + tl].decode()
+            p += tl
+            if "gfx950" in triple and size:
+                yield blob[i + off: i + off + size]
+        pos = i + len(magic)
+
+
+REG = re.compile(r"\bv(\d+)\b|\bv\[(\d+):(\d+)\]")
+
+
+def regs_of(text):
+    out = set()
+    for m in REG.finditer(text):
+        if m.group(1) is not None:
+            out.add(int(m.group(1)))
+        else:
+            out.update(range(int(m.group(2)), int(m.group(3)) + 1))
+    return out
+
+
+def first_operand_regs(ops):
+    return regs_of(ops.split(",")[0])
+
+
+VMEM = re.compile(r"^(global|buffer|flat|scratch)_(load|store|atomic)")
+ADDR = re.compile(r"//\s*([0-9A-Fa-f]+):")
+CAP = 64                                                        # vmcnt counts to 63
+
+
+def parse(lines):
+    """-> list of (address, opcode, operands, text)"""
+    out = []
+    for line in lines:
+        m = ADDR.search(line)
+        code = line.split("//")[0].strip()
+        if not m or not code or code.endswith(":"):
+            continue
+        parts = code.split(None, 1)
+        out.append((int(m.group(1), 16), parts[0], parts[1] if len(parts) > 1 else "", code))
+    return out
+
+
+def dest_of(op, ops):
+    if re.search(r"\blds\b", ops):                            # buffer_load ... lds: the data goes to LDS, the first operand is an address
+        return frozenset()
+    if "_load" in op and "lds" not in op:
+        return frozenset(first_operand_regs(ops))
+    if "_atomic" in op and ("sc0" in ops or "glc" in ops):
+        return frozenset(first_operand_regs(ops))
+    return frozenset()
+
+
+def step(state, ins, report=None):
+    """one instruction on the abstract queue: a tuple of register sets, YOUNGEST first (position = number of younger operations)"""
+    addr, op, ops, code = ins
+    if op == "s_waitcnt":
+        m = re.search(r"vmcnt\((\d+)\)", ops)
+        return state[: int(m.group(1))] if m else state
+    if report is not None and state:
+        touched = regs_of(ops)
+        if VMEM.match(op) and dest_of(op, ops):
+            # a load into a register an older load still writes is in order (loads retire in order): only its address operands count
+            touched = regs_of(ops.split(",", 1)[1]) if "," in ops else set()
+        if touched:
+            for age, regs in enumerate(state):
+                hit = touched & regs
+                if hit:
+                    report.append((addr, code, sorted(hit), age))
+                    break
+    if VMEM.match(op):
+        state = ((dest_of(op, ops),) + state)[:CAP]
+    return state
+
+
+def merge(a, b):
+    if a is None:
+        return b
+    if len(a) < len(b):
+        a, b = b, a
+    return tuple((a[i] | b[i]) if i < len(b) else a[i] for i in range(len(a)))
+
+
+def scan(name, lines, verbose=False):
+    """forward data flow over the kernel's control-flow graph: at a join the queues are merged position by position, counted from
+    the youngest operation (sound for in-order retirement: whatever a path has outstanding is in the merged queue at the same age)"""
+    ins = parse(lines)
+    if not ins:
+        return []
+    index = {a: k for k, (a, _, _, _) in enumerate(ins)}
+    target = {}
+    leaders = {0}
+    for k, (addr, op, ops, _) in enumerate(ins):
+        if op == "s_endpgm" or op == "s_branch" or op.startswith("s_cbranch"):
+            if k + 1 < len(ins):
+                leaders.add(k + 1)
+            if op != "s_endpgm":
+                off = int(ops.split()[0], 0)
+                off = off - 65536 if off >= 32768 else off
+                t = index.get(addr + 4 + 4 * off)
+                if t is None:
+                    raise RuntimeError(f"{name}: branch at {addr:#x} to an unknown address")
+                target[k] = t
+                leaders.add(t)
+    starts = sorted(leaders)
+    block_of = {}
+    blocks = []
+    for bi, st in enumerate(starts):
+        en = starts[bi + 1] if bi + 1 < len(starts) else len(ins)
+        blocks.append((st, en))
+        block_of[st] = bi
+    succ = []
+    for (st, en) in blocks:
+        last = ins[en - 1]
+        sx = []
+        if last[1] == "s_endpgm":
+            pass
+        elif last[1] == "s_branch":
+            sx.append(block_of[target[en - 1]])
+        elif last[1].startswith("s_cbranch"):
+            sx.append(block_of[target[en - 1]])
+            if en < len(ins):
+                sx.append(block_of[en])
+        elif en < len(ins):
+            sx.append(block_of[en])
+        succ.append(sx)
+    state_in = [None] * len(blocks)
+    state_in[0] = ()
+    work = [0]
+    while work:
+        b = work.pop()
+        st = state_in[b]
+        for k in range(blocks[b][0], blocks[b][1]):
+            st = step(st, ins[k])
+        for sb in succ[b]:
+            m = merge(state_in[sb], st)
+            if m != state_in[sb]:
+                state_in[sb] = m
+                work.append(sb)
+    findings = []
+    for b, (s0, e0) in enumerate(blocks):
+        st = state_in[b]
+        if st is None:
+            continue
+        for k in range(s0, e0):
+            st = step(st, ins[k], findings)
+    return findings
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--lib", default=os.path.join(ROOT, "bitblas_amd", "libwqaa_hip.so"))
+    ap.add_argument("--match", default=DEFAULT_MATCH)
+    ap.add_argument("-v", action="store_true")
+    args = ap.parse_args()
+    rx = re.compile(args.match)
+    total, bad = 0, 0
+    with tempfile.TemporaryDirectory() as td:
+        for k, co in enumerate(code_objects(args.lib)):
+            if not rx.search(co.decode("latin1")):
+                continue
+            f = os.path.join(td, f"co{k}.elf")
+            open(f, "wb").write(co)
+            dis = subprocess.run([OBJDUMP, "-d", f], capture_output=True, text=True).stdout.split("\n")
+            cur, body = None, []
+            kernels = []
+            for line in dis:
+                m = re.match(r"^[0-9a-f]+ <(.+)>:$", line)
+                if m:
+                    if cur:
+                        kernels.append((cur, body))
+                    cur, body = m.group(1), []
+                elif cur:
+                    body.append(line)
+            if cur:
+                kernels.append((cur, body))
+            for name, body in kernels:
+                if not rx.search(name):
+                    continue
+                total += 1
+                fnd = scan(name, body, args.v)
+                loads = sum(1 for b in body if re.match(r"\s*global_load_dwordx4", b))
+                print(f"{'HAZARD' if fnd else 'ok    '} {name[:110]}  ({len(body)} instructions, {loads} 16-byte loads, {len(fnd)} findings)")
+                if fnd:
+                    bad += 1
+                    for addr, code, hit, age in fnd[:8 if not args.v else 1000]:
+                        print(f"      {addr:#x}: {code}   touches v{hit}: possibly in flight, {age} younger operation(s)")
+    print(f"{total} kernels checked, {bad} with findings")
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
