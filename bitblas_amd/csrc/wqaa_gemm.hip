@@ -339,7 +339,8 @@ static int gemm_choose(const wqaa_matmul_desc& d, int m, GemmChoice* c, bool fus
     // (the hand-counted form - 4-bit weights, one Scale / Zeros group per k-step - takes up to six rounds of fragments, two batches)
     const bool counted = c->at == AT_F16 && (c->kind == DK_INT4 || c->kind == DK_LUT4) && (c->mode == MD_S || c->mode == MD_ZO || c->mode == MD_ZR) &&
                          g == c->ks && ((d.K / g) & 1) == 0;     // (8-byte metadata loads as instructions: 4-byte alignment)
-    persist = (c->at == AT_F16 || c->at == AT_F8) && frags > cus_ && frags <= (counted ? 6 : 3) * cus_ && nsteps <= 8 * 4 && (!pf || atoi(pf) != 0);
+    const int pgrid = (cus_ / 8) * 8;                 // the persistent grid (whole XCD rounds): what bounds the fragments per workgroup
+    persist = (c->at == AT_F16 || c->at == AT_F8) && frags > cus_ && frags <= (counted ? 6 : 3) * pgrid && nsteps <= 8 * 4 && (!pf || atoi(pf) != 0);
     // round 4 - WHOLE TILE, K > 4096 (hand-counted formats): a wave's k-range is nbk = 2 or 3 blocks of 4 k-steps; with slots of
     // nq = ceil(M / 4) KiB per k-step (only the row groups below M) it fits the wave's 16 KiB region for M <= 8 (nbk 2: K <= 8192)
     // and M <= 4 (nbk 3: K <= 12288); units (fragment, block) <= 6 per workgroup.  WQAA_GEMM_DECODE_LONG=0: off.
@@ -349,7 +350,7 @@ static int gemm_choose(const wqaa_matmul_desc& d, int m, GemmChoice* c, bool fus
     // 18.0, 8192^2 15.0 / 16.2 -> 12.7 / 13.4, 10240 x 8192 20.2 / 21.2 -> 17.4 / 17.8); with one fragment each (N <= 4096) asking for
     // everything at once measured the same as block by block - 4096 x 11008 M = 4 10.8 vs 11.0 us - and the old form stays
     // (profiles/r04_ab_decode_long.txt).
-    if (counted && nbk >= 2 && nbk <= 3 && run * nq <= 16 && frags > cus_ && frags <= (6 / nbk) * cus_ && (!lf || atoi(lf) != 0)) {
+    if (counted && nbk >= 2 && nbk <= 3 && run * nq <= 16 && frags > cus_ && frags <= (6 / nbk) * pgrid && (!lf || atoi(lf) != 0)) {
       c->decode_long = 1;
       persist = true;
     }
