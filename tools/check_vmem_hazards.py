@@ -66,6 +66,7 @@ def first_operand_regs(ops):
 VMEM = re.compile(r"^(global|buffer|flat|scratch)_(load|store|atomic)")
 ADDR = re.compile(r"//\s*([0-9A-Fa-f]+):")
 CAP = 64                                                        # vmcnt counts to 63
+CHECK_LDS = False                                               # --lds-dma: also no DS instruction while an LDS-DMA operation is outstanding
 
 
 def parse(lines):
@@ -81,9 +82,12 @@ def parse(lines):
     return out
 
 
+LDS_DMA = frozenset({-1})                                       # marker: an operation that writes LDS (global_load_lds_*, buffer_load ... lds)
+
+
 def dest_of(op, ops):
-    if re.search(r"\blds\b", ops):                            # buffer_load ... lds: the data goes to LDS, the first operand is an address
-        return frozenset()
+    if re.search(r"\blds\b", ops) or "_load_lds_" in op:      # the data goes to LDS (with `buffer_load ... lds` the first operand is an address)
+        return LDS_DMA
     if "_load" in op and "lds" not in op:
         return frozenset(first_operand_regs(ops))
     if "_atomic" in op and ("sc0" in ops or "glc" in ops):
@@ -97,9 +101,11 @@ def step(state, ins, report=None):
     if op == "s_waitcnt":
         m = re.search(r"vmcnt\((\d+)\)", ops)
         return state[: int(m.group(1))] if m else state
+    if report is not None and state and CHECK_LDS and op.startswith("ds_") and any(-1 in regs for regs in state):
+        report.append((addr, code, ["LDS"], max(age for age, regs in enumerate(state) if -1 in regs)))
     if report is not None and state:
         touched = regs_of(ops)
-        if VMEM.match(op) and dest_of(op, ops):
+        if VMEM.match(op) and dest_of(op, ops) and dest_of(op, ops) != LDS_DMA:
             # a load into a register an older load still writes is in order (loads retire in order): only its address operands count
             touched = regs_of(ops.split(",", 1)[1]) if "," in ops else set()
         if touched:
@@ -192,7 +198,14 @@ def main():
     ap.add_argument("--lib", default=os.path.join(ROOT, "bitblas_amd", "libwqaa_hip.so"))
     ap.add_argument("--match", default=DEFAULT_MATCH)
     ap.add_argument("-v", action="store_true")
+    ap.add_argument("--lds-dma", action="store_true",
+                    help="also: no ds_* instruction while a global_load_lds / buffer_load ... lds is outstanding.  A DIAGNOSTIC, not a "
+                         "gate: it has no addresses, and on the one-launch decode member every finding it has is a path of the graph "
+                         "that cannot run (the compiler merges the fragment-count arms behind flag registers: from the tile's DMA "
+                         "straight to the meeting); the register rule has no such findings")
     args = ap.parse_args()
+    global CHECK_LDS
+    CHECK_LDS = args.lds_dma
     rx = re.compile(args.match)
     total, bad = 0, 0
     with tempfile.TemporaryDirectory() as td:
