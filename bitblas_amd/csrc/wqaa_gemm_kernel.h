@@ -1405,223 +1405,223 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_decode_lds_kernel(const Ge
   // the tile is staged once here too and the walk is over UNITS (fragment, block), three in flight, fragment-major - instead of
   // blocks drained one by one at ~2 TB/s (profiles/r04_decode_longk.txt).  Same k order per wave, same meeting: bit-identical.
   if constexpr (WL == 4 && WIDE_OK) {
-      // (8-byte metadata loads as instructions need 4-byte alignment only: K / g even.  Where K / g is not a multiple of 4 the last
-      // block's load is moved back to end inside the row and the halves are taken `sh` groups further on)
-      const bool wide_c = a.gq_shift == 2 && (a.kg & 1) == 0;
-      if (wide_c && (persistent || a.decode_long)) {
-        constexpr bool ZP = MODE == MD_ZO || MODE == MD_ZR;
-        constexpr int NOPS = PF + 1 + (ZP ? 1 : 0);        // loads per unit and lane
-        struct AF {
-          u32x4 w[PF];
-          u32x2 gs, gz;
-          int row, sh;
-        };
-        const int G = (int)gridDim.x;
-        const int n_own = (nfrags - 1 - blk) / G + 1;      // fragments of this workgroup
-        auto issue_blk = [&](int frag, int j, AF& f) __attribute__((always_inline)) {          // block j of the wave's k-range
-          set_fragment(frag);
-          f.row = nrow;
-          const int t0 = t_lo + j * PF;
-          int base = t0 < a.kg - 4 ? t0 : a.kg - 4;
-          base = base < 0 ? 0 : base;
-          f.sh = (t0 - base) & 3;
-          const uint16_t* sp = Sp + srow + base;
-          asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(f.gs) : "v"(sp) : "memory");
-          if constexpr (ZP) {
-            const uint16_t* zp = Zp + srow + base;
-            asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(f.gz) : "v"(zp) : "memory");
-          } else {
-            f.gz = u32x2{0u, 0u};
-          }
-#pragma unroll
-          for (int i = 0; i < PF; ++i) {
-            int t = t0 + i;
-            t = t < nsteps ? t : last;
-            const uint8_t* wp = brow + (long)t * (4 * WL * 4);
-            asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(f.w[i]) : "v"(wp) : "memory");
-          }
-        };
-        auto issue = [&](int frag, AF& f) __attribute__((always_inline)) { issue_blk(frag, 0, f); };
-        // the wait hands the fragment's registers on: nothing that reads them can be scheduled above it.
-        // CONTRACT with the compiler: between a load and its wait the destination registers must stay where they are - a spill
-        // or an out-of-line call (captures on the stack) would copy them before the data is there.  Hence every lambda of this
-        // kernel is always_inline, and tests/test_abi.py::test_counted_decode_members_keep_their_loads_in_registers reads the
-        // built library's metadata: no scratch, no stack in any instantiation that takes this path; tools/check_vmem_hazards.py
-        // (tests/test_vmem_hazard_checker.py) walks their disassembly: nothing touches a register a load is still to write.  (The same walk with
-        // compiler-tracked loads needs no contract and was measured ~0.8 us slower at 11008 x 4096: where the one-, two- and
-        // three-fragment paths share their first loads the compiler's count falls back to vmcnt(0).)
-        auto landed = [&](auto NY, AF& f) __attribute__((always_inline)) {
-          constexpr int ny = decltype(NY)::value;          // loads issued after this fragment's
-          static_assert(PF == 4, "the operand list below");
-          if constexpr (ZP)
-            asm volatile("s_waitcnt vmcnt(%6)" : "+v"(f.w[0]), "+v"(f.w[1]), "+v"(f.w[2]), "+v"(f.w[3]), "+v"(f.gs), "+v"(f.gz) : "n"(ny) : "memory");
-          else
-            asm volatile("s_waitcnt vmcnt(%5)" : "+v"(f.w[0]), "+v"(f.w[1]), "+v"(f.w[2]), "+v"(f.w[3]), "+v"(f.gs) : "n"(ny) : "memory");
-        };
-        auto multiply_blk = [&](const AF& f, int j, int slot_bytes) __attribute__((always_inline)) {   // acc += block j (slots of slot_bytes)
-          zq_row = f.row;
-          const uint64_t s64 = (((uint64_t)f.gs[1] << 32) | f.gs[0]) >> (16 * f.sh);
-          const uint64_t z64 = (((uint64_t)f.gz[1] << 32) | f.gz[0]) >> (16 * f.sh);
-#pragma unroll
-          for (int i = 0; i < PF; ++i) {
-            BLane<P> bl;
-            bl.w[0][0] = f.w[i][0]; bl.w[0][1] = f.w[i][1]; bl.w[0][2] = f.w[i][2]; bl.w[0][3] = f.w[i][3];
-            bl.s[0] = (uint32_t)(s64 >> (16 * i)) & 0xFFFFu;
-            bl.z[0] = (uint32_t)(z64 >> (16 * i)) & 0xFFFFu;
-            if (j * PF + i < my_steps) compute(bl, (j * PF + i) * slot_bytes);
-          }
-        };
-        auto multiply = [&](const AF& f) __attribute__((always_inline)) -> acc_t {
-          acc = acc_t{0, 0, 0, 0};
-          multiply_blk(f, 0, STEP_BYTES);
-          return acc;
-        };
-        // the waves meet once per batch of (up to) three fragments, with their partial sums of the whole batch (three sets of
-        // slots), and waves 0, 1, 2 sum and store one fragment each - in wave order, as the one-fragment form does
-        auto meet = [&](const acc_t& p0, const acc_t& p1, const acc_t& p2, int first, int count) __attribute__((always_inline)) {
-          red[wave * 64 + lane] = p0;
-          red[(NW + wave) * 64 + lane] = p1;
-          red[(2 * NW + wave) * 64 + lane] = p2;
-          __syncthreads();
-          if (wave < count) {
-            const acc_t* r = red + wave * (NW * 64);
-            acc_t sum = r[lane];
-#pragma unroll
-            for (int w = 1; w < NW; ++w) sum += r[w * 64 + lane];
-            const int nb = (first + wave * G) * 16 + kb * 4;
-            if (nb < a.N && fr < a.M) store_quad<P>(a, sum, fr, nb);
-          }
-        };
-        AF f0, f1, f2;
-        const acc_t zero = acc_t{0, 0, 0, 0};
-        acc_t p0 = zero, p1 = zero, p2 = zero;
-        if (a.decode_long) {
-          const int slot_bytes = nq * 1024;
-          // units u = (fragment u / NBK, block u % NBK), registers u % 3; a wait counts the loads of the units issued after u
-          auto long_walk = [&](auto NOWN_, auto NBK_) __attribute__((always_inline)) {
-            constexpr int NOWN = decltype(NOWN_)::value, NBK = decltype(NBK_)::value, U = NOWN * NBK;
-            static_assert(U <= 6 && NOWN <= 3, "units");
-#pragma unroll
-            for (int sidx = 0; sidx < NBK * PF; ++sidx) {
-              const int t = t_lo + sidx;
-              dma_step_unseen(t < nsteps ? t : last, sidx * slot_bytes);
-            }
-            auto regs = [&](auto UC) __attribute__((always_inline)) -> AF& {
-              constexpr int r = decltype(UC)::value % 3;
-              if constexpr (r == 0) return f0;
-              else if constexpr (r == 1) return f1;
-              else return f2;
-            };
-            auto ask = [&](auto UC) __attribute__((always_inline)) {
-              constexpr int u = decltype(UC)::value;
-              if constexpr (u < U) issue_blk(blk + (u / NBK) * G, u % NBK, regs(UC));
-            };
-            auto unit = [&](auto UC) __attribute__((always_inline)) {
-              constexpr int u = decltype(UC)::value;
-              if constexpr (u < U) {
-                constexpr int after = (U - 1 < u + 2 ? U - 1 : u + 2) - u;
-                landed(std::integral_constant<int, after * NOPS>{}, regs(UC));
-                if constexpr (u % NBK == 0) acc = zero;
-                multiply_blk(regs(UC), u % NBK, slot_bytes);
-                if constexpr (u % NBK == NBK - 1) {
-                  if constexpr (u / NBK == 0) p0 = acc;
-                  else if constexpr (u / NBK == 1) p1 = acc;
-                  else p2 = acc;
-                }
-                ask(std::integral_constant<int, u + 3>{});
-              }
-            };
-            ask(std::integral_constant<int, 0>{});
-            ask(std::integral_constant<int, 1>{});
-            ask(std::integral_constant<int, 2>{});
-            unit(std::integral_constant<int, 0>{});
-            unit(std::integral_constant<int, 1>{});
-            unit(std::integral_constant<int, 2>{});
-            unit(std::integral_constant<int, 3>{});
-            unit(std::integral_constant<int, 4>{});
-            unit(std::integral_constant<int, 5>{});
-            meet(p0, p1, p2, blk, NOWN);
-          };
-          using std::integral_constant;
-          const int nbk = run / PF;                            // (the launcher: nbk = 2, 3; nbk * PF * nq <= 16 slots of 1 KiB; n_own * nbk <= 6)
-          if (nbk == 2) {
-            if (n_own == 1) long_walk(integral_constant<int, 1>{}, integral_constant<int, 2>{});
-            else if (n_own == 2) long_walk(integral_constant<int, 2>{}, integral_constant<int, 2>{});
-            else long_walk(integral_constant<int, 3>{}, integral_constant<int, 2>{});
-          } else {                                             // nbk == 3
-            if (n_own == 1) long_walk(integral_constant<int, 1>{}, integral_constant<int, 3>{});
-            else long_walk(integral_constant<int, 2>{}, integral_constant<int, 3>{});
-          }
-          return;
+    // (8-byte metadata loads as instructions need 4-byte alignment only: K / g even.  Where K / g is not a multiple of 4 the last
+    // block's load is moved back to end inside the row and the halves are taken `sh` groups further on)
+    const bool wide_c = a.gq_shift == 2 && (a.kg & 1) == 0;
+    if (wide_c && (persistent || a.decode_long)) {
+      constexpr bool ZP = MODE == MD_ZO || MODE == MD_ZR;
+      constexpr int NOPS = PF + 1 + (ZP ? 1 : 0);        // loads per unit and lane
+      struct AF {
+        u32x4 w[PF];
+        u32x2 gs, gz;
+        int row, sh;
+      };
+      const int G = (int)gridDim.x;
+      const int n_own = (nfrags - 1 - blk) / G + 1;      // fragments of this workgroup
+      auto issue_blk = [&](int frag, int j, AF& f) __attribute__((always_inline)) {          // block j of the wave's k-range
+        set_fragment(frag);
+        f.row = nrow;
+        const int t0 = t_lo + j * PF;
+        int base = t0 < a.kg - 4 ? t0 : a.kg - 4;
+        base = base < 0 ? 0 : base;
+        f.sh = (t0 - base) & 3;
+        const uint16_t* sp = Sp + srow + base;
+        asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(f.gs) : "v"(sp) : "memory");
+        if constexpr (ZP) {
+          const uint16_t* zp = Zp + srow + base;
+          asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(f.gz) : "v"(zp) : "memory");
+        } else {
+          f.gz = u32x2{0u, 0u};
         }
-        // (persistent) the tile: one block per wave
 #pragma unroll
         for (int i = 0; i < PF; ++i) {
-          const int t = t_lo + i;
-          dma_step_unseen(t < nsteps ? t : last, i * STEP_BYTES);
+          int t = t0 + i;
+          t = t < nsteps ? t : last;
+          const uint8_t* wp = brow + (long)t * (4 * WL * 4);
+          asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(f.w[i]) : "v"(wp) : "memory");
         }
-        if (n_own > 3) {
-          // four to six fragments: the second batch refills the first one's registers as they are consumed.  NB2 = fragments of the
-          // second batch; a wait counts the loads issued after the fragment it is for
-          auto two_batches = [&](auto NB2) __attribute__((always_inline)) {
-            constexpr int nb2 = decltype(NB2)::value;
-            issue(blk, f0);
-            issue(blk + G, f1);
-            issue(blk + 2 * G, f2);
-            landed(std::integral_constant<int, 2 * NOPS>{}, f0);
-            p0 = multiply(f0);
-            issue(blk + 3 * G, f0);
-            landed(std::integral_constant<int, 2 * NOPS>{}, f1);
-            p1 = multiply(f1);
-            if constexpr (nb2 >= 2) issue(blk + 4 * G, f1);
-            landed(std::integral_constant<int, (1 + (nb2 >= 2 ? 1 : 0)) * NOPS>{}, f2);
-            p2 = multiply(f2);
-            if constexpr (nb2 >= 3) issue(blk + 5 * G, f2);
-            meet(p0, p1, p2, blk, 3);
-            acc_t q0 = zero, q1 = zero, q2 = zero;
-            landed(std::integral_constant<int, (nb2 - 1) * NOPS>{}, f0);
-            q0 = multiply(f0);
-            if constexpr (nb2 >= 2) {
-              landed(std::integral_constant<int, (nb2 - 2) * NOPS>{}, f1);
-              q1 = multiply(f1);
-            }
-            if constexpr (nb2 >= 3) {
-              landed(std::integral_constant<int, 0>{}, f2);
-              q2 = multiply(f2);
-            }
-            __syncthreads();                               // the first batch's slots have been read
-            meet(q0, q1, q2, blk + 3 * G, nb2);
+      };
+      auto issue = [&](int frag, AF& f) __attribute__((always_inline)) { issue_blk(frag, 0, f); };
+      // the wait hands the fragment's registers on: nothing that reads them can be scheduled above it.
+      // CONTRACT with the compiler: between a load and its wait the destination registers must stay where they are - a spill
+      // or an out-of-line call (captures on the stack) would copy them before the data is there.  Hence every lambda of this
+      // kernel is always_inline, and tests/test_abi.py::test_counted_decode_members_keep_their_loads_in_registers reads the
+      // built library's metadata: no scratch, no stack in any instantiation that takes this path; tools/check_vmem_hazards.py
+      // (tests/test_vmem_hazard_checker.py) walks their disassembly: nothing touches a register a load is still to write.  (The same walk with
+      // compiler-tracked loads needs no contract and was measured ~0.8 us slower at 11008 x 4096: where the one-, two- and
+      // three-fragment paths share their first loads the compiler's count falls back to vmcnt(0).)
+      auto landed = [&](auto NY, AF& f) __attribute__((always_inline)) {
+        constexpr int ny = decltype(NY)::value;          // loads issued after this fragment's
+        static_assert(PF == 4, "the operand list below");
+        if constexpr (ZP)
+          asm volatile("s_waitcnt vmcnt(%6)" : "+v"(f.w[0]), "+v"(f.w[1]), "+v"(f.w[2]), "+v"(f.w[3]), "+v"(f.gs), "+v"(f.gz) : "n"(ny) : "memory");
+        else
+          asm volatile("s_waitcnt vmcnt(%5)" : "+v"(f.w[0]), "+v"(f.w[1]), "+v"(f.w[2]), "+v"(f.w[3]), "+v"(f.gs) : "n"(ny) : "memory");
+      };
+      auto multiply_blk = [&](const AF& f, int j, int slot_bytes) __attribute__((always_inline)) {   // acc += block j (slots of slot_bytes)
+        zq_row = f.row;
+        const uint64_t s64 = (((uint64_t)f.gs[1] << 32) | f.gs[0]) >> (16 * f.sh);
+        const uint64_t z64 = (((uint64_t)f.gz[1] << 32) | f.gz[0]) >> (16 * f.sh);
+#pragma unroll
+        for (int i = 0; i < PF; ++i) {
+          BLane<P> bl;
+          bl.w[0][0] = f.w[i][0]; bl.w[0][1] = f.w[i][1]; bl.w[0][2] = f.w[i][2]; bl.w[0][3] = f.w[i][3];
+          bl.s[0] = (uint32_t)(s64 >> (16 * i)) & 0xFFFFu;
+          bl.z[0] = (uint32_t)(z64 >> (16 * i)) & 0xFFFFu;
+          if (j * PF + i < my_steps) compute(bl, (j * PF + i) * slot_bytes);
+        }
+      };
+      auto multiply = [&](const AF& f) __attribute__((always_inline)) -> acc_t {
+        acc = acc_t{0, 0, 0, 0};
+        multiply_blk(f, 0, STEP_BYTES);
+        return acc;
+      };
+      // the waves meet once per batch of (up to) three fragments, with their partial sums of the whole batch (three sets of
+      // slots), and waves 0, 1, 2 sum and store one fragment each - in wave order, as the one-fragment form does
+      auto meet = [&](const acc_t& p0, const acc_t& p1, const acc_t& p2, int first, int count) __attribute__((always_inline)) {
+        red[wave * 64 + lane] = p0;
+        red[(NW + wave) * 64 + lane] = p1;
+        red[(2 * NW + wave) * 64 + lane] = p2;
+        __syncthreads();
+        if (wave < count) {
+          const acc_t* r = red + wave * (NW * 64);
+          acc_t sum = r[lane];
+#pragma unroll
+          for (int w = 1; w < NW; ++w) sum += r[w * 64 + lane];
+          const int nb = (first + wave * G) * 16 + kb * 4;
+          if (nb < a.N && fr < a.M) store_quad<P>(a, sum, fr, nb);
+        }
+      };
+      AF f0, f1, f2;
+      const acc_t zero = acc_t{0, 0, 0, 0};
+      acc_t p0 = zero, p1 = zero, p2 = zero;
+      if (a.decode_long) {
+        const int slot_bytes = nq * 1024;
+        // units u = (fragment u / NBK, block u % NBK), registers u % 3; a wait counts the loads of the units issued after u
+        auto long_walk = [&](auto NOWN_, auto NBK_) __attribute__((always_inline)) {
+          constexpr int NOWN = decltype(NOWN_)::value, NBK = decltype(NBK_)::value, U = NOWN * NBK;
+          static_assert(U <= 6 && NOWN <= 3, "units");
+#pragma unroll
+          for (int sidx = 0; sidx < NBK * PF; ++sidx) {
+            const int t = t_lo + sidx;
+            dma_step_unseen(t < nsteps ? t : last, sidx * slot_bytes);
+          }
+          auto regs = [&](auto UC) __attribute__((always_inline)) -> AF& {
+            constexpr int r = decltype(UC)::value % 3;
+            if constexpr (r == 0) return f0;
+            else if constexpr (r == 1) return f1;
+            else return f2;
           };
-          if (n_own == 4) two_batches(std::integral_constant<int, 1>{});
-          else if (n_own == 5) two_batches(std::integral_constant<int, 2>{});
-          else two_batches(std::integral_constant<int, 3>{});
-          return;
+          auto ask = [&](auto UC) __attribute__((always_inline)) {
+            constexpr int u = decltype(UC)::value;
+            if constexpr (u < U) issue_blk(blk + (u / NBK) * G, u % NBK, regs(UC));
+          };
+          auto unit = [&](auto UC) __attribute__((always_inline)) {
+            constexpr int u = decltype(UC)::value;
+            if constexpr (u < U) {
+              constexpr int after = (U - 1 < u + 2 ? U - 1 : u + 2) - u;
+              landed(std::integral_constant<int, after * NOPS>{}, regs(UC));
+              if constexpr (u % NBK == 0) acc = zero;
+              multiply_blk(regs(UC), u % NBK, slot_bytes);
+              if constexpr (u % NBK == NBK - 1) {
+                if constexpr (u / NBK == 0) p0 = acc;
+                else if constexpr (u / NBK == 1) p1 = acc;
+                else p2 = acc;
+              }
+              ask(std::integral_constant<int, u + 3>{});
+            }
+          };
+          ask(std::integral_constant<int, 0>{});
+          ask(std::integral_constant<int, 1>{});
+          ask(std::integral_constant<int, 2>{});
+          unit(std::integral_constant<int, 0>{});
+          unit(std::integral_constant<int, 1>{});
+          unit(std::integral_constant<int, 2>{});
+          unit(std::integral_constant<int, 3>{});
+          unit(std::integral_constant<int, 4>{});
+          unit(std::integral_constant<int, 5>{});
+          meet(p0, p1, p2, blk, NOWN);
+        };
+        using std::integral_constant;
+        const int nbk = run / PF;                            // (the launcher: nbk = 2, 3; nbk * PF * nq <= 16 slots of 1 KiB; n_own * nbk <= 6)
+        if (nbk == 2) {
+          if (n_own == 1) long_walk(integral_constant<int, 1>{}, integral_constant<int, 2>{});
+          else if (n_own == 2) long_walk(integral_constant<int, 2>{}, integral_constant<int, 2>{});
+          else long_walk(integral_constant<int, 3>{}, integral_constant<int, 2>{});
+        } else {                                             // nbk == 3
+          if (n_own == 1) long_walk(integral_constant<int, 1>{}, integral_constant<int, 3>{});
+          else long_walk(integral_constant<int, 2>{}, integral_constant<int, 3>{});
         }
-        if (n_own >= 3) {
+        return;
+      }
+      // (persistent) the tile: one block per wave
+#pragma unroll
+      for (int i = 0; i < PF; ++i) {
+        const int t = t_lo + i;
+        dma_step_unseen(t < nsteps ? t : last, i * STEP_BYTES);
+      }
+      if (n_own > 3) {
+        // four to six fragments: the second batch refills the first one's registers as they are consumed.  NB2 = fragments of the
+        // second batch; a wait counts the loads issued after the fragment it is for
+        auto two_batches = [&](auto NB2) __attribute__((always_inline)) {
+          constexpr int nb2 = decltype(NB2)::value;
           issue(blk, f0);
           issue(blk + G, f1);
           issue(blk + 2 * G, f2);
           landed(std::integral_constant<int, 2 * NOPS>{}, f0);
           p0 = multiply(f0);
-          landed(std::integral_constant<int, NOPS>{}, f1);
+          issue(blk + 3 * G, f0);
+          landed(std::integral_constant<int, 2 * NOPS>{}, f1);
           p1 = multiply(f1);
-          landed(std::integral_constant<int, 0>{}, f2);
+          if constexpr (nb2 >= 2) issue(blk + 4 * G, f1);
+          landed(std::integral_constant<int, (1 + (nb2 >= 2 ? 1 : 0)) * NOPS>{}, f2);
           p2 = multiply(f2);
-        } else if (n_own == 2) {
-          issue(blk, f0);
-          issue(blk + G, f1);
-          landed(std::integral_constant<int, NOPS>{}, f0);
-          p0 = multiply(f0);
-          landed(std::integral_constant<int, 0>{}, f1);
-          p1 = multiply(f1);
-        } else {
-          issue(blk, f0);
-          landed(std::integral_constant<int, 0>{}, f0);
-          p0 = multiply(f0);
-        }
-        meet(p0, p1, p2, blk, n_own);
+          if constexpr (nb2 >= 3) issue(blk + 5 * G, f2);
+          meet(p0, p1, p2, blk, 3);
+          acc_t q0 = zero, q1 = zero, q2 = zero;
+          landed(std::integral_constant<int, (nb2 - 1) * NOPS>{}, f0);
+          q0 = multiply(f0);
+          if constexpr (nb2 >= 2) {
+            landed(std::integral_constant<int, (nb2 - 2) * NOPS>{}, f1);
+            q1 = multiply(f1);
+          }
+          if constexpr (nb2 >= 3) {
+            landed(std::integral_constant<int, 0>{}, f2);
+            q2 = multiply(f2);
+          }
+          __syncthreads();                               // the first batch's slots have been read
+          meet(q0, q1, q2, blk + 3 * G, nb2);
+        };
+        if (n_own == 4) two_batches(std::integral_constant<int, 1>{});
+        else if (n_own == 5) two_batches(std::integral_constant<int, 2>{});
+        else two_batches(std::integral_constant<int, 3>{});
         return;
       }
+      if (n_own >= 3) {
+        issue(blk, f0);
+        issue(blk + G, f1);
+        issue(blk + 2 * G, f2);
+        landed(std::integral_constant<int, 2 * NOPS>{}, f0);
+        p0 = multiply(f0);
+        landed(std::integral_constant<int, NOPS>{}, f1);
+        p1 = multiply(f1);
+        landed(std::integral_constant<int, 0>{}, f2);
+        p2 = multiply(f2);
+      } else if (n_own == 2) {
+        issue(blk, f0);
+        issue(blk + G, f1);
+        landed(std::integral_constant<int, NOPS>{}, f0);
+        p0 = multiply(f0);
+        landed(std::integral_constant<int, 0>{}, f1);
+        p1 = multiply(f1);
+      } else {
+        issue(blk, f0);
+        landed(std::integral_constant<int, 0>{}, f0);
+        p0 = multiply(f0);
+      }
+      meet(p0, p1, p2, blk, n_own);
+      return;
+    }
   }
   if (persistent) {
     struct FragLoad {
