@@ -1,7 +1,8 @@
 // wqaa_gemm.hip - host side of the MFMA GEMM family: tile-config selector, split-K scratch, launch.
 // The kernels live in wqaa_gemm_kernel.h; the member tables are instantiated in wqaa_gemm_inst_*.hip.
-#include "wqaa_gemm_kernel.h"
+#include "wqaa_gemm_mid_kernel.h"
 
+#include <unordered_map>
 #include <vector>
 
 namespace wqaa {
@@ -69,6 +70,50 @@ bool pool_workspace_ready(hipStream_t stream, size_t bytes) {
   return cs == hipStreamCaptureStatusNone;
 }
 
+// Sync words of the mid-M member's in-launch split-K meeting (wqaa_gemm_mid_kernel.h): kMidSyncWords per output tile, zero
+// between launches (the kernel cleans up after itself).  They are NOT part of the workspace - a caller's scratch may hold
+// anything - but they are keyed BY it: a workspace is never shared by two launches in flight (two streams never share partial
+// sums, see above), so neither are the words that go with it.  One zero-initialised slab per device, carved into regions of
+// kMidMaxTiles tiles; first use of a device allocates (not during stream capture: the caller falls back to the two-launch
+// member then, as it does when the regions run out).
+constexpr int kMidMaxTiles = 256;
+constexpr int kMidRegions = 1024;            // 16 KiB each: a 16 MiB slab per device
+struct MidDev {
+  int dev;
+  unsigned* slab;
+  std::unordered_map<const void*, unsigned*> by_ws;
+};
+static std::vector<MidDev> g_mid;
+static std::mutex g_mid_mu;
+static unsigned* mid_sync_words(hipStream_t stream, const void* ws) {
+  const int dev = current_device();
+  if (dev < 0 || !ws) return nullptr;
+  std::lock_guard<std::mutex> lk(g_mid_mu);
+  MidDev* md = nullptr;
+  for (auto& x : g_mid)
+    if (x.dev == dev) md = &x;
+  if (!md) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cs) != hipSuccess) (void)hipGetLastError();
+    if (cs != hipStreamCaptureStatusNone) return nullptr;
+    const size_t bytes = (size_t)kMidRegions * kMidMaxTiles * kMidSyncWords * sizeof(unsigned);
+    void* p = nullptr;
+    if (hipMalloc(&p, bytes) != hipSuccess || hipMemset(p, 0, bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+      (void)hipGetLastError();
+      if (p) (void)hipFree(p);
+      return nullptr;
+    }
+    g_mid.push_back(MidDev{dev, reinterpret_cast<unsigned*>(p), {}});
+    md = &g_mid.back();
+  }
+  auto it = md->by_ws.find(ws);
+  if (it != md->by_ws.end()) return it->second;
+  if ((int)md->by_ws.size() >= kMidRegions) return nullptr;
+  unsigned* words = md->slab + md->by_ws.size() * (size_t)kMidMaxTiles * kMidSyncWords;
+  md->by_ws.emplace(ws, words);
+  return words;
+}
+
 static gemm_fn pick_gemm(int kind, int layout, int at, int mode, int flags, int mf) {
   if (at == AT_F16 && (flags & FL_BF16)) return layout == LAYOUT_PLAIN ? pick_gemm_bf16(kind, mode, mf) : nullptr;
   if (at == AT_F16) {
@@ -95,10 +140,14 @@ struct GemmChoice {
   int decode_long;      // the one-launch decode member stages the wave's whole k-range (M-sized slots) and walks units (fragment, k-block)
   int decode_grid;      // > 0: the persistent form of the one-launch decode member (grid < number of 16-row fragments)
   int pp_avail;         // m > 128: a fused ping-pong member takes this descriptor (whether or not the round estimate chose it here)
+  int mid;              // the mid-M one-launch split-K member (wqaa_gemm_mid_kernel.h); mid_nkh: k-steps per k-half of a slice
+  int mid_nkh;
 };
 
-static int gemm_choose(const wqaa_matmul_desc& d, int m, GemmChoice* c, bool fused_epilogue = false) {
+static int gemm_choose(const wqaa_matmul_desc& d, int m, GemmChoice* c, bool fused_epilogue = false, bool no_mid = false) {
   const int a = d.a_dtype;
+  c->mid = 0;
+  c->mid_nkh = 0;
   c->fp4_table = 0;
   c->tail_fn = nullptr;
   c->tail_lds = c->tail_tiles_m = c->tail_tiles_n = 0;
@@ -302,6 +351,43 @@ static int gemm_choose(const wqaa_matmul_desc& d, int m, GemmChoice* c, bool fus
     set_error(WQAA_ERR_UNSUPPORTED, "gemm: K=%d must be a multiple of %d", d.K, c->ks);
     return WQAA_ERR_UNSUPPORTED;
   }
+  // round 5 - the mid-M member (wqaa_gemm_mid_kernel.h): 4-bit weights x float16, M = 17 ... 128 per M-tile, K = 2048 nkh with the
+  // workgroup's whole activation slice (16 mf rows x K / 8) in LDS; one launch, K in 8 slices that meet inside it.  Taken where
+  // its tiles x 8 workgroups are at most one round of the chip (WQAA_GEMM_MID=0: never; WQAA_GEMM_MID_MAXM / _MINM / _ROUNDS: tuning aids)
+  if (!no_mid && !fused_epilogue && c->at == AT_F16 && !(c->flags & FL_BF16) && c->kind == DK_INT4 && d.k_split_hint <= 1 &&
+      getenv("WQAA_GEMM_KSPLIT") == nullptr && getenv("WQAA_GEMM_MF") == nullptr) {
+    const char* mf_ = getenv("WQAA_GEMM_MID");
+    int max_m = 128, min_m = 17, rounds = 1;
+    if (const char* f = getenv("WQAA_GEMM_MID_MAXM")) max_m = atoi(f);
+    if (const char* f = getenv("WQAA_GEMM_MID_MINM")) min_m = atoi(f);
+    if (const char* f = getenv("WQAA_GEMM_MID_ROUNDS")) rounds = atoi(f);
+    const int nkh = d.K % 2048 == 0 ? d.K / 2048 : 0;
+    const int tm = (m + 127) / 128;
+    const int rows = (m + tm - 1) / tm;                       // rows per M-tile
+    const int mf = rows > 64 ? 8 : rows > 32 ? 4 : 2;
+    const long tiles = (long)((m + 16 * mf - 1) / (16 * mf)) * ((d.N + 127) / 128);
+    int lds = 0;
+    gemm_fn fn = (nkh == 1 || nkh == 2 || nkh == 4) && mf * nkh <= 16 ? pick_gemm_mid(c->kind, c->layout, c->mode, mf, nkh, &lds) : nullptr;
+    // (the members with NKH >= 2 fetch Scale / Zeros of their NKH consecutive groups in one load per row: one group per k-step,
+    // rows aligned; other group sizes keep the members they had)
+    const bool widemeta = (c->mode == MD_S || c->mode == MD_ZO || c->mode == MD_ZR) && nkh >= 2;
+    const bool meta_ok = !widemeta || (g == c->ks && (d.K / g) % nkh == 0);
+    if (fn && meta_ok && (!mf_ || atoi(mf_) != 0) && m >= min_m && m <= max_m && tiles * 8 <= (long)rounds * cus_ && tiles <= kMidMaxTiles &&
+        (long)m * d.K * 2 < (1L << 32) && d.K < (1 << 23) && (c->mode != MD_ZQ || d.N % 2 == 0)) {
+      c->mid = 1;
+      c->mid_nkh = nkh;
+      c->fn = fn;
+      c->mf = mf;
+      c->nwaves = 8;
+      c->bn = 128;
+      c->skinny = c->decode = c->wide = 0;
+      c->tiles_m = (m + 16 * mf - 1) / (16 * mf);
+      c->tiles_n = (d.N + 127) / 128;
+      c->lds = lds;
+      c->ksplit = 1;              // (no second launch: the slices meet inside this one)
+      return WQAA_OK;
+    }
+  }
   // small decode batches: one launch with K split across the 8 waves of a workgroup, no partial sums
   // in memory (WQAA_GEMM_DECODE=0: back to the split-K skinny member + reduce launch).  Every
   // workgroup reads all M activation rows, so it pays only while M and the number of 16-row weight
@@ -338,7 +424,7 @@ static int gemm_choose(const wqaa_matmul_desc& d, int m, GemmChoice* c, bool fus
     // than the skinny member + reduce)
     // (the hand-counted form - 4-bit weights, one Scale / Zeros group per k-step - takes up to six rounds of fragments, two batches)
     const bool counted = c->at == AT_F16 && (c->kind == DK_INT4 || c->kind == DK_LUT4) && (c->mode == MD_S || c->mode == MD_ZO || c->mode == MD_ZR) &&
-                         g == c->ks && ((d.K / g) & 1) == 0;     // (8-byte metadata loads as instructions: 4-byte alignment)
+                         g == c->ks && ((d.K / g) & 1) == 0 && d.K / g >= 4;     // (8-byte metadata loads as instructions: 4-byte alignment; four groups per load: a row of two would be read 4 bytes past its end)
     const int pgrid = (cus_ / 8) * 8;                 // the persistent grid (whole XCD rounds): what bounds the fragments per workgroup
     persist = (c->at == AT_F16 || c->at == AT_F8) && frags > cus_ && frags <= (counted ? 6 : 3) * pgrid && nsteps <= 8 * 4 && (!pf || atoi(pf) != 0);
     // round 4 - WHOLE TILE, K > 4096 (hand-counted formats): a wave's k-range is nbk = 2 or 3 blocks of 4 k-steps; with slots of
@@ -447,23 +533,34 @@ int gemm_plan(const wqaa_matmul_desc& d, int m, wqaa_plan* plan, bool fused_epil
     plan->rows_per_wave = 32;
     plan->batch_tile = 16 * c.mf;
     plan->pipeline_depth = 2;
-    plan->split_k = c.ksplit;
+    plan->split_k = c.mid ? kMidSlices : c.ksplit;
     plan->lds_bytes = c.lds;
-    plan->grid = c.tiles_m * c.tiles_n * c.ksplit + (c.tail_fn ? c.tail_tiles_m * c.tail_tiles_n : 0);
+    plan->grid = c.tiles_m * c.tiles_n * (c.mid ? kMidSlices : c.ksplit) + (c.tail_fn ? c.tail_tiles_m * c.tail_tiles_n : 0);
     if (c.decode_grid > 0) plan->grid = c.decode_grid;
     char wd[24];
     short_wdtype(d, wd, sizeof(wd));
     char tail[16] = "";
     if (c.tail_fn) snprintf(tail, sizeof(tail), "t%d", c.tail_tiles_n);      // "ppt11": the last 11 N-tiles as a launch of the 128-row tile
     snprintf(plan->name, sizeof(plan->name), "matmul_m%dn%dk%d_%sx%s_tcx%dx%dx%d%s%s%s", m, d.N, d.K, short_dtype(d.a_dtype),
-             wd, 16 * c.mf, c.bn, c.ks, c.ksplit > 1 ? "xr" : "", c.pp ? "pp" : c.skinny ? "xs" : c.decode == 2 ? (c.decode_long ? "xdlt" : c.decode_grid > 0 ? "xdlp" : "xdl") : c.decode ? "xd" : c.wide ? "xw" : "", tail);
+             wd, 16 * c.mf, c.bn, c.ks, c.ksplit > 1 ? "xr" : "", c.mid ? "xmk" : c.pp ? "pp" : c.skinny ? "xs" : c.decode == 2 ? (c.decode_long ? "xdlt" : c.decode_grid > 0 ? "xdlp" : "xdl") : c.decode ? "xd" : c.wide ? "xw" : "", tail);
   }
   return WQAA_OK;
 }
 
+// (the mid-M member's exchange buffer: tiles x 8 portions x 8 slices x mf KiB)
+static size_t mid_ws_bytes(const GemmChoice& c) { return (size_t)c.tiles_m * c.tiles_n * 8 * kMidSlices * c.mf * 1024; }
+
 size_t gemm_workspace_bytes(const wqaa_matmul_desc& d, int m) {
   GemmChoice c;
   if (gemm_choose(d, m, &c) != WQAA_OK) return 0;
+  if (c.mid) {
+    // ... or, should its sync words be unavailable at launch time (first use of a device inside a stream capture), the member it
+    // stands in for: the larger of the two needs
+    GemmChoice f;
+    const size_t fb = gemm_choose(d, m, &f, false, true) == WQAA_OK && f.ksplit > 1 ? (size_t)f.ksplit * m * d.N * 4 : 0;
+    const size_t mine = mid_ws_bytes(c);
+    return mine > fb ? mine : fb;
+  }
   return c.ksplit > 1 ? (size_t)c.ksplit * m * d.N * 4 : 0;
 }
 
@@ -510,6 +607,23 @@ int gemm_launch(const wqaa_matmul_desc& d, const void* A, const void* B, const v
   }
   const int g = d.group_size <= 0 ? d.K : d.group_size;
   GemmArgs a;
+  // the mid-M member needs its exchange buffer and the tiles' sync words; without them (a short caller workspace, a pool that
+  // cannot grow or a device's first use inside a stream capture) the call runs the member it stands in for
+  void* mid_ws = nullptr;
+  unsigned* mid_sync = nullptr;
+  if (c.mid && !epi) {
+    const size_t need = mid_ws_bytes(c);
+    if (opts && opts->workspace) {
+      if (opts->workspace_bytes >= need && (reinterpret_cast<uintptr_t>(opts->workspace) & 15) == 0) mid_ws = opts->workspace;
+    } else if (pool_workspace_ready(stream, need)) {
+      mid_ws = pool_workspace(stream, need);
+    }
+    if (mid_ws) mid_sync = mid_sync_words(stream, mid_ws);
+    if (!mid_ws || !mid_sync) {
+      int st = gemm_choose(d, m, &c, false, true);
+      if (st != WQAA_OK) return st;
+    }
+  }
   a.A = A; a.B = B; a.lut = LUT; a.scale = Scale; a.zeros = Zeros; a.bias = Bias; a.C = C;
   a.M = m; a.N = d.N; a.K = d.K;
   a.kg = d.K / g;
@@ -579,8 +693,24 @@ int gemm_launch(const wqaa_matmul_desc& d, const void* A, const void* B, const v
       if (!a.ws) return WQAA_ERR_LAUNCH;
     }
   }
+  if (c.mid) {
+    a.ws = mid_ws;
+    a.mid_sync = mid_sync;
+    a.mg_ntiles = tile_magic((uint32_t)c.tiles_n);          // (this member's tile map: tile -> (tile / tiles_n, tile % tiles_n))
+    // bound of the in-launch wait: 10 ns ticks (WQAA_GEMM_MID_SPIN_US, default 50 us; 0 = nobody waits, every portion takes the
+    // abandon / sweep path - the test aid)
+    static thread_local unsigned seen = ~0u;
+    static thread_local int spin_us = 50;
+    const unsigned ep = g_plan_epoch.load(std::memory_order_relaxed);
+    if (ep != seen) {
+      const char* f = getenv("WQAA_GEMM_MID_SPIN_US");
+      spin_us = f ? atoi(f) : 50;
+      seen = ep;
+    }
+    a.mid_spin = spin_us * 100;
+  }
   void* params[] = {&a};
-  dim3 grid(c.decode_grid > 0 ? c.decode_grid : c.tiles_m * c.tiles_n * c.ksplit, 1, 1), block(64 * c.nwaves, 1, 1);
+  dim3 grid(c.decode_grid > 0 ? c.decode_grid : c.tiles_m * c.tiles_n * (c.mid ? kMidSlices : c.ksplit), 1, 1), block(64 * c.nwaves, 1, 1);
   hipError_t e;
   if (start || stop) {
     e = hipExtLaunchKernel(reinterpret_cast<const void*>(c.fn), grid, block, params, c.lds, stream, start,
@@ -818,6 +948,14 @@ void gemm_init() {
               gemm_fn fn = pick_gemm_pp(kind, layout, at, mode, flags, bm, bn, &lds);
               if (fn) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             }
+        }
+  for (int layout = 0; layout < 2; ++layout)
+    for (int mode = 0; mode <= MD_ZQ; ++mode)
+      for (int mf : {2, 4, 8})
+        for (int nkh : {1, 2, 4}) {
+          int lds = 0;
+          gemm_fn fn = pick_gemm_mid(DK_INT4, layout, mode, mf, nkh, &lds);
+          if (fn) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         }
   (void)hipGetLastError();   // a refused attribute must not linger as this thread's "last error"
 }

@@ -179,7 +179,7 @@ def test_selector_invariants_over_a_random_configuration_sweep():
     kernel-name style (general_matmul/__init__.py:240-318) - and a refusal must carry a message."""
     import re
     rng = np.random.default_rng(7)
-    name_re = re.compile(r"^matmul_m\d+n\d+k\d+_[a-z0-9]+x[a-z0-9_]+_(gemv_b\d+r\d+d\d+(k\d+)?(_areg)?|gemvx_b\d+r\d+d\d+k\d+(_areg)?|(dq_)?tcx\d+x\d+x\d+(xr)?(pp(t\d+)?|xs|xdl[pt]?|xd|xw)?)$")
+    name_re = re.compile(r"^matmul_m\d+n\d+k\d+_[a-z0-9]+x[a-z0-9_]+_(gemv_b\d+r\d+d\d+(k\d+)?(_areg)?|gemvx_b\d+r\d+d\d+k\d+(_areg)?|(dq_)?tcx\d+x\d+x\d+(xr)?(pp(t\d+)?|xs|xdl[pt]?|xd|xw|xmk)?)$")
     pairs = [(wlib.F16, wlib.W_UINT, b) for b in (1, 2, 4, 8)] + [(wlib.F16, wlib.W_INT, b) for b in (1, 2, 4, 8)] + \
             [(wlib.F16, wlib.W_NF, 4), (wlib.F16, wlib.W_FP4, 4), (wlib.F16, wlib.W_E4M3, 8),
              (wlib.BF16, wlib.W_UINT, 4), (wlib.BF16, wlib.W_NF, 4),
@@ -362,6 +362,32 @@ def test_counted_decode_members_keep_their_loads_in_registers(tmp_path):
                 dyn = re.search(r"\.uses_dynamic_stack:\s+(\w+)", blk)
                 seen[m.group(1)] = (scratch, dyn.group(1) if dyn else "false")
     assert len(seen) >= 8, sorted(seen)                                          # {int4, lut4} x layouts x modes x {f16, bf16}, as instantiated
+    bad = {k: v for k, v in seen.items() if v != (0, "false")}
+    assert not bad, bad
+
+
+def test_mid_m_members_keep_their_loads_in_registers(tmp_path):
+    """the same for the mid-M member (csrc/wqaa_gemm_mid_kernel.h, round 5): every register load an inline-assembly instruction,
+    one wait - no scratch, no dynamic stack in any of its instantiations"""
+    import re
+    import shutil
+    import subprocess
+    readelf = "/opt/rocm/lib/llvm/bin/llvm-readelf"
+    if not (os.path.exists(readelf) and shutil.which("objcopy")):
+        pytest.skip("no llvm-readelf / objcopy on this box")
+    seen = {}
+    for k, co in enumerate(_gfx950_code_objects(wlib.LIB_PATH)):
+        f = tmp_path / f"co{k}.elf"
+        f.write_bytes(co)
+        notes = subprocess.run([readelf, "--notes", str(f)], capture_output=True, text=True).stdout
+        for blk in re.split(r"\n\s+- \.agpr_count:", notes):
+            m = re.search(r"\.name:\s+(_ZN4wqaa18wq_gemm_mid_kernelINS_9MidPolicy\S*)", blk)
+            if not m:
+                continue
+            scratch = int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", blk).group(1))
+            dyn = re.search(r"\.uses_dynamic_stack:\s+(\w+)", blk)
+            seen[m.group(1)] = (scratch, dyn.group(1) if dyn else "false")
+    assert len(seen) >= 60, len(seen)                                            # 2 layouts x 5 modes x 7 (rows, k-steps) shapes
     bad = {k: v for k, v in seen.items() if v != (0, "false")}
     assert not bad, bad
 

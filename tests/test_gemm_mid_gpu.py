@@ -1,0 +1,166 @@
+"""The mid-M member (csrc/wqaa_gemm_mid_kernel.h, plan suffix `xmk`; round 5): W int4 / uint4 x A float16 at M = 17 ... 128,
+ONE launch, K in 8 slices that meet inside it - BASELINE c3's M = 128 config (`W_int4 A_fp16 GEMM, M in {16, 128, 4096},
+N = K = 4096, group_size = 128 with zeros`) and the M = 32 / 64 steps of the reference's default `opt_M` list
+(ops/general_matmul/__init__.py:188-192; the split-K heuristic it replaces: tilelang/dequantize/matmul_dequantize_mma.py:127-168).
+
+Checked against the CPU oracle, and - bit for bit - against itself under the three ways a tile's portions can get reduced:
+  * every workgroup finds the others within the bound of its wait (the normal path),
+  * nobody waits at all (WQAA_GEMM_MID_SPIN_US=0): every non-last workgroup publishes its own portion, abandons it and leaves,
+    the last arriver of each tile sweeps and reduces all eight portions (what happens when a tile's workgroups are not
+    co-resident: a CU mask, a concurrent kernel),
+  * hipGraph replays (the tiles' sync words clean up after themselves: a replay finds them zero),
+and against the two-launch member it stands in for (oracle tolerance: the slices are other k ranges there)."""
+import numpy as np
+import pytest
+import torch
+
+import bitblas_amd as bitblas
+from helpers import assert_fp_parity, hip_output, make_case, oracle_output
+
+pytestmark = pytest.mark.gpu
+
+
+def _bits(x):
+    return x.view(np.uint16) if x.dtype == np.float16 else x.view(np.uint32)
+
+
+def _run(case, M, monkeypatch, check_paths=True):
+    monkeypatch.delenv("WQAA_GEMM_MID", raising=False)
+    monkeypatch.delenv("WQAA_GEMM_MID_SPIN_US", raising=False)
+    got, mm = hip_output(case)
+    assert mm.plans[M]["name"].endswith("xmk"), mm.plans[M]["name"]
+    assert mm.plans[M]["split_k"] == 8
+    want = oracle_output(case)
+    assert_fp_parity(got, want)
+    again, _ = hip_output(case, matmul=mm)
+    assert np.array_equal(_bits(got), _bits(again)), "run to run"
+    if check_paths:
+        monkeypatch.setenv("WQAA_GEMM_MID_SPIN_US", "0")
+        swept, mm0 = hip_output(case)
+        assert mm0.plans[M]["name"].endswith("xmk")
+        assert np.array_equal(_bits(got), _bits(swept)), "abandon / sweep path differs from the normal one"
+        monkeypatch.delenv("WQAA_GEMM_MID_SPIN_US")
+        back, _ = hip_output(case)
+        assert np.array_equal(_bits(got), _bits(back)), "the sync words were not left clean by the sweep path"
+    return got, mm
+
+
+@pytest.mark.parametrize("M", [17, 32, 33, 64, 100, 128])
+def test_c3_uint4_scale_zeros_4096(M, monkeypatch):
+    """BASELINE c3 at N = K = 4096 (uint4, g = 128, zeros original) - every tile height, ragged M included"""
+    case = make_case(M, 4096, 4096, W_dtype="uint4", group_size=128, with_scaling=True, with_zeros=True, zeros_mode="original", scale_mul=0.02, seed=M)
+    _run(case, M, monkeypatch)
+
+
+@pytest.mark.parametrize("zeros_mode", ["rescale", "quantized"])
+@pytest.mark.parametrize("M", [48, 128])
+def test_other_zero_point_forms_and_bias(zeros_mode, M, monkeypatch):
+    case = make_case(M, 2048 + 128, 4096, W_dtype="uint4", group_size=128, with_scaling=True, with_zeros=True, zeros_mode=zeros_mode, with_bias=True,
+                     scale_mul=0.02, seed=7 + M)
+    _run(case, M, monkeypatch)
+
+
+@pytest.mark.parametrize("fast", [False, True])
+@pytest.mark.parametrize("K,cfg", [(4096, dict(with_scaling=True, group_size=128)), (4096, dict()),
+                                   (2048, dict(with_scaling=True, group_size=-1)), (2048, dict(with_scaling=True, group_size=32)),
+                                   (2048, dict(with_scaling=True, group_size=256)), (2048, dict(with_scaling=True, group_size=128))])
+def test_int4_layouts_and_group_sizes(K, cfg, fast, monkeypatch):
+    """signed int4, both checkpoint layouts (plain / LOP3-interleaved); no scale; at K = 2048 (one k-step per k-half: the per-step
+    metadata loads) per-channel scales and g = 32 / 128 / 256"""
+    case = make_case(96, 1024, K, W_dtype="int4", fast_decoding=fast, scale_mul=0.02, seed=3, **cfg)
+    _run(case, 96, monkeypatch, check_paths=fast)
+
+
+def test_group_sizes_the_wide_metadata_loads_do_not_take_keep_their_members():
+    for g in (-1, 32, 256):
+        mm = bitblas.Matmul(bitblas.MatmulConfig(M=96, N=1024, K=4096, A_dtype="float16", W_dtype="int4", group_size=g, with_scaling=True), enable_tuning=False)
+        assert "xmk" not in mm.plans[96]["name"], mm.plans[96]["name"]
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 4096, 2048), (64, 2048, 8192), (32, 4096, 8192), (40, 1000, 4096), (128, 132, 4096)])
+def test_other_k_and_ragged_n(M, N, K, monkeypatch):
+    """K = 2048 (one k-step per k-half) and 8192 (four: M <= 64 fits the LDS), N off the 128-column tile"""
+    case = make_case(M, N, K, W_dtype="uint4", group_size=128, with_scaling=True, with_zeros=True, zeros_mode="original", scale_mul=0.02, seed=M + N)
+    _run(case, M, monkeypatch)
+
+
+def test_float32_output(monkeypatch):
+    case = make_case(128, 2048, 4096, W_dtype="uint4", group_size=128, with_scaling=True, with_zeros=True, out_dtype="float32", scale_mul=0.02, seed=5)
+    _run(case, 128, monkeypatch)
+
+
+def test_hipgraph_replays_find_clean_sync_words(monkeypatch):
+    """one captured launch replayed: same kernel arguments every time, so the tiles' sync words must be zero again after each"""
+    monkeypatch.delenv("WQAA_GEMM_MID", raising=False)
+    M = 128
+    case = make_case(M, 4096, 4096, W_dtype="uint4", group_size=128, with_scaling=True, with_zeros=True, scale_mul=0.02, seed=9)
+    ref, mm = hip_output(case)
+    dev = "cuda"
+    A = torch.from_numpy(case["A"]).to(dev)
+    qw = mm.transform_weight(torch.from_numpy(case["codes"])).to(dev)
+    sc = torch.from_numpy(case["scale"]).to(dev)
+    zr = torch.from_numpy(case["zeros"]).to(dev)
+    out = torch.zeros((M, 4096), dtype=torch.float16, device=dev)
+    mm.forward(A, qw, scale=sc, zeros=zr, output=out)          # (outside capture first: the device's sync slab exists)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        mm.forward(A, qw, scale=sc, zeros=zr, output=out)
+        mm.forward(A, qw, scale=sc, zeros=zr, output=out)      # (two launches on one workspace, back to back)
+    for _ in range(5):
+        out.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        assert np.array_equal(_bits(out.cpu().numpy()), _bits(ref))
+
+
+def test_two_streams_do_not_share_sync_words(monkeypatch):
+    """two operators' launches in flight on two streams: each stream's workspace brings its own sync words"""
+    monkeypatch.delenv("WQAA_GEMM_MID", raising=False)
+    M = 64
+    case = make_case(M, 4096, 4096, W_dtype="uint4", group_size=128, with_scaling=True, with_zeros=True, scale_mul=0.02, seed=21)
+    ref, mm = hip_output(case)
+    dev = "cuda"
+    A = torch.from_numpy(case["A"]).to(dev)
+    qw = mm.transform_weight(torch.from_numpy(case["codes"])).to(dev)
+    sc = torch.from_numpy(case["scale"]).to(dev)
+    zr = torch.from_numpy(case["zeros"]).to(dev)
+    outs = [torch.zeros((M, 4096), dtype=torch.float16, device=dev) for _ in range(2)]
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    torch.cuda.synchronize()
+    for _ in range(20):
+        for s, o in zip(streams, outs):
+            with torch.cuda.stream(s):
+                mm.forward(A, qw, scale=sc, zeros=zr, output=o)
+    torch.cuda.synchronize()
+    for o in outs:
+        assert np.array_equal(_bits(o.cpu().numpy()), _bits(ref))
+
+
+def test_the_member_it_stands_in_for_is_still_there(monkeypatch):
+    """WQAA_GEMM_MID=0: the two-launch member (split-K + reduce kernel); both within the oracle's tolerance of each other"""
+    M = 128
+    case = make_case(M, 4096, 4096, W_dtype="uint4", group_size=128, with_scaling=True, with_zeros=True, scale_mul=0.02, seed=2)
+    monkeypatch.delenv("WQAA_GEMM_MID", raising=False)
+    got, mm = hip_output(case)
+    assert mm.plans[M]["name"].endswith("xmk")
+    monkeypatch.setenv("WQAA_GEMM_MID", "0")
+    old, mm0 = hip_output(case)
+    assert "xmk" not in mm0.plans[M]["name"] and "xr" in mm0.plans[M]["name"], mm0.plans[M]["name"]
+    want = oracle_output(case)
+    assert_fp_parity(got, want)
+    assert_fp_parity(old, want)
+
+
+def test_shapes_outside_the_member_keep_theirs():
+    """more than one round of workgroups, K off the 2048 grid, M <= 16, other formats"""
+    def name(M, N, K, **kw):
+        cfg = dict(A_dtype="float16", W_dtype="uint4", group_size=128, with_scaling=True, with_zeros=True)
+        cfg.update(kw)
+        return bitblas.Matmul(bitblas.MatmulConfig(M=M, N=N, K=K, **cfg), enable_tuning=False).plans[M]["name"]
+    assert "xmk" not in name(128, 11008, 4096)
+    assert "xmk" not in name(128, 4096, 11008)
+    assert "xmk" not in name(16, 4096, 4096)
+    assert "xmk" not in name(128, 4096, 4096, W_dtype="uint2")
+    assert "xmk" not in name(128, 4096, 8192)          # (128 rows x K / 8 = 1024 k does not fit the LDS)
+    assert name(64, 4096, 8192).endswith("xmk")

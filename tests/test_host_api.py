@@ -171,8 +171,9 @@ def test_k_split_reaches_the_selector():
     op = bitblas.MatmulWithSplitK(bitblas.MatmulConfigWithSplitK(M=128, N=4096, K=512, A_dtype="float16", W_dtype="int4",
                                                                  group_size=128, with_scaling=True, k_split=64), enable_tuning=False)
     assert op.plans[128]["split_k"] == 4
-    # the plain operator decides for itself
-    assert bitblas.Matmul(bitblas.MatmulConfig(M=128, **kw), enable_tuning=False).plans[128]["split_k"] == 4
+    # the plain operator decides for itself (round 5: the mid-M member - K in 8 slices that meet inside the one launch)
+    plain = bitblas.Matmul(bitblas.MatmulConfig(M=128, **kw), enable_tuning=False).plans[128]
+    assert plain["split_k"] == 8 and plain["name"].endswith("xmk"), plain
     # M = 1 exact-product GEMV: the K split across the waves of a workgroup
     kw.update(N=1024, K=16384)          # four 4096-deep steps of the 4-bit GEMV
     op = bitblas.MatmulWithSplitK(bitblas.MatmulConfigWithSplitK(M=1, k_split=2, **kw), enable_tuning=False, strict_reference=False)

@@ -77,3 +77,25 @@ def test_the_hand_counted_decode_kernels_of_the_built_library_are_clean():
     out = buf.getvalue()
     assert rc == 0, out[-3000:]
     assert "kernels checked, 0 with findings" in out and int(out.strip().split("\n")[-1].split()[0]) >= 8, out[-500:]
+
+
+def test_the_mid_m_kernels_of_the_built_library_are_clean():
+    """round 5: wq_gemm_mid_kernel (csrc/wqaa_gemm_mid_kernel.h) issues every register load as inline assembly next to its LDS-DMA
+    and waits once - the same contract, checked the same way (its first build had a run-time branch that joined two register
+    assignments of in-flight loads: 30 of 70 instantiations had findings)"""
+    from bitblas_amd import lib as wlib
+    if not (os.path.exists(chk.OBJDUMP) and shutil.which("objcopy")):
+        pytest.skip("no llvm-objdump / objcopy on this box")
+    import io
+    from contextlib import redirect_stdout
+    buf = io.StringIO()
+    old = sys.argv
+    sys.argv = ["check_vmem_hazards.py", "--lib", wlib.LIB_PATH, "--match", "wq_gemm_mid_kernel"]
+    try:
+        with redirect_stdout(buf):
+            rc = chk.main()
+    finally:
+        sys.argv = old
+    out = buf.getvalue()
+    assert rc == 0, out[-3000:]
+    assert "kernels checked, 0 with findings" in out and int(out.strip().split("\n")[-1].split()[0]) >= 60, out[-500:]

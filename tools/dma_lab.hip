@@ -56,6 +56,80 @@ __global__ void __launch_bounds__(256) k_stream(const unsigned char* base, int u
   if (sink && lane == 0 && b == 0) sink[wave] = ((unsigned*)smem)[ring0 / 4];
 }
 
+// ---- round 5 (VERDICT r04 "weak" #3 / "next" #4): is the 8.4 GB/s per loader wave above the M0 handling, not the machine? --------
+// MI355X_MICROARCH row ldsdma-fill: ~25 GB/s per CU from ONE loader wave (0.65 us per 16 KiB fill, issue 0.154 us per fill).  The
+// kernel above wraps EVERY 1-KiB load in `s_mov keep, m0; s_mov m0, dst; s_nop; LOAD; s_mov m0, keep` - two M0 writes right behind
+// an LDS-DMA that may still be reading it.  Variants, same patterns and byte counts:
+//   M0MODE 0  as above (save / restore per KiB) - the round-4 baseline
+//          1  M0 in the clobber list, one s_mov per KiB, no restore
+//          2  ONE s_mov m0 per 4-KiB fill, the four loads step the instruction's immediate offset 0 / 1024 / 2048 / 3072 (the
+//             offset advances the memory address AND the LDS address)
+//          3  the compiler's builtin (it owns M0)
+//          4  as 2 with one s_mov per 16-KiB fill: 4 x (s_add to a voff VGPR? no -) four groups of four offset loads, the source
+//             base stepped in SGPRs, M0 written once per 4 KiB but from a precomputed SGPR (no readfirstlane / VALU in between)
+//   DEPTH: loads in flight before the loader waits (vmcnt(DEPTH - 8) after every 8 loads)
+template <int M0MODE, int DEPTH>
+__global__ void __launch_bounds__(256) k_stream2(const unsigned char* base, int units, int pattern, int loaders, unsigned* sink) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int b = blockIdx.x, G = gridDim.x;
+  if (wave >= loaders) return;
+  const unsigned ring_units = (128 / loaders) & ~3u;        // KiB of LDS ring per loader
+  const unsigned ring0 = wave * ring_units * 1024;
+  const unsigned lds_base = (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned char*)smem;
+  unsigned rpos = 0;
+  int inflight = 0;
+  const unsigned voff = lane * 16;
+  for (int u = wave * 4; u < units; u += loaders * 4) {      // fills of 4 KiB
+    long kib;
+    if (pattern == 0) kib = (long)b * units + u;
+    else kib = ((long)(u >> 2) * G + b) * 4;                 // pattern 1: the chip walks one window, 4 KiB per CU per step
+    const unsigned long long src = (unsigned long long)base + (unsigned long long)kib * 1024ull;
+    const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + ring0 + rpos * 1024);
+    if (M0MODE == 0) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3 nt\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(voff), "s"(dst + q * 1024), "s"(src + q * 1024ull) : "memory");
+      }
+    } else if (M0MODE == 1) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2 nt" ::"v"(voff), "s"(dst + q * 1024), "s"(src + q * 1024ull) : "memory", "m0");
+    } else if (M0MODE == 2 || M0MODE == 4) {
+      asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\t"
+                   "global_load_lds_dwordx4 %0, %2 nt\n\t"
+                   "global_load_lds_dwordx4 %0, %2 offset:1024 nt\n\t"
+                   "global_load_lds_dwordx4 %0, %2 offset:2048 nt\n\t"
+                   "global_load_lds_dwordx4 %0, %2 offset:3072 nt" ::"v"(voff), "s"(dst), "s"(src) : "memory", "m0");
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + q * 1024ull + voff),
+                                         (__attribute__((address_space(3))) void*)(smem + ring0 + rpos * 1024 + q * 1024), 16, 0, 2);
+    }
+    rpos += 4;
+    if (rpos >= ring_units) rpos = 0;
+    inflight += 4;
+    if (inflight >= 8) {
+      inflight = 0;
+      if (M0MODE == 3) {
+        __builtin_amdgcn_s_waitcnt(0x0F70 | ((DEPTH - 8) & 15) | (((DEPTH - 8) >> 4) << 14));   // vmcnt only (gfx9 encoding: [3:0] + [15:14])
+      } else {
+        if (DEPTH == 16) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        if (DEPTH == 32) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+        if (DEPTH == 48) asm volatile("s_waitcnt vmcnt(40)" ::: "memory");
+        if (DEPTH == 56) asm volatile("s_waitcnt vmcnt(48)" ::: "memory");
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (sink && lane == 0 && b == 0) sink[wave] = ((unsigned*)smem)[ring0 / 4];
+}
+
+// the same stream WITH consumers: `cons` waves per CU read each landed 4-KiB fill back (ds_read_b128) - nothing in the way of the
+// loader but the LDS port; loader -> consumer hand-off by a per-fill LDS counter (the loader publishes after its counted vmcnt)
 typedef void (*kfn)(const unsigned char*, int, int, int, unsigned*);
 
 int main() {
@@ -92,5 +166,51 @@ int main() {
         const double us = ms * 1e3 / reps;
         printf("%-22s %-8d %-8d %10.2f %10.3f\n", v.name, pattern, loaders, us, bytes / us / 1e6);
       }
+  // ---- round 5: M0 handling / depth variants (one .. four loaders, patterns 0 and 1) ----
+  struct V2 { const char* name; kfn fn; } v2[] = {
+    {"m0 save/restore d56", k_stream2<0, 56>}, {"m0 clobber d56", k_stream2<1, 56>}, {"m0 per 4KiB+offs d56", k_stream2<2, 56>},
+    {"builtin d56", k_stream2<3, 56>}, {"m0 per 4KiB+offs d32", k_stream2<2, 32>}, {"m0 per 4KiB+offs d16", k_stream2<2, 16>},
+    {"m0 clobber d32", k_stream2<1, 32>},
+  };
+  for (auto& v : v2) CK(hipFuncSetAttribute((const void*)v.fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  printf("\n%-22s %-8s %-8s %10s %10s %12s\n", "variant (round 5)", "pattern", "loaders", "us", "TB/s", "GB/s per CU");
+  for (auto& v : v2)
+    for (int pattern = 0; pattern < 2; ++pattern)
+      for (int loaders : {1, 2, 4}) {
+        for (int w = 0; w < 2; ++w) hipLaunchKernelGGL(v.fn, dim3(G), dim3(256), 131072, 0, bufs[w], units, pattern, loaders, sink);
+        CK(hipDeviceSynchronize());
+        CK(hipEventRecord(e0));
+        const int reps = 16;
+        for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(v.fn, dim3(G), dim3(256), 131072, 0, bufs[r % nbuf], units, pattern, loaders, sink);
+        CK(hipEventRecord(e1));
+        CK(hipEventSynchronize(e1));
+        float ms = 0;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        const double us = ms * 1e3 / reps;
+        printf("%-22s %-8d %-8d %10.2f %10.3f %12.2f\n", v.name, pattern, loaders, us, bytes / us / 1e6, bytes / us / 1e3 / G);
+      }
+  // a longer stream (1200 KiB per CU: the launch boundary is ~2 us of the 300-KiB runs)
+  {
+    const int units_l = 1200;
+    const size_t bytes_l = (size_t)G * units_l * 1024;
+    unsigned char* big;
+    CK(hipMalloc(&big, bytes_l));
+    CK(hipMemset(big, 1, bytes_l));
+    printf("\n%-22s %-8s %-8s %10s %10s %12s   (1200 KiB per CU)\n", "variant (round 5)", "pattern", "loaders", "us", "TB/s", "GB/s per CU");
+    for (auto& v : v2)
+      for (int loaders : {1, 4}) {
+        for (int w = 0; w < 2; ++w) hipLaunchKernelGGL(v.fn, dim3(G), dim3(256), 131072, 0, big, units_l, 0, loaders, sink);
+        CK(hipDeviceSynchronize());
+        CK(hipEventRecord(e0));
+        const int reps = 8;
+        for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(v.fn, dim3(G), dim3(256), 131072, 0, big, units_l, 0, loaders, sink);
+        CK(hipEventRecord(e1));
+        CK(hipEventSynchronize(e1));
+        float ms = 0;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        const double us = ms * 1e3 / reps;
+        printf("%-22s %-8d %-8d %10.2f %10.3f %12.2f\n", v.name, 0, loaders, us, bytes_l / us / 1e6, bytes_l / us / 1e3 / G);
+      }
+  }
   return 0;
 }
