@@ -351,29 +351,36 @@ static int gemm_choose(const wqaa_matmul_desc& d, int m, GemmChoice* c, bool fus
     set_error(WQAA_ERR_UNSUPPORTED, "gemm: K=%d must be a multiple of %d", d.K, c->ks);
     return WQAA_ERR_UNSUPPORTED;
   }
-  // round 5 - the mid-M member (wqaa_gemm_mid_kernel.h): 4-bit weights x float16, M = 17 ... 128 per M-tile, K = 2048 nkh with the
-  // workgroup's whole activation slice (16 mf rows x K / 8) in LDS; one launch, K in 8 slices that meet inside it.  Taken where
-  // its tiles x 8 workgroups are at most one round of the chip (WQAA_GEMM_MID=0: never; WQAA_GEMM_MID_MAXM / _MINM / _ROUNDS: tuning aids)
+  // round 5 - the mid-M member (wqaa_gemm_mid_kernel.h): 4-bit weights x float16, up to 128 rows per M-tile, K = 2048 nkh with the
+  // workgroup's whole activation slice (16 mf rows x K / 8) in LDS; K in 8 slices, everything a workgroup reads asked for at once.
+  // WHERE, from same-process A/B against the members it stands in for (tools/r05_ab_mid.py, profiles/r05_ab_mid_v3.txt; uint4 g128 +
+  // zeros, us): 65 ... 128 rows in one round of the chip at K = 4096: M = 96 16.1 vs 16.7, M = 128 16.9 vs 17.1; up to 64 rows where
+  // the old members ran long k ranges or several rounds: 64 x 4096 x 8192 17.9 vs 21.1, 32 x 4096 x 8192 13.8 vs 15.2, 64 x 8192 x 4096
+  // 18.4 vs 20.9, 64 x 11008 x 4096 23.9 vs 26.4.  It LOSES at up to 64 rows in one round at K = 4096 (M = 32 11.0 vs 9.6, M = 64 13.8 vs
+  // 12.3: the split-K skinny member's smaller workgroups overlap), at 128 rows over several rounds (11008 x 4096 39.0 vs 33.8) and at
+  // K = 2048 (16.4 vs 13.1) - those keep their members.  WQAA_GEMM_MID=0: never; WQAA_GEMM_MID_FORCE=1: wherever the shape fits (the
+  // parity tests run every instantiation that way).
   if (!no_mid && !fused_epilogue && c->at == AT_F16 && !(c->flags & FL_BF16) && c->kind == DK_INT4 && d.k_split_hint <= 1 &&
-      getenv("WQAA_GEMM_KSPLIT") == nullptr && getenv("WQAA_GEMM_MF") == nullptr) {
+      getenv("WQAA_GEMM_KSPLIT") == nullptr && getenv("WQAA_GEMM_MF") == nullptr && m > 16) {
     const char* mf_ = getenv("WQAA_GEMM_MID");
-    int max_m = 128, min_m = 17, rounds = 1;
-    if (const char* f = getenv("WQAA_GEMM_MID_MAXM")) max_m = atoi(f);
-    if (const char* f = getenv("WQAA_GEMM_MID_MINM")) min_m = atoi(f);
-    if (const char* f = getenv("WQAA_GEMM_MID_ROUNDS")) rounds = atoi(f);
+    const char* ff_ = getenv("WQAA_GEMM_MID_FORCE");
+    const bool force = ff_ && atoi(ff_) != 0;
     const int nkh = d.K % 2048 == 0 ? d.K / 2048 : 0;
     const int tm = (m + 127) / 128;
     const int rows = (m + tm - 1) / tm;                       // rows per M-tile
     const int mf = rows > 64 ? 8 : rows > 32 ? 4 : 2;
     const long tiles = (long)((m + 16 * mf - 1) / (16 * mf)) * ((d.N + 127) / 128);
+    const long wgs = tiles * 8;
     int lds = 0;
     gemm_fn fn = (nkh == 1 || nkh == 2 || nkh == 4) && mf * nkh <= 16 ? pick_gemm_mid(c->kind, c->layout, c->mode, mf, nkh, &lds) : nullptr;
     // (the members with NKH >= 2 fetch Scale / Zeros of their NKH consecutive groups in one load per row: one group per k-step,
     // rows aligned; other group sizes keep the members they had)
     const bool widemeta = (c->mode == MD_S || c->mode == MD_ZO || c->mode == MD_ZR) && nkh >= 2;
     const bool meta_ok = !widemeta || (g == c->ks && (d.K / g) % nkh == 0);
-    if (fn && meta_ok && (!mf_ || atoi(mf_) != 0) && m >= min_m && m <= max_m && tiles * 8 <= (long)rounds * cus_ && tiles <= kMidMaxTiles &&
-        (long)m * d.K * 2 < (1L << 32) && d.K < (1 << 23) && (c->mode != MD_ZQ || d.N % 2 == 0)) {
+    const bool measured = m <= 128 && (mf == 8 ? (nkh == 2 && wgs <= cus_)
+                                               : (nkh == 4 ? wgs <= 3L * cus_ : (nkh == 2 && wgs > cus_ && wgs <= 3L * cus_)));
+    if (fn && meta_ok && (!mf_ || atoi(mf_) != 0) && (force || measured) && tiles <= kMidMaxTiles &&
+        (long)m * d.K * 2 < (1L << 32) && d.K < (1 << 23) && m < (1 << 23) && (c->mode != MD_ZQ || d.N % 2 == 0)) {
       c->mid = 1;
       c->mid_nkh = nkh;
       c->fn = fn;
@@ -384,7 +391,7 @@ static int gemm_choose(const wqaa_matmul_desc& d, int m, GemmChoice* c, bool fus
       c->tiles_m = (m + 16 * mf - 1) / (16 * mf);
       c->tiles_n = (d.N + 127) / 128;
       c->lds = lds;
-      c->ksplit = 1;              // (no second launch: the slices meet inside this one)
+      c->ksplit = 1;              // (no split-K reduce of the old kind: the member brings its own second launch, or none)
       return WQAA_OK;
     }
   }
@@ -611,6 +618,7 @@ int gemm_launch(const wqaa_matmul_desc& d, const void* A, const void* B, const v
   // cannot grow or a device's first use inside a stream capture) the call runs the member it stands in for
   void* mid_ws = nullptr;
   unsigned* mid_sync = nullptr;
+  bool mid_in_launch = false;
   if (c.mid && !epi) {
     const size_t need = mid_ws_bytes(c);
     if (opts && opts->workspace) {
@@ -618,8 +626,21 @@ int gemm_launch(const wqaa_matmul_desc& d, const void* A, const void* B, const v
     } else if (pool_workspace_ready(stream, need)) {
       mid_ws = pool_workspace(stream, need);
     }
-    if (mid_ws) mid_sync = mid_sync_words(stream, mid_ws);
-    if (!mid_ws || !mid_sync) {
+    // the seam: 0 (default) = a second launch adds the slices (wq_mid_reduce_kernel); 1 = they meet inside the launch (needs the
+    // tiles' sync words).  Same summation order, same bits; the second launch measured faster
+    static thread_local unsigned seam_seen = ~0u;
+    static thread_local int seam_mode = 0;
+    {
+      const unsigned ep = g_plan_epoch.load(std::memory_order_relaxed);
+      if (ep != seam_seen) {
+        const char* f = getenv("WQAA_GEMM_MID_SEAM");
+        seam_mode = f ? atoi(f) : 0;
+        seam_seen = ep;
+      }
+    }
+    mid_in_launch = seam_mode == 1;
+    if (mid_ws && mid_in_launch) mid_sync = mid_sync_words(stream, mid_ws);
+    if (!mid_ws || (mid_in_launch && !mid_sync)) {
       int st = gemm_choose(d, m, &c, false, true);
       if (st != WQAA_OK) return st;
     }
@@ -714,7 +735,7 @@ int gemm_launch(const wqaa_matmul_desc& d, const void* A, const void* B, const v
   hipError_t e;
   if (start || stop) {
     e = hipExtLaunchKernel(reinterpret_cast<const void*>(c.fn), grid, block, params, c.lds, stream, start,
-                           (c.ksplit > 1 || c.tail_fn) ? nullptr : stop, 0);
+                           (c.ksplit > 1 || c.tail_fn || (c.mid && !mid_in_launch)) ? nullptr : stop, 0);
   } else {
     e = hipLaunchKernel(reinterpret_cast<const void*>(c.fn), grid, block, params, c.lds, stream);
   }
@@ -730,6 +751,14 @@ int gemm_launch(const wqaa_matmul_desc& d, const void* A, const void* B, const v
     const dim3 tgrid(c.tail_tiles_m * c.tail_tiles_n, 1, 1);
     if (start || stop) e = hipExtLaunchKernel(reinterpret_cast<const void*>(c.tail_fn), tgrid, block, tparams, c.tail_lds, stream, nullptr, stop, 0);
     else e = hipLaunchKernel(reinterpret_cast<const void*>(c.tail_fn), tgrid, block, tparams, c.tail_lds, stream);
+  }
+  if (e == hipSuccess && c.mid && !mid_in_launch) {
+    int mfc = c.mf, units = c.tiles_m * c.tiles_n * 8 * c.mf;
+    void* rparams[] = {&a, &mfc, &units};
+    const dim3 rgrid((unsigned)((units + 3) / 4)), rblock(256);
+    const void* rfn = reinterpret_cast<const void*>(wq_mid_reduce_kernel<0>);
+    if (start || stop) e = hipExtLaunchKernel(rfn, rgrid, rblock, rparams, 0, stream, nullptr, stop, 0);
+    else e = hipLaunchKernel(rfn, rgrid, rblock, rparams, 0, stream);
   }
   if (e == hipSuccess && c.ksplit > 1) {
     const long quads = (long)m * d.N / 4;

@@ -66,7 +66,13 @@ constexpr int kMidSlices = 8;
 constexpr int kMidSyncWords = 16;           // per tile: [0] arrivals, [1] portions done, [2..9] portion state (0 free, 1 abandoned, 2 taken)
 
 __device__ __forceinline__ void st_wt(f32x4* dst, const f32x4 v) {      // write-through: visible to every CU once the store has been acknowledged
-  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(v) : "memory");
+  // (the wait states: a vector-memory store of more than 64 bits reads its data registers over several cycles after issue, and the
+  // compiler - which sees an opaque asm, not a store - puts no hazard nops in front of the next write of those registers.  Round 5's
+  // first two-launch build re-used the first two data registers for the next store's address three scalar instructions later:
+  // lanes 12-15 of every 16 stored address bits (tools/r05_diag_mid.py found the rows).  Two wait states are what the hardware needs
+  // and what the compiler pads its own stores with: tools/store_hazard_lab.hip, profiles/r05_lab_store_hazard.txt; tools/check_vmem_hazards.py
+  // now looks for this on every kernel of the built library.)
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(dst), "v"(v) : "memory");
 }
 
 template <class P>
@@ -84,6 +90,8 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_mid_kernel(const GemmArgs 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fr = lane & 15, kb = lane >> 4;
   const int nq = wave & 3, kh = wave >> 2;
+  WQ_TRACE_DECL;      // (lab builds only, tools/mid_trace.hip: per-wave phase stamps)
+  WQ_TRACE(0);
 
   // workgroup -> (tile, slice): the eight slices of a tile are consecutive in the XCD-contiguous order, so they share an XCD
   // when the dispatcher deals blocks round-robin (for speed only - nothing below relies on it)
@@ -117,36 +125,51 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_mid_kernel(const GemmArgs 
     const int n = n0 + nf * 16 + fr;
     nrow[nf] = n < a.N ? n : a.N - 1;
   }
+  // Issue order per wave, k-step by k-step: [weights i] [Scale / Zeros, with step 0] [this wave's share of the activation
+  // tile of step i, by LDS-DMA] - a wave's vector-memory operations retire in order, so `vmcnt(everything issued for the later
+  // steps)` means step i has landed and the multiply of step i runs while steps i + 1 ... are still arriving (the first build
+  // waited for everything: 5.2 us before the first MFMA at M = 128, profiles/r05_lab_mid_trace_v1.txt).
+  uint32_t s32[2] = {0u, 0u}, z32[2] = {0u, 0u};
+  u32x2 s64[2] = {u32x2{0u, 0u}, u32x2{0u, 0u}}, z64[2] = {u32x2{0u, 0u}, u32x2{0u, 0u}};
+  // LDS-DMA source of this lane: 4 rows x 256 B per instruction, the four waves of the k-half interleaved over the row groups.
+  // Slot p of row r holds granule p ^ (r & 15) in the order (j << 2) | kb (wq_gemm_kernel): conflict-free ds_read_b128 for the
+  // MFMA operand map; the swizzle is applied on the SOURCE address
+  const int rsub = lane >> 4;
+  const int xs = (lane & 15) ^ ((4 * nq + rsub) & 15);            // (row group q = nq mod 4 for every instruction of this wave)
+  const int ns = (xs & 3) * 4 + (xs >> 2);
+  const uint32_t a_row_bytes = (uint32_t)a.K * 2u;
+  const uint8_t* a_k = Ap + (long)(split * (2 * NKH) + kh * NKH) * 256;              // wave-uniform: the half's first k-step
+  constexpr int NMETA0 = P::WIDEMETA ? (ZP ? 4 : 2) : 0;          // metadata loads issued with step 0 (the wide form)
+  constexpr int NMETAI = (!P::WIDEMETA && MODE != MD_NONE) ? ((ZP || MODE == MD_ZQ) ? 4 : 2) : 0;   // ... with every step (the per-step form)
+  constexpr int OPS_STEP = 2 + NMETAI + MF;                       // vector-memory operations per k-step and wave (+ NMETA0 for step 0)
 #pragma unroll
-  for (int i = 0; i < NKH; ++i)
+  for (int i = 0; i < NKH; ++i) {
 #pragma unroll
     for (int nf = 0; nf < 2; ++nf) {
       const uint8_t* wp = Bp + (long)nrow[nf] * a.row_bytes + (long)(t0 + i) * 64 + kb * 16;
       asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(wreg[i][nf]) : "v"(wp) : "memory");
     }
-  // Scale / Zeros.  WIDE members (Scale / Zeros in A_dtype, NKH = 2 / 4; the host admits them for one group per k-step - g = 128 -
-  // with K / g a multiple of NKH): the wave's groups are consecutive and aligned - ONE 4- / 8-byte load per row instead of NKH
-  // 2-byte ones (a 2-byte load per lane touches as many cache lines per instruction as the weights do).  The others (packed
-  // integer zero points, NKH = 1) load per k-step, any group size.  Compile-time: no branch joins two register assignments
-  // of in-flight loads.
-  uint32_t s32[2] = {0u, 0u}, z32[2] = {0u, 0u};
-  u32x2 s64[2] = {u32x2{0u, 0u}, u32x2{0u, 0u}}, z64[2] = {u32x2{0u, 0u}, u32x2{0u, 0u}};
-  if constexpr (P::WIDEMETA) {
+    // Scale / Zeros.  WIDE members (Scale / Zeros in A_dtype, NKH = 2 / 4; the host admits them for one group per k-step - g = 128 -
+    // with K / g a multiple of NKH): the wave's groups are consecutive and aligned - ONE 4- / 8-byte load per row instead of NKH
+    // 2-byte ones (a 2-byte load per lane touches as many cache lines per instruction as the weights do).  The others (packed
+    // integer zero points, NKH = 1) load per k-step, any group size.  Compile-time: no branch joins two register assignments
+    // of in-flight loads.
+    if constexpr (P::WIDEMETA) {
+      if (i == 0) {
 #pragma unroll
-    for (int nf = 0; nf < 2; ++nf) {
-      const uint16_t* sp = Sp + (long)nrow[nf] * a.kg + t0;
-      const uint16_t* zp = Zp + (long)nrow[nf] * a.kg + t0;
-      if constexpr (NKH == 2) {
-        asm volatile("global_load_dword %0, %1, off" : "=v"(s32[nf]) : "v"(sp) : "memory");
-        if constexpr (ZP) asm volatile("global_load_dword %0, %1, off" : "=v"(z32[nf]) : "v"(zp) : "memory");
-      } else {
-        asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(s64[nf]) : "v"(sp) : "memory");
-        if constexpr (ZP) asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(z64[nf]) : "v"(zp) : "memory");
+        for (int nf = 0; nf < 2; ++nf) {
+          const uint16_t* sp = Sp + (long)nrow[nf] * a.kg + t0;
+          const uint16_t* zp = Zp + (long)nrow[nf] * a.kg + t0;
+          if constexpr (NKH == 2) {
+            asm volatile("global_load_dword %0, %1, off" : "=v"(s32[nf]) : "v"(sp) : "memory");
+            if constexpr (ZP) asm volatile("global_load_dword %0, %1, off" : "=v"(z32[nf]) : "v"(zp) : "memory");
+          } else {
+            asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(s64[nf]) : "v"(sp) : "memory");
+            if constexpr (ZP) asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(z64[nf]) : "v"(zp) : "memory");
+          }
+        }
       }
-    }
-  } else if constexpr (MODE != MD_NONE) {
-#pragma unroll
-    for (int i = 0; i < NKH; ++i) {
+    } else if constexpr (MODE != MD_NONE) {
       const int kidx = (t0 + i) * 4 + kb;
       const int gi = a.gq_shift >= 0 ? (kidx >> a.gq_shift) : (int)__umulhi((uint32_t)kidx, a.gq_magic);
 #pragma unroll
@@ -163,21 +186,9 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_mid_kernel(const GemmArgs 
         }
       }
     }
-  }
-
-  // ---- 2. the activation slice by LDS-DMA: this k-half's NKH k-steps, 4 rows x 256 B per instruction, the four waves of the half
-  // interleaved over the row groups.  Slot p of row r holds granule p ^ (r & 15) in the order (j << 2) | kb (wq_gemm_kernel):
-  // conflict-free ds_read_b128 for the MFMA operand map; the swizzle is applied on the SOURCE address ----
-  {
-    const int rsub = lane >> 4;
-    const int xs = (lane & 15) ^ ((4 * nq + rsub) & 15);          // (row group q = nq mod 4 for every instruction of this wave)
-    const int ns = (xs & 3) * 4 + (xs >> 2);
-    const uint32_t a_row_bytes = (uint32_t)a.K * 2u;
-    const uint8_t* a_k = Ap + (long)(split * (2 * NKH) + kh * NKH) * 256;            // wave-uniform: the half's first k-step
 #pragma unroll
-    for (int y = 0; y < NKH * MF; ++y) {
-      const int i = y / MF;                                        // k-step of the half
-      const int q = nq + 4 * (y % MF);                             // row group (4 rows) of the tile
+    for (int y = 0; y < MF; ++y) {
+      const int q = nq + 4 * y;                                    // row group (4 rows) of the tile
       int r = m0 + 4 * q + rsub;
       r = r < a.M ? r : a.M - 1;                                   // rows >= M: a copy of the last row, never stored (no branch per instruction)
       const uint32_t voff = __umul24((uint32_t)r, a_row_bytes) + (uint32_t)(ns * 16);   // one 32-bit v_mad_u32_u24 (the host keeps M and 2 K below 2^24, M K 2 below 4 GiB)
@@ -186,6 +197,7 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_mid_kernel(const GemmArgs 
     }
   }
 
+  WQ_TRACE(1);
   DecodeCtx cx;
   cx.zf = (a.is_signed) ? (half_t)(float)(1 << (T::BITS - 1)) : (half_t)0.0f;
   cx.flip = 0u;
@@ -204,31 +216,37 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_mid_kernel(const GemmArgs 
     acc[mf][1] = f32x4{0, 0, 0, 0};
   }
 
-  // everything this workgroup will ever read is in flight; one wait, one barrier.  The wait hands the loaded registers on
-  // ("+v": nothing that reads them can be scheduled above it, and they must exist - in place - up to here)
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-  for (int i = 0; i < NKH; ++i) asm volatile("" : "+v"(wreg[i][0]), "+v"(wreg[i][1])::"memory");
-  if constexpr (P::WIDEMETA) {
-    if constexpr (NKH == 2) {
-      asm volatile("" : "+v"(s32[0]), "+v"(s32[1])::"memory");
-      if constexpr (ZP) asm volatile("" : "+v"(z32[0]), "+v"(z32[1])::"memory");
-    } else {
-      asm volatile("" : "+v"(s64[0]), "+v"(s64[1])::"memory");
-      if constexpr (ZP) asm volatile("" : "+v"(z64[0]), "+v"(z64[1])::"memory");
-    }
-  } else if constexpr (MODE != MD_NONE) {
-#pragma unroll
-    for (int i = 0; i < NKH; ++i) {
+  // ---- 3. multiply, k-step by k-step: wait for step I (counted: the later steps' operations stay in flight), one barrier (the
+  // tile of a step is the work of the k-half's four waves), decode the two fragments once, every activation fragment read from
+  // LDS feeds two MFMAs.  The wait hands step I's registers on ("+v": nothing that reads them can be scheduled above it, and they
+  // must exist - in place - up to here) ----
+  auto step = [&](auto IC) __attribute__((always_inline)) {
+    constexpr int i = decltype(IC)::value;
+    constexpr int later = (NKH - 1 - i) * OPS_STEP;
+    asm volatile("s_waitcnt vmcnt(%2)" : "+v"(wreg[i][0]), "+v"(wreg[i][1]) : "n"(later) : "memory");
+    if constexpr (P::WIDEMETA) {
+      if constexpr (i == 0) {
+        if constexpr (NKH == 2) {
+          asm volatile("" : "+v"(s32[0]), "+v"(s32[1])::"memory");
+          if constexpr (ZP) asm volatile("" : "+v"(z32[0]), "+v"(z32[1])::"memory");
+        } else {
+          asm volatile("" : "+v"(s64[0]), "+v"(s64[1])::"memory");
+          if constexpr (ZP) asm volatile("" : "+v"(z64[0]), "+v"(z64[1])::"memory");
+        }
+      }
+    } else if constexpr (MODE != MD_NONE) {
       asm volatile("" : "+v"(sreg[i][0]), "+v"(sreg[i][1])::"memory");
       if constexpr (ZP || MODE == MD_ZQ) asm volatile("" : "+v"(zreg[i][0]), "+v"(zreg[i][1])::"memory");
     }
-  }
-  __syncthreads();
-
-  // ---- 3. multiply: per k-step decode the two fragments once, every activation fragment read feeds two MFMAs ----
-#pragma unroll
-  for (int i = 0; i < NKH; ++i) {
+    // (a bare s_barrier: `__syncthreads()` carries a workgroup fence, for which the compiler drains EVERY vector-memory operation it
+    // knows of - the LDS-DMA of the later steps - back to vmcnt(0).  The wait above has put this wave's share of step i into LDS;
+    // the barrier says the other three waves of the k-half have done the same; the fences keep the reads below it)
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("" ::: "memory");
+    if constexpr (i == 0) WQ_TRACE(2);
     uint32_t bfrag[2][NJ][4];
 #pragma unroll
     for (int nf = 0; nf < 2; ++nf) {
@@ -268,8 +286,15 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_mid_kernel(const GemmArgs 
         acc[mf][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8_t, b1), __builtin_bit_cast(half8_t, av), acc[mf][1], 0, 0, 0);
       }
     }
+  };
+  step(std::integral_constant<int, 0>{});
+  if constexpr (NKH >= 2) step(std::integral_constant<int, 1>{});
+  if constexpr (NKH >= 4) {
+    step(std::integral_constant<int, 2>{});
+    step(std::integral_constant<int, 3>{});
   }
 
+  WQ_TRACE(3);
   // ---- 4. the k-halves meet: wave (nq, kh) finishes M-fragments [kh KEEP, kh KEEP + KEEP) and hands the others to (nq, 1 - kh) ----
   __syncthreads();                                     // the activation slice is dead: its LDS carries the exchange
   f32x4* xch = reinterpret_cast<f32x4*>(smem_raw);
@@ -318,6 +343,21 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_mid_kernel(const GemmArgs 
   auto chunk = [&](int p, int s, int mf) __attribute__((always_inline)) -> f32x4* {
     return ws + ((((long)tile * 8 + p) * kMidSlices + s) * MF + mf) * 64 + lane;
   };
+  if (a.mid_sync == nullptr) {
+    // TWO-LAUNCH seam (the default, round 5's measurement: profiles/r05_lab_mid_trace_v1.txt): all eight portions leave
+    // write-through and the launch ends - wq_mid_reduce_kernel, behind the kernel boundary, adds the slices in the same order.
+    // The hardware's boundary (~1.5 us) turned out cheaper than the software hand-shake it replaces (store acknowledgement 1.2-2.6 us
+    // + ticket 0.75 + poll 0.7 before the first partial sum can be read back)
+    if (keeper) {
+#pragma unroll
+      for (int nf = 0; nf < 2; ++nf)
+#pragma unroll
+        for (int x = 0; x < KEEP; ++x) st_wt(chunk(2 * nq + nf, split, keep_lo + x), fin[x][nf]);
+    }
+    WQ_TRACE(4);
+    WQ_TRACE_DUMP(8);
+    return;
+  }
   if (keeper) {
 #pragma unroll
     for (int nf = 0; nf < 2; ++nf) {
@@ -330,6 +370,7 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_mid_kernel(const GemmArgs 
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the write-through stores have been acknowledged
+  WQ_TRACE(4);
   __syncthreads();
 
   unsigned* sync = a.mid_sync + (long)tile * kMidSyncWords;
@@ -405,10 +446,13 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_mid_kernel(const GemmArgs 
   unsigned ticket = 0;
   if (tid == 0) ticket = __hip_atomic_fetch_add(sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   ticket = bcast(ticket);
+  WQ_TRACE(5);
 
   if (ticket == kMidSlices - 1) {
     // LAST arriver: every slice's published portions are in memory.  Its own portion first, then whatever was abandoned.
+    WQ_TRACE(6);
     reduce(split, true);
+    WQ_TRACE(7);
     portion_done();
     for (int p = 0; p < kMidSlices; ++p) {
       if (p == split) continue;
@@ -423,6 +467,7 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_mid_kernel(const GemmArgs 
         portion_done();
       }
     }
+    WQ_TRACE_DUMP(8);
     return;
   }
 
@@ -438,9 +483,12 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_mid_kernel(const GemmArgs 
     }
   }
   all_here = bcast(all_here);
+  WQ_TRACE(6);
   if (all_here) {
     reduce(split, true);
+    WQ_TRACE(7);
     portion_done();
+    WQ_TRACE_DUMP(8);
     return;
   }
   // ABANDON: publish the own portion as well, mark it, and leave - unless everybody turned up in the meantime
@@ -468,6 +516,35 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_mid_kernel(const GemmArgs 
     reduce(split, true);
     portion_done();
   }
+  WQ_TRACE_DUMP(8);
+}
+
+// second launch of the two-launch seam: one wave per unit (tile, portion p, M-fragment mf) - the eight slices' chunks (1 KiB each, the
+// accumulators' lane order) added in slice order 0 .. 7, cast, + bias, stored.  Same order as the in-launch meeting: same bits.
+struct MidStorePolicy {
+  static constexpr int AT = AT_F16;
+  static constexpr bool BF = false;
+};
+template <int UNUSED = 0>      // (a template for its linkage: the header is included by two translation units)
+__global__ void __launch_bounds__(256) wq_mid_reduce_kernel(const GemmArgs a, int mf_count, int units) {
+  const int lane = threadIdx.x & 63;
+  const int unit = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+  if (unit >= units) return;
+  const int mf = unit % mf_count;
+  const int tp = unit / mf_count;
+  const int p = tp & 7, tile = tp >> 3;
+  const int tile_m = udiv_magic(tile, a.tiles_n, a.mg_ntiles);
+  const int tile_n = tile - tile_m * a.tiles_n;
+  const f32x4* ws = reinterpret_cast<const f32x4*>(a.ws) + (((long)tile * 8 + p) * kMidSlices * mf_count + mf) * 64 + lane;
+  f32x4 part[kMidSlices];
+#pragma unroll
+  for (int s = 0; s < kMidSlices; ++s) part[s] = __builtin_nontemporal_load(ws + (long)s * mf_count * 64);
+  f32x4 sum = part[0];
+#pragma unroll
+  for (int s = 1; s < kMidSlices; ++s) sum += part[s];
+  const int m = tile_m * 16 * mf_count + mf * 16 + (lane & 15);
+  const int nb = tile_n * 128 + p * 16 + (lane >> 4) * 4;
+  if (m < a.M && nb < a.N) store_quad<MidStorePolicy>(a, sum, m, nb);
 }
 
 typedef void (*gemm_fn)(const GemmArgs);

@@ -25,9 +25,18 @@ def _bits(x):
 
 
 def _run(case, M, monkeypatch, check_paths=True):
+    """default seam (a second launch adds the slices) against the oracle; the in-launch meeting (WQAA_GEMM_MID_SEAM=1) and its
+    abandon / sweep path bit for bit against it"""
     monkeypatch.delenv("WQAA_GEMM_MID", raising=False)
     monkeypatch.delenv("WQAA_GEMM_MID_SPIN_US", raising=False)
+    monkeypatch.delenv("WQAA_GEMM_MID_SEAM", raising=False)
+    monkeypatch.setenv("WQAA_GEMM_MID_FORCE", "1")         # (every shape the member takes, not only where it measured ahead)
+    two, mm2 = hip_output(case)
+    assert mm2.plans[M]["name"].endswith("xmk"), mm2.plans[M]["name"]
+    assert_fp_parity(two, oracle_output(case))
+    monkeypatch.setenv("WQAA_GEMM_MID_SEAM", "1")
     got, mm = hip_output(case)
+    assert np.array_equal(_bits(got), _bits(two)), "the in-launch meeting differs from the two-launch seam"
     assert mm.plans[M]["name"].endswith("xmk"), mm.plans[M]["name"]
     assert mm.plans[M]["split_k"] == 8
     want = oracle_output(case)
@@ -71,7 +80,8 @@ def test_int4_layouts_and_group_sizes(K, cfg, fast, monkeypatch):
     _run(case, 96, monkeypatch, check_paths=fast)
 
 
-def test_group_sizes_the_wide_metadata_loads_do_not_take_keep_their_members():
+def test_group_sizes_the_wide_metadata_loads_do_not_take_keep_their_members(monkeypatch):
+    monkeypatch.setenv("WQAA_GEMM_MID_FORCE", "1")
     for g in (-1, 32, 256):
         mm = bitblas.Matmul(bitblas.MatmulConfig(M=96, N=1024, K=4096, A_dtype="float16", W_dtype="int4", group_size=g, with_scaling=True), enable_tuning=False)
         assert "xmk" not in mm.plans[96]["name"], mm.plans[96]["name"]
@@ -89,9 +99,12 @@ def test_float32_output(monkeypatch):
     _run(case, 128, monkeypatch)
 
 
-def test_hipgraph_replays_find_clean_sync_words(monkeypatch):
+@pytest.mark.parametrize("seam", ["0", "1"])
+def test_hipgraph_replays_find_clean_sync_words(seam, monkeypatch):
     """one captured launch replayed: same kernel arguments every time, so the tiles' sync words must be zero again after each"""
     monkeypatch.delenv("WQAA_GEMM_MID", raising=False)
+    monkeypatch.setenv("WQAA_GEMM_MID_SEAM", seam)
+    monkeypatch.setenv("WQAA_GEMM_MID_FORCE", "1")
     M = 128
     case = make_case(M, 4096, 4096, W_dtype="uint4", group_size=128, with_scaling=True, with_zeros=True, scale_mul=0.02, seed=9)
     ref, mm = hip_output(case)
@@ -114,9 +127,12 @@ def test_hipgraph_replays_find_clean_sync_words(monkeypatch):
         assert np.array_equal(_bits(out.cpu().numpy()), _bits(ref))
 
 
-def test_two_streams_do_not_share_sync_words(monkeypatch):
+@pytest.mark.parametrize("seam", ["0", "1"])
+def test_two_streams_do_not_share_sync_words(seam, monkeypatch):
     """two operators' launches in flight on two streams: each stream's workspace brings its own sync words"""
     monkeypatch.delenv("WQAA_GEMM_MID", raising=False)
+    monkeypatch.setenv("WQAA_GEMM_MID_SEAM", seam)
+    monkeypatch.setenv("WQAA_GEMM_MID_FORCE", "1")
     M = 64
     case = make_case(M, 4096, 4096, W_dtype="uint4", group_size=128, with_scaling=True, with_zeros=True, scale_mul=0.02, seed=21)
     ref, mm = hip_output(case)
@@ -138,12 +154,13 @@ def test_two_streams_do_not_share_sync_words(monkeypatch):
 
 
 def test_the_member_it_stands_in_for_is_still_there(monkeypatch):
-    """WQAA_GEMM_MID=0: the two-launch member (split-K + reduce kernel); both within the oracle's tolerance of each other"""
+    """WQAA_GEMM_MID=0: the two-launch member (split-K + reduce kernel); both within the oracle's tolerance"""
     M = 128
     case = make_case(M, 4096, 4096, W_dtype="uint4", group_size=128, with_scaling=True, with_zeros=True, scale_mul=0.02, seed=2)
-    monkeypatch.delenv("WQAA_GEMM_MID", raising=False)
+    for k in ("WQAA_GEMM_MID", "WQAA_GEMM_MID_FORCE", "WQAA_GEMM_MID_SEAM"):
+        monkeypatch.delenv(k, raising=False)
     got, mm = hip_output(case)
-    assert mm.plans[M]["name"].endswith("xmk")
+    assert mm.plans[M]["name"].endswith("xmk")            # (BASELINE c3's M = 128: the selector's own choice)
     monkeypatch.setenv("WQAA_GEMM_MID", "0")
     old, mm0 = hip_output(case)
     assert "xmk" not in mm0.plans[M]["name"] and "xr" in mm0.plans[M]["name"], mm0.plans[M]["name"]
@@ -152,15 +169,19 @@ def test_the_member_it_stands_in_for_is_still_there(monkeypatch):
     assert_fp_parity(old, want)
 
 
-def test_shapes_outside_the_member_keep_theirs():
-    """more than one round of workgroups, K off the 2048 grid, M <= 16, other formats"""
+def test_where_the_selector_takes_the_member(monkeypatch):
+    """the measured rule (csrc/wqaa_gemm.hip, profiles/r05_ab_mid_v3.txt): 65 ... 128 rows in one round at K = 4096; up to 64 rows on long
+    K (8192) or over several rounds of workgroups; never at M <= 16, K off the 2048 grid, other formats, 128 rows over several rounds"""
+    for k in ("WQAA_GEMM_MID", "WQAA_GEMM_MID_FORCE"):
+        monkeypatch.delenv(k, raising=False)
+
     def name(M, N, K, **kw):
         cfg = dict(A_dtype="float16", W_dtype="uint4", group_size=128, with_scaling=True, with_zeros=True)
         cfg.update(kw)
         return bitblas.Matmul(bitblas.MatmulConfig(M=M, N=N, K=K, **cfg), enable_tuning=False).plans[M]["name"]
-    assert "xmk" not in name(128, 11008, 4096)
-    assert "xmk" not in name(128, 4096, 11008)
-    assert "xmk" not in name(16, 4096, 4096)
+    for (M, N, K) in ((128, 4096, 4096), (96, 4096, 4096), (65, 2048, 4096), (64, 4096, 8192), (32, 4096, 8192), (64, 8192, 4096), (64, 11008, 4096), (17, 8192, 8192)):
+        assert name(M, N, K).endswith("xmk"), (M, N, K, name(M, N, K))
+    for (M, N, K) in ((128, 11008, 4096), (128, 4096, 11008), (16, 4096, 4096), (64, 4096, 4096), (32, 4096, 4096), (128, 4096, 2048), (128, 4096, 8192),
+                      (256, 4096, 4096)):
+        assert "xmk" not in name(M, N, K), (M, N, K, name(M, N, K))
     assert "xmk" not in name(128, 4096, 4096, W_dtype="uint2")
-    assert "xmk" not in name(128, 4096, 8192)          # (128 rows x K / 8 = 1024 k does not fit the LDS)
-    assert name(64, 4096, 8192).endswith("xmk")

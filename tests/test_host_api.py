@@ -171,7 +171,7 @@ def test_k_split_reaches_the_selector():
     op = bitblas.MatmulWithSplitK(bitblas.MatmulConfigWithSplitK(M=128, N=4096, K=512, A_dtype="float16", W_dtype="int4",
                                                                  group_size=128, with_scaling=True, k_split=64), enable_tuning=False)
     assert op.plans[128]["split_k"] == 4
-    # the plain operator decides for itself (round 5: the mid-M member - K in 8 slices that meet inside the one launch)
+    # the plain operator decides for itself (round 5: the mid-M member - K in 8 slices, its own second launch adds them)
     plain = bitblas.Matmul(bitblas.MatmulConfig(M=128, **kw), enable_tuning=False).plans[128]
     assert plain["split_k"] == 8 and plain["name"].endswith("xmk"), plain
     # M = 1 exact-product GEMV: the K split across the waves of a workgroup

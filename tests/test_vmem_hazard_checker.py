@@ -79,6 +79,43 @@ def test_the_hand_counted_decode_kernels_of_the_built_library_are_clean():
     assert "kernels checked, 0 with findings" in out and int(out.strip().split("\n")[-1].split()[0]) >= 8, out[-500:]
 
 
+def test_store_data_overwritten_within_two_wait_states_is_found():
+    """round 5: a vector-memory store of more than 64 bits reads its data registers for two more issue cycles; an inline-assembly
+    store gets no hazard padding from the compiler (tools/store_hazard_lab.hip: lanes 8-15 / 12-15 of every 16 store the overwriting
+    value at gap 0 / 1, nothing from gap 2 on).  The mid-M member's first two-launch build had exactly this stream."""
+    st = "global_store_dwordx4 v[34:35], v[2:5], off sc0 sc1+"
+    assert [f[2] for f in chk.scan("k", _asm(st, "v_lshl_add_u64 v[2:3], v[0:1], 0, s[2:3]+", "s_endpgm"))] == [[2, 3]]
+    assert len(chk.scan("k", _asm(st, "s_lshl_b64 s[2:3], s[2:3], 10", "v_mov_b32_e32 v5, 0", "s_endpgm"))) == 1        # one wait state: still inside
+    assert chk.scan("k", _asm(st, "s_nop 1", "v_mov_b32_e32 v2, 0", "s_endpgm")) == []
+    assert chk.scan("k", _asm(st, "s_mov_b32 s2, 0", "s_mov_b32 s3, 0", "v_mov_b32_e32 v2, 0", "s_endpgm")) == []          # two instructions in between
+    assert chk.scan("k", _asm(st, "v_mov_b32_e32 v34, 0", "v_mov_b32_e32 v6, 0", "s_endpgm")) == []                         # the ADDRESS may be re-used
+    assert chk.scan("k", _asm("global_store_dwordx2 v[34:35], v[2:3], off+", "v_mov_b32_e32 v2, 0", "s_endpgm")) == []     # 64 bits: no hazard
+    # across a branch: the window follows both arms
+    prog = _asm(st, "s_cbranch_scc1 1", "s_nop 0", "v_mov_b32_e32 v4, 0", "s_endpgm")
+    assert len(chk.scan("k", prog)) == 1
+
+
+def test_every_gemm_kernel_of_the_built_library_is_clean_of_both_hazards():
+    """the whole GEMM family (the split-K and ping-pong members write their partial sums / output tiles with inline-assembly
+    write-through stores too)"""
+    from bitblas_amd import lib as wlib
+    if not (os.path.exists(chk.OBJDUMP) and shutil.which("objcopy")):
+        pytest.skip("no llvm-objdump / objcopy on this box")
+    import io
+    from contextlib import redirect_stdout
+    buf = io.StringIO()
+    old = sys.argv
+    sys.argv = ["check_vmem_hazards.py", "--lib", wlib.LIB_PATH, "--match", "wq_gemm_(pp|mid)_kernel|wq_gemm_kernelINS_10GemmPolicyILi0ELi1ELi0ELi2"]
+    try:
+        with redirect_stdout(buf):
+            rc = chk.main()
+    finally:
+        sys.argv = old
+    out = buf.getvalue()
+    assert rc == 0, out[-3000:]
+    assert "kernels checked, 0 with findings" in out and int(out.strip().split("\n")[-1].split()[0]) >= 100, out[-500:]
+
+
 def test_the_mid_m_kernels_of_the_built_library_are_clean():
     """round 5: wq_gemm_mid_kernel (csrc/wqaa_gemm_mid_kernel.h) issues every register load as inline assembly next to its LDS-DMA
     and waits once - the same contract, checked the same way (its first build had a run-time branch that joined two register

@@ -127,6 +127,60 @@ def merge(a, b):
     return tuple((a[i] | b[i]) if i < len(b) else a[i] for i in range(len(a)))
 
 
+WIDE_STORE = re.compile(r"^(global|buffer|flat|scratch)_store_(dwordx3|dwordx4|b96|b128)$")
+STORE_DATA_WAIT_STATES = 2          # gfx950, measured (tools/store_hazard_lab.hip -> profiles/r05_lab_store_hazard.txt); the compiler's own: s_nop 1
+
+
+def store_data_hazards(ins, index_of_addr):
+    """Round 5.  A vector-memory store of MORE than 64 bits reads its data registers over the two issue cycles after its own: an
+    instruction that writes one of them within STORE_DATA_WAIT_STATES wait states stores its own result in lanes 8-15 (no gap) /
+    12-15 (one wait state) of every 16.  The compiler's hazard recognizer pads stores it knows (`s_nop 1`); an inline-assembly store
+    is opaque to it - csrc/wqaa_gemm_mid_kernel.h's first two-launch build re-used a store's data registers for the next address
+    and every output of two rows per fragment was wrong.  -> [(addr, code, registers, -1)]"""
+    out = []
+
+    def walk(k, data, left, seen, origin):
+        while left > 0 and k < len(ins):
+            if (k, left) in seen:
+                return
+            seen.add((k, left))
+            addr, op, ops, code = ins[k]
+            if op == "s_endpgm":
+                return
+            if op == "s_nop":
+                left -= int(ops.split()[0], 0) + 1
+                k += 1
+                continue
+            written = set()
+            if op.startswith("v_") and not op.startswith(("v_cmp", "v_nop", "v_readfirstlane", "v_readlane")):
+                written = first_operand_regs(ops)
+            elif re.match(r"^(global|buffer|flat|scratch)_load|^ds_read|^ds_load", op) and not re.search(r"\blds\b", ops):
+                written = first_operand_regs(ops)
+            hit = written & data
+            if hit:
+                out.append((origin[0], origin[1] + "   <-   " + code, sorted(hit), -1))
+                return
+            left -= 1
+            if op == "s_branch" or op.startswith("s_cbranch"):
+                off = int(ops.split()[0], 0)
+                off = off - 65536 if off >= 32768 else off
+                t = index_of_addr.get(addr + 4 + 4 * off)
+                if t is not None:
+                    walk(t, data, left, seen, origin)
+                if op == "s_branch":
+                    return
+            k += 1
+
+    for k, (addr, op, ops, code) in enumerate(ins):
+        if not WIDE_STORE.match(op):
+            continue
+        parts = [x.strip() for x in ops.split(",")]
+        data = regs_of(parts[0]) if op.startswith("buffer") else (regs_of(parts[1]) if len(parts) > 1 else set())
+        if data:
+            walk(k + 1, data, STORE_DATA_WAIT_STATES, set(), (addr, code))
+    return out
+
+
 def scan(name, lines, verbose=False):
     """forward data flow over the kernel's control-flow graph: at a join the queues are merged position by position, counted from
     the youngest operation (sound for in-order retirement: whatever a path has outstanding is in the merged queue at the same age)"""
@@ -190,6 +244,7 @@ def scan(name, lines, verbose=False):
             continue
         for k in range(s0, e0):
             st = step(st, ins[k], findings)
+    findings += store_data_hazards(ins, index)
     return findings
 
 
@@ -237,7 +292,10 @@ def main():
                 if fnd:
                     bad += 1
                     for addr, code, hit, age in fnd[:8 if not args.v else 1000]:
-                        print(f"      {addr:#x}: {code}   touches v{hit}: possibly in flight, {age} younger operation(s)")
+                        if age < 0:
+                            print(f"      {addr:#x}: {code}   overwrites store data v{hit} within {STORE_DATA_WAIT_STATES} wait states of the store")
+                        else:
+                            print(f"      {addr:#x}: {code}   touches v{hit}: possibly in flight, {age} younger operation(s)")
     print(f"{total} kernels checked, {bad} with findings")
     return 1 if bad else 0
 

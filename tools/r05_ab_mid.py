@@ -11,10 +11,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 
-ARMS = (("mid", {"WQAA_GEMM_MID_MINM": "3", "WQAA_GEMM_MID_MAXM": "512", "WQAA_GEMM_MID_ROUNDS": "4"}),
-        ("sweep", {"WQAA_GEMM_MID_MINM": "3", "WQAA_GEMM_MID_MAXM": "512", "WQAA_GEMM_MID_ROUNDS": "4", "WQAA_GEMM_MID_SPIN_US": "0"}),
+OPEN = {"WQAA_GEMM_MID_MINM": "3", "WQAA_GEMM_MID_MAXM": "512", "WQAA_GEMM_MID_ROUNDS": "4"}
+ARMS = (("mid", dict(OPEN)),                                            # two-launch seam (default)
+        ("inl", dict(OPEN, WQAA_GEMM_MID_SEAM="1")),                    # the slices meet inside the launch
         ("old", {"WQAA_GEMM_MID": "0"}))
-
 
 def main():
     dev = torch.device("cuda", 0)
@@ -26,12 +26,13 @@ def main():
         row = []
         for rep in range(2):
             for arm, env in ARMS:
-                if arm == "sweep" and rep:
+                if arm == "inl" and rep:
                     continue
                 for k in list(os.environ):
                     if k.startswith("WQAA_GEMM_MID"):
                         del os.environ[k]
                 os.environ.update(env)
+                bench._OPS.clear()          # (bench.get_op caches operators: the plan is made when the operator is)
                 r = bench.time_member_gemm(dev, gen, M, N, K)
                 row.append((arm, r.get("kernel", "?").split("_")[-1], r.get("us_per_launch", float("nan"))))
         print(f"M={M:4d} {N}x{K}  " + "  ".join(f"{a}:{k} {t:7.2f}" for a, k, t in row), flush=True)
