@@ -179,6 +179,18 @@ static bool two_pass_forced() {
     on = getenv("WQAA_TWO_PASS") != nullptr;
     seen_epoch = ep;
   }
+
+// The two-pass member as the PLAN sees it: eligible, and - for the automatic form (no caller threshold, not forced) - its scratch
+// N K sizeof(A_dtype) within the cap (WQAA_TWO_PASS_AUTO_MAX_MB, default 256).  wqaa_select, wqaa_workspace_bytes and the call agree.
+static size_t two_pass_auto_cap() {
+  const char* f = getenv("WQAA_TWO_PASS_AUTO_MAX_MB");
+  return (size_t)(f ? atol(f) : 256) << 20;
+}
+static bool two_pass_planned(const wqaa_matmul_desc& d, int m) {
+  if (!gemm_two_pass_eligible(d, m)) return false;
+  const bool automatic = d.two_pass_min_m <= 0 && !two_pass_forced();
+  return !automatic || gemm_two_pass_workspace_bytes(d, m) <= two_pass_auto_cap();
+}
   return on;
 }
 
@@ -244,29 +256,53 @@ static int matmul_impl(const wqaa_matmul_desc* desc, const void* A, const void* 
       if (st == WQAA_OK) g_last_error = WQAA_OK;
       return st;
     }
-    // the tuned two-pass member (desc.two_pass_min_m): B_decode to a scratch, then the plain GEMM through the library
-    // (m >= 256: the automatic form - own B_decode + own dense member where the fused member is still a lockstep one)
-    if (desc->two_pass_min_m > 0 || two_pass_forced() || m >= 256) {
-      static thread_local ChoiceMemo<int> tp_memo;
-      bool tp;
-      if (const int* hit = tp_memo.find(*desc, m, 5)) {
-        tp = *hit != 0;
-      } else {
-        const int saved = g_last_error;
-        tp = gemm_two_pass_eligible(*desc, m);
-        g_last_error = saved;
-        tp_memo.put(*desc, m, 5, tp ? 1 : 0);
+  }
+  // the two-pass member: B_decode to a scratch, then the plain GEMM (desc.two_pass_min_m: the caller's tuned threshold; m >= 256: the
+  // automatic form - own B_decode + own dense member where the fused member is still a lockstep one).  Also under wqaa_matmul_timed
+  // (events recorded around the two launches): what is timed is what is dispatched.
+  if (!epi && (desc->two_pass_min_m > 0 || two_pass_forced() || m >= 256)) {
+    static thread_local ChoiceMemo<int> tp_memo;
+    bool tp;
+    if (const int* hit = tp_memo.find(*desc, m, 5)) {
+      tp = *hit != 0;
+    } else {
+      const int saved = g_last_error;
+      tp = gemm_two_pass_eligible(*desc, m);
+      g_last_error = saved;
+      tp_memo.put(*desc, m, 5, tp ? 1 : 0);
+    }
+    const bool automatic = desc->two_pass_min_m <= 0 && !two_pass_forced();
+    if (tp && automatic) {
+      // the AUTOMATIC form never turns a call that used to need no scratch into a refused or a memory-hungry one:
+      //  * its scratch is N K sizeof(A_dtype) per stream - capped (WQAA_TWO_PASS_AUTO_MAX_MB, default 256: a 8192 x 28672 layer
+      //    would pin 470 MB per stream to save ~15 % of a prefill call);
+      //  * a caller workspace too small for it (sized for the fused member's needs: none), or a library pool that cannot grow
+      //    (stream capture), means the fused member runs;
+      //  * and so does a failed allocation (below).
+      static thread_local unsigned seen = ~0u;
+      static thread_local size_t cap = (size_t)256 << 20;
+      const unsigned ep = g_plan_epoch.load(std::memory_order_relaxed);
+      if (ep != seen) {
+        cap = two_pass_auto_cap();
+        seen = ep;
       }
-      // the AUTOMATIC form never turns a call that used to need no scratch into a refused one: while the stream is being captured
-      // and the library's scratch would have to grow (no caller workspace, no earlier call of this shape), the fused member runs
-      if (tp && desc->two_pass_min_m <= 0 && !two_pass_forced() && !(opts && opts->workspace) &&
-          !pool_workspace_ready(s, gemm_two_pass_workspace_bytes(*desc, m)))
-        tp = false;
-      if (tp) {
-        int st = gemm_two_pass_launch(*desc, A, B, LUT, Scale, Zeros, C, m, s, opts);
-        if (st == WQAA_OK) g_last_error = WQAA_OK;
+      const size_t need = gemm_two_pass_workspace_bytes(*desc, m);
+      if (need > cap) tp = false;
+      else if (opts && opts->workspace) {
+        if (opts->workspace_bytes < need || (reinterpret_cast<uintptr_t>(opts->workspace) & 15)) tp = false;
+      } else if (!pool_workspace_ready(s, need)) tp = false;
+    }
+    if (tp) {
+      if (e0 && hipEventRecord(e0, s) != hipSuccess) (void)hipGetLastError();
+      const int saved = g_last_error;
+      int st = gemm_two_pass_launch(*desc, A, B, LUT, Scale, Zeros, C, m, s, opts);
+      if (st == WQAA_OK) {
+        if (e1 && hipEventRecord(e1, s) != hipSuccess) (void)hipGetLastError();
+        g_last_error = WQAA_OK;
         return st;
       }
+      if (!automatic) return st;
+      g_last_error = saved;              // (the automatic form failed to get its scratch: the fused member, as before round 4)
     }
   }
   const bool quant_in = epi && (epi->flags & WQAA_EPI_QUANTIZE_INPUT);
@@ -384,7 +420,7 @@ int wqaa_matmul_ex(const wqaa_matmul_desc* desc, const void* A, const void* B, c
 uint64_t wqaa_workspace_bytes(const wqaa_matmul_desc* desc, int m) {
   if (!valid_desc(desc) || m <= 0) return 0;
   if (dense_lib_eligible(*desc, m)) return (uint64_t)dense_lib_workspace_bytes(*desc, m);
-  if (gemm_two_pass_eligible(*desc, m)) return (uint64_t)gemm_two_pass_workspace_bytes(*desc, m);
+  if (two_pass_planned(*desc, m)) return (uint64_t)gemm_two_pass_workspace_bytes(*desc, m);
   bool use_gemm = false;
   dispatch(*desc, m, &use_gemm);
   return use_gemm ? (uint64_t)gemm_workspace_bytes(*desc, m) : 0;
@@ -641,7 +677,7 @@ int wqaa_select(const wqaa_matmul_desc* desc, int m, wqaa_plan* plan) {
   if (m <= 0) m = 1;
   g_plan_epoch.fetch_add(1, std::memory_order_relaxed);   // planning re-reads the tuning environment (ChoiceMemo)
   if (dense_lib_eligible(*desc, m)) return dense_lib_plan(*desc, m, plan);
-  if (gemm_two_pass_eligible(*desc, m)) return gemm_two_pass_plan(*desc, m, plan);
+  if (two_pass_planned(*desc, m)) return gemm_two_pass_plan(*desc, m, plan);
   bool use_gemm = false;
   dispatch(*desc, m, &use_gemm);
   return use_gemm ? gemm_plan(*desc, m, plan) : gemv_plan(*desc, m, plan);

@@ -131,7 +131,13 @@ static const ChainKnobs& chain_knobs() {
       const char* f = getenv(name);
       return f ? atoi(f) : dflt;
     };
-    k.fuse = geti("WQAA_CHAIN_FUSE", 1) != 0;
+    // Round 5: the persistent member is OPT-IN (WQAA_CHAIN_FUSE=1).  `wqaa_matmul_chain` is DEFINED as the launches it stands for and
+    // runs them by default: they are faster (26.0 vs 38.5 us per decoder-layer tail, profiles/r04_chain_lab.txt) and need nothing
+    // from the rest of the chip, whereas the persistent launch spin-waits on granules other workgroups write - its grid of one
+    // 160 KiB workgroup per CU is only co-resident on an otherwise idle device (two chains on two streams, a CU mask or
+    // any kernel holding LDS leave part of it queued; every wait then ends in its 250 ms bound with an error code only
+    // `wqaa_debug_chain_status` reads).  Whoever opts in owns that precondition.
+    k.fuse = geti("WQAA_CHAIN_FUSE", 0) != 0;
     k.lanes = geti("WQAA_CHAIN_LANES", 0);
     k.cpl = geti("WQAA_CHAIN_CPL", 0);
     k.ring = geti("WQAA_CHAIN_RING", 0);
@@ -256,6 +262,13 @@ static int chain_build(const wqaa_chain_item* items, int count, int m, ChainBuil
     const int pro = it.norm_weight ? (pair ? 4 : 3) : pair ? 2 : has_res ? 1 : 0;
     int st = gemvx_chain_geometry(d, m, pro, pair, &ga, &kw, &nw, &nai);
     if (st != WQAA_OK) return st;
+    // a PLAIN item (no norm, no residual, not a pair) stands for `wqaa_matmul`, which takes the exact-product family only where
+    // gemvx_eligible says so (not for strict_reference descriptors, not under WQAA_GEMVX=0, not behind its fences): anywhere else
+    // the launches' bits are the rounding family's and the persistent member - exact products always - would differ
+    if (pro == 0 && !gemvx_eligible(d, m)) {
+      set_error(WQAA_ERR_UNSUPPORTED, "matmul_chain: item %d's single launch is a per-element-rounding member (strict_reference, or outside the exact-product family's fences): other bits than the persistent member's", i);
+      return WQAA_ERR_UNSUPPORTED;
+    }
     if (kw != 1) {
       set_error(WQAA_ERR_UNSUPPORTED, "matmul_chain: item %d's single launch splits K over %d waves (another summation order than the chain's)", i, kw);
       return WQAA_ERR_UNSUPPORTED;

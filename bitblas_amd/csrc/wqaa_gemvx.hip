@@ -33,23 +33,23 @@ bool gemvx_eligible(const wqaa_matmul_desc& d, int m) {
   // At M = 1 the exact members keep long K too since their workgroups take 16 rows there (gemvx_choose; profiles/
   // r02_ab_knobs_longk.txt: 5120x13824 13.0 vs 14.8 us, 8192x28672 24.7 vs 26.7, 4096x14336 9.9-10.2 vs 9.6-10.2).
   // Either numerics meets the contract when strict_reference = 0: the faster member is taken.
-  {
-    const int cus = device_info().ok ? device_info().cus : 256;
-    const char* f = getenv("WQAA_GEMVX");
-    const bool forced = f && atoi(f) == 2;                    // WQAA_GEMVX=2: A/B aid, ignores the fences
-    if (!forced && d.K > 8192 && (d.N + 1) / 2 >= 8 * cus && m > 1) return false;
-    // two activation rows: twice the LDS reads and dots per weight word - the exact member only wins on many-row matrices
-    // (same-call, int4 g128: 11008x4096 8.8 vs 9.4 us; 4096^2 5.4 vs 5.1, 4096x11008 11.2 vs 10.2)
-    if (!forced && m == 2 && d.N < 8192) return false;
-  }
-  // the switch is a plan-time one like every tuning variable (ChoiceMemo): re-read when wqaa_select bumps the epoch
+  // the switch is a plan-time one like every tuning variable (ChoiceMemo): re-read when wqaa_select bumps the epoch - ONE getenv per
+  // epoch, not per call (the `forced` test used to read the environment on every eligibility question)
   static thread_local unsigned seen_epoch = 0;
-  static thread_local bool enabled = true;
+  static thread_local bool enabled = true, forced = false;
   const unsigned ep = g_plan_epoch.load(std::memory_order_relaxed);
   if (ep != seen_epoch) {
     const char* f = getenv("WQAA_GEMVX");
     enabled = !(f && atoi(f) == 0);
+    forced = f && atoi(f) == 2;                               // WQAA_GEMVX=2: A/B aid, ignores the fences
     seen_epoch = ep;
+  }
+  {
+    const int cus = device_info().ok ? device_info().cus : 256;
+    if (!forced && d.K > 8192 && (d.N + 1) / 2 >= 8 * cus && m > 1) return false;
+    // two activation rows: twice the LDS reads and dots per weight word - the exact member only wins on many-row matrices
+    // (same-call, int4 g128: 11008x4096 8.8 vs 9.4 us; 4096^2 5.4 vs 5.1, 4096x11008 11.2 vs 10.2)
+    if (!forced && m == 2 && d.N < 8192) return false;
   }
   return enabled;
 }

@@ -63,6 +63,8 @@ int wqaa_peer_alloc(size_t bytes, void** ptr) {
   void* p = nullptr;
   hipError_t e = hipExtMallocWithFlags(&p, bytes, hipDeviceMallocUncached);
   if (e == hipSuccess) e = hipMemset(p, 0, bytes);
+  // hipMemset of device memory is asynchronous: a peer's first remote store or flag post must not race a late clear
+  if (e == hipSuccess) e = hipDeviceSynchronize();
   if (e != hipSuccess) {
     set_error(WQAA_ERR_LAUNCH, "wqaa_peer_alloc(%zu): %s", bytes, hipGetErrorString(e));
     return WQAA_ERR_LAUNCH;

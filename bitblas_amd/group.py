@@ -193,6 +193,17 @@ def gate_up_plan(op: Matmul, m: int = 1, norm: bool = False):
     return plan.as_dict()
 
 
+def _pair_planned(op: Matmul, m: int, norm: bool) -> bool:
+    """`gate_up_plan(...) is not None`, asked once per (operator, m, norm): the forward path of a decode step made one or two ctypes
+    plan calls per call.  The verdict is a plan-time one (the tuning variables are read when an operator is built)."""
+    cache = op.__dict__.setdefault("_pair_planned", {})
+    key = (int(m), bool(norm))
+    hit = cache.get(key)
+    if hit is None:
+        hit = cache[key] = gate_up_plan(op, m, norm=norm) is not None
+    return hit
+
+
 def matmul_gate_up(gate_op: Matmul, up_op: Matmul, A: torch.Tensor, gate_weights, up_weights,
                    output: Optional[torch.Tensor] = None, norm=None) -> torch.Tensor:
     """`F.silu(gate_op(A, *gate_weights)) * up_op(A, *up_weights)` - the gated activation of a Llama-style MLP (the reference's
@@ -205,10 +216,10 @@ def matmul_gate_up(gate_op: Matmul, up_op: Matmul, A: torch.Tensor, gate_weights
         raise ValueError("gate and up must be operators of one configuration (same N, K, formats, group size)")
     if norm is not None:
         check_norm(norm, A, gate_op.K)
-        if not gate_op.fused_ops_supported(m) or gate_up_plan(gate_op, m, norm=True) is None:     # the selector's word
+        if not gate_op.fused_ops_supported(m) or not _pair_planned(gate_op, m, True):     # the selector's word
             A, norm = rms_norm_reference(A, *norm), None
     # the selector's word is final: where it refuses the pair (no member, the LDS limit) the group launch + torch's two kernels run
-    if not gate_op.fused_ops_supported(m) or m == 0 or gate_up_plan(gate_op, m, norm=norm is not None) is None:
+    if not gate_op.fused_ops_supported(m) or m == 0 or not _pair_planned(gate_op, m, norm is not None):
         if norm is not None:
             A, norm = rms_norm_reference(A, *norm), None
         g, u = matmul_group([gate_op, up_op], A, [gate_weights, up_weights])

@@ -177,6 +177,18 @@ class ColumnParallelMatmul:
         if self._window is not None:
             self._window.check()
 
+    def close(self) -> None:
+        """release the peer-store window (hipIpc mappings of the peers' windows + the own uncached allocation); idempotent"""
+        win, self._window = self._window, None
+        if win is not None:
+            win.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001 - interpreter shutdown: the driver releases the mappings with the process
+            pass
+
     def forward(self, A, W, scale=None, zeros=None, bias=None, out=None):
         rows = A.numel() // A.shape[-1]
         if self.direct_store and rows == 1 and self.world > 1:

@@ -18,6 +18,14 @@ from helpers import _to_dev, assert_fp_parity, make_case
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _opt_in(monkeypatch):
+    """round 5: the persistent member is opt-in (WQAA_CHAIN_FUSE=1) - `wqaa_matmul_chain` runs the launches it is defined as unless
+    the caller asks for it (the launches are faster and need no co-residency of 256 x 160 KiB workgroups).  These tests are about
+    the persistent member, so they opt in; test_default_is_the_launches checks the default."""
+    monkeypatch.setenv("WQAA_CHAIN_FUSE", "1")
+
+
 def build(case):
     mm = bitblas.Matmul(case["config"], enable_tuning=False)
     W = mm.weight_transform(torch.from_numpy(case["codes"])).cuda()
@@ -241,3 +249,42 @@ def test_decoder_tail_module_both_forms():
     want = h + down(torch.nn.functional.silu(gate(hn)) * up(hn))
     # (torch's norm sums x^2 in another order, its layers round where the fused ops do not: a last float16 bit here and there)
     assert_fp_parity(b.cpu().numpy(), want.float().cpu().numpy(), rtol=4e-3, atol_frac=4e-3)
+
+
+def test_default_is_the_launches(monkeypatch):
+    """without WQAA_CHAIN_FUSE=1 the same call runs the three launches: same bits, `chain_plan` says so and why"""
+    monkeypatch.delenv("WQAA_CHAIN_FUSE", raising=False)
+    cases, ops, attn, x, nw = layer(4096, 11008, "int4", 128, None, False, seed=5)
+    eps = 1e-5
+    steps = tail_steps(ops, attn, x, nw, eps)
+    plan = chain_plan(steps)
+    assert plan["launches"] == 3 and "WQAA_CHAIN_FUSE" in (plan["reason"] or ""), plan
+    want = by_launches(ops, attn, x, nw, eps)
+    got = matmul_chain(steps)
+    torch.cuda.synchronize()
+    assert all(torch.equal(a, b) for a, b in zip(got, want))
+
+
+def test_strict_reference_plain_items_are_not_fused():
+    """a PLAIN item (no norm, no residual) stands for `wqaa_matmul`, which runs a per-element-rounding member for a
+    strict_reference operator - the persistent member computes exact products, so it must refuse the chain (and the call still
+    gives the launches' bits)"""
+    H = 4096
+    kw = dict(W_dtype="int4", group_size=128, with_scaling=True, scale_mul=0.03)
+
+    def strict(case):
+        mm = bitblas.Matmul(case["config"], enable_tuning=False, strict_reference=True)
+        W = mm.weight_transform(torch.from_numpy(case["codes"])).cuda()
+        return mm, (W, _to_dev(case["scale"], "cuda"), None, None)
+    a_op = strict(make_case(1, H, H, seed=1, **kw))
+    b_op = strict(make_case(1, H, H, seed=2, **kw))
+    rng = np.random.default_rng(0)
+    a = torch.from_numpy((rng.random((1, H), dtype=np.float32) - 0.5).astype(np.float16)).cuda()
+    steps = [ChainStep(a_op[0], a_op[1], a), ChainStep(b_op[0], b_op[1], 0, output=None)]
+    plan = chain_plan(steps)
+    assert plan["launches"] == 2 and "rounding" in (plan["reason"] or ""), plan
+    got = matmul_chain(steps)
+    h = a_op[0].forward(a, a_op[1][0], scale=a_op[1][1])
+    want = b_op[0].forward(h, b_op[1][0], scale=b_op[1][1])
+    torch.cuda.synchronize()
+    assert torch.equal(got[0], h) and torch.equal(got[1], want)
