@@ -99,7 +99,22 @@ typedef struct wqaa_matmul_desc {
                                per element (TE graph, matmul_dequantize_impl.py:391-459), e4m3->f16 bit trick
                                (0 -> 2^-7, quantization.py:169-176), "uint8" weights read through the signed storage
                                type; 0: members that skip the intermediate rounding (M <= 2 exact-product GEMV) and
-                               decode e4m3 per IEEE may be taken - within the 1e-3 contract, closer to the real product */
+                               decode e4m3 per IEEE may be taken - closer to the real-valued product.
+                               NUMERICS CONTRACT (what a binder may rely on; C_ref = the reference's definition, i.e. the TE graph
+                               evaluated with fp32 / int32 accumulation, oracle/wqaa_oracle.py; rms over the output):
+                                 integer accumulators (A int8 / int4):          bit-exact;
+                                 strict_reference = 1, float16:                 |C - C_ref| <= 1e-3 |C_ref| + 1e-3 rms(C_ref), any K
+                                                                                (the per-element rounding of the definition itself);
+                                 strict_reference = 0, float16, K >= 2048:      the same bound (measured over every member class:
+                                                                                <= 4.8e-4 relative, <= 9.3e-4 rms; profiles/r04_parity_margins.txt);
+                                 strict_reference = 0, float16, K <  2048, M <= 2 (exact-product GEMV): 1e-3 |C_ref| + 2e-3 rms(C_ref) -
+                                                                                with few products per output the definition's own per-element
+                                                                                rounding (which these members skip) does not average out: up to
+                                                                                1.43e-3 rms on the reference's K = 256 fixtures, 1.6e-3 at K = 1024
+                                                                                with one group per row; against the REAL-valued product these
+                                                                                members are within 1e-3 at any K (tests/test_gemvx_gpu.py,
+                                                                                test_linear_gpu.py);
+                                 bfloat16 outputs:                              8e-3 (the 2^-8 rounding of the result itself). */
   int32_t k_split_hint;  /* 0 / 1: the selector decides.  > 1: the caller's split-K request, as `MatmulConfigWithSplitK.k_split`
                             (ops/general_matmul_splitk.py:21-23).  Honoured where K is split by a free parameter: the
                             K split across the waves of a workgroup of the M <= 2 exact-product GEMV, and the split-K

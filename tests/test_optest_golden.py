@@ -131,4 +131,6 @@ def test_hip_path_reproduces_the_reference_tests_expectation(i, members):
     # the reference test's own rtol = atol = 1e-2 with 5 % mismatches allowed (backend_tl.py:275)
     from helpers import record_margin
     record_margin(f"optest/{IDS[i]}/{members}/{mm.plans[c['rows']]['name']}", out.float().cpu().numpy(), c["expected"])
-    assert_fp_parity(out.float().cpu().numpy(), c["expected"], **tolerance(c, slack=2.0))
+    from helpers import contract
+    assert_fp_parity(out.float().cpu().numpy(), c["expected"],
+                     **contract(cfg["K"], default_members=members == "default", m=c["rows"], bf16=cfg["A_dtype"] == "bfloat16"))
