@@ -180,6 +180,9 @@ static bool two_pass_forced() {
     seen_epoch = ep;
   }
 
+  return on;
+}
+
 // The two-pass member as the PLAN sees it: eligible, and - for the automatic form (no caller threshold, not forced) - its scratch
 // N K sizeof(A_dtype) within the cap (WQAA_TWO_PASS_AUTO_MAX_MB, default 256).  wqaa_select, wqaa_workspace_bytes and the call agree.
 static size_t two_pass_auto_cap() {
@@ -190,8 +193,6 @@ static bool two_pass_planned(const wqaa_matmul_desc& d, int m) {
   if (!gemm_two_pass_eligible(d, m)) return false;
   const bool automatic = d.two_pass_min_m <= 0 && !two_pass_forced();
   return !automatic || gemm_two_pass_workspace_bytes(d, m) <= two_pass_auto_cap();
-}
-  return on;
 }
 
 constexpr int32_t kEpilogueV1Bytes = 24;   // wqaa_epilogue up to `reserved2`: callers built before the float16 pre/post ops

@@ -57,6 +57,26 @@ gemm_fn pick_gemm_pp(int kind, int layout, int at, int mode, int flags, int bm, 
                : (!ab ? wq_gemm_pp8s_kernel<PP8SPolicy<1, 0>> : wq_gemm_pp8s_kernel<PP8SPolicy<1, 1>>);
   }
   if (bn != 256 || (bm != 256 && bm != 128)) return nullptr;
+  // round 5: the dense 256 x 256 tile on a 2 x 4 wave grid (wq_gemm_pp8w_kernel).  WQAA_GEMM_PP8_WIDE=0: the 1 x 8 grid (plan time)
+  static const bool kWideDefault = true;
+  const char* wf_ = getenv("WQAA_GEMM_PP8_WIDE");
+  const bool wide = bm == 256 && (wf_ ? atoi(wf_) != 0 : kWideDefault);
+  if (wide && mode == MD_NONE) {
+    if (at == AT_F8 && (kind == DK_E4M3 || kind == DK_E5M2) && (flags & ~FL_ABF8) == 0) {
+      const bool wb = kind == DK_E5M2, ab = (flags & FL_ABF8) != 0;
+      *lds_bytes = PP8WPolicy<0, 0>::LDS_BYTES;
+      return !wb ? (!ab ? wq_gemm_pp8w_kernel<PP8WPolicy<0, 0>> : wq_gemm_pp8w_kernel<PP8WPolicy<0, 1>>)
+                 : (!ab ? wq_gemm_pp8w_kernel<PP8WPolicy<1, 0>> : wq_gemm_pp8w_kernel<PP8WPolicy<1, 1>>);
+    }
+    if (at == AT_I8 && kind == DK_NATIVE && flags == 0) {
+      *lds_bytes = PP8WPolicy<4, 4>::LDS_BYTES;
+      return wq_gemm_pp8w_kernel<PP8WPolicy<4, 4>>;
+    }
+    if (at == AT_F16 && kind == DK_NATIVE && (flags & ~(int)FL_BF16) == 0) {
+      *lds_bytes = PP8WPolicy<2, 2>::LDS_BYTES;
+      return (flags & FL_BF16) ? wq_gemm_pp8w_kernel<PP8WPolicy<3, 3>> : wq_gemm_pp8w_kernel<PP8WPolicy<2, 2>>;
+    }
+  }
   if (at == AT_F8 && mode == MD_NONE && (kind == DK_E4M3 || kind == DK_E5M2) && (flags & ~FL_ABF8) == 0) {   // dense fp8 x fp8, all four pairings
     const bool wb = kind == DK_E5M2, ab = (flags & FL_ABF8) != 0;
     if (bm == 256) {

@@ -1116,6 +1116,258 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_pp8_kernel(const GemmArgs 
 }
 
 // ------------------------------------------------------------------------------------------
+// Round 5 (VERDICT r04 "next" #3a): the dense 256 x 256 tile on a 2 (m) x 4 (n) WAVE GRID - a wave owns 64 weight rows (four
+// fragments) x 128 activation rows (eight fragments).  wq_gemm_pp8_kernel's 1 x 8 grid reads every activation fragment in every
+// wave: per k-tile and wave 32 activation + 4 weight reads of 16 bytes for its 64 fragment pairs; here 16 + 8 - a third fewer LDS
+// reads per MFMA, which on a power-limited chip is time (tools/mfma_power.hip: one ds_read_b128 per 32 matrix cycles costs 17-19 %).
+// The price: both operands are SHARED tiles now (the weight rows of a wave pair w, w + 4 are the same 64), so the weights get the
+// activations' discipline - a ring of whole 256-row tiles in LDS (2 slots of 32 KiB next to the activations' 3: exactly the CU's
+// 160 KiB), every wave copies its 32 rows of each, waits for its own pieces, and a barrier stands between "landed" and "read".
+// Slot re-use across the two role groups (one barrier apart): W(t + 2) goes into W(t)'s slot from load segment 1 of tile t on -
+// two barriers after the issuing group's own read of W(t), one after the other group's; A(t + 2) into A(t - 1)'s slot from load
+// segment 0 of tile t on - likewise behind both groups' last reads of it.  Per k-tile and wave 8 LDS-DMA pieces in one order
+// ([A p0, p1] with segment 0, [A p2, p3, W p0..p3] with segment 1), so "tile t + 1 has landed" is `vmcnt(8)` at the end of segment 1.
+// Two phases per k-tile (4 activation fragments x 4 weight fragments each: 16 pairs = 16 / 32 MFMAs).  Same k order per output as
+// the 1 x 8 grid (ascending k inside a tile, tiles in order): bit-identical results.
+// ------------------------------------------------------------------------------------------
+template <int WFMT_, int AFMT_>
+struct PP8WPolicy {
+  static constexpr int WFMT = WFMT_, AFMT = AFMT_;
+  static constexpr int ESZ = (WFMT_ == 2 || WFMT_ == 3) ? 2 : 1;
+  static constexpr bool I8 = WFMT_ == 4;
+  static_assert(WFMT_ < 2 || WFMT_ == AFMT_, "the 16-bit / int8 members take one type for both operands");
+  static constexpr int BM = 256, BN = 256, THREADS = 512, KT = 128 / ESZ, TILE_ROW = 128;
+  static constexpr int RING = 3, D = 2, WS = 2;
+  static constexpr int A_SLOT = BM * TILE_ROW, W_SLOT = BN * TILE_ROW;
+  static constexpr int W_OFF = RING * A_SLOT;
+  static constexpr int LDS_BYTES = W_OFF + WS * W_SLOT;
+  static_assert(LDS_BYTES <= 160 * 1024 && LDS_BYTES >= BM * BN * 2, "LDS budget / output staging");
+};
+
+template <class P>
+__global__ void __launch_bounds__(P::THREADS) wq_gemm_pp8w_kernel(const GemmArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int D = P::D, RING = P::RING;
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+  typedef int i32x8 __attribute__((ext_vector_type(8)));
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave >> 2;                         // role group = M-half: waves w and w + 4 share a SIMD and a set of weight rows
+  const int nq = wave & 3;
+  const int fr = lane & 15, kb = lane >> 4;
+
+  const TileOfBlock tob = tile_of_block(a, (int)blockIdx.x, (int)gridDim.x);
+  const int tile_m = tob.tile_m, tile_n = tob.tile_n;
+  const int m0 = tile_m * P::BM, n0 = (tile_n + a.tile_n_off) * P::BN;
+  const int ntiles = a.K / P::KT;
+  const uint32_t rowb = (uint32_t)a.K * (uint32_t)P::ESZ;
+
+  const auto a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.A), 0, (int)((long)a.M * rowb), 0x00020000);
+  const auto w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.B), 0, (int)((long)a.N * rowb), 0x00020000);
+  // piece j of either operand: 8 rows x one 128-byte line of this wave's 32-row share of the tile; rows beyond the matrix are out of
+  // the buffer's range (read as zero)
+  const int g0_ = (lane & 7) ^ ((lane >> 4) & 7);
+  const uint32_t v0 = (uint32_t)(wave * 32 + (lane >> 3)) * rowb + (uint32_t)(g0_ * 16);
+  const int vd = ((g0_ ^ 4) - g0_) * 16;
+  const uint32_t a_rows0 = (uint32_t)m0 * rowb, w_rows0 = (uint32_t)n0 * rowb;
+
+  unsigned char* const a_ring = smem;
+  unsigned char* const w_ring = smem + P::W_OFF;
+  auto dma_a = [&](int tt, int slot, int j) {
+    const int tc = tt < ntiles ? tt : ntiles - 1;
+    unsigned char* dst = a_ring + slot * P::A_SLOT + (wave * 32 + j * 8) * P::TILE_ROW;
+    const uint32_t rows = a_rows0 + (uint32_t)(j * 8) * rowb;
+    const uint32_t voff = (j & 1) ? v0 + (uint32_t)vd + rows : v0 + rows;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rsrc, (lds_ptr_t)dst, 16, voff, tc * P::TILE_ROW, 0, 0);
+  };
+  auto dma_w = [&](int tt, int ws, int j) {
+    const int tc = tt < ntiles ? tt : ntiles - 1;
+    unsigned char* dst = w_ring + ws * P::W_SLOT + (wave * 32 + j * 8) * P::TILE_ROW;
+    const uint32_t rows = w_rows0 + (uint32_t)(j * 8) * rowb;
+    const uint32_t voff = (j & 1) ? v0 + (uint32_t)vd + rows : v0 + rows;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (lds_ptr_t)dst, 16, voff, tc * P::TILE_ROW, 0, 0);
+  };
+
+  const int swl = (fr >> 1) & 7;
+  uint32_t rd[2];                                    // granules kb and 4 + kb of row fr
+  rd[0] = (uint32_t)(fr * P::TILE_ROW + ((kb ^ swl) * 16));
+  rd[1] = (uint32_t)(fr * P::TILE_ROW + (((4 + kb) ^ swl) * 16));
+
+  using acc_t = typename std::conditional<P::I8, i32x4, f32x4>::type;
+  acc_t acc[8][4];                                   // [activation fragment of the wave's M-half][weight fragment of its 64 rows]
+#pragma unroll
+  for (int f = 0; f < 8; ++f)
+#pragma unroll
+    for (int nf = 0; nf < 4; ++nf) acc[f][nf] = acc_t{0, 0, 0, 0};
+  u32x4 afrag[4][2], wfrag[4][2];
+
+  // ---- prologue: tiles 0 and 1, each as [A p0..p3, W p0..p3] ----
+#pragma unroll
+  for (int tt = 0; tt < 2; ++tt) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) dma_a(tt, tt, j);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) dma_w(tt, tt, j);
+  }
+  pp_wait_vmcnt<8>();
+  PP_BARRIER();
+  if (grp == 1) PP_BARRIER();
+
+  int slot = 0;
+  auto load_segment = [&](auto PH, int t) {
+    constexpr int p = decltype(PH)::value;
+    const unsigned char* sl = a_ring + slot * P::A_SLOT + (grp * 8 + p * 4) * (16 * P::TILE_ROW);
+    if constexpr (p == 0) {
+      const unsigned char* ws = w_ring + (t & 1) * P::W_SLOT + nq * (64 * P::TILE_ROW);
+#pragma unroll
+      for (int nf = 0; nf < 4; ++nf)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) wfrag[nf][i] = *reinterpret_cast<const u32x4*>(ws + nf * (16 * P::TILE_ROW) + rd[i]);
+    }
+#pragma unroll
+    for (int f = 0; f < 4; ++f)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) afrag[f][i] = *reinterpret_cast<const u32x4*>(sl + f * (16 * P::TILE_ROW) + rd[i]);
+    const int dslot = slot + D >= RING ? slot + D - RING : slot + D;
+    if constexpr (p == 0) {
+      dma_a(t + 2, dslot, 0);
+      dma_a(t + 2, dslot, 1);
+    } else {
+      dma_a(t + 2, dslot, 2);
+      dma_a(t + 2, dslot, 3);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) dma_w(t + 2, t & 1, j);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if constexpr (p == 1) pp_wait_vmcnt<8>();        // tile t + 1 complete: only tile t + 2's eight pieces may be outstanding
+    PP_BARRIER();
+  };
+  auto compute_segment = [&](auto PH) {
+    constexpr int p = decltype(PH)::value;
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      if constexpr (P::I8) {
+#pragma unroll
+        for (int nf = 0; nf < 4; ++nf)
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+            acc[p * 4 + f][nf] = __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4, wfrag[nf][i]), __builtin_bit_cast(i32x4, afrag[f][i]),
+                                                                       acc[p * 4 + f][nf], 0, 0, 0);
+      } else if constexpr (P::ESZ == 2) {
+#pragma unroll
+        for (int nf = 0; nf < 4; ++nf)
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            if constexpr (P::WFMT == 3)
+              acc[p * 4 + f][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wfrag[nf][i]), __builtin_bit_cast(bf16x8_t, afrag[f][i]),
+                                                                          acc[p * 4 + f][nf], 0, 0, 0);
+            else
+              acc[p * 4 + f][nf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8_t, wfrag[nf][i]), __builtin_bit_cast(half8_t, afrag[f][i]),
+                                                                         acc[p * 4 + f][nf], 0, 0, 0);
+          }
+      } else {
+        const i32x8 av = {(int)afrag[f][0][0], (int)afrag[f][0][1], (int)afrag[f][0][2], (int)afrag[f][0][3],
+                          (int)afrag[f][1][0], (int)afrag[f][1][1], (int)afrag[f][1][2], (int)afrag[f][1][3]};
+#pragma unroll
+        for (int nf = 0; nf < 4; ++nf) {
+          const i32x8 wv = {(int)wfrag[nf][0][0], (int)wfrag[nf][0][1], (int)wfrag[nf][0][2], (int)wfrag[nf][0][3],
+                            (int)wfrag[nf][1][0], (int)wfrag[nf][1][1], (int)wfrag[nf][1][2], (int)wfrag[nf][1][3]};
+          acc[p * 4 + f][nf] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wv, av, acc[p * 4 + f][nf], P::WFMT, P::AFMT, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+        }
+      }
+    }
+    PP_BARRIER();
+  };
+  for (int t = 0; t < ntiles; ++t) {
+    load_segment(ic<0>{}, t);
+    compute_segment(ic<0>{});
+    load_segment(ic<1>{}, t);
+    compute_segment(ic<1>{});
+    slot = slot + 1 == RING ? 0 : slot + 1;
+  }
+  if (grp == 0) PP_BARRIER();
+
+  // ---- epilogue: wq_gemm_pp8_kernel's, with this grid's (row, column) of a fragment ----
+  pp_wait_vmcnt<0>();
+  PP_BARRIER();
+  const int el = pp_opaque(lane);
+  const int e_fr = el & 15, e_kb = el >> 4, e_ln = el & 31, e_h = el >> 5;
+  if constexpr (P::I8) {
+    int bias_i[4][4];
+#pragma unroll
+    for (int nf = 0; nf < 4; ++nf)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int n = n0 + nq * 64 + nf * 16 + e_kb * 4 + i;
+        bias_i[nf][i] = a.has_bias ? (int)reinterpret_cast<const int8_t*>(a.bias)[n < a.N ? n : a.N - 1] : 0;
+      }
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {            // pass = M-half: the half's four waves stage its 128 rows, all eight store them
+      if (pass) __syncthreads();
+      if (grp == pass) {
+#pragma unroll
+        for (int f = 0; f < 8; ++f) {
+          const int ml = f * 16 + e_fr;
+#pragma unroll
+          for (int nf = 0; nf < 4; ++nf) {
+            const int sidx = nq * 16 + nf * 4 + e_kb;
+            const i32x4 v = {(int)acc[f][nf][0] + bias_i[nf][0], (int)acc[f][nf][1] + bias_i[nf][1], (int)acc[f][nf][2] + bias_i[nf][2],
+                             (int)acc[f][nf][3] + bias_i[nf][3]};
+            *reinterpret_cast<i32x4*>(smem + ml * 1024 + ((sidx ^ (ml & 7)) * 16)) = v;
+          }
+        }
+      }
+      PP_FENCE();
+      __syncthreads();
+#pragma unroll
+      for (int rr = 0; rr < 16; ++rr) {
+        const int ml = wave * 16 + rr;
+        const i32x4 x = *reinterpret_cast<const i32x4*>(smem + ml * 1024 + ((el ^ (ml & 7)) * 16));
+        const int m = m0 + pass * 128 + ml, n = n0 + el * 4;
+        if (m < a.M && n < a.N) pp_store_out(reinterpret_cast<i32x4*>(reinterpret_cast<int*>(a.C) + (long)m * a.N + n), x, a.ws_policy);
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int f = 0; f < 8; ++f) {
+    const int m = (grp * 8 + f) * 16 + e_fr;
+#pragma unroll
+    for (int nf = 0; nf < 4; ++nf) {
+      uint32_t lo_u, hi_u;
+      if constexpr (P::WFMT == 3) {
+        float x[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) x[i] = bf16_round(acc[f][nf][i]);
+        lo_u = (__builtin_bit_cast(uint32_t, x[0]) >> 16) | (__builtin_bit_cast(uint32_t, x[1]) & 0xFFFF0000u);
+        hi_u = (__builtin_bit_cast(uint32_t, x[2]) >> 16) | (__builtin_bit_cast(uint32_t, x[3]) & 0xFFFF0000u);
+      } else {
+        const half2_t lo = {(half_t)acc[f][nf][0], (half_t)acc[f][nf][1]}, hi = {(half_t)acc[f][nf][2], (half_t)acc[f][nf][3]};
+        lo_u = as_u32(lo);
+        hi_u = as_u32(hi);
+      }
+      const int u = nq * 16 + nf * 4 + e_kb;
+      const int up = (((u >> 1) ^ (m & 7)) << 1) | ((u & 1) ^ ((m >> 3) & 1));
+      *reinterpret_cast<u32x2*>(smem + m * 512 + up * 8) = u32x2{lo_u, hi_u};
+    }
+  }
+  PP_FENCE();
+  __syncthreads();
+#pragma unroll
+  for (int rr = 0; rr < 16; ++rr) {
+    const int m = wave * 32 + rr * 2 + e_h;
+    u32x4 x = *reinterpret_cast<const u32x4*>(smem + m * 512 + ((e_ln ^ (m & 7)) * 16));
+    if ((m >> 3) & 1) x = u32x4{x[2], x[3], x[0], x[1]};
+    const int n = n0 + e_ln * 8;
+    if (m0 + m < a.M && n < a.N) pp_store_out(reinterpret_cast<u32x4*>(reinterpret_cast<half_t*>(a.C) + (long)(m0 + m) * a.N + n), x, a.ws_policy);
+  }
+#endif
+}
+
+// ------------------------------------------------------------------------------------------
 // dense fp8, 128 x 128 tile: the member for outputs too small to give every CU a wider tile - the N / 8 column shards of
 // BASELINE c5 (4096 x 1024: 128 tiles of 128 x 256, 256 of these).  Wave grid 4 (n) x 2 (m): a wave owns 32 weight rows and
 // 64 activation rows (4 fragments x 2 = 8 MFMAs per k-tile: ONE phase), the two m-halves are the two role groups of the

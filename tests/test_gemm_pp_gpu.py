@@ -250,3 +250,39 @@ def test_two_launches_of_different_rows_share_nothing():
     case["A"] = A
     got, _ = _run(case, 512)
     assert np.array_equal(got[1::2], got[0::2])
+
+
+@pytest.mark.parametrize("kind", ["float16", "bfloat16", "int8", "e4m3_float8", "e5m2_e4m3"])
+@pytest.mark.parametrize("M,N,K", [(300, 520, 512), (512, 512, 1152), (257, 264, 128)])
+def test_dense_2x4_wave_grid_is_bit_identical_to_the_1x8_grid(kind, M, N, K, monkeypatch, pin_the_tile):
+    """round 5: the dense 256 x 256 tile on a 2 (m) x 4 (n) wave grid (wq_gemm_pp8w_kernel: both operands shared LDS tiles, a third
+    fewer LDS reads per MFMA) adds every output's products in the same order as the 1 x 8 grid it replaces (WQAA_GEMM_PP8_WIDE=0)"""
+    if pin_the_tile != 256:
+        pytest.skip("the 256-row tile only")
+    import bitblas_amd as bitblas
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(M + K)
+    if kind == "int8":
+        A = torch.randint(-128, 128, (M, K), device="cuda", dtype=torch.int8, generator=gen)
+        W = torch.randint(-128, 128, (N, K), device="cuda", dtype=torch.int8, generator=gen)
+        cfg = dict(A_dtype="int8", W_dtype="int8", accum_dtype="int32", out_dtype="int32")
+    elif kind in ("float16", "bfloat16"):
+        tdt = torch.float16 if kind == "float16" else torch.bfloat16
+        A = (torch.rand((M, K), device="cuda", generator=gen) - 0.5).to(tdt)
+        W = (torch.rand((N, K), device="cuda", generator=gen) - 0.5).to(tdt)
+        cfg = dict(A_dtype=kind, W_dtype=kind, accum_dtype="float32", out_dtype=kind)
+    else:
+        a_dt, w_dt = ("e4m3_float8", "e4m3_float8") if kind == "e4m3_float8" else ("e5m2_float8", "e4m3_float8")
+        tdt = {"e4m3_float8": torch.float8_e4m3fn, "e5m2_float8": torch.float8_e5m2}
+        A = (torch.rand((M, K), device="cuda", generator=gen) * 2 - 1).to(tdt[a_dt])
+        W = (torch.rand((N, K), device="cuda", generator=gen) * 2 - 1).to(tdt[w_dt])
+        cfg = dict(A_dtype=a_dt, W_dtype=w_dt, accum_dtype="float32", out_dtype="float16")
+    outs = []
+    for wide in ("1", "0"):
+        monkeypatch.setenv("WQAA_GEMM_PP8_WIDE", wide)
+        mm = bitblas.Matmul(bitblas.MatmulConfig(M=M, N=N, K=K, **cfg), enable_tuning=False)
+        assert mm.plans[M]["name"].endswith("pp"), mm.plans[M]["name"]
+        out = mm(A, W)
+        torch.cuda.synchronize()
+        outs.append(out.view(torch.int16 if out.element_size() == 2 else torch.int32).cpu())
+    assert torch.equal(outs[0], outs[1])

@@ -158,7 +158,9 @@ def test_growth_during_capture_is_refused_and_a_caller_workspace_works():
     assert_fp_parity(out.cpu().numpy(), oracle_output(case))
     with pytest.raises(wl.WqaaError, match="workspace"):
         mm.lib.run_ws(ops["A"].data_ptr(), ops["W"].data_ptr(), None, ops["scale"].data_ptr(), ops["zeros"].data_ptr(),
-                      None, out.data_ptr(), 48, torch.cuda.current_stream().cuda_stream, ws.data_ptr(), need - 16)
+                      None, out.data_ptr(), 48, torch.cuda.current_stream().cuda_stream, ws.data_ptr(), 1 << 16)
+    # (round 5: `workspace_bytes` is the larger of the mid-M member's exchange buffer and the split-K member's partial sums it falls back
+    # to; a workspace that holds either is served - one that holds neither is refused)
 
 
 def test_automatic_two_pass_does_not_refuse_a_capture_that_needed_no_scratch_before():
