@@ -155,8 +155,7 @@ static int dispatch(const wqaa_matmul_desc& d, int m, bool* use_gemm) {
   //   M = 4   4096^2 7.8 vs 6.6,  11008 x 4096 14.4 vs 13.2 (skinny member + reduce launch)
   //   M = 5-7 4096^2 10.9-11.8 vs 7.6-8.2
   // M <= 2 stays on the GEMV family (M = 2: 5.2 us at 4096^2, the MFMA members take ~6.2).
-  int min_m = 3;
-  if (const char* f = getenv("WQAA_GEMM_MIN_M")) min_m = atoi(f);   // tuning aid
+  const int min_m = 3;
   if (m >= min_m) {
     if (gemm_plan(d, m, &p) == WQAA_OK) *use_gemm = true;
   } else if (gemv_plan(d, m, &p) != WQAA_OK && gemm_plan(d, m, &p) == WQAA_OK) {
@@ -344,7 +343,6 @@ static int matmul_impl(const wqaa_matmul_desc* desc, const void* A, const void* 
 static bool group_fusable(const wqaa_matmul_desc* const* descs, int count, int m, wqaa_matmul_desc* merged, int* fused_x,
                           int epi_mode = 0) {      // epi_mode: 0 none, 1 caller's row scales, 2 in-kernel activation quantiser, 3 RMSNorm in front
   if (count < 2 || count > WQAA_GROUP_MAX || m < 1 || m > 2) return false;
-  if (const char* f = getenv("WQAA_GROUP_FUSE")) { if (atoi(f) == 0) return false; }    // A/B aid: members launched one by one
   long total = 0;
   for (int i = 0; i < count; ++i) {
     wqaa_matmul_desc a = *descs[i], b = *descs[0];

@@ -138,14 +138,15 @@ static const ChainKnobs& chain_knobs() {
     // any kernel holding LDS leave part of it queued; every wait then ends in its 250 ms bound with an error code only
     // `wqaa_debug_chain_status` reads).  Whoever opts in owns that precondition.
     k.fuse = geti("WQAA_CHAIN_FUSE", 0) != 0;
-    k.lanes = geti("WQAA_CHAIN_LANES", 0);
-    k.cpl = geti("WQAA_CHAIN_CPL", 0);
-    k.ring = geti("WQAA_CHAIN_RING", 0);
-    k.thin = geti("WQAA_CHAIN_THIN", 1) != 0;
-    k.sweep_sleep = geti("WQAA_CHAIN_SWEEP_SLEEP", 2);
-    if (k.sweep_sleep < 0) k.sweep_sleep = 0;
+    // (round 4's lab aids WQAA_CHAIN_LANES / _CPL / _RING / _THIN / _SWEEP_SLEEP / _LAB are gone with round 5's prune: the values
+    // they settled on - profiles/r04_chain_lab.txt)
+    k.lanes = 0;
+    k.cpl = 0;
+    k.ring = 0;
+    k.thin = 1;
+    k.sweep_sleep = 2;
     k.trace = geti("WQAA_CHAIN_TRACE", 0);
-    k.lab = geti("WQAA_CHAIN_LAB", 0);
+    k.lab = 0;
     const int ms = geti("WQAA_CHAIN_TIMEOUT_MS", 250);
     k.timeout_ticks = (unsigned)(ms > 0 ? ms : 1) * 100000u;          // s_memrealtime runs at 100 MHz
     seen = ep;

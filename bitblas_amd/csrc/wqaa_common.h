@@ -220,11 +220,9 @@ inline void short_wdtype(const wqaa_matmul_desc& d, char* buf, size_t n) {
 }
 
 
-// WQAA_GEMV_UNCAP=1 (A/B aid, plan-time): GEMV grids are not capped at the workgroups the chip holds at once
-inline bool gemv_uncapped() {
-  const char* f = getenv("WQAA_GEMV_UNCAP");
-  return f && atoi(f) != 0;
-}
+// (round 2's A/B aid WQAA_GEMV_UNCAP - GEMV grids not capped at the workgroups the chip holds at once - was settled by
+// profiles/r02_ab_cap.txt and is gone: round 5's prune)
+inline bool gemv_uncapped() { return false; }
 
 inline int ilog2_exact(int v) {
   if (v <= 0 || (v & (v - 1))) return -1;

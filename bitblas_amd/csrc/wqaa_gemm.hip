@@ -232,7 +232,6 @@ static int gemm_choose(const wqaa_matmul_desc& d, int m, GemmChoice* c, bool fus
   const long tiles256 = (long)((m + 255) / 256) * ((d.N + 255) / 256);
   c->mf = (m >= 256 && d.N >= 256 && tiles256 * 10 >= (long)cus_ * 9) ? 16
           : m > 128 ? 8 : m > 32 ? 4 : m > 16 ? 2 : 1;
-  if (const char* f = getenv("WQAA_GEMM_MF")) c->mf = atoi(f);   // tuning aid
   const int nsteps = d.K / c->ks;
   // The ping-pong members (wqaa_gemm_pp_kernel.h), where one exists: 4-bit weights x float16, 2-bit weights x int8, dense fp8;
   // four k-tiles (256 / 512 / 128 k) per trip, groups of 128 * 2^i (Scale / Zeros rows 4-byte aligned: K / g even), float16 /
@@ -245,7 +244,6 @@ static int gemm_choose(const wqaa_matmul_desc& d, int m, GemmChoice* c, bool fus
   c->pp_shift = 0;
   c->pp_bm = 0;
   if (m > 128 && d.N >= 128) {
-    const char* pf = getenv("WQAA_GEMM_PP");
     const bool dense16 = c->kind == DK_NATIVE && c->at == AT_F16;        // float16 / bfloat16 x the same type: the dense fp8 skeleton on 16-bit lines
     const bool dense8 = c->kind == DK_NATIVE && c->at == AT_I8;          // int8 x int8: the same skeleton, 128 k per line
     const int kb = dense16 ? 64 : c->at == AT_F16 ? 256 : (c->at == AT_F8 || dense8) ? 128 : 512;   // k per trip of the main loop
@@ -264,7 +262,7 @@ static int gemm_choose(const wqaa_matmul_desc& d, int m, GemmChoice* c, bool fus
                         : (d.out_dtype == WQAA_F32 || d.out_dtype == ((c->flags & FL_BF16) ? WQAA_BF16 : WQAA_F16));
     const long a_bytes = (long)m * d.K * (c->at == AT_F16 ? 2 : 1), w_bytes = (long)d.N * d.K * c->bits / 8;
     const bool shape_ok = epi_ok && d.K % kb == 0 && meta_ok && out_ok && d.N % 8 == 0 && a_bytes + 256L * d.K * 2 < (1L << 31) &&
-                          w_bytes < (1L << 31) && d.k_split_hint <= 1 && getenv("WQAA_GEMM_KSPLIT") == nullptr && (!pf || atoi(pf) != 0);
+                          w_bytes < (1L << 31) && d.k_split_hint <= 1 && getenv("WQAA_GEMM_KSPLIT") == nullptr;
     auto rounds_time = [&](long tiles, double base, double slope) {
       const long full = tiles / cus_, rem = tiles % cus_;
       return (double)full * (base + slope * cus_) + (rem ? base + slope * (double)rem : 0.0);
@@ -310,8 +308,6 @@ static int gemm_choose(const wqaa_matmul_desc& d, int m, GemmChoice* c, bool fus
       const char* fb = getenv("WQAA_GEMM_PP_BN");
       if (bm == 128 && fb && atoi(fb) == 128 && fns) bn = 128;
       else if ((bm == 256 && !fn256) || (bm == 128 && !fn128)) bm = 0;
-    } else if (getenv("WQAA_GEMM_MF") != nullptr) {
-      bm = (c->mf == 16 && fn256) ? 256 : 0;                       // a forced tile height keeps its round-2 meaning
     } else {
       double best = k_ok ? 0.97 * tlock : 1e30;      // (K off the lockstep members' grid: any ping-pong member that takes it)
       if (fn256 && t256 < best) { bm = 256; best = t256; }
@@ -361,7 +357,7 @@ static int gemm_choose(const wqaa_matmul_desc& d, int m, GemmChoice* c, bool fus
   // K = 2048 (16.4 vs 13.1) - those keep their members.  WQAA_GEMM_MID=0: never; WQAA_GEMM_MID_FORCE=1: wherever the shape fits (the
   // parity tests run every instantiation that way).
   if (!no_mid && !fused_epilogue && c->at == AT_F16 && !(c->flags & FL_BF16) && c->kind == DK_INT4 && d.k_split_hint <= 1 &&
-      getenv("WQAA_GEMM_KSPLIT") == nullptr && getenv("WQAA_GEMM_MF") == nullptr && m > 16) {
+      getenv("WQAA_GEMM_KSPLIT") == nullptr && m > 16) {
     const char* mf_ = getenv("WQAA_GEMM_MID");
     const char* ff_ = getenv("WQAA_GEMM_MID_FORCE");
     const bool force = ff_ && atoi(ff_) != 0;
@@ -372,12 +368,13 @@ static int gemm_choose(const wqaa_matmul_desc& d, int m, GemmChoice* c, bool fus
     const long tiles = (long)((m + 16 * mf - 1) / (16 * mf)) * ((d.N + 127) / 128);
     const long wgs = tiles * 8;
     int lds = 0;
-    gemm_fn fn = (nkh == 1 || nkh == 2 || nkh == 4) && mf * nkh <= 16 ? pick_gemm_mid(c->kind, c->layout, c->mode, mf, nkh, &lds) : nullptr;
+    gemm_fn fn = (nkh == 2 || nkh == 4) && mf * nkh <= 16 ? pick_gemm_mid(c->kind, c->layout, c->mode, mf, nkh, &lds) : nullptr;
     // (the members with NKH >= 2 fetch Scale / Zeros of their NKH consecutive groups in one load per row: one group per k-step,
     // rows aligned; other group sizes keep the members they had)
     const bool widemeta = (c->mode == MD_S || c->mode == MD_ZO || c->mode == MD_ZR) && nkh >= 2;
     const bool meta_ok = !widemeta || (g == c->ks && (d.K / g) % nkh == 0);
-    const bool measured = m <= 128 && (mf == 8 ? (nkh == 2 && wgs <= cus_)
+    // (128 rows on half a chip of workgroups - N = 2048: 16.0 vs 14.1 us - keeps its member: at least three quarters of a round)
+    const bool measured = m <= 128 && (mf == 8 ? (nkh == 2 && wgs <= cus_ && 4 * wgs >= 3L * cus_)
                                                : (nkh == 4 ? wgs <= 3L * cus_ : (nkh == 2 && wgs > cus_ && wgs <= 3L * cus_)));
     if (fn && meta_ok && (!mf_ || atoi(mf_) != 0) && (force || measured) && tiles <= kMidMaxTiles &&
         (long)m * d.K * 2 < (1L << 32) && d.K < (1 << 23) && m < (1 << 23) && (c->mode != MD_ZQ || d.N % 2 == 0)) {
@@ -410,8 +407,7 @@ static int gemm_choose(const wqaa_matmul_desc& d, int m, GemmChoice* c, bool fus
   // M=8 N=6144 (1.5 rounds) 9.8 vs 10.2, N=8192 10.4 vs 11.3, N=11008 14.5 vs 13.5, 4096x11008 12.1 vs 18.8;
   // M=4 8192^2 15.9 vs 17.3.
   const int frags = (d.N + 15) / 16;
-  int decode_max_m = 16;
-  if (const char* f = getenv("WQAA_GEMM_DECODE_MAXM")) decode_max_m = atoi(f);   // tuning aid
+  const int decode_max_m = 16;
   // (the direct-load member, which only packed-int4 activations still use: M <= 8 up to 1.5 rounds, M = 9..16 between
   // 0.75 and 1 round - the round-1 table above)
   // (two whole rounds of fragments at M = 9 ... 16: a tie with the split-K skinny member at K = 8192 - 19.2 vs 19.4 us at 8192^2 - and
@@ -456,9 +452,8 @@ static int gemm_choose(const wqaa_matmul_desc& d, int m, GemmChoice* c, bool fus
     if (!dflag || atoi(dflag) != 0) c->decode = 1;
   }
   if (c->decode) {
-    // activations through LDS-DMA (member 211) unless disabled (WQAA_GEMM_DECODE_LDS=0: the direct-load member 201)
-    const char* lflag = getenv("WQAA_GEMM_DECODE_LDS");
-    const bool want_lds = c->mf == 1 && c->at != AT_I4 && (!lflag || atoi(lflag) != 0);
+    // activations through LDS-DMA (member 211); packed int4 activations: the direct-load member 201
+    const bool want_lds = c->mf == 1 && c->at != AT_I4;
     c->fn = want_lds ? pick_gemm(c->kind, c->layout, c->at, c->mode, c->flags, 211) : nullptr;
     const bool lds_member = c->fn != nullptr;
     if (!c->fn) c->fn = pick_gemm(c->kind, c->layout, c->at, c->mode, c->flags, 200 + c->mf);
@@ -480,9 +475,8 @@ static int gemm_choose(const wqaa_matmul_desc& d, int m, GemmChoice* c, bool fus
     c->decode = 0;
   }
   // otherwise the skinny member, unless disabled
-  int skinny_max_m = 64;
-  if (const char* f = getenv("WQAA_GEMM_SKINNY_MAXM")) skinny_max_m = atoi(f);   // tuning aid
-  c->skinny = (m <= skinny_max_m && c->mf <= 4 && getenv("WQAA_GEMM_NOSKINNY") == nullptr) ? 4 : 0;
+  const int skinny_max_m = 64;
+  c->skinny = (m <= skinny_max_m && c->mf <= 4) ? 4 : 0;
   c->nwaves = c->mf == 16 ? 8 : 4;
   c->bn = c->skinny ? 64 : c->nwaves * 32;
   int code = c->skinny ? 100 + c->mf : c->mf;
@@ -664,7 +658,6 @@ int gemm_launch(const wqaa_matmul_desc& d, const void* A, const void* B, const v
   // tile order: groups of 4 M-tiles (same-box sweep over 1/2/4/8/16: fp8 4096 x 8192 x 8192 375 -> 361 us,
   // 4096 x 28672 x 8192 1355 -> 1293, uint4 8192^3 1012 -> 984, 4096^3 unchanged; 8 and 16 lose on int2 x int8)
   a.group_m = c.tiles_m >= 4 ? 4 : 1;
-  if (const char* f = getenv("WQAA_GEMM_GROUP_M")) a.group_m = atoi(f) > 0 ? atoi(f) : 1;
   a.tiles_m = c.tiles_m;
   a.tiles_n = c.tiles_n;
   fill_tile_magics(a, c.ksplit, d.K);
@@ -854,9 +847,8 @@ static bool own_dense_second_pass(const wqaa_matmul_desc& dd, int m) {
 }
 
 static bool two_pass_auto(const wqaa_matmul_desc& d, const wqaa_matmul_desc& dd, int m) {
-  int auto_m = 1024;
-  if (const char* f = getenv("WQAA_TWO_PASS_AUTO")) auto_m = atoi(f);          // (plan time: the callers memoise the verdict)
-  if (auto_m <= 0 || m < auto_m) return false;
+  const int auto_m = 1024;
+  if (m < auto_m) return false;
   if (d.K % (d.a_dtype == WQAA_I8 ? 256 : 128) != 0 || !own_dense_second_pass(dd, m)) return false;
   // only for descriptors NO fused ping-pong member takes (a format with one keeps its fused members at every shape: where the round
   // estimate prefers the lockstep member - uint4 1024 x 4096^2: 48.9 us - B_decode + dense would be 60)
@@ -981,7 +973,7 @@ void gemm_init() {
   for (int layout = 0; layout < 2; ++layout)
     for (int mode = 0; mode <= MD_ZQ; ++mode)
       for (int mf : {2, 4, 8})
-        for (int nkh : {1, 2, 4}) {
+        for (int nkh : {2, 4}) {
           int lds = 0;
           gemm_fn fn = pick_gemm_mid(DK_INT4, layout, mode, mf, nkh, &lds);
           if (fn) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

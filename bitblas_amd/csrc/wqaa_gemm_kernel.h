@@ -1932,7 +1932,9 @@ static gemm_fn pick_mf(int mf) {
     case 102: return wq_gemm_kernel<GemmPolicy<KIND, LAYOUT, AT, MODE, FLAGS, 2, 4, 1, 4>>;
     case 104: return wq_gemm_kernel<GemmPolicy<KIND, LAYOUT, AT, MODE, FLAGS, 4, 4, 1, 4>>;
     // 128-row skinny member: 8 waves x one weight fragment each (BN = 128), 4 k-steps per workgroup, every load first
-    case 201: return wq_gemm_decode_kernel<GemmPolicy<KIND, LAYOUT, AT, MODE, FLAGS, 1, 8, 1>>;
+    // (round 5's prune: the direct-load decode member is instantiated only where it is the selector's choice - packed int4 activations,
+    // which the LDS-DMA member does not take; elsewhere it was reachable through the A/B aid WQAA_GEMM_DECODE_LDS=0 alone)
+    case 201: if constexpr (AT == AT_I4) return wq_gemm_decode_kernel<GemmPolicy<KIND, LAYOUT, AT, MODE, FLAGS, 1, 8, 1>>; else return nullptr;
     case 211: if constexpr (AT != AT_I4) return wq_gemm_decode_lds_kernel<GemmPolicy<KIND, LAYOUT, AT, MODE, FLAGS, 1, 8, 1>>; else return nullptr;
     // 900: not a GEMM - B_decode to memory (two-pass member, wqaa_dequantize); launched with (GemmArgs, void* out)
     case 900:

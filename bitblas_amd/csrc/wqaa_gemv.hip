@@ -200,8 +200,6 @@ static int choose(const wqaa_matmul_desc& d, int m, GemvChoice* c, bool quant_in
     const int n_rg0 = (d.N + c->R - 1) / c->R;
     while (nw > 4 && (n_rg0 + nw - 1) / nw < cus) nw /= 2;
   }
-  const char* force = getenv("WQAA_GEMV_THREADS");   // tuning aid
-  if (force && atoi(force) >= 64) nw = atoi(force) / 64;
   const int n_rg = (d.N + c->R - 1) / c->R;
   // Few-row shards (N / 8 slices of a column-parallel layer: 1024 x 28672, 1280 x 8192): one wave per row group leaves
   // most of the chip without a wave.  Split K across kw waves of a workgroup until ~8 waves per CU are busy; the parts

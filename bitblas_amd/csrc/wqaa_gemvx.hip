@@ -99,7 +99,6 @@ static int gemvx_choose(const wqaa_matmul_desc& d, int m, GemvxChoice* c, int pr
   gemvx_candidate(d.N, c->nsteps, cus, 2, &k2, &sc2);
   gemvx_candidate(d.N, c->nsteps, cus, 1, &k1, &sc1);
   c->R = sc2 >= 0.9 * sc1 ? 2 : 1;
-  if (const char* f = getenv("WQAA_GEMVX_R")) c->R = atoi(f) == 1 ? 1 : 2;
   if (pro == 2 || pro == 4) c->R = 2;
   int kw = c->R == 2 ? k2 : k1;
   if (d.k_split_hint > 1) kw = d.k_split_hint;                                          // the caller's k_split
@@ -132,7 +131,6 @@ static int gemvx_choose(const wqaa_matmul_desc& d, int m, GemvxChoice* c, int pr
       slots *= 2;
     }
   }
-  if (const char* f = getenv("WQAA_GEMVX_SLOTS")) slots = atoi(f) > 0 ? atoi(f) : 1;
   if (slots * kw > 16) slots = 16 / kw;
   if (slots < 1) slots = 1;
   c->nw = slots * kw;
@@ -191,10 +189,6 @@ static int gemvx_choose(const wqaa_matmul_desc& d, int m, GemvxChoice* c, int pr
   c->fn = c->bits == 4 ? pick_gemvx_int4(c->layout, c->mode, c->mb, rd)
           : c->bits == 2 ? pick_gemvx_int2(c->layout, c->mode, c->mb, rd)
                          : pick_gemvx_int1(c->layout, c->mode, c->mb, rd);
-  if (const char* f = getenv("WQAA_GEMVX_ABL")) {      // ablation members (tools only): wrong results by construction
-    if (!pro && atoi(f) > 0 && c->bits == 4 && c->layout == LAYOUT_LOP3 && c->mode == MD_S && c->mb == 1 && c->R == 2 && pick_gemvx_lab(atoi(f)))
-      c->fn = pick_gemvx_lab(atoi(f));
-  }
   if (!c->fn) {
     set_error(WQAA_ERR_UNSUPPORTED, "gemvx: no member for bits=%d layout=%d mode=%d mb=%d rd=%d", c->bits, c->layout, c->mode, c->mb, rd);
     return WQAA_ERR_UNSUPPORTED;

@@ -799,6 +799,5 @@ gemvx_fn pick_gemvx_pro1(int layout, int mode, int mb, int rd);
 gemvx_fn pick_gemvx_norm4(int layout, int mode, int mb, int rd);    // RMSNorm in front (wqaa_gemvx_inst_norm*.hip)
 gemvx_fn pick_gemvx_norm2(int layout, int mode, int mb, int rd);
 gemvx_fn pick_gemvx_norm1(int layout, int mode, int mb, int rd);
-gemvx_fn pick_gemvx_lab(int abl);     // ablation members of the int4 / LOP3 / scale / M = 1 / R = 2 configuration (tools only)
 
 }  // namespace wqaa

@@ -70,26 +70,23 @@ def test_other_zero_point_forms_and_bias(zeros_mode, M, monkeypatch):
 
 
 @pytest.mark.parametrize("fast", [False, True])
-@pytest.mark.parametrize("K,cfg", [(4096, dict(with_scaling=True, group_size=128)), (4096, dict()),
-                                   (2048, dict(with_scaling=True, group_size=-1)), (2048, dict(with_scaling=True, group_size=32)),
-                                   (2048, dict(with_scaling=True, group_size=256)), (2048, dict(with_scaling=True, group_size=128))])
-def test_int4_layouts_and_group_sizes(K, cfg, fast, monkeypatch):
-    """signed int4, both checkpoint layouts (plain / LOP3-interleaved); no scale; at K = 2048 (one k-step per k-half: the per-step
-    metadata loads) per-channel scales and g = 32 / 128 / 256"""
-    case = make_case(96, 1024, K, W_dtype="int4", fast_decoding=fast, scale_mul=0.02, seed=3, **cfg)
+@pytest.mark.parametrize("cfg", [dict(with_scaling=True, group_size=128), dict()])
+def test_int4_both_checkpoint_layouts(cfg, fast, monkeypatch):
+    """signed int4, plain and LOP3-interleaved (`fast_decoding`) checkpoint layouts, with the group scale and without any"""
+    case = make_case(96, 1024, 4096, W_dtype="int4", fast_decoding=fast, scale_mul=0.02, seed=3, **cfg)
     _run(case, 96, monkeypatch, check_paths=fast)
 
 
 def test_group_sizes_the_wide_metadata_loads_do_not_take_keep_their_members(monkeypatch):
     monkeypatch.setenv("WQAA_GEMM_MID_FORCE", "1")
-    for g in (-1, 32, 256):
+    for g in (-1, 32, 256):             # (one load fetches Scale / Zeros of a wave's consecutive k-steps: one group per k-step, g = 128)
         mm = bitblas.Matmul(bitblas.MatmulConfig(M=96, N=1024, K=4096, A_dtype="float16", W_dtype="int4", group_size=g, with_scaling=True), enable_tuning=False)
         assert "xmk" not in mm.plans[96]["name"], mm.plans[96]["name"]
 
 
-@pytest.mark.parametrize("M,N,K", [(128, 4096, 2048), (64, 2048, 8192), (32, 4096, 8192), (40, 1000, 4096), (128, 132, 4096)])
+@pytest.mark.parametrize("M,N,K", [(64, 2048, 8192), (32, 4096, 8192), (40, 1000, 4096), (128, 132, 4096)])
 def test_other_k_and_ragged_n(M, N, K, monkeypatch):
-    """K = 2048 (one k-step per k-half) and 8192 (four: M <= 64 fits the LDS), N off the 128-column tile"""
+    """K = 8192 (four k-steps per k-half: M <= 64 fits the LDS), N off the 128-column tile"""
     case = make_case(M, N, K, W_dtype="uint4", group_size=128, with_scaling=True, with_zeros=True, zeros_mode="original", scale_mul=0.02, seed=M + N)
     _run(case, M, monkeypatch)
 
@@ -179,9 +176,9 @@ def test_where_the_selector_takes_the_member(monkeypatch):
         cfg = dict(A_dtype="float16", W_dtype="uint4", group_size=128, with_scaling=True, with_zeros=True)
         cfg.update(kw)
         return bitblas.Matmul(bitblas.MatmulConfig(M=M, N=N, K=K, **cfg), enable_tuning=False).plans[M]["name"]
-    for (M, N, K) in ((128, 4096, 4096), (96, 4096, 4096), (65, 2048, 4096), (64, 4096, 8192), (32, 4096, 8192), (64, 8192, 4096), (64, 11008, 4096), (17, 8192, 8192)):
+    for (M, N, K) in ((128, 4096, 4096), (96, 4096, 4096), (65, 3072, 4096), (64, 4096, 8192), (32, 4096, 8192), (64, 8192, 4096), (64, 11008, 4096), (17, 8192, 8192)):
         assert name(M, N, K).endswith("xmk"), (M, N, K, name(M, N, K))
     for (M, N, K) in ((128, 11008, 4096), (128, 4096, 11008), (16, 4096, 4096), (64, 4096, 4096), (32, 4096, 4096), (128, 4096, 2048), (128, 4096, 8192),
-                      (256, 4096, 4096)):
+                      (256, 4096, 4096), (128, 2048, 4096)):
         assert "xmk" not in name(M, N, K), (M, N, K, name(M, N, K))
     assert "xmk" not in name(128, 4096, 4096, W_dtype="uint2")

@@ -7,7 +7,7 @@ import torch
 
 import wqaa_oracle as oracle
 import bitblas_amd as bitblas
-from helpers import assert_fp_parity
+from helpers import contract, assert_fp_parity
 
 pytestmark = pytest.mark.gpu
 

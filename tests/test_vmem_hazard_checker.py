@@ -135,4 +135,4 @@ def test_the_mid_m_kernels_of_the_built_library_are_clean():
         sys.argv = old
     out = buf.getvalue()
     assert rc == 0, out[-3000:]
-    assert "kernels checked, 0 with findings" in out and int(out.strip().split("\n")[-1].split()[0]) >= 60, out[-500:]
+    assert "kernels checked, 0 with findings" in out and int(out.strip().split("\n")[-1].split()[0]) >= 50, out[-500:]

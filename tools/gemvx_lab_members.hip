@@ -1,3 +1,4 @@
+// (round 5: moved out of the product library - csrc/ - with the WQAA_GEMVX_ABL switch; kept as the source of the round-2 ablation numbers)
 // lab members: ablations of the int4 / LOP3 / scale / M = 1 / R = 2 exact-product GEMV (WQAA_GEMVX_ABL=<bits>, tools only)
 #include "wqaa_gemvx_kernel.h"
 namespace wqaa {
