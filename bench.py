@@ -980,6 +980,11 @@ def main():
             member("gemm_uint4_m4096_two_pass_vendor", time_member_gemm, device, gen, 4096, tuned=True)
             member("gemm_uint4_m128", time_member_gemm, device, gen, 128)
             member("gemm_uint4_m16", time_member_gemm, device, gen, 16)
+            # the rest of the reference's default opt_M steps below the ping-pong tiles ("M = 32 / 64 / 256 reported"), and a
+            # shape where the mid-M member (round 5, `...xmk`) is the selector's choice below 65 rows
+            for m_ in (32, 64, 256):
+                member(f"gemm_uint4_m{m_}", time_member_gemm, device, gen, m_)
+            member("gemm_uint4_m64_n4096k8192", time_member_gemm, device, gen, 64, 4096, 8192)
             # decode batches on wide outputs (round 4): the persistent form of the one-launch decode member (a 7B model's gate / up and
             # q/k/v widths, `...xdlp`) and its whole-tile form on long K (a 70B model's hidden size, `...xdlt`)
             member("gemm_uint4_m8_n11008k4096", time_member_gemm, device, gen, 8, 11008, 4096)
