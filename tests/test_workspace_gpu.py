@@ -200,3 +200,38 @@ def test_automatic_two_pass_does_not_refuse_a_capture_that_needed_no_scratch_bef
     assert_fp_parity(out2.float().cpu().numpy()[rows], want.astype(np.float16).astype(np.float32), rtol=1e-3, atol_frac=1e-3)
     # (the fused member of this shape splits K: another summation order - the two forms agree to rounding, not bit for bit)
     assert_fp_parity(out.float().cpu().numpy()[rows], out2.float().cpu().numpy()[rows], rtol=1e-3, atol_frac=1e-3)
+
+
+def test_automatic_two_pass_is_capped_and_takes_a_short_workspace_as_the_fused_member(monkeypatch):
+    """round 5: the automatic two-pass form must not turn a call that needed no scratch into a refused or a memory-hungry
+    one.  Beyond WQAA_TWO_PASS_AUTO_MAX_MB the plan, `workspace_bytes` and the call all say "fused member"; with the cap open, a caller
+    workspace too small for B_decode runs the fused member instead of returning BAD_DESC; both meet the oracle."""
+    import ctypes
+    import wqaa_oracle as oracle
+    M, N, K = 2048, 2048, 1024
+    rng = np.random.default_rng(6)
+    A = (rng.random((M, K), dtype=np.float32) - 0.5).astype(np.float16)
+    W = rng.integers(-128, 128, size=(N, K), dtype=np.int8)
+    cfg = bitblas.MatmulConfig(M=M, N=N, K=K, A_dtype="float16", W_dtype="int8", accum_dtype="float32", out_dtype="float16")
+    rows = np.arange(0, M, 67)
+    want = oracle.matmul_dequant(A[rows], W, source_format="int", bit=8, a_dtype="float16", out_dtype="float32").astype(np.float16).astype(np.float32)
+    Ad, Wd = torch.from_numpy(A).cuda(), torch.from_numpy(W).cuda()
+    # (a) the cap: N K 2 = 4 MiB of scratch against a 1 MiB cap
+    monkeypatch.setenv("WQAA_TWO_PASS_AUTO_MAX_MB", "1")
+    capped = bitblas.Matmul(cfg, enable_tuning=False)
+    assert "_dq_" not in capped.plans[M]["name"], capped.plans[M]["name"]
+    fused_need = capped.lib.workspace_bytes(M)
+    assert fused_need < N * K * 2
+    out = capped(Ad, Wd)
+    torch.cuda.synchronize()
+    assert_fp_parity(out.float().cpu().numpy()[rows], want, rtol=1e-3, atol_frac=1e-3)
+    # (b) cap open, the caller's workspace holds the fused member's partial sums but not B_decode
+    monkeypatch.delenv("WQAA_TWO_PASS_AUTO_MAX_MB")
+    mm = bitblas.Matmul(cfg, enable_tuning=False)
+    need = mm.lib.workspace_bytes(M)
+    assert "_dq_" in mm.plans[M]["name"] and need >= N * K * 2
+    small = torch.empty(max(fused_need, 4096), dtype=torch.uint8, device="cuda")      # what the fused member needs - not B_decode's 4 MiB
+    out2 = torch.zeros((M, N), dtype=torch.float16, device="cuda")
+    mm.lib.run_ws(Ad.data_ptr(), Wd.data_ptr(), None, None, None, None, out2.data_ptr(), M, torch.cuda.current_stream().cuda_stream, small.data_ptr(), small.numel())
+    torch.cuda.synchronize()
+    assert_fp_parity(out2.float().cpu().numpy()[rows], want, rtol=1e-3, atol_frac=1e-3)
