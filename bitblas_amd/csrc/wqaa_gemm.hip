@@ -139,6 +139,7 @@ struct GemmChoice {
   int tail_lds, tail_tiles_m, tail_tiles_n;
   int decode_long;      // the one-launch decode member stages the wave's whole k-range (M-sized slots) and walks units (fragment, k-block)
   int decode_grid;      // > 0: the persistent form of the one-launch decode member (grid < number of 16-row fragments)
+  int decode_kslice;    // the K-sliced form of the decode member: 8 slices x decode_grid / 8 workgroups, fp32 partial sums + wq_mid_reduce_kernel
   int pp_avail;         // m > 128: a fused ping-pong member takes this descriptor (whether or not the round estimate chose it here)
   int mid;              // the mid-M one-launch split-K member (wqaa_gemm_mid_kernel.h); mid_nkh: k-steps per k-half of a slice
   int mid_nkh;
@@ -154,6 +155,7 @@ static int gemm_choose(const wqaa_matmul_desc& d, int m, GemmChoice* c, bool fus
   c->pp_avail = 0;
   c->decode_grid = 0;
   c->decode_long = 0;
+  c->decode_kslice = 0;
   c->flags = 0;
   c->layout = d.w_layout == WQAA_LAYOUT_LOP3 ? LAYOUT_LOP3 : LAYOUT_PLAIN;
   if (a == WQAA_F16) c->at = AT_F16;
@@ -420,7 +422,8 @@ static int gemm_choose(const wqaa_matmul_desc& d, int m, GemmChoice* c, bool fus
   // fragments' weights in flight; the grid is capped at one workgroup per CU.  Partial rounds no longer cost a round:
   // 11008 x 4096 M = 3 ... 16 13.3-15.1 us (skinny + reduce) -> 11.6-12.6; 8192 9.8-11.3 -> 8.6-9.7; 5120 9.2-10.6 -> 8.2-9.2
   // (profiles/r04_ab_decode_persistent.txt).  WQAA_GEMM_DECODE_PERSIST=0: off.
-  bool persist = false;
+  bool persist = false, ksl_ok = false, ksl_take = false;
+  int ksl_lds = 0;
   {
     const char* pf = getenv("WQAA_GEMM_DECODE_PERSIST");
     // (float types, up to three rounds of fragments: 22016 x 4096 - 5.4 per workgroup - and int2 x int8 measured no better
@@ -439,8 +442,29 @@ static int gemm_choose(const wqaa_matmul_desc& d, int m, GemmChoice* c, bool fus
     // 18.0, 8192^2 15.0 / 16.2 -> 12.7 / 13.4, 10240 x 8192 20.2 / 21.2 -> 17.4 / 17.8); with one fragment each (N <= 4096) asking for
     // everything at once measured the same as block by block - 4096 x 11008 M = 4 10.8 vs 11.0 us - and the old form stays
     // (profiles/r04_ab_decode_long.txt).
-    if (counted && nbk >= 2 && nbk <= 3 && run * nq <= 16 && frags > cus_ && frags <= (6 / nbk) * pgrid && (!lf || atoi(lf) != 0)) {
+    const int lmode = lf ? atoi(lf) : 1;               // 0: neither long-K form; 1: the measured rules; 2: whole tile only; 3: K-sliced wherever it fits
+    if (counted && nbk >= 2 && nbk <= 3 && run * nq <= 16 && frags > cus_ && frags <= (6 / nbk) * pgrid && lmode != 0) {
       c->decode_long = 1;
+      persist = true;
+    }
+    // round 5 - K-SLICED, K > 4096 (hand-counted formats, float16): workgroup (k-slice, group) keeps rows < M of ITS eighth of K in LDS
+    // (run x nq KiB + the over-read of the last slot) and its waves walk weight fragments; the partial sums (N x 512 B of fp32) meet in
+    // wq_mid_reduce_kernel, slices in wave order: the same bits as the one-launch forms.  What it buys: a CU reads an eighth of A once
+    // instead of all of A per fragment (at K = 28672 A was twice the weights' bytes per workgroup).  What it costs: the second launch and
+    // 128 M / K of the weights' bytes in partial sums - hence long K only.
+    ksl_lds = run * nq * 1024 + 4096;
+    ksl_ok = !no_mid && counted && !(c->flags & FL_BF16) && nsteps > 32 && ksl_lds <= 160 * 1024 && frags >= 8 && lmode != 0 && lmode != 2 &&
+             d.k_split_hint <= 1 && getenv("WQAA_GEMM_KSPLIT") == nullptr && (long)m * d.K * 2 < (1L << 32) &&
+             pick_gemm(c->kind, c->layout, c->at, c->mode, c->flags, 212) != nullptr;
+    // WHERE (same-process A/B against the members it stands in for, uint4 g128 + zeros, us; tools/r05_ab_kslice.py, profiles/r05_ab_kslice.txt):
+    // two rounds of fragments or more at K >= 8192 with M = 9 ... 16 - 8192 x 28672 41.1 vs 54.9 (split-K skinny + reduce), 12288 x 8192 22.9
+    // vs 26.0, 11008 x 8192 22.4 vs 24.1, 8192^2 18.3 vs 19.2 - and M = 5 ... 8 on the longest K (8192 x 28672 M = 8 40.5 vs 46.2; M = 4 a tie).
+    // Everywhere else it is BEHIND - 4096 x 11008 M = 8 15.4 vs 11.8, 12288 x 8192 M = 8 22.5 vs 18.0, 4096 x 8192 13.7 vs 8.8: its fixed
+    // cost (the request burst of tile + three units per wave at the ~43 GB/s a CU's load path takes, the second launch) is ~9 us against
+    // ~3 of the one-launch forms, and only its slope is better (3.8 vs 3.4 TB/s and no second round of A).
+    ksl_take = ksl_ok && (lmode == 3 || (frags >= 2 * cus_ && ((m >= 9 && d.K >= 8192) || (m >= 5 && d.K >= 24576))));
+    if (ksl_take) {
+      c->decode_long = 0;
       persist = true;
     }
   }
@@ -469,6 +493,16 @@ static int gemm_choose(const wqaa_matmul_desc& d, int m, GemmChoice* c, bool fus
       // persistent: a grid of one workgroup per CU (whole XCD rounds keep the block swizzle on); the direct-load member has no such form
       c->decode_grid = (lds_member && persist) ? (cus_ / 8) * 8 : 0;
       if (!lds_member) c->decode_long = 0;
+      gemm_fn ksl_fn = (lds_member && ksl_take) ? pick_gemm(c->kind, c->layout, c->at, c->mode, c->flags, 212) : nullptr;
+      if (ksl_fn) {
+        c->fn = ksl_fn;
+        // (8 slices x groups of 8 waves: one fragment per wave and round; at most one workgroup per CU - two per CU, where the tile
+        // leaves room, measured 5-15 % slower)
+        const int groups = (frags + 7) / 8 < cus_ / 8 ? (frags + 7) / 8 : cus_ / 8;
+        c->decode_kslice = 1;
+        c->decode_grid = 8 * groups;
+        c->lds = ksl_lds;
+      }
       if (lds_member || fits_one_each) return WQAA_OK;
       c->fn = nullptr;                       // (persistent asked for, but this format has only the direct-load member)
     }
@@ -534,7 +568,7 @@ int gemm_plan(const wqaa_matmul_desc& d, int m, wqaa_plan* plan, bool fused_epil
     plan->rows_per_wave = 32;
     plan->batch_tile = 16 * c.mf;
     plan->pipeline_depth = 2;
-    plan->split_k = c.mid ? kMidSlices : c.ksplit;
+    plan->split_k = (c.mid || c.decode_kslice) ? kMidSlices : c.ksplit;
     plan->lds_bytes = c.lds;
     plan->grid = c.tiles_m * c.tiles_n * (c.mid ? kMidSlices : c.ksplit) + (c.tail_fn ? c.tail_tiles_m * c.tail_tiles_n : 0);
     if (c.decode_grid > 0) plan->grid = c.decode_grid;
@@ -543,18 +577,21 @@ int gemm_plan(const wqaa_matmul_desc& d, int m, wqaa_plan* plan, bool fused_epil
     char tail[16] = "";
     if (c.tail_fn) snprintf(tail, sizeof(tail), "t%d", c.tail_tiles_n);      // "ppt11": the last 11 N-tiles as a launch of the 128-row tile
     snprintf(plan->name, sizeof(plan->name), "matmul_m%dn%dk%d_%sx%s_tcx%dx%dx%d%s%s%s", m, d.N, d.K, short_dtype(d.a_dtype),
-             wd, 16 * c.mf, c.bn, c.ks, c.ksplit > 1 ? "xr" : "", c.mid ? "xmk" : c.pp ? "pp" : c.skinny ? "xs" : c.decode == 2 ? (c.decode_long ? "xdlt" : c.decode_grid > 0 ? "xdlp" : "xdl") : c.decode ? "xd" : c.wide ? "xw" : "", tail);
+             wd, 16 * c.mf, c.bn, c.ks, c.ksplit > 1 ? "xr" : "", c.mid ? "xmk" : c.pp ? "pp" : c.skinny ? "xs" : c.decode == 2 ? (c.decode_kslice ? "xdlk" : c.decode_long ? "xdlt" : c.decode_grid > 0 ? "xdlp" : "xdl") : c.decode ? "xd" : c.wide ? "xw" : "", tail);
   }
   return WQAA_OK;
 }
 
 // (the mid-M member's exchange buffer: tiles x 8 portions x 8 slices x mf KiB)
-static size_t mid_ws_bytes(const GemmChoice& c) { return (size_t)c.tiles_m * c.tiles_n * 8 * kMidSlices * c.mf * 1024; }
+static size_t mid_ws_bytes(const GemmChoice& c) {
+  if (c.decode_kslice) return (size_t)c.tiles_n * kMidSlices * 1024;       // (the K-sliced decode form: fragments x 8 slices x 1 KiB)
+  return (size_t)c.tiles_m * c.tiles_n * 8 * kMidSlices * c.mf * 1024;
+}
 
 size_t gemm_workspace_bytes(const wqaa_matmul_desc& d, int m) {
   GemmChoice c;
   if (gemm_choose(d, m, &c) != WQAA_OK) return 0;
-  if (c.mid) {
+  if (c.mid || c.decode_kslice) {
     // ... or, should its sync words be unavailable at launch time (first use of a device inside a stream capture), the member it
     // stands in for: the larger of the two needs
     GemmChoice f;
@@ -613,7 +650,7 @@ int gemm_launch(const wqaa_matmul_desc& d, const void* A, const void* B, const v
   void* mid_ws = nullptr;
   unsigned* mid_sync = nullptr;
   bool mid_in_launch = false;
-  if (c.mid && !epi) {
+  if ((c.mid || c.decode_kslice) && !epi) {
     const size_t need = mid_ws_bytes(c);
     if (opts && opts->workspace) {
       if (opts->workspace_bytes >= need && (reinterpret_cast<uintptr_t>(opts->workspace) & 15) == 0) mid_ws = opts->workspace;
@@ -632,7 +669,7 @@ int gemm_launch(const wqaa_matmul_desc& d, const void* A, const void* B, const v
         seam_seen = ep;
       }
     }
-    mid_in_launch = seam_mode == 1;
+    mid_in_launch = seam_mode == 1 && c.mid;
     if (mid_ws && mid_in_launch) mid_sync = mid_sync_words(stream, mid_ws);
     if (!mid_ws || (mid_in_launch && !mid_sync)) {
       int st = gemm_choose(d, m, &c, false, true);
@@ -707,6 +744,7 @@ int gemm_launch(const wqaa_matmul_desc& d, const void* A, const void* B, const v
       if (!a.ws) return WQAA_ERR_LAUNCH;
     }
   }
+  if (c.decode_kslice) a.ws = mid_ws;
   if (c.mid) {
     a.ws = mid_ws;
     a.mid_sync = mid_sync;
@@ -728,7 +766,7 @@ int gemm_launch(const wqaa_matmul_desc& d, const void* A, const void* B, const v
   hipError_t e;
   if (start || stop) {
     e = hipExtLaunchKernel(reinterpret_cast<const void*>(c.fn), grid, block, params, c.lds, stream, start,
-                           (c.ksplit > 1 || c.tail_fn || (c.mid && !mid_in_launch)) ? nullptr : stop, 0);
+                           (c.ksplit > 1 || c.tail_fn || (c.mid && !mid_in_launch) || c.decode_kslice) ? nullptr : stop, 0);
   } else {
     e = hipLaunchKernel(reinterpret_cast<const void*>(c.fn), grid, block, params, c.lds, stream);
   }
@@ -748,6 +786,19 @@ int gemm_launch(const wqaa_matmul_desc& d, const void* A, const void* B, const v
   if (e == hipSuccess && c.mid && !mid_in_launch) {
     int mfc = c.mf, units = c.tiles_m * c.tiles_n * 8 * c.mf;
     void* rparams[] = {&a, &mfc, &units};
+    const dim3 rgrid((unsigned)((units + 3) / 4)), rblock(256);
+    const void* rfn = reinterpret_cast<const void*>(wq_mid_reduce_kernel<0>);
+    if (start || stop) e = hipExtLaunchKernel(rfn, rgrid, rblock, rparams, 0, stream, nullptr, stop, 0);
+    else e = hipLaunchKernel(rfn, rgrid, rblock, rparams, 0, stream);
+  }
+  if (e == hipSuccess && c.decode_kslice) {
+    // unit = fragment: (tile, portion) = (fragment / 8, fragment % 8) of a one-row map of 128-column tiles
+    GemmArgs r = a;
+    r.tiles_m = 1;
+    r.tiles_n = (d.N + 127) / 128;
+    r.mg_ntiles = tile_magic((uint32_t)r.tiles_n);
+    int mfc = 1, units = c.tiles_n;
+    void* rparams[] = {&r, &mfc, &units};
     const dim3 rgrid((unsigned)((units + 3) / 4)), rblock(256);
     const void* rfn = reinterpret_cast<const void*>(wq_mid_reduce_kernel<0>);
     if (start || stop) e = hipExtLaunchKernel(rfn, rgrid, rblock, rparams, 0, stream, nullptr, stop, 0);
@@ -954,7 +1005,7 @@ void gemm_init() {
       for (int at = 0; at < 4; ++at)
         for (int mode = 0; mode <= MD_ZQ; ++mode)
           for (int flags : {0, (int)FL_STRICT, (int)FL_ABF8, (int)FL_BF16})
-            for (int mf : {1, 2, 4, 8, 16, 101, 102, 104, 201, 211, 404}) {
+            for (int mf : {1, 2, 4, 8, 16, 101, 102, 104, 201, 211, 212, 404}) {
               gemm_fn fn = pick_gemm(kind, layout, at, mode, flags, mf);
               if (fn) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             }

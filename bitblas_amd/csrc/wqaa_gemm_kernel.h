@@ -1210,7 +1210,7 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_decode_kernel(const GemmAr
 // and hand-kept per-k-step vmcnt waits were tried and measured no better (the wave is through its DMA queue only
 // when everything else has long arrived).
 // ------------------------------------------------------------------------------------------
-template <class P>
+template <class P, bool KSL = false>      // KSL: the K-sliced form alone (its own instantiation: member 212) - every other form is compiled out of it
 __global__ void __launch_bounds__(P::THREADS) wq_gemm_decode_lds_kernel(const GemmArgs a) {
   using T = typename P::T;
   constexpr int NJ = P::NJ, WL = P::WL, MODE = P::MODE, NW = P::NWAVES;
@@ -1394,7 +1394,18 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_decode_lds_kernel(const Ge
   const int nsteps = a.nsteps;
   const int last = nsteps - 1;
   const int run = (((nsteps + NW - 1) / NW) + 3) & ~3;
-  const int t_lo = wave * run;
+  // (K-sliced form: the eighth of K is the WORKGROUP's - block % 8, one slice per XCD - and every wave of it walks that range)
+  // K-sliced form, workgroup -> (slice, group): a band of ROWS per XCD - the eight slices of a group run on the group's XCD (block = xcd +
+  // 8 (slice + 8 (group / 8)), group = xcd + 8 (group / 8)) - where the groups come in eights; else slice = block % 8.  (One SLICE per
+  // XCD measured 3-10 % slower - at K = 8192, where an XCD would read 512 B of every 4 KiB row, two of its sixteen L2 channels:
+  // profiles/r05_ab_kslice.txt)
+  int ksl_slice = (int)blockIdx.x & 7, ksl_grp = (int)blockIdx.x >> 3;
+  if (KSL && (gridDim.x & 63) == 0) {
+    const int j = (int)blockIdx.x >> 3;
+    ksl_slice = j & 7;
+    ksl_grp = ((int)blockIdx.x & 7) + 8 * (j >> 3);
+  }
+  const int t_lo = (KSL ? ksl_slice : wave) * run;
   const int my_steps = t_lo >= nsteps ? 0 : (nsteps - t_lo < run ? nsteps - t_lo : run);   // wave-uniform
   acc_t* red = reinterpret_cast<acc_t*>(smem_raw + NW * REGION);
   // ---- the hand-counted forms: 4-bit weights with one Scale / Zeros group per k-step (the headline formats) --------------------------
@@ -1412,7 +1423,7 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_decode_lds_kernel(const Ge
     // (8-byte metadata loads as instructions need 4-byte alignment only: K / g even.  Where K / g is not a multiple of 4 the last
     // block's load is moved back to end inside the row and the halves are taken `sh` groups further on)
     const bool wide_c = a.gq_shift == 2 && (a.kg & 1) == 0;
-    if (wide_c && (persistent || a.decode_long)) {
+    if (KSL || (wide_c && (persistent || a.decode_long))) {      // (KSL: the launcher checked the metadata's alignment)
       constexpr bool ZP = MODE == MD_ZO || MODE == MD_ZR;
       constexpr int NOPS = PF + 1 + (ZP ? 1 : 0);        // loads per unit and lane
       struct AF {
@@ -1499,6 +1510,85 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_decode_lds_kernel(const Ge
       AF f0, f1, f2;
       const acc_t zero = acc_t{0, 0, 0, 0};
       acc_t p0 = zero, p1 = zero, p2 = zero;
+      if constexpr (KSL) {
+        static_assert(F16 && !P::BF, "the K-sliced form: float16 activations");
+        {
+          // K-SLICED (round 5, long K): the forms above make every workgroup read ALL of A - at K = 28672 twice its weights' bytes, and a CU
+          // ingests ~40 GB/s: 8192 x 28672 ran at 2.5 TB/s.  Here the k-range that was a WAVE's is a WORKGROUP's: workgroup
+          // (slice, group) stages rows < M of slice
+          // `slice` once, in M-sized slots SHARED by its 8 waves (run x nq KiB), and every wave walks its own weight fragments
+          // (group * 8 + wave, + waves-per-slice, ...) through the slice's blocks - units (fragment, block), three in flight, as the
+          // whole-tile form - keeping ONE accumulator per fragment in k order: exactly the partial sum wave `slice` of the one-launch form
+          // holds.  It leaves as 1 KiB of fp32 (ws[fragment][slice][lane]) and wq_mid_reduce_kernel adds slices 0 .. 7 in that order:
+          // bit-identical to `xdl`.  Waits are counted: a unit's wait leaves the loads of the two units asked for after it outstanding;
+          // beyond the wave's last unit the asks go on (fragment index past the end = row N - 1 for all 16 rows: one cache line per
+          // instruction) so that the count holds to the end without a branch around a load.
+          const int slice = ksl_slice, grp = ksl_grp;
+          const int slot_bytes = nq * 1024;
+          const int nbk = run / PF;
+          region = smem_raw;
+          for (int sidx = wave; sidx < run; sidx += NW) {
+            const int t = t_lo + sidx;
+            const unsigned char* srcb = Ap + (long)(t < nsteps ? t : last) * ASTEP;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              if (q < nq) {
+                const unsigned char* src = srcb + dsrc[q];
+                const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_base + (uint32_t)(sidx * slot_bytes + q * 1024));
+                uint32_t keep;
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+              }
+          }
+          const int wps = ((int)gridDim.x >> 3) * NW;            // waves per slice
+          const int first = grp * NW + wave;
+          const int nfr = first < nfrags ? (nfrags - 1 - first) / wps + 1 : 0;
+          const int U = nfr * nbk;
+          int qf = first, qj = 0;                                // the unit asked for next
+          auto ask = [&](AF& f) __attribute__((always_inline)) {
+            issue_blk(qf, qj, f);
+            if (++qj == nbk) {
+              qj = 0;
+              qf += wps;
+            }
+          };
+          ask(f0);
+          ask(f1);
+          ask(f2);
+          WQ_TRACE(1);
+          asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * NOPS) : "memory");     // this wave's share of the slice is in LDS ...
+          __builtin_amdgcn_sched_barrier(0);
+          WQ_TRACE(2);
+          __builtin_amdgcn_s_barrier();                                        // ... and everybody else's
+          __builtin_amdgcn_sched_barrier(0);
+          WQ_TRACE(3);
+          f32x4* wsq = reinterpret_cast<f32x4*>(a.ws);
+          int cf = first, cj = 0, done = 0;                      // the unit multiplied next
+          auto unit = [&](AF& f) __attribute__((always_inline)) {
+            landed(std::integral_constant<int, 2 * NOPS>{}, f);
+            if (done < U) {
+              if (cj == 0) acc = zero;
+              multiply_blk(f, cj, slot_bytes);
+              if (++cj == nbk) {
+                wsq[((long)cf * 8 + slice) * 64 + lane] = acc;
+                cj = 0;
+                cf += wps;
+              }
+            }
+            ++done;
+            WQ_TRACE_IF(done == 1, 4);
+            ask(f);
+          };
+          for (int u = 0; u < U; u += 3) {
+            unit(f0);
+            unit(f1);
+            unit(f2);
+          }
+          WQ_TRACE(5);
+          WQ_TRACE_DUMP(NW);
+          return;
+        }
+      }
       if (a.decode_long) {
         const int slot_bytes = nq * 1024;
         // units u = (fragment u / NBK, block u % NBK), registers u % 3; a wait counts the loads of the units issued after u
@@ -1936,6 +2026,11 @@ static gemm_fn pick_mf(int mf) {
     // which the LDS-DMA member does not take; elsewhere it was reachable through the A/B aid WQAA_GEMM_DECODE_LDS=0 alone)
     case 201: if constexpr (AT == AT_I4) return wq_gemm_decode_kernel<GemmPolicy<KIND, LAYOUT, AT, MODE, FLAGS, 1, 8, 1>>; else return nullptr;
     case 211: if constexpr (AT != AT_I4) return wq_gemm_decode_lds_kernel<GemmPolicy<KIND, LAYOUT, AT, MODE, FLAGS, 1, 8, 1>>; else return nullptr;
+    // 212: the K-sliced form of 211 (long K; 4-bit weights x float16, Scale (+ Zeros) per 128: the hand-counted formats)
+    case 212:
+      if constexpr (AT == AT_F16 && (FLAGS & FL_BF16) == 0 && (KIND == DK_INT4 || KIND == DK_LUT4) && (MODE == MD_S || MODE == MD_ZO || MODE == MD_ZR))
+        return wq_gemm_decode_lds_kernel<GemmPolicy<KIND, LAYOUT, AT, MODE, FLAGS, 1, 8, 1>, true>;
+      else return nullptr;
     // 900: not a GEMM - B_decode to memory (two-pass member, wqaa_dequantize); launched with (GemmArgs, void* out)
     case 900:
       if constexpr (AT == AT_F16 || AT == AT_I8) return reinterpret_cast<gemm_fn>(wq_dequant_kernel<GemmPolicy<KIND, LAYOUT, AT, MODE, FLAGS, 1>>);

@@ -179,7 +179,7 @@ def test_selector_invariants_over_a_random_configuration_sweep():
     kernel-name style (general_matmul/__init__.py:240-318) - and a refusal must carry a message."""
     import re
     rng = np.random.default_rng(7)
-    name_re = re.compile(r"^matmul_m\d+n\d+k\d+_[a-z0-9]+x[a-z0-9_]+_(gemv_b\d+r\d+d\d+(k\d+)?(_areg)?|gemvx_b\d+r\d+d\d+k\d+(_areg)?|(dq_)?tcx\d+x\d+x\d+(xr)?(pp(t\d+)?|xs|xdl[pt]?|xd|xw|xmk)?)$")
+    name_re = re.compile(r"^matmul_m\d+n\d+k\d+_[a-z0-9]+x[a-z0-9_]+_(gemv_b\d+r\d+d\d+(k\d+)?(_areg)?|gemvx_b\d+r\d+d\d+k\d+(_areg)?|(dq_)?tcx\d+x\d+x\d+(xr)?(pp(t\d+)?|xs|xdl[ptk]?|xd|xw|xmk)?)$")
     pairs = [(wlib.F16, wlib.W_UINT, b) for b in (1, 2, 4, 8)] + [(wlib.F16, wlib.W_INT, b) for b in (1, 2, 4, 8)] + \
             [(wlib.F16, wlib.W_NF, 4), (wlib.F16, wlib.W_FP4, 4), (wlib.F16, wlib.W_E4M3, 8),
              (wlib.BF16, wlib.W_UINT, 4), (wlib.BF16, wlib.W_NF, 4),
@@ -393,7 +393,7 @@ def test_mid_m_members_keep_their_loads_in_registers(tmp_path):
 
 
 def test_decode_batch_forms_are_chosen_where_they_were_measured(monkeypatch):
-    """one-launch decode member, round 4 (no device needed): persistent on wide outputs at K <= 4096 (`xdlp`, up to six rounds of
+    """one-launch decode member, rounds 4 and 5 (no device needed): persistent on wide outputs at K <= 4096 (`xdlp`, up to six rounds of
     fragments for the hand-counted formats), whole tile on long K where M-sized slots fit (`xdlt`: M <= 8 at K <= 8192, M <= 4 at
     K <= 12288, more than one fragment per workgroup), the block-by-block form otherwise"""
     for k in ("WQAA_GEMM_DECODE_PERSIST", "WQAA_GEMM_DECODE_FORCE", "WQAA_GEMM_DECODE_LONG", "WQAA_GEMM_DECODE"):
@@ -406,7 +406,14 @@ def test_decode_batch_forms_are_chosen_where_they_were_measured(monkeypatch):
 
     for m, N, K, suffix in ((8, 11008, 4096, "xdlp"), (16, 22016, 4096, "xdlp"), (3, 12288, 4096, "xdlp"), (8, 11008, 3840, "xdlp"),
                             (8, 8192, 8192, "xdlt"), (3, 12288, 8192, "xdlt"), (4, 8192, 11008, "xdlt"), (4, 8176, 12288, "xdlt"),
-                            (9, 8192, 8192, "xdl"), (5, 8192, 11008, "xdl"), (4, 4096, 11008, "xdl"), (16, 4096, 4096, "xdl")):
+                            (8, 8192, 8192, "xdlt"), (5, 8192, 11008, "xdl"), (4, 4096, 11008, "xdl"), (16, 4096, 4096, "xdl"), (4, 8192, 28672, "xdl"),
+                            # round 5, the K-sliced form (`xdlk`): two rounds of fragments or more, M >= 9 at K >= 8192, M >= 5 at K >= 24576
+                            (9, 8192, 8192, "xdlk"), (16, 12288, 8192, "xdlk"), (16, 11008, 8192, "xdlk"), (8, 8192, 28672, "xdlk"), (16, 8192, 28672, "xdlk"),
+                            (16, 4096, 11008, "xdl"), (8, 12288, 8192, "xdlt")):
         assert name(m, N, K).endswith("_f16xu4_tcx16x16x128" + suffix), (m, N, K, name(m, N, K))
     monkeypatch.setenv("WQAA_GEMM_DECODE_LONG", "0")
-    assert not name(8, 8192, 8192).endswith("xdlt")
+    assert not name(8, 8192, 8192).endswith("xdlt") and not name(16, 8192, 28672).endswith("xdlk")
+    monkeypatch.setenv("WQAA_GEMM_DECODE_LONG", "2")          # the round-4 selector: whole tile, never K-sliced
+    assert name(8, 8192, 8192).endswith("xdlt") and not name(16, 8192, 28672).endswith("xdlk")
+    monkeypatch.setenv("WQAA_GEMM_DECODE_LONG", "3")          # K-sliced wherever the shape fits (the parity tests)
+    assert name(8, 4096, 11008).endswith("xdlk") and name(3, 512, 8192).endswith("xdlk")

@@ -93,6 +93,30 @@ def test_store_data_overwritten_within_two_wait_states_is_found():
     # across a branch: the window follows both arms
     prog = _asm(st, "s_cbranch_scc1 1", "s_nop 0", "v_mov_b32_e32 v4, 0", "s_endpgm")
     assert len(chk.scan("k", prog)) == 1
+    # a LOAD into the data registers is no overwrite inside the window (its data is a memory latency away; the compiler's spill code
+    # has `scratch_store v[a:d]; global_load v[a:d]` back to back)
+    assert chk.scan("k", _asm(st, "global_load_dwordx4 v[2:5], v[0:1], off+", "s_waitcnt vmcnt(0)", "s_endpgm")) == []
+
+
+def test_the_compilers_long_branch_is_followed_and_branches_on_constants_are_pruned():
+    """round 5: with the K-sliced form in it a decode kernel grew past the 16-bit branch range and the compiler wrote
+    `s_getpc_b64; s_add_u32; s_addc_u32; s_setpc_b64` - without following it the walk fell through into the code behind the jump with the
+    jumping path's loads in flight (866 findings per kernel, none real)."""
+    load = "global_load_dwordx4 v[4:7], v[0:1], off+"
+    # 0: load (8 B)  8: getpc (4)  12: add (8)  20: addc (8)  28: setpc (4)  32: v_add (touches the load: NOT reachable)  36: waitcnt  40: endpgm
+    prog = _asm(load, "s_getpc_b64 s[98:99]", "s_add_u32 s98, s98, 0x18+", "s_addc_u32 s99, s99, 0+", "s_setpc_b64 s[98:99]",
+                "v_add_u32_e32 v8, v4, v5", "s_waitcnt vmcnt(0)", "s_endpgm")
+    assert chk.scan("k", prog) == []
+    # the same with the jump landing ON the instruction that touches the load: found
+    bad = _asm(load, "s_getpc_b64 s[98:99]", "s_add_u32 s98, s98, 0x14+", "s_addc_u32 s99, s99, 0+", "s_setpc_b64 s[98:99]",
+               "v_add_u32_e32 v8, v4, v5", "s_waitcnt vmcnt(0)", "s_endpgm")
+    assert len(chk.scan("k", bad)) == 1
+    # a branch on a constant: `s_mov_b64 sx, 0; s_and_b64 vcc, exec, sx; s_cbranch_vccnz` is never taken
+    never = _asm(load, "s_mov_b64 s[4:5], 0", "s_and_b64 vcc, exec, s[4:5]", "s_cbranch_vccnz 1", "s_branch 1", "v_add_u32_e32 v8, v4, v5",
+                 "s_waitcnt vmcnt(0)", "s_endpgm")
+    assert chk.scan("k", never) == []
+    with pytest.raises(RuntimeError):
+        chk.scan("k", _asm(load, "s_setpc_b64 s[30:31]", "s_endpgm"))
 
 
 def test_every_gemm_kernel_of_the_built_library_is_clean_of_both_hazards():

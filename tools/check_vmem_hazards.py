@@ -154,8 +154,8 @@ def store_data_hazards(ins, index_of_addr):
             written = set()
             if op.startswith("v_") and not op.startswith(("v_cmp", "v_nop", "v_readfirstlane", "v_readlane")):
                 written = first_operand_regs(ops)
-            elif re.match(r"^(global|buffer|flat|scratch)_load|^ds_read|^ds_load", op) and not re.search(r"\blds\b", ops):
-                written = first_operand_regs(ops)
+            # (a load that names the data registers as its destination is no writer here: its data comes back a memory latency later,
+            # and the compiler itself issues `scratch_store v[a:d]; global_load v[a:d]` back to back in its spill code)
             hit = written & data
             if hit:
                 out.append((origin[0], origin[1] + "   <-   " + code, sorted(hit), -1))
@@ -181,6 +181,28 @@ def store_data_hazards(ins, index_of_addr):
     return out
 
 
+def long_branch_target(ins, k):
+    """target of the s_setpc_b64 at index k when it ends the compiler's long-branch sequence, else None"""
+    if k < 3:
+        return None
+    (a0, o0, p0, _), (_, o1, p1, _), (_, o2, p2, _), (_, _, p3, _) = ins[k - 3], ins[k - 2], ins[k - 1], ins[k]
+    m0 = re.fullmatch(r"s\[(\d+):(\d+)\]", p0.strip())
+    if o0 != "s_getpc_b64" or o1 != "s_add_u32" or o2 != "s_addc_u32" or not m0 or p3.strip() != p0.strip():
+        return None
+    lo, hi = int(m0.group(1)), int(m0.group(2))
+    f1 = [x.strip() for x in p1.split(",")]
+    f2 = [x.strip() for x in p2.split(",")]
+    if f1[:2] != [f"s{lo}", f"s{lo}"] or f2[:2] != [f"s{hi}", f"s{hi}"] or len(f1) != 3 or len(f2) != 3:
+        return None
+    imm = int(f1[2], 0) & 0xFFFFFFFF
+    carry_hi = int(f2[2], 0)
+    if carry_hi not in (0, -1, 0xFFFFFFFF):
+        return None
+    if imm >= 0x80000000:
+        imm -= 1 << 32
+    return a0 + 4 + imm
+
+
 def scan(name, lines, verbose=False):
     """forward data flow over the kernel's control-flow graph: at a join the queues are merged position by position, counted from
     the youngest operation (sound for in-order retirement: whatever a path has outstanding is in the merged queue at the same age)"""
@@ -191,6 +213,17 @@ def scan(name, lines, verbose=False):
     target = {}
     leaders = {0}
     for k, (addr, op, ops, _) in enumerate(ins):
+        if op == "s_setpc_b64":
+            # the compiler's long branch (a kernel beyond the 16-bit branch range): s_getpc_b64 s[a:a+1]; s_add_u32 sa, sa, imm;
+            # s_addc_u32 sa+1, sa+1, 0|-1; s_setpc_b64 s[a:a+1] - the target is (address after s_getpc) + imm.  Anything else: refuse
+            t = long_branch_target(ins, k)
+            if t is None or index.get(t) is None:
+                raise RuntimeError(f"{name}: s_setpc_b64 at {addr:#x} is not a long branch this tool can follow")
+            if k + 1 < len(ins):
+                leaders.add(k + 1)
+            target[k] = index[t]
+            leaders.add(index[t])
+            continue
         if op == "s_endpgm" or op == "s_branch" or op.startswith("s_cbranch"):
             if k + 1 < len(ins):
                 leaders.add(k + 1)
@@ -215,11 +248,21 @@ def scan(name, lines, verbose=False):
         sx = []
         if last[1] == "s_endpgm":
             pass
-        elif last[1] == "s_branch":
+        elif last[1] == "s_branch" or last[1] == "s_setpc_b64":
             sx.append(block_of[target[en - 1]])
         elif last[1].startswith("s_cbranch"):
-            sx.append(block_of[target[en - 1]])
-            if en < len(ins):
+            # `s_mov_b64 s[x:y], 0 / -1; s_and_b64 vcc, exec, s[x:y]; s_cbranch_vccnz / vccz` inside one block: a branch on a constant (how
+            # the compiler writes "fall into the long branch that follows"): only the edge that can be taken
+            const = None
+            if en - 3 >= st and last[1] in ("s_cbranch_vccnz", "s_cbranch_vccz"):
+                mv, an = ins[en - 3], ins[en - 2]
+                mm = re.fullmatch(r"(s\[\d+:\d+\]), (0|-1)", mv[2].strip())
+                if mv[1] == "s_mov_b64" and mm and an[1] == "s_and_b64" and an[2].replace(" ", "") == f"vcc,exec,{mm.group(1)}":
+                    const = mm.group(2) == "-1"                 # vcc != 0 (for the lanes that run)
+            taken = None if const is None else (const if last[1] == "s_cbranch_vccnz" else not const)
+            if taken is not False:
+                sx.append(block_of[target[en - 1]])
+            if en < len(ins) and taken is not True:
                 sx.append(block_of[en])
         elif en < len(ins):
             sx.append(block_of[en])

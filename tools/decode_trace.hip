@@ -20,8 +20,11 @@ int main(int argc, char** argv) {
   const int launches = 64, g = 128;
   using PD = GemmPolicy<DK_INT4, LAYOUT_LOP3, AT_F16, MD_ZO, 0, 1, 8, 1>;
   using PP = GemmPolicy<DK_INT4, LAYOUT_LOP3, AT_F16, MD_ZO, 0, 4, 4, 2, 0, true>;
-  void (*fn)(const GemmArgs) = ksplit > 0 ? wq_gemm_kernel<PP> : wq_gemm_decode_lds_kernel<PD>;
-  const int lds = ksplit > 0 ? 2 * 64 * 256 : 8 * 4 * 16 * 256 + 8 * 64 * 16;
+  // 4th argument < 0: the K-sliced form of the decode member (plan suffix xdlk): 8 slices x min(fragments / 8, 32) groups
+  const bool ksl = ksplit < 0;
+  const int ksl_run = (((K / 128 + 7) / 8) + 3) & ~3;
+  void (*fn)(const GemmArgs) = ksplit > 0 ? wq_gemm_kernel<PP> : ksl ? wq_gemm_decode_lds_kernel<PD, true> : wq_gemm_decode_lds_kernel<PD>;
+  const int lds = ksplit > 0 ? 2 * 64 * 256 : ksl ? ksl_run * ((M + 3) / 4) * 1024 + 4096 : 8 * 4 * 16 * 256 + 8 * 64 * 16;
   const int nwaves = ksplit > 0 ? 4 : 8;
   CK(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   const size_t wbytes = (size_t)N * K / 2, sbytes = (size_t)N * (K / g) * 2;
@@ -40,10 +43,11 @@ int main(int argc, char** argv) {
   CK(hipMalloc(&A, ha.size() * 2)); CK(hipMemcpy(A, ha.data(), ha.size() * 2, hipMemcpyHostToDevice));
   CK(hipMalloc(&C, (size_t)M * N * 2));
   const int tiles_m = ksplit > 0 ? (M + 63) / 64 : 1, tiles_n = ksplit > 0 ? (N + 127) / 128 : (N + 15) / 16;
-  const int grid = tiles_m * tiles_n * (ksplit > 0 ? ksplit : 1);
+  const int grid = ksl ? 8 * std::min((tiles_n + 7) / 8, 32) : tiles_m * tiles_n * (ksplit > 0 ? ksplit : 1);
   const size_t trace_words = (size_t)grid * nwaves * 16;
   void* WS = nullptr;
   if (ksplit > 1) CK(hipMalloc(&WS, (size_t)ksplit * M * N * 4));
+  if (ksl) CK(hipMalloc(&WS, (size_t)tiles_n * 8 * 1024));
   unsigned long long* T;
   CK(hipMalloc(&T, trace_words * 8 * launches)); CK(hipMemset(T, 0, trace_words * 8 * launches));
   hipStream_t st; CK(hipStreamCreate(&st));
@@ -83,6 +87,15 @@ int main(int argc, char** argv) {
     stat("wave start since first start", [&](const unsigned long long* x) { return (double)(x[8] - r0); }, 0.01, "us");
     stat("wave end since first start", [&](const unsigned long long* x) { return (double)(x[9] - r0); }, 0.01, "us");
     stat("wave lifetime", [&](const unsigned long long* x) { return (double)(x[9] - x[8]); }, 0.01, "us");
+    if (ksl) {
+      stat("entry -> tile + 3 units asked for", [&](const unsigned long long* x) { return (double)(x[1] - x[0]); }, 1.0, "clk");
+      stat("-> own share of the tile in LDS", [&](const unsigned long long* x) { return (double)(x[2] - x[1]); }, 1.0, "clk");
+      stat("-> past the barrier", [&](const unsigned long long* x) { return (double)(x[3] - x[2]); }, 1.0, "clk");
+      stat("-> first unit multiplied", [&](const unsigned long long* x) { return x[4] ? (double)(x[4] - x[3]) : 0.0; }, 1.0, "clk");
+      stat("-> all units done", [&](const unsigned long long* x) { return x[4] ? (double)(x[5] - x[4]) : 0.0; }, 1.0, "clk");
+      stat("entry -> all units done", [&](const unsigned long long* x) { return (double)(x[5] - x[0]); }, 1.0, "clk");
+      continue;
+    }
     if (ksplit > 0) {
       stat("entry -> first loads issued", [&](const unsigned long long* x) { return (double)(x[1] - x[0]); }, 1.0, "clk");
       stat("-> first tile in LDS (barrier)", [&](const unsigned long long* x) { return (double)(x[2] - x[1]); }, 1.0, "clk");
