@@ -457,12 +457,13 @@ static int gemm_choose(const wqaa_matmul_desc& d, int m, GemmChoice* c, bool fus
              d.k_split_hint <= 1 && getenv("WQAA_GEMM_KSPLIT") == nullptr && (long)m * d.K * 2 < (1L << 32) &&
              pick_gemm(c->kind, c->layout, c->at, c->mode, c->flags, 212) != nullptr;
     // WHERE (same-process A/B against the members it stands in for, uint4 g128 + zeros, us; tools/r05_ab_kslice.py, profiles/r05_ab_kslice.txt):
-    // two rounds of fragments or more at K >= 8192 with M = 9 ... 16 - 8192 x 28672 41.1 vs 54.9 (split-K skinny + reduce), 12288 x 8192 22.9
-    // vs 26.0, 11008 x 8192 22.4 vs 24.1, 8192^2 18.3 vs 19.2 - and M = 5 ... 8 on the longest K (8192 x 28672 M = 8 40.5 vs 46.2; M = 4 a tie).
+    // two rounds of fragments or more at K >= 8192 with M = 13 ... 16 - 8192 x 28672 41.1 vs 54.9 (split-K skinny + reduce), 12288 x 8192 22.9
+    // vs 26.0, 11008 x 8192 22.4 vs 24.1, 8192^2 18.3 vs 19.2 (M = 9 there: 18.4 vs 17.2, behind) - and M = 5 ... 16 on the longest K (8192 x
+    // 28672 M = 8 40.5 vs 46.2; M = 4 a tie).
     // Everywhere else it is BEHIND - 4096 x 11008 M = 8 15.4 vs 11.8, 12288 x 8192 M = 8 22.5 vs 18.0, 4096 x 8192 13.7 vs 8.8: its fixed
     // cost (the request burst of tile + three units per wave at the ~43 GB/s a CU's load path takes, the second launch) is ~9 us against
     // ~3 of the one-launch forms, and only its slope is better (3.8 vs 3.4 TB/s and no second round of A).
-    ksl_take = ksl_ok && (lmode == 3 || (frags >= 2 * cus_ && ((m >= 9 && d.K >= 8192) || (m >= 5 && d.K >= 24576))));
+    ksl_take = ksl_ok && (lmode == 3 || (frags >= 2 * cus_ && ((m >= 13 && d.K >= 8192) || (m >= 5 && d.K >= 24576))));
     if (ksl_take) {
       c->decode_long = 0;
       persist = true;

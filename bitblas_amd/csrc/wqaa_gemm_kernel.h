@@ -118,6 +118,9 @@ __host__ __device__ __forceinline__ TileOfBlock tile_of_block(const GemmArgs& a,
 #define WQ_TRACE_DECL unsigned long long tr_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; const unsigned long long tr_real0_ = __builtin_amdgcn_s_memrealtime()
 #define WQ_TRACE(i) tr_[i] = __builtin_readcyclecounter()
 #define WQ_TRACE_IF(c, i) if (c) tr_[i] = __builtin_readcyclecounter()
+#define WQ_TRACE_WAIT_BEGIN const unsigned long long tw0_ = __builtin_readcyclecounter()
+#define WQ_TRACE_WAIT_END(i) tr_[i] += __builtin_readcyclecounter() - tw0_
+#define WQ_TRACE_DRAIN asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 #define WQ_TRACE_DUMP(nw)                                                                                             \
   if (lane == 0 && a.lut) {                                                                                             \
     unsigned long long* d_ = reinterpret_cast<unsigned long long*>(const_cast<void*>(a.lut)) + ((long)blockIdx.x * (nw) + wave) * 16;      \
@@ -129,6 +132,9 @@ __host__ __device__ __forceinline__ TileOfBlock tile_of_block(const GemmArgs& a,
 #define WQ_TRACE_DECL
 #define WQ_TRACE(i)
 #define WQ_TRACE_IF(c, i)
+#define WQ_TRACE_WAIT_BEGIN
+#define WQ_TRACE_WAIT_END(i)
+#define WQ_TRACE_DRAIN
 #define WQ_TRACE_DUMP(nw)
 #endif
 
@@ -1565,7 +1571,9 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_decode_lds_kernel(const Ge
           f32x4* wsq = reinterpret_cast<f32x4*>(a.ws);
           int cf = first, cj = 0, done = 0;                      // the unit multiplied next
           auto unit = [&](AF& f) __attribute__((always_inline)) {
+            WQ_TRACE_WAIT_BEGIN;
             landed(std::integral_constant<int, 2 * NOPS>{}, f);
+            WQ_TRACE_WAIT_END(6);
             if (done < U) {
               if (cj == 0) acc = zero;
               multiply_blk(f, cj, slot_bytes);
@@ -1585,6 +1593,7 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_decode_lds_kernel(const Ge
             unit(f2);
           }
           WQ_TRACE(5);
+          WQ_TRACE_DRAIN;          // (trace builds: the asks beyond the last unit are still in flight and the dump re-uses their registers)
           WQ_TRACE_DUMP(NW);
           return;
         }

@@ -407,8 +407,8 @@ def test_decode_batch_forms_are_chosen_where_they_were_measured(monkeypatch):
     for m, N, K, suffix in ((8, 11008, 4096, "xdlp"), (16, 22016, 4096, "xdlp"), (3, 12288, 4096, "xdlp"), (8, 11008, 3840, "xdlp"),
                             (8, 8192, 8192, "xdlt"), (3, 12288, 8192, "xdlt"), (4, 8192, 11008, "xdlt"), (4, 8176, 12288, "xdlt"),
                             (8, 8192, 8192, "xdlt"), (5, 8192, 11008, "xdl"), (4, 4096, 11008, "xdl"), (16, 4096, 4096, "xdl"), (4, 8192, 28672, "xdl"),
-                            # round 5, the K-sliced form (`xdlk`): two rounds of fragments or more, M >= 9 at K >= 8192, M >= 5 at K >= 24576
-                            (9, 8192, 8192, "xdlk"), (16, 12288, 8192, "xdlk"), (16, 11008, 8192, "xdlk"), (8, 8192, 28672, "xdlk"), (16, 8192, 28672, "xdlk"),
+                            # round 5, the K-sliced form (`xdlk`): two rounds of fragments or more, M >= 13 at K >= 8192, M >= 5 at K >= 24576
+                            (9, 8192, 8192, "xdl"), (13, 8192, 8192, "xdlk"), (16, 12288, 8192, "xdlk"), (16, 11008, 8192, "xdlk"), (8, 8192, 28672, "xdlk"), (16, 8192, 28672, "xdlk"),
                             (16, 4096, 11008, "xdl"), (8, 12288, 8192, "xdlt")):
         assert name(m, N, K).endswith("_f16xu4_tcx16x16x128" + suffix), (m, N, K, name(m, N, K))
     monkeypatch.setenv("WQAA_GEMM_DECODE_LONG", "0")

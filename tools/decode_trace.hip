@@ -94,6 +94,8 @@ int main(int argc, char** argv) {
       stat("-> first unit multiplied", [&](const unsigned long long* x) { return x[4] ? (double)(x[4] - x[3]) : 0.0; }, 1.0, "clk");
       stat("-> all units done", [&](const unsigned long long* x) { return x[4] ? (double)(x[5] - x[4]) : 0.0; }, 1.0, "clk");
       stat("entry -> all units done", [&](const unsigned long long* x) { return (double)(x[5] - x[0]); }, 1.0, "clk");
+      stat("of which in the units' waits", [&](const unsigned long long* x) { return (double)x[6]; }, 1.0, "clk");
+      stat("barrier -> done, not waiting", [&](const unsigned long long* x) { return (double)(x[5] - x[3]) - (double)x[6]; }, 1.0, "clk");
       continue;
     }
     if (ksplit > 0) {

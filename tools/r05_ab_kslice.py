@@ -11,9 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 
-K1 = {"WQAA_GEMM_DECODE_LONG": "3", "WQAA_GEMM_KSL_MAP": "1"}
-ARMS = (("reg", dict(K1, WQAA_GEMM_KSL_W="1")), ("rg2", dict(K1, WQAA_GEMM_KSL_W="1", WQAA_GEMM_KSL_GROUPS="64")), ("dm2", dict(K1, WQAA_GEMM_KSL_GROUPS="64")),
-        ("old", {"WQAA_GEMM_DECODE_LONG": "2"}))
+ARMS = (("ksl", {"WQAA_GEMM_DECODE_LONG": "3"}), ("dflt", {}), ("old", {"WQAA_GEMM_DECODE_LONG": "2"}))
 
 
 def main():
@@ -25,12 +23,12 @@ def main():
         for M in (4, 8, 16):
             shapes.append((M, N, K))
     if len(sys.argv) > 1 and sys.argv[1] == "quick":
-        shapes = [(8, 4096, 11008), (8, 8192, 28672), (16, 8192, 28672), (4, 8192, 8192)]
+        shapes = [(8, 4096, 11008), (8, 8192, 28672), (16, 8192, 28672), (4, 8192, 28672), (16, 12288, 8192), (8, 12288, 8192), (9, 8192, 8192)]
     for (M, N, K) in shapes:
         row = []
         for rep in range(1):
             for arm, env in ARMS:
-                for k in ("WQAA_GEMM_DECODE_LONG", "WQAA_GEMM_KSL_MAP", "WQAA_GEMM_KSL_W", "WQAA_GEMM_KSL_GROUPS"):
+                for k in ("WQAA_GEMM_DECODE_LONG",):
                     os.environ.pop(k, None)
                 os.environ.update(env)
                 bench._OPS.clear()          # (bench.get_op caches operators: the plan is made when the operator is)
