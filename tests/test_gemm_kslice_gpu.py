@@ -119,3 +119,28 @@ def test_hipgraph_replays(monkeypatch):
         g.replay()
         torch.cuda.synchronize()
         assert np.array_equal(_bits(out.cpu().numpy()), _bits(ref))
+
+
+def test_caller_workspace_full_and_short(monkeypatch):
+    """`wqaa_matmul_opts`: a caller workspace of `wqaa_workspace_bytes` holds the slices' partial sums; one too short for them makes the
+    call run the member the form stands in for (a one-launch form here: the same bits) instead of failing"""
+    import torch
+    monkeypatch.setenv("WQAA_GEMM_DECODE_LONG", "3")
+    M, N, K = 8, 2048, 8192
+    case = make_case(M, N, K, W_dtype="uint4", group_size=128, with_scaling=True, with_zeros=True, zeros_mode="original", scale_mul=0.02, seed=31)
+    ref, mm = hip_output(case)
+    assert mm.plans[M]["name"].endswith("xdlk")
+    need = mm.lib.workspace_bytes(M)
+    assert need >= (N // 16) * 8 * 1024
+    dev = "cuda"
+    A = torch.from_numpy(case["A"]).to(dev)
+    qw = mm.transform_weight(torch.from_numpy(case["codes"])).to(dev)
+    sc = torch.from_numpy(case["scale"]).to(dev)
+    zr = torch.from_numpy(case["zeros"]).to(dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    for nbytes in (need, 4096):
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        out = torch.zeros((M, N), dtype=torch.float16, device=dev)
+        mm.lib.run_ws(A.data_ptr(), qw.data_ptr(), None, sc.data_ptr(), zr.data_ptr(), None, out.data_ptr(), M, stream, ws.data_ptr(), nbytes)
+        torch.cuda.synchronize()
+        assert np.array_equal(_bits(out.cpu().numpy()), _bits(ref)), nbytes
