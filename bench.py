@@ -995,6 +995,8 @@ def main():
             member("gemm_uint4_m8_n4096k11008", time_member_gemm, device, gen, 8, 4096, 11008)
             member("gemm_uint4_m8_n8192k28672", time_member_gemm, device, gen, 8, 8192, 28672)
             member("gemm_uint4_m16_n8192k28672", time_member_gemm, device, gen, 16, 8192, 28672)
+            # a vocabulary projection at a decode batch: wider than the persistent form reaches - a wave per fragment (`...xdlw`, round 5)
+            member("gemm_uint4_m8_n32000k4096", time_member_gemm, device, gen, 8, 32000, 4096)
             member("gemm_int2_int8_m4096", time_member_gemm, device, gen, 4096, W_dtype="int2", A_dtype="int8")
             member("gemm_int2_int8_m4096_bitnet", time_member_gemm, device, gen, 4096, W_dtype="int2", A_dtype="int8", bitnet=True)
             # the reference's plain matmul (float16 x float16, README.md support matrix): this library's dense member on the ping-pong

@@ -422,8 +422,8 @@ static int gemm_choose(const wqaa_matmul_desc& d, int m, GemmChoice* c, bool fus
   // fragments' weights in flight; the grid is capped at one workgroup per CU.  Partial rounds no longer cost a round:
   // 11008 x 4096 M = 3 ... 16 13.3-15.1 us (skinny + reduce) -> 11.6-12.6; 8192 9.8-11.3 -> 8.6-9.7; 5120 9.2-10.6 -> 8.2-9.2
   // (profiles/r04_ab_decode_persistent.txt).  WQAA_GEMM_DECODE_PERSIST=0: off.
-  bool persist = false, ksl_ok = false, ksl_take = false;
-  int ksl_lds = 0;
+  bool persist = false, ksl_ok = false, ksl_take = false, wpf_take = false;
+  int ksl_lds = 0, wpf_lds = 0;
   {
     const char* pf = getenv("WQAA_GEMM_DECODE_PERSIST");
     // (float types, up to three rounds of fragments: 22016 x 4096 - 5.4 per workgroup - and int2 x int8 measured no better
@@ -442,7 +442,8 @@ static int gemm_choose(const wqaa_matmul_desc& d, int m, GemmChoice* c, bool fus
     // 18.0, 8192^2 15.0 / 16.2 -> 12.7 / 13.4, 10240 x 8192 20.2 / 21.2 -> 17.4 / 17.8); with one fragment each (N <= 4096) asking for
     // everything at once measured the same as block by block - 4096 x 11008 M = 4 10.8 vs 11.0 us - and the old form stays
     // (profiles/r04_ab_decode_long.txt).
-    const int lmode = lf ? atoi(lf) : 1;               // 0: neither long-K form; 1: the measured rules; 2: whole tile only; 3: K-sliced wherever it fits
+    const int lmode = lf ? atoi(lf) : 1;               // 0: none of round 4 / 5's forms; 1: the measured rules; 2: whole tile only (round 4's selector); 3: K-sliced
+                                                       // wherever it fits; 4: a wave per fragment wherever it fits
     if (counted && nbk >= 2 && nbk <= 3 && run * nq <= 16 && frags > cus_ && frags <= (6 / nbk) * pgrid && lmode != 0) {
       c->decode_long = 1;
       persist = true;
@@ -465,6 +466,23 @@ static int gemm_choose(const wqaa_matmul_desc& d, int m, GemmChoice* c, bool fus
     // ~3 of the one-launch forms, and only its slope is better (3.8 vs 3.4 TB/s and no second round of A).
     ksl_take = ksl_ok && (lmode == 3 || (frags >= 2 * cus_ && ((m >= 13 && d.K >= 8192) || (m >= 5 && d.K >= 24576))));
     if (ksl_take) {
+      c->decode_long = 0;
+      persist = true;
+    }
+    // round 5 - A WAVE PER FRAGMENT, the whole of K (member 213, plan `xdlw`): the same walk with one slice.  The workgroup's waves share
+    // the activation tile (nsteps x nq KiB: K <= 4096 at M <= 16, K <= 8192 at M <= 8) and each adds ALL of K for its own fragments in one
+    // accumulator and stores them - no meeting, no barrier behind the tile's, no partial sums (other summation order than the forms whose
+    // eight waves split K: other bits, same contract).  (lab switch WQAA_GEMM_DECODE_LONG=4: wherever it fits)
+    wpf_lds = ((nsteps + 3) & ~3) * nq * 1024 + 4096;
+    // WHERE (tools/r05_ab_wpf.py, profiles/r05_ab_wpf.txt; uint4 g128 + zeros, us): outputs wider than the persistent / whole-tile forms
+    // reach, which went to the split-K skinny member + reduce - 32000 x 4096 (a vocabulary projection) M = 4 / 8 / 16 21.3 / 21.4 / 22.6 vs
+    // 25.2 / 26.7 / 31.2, 28672 x 4096 20.5 / 20.5 / 21.4 vs 23.4 / 24.7 / 28.2, 16384 x 8192 M = 4 / 8 25.0 / 25.5 vs 27.4 / 28.6.  Its fixed
+    // cost (every workgroup stages the whole tile behind one barrier: 12.7 us at 4096^2) keeps it BEHIND wherever those forms exist:
+    // 22016 x 4096 19.3 vs 17.3, 11008 x 4096 14.2 vs 9.7, 8192^2 22.5 vs 12.5.
+    const bool wpf_ok = !ksl_take && counted && !(c->flags & FL_BF16) && wpf_lds <= 160 * 1024 && frags >= 8 && (long)m * d.K * 2 < (1L << 32) &&
+                        pick_gemm(c->kind, c->layout, c->at, c->mode, c->flags, 213) != nullptr && lmode != 0 && lmode != 2 && lmode != 3;
+    wpf_take = wpf_ok && (lmode == 4 || (!decode_fits && !persist && !c->decode_long && frags > 3 * cus_));
+    if (wpf_take) {
       c->decode_long = 0;
       persist = true;
     }
@@ -503,6 +521,14 @@ static int gemm_choose(const wqaa_matmul_desc& d, int m, GemmChoice* c, bool fus
         c->decode_kslice = 1;
         c->decode_grid = 8 * groups;
         c->lds = ksl_lds;
+      }
+      if (lds_member && wpf_take) {
+        c->fn = pick_gemm(c->kind, c->layout, c->at, c->mode, c->flags, 213);
+        int groups = frags < cus_ ? frags : cus_;                      // (fragment = wave x groups + group: every CU gets its share)
+        if (groups >= 8) groups = groups / 8 * 8;                     // whole XCD rounds keep the block swizzle on
+        c->decode_kslice = 2;
+        c->decode_grid = groups;
+        c->lds = wpf_lds;
       }
       if (lds_member || fits_one_each) return WQAA_OK;
       c->fn = nullptr;                       // (persistent asked for, but this format has only the direct-load member)
@@ -569,7 +595,7 @@ int gemm_plan(const wqaa_matmul_desc& d, int m, wqaa_plan* plan, bool fused_epil
     plan->rows_per_wave = 32;
     plan->batch_tile = 16 * c.mf;
     plan->pipeline_depth = 2;
-    plan->split_k = (c.mid || c.decode_kslice) ? kMidSlices : c.ksplit;
+    plan->split_k = (c.mid || c.decode_kslice == 1) ? kMidSlices : c.ksplit;
     plan->lds_bytes = c.lds;
     plan->grid = c.tiles_m * c.tiles_n * (c.mid ? kMidSlices : c.ksplit) + (c.tail_fn ? c.tail_tiles_m * c.tail_tiles_n : 0);
     if (c.decode_grid > 0) plan->grid = c.decode_grid;
@@ -578,21 +604,21 @@ int gemm_plan(const wqaa_matmul_desc& d, int m, wqaa_plan* plan, bool fused_epil
     char tail[16] = "";
     if (c.tail_fn) snprintf(tail, sizeof(tail), "t%d", c.tail_tiles_n);      // "ppt11": the last 11 N-tiles as a launch of the 128-row tile
     snprintf(plan->name, sizeof(plan->name), "matmul_m%dn%dk%d_%sx%s_tcx%dx%dx%d%s%s%s", m, d.N, d.K, short_dtype(d.a_dtype),
-             wd, 16 * c.mf, c.bn, c.ks, c.ksplit > 1 ? "xr" : "", c.mid ? "xmk" : c.pp ? "pp" : c.skinny ? "xs" : c.decode == 2 ? (c.decode_kslice ? "xdlk" : c.decode_long ? "xdlt" : c.decode_grid > 0 ? "xdlp" : "xdl") : c.decode ? "xd" : c.wide ? "xw" : "", tail);
+             wd, 16 * c.mf, c.bn, c.ks, c.ksplit > 1 ? "xr" : "", c.mid ? "xmk" : c.pp ? "pp" : c.skinny ? "xs" : c.decode == 2 ? (c.decode_kslice == 2 ? "xdlw" : c.decode_kslice ? "xdlk" : c.decode_long ? "xdlt" : c.decode_grid > 0 ? "xdlp" : "xdl") : c.decode ? "xd" : c.wide ? "xw" : "", tail);
   }
   return WQAA_OK;
 }
 
 // (the mid-M member's exchange buffer: tiles x 8 portions x 8 slices x mf KiB)
 static size_t mid_ws_bytes(const GemmChoice& c) {
-  if (c.decode_kslice) return (size_t)c.tiles_n * kMidSlices * 1024;       // (the K-sliced decode form: fragments x 8 slices x 1 KiB)
+  if (c.decode_kslice == 1) return (size_t)c.tiles_n * kMidSlices * 1024;       // (the K-sliced decode form: fragments x 8 slices x 1 KiB)
   return (size_t)c.tiles_m * c.tiles_n * 8 * kMidSlices * c.mf * 1024;
 }
 
 size_t gemm_workspace_bytes(const wqaa_matmul_desc& d, int m) {
   GemmChoice c;
   if (gemm_choose(d, m, &c) != WQAA_OK) return 0;
-  if (c.mid || c.decode_kslice) {
+  if (c.mid || c.decode_kslice == 1) {
     // ... or, should its sync words be unavailable at launch time (first use of a device inside a stream capture), the member it
     // stands in for: the larger of the two needs
     GemmChoice f;
@@ -651,7 +677,7 @@ int gemm_launch(const wqaa_matmul_desc& d, const void* A, const void* B, const v
   void* mid_ws = nullptr;
   unsigned* mid_sync = nullptr;
   bool mid_in_launch = false;
-  if ((c.mid || c.decode_kslice) && !epi) {
+  if ((c.mid || c.decode_kslice == 1) && !epi) {
     const size_t need = mid_ws_bytes(c);
     if (opts && opts->workspace) {
       if (opts->workspace_bytes >= need && (reinterpret_cast<uintptr_t>(opts->workspace) & 15) == 0) mid_ws = opts->workspace;
@@ -745,7 +771,7 @@ int gemm_launch(const wqaa_matmul_desc& d, const void* A, const void* B, const v
       if (!a.ws) return WQAA_ERR_LAUNCH;
     }
   }
-  if (c.decode_kslice) a.ws = mid_ws;
+  if (c.decode_kslice == 1) a.ws = mid_ws;
   if (c.mid) {
     a.ws = mid_ws;
     a.mid_sync = mid_sync;
@@ -767,7 +793,7 @@ int gemm_launch(const wqaa_matmul_desc& d, const void* A, const void* B, const v
   hipError_t e;
   if (start || stop) {
     e = hipExtLaunchKernel(reinterpret_cast<const void*>(c.fn), grid, block, params, c.lds, stream, start,
-                           (c.ksplit > 1 || c.tail_fn || (c.mid && !mid_in_launch) || c.decode_kslice) ? nullptr : stop, 0);
+                           (c.ksplit > 1 || c.tail_fn || (c.mid && !mid_in_launch) || c.decode_kslice == 1) ? nullptr : stop, 0);
   } else {
     e = hipLaunchKernel(reinterpret_cast<const void*>(c.fn), grid, block, params, c.lds, stream);
   }
@@ -792,7 +818,7 @@ int gemm_launch(const wqaa_matmul_desc& d, const void* A, const void* B, const v
     if (start || stop) e = hipExtLaunchKernel(rfn, rgrid, rblock, rparams, 0, stream, nullptr, stop, 0);
     else e = hipLaunchKernel(rfn, rgrid, rblock, rparams, 0, stream);
   }
-  if (e == hipSuccess && c.decode_kslice) {
+  if (e == hipSuccess && c.decode_kslice == 1) {
     // unit = fragment: (tile, portion) = (fragment / 8, fragment % 8) of a one-row map of 128-column tiles
     GemmArgs r = a;
     r.tiles_m = 1;
@@ -1006,7 +1032,7 @@ void gemm_init() {
       for (int at = 0; at < 4; ++at)
         for (int mode = 0; mode <= MD_ZQ; ++mode)
           for (int flags : {0, (int)FL_STRICT, (int)FL_ABF8, (int)FL_BF16})
-            for (int mf : {1, 2, 4, 8, 16, 101, 102, 104, 201, 211, 212, 404}) {
+            for (int mf : {1, 2, 4, 8, 16, 101, 102, 104, 201, 211, 212, 213, 404}) {
               gemm_fn fn = pick_gemm(kind, layout, at, mode, flags, mf);
               if (fn) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             }

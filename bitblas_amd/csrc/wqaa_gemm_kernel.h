@@ -1216,7 +1216,9 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_decode_kernel(const GemmAr
 // and hand-kept per-k-step vmcnt waits were tried and measured no better (the wave is through its DMA queue only
 // when everything else has long arrived).
 // ------------------------------------------------------------------------------------------
-template <class P, bool KSL = false>      // KSL: the K-sliced form alone (its own instantiation: member 212) - every other form is compiled out of it
+template <class P, int KSL = 0>      // KSL = 1: the K-sliced form alone (its own instantiation: member 212) - every other form is compiled out of it;
+                                     // KSL = 2: the same walk with ONE slice - the whole of K - per workgroup (member 213): a wave owns whole
+                                     // fragments, adds all of K in one accumulator and stores the output itself: no meeting, no partial sums
 __global__ void __launch_bounds__(P::THREADS) wq_gemm_decode_lds_kernel(const GemmArgs a) {
   using T = typename P::T;
   constexpr int NJ = P::NJ, WL = P::WL, MODE = P::MODE, NW = P::NWAVES;
@@ -1399,19 +1401,22 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_decode_lds_kernel(const Ge
   // wave w takes a contiguous run of k-steps, a multiple of 4 long (blocks line up with the 8-byte metadata loads)
   const int nsteps = a.nsteps;
   const int last = nsteps - 1;
-  const int run = (((nsteps + NW - 1) / NW) + 3) & ~3;
+  const int run = KSL == 2 ? ((nsteps + 3) & ~3) : ((((nsteps + NW - 1) / NW) + 3) & ~3);
   // (K-sliced form: the eighth of K is the WORKGROUP's - block % 8, one slice per XCD - and every wave of it walks that range)
   // K-sliced form, workgroup -> (slice, group): a band of ROWS per XCD - the eight slices of a group run on the group's XCD (block = xcd +
   // 8 (slice + 8 (group / 8)), group = xcd + 8 (group / 8)) - where the groups come in eights; else slice = block % 8.  (One SLICE per
   // XCD measured 3-10 % slower - at K = 8192, where an XCD would read 512 B of every 4 KiB row, two of its sixteen L2 channels:
   // profiles/r05_ab_kslice.txt)
   int ksl_slice = (int)blockIdx.x & 7, ksl_grp = (int)blockIdx.x >> 3;
-  if (KSL && (gridDim.x & 63) == 0) {
+  if (KSL == 2) {
+    ksl_slice = 0;
+    ksl_grp = blk;                                  // (the XCD swizzle above: a band of row groups per XCD)
+  } else if (KSL == 1 && (gridDim.x & 63) == 0) {
     const int j = (int)blockIdx.x >> 3;
     ksl_slice = j & 7;
     ksl_grp = ((int)blockIdx.x & 7) + 8 * (j >> 3);
   }
-  const int t_lo = (KSL ? ksl_slice : wave) * run;
+  const int t_lo = (KSL != 0 ? ksl_slice : wave) * run;
   const int my_steps = t_lo >= nsteps ? 0 : (nsteps - t_lo < run ? nsteps - t_lo : run);   // wave-uniform
   acc_t* red = reinterpret_cast<acc_t*>(smem_raw + NW * REGION);
   // ---- the hand-counted forms: 4-bit weights with one Scale / Zeros group per k-step (the headline formats) --------------------------
@@ -1429,7 +1434,7 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_decode_lds_kernel(const Ge
     // (8-byte metadata loads as instructions need 4-byte alignment only: K / g even.  Where K / g is not a multiple of 4 the last
     // block's load is moved back to end inside the row and the halves are taken `sh` groups further on)
     const bool wide_c = a.gq_shift == 2 && (a.kg & 1) == 0;
-    if (KSL || (wide_c && (persistent || a.decode_long))) {      // (KSL: the launcher checked the metadata's alignment)
+    if (KSL != 0 || (wide_c && (persistent || a.decode_long))) {      // (KSL: the launcher checked the metadata's alignment)
       constexpr bool ZP = MODE == MD_ZO || MODE == MD_ZR;
       constexpr int NOPS = PF + 1 + (ZP ? 1 : 0);        // loads per unit and lane
       struct AF {
@@ -1516,7 +1521,7 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_decode_lds_kernel(const Ge
       AF f0, f1, f2;
       const acc_t zero = acc_t{0, 0, 0, 0};
       acc_t p0 = zero, p1 = zero, p2 = zero;
-      if constexpr (KSL) {
+      if constexpr (KSL != 0) {
         static_assert(F16 && !P::BF, "the K-sliced form: float16 activations");
         {
           // K-SLICED (round 5, long K): the forms above make every workgroup read ALL of A - at K = 28672 twice its weights' bytes, and a CU
@@ -1546,8 +1551,9 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_decode_lds_kernel(const Ge
                              : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
               }
           }
-          const int wps = ((int)gridDim.x >> 3) * NW;            // waves per slice
-          const int first = grp * NW + wave;
+          const int wps = (KSL == 2 ? (int)gridDim.x : ((int)gridDim.x >> 3)) * NW;            // waves per slice
+          // (whole-K form: fragment = wave x groups + group - with fewer fragments than waves every CU still gets its share of them)
+          const int first = KSL == 2 ? wave * (int)gridDim.x + grp : grp * NW + wave;
           const int nfr = first < nfrags ? (nfrags - 1 - first) / wps + 1 : 0;
           const int U = nfr * nbk;
           int qf = first, qj = 0;                                // the unit asked for next
@@ -1578,7 +1584,12 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_decode_lds_kernel(const Ge
               if (cj == 0) acc = zero;
               multiply_blk(f, cj, slot_bytes);
               if (++cj == nbk) {
-                wsq[((long)cf * 8 + slice) * 64 + lane] = acc;
+                if constexpr (KSL == 2) {
+                  const int nb = cf * 16 + kb * 4;                 // the whole sum: this wave stores the fragment's outputs
+                  if (nb < a.N && fr < a.M) store_quad<P>(a, acc, fr, nb);
+                } else {
+                  wsq[((long)cf * 8 + slice) * 64 + lane] = acc;
+                }
                 cj = 0;
                 cf += wps;
               }
@@ -2038,7 +2049,12 @@ static gemm_fn pick_mf(int mf) {
     // 212: the K-sliced form of 211 (long K; 4-bit weights x float16, Scale (+ Zeros) per 128: the hand-counted formats)
     case 212:
       if constexpr (AT == AT_F16 && (FLAGS & FL_BF16) == 0 && (KIND == DK_INT4 || KIND == DK_LUT4) && (MODE == MD_S || MODE == MD_ZO || MODE == MD_ZR))
-        return wq_gemm_decode_lds_kernel<GemmPolicy<KIND, LAYOUT, AT, MODE, FLAGS, 1, 8, 1>, true>;
+        return wq_gemm_decode_lds_kernel<GemmPolicy<KIND, LAYOUT, AT, MODE, FLAGS, 1, 8, 1>, 1>;
+      else return nullptr;
+    // 213: a wave per fragment, the whole of K (wide outputs at K <= 4096 ... where the activation tile fits LDS)
+    case 213:
+      if constexpr (AT == AT_F16 && (FLAGS & FL_BF16) == 0 && (KIND == DK_INT4 || KIND == DK_LUT4) && (MODE == MD_S || MODE == MD_ZO || MODE == MD_ZR))
+        return wq_gemm_decode_lds_kernel<GemmPolicy<KIND, LAYOUT, AT, MODE, FLAGS, 1, 8, 1>, 2>;
       else return nullptr;
     // 900: not a GEMM - B_decode to memory (two-pass member, wqaa_dequantize); launched with (GemmArgs, void* out)
     case 900:

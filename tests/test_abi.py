@@ -179,7 +179,7 @@ def test_selector_invariants_over_a_random_configuration_sweep():
     kernel-name style (general_matmul/__init__.py:240-318) - and a refusal must carry a message."""
     import re
     rng = np.random.default_rng(7)
-    name_re = re.compile(r"^matmul_m\d+n\d+k\d+_[a-z0-9]+x[a-z0-9_]+_(gemv_b\d+r\d+d\d+(k\d+)?(_areg)?|gemvx_b\d+r\d+d\d+k\d+(_areg)?|(dq_)?tcx\d+x\d+x\d+(xr)?(pp(t\d+)?|xs|xdl[ptk]?|xd|xw|xmk)?)$")
+    name_re = re.compile(r"^matmul_m\d+n\d+k\d+_[a-z0-9]+x[a-z0-9_]+_(gemv_b\d+r\d+d\d+(k\d+)?(_areg)?|gemvx_b\d+r\d+d\d+k\d+(_areg)?|(dq_)?tcx\d+x\d+x\d+(xr)?(pp(t\d+)?|xs|xdl[ptkw]?|xd|xw|xmk)?)$")
     pairs = [(wlib.F16, wlib.W_UINT, b) for b in (1, 2, 4, 8)] + [(wlib.F16, wlib.W_INT, b) for b in (1, 2, 4, 8)] + \
             [(wlib.F16, wlib.W_NF, 4), (wlib.F16, wlib.W_FP4, 4), (wlib.F16, wlib.W_E4M3, 8),
              (wlib.BF16, wlib.W_UINT, 4), (wlib.BF16, wlib.W_NF, 4),
@@ -409,7 +409,9 @@ def test_decode_batch_forms_are_chosen_where_they_were_measured(monkeypatch):
                             (8, 8192, 8192, "xdlt"), (5, 8192, 11008, "xdl"), (4, 4096, 11008, "xdl"), (16, 4096, 4096, "xdl"), (4, 8192, 28672, "xdl"),
                             # round 5, the K-sliced form (`xdlk`): two rounds of fragments or more, M >= 13 at K >= 8192, M >= 5 at K >= 24576
                             (9, 8192, 8192, "xdl"), (13, 8192, 8192, "xdlk"), (16, 12288, 8192, "xdlk"), (16, 11008, 8192, "xdlk"), (8, 8192, 28672, "xdlk"), (16, 8192, 28672, "xdlk"),
-                            (16, 4096, 11008, "xdl"), (8, 12288, 8192, "xdlt")):
+                            (16, 4096, 11008, "xdl"), (8, 12288, 8192, "xdlt"),
+                            # round 5, a wave per fragment (`xdlw`): outputs wider than the persistent / whole-tile forms reach, where the tile fits LDS
+                            (8, 32000, 4096, "xdlw"), (16, 28672, 4096, "xdlw"), (3, 128256, 4096, "xdlw"), (8, 16384, 8192, "xdlw"), (8, 24576, 4096, "xdlp")):
         assert name(m, N, K).endswith("_f16xu4_tcx16x16x128" + suffix), (m, N, K, name(m, N, K))
     monkeypatch.setenv("WQAA_GEMM_DECODE_LONG", "0")
     assert not name(8, 8192, 8192).endswith("xdlt") and not name(16, 8192, 28672).endswith("xdlk")
@@ -417,3 +419,7 @@ def test_decode_batch_forms_are_chosen_where_they_were_measured(monkeypatch):
     assert name(8, 8192, 8192).endswith("xdlt") and not name(16, 8192, 28672).endswith("xdlk")
     monkeypatch.setenv("WQAA_GEMM_DECODE_LONG", "3")          # K-sliced wherever the shape fits (the parity tests)
     assert name(8, 4096, 11008).endswith("xdlk") and name(3, 512, 8192).endswith("xdlk")
+    monkeypatch.setenv("WQAA_GEMM_DECODE_LONG", "4")          # a wave per fragment wherever the tile fits
+    assert name(8, 4096, 4096).endswith("xdlw") and name(5, 1000, 8192).endswith("xdlw") and not name(16, 512, 8192).endswith("xdlw")
+    monkeypatch.setenv("WQAA_GEMM_DECODE_LONG", "2")
+    assert not name(8, 32000, 4096).endswith("xdlw")
