@@ -1,5 +1,8 @@
 #!/bin/bash
-o=gpurun_out/r05last; mkdir -p $o
-timeout 1500 python -m pytest tests -q -m gpu -x > $o/gpu_tests.txt 2>&1; tail -3 $o/gpu_tests.txt
-timeout 600 python bench.py > $o/bench_stdout.txt 2> $o/bench.err; tail -1 $o/bench_stdout.txt | cut -c1-400; tail -1 $o/bench_stdout.txt | wc -c
+# the last check of the round on a fresh box: the GPU parity suite with margins and member coverage, bench.py as the driver runs it, smoke()
+bash tools/parity_margins.sh r05last
+o=gpurun_out/r05last
+timeout 900 python bench.py > $o/bench_stdout.txt 2> $o/bench.err
+tail -1 $o/bench_stdout.txt > $o/bench.json; wc -c $o/bench.json
+cp gpurun_out/bench_members.json $o/bench_members.json
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
