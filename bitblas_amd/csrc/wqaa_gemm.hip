@@ -481,7 +481,9 @@ static int gemm_choose(const wqaa_matmul_desc& d, int m, GemmChoice* c, bool fus
     // 22016 x 4096 19.3 vs 17.3, 11008 x 4096 14.2 vs 9.7, 8192^2 22.5 vs 12.5.
     const bool wpf_ok = !ksl_take && counted && !(c->flags & FL_BF16) && wpf_lds <= 160 * 1024 && frags >= 8 && (long)m * d.K * 2 < (1L << 32) &&
                         pick_gemm(c->kind, c->layout, c->at, c->mode, c->flags, 213) != nullptr && lmode != 0 && lmode != 2 && lmode != 3;
-    wpf_take = wpf_ok && (lmode == 4 || (!decode_fits && !persist && !c->decode_long && frags > 3 * cus_));
+    // (not where the A/B aids of the older forms are in use: WQAA_GEMM_DECODE_PERSIST=0 / WQAA_GEMM_DECODE_FORCE ask for THOSE members)
+    const bool older_forced = (pf && atoi(pf) == 0) || getenv("WQAA_GEMM_DECODE_FORCE") != nullptr;
+    wpf_take = wpf_ok && (lmode == 4 || (!older_forced && !decode_fits && !persist && !c->decode_long && frags > 3 * cus_));
     if (wpf_take) {
       c->decode_long = 0;
       persist = true;
