@@ -96,6 +96,10 @@ def make_linear(N, K, device, gen):
     return op, qweight, scale, out
 
 
+# which members the headline is timed on: the library's default at M <= 2, as a caller of the reference
+# constructs the operator; the contract is include/wqaa.h's (at `strict_reference`), tests/helpers.py: contract
+NUMERICS = "default members (strict_reference=0): exact products, 1e-3 rel + 2e-3 rms vs the TE definition; *_strict members: per-element rounding, 1e-3 + 1e-3"
+
 GRAPH_WARM_MS = float(os.environ.get("WQAA_BENCH_WARM_MS", "25"))
 
 
@@ -331,69 +335,34 @@ def time_step_chained(device, gen, n_layers=4):
             "roofline": {"bound": "hbm", "achieved": res["fused"]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": res["fused"]["frac"]}}
 
 
-def time_chain_tail(device, gen, n_layers=6, reps=5):
-    """the post-attention half of a decoder layer - o_proj (+ x) -> RMSNorm -> gate / up * silu -> down_proj
-    (+ h) - as ONE persistent run-ahead launch (`wqaa_matmul_chain`, csrc/wqaa_chain_kernel.h) against the three launches it
-    stands for (`forward_ex`, `matmul_gate_up`, `forward_ex`): one hipGraph replay over `n_layers` tails with distinct weights
-    each, every stage's output compared bit for bit.  The launches are what the headline step and `step_chained` use (the
-    chain loses: DESIGN.md section 3.3c)."""
-    from bitblas_amd.chain import ChainStep, chain_plan, matmul_chain
-    H, I = 4096, 11008
-    o_op, g_op, d_op = get_op(1, H, H), get_op(1, I, H), get_op(1, H, I)
+LLAMA_70B_LINEARS = [(8192, 8192), (28672, 8192), (8192, 28672), (10240, 8192)]   # o, gate / up, down, q+k+v (64 q + 8 + 8 kv heads)
 
-    def lin(op):
-        return (torch.randint(-128, 128, (op.N, op.K // 2), dtype=torch.int8, device=device, generator=gen),
-                (torch.rand((op.N, op.K // GROUP), device=device, generator=gen) * 0.02 * 0.04).to(torch.float16))
 
-    layers = [dict(o=lin(o_op), g=lin(g_op), u=lin(g_op), d=lin(d_op),
-                   nw=(1.0 + (torch.rand(H, device=device, generator=gen) - 0.5) * 0.2).to(torch.float16)) for _ in range(n_layers)]
-    attn = (torch.rand((1, H), device=device, generator=gen) - 0.5).to(torch.float16)
-    x0 = (torch.rand((1, H), device=device, generator=gen) - 0.5).to(torch.float16)
-    eps = 1e-5
-    mk = lambda n: [torch.empty((1, n), dtype=torch.float16, device=device) for _ in range(n_layers)]   # noqa: E731
-    hs, acts, outs, chs, cas, cos = mk(H), mk(I), mk(H), mk(H), mk(I), mk(H)
+def time_member_group(device, gen, Ns, K, n_sets=None):
+    """Projections that share an input as ONE launch (wqaa_matmul_group) at a 70B layer's widths: q/k/v under grouped-query
+    attention (8192 + 1024 + 1024 rows) and gate/up (2 x 28672), every member with its own packed tensors and output."""
+    ops = [get_op(1, N, K) for N in Ns]
+    wbytes = sum(N * K // 2 for N in Ns)
+    n_sets = n_sets or max(3, min(32, (640 << 20) // wbytes))
+    sets = []
+    for _ in range(n_sets):
+        sets.append([(torch.randint(-128, 128, (N, K // 2), dtype=torch.int8, device=device, generator=gen),
+                      (torch.rand((N, K // GROUP), device=device, generator=gen) * 0.02).to(torch.float16)) for N in Ns])
+    outs = [torch.empty((1, N), dtype=torch.float16, device=device) for N in Ns]
+    A = (torch.rand((1, K), device=device, generator=gen) - 0.5).to(torch.float16)
 
-    def run_launches():
-        x = x0
-        for L, h, a, o in zip(layers, hs, acts, outs):
-            o_op.forward_ex(attn, L["o"][0], scale=L["o"][1], residual=x, output=h)
-            bitblas.matmul_gate_up(g_op, g_op, h, L["g"], L["u"], output=a, norm=(L["nw"], eps))
-            d_op.forward_ex(a, L["d"][0], scale=L["d"][1], residual=h, output=o)
-            x = o
+    def launch_all():
+        for ws in sets:
+            bitblas.matmul_group(ops, A, ws, outputs=outs)
 
-    def steps_of(L, x, h, a, o):
-        return [ChainStep(o_op, L["o"], attn, residual=x, output=h),
-                ChainStep(g_op, L["g"], 0, norm=(L["nw"], eps), up_op=g_op, up_weights=L["u"], output=a),
-                ChainStep(d_op, L["d"], 1, residual=0, output=o)]
-
-    def run_chain():
-        x = x0
-        for i, L in enumerate(layers):
-            matmul_chain(steps_of(L, x, chs[i], cas[i], cos[i]))
-            x = cos[i]
-
-    # (round 5: the persistent member is opt-in - `matmul_chain` runs the launches by default, which is what this member shows to
-    # be faster; the "chain" arm opts in, and the plan bumps the library's plan epoch so the launch path re-reads the switch)
-    os.environ["WQAA_CHAIN_FUSE"] = "1"
-    plan = chain_plan(steps_of(layers[0], x0, chs[0], cas[0], cos[0]))
-    run_launches()
-    run_chain()
-    torch.cuda.synchronize(device)
-    same = [bool(torch.equal(a, b)) for a, b in zip(hs + acts + outs, chs + cas + cos)]
-    tail_bytes = sum(algorithmic_bytes(1, N, K) for (N, K) in ((H, H), (I, H), (I, H), (H, I))) - I * 2 * 2 + I * 2 + 2 * H * 2
-    res = {}
-    for name, fn in (("launches", run_launches), ("chain", run_chain)):
-        t = min(graph_time(device, fn, n_layers) for _ in range(reps))
-        res[name] = {"us_per_tail": t * 1e6, "launches_per_tail": 3 if name == "launches" else (plan.get("launches") or 1),
-                     "GBps": tail_bytes / t / 1e9, "frac": tail_bytes / t / 1e9 / HBM_PEAK_GBS}
-    os.environ.pop("WQAA_CHAIN_FUSE", None)
-    chain_plan(steps_of(layers[0], x0, chs[0], cas[0], cos[0]))          # (epoch bump: back to the default)
-    return {"workload": f"W_int4 A_fp16 M=1: o_proj(+x) -> RMSNorm -> gate/up*silu -> down_proj(+h) of a Llama-2-7B layer, {n_layers} tails "
-                        "with distinct weights per hipGraph replay",
-            "chain_plan": (plan.get("plan") or {}).get("name"), "chain_fused": plan.get("launches") == 1, "chain_reason": plan.get("reason"),
-            "bytes_per_tail": tail_bytes, **res, "bit_identical_stages": f"{sum(same)}/{len(same)}", "bit_identical": all(same),
-            "chain_over_launches": res["chain"]["us_per_tail"] / res["launches"]["us_per_tail"],
-            "roofline": {"bound": "hbm", "achieved": res["launches"]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": res["launches"]["frac"]}}
+    t = graph_time(device, launch_all, n_sets)
+    nbytes = sum(algorithmic_bytes(1, N, K) for N in Ns) - (len(Ns) - 1) * K * 2      # the shared input is read once
+    from bitblas_amd import group_plan
+    gp = group_plan(ops, 1)
+    return {"workload": f"W_int4 A_fp16 GEMV M=1, {len(Ns)} projections N={list(Ns)} K={K} g=128 sharing one input",
+            "kernel": (gp["plan"] or {}).get("name"), "launches": gp["launches"],
+            "us_per_launch": t * 1e6, "bytes_per_launch": nbytes, "GBps": nbytes / t / 1e9,
+            "roofline": {"bound": "hbm", "achieved": nbytes / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": nbytes / t / 1e9 / HBM_PEAK_GBS}}
 
 
 def time_member_f16_gemv(device, gen, N, K, int4_us=None):
@@ -925,6 +894,7 @@ def main():
                                       " in 4 launches per layer ({q,k,v}, o, {gate,up}, down: wqaa_matmul_group runs the projections "
                                       "that share an input as one launch, each with its own packed tensors and output), ")
                                    + f"{'one hipGraph replay per step' if graph is not None else 'eager launches'}",
+                       "numerics": NUMERICS,
                        "launches": {k: v for k, v in group_names},
                        "launches_per_step": launches_per_step, "bytes_per_step_per_gpu": step_bytes,
                        "sharding": (f"column (N) shard per rank + 1 RCCL all-gather per step ({gather_mode}: " +
@@ -973,6 +943,17 @@ def main():
             for (N, K) in ((4096, 4096), (11008, 4096), (4096, 11008), (12288, 4096)):     # c2 shapes
                 member(f"gemv_int4_n{N}k{K}", time_member_gemv, device, gen, N, K)
                 member(f"gemv_int4_n{N}k{K}_strict", time_member_gemv, device, gen, N, K, strict=True)
+            # what BASELINE.json's `metric` is quoted on - W_int4 A_fp16 at M = 1 and M = 4096 on the Llama-70B linears (the
+            # reference's benchmark table, benchmark/README.md:60-62 V10-V12 and :73-75 M10-M12) - plus the q/k/v width of
+            # grouped-query attention and the group launches of a 70B layer
+            for (N, K) in LLAMA_70B_LINEARS:
+                member(f"gemv_int4_n{N}k{K}", time_member_gemv, device, gen, N, K)
+            for (N, K) in LLAMA_70B_LINEARS[1:3]:
+                member(f"gemv_int4_n{N}k{K}_strict", time_member_gemv, device, gen, N, K, strict=True)
+            member("group_int4_70b_qkv", time_member_group, device, gen, (8192, 1024, 1024), 8192)
+            member("group_int4_70b_gate_up", time_member_group, device, gen, (28672, 28672), 8192)
+            for (N, K) in LLAMA_70B_LINEARS[:3]:
+                member(f"gemm_uint4_m4096_n{N}k{K}", time_member_gemm, device, gen, 4096, N, K, n_buf=2)
             for (N, K) in ((4096, 4096), (11008, 4096)):        # the reference's own yardstick: speed-up over the float16 GEMV
                 member(f"gemv_f16_yardstick_n{N}k{K}", time_member_f16_gemv, device, gen, N, K,
                        int4_us=(members.get(f"gemv_int4_n{N}k{K}") or {}).get("us_per_launch"))
@@ -1006,7 +987,6 @@ def main():
             member("gemm_int8_dense_m4096", time_member_dense, device, gen, 4096, 4096, 4096, kind="int8", n_buf=4)
             member("gemv_int2_int8_m1", time_member_dense, device, gen, 1, 4096, 4096, kind="int2", n_buf=64)
             member("step_chained", time_step_chained, device, gen)
-            member("chain_tail", time_chain_tail, device, gen)
             member("step_int2_int8", time_step_int2_int8, device, gen)
             member("step_int2_int8_ungrouped", time_step_int2_int8, device, gen, grouped=False)
             # c5: dense e4m3 x e4m3 on every Llama-3-70B linear of one (unsharded) GPU, M = 4096 and M = 1
@@ -1057,7 +1037,9 @@ def main():
 
 
 MEMBER_KEYS = ("gemm_uint4_m4096", "gemm_uint4_m128", "gemm_uint4_m16", "gemv_int4_n4096k4096", "gemm_int2_int8_m4096",
-               "gemv_int2_int8_m1")
+               "gemv_int2_int8_m1",
+               # the metric's own shapes (Llama-70B linears, reference benchmark/README.md:60-62, 73-75)
+               "gemv_int4_n8192k28672", "gemv_int4_n28672k8192", "gemm_uint4_m4096_n28672k8192")
 
 
 def brief_member(v):
@@ -1068,9 +1050,6 @@ def brief_member(v):
     if t is None and isinstance(v.get("fused"), dict):
         return {"fused_us": round(v["fused"]["us_per_step"], 1), "composed_us": round(v["composed"]["us_per_step"], 1),
                 "frac": round(v["fused"]["frac"], 3)}
-    if t is None and isinstance(v.get("chain"), dict) and isinstance(v.get("launches"), dict):
-        return {"launches_us_per_tail": round(v["launches"]["us_per_tail"], 2), "chain_us_per_tail": round(v["chain"]["us_per_tail"], 2),
-                "bit_identical": v.get("bit_identical"), "frac": round(v["launches"]["frac"], 3)}
     if t is None and "own_us_per_launch" in v:
         return {"own_f16_us": round(v["own_us_per_launch"], 2), "vendor_f16_us": round(v["vendor_us_per_launch"], 2),
                 "int4_speedup_vs_vendor_f16": round(v.get("int4_speedup_vs_vendor_f16") or 0.0, 2)}
@@ -1104,25 +1083,26 @@ def final_line(result, members=None):
     cpu = result.get("cpu_baseline")
     line = {k: result.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
                                          "scaling", "vs_baseline", "dtype", "data")}
-    line["metric"] = _clip(line["metric"], 120)
+    line["metric"] = _clip(line["metric"], 90)
     for k in ("value", "ms_per_step"):
         if isinstance(line.get(k), float):
             line[k] = round(line[k], 4)
-    line["config"] = {"workload": _clip(cfg.get("workload", ""), 200), "launches_per_step": cfg.get("launches_per_step"),
-                      "bytes_per_step_per_gpu": cfg.get("bytes_per_step_per_gpu"), "sharding": _clip(cfg.get("sharding", "none"), 60)}
+    line["config"] = {"workload": _clip(cfg.get("workload", ""), 120), "numerics": _clip(cfg.get("numerics", NUMERICS), 160),
+                      "launches_per_step": cfg.get("launches_per_step"),
+                      "bytes_per_step_per_gpu": cfg.get("bytes_per_step_per_gpu"), "sharding": _clip(cfg.get("sharding", "none"), 40)}
     line["roofline"] = {"bound": roof.get("bound"), "achieved": None if roof.get("achieved") is None else round(roof["achieved"], 2),
                         "peak": roof.get("peak"), "unit": roof.get("unit"),
                         "frac": None if roof.get("frac") is None else round(roof["frac"], 4), "traffic": roof.get("traffic"),
-                        "kernel": _clip(roof.get("kernel", ""), 120), "bytes_per_launch": roof.get("bytes_per_launch"),
+                        "kernel": _clip(roof.get("kernel", ""), 70), "bytes_per_launch": roof.get("bytes_per_launch"),
                         "mean_launch_us": None if roof.get("mean_launch_us") is None else round(roof["mean_launch_us"], 3)}
     if isinstance(cpu, dict):
         line["cpu_baseline"] = ({"error": _clip(cpu["error"], 120)} if "error" in cpu else
                                 {"value": cpu.get("value"), "unit": cpu.get("unit"), "cores": cpu.get("cores"), "kind": cpu.get("kind"),
-                                 "sample": _clip(cpu.get("sample", ""), 160)})
+                                 "sample": _clip(cpu.get("sample", ""), 100)})
     if members:
         line["members"] = {k: brief_member(members[k]) for k in MEMBER_KEYS
                            if k in members and not (isinstance(members[k], dict) and "error" in members[k])}
-        line["members_file"] = "gpurun_out/bench_members.json (+ the [bench-members] stdout line)"
+        line["members_file"] = "gpurun_out/bench_members.json"
     if isinstance(result.get("multi_gpu_c5"), dict):
         c5 = result["multi_gpu_c5"]
         line["multi_gpu_c5"] = {k: (round(v, 3) if isinstance(v, float) else v) for k, v in c5.items()

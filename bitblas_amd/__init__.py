@@ -21,7 +21,7 @@ from .matmul import (  # noqa: F401
 )
 from .module import Linear  # noqa: F401
 from .group import GatedMLP, LinearGroup, gate_up_plan, group_plan, matmul_gate_up, matmul_group  # noqa: F401  (MI355X extension: one launch for q/k/v, gate/up)
-from .chain import ChainStep, DecoderTail, chain_plan, matmul_chain  # noqa: F401  (MI355X extension: a chain of dependent GEMVs as one persistent launch)
+from .chain import ChainStep, DecoderTail, chain_plan, matmul_chain  # noqa: F401  (a chain of dependent operators described once, run as its launches)
 from .cache import (  # noqa: F401
     OperatorCache, get_database_path, global_operator_cache, load_global_ops_cache,
     set_database_path,

@@ -1,13 +1,11 @@
-"""Chains of DEPENDENT operators in one persistent launch: `matmul_chain`, `DecoderTail`.
+"""Chains of DEPENDENT operators described once: `matmul_chain`, `DecoderTail`.
 
 The reference runs a decoder layer as one operator call per `nn.Linear` with the caller's elementwise kernels between them
-(integration/BitNet/modeling_bitnet.py: `BitnetMLP.forward` :240-244, `BitnetDecoderLayer.forward` :839-860).  At decode row
-counts on MI355X the dependent launch boundaries are a third of the layer; `wqaa_matmul_chain` (include/wqaa.h,
-csrc/wqaa_chain_kernel.h) runs o_proj (+ residual) -> RMSNorm -> gate / up * silu -> down_proj (+ residual) - or any chain of
-exact-product GEMV operators wired output -> input - as ONE launch whose loader waves stream the next operator's weights
-while the consumers wait for this operator's result.  The call is defined as the launches it stands for, in order, and gives
-their bits (tests/test_chain_gpu.py); chains the persistent member does not cover (m > 1, mixed formats, ...) run as those
-launches.
+(integration/BitNet/modeling_bitnet.py: `BitnetMLP.forward` :240-244, `BitnetDecoderLayer.forward` :839-860).
+`wqaa_matmul_chain` (include/wqaa.h) takes o_proj (+ residual) -> RMSNorm -> gate / up * silu -> down_proj (+ residual) - or
+any chain of operators wired output -> input - and runs the launches it stands for, in order, each with the callers'
+elementwise ops folded in (`Matmul.forward_ex`, `matmul_gate_up`).  (Rounds 3-5 also had a persistent one-launch member behind
+the same call; bit-identical, 50 % slower, removed in round 6: docs/DESIGN_r04.md section 3.3c.)
 """
 from __future__ import annotations
 
@@ -44,10 +42,6 @@ def _library():
         lib.wqaa_chain_plan.restype = ctypes.c_int
         lib.wqaa_chain_plan.argtypes = [ctypes.POINTER(ChainItem), ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int),
                                         ctypes.POINTER(_lib.Plan)]
-        lib.wqaa_debug_chain_status.restype = ctypes.c_int
-        lib.wqaa_debug_chain_status.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint32)]
-        lib.wqaa_debug_chain_trace.restype = ctypes.c_int64
-        lib.wqaa_debug_chain_trace.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint64), ctypes.c_int64]
         _bound = True
     return lib
 
@@ -65,7 +59,7 @@ class ChainStep:
     input         a tensor (m, K), or the index of the earlier step whose output it reads
     residual      None, a tensor (m, N), or the index of an earlier step whose output is added (`Matmul.forward_ex(residual=)`)
     norm          None or (weight, eps): RMSNorm in front of the operator (`forward_ex(norm=)`)
-    output        None: allocated and returned; a tensor: written; False: not stored (only later steps read it)"""
+    output        None: allocated and returned; a tensor: written; False: a temporary only later steps read (not returned)"""
     op: Matmul
     weights: Weights
     input: Union[torch.Tensor, int]
@@ -158,9 +152,7 @@ def _build(steps: Sequence[ChainStep], allocate: bool):
     if m is None:
         raise ValueError("a chain starts from a tensor")
     for i, st in enumerate(steps):
-        if st.output is False:
-            items[i].C = None
-        elif isinstance(st.output, torch.Tensor):
+        if isinstance(st.output, torch.Tensor):
             o = st.output
             if not o.is_contiguous() or o.device != dev:
                 raise ValueError(f"step {i}: output must be a contiguous tensor on the chain's device")
@@ -168,26 +160,27 @@ def _build(steps: Sequence[ChainStep], allocate: bool):
             outs[i] = o
             items[i].C = o.data_ptr()
         elif allocate:
+            # (every item is a launch that stores its result: `output=False` gets a temporary the caller never sees)
             o = torch.empty((m, st.op.N), dtype=st.op.torch_output_dtype, device=dev)
-            outs[i] = o
+            if st.output is False:
+                keep.append(o)
+            else:
+                outs[i] = o
             items[i].C = o.data_ptr()
     return items, outs, keep, m, dev
 
 
 def chain_plan(steps: Sequence[ChainStep], m: Optional[int] = None) -> dict:
-    """{"launches": 1 (the persistent member) | n, "plan": {...} | None} for the chain at its row count.  Needs no device
-    (tensors may live anywhere: only their shapes are read)."""
+    """{"launches": n, "plan": None, "reason": ...}: validates the chain at its row count; the chain runs as its n launches.  Needs
+    no device (tensors may live anywhere: only their shapes are read)."""
     items, _, keep, mm, _ = _build(steps, allocate=False)
-    for i, st in enumerate(steps):                      # the plan does not read outputs: any non-NULL stands for "stored"
-        if st.output is not False and not items[i].C:
+    for i in range(len(steps)):                          # the plan does not read outputs: any non-NULL stands for "stored"
+        if not items[i].C:
             items[i].C = 1
     launches = ctypes.c_int(0)
     plan = _lib.Plan()
     _lib.check(_library().wqaa_chain_plan(items, len(steps), int(m if m is not None else mm), ctypes.byref(launches), ctypes.byref(plan)))
-    fused = launches.value == 1 and plan.kernel_family != 0
-    # (where the persistent member refuses, the library's error string says why; the call itself succeeded)
-    return {"launches": launches.value, "plan": plan.as_dict() if fused else None,
-            "reason": None if fused else _library().wqaa_last_error_string().decode(errors="replace")}
+    return {"launches": launches.value, "plan": None, "reason": "a chain runs as the launches it stands for"}
 
 
 def matmul_chain(steps: Sequence[ChainStep]) -> List[Optional[torch.Tensor]]:
@@ -199,26 +192,6 @@ def matmul_chain(steps: Sequence[ChainStep]) -> List[Optional[torch.Tensor]]:
     if status != _lib.OK:
         _lib.check(status)
     return outs
-
-
-def chain_status(device=None) -> dict:
-    """test aid (synchronises the current stream): generation counter and first error code of the stream's fused launches"""
-    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
-    out = (ctypes.c_uint32 * 4)()
-    with torch.cuda.device(dev):
-        _lib.check(_library().wqaa_debug_chain_status(_lib.current_stream_handle(dev), out))
-    code = int(out[1])
-    return {"generation": int(out[0]), "error": code & 0xFF, "stage": (code >> 8) & 0xFF, "wave": (code >> 16) & 0xF, "workgroup": code >> 20}
-
-
-def chain_trace(device=None):
-    """lab aid: the [workgroup][wave (16 slots)][64] s_memrealtime stamps (100 MHz) of the last fused launch planned with WQAA_CHAIN_TRACE=1"""
-    import numpy as np
-    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
-    buf = np.zeros(1024 * 16 * 64, dtype=np.uint64)
-    with torch.cuda.device(dev):
-        n = _library().wqaa_debug_chain_trace(_lib.current_stream_handle(dev), buf.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)), buf.size)
-    return buf[:n].reshape(-1, 16, 64)
 
 
 def _lin_weights(lin):
@@ -236,9 +209,8 @@ class DecoderTail(torch.nn.Module):
         out = h + down_proj(silu(gate_proj(norm(h))) * up_proj(norm(h)))
 
     (integration/BitNet/modeling_bitnet.py:839-860 with the MLP of :240-244).  At decode row counts: three launches with the
-    elementwise ops folded in (`forward_ex`, `matmul_gate_up`) - or, `persistent=True`, ONE launch (`matmul_chain`; same bits,
-    measured SLOWER on MI355X for the int4 layers of BASELINE c2: 38.5 vs 25.9 us, profiles/r04_chain_lab.txt, DESIGN.md
-    section 3.3c - hence not the default); the layers' plain launches with torch's elementwise kernels elsewhere.  The layers keep
+    elementwise ops folded in (`forward_ex`, `matmul_gate_up`); the layers' plain launches with torch's elementwise kernels
+    elsewhere.  `persistent` is accepted for callers of rounds 3-5 and ignored (the one-launch member is gone).  The layers keep
     their own buffers and state_dict keys."""
 
     def __init__(self, o_proj, gate_proj, up_proj, down_proj, norm_weight: torch.Tensor, eps: float = 1e-6, persistent: bool = False):
@@ -264,8 +236,6 @@ class DecoderTail(torch.nn.Module):
         if m >= 1 and all(op.fused_ops_supported(m) for op in ops):
             a2 = attn.reshape(m, attn.shape[-1])
             x2 = x.reshape(m, x.shape[-1]).contiguous()
-            if self.persistent:
-                return matmul_chain(self.steps(a2, x2))[2].reshape(x.shape)
             h = self.o_proj.forward_ex(a2, residual=x2)
             act = matmul_gate_up(ops[1], ops[2], h, _lin_weights(self.gate_proj), _lin_weights(self.up_proj), norm=(self.norm_weight, self.eps))
             return self.down_proj.forward_ex(act, residual=h).reshape(x.shape)

@@ -68,7 +68,6 @@ static void ensure_device(int dev) {
       di.ok = 1;
       gemv_init();
       gemm_init();
-      chain_init();
     } else {
       (void)hipGetLastError();
     }
@@ -612,19 +611,6 @@ int wqaa_matmul_chain(const wqaa_chain_item* items, int count, int m, void* stre
 
 int wqaa_chain_plan(const wqaa_chain_item* items, int count, int m, int* launches, wqaa_plan* plan) {
   return chain_plan(items, count, m <= 0 ? 1 : m, launches, plan);
-}
-
-int wqaa_debug_chain_status(void* stream, uint32_t* out4) {
-  if (!out4) return WQAA_ERR_BAD_DESC;
-  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  StreamDeviceScope scope(s);
-  return chain_status(s, out4);
-}
-
-int64_t wqaa_debug_chain_trace(void* stream, uint64_t* out, int64_t max_words) {
-  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  StreamDeviceScope scope(s);
-  return chain_trace(s, out, max_words);
 }
 
 int wqaa_tune(const wqaa_matmul_desc* desc, int m, void* stream) {

@@ -101,13 +101,9 @@ int gemvx_pair_plan(const wqaa_matmul_desc& d, int m, wqaa_plan* plan, bool norm
 int gemvx_pair_launch(const wqaa_matmul_desc& d, const wqaa_group_item* gate, const wqaa_group_item* up, void* act, int m,
                       hipStream_t stream, const wqaa_epilogue* norm);
 struct GemvxArgs;
-int gemvx_chain_geometry(const wqaa_matmul_desc& d, int m, int pro, bool pair, GemvxArgs* a, int* kw, int* nw, int* nai);
-// chains of dependent operators in one persistent launch (wqaa_chain.hip)
+// chains of dependent operators, run as the launches they stand for (wqaa_chain.hip)
 int chain_launch(const wqaa_chain_item* items, int count, int m, hipStream_t stream);
 int chain_plan(const wqaa_chain_item* items, int count, int m, int* launches, wqaa_plan* plan);
-int chain_status(hipStream_t stream, uint32_t* out4);
-int64_t chain_trace(hipStream_t stream, uint64_t* out, int64_t max_words);
-void chain_init();
 void gemvx_init();
 
 void gemm_debug_tile_of_block(int tiles_m, int tiles_n, int ksplit, int group_m, int block, int* out4);

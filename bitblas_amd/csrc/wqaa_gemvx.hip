@@ -446,26 +446,6 @@ int gemvx_group_launch(const wqaa_matmul_desc& merged, const wqaa_group_item* it
   return gemvx_dispatch(c, ga, gx, count, stream, nullptr, nullptr);
 }
 
-// ---- what wqaa_matmul_chain (wqaa_chain.hip) has to know about the SINGLE launch an item stands for: the K split across
-// waves (the fp32 summation order of a row: the chain's consumers sum a row unsplit, so it must be 1), the workgroup width
-// and items per thread (the order of the norm's sum of squares) and the operand arithmetic of the row (GemvxArgs).
-// pro as gemvx_choose: 0 plain, 1 residual add, 3 RMSNorm in front; pair: the gate / up launch (pro 2, or 4 with the norm) ----
-int gemvx_chain_geometry(const wqaa_matmul_desc& d, int m, int pro, bool pair, GemvxArgs* a, int* kw, int* nw, int* nai) {
-  GemvxChoice c;
-  int st;
-  if (pair) st = gemvx_pair_choose(d, m, &c, pro >= 3);
-  else if (!gemvx_covers(d, m) || d.out_dtype != WQAA_F16) {
-    set_error(WQAA_ERR_UNSUPPORTED, "matmul_chain: needs float16 activations, 1/2/4-bit integer weights, float16 output and m <= 2");
-    st = WQAA_ERR_UNSUPPORTED;
-  } else st = gemvx_choose(d, m, &c, pro);
-  if (st != WQAA_OK) return st;
-  gemvx_fill(d, c, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, m, a);
-  *kw = c.kw;
-  *nw = c.nw;
-  *nai = c.R == 1 ? 3 : 2;
-  return WQAA_OK;
-}
-
 void gemvx_init() {
   for (int bits : {4, 2, 1})
     for (int layout = 0; layout < 2; ++layout)

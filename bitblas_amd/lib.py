@@ -41,7 +41,7 @@ ZEROS_CODE = {"original": Z_ORIGINAL, "rescale": Z_RESCALE, "quantized": Z_QUANT
 
 EXPORTED_SYMBOLS = (
     "init", "wqaa_abi_version", "wqaa_device_count", "wqaa_matmul", "wqaa_matmul_timed",
-    "wqaa_matmul_ex", "wqaa_matmul_opts", "wqaa_workspace_bytes", "wqaa_matmul_group", "wqaa_matmul_group_ex", "wqaa_group_plan", "wqaa_matmul_gate_up", "wqaa_gate_up_plan", "wqaa_matmul_chain", "wqaa_chain_plan", "wqaa_debug_chain_status", "wqaa_debug_chain_trace", "wqaa_dequantize", "wqaa_tune", "wqaa_act_quant_int8", "wqaa_select", "wqaa_select_ex", "wqaa_pack_weight", "wqaa_unpack_weight", "wqaa_relayout_weight", "wqaa_debug_decode", "wqaa_debug_row_blocks", "wqaa_debug_tile_of_block",
+    "wqaa_matmul_ex", "wqaa_matmul_opts", "wqaa_workspace_bytes", "wqaa_matmul_group", "wqaa_matmul_group_ex", "wqaa_group_plan", "wqaa_matmul_gate_up", "wqaa_gate_up_plan", "wqaa_matmul_chain", "wqaa_chain_plan", "wqaa_dequantize", "wqaa_tune", "wqaa_act_quant_int8", "wqaa_select", "wqaa_select_ex", "wqaa_pack_weight", "wqaa_unpack_weight", "wqaa_relayout_weight", "wqaa_debug_decode", "wqaa_debug_row_blocks", "wqaa_debug_tile_of_block",
     "wqaa_peer_alloc", "wqaa_peer_free", "wqaa_peer_export", "wqaa_peer_open", "wqaa_peer_close", "wqaa_peer_exchange",
     "wqaa_last_error", "wqaa_last_error_string",
 )
@@ -204,8 +204,8 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
         lib.wqaa_peer_exchange.argtypes = [ctypes.POINTER(PeerExchangeDesc), vp]
         lib.wqaa_last_error.restype = ci
         lib.wqaa_last_error_string.restype = ctypes.c_char_p
-        if lib.wqaa_abi_version() != 3:
-            raise ImportError(f"{p}: ABI version {lib.wqaa_abi_version()} != 3 (rebuild: python -m bitblas_amd.build)")
+        if lib.wqaa_abi_version() != 4:
+            raise ImportError(f"{p}: ABI version {lib.wqaa_abi_version()} != 4 (rebuild: python -m bitblas_amd.build)")
         lib.init()
         if path is None:
             _lib = lib

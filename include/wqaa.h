@@ -34,9 +34,11 @@
 extern "C" {
 #endif
 
-#define WQAA_ABI_VERSION 3   /* 2: wqaa_matmul_opts, wqaa_workspace_bytes (+ wqaa_matmul_group, new symbols only); 3: the 48-byte
+#define WQAA_ABI_VERSION 4   /* 2: wqaa_matmul_opts, wqaa_workspace_bytes (+ wqaa_matmul_group, new symbols only); 3: the 48-byte
                               * wqaa_epilogue (residual / norm), wqaa_matmul_gate_up, wqaa_matmul_chain - a caller built against this
-                              * header probes wqaa_abi_version() >= 3 before it passes the long epilogue or calls them */
+                              * header probes wqaa_abi_version() >= 3 before it passes the long epilogue or calls them;
+                              * 4: wqaa_matmul_chain always runs its launches and wants every item's C (the persistent chain
+                              * member and the wqaa_debug_chain_* test aids are gone) */
 
 /* element types of A / C / Scale / Bias */
 enum wqaa_dtype {
@@ -291,26 +293,18 @@ int wqaa_matmul_gate_up(const wqaa_group_item* gate, const wqaa_group_item* up, 
                         const wqaa_epilogue* norm);
 int wqaa_gate_up_plan(const wqaa_matmul_desc* desc, int m, int with_norm, wqaa_plan* plan);
 
-/* ---- chains of DEPENDENT operators: the post-attention half of a decoder layer as ONE persistent launch -----------------
+/* ---- chains of DEPENDENT operators: the post-attention half of a decoder layer described once ------------------------------
  * o_proj (+ residual) -> RMSNorm -> gate / up * silu -> down_proj (+ residual) is four calls of this library whose only
  * coupling is a few KB of activations (the reference's callers: integration/BitNet/modeling_bitnet.py: BitnetMLP.forward
- * :240-244, BitnetDecoderLayer.forward :839-860, one `call` per nn.Linear through ops/operator.py:458-463).  On MI355X every
- * dependent launch pays ~2.85 us of dispatch, load ramp and store tail around a weight stream that itself runs at the memory's
- * rate.  wqaa_matmul_chain runs `count` items AS IF each had been its own call, in order -
+ * :240-244, BitnetDecoderLayer.forward :839-860, one `call` per nn.Linear through ops/operator.py:458-463).
+ * wqaa_matmul_chain runs `count` items as the launches they stand for, in order -
  *     kind 0:  C = wqaa_matmul_ex(desc, input, B, Scale, Zeros, Bias; RMSNorm in front when norm_weight, residual added when
  *              residual / residual_from - never both on one item)
  *     kind 1:  C = wqaa_matmul_gate_up(gate = (B, Scale, Zeros, Bias), up = (B2, Scale2, Zeros2, Bias2); norm when norm_weight)
- * with `input` = A (input_from < 0) or the output C of the earlier item input_from, and the residual likewise - the same
- * bits as those calls (exact-product GEMV family: the K split, the order of the norm's sum of squares and every rounding
- * are the single launch's) - and, where the fused member covers the chain, in ONE launch: one workgroup per CU whose loader
- * wave streams the NEXT operator's weights into an LDS ring (LDS-DMA, non-temporal) while the consumers wait for this
- * operator's output, which crosses between CUs as 8-byte {tag, 2 x float16} write-through granules - no grid barrier, no
- * memset between replays of a captured graph (csrc/wqaa_chain_kernel.h).  The fused member: m == 1, float16 activations x
- * 1 / 2 / 4-bit integer weights of ONE format across the chain (bits, layout, scale / zeros mode; zeros not quantized),
- * float16 outputs, every item's single launch unsplit in K, every N >= 2 x the CU count, count <= WQAA_CHAIN_MAX; anything else
- * runs as the `count` launches it stands for.  C may be NULL for an item only later items read (the fused launch then never
- * stores it; the launches use library scratch).  The library keeps ~100 KB of hand-off scratch per (device, stream).
- * wqaa_chain_plan: *launches = 1 and the fused plan (name "chain_..."), or the number of launches the chain takes. */
+ * with `input` = A (input_from < 0) or the output C of the earlier item input_from, and the residual likewise.  Every item
+ * stores its output: C must not be NULL.  (ABI 3 also carried a persistent one-launch member behind this entry point; it was
+ * bit-identical to the launches and slower than them, and was removed in ABI 4 together with its wqaa_debug_chain_* aids.)
+ * wqaa_chain_plan: validates the chain; *launches = count. */
 #define WQAA_CHAIN_MAX 8
 typedef struct wqaa_chain_item {
   const wqaa_matmul_desc* desc;
@@ -323,7 +317,7 @@ typedef struct wqaa_chain_item {
   const void* Scale2;
   const void* Zeros2;
   const void* Bias2;
-  void* C;                  /* (m, N) float16, or NULL */
+  void* C;                  /* (m, N) float16 */
   const void* residual;     /* (m, N) float16 added to the rounded result (kind 0), or NULL */
   const void* norm_weight;  /* (K,) float16: RMSNorm in front of the operator, or NULL */
   float norm_eps;
@@ -334,11 +328,6 @@ typedef struct wqaa_chain_item {
 
 int wqaa_matmul_chain(const wqaa_chain_item* items, int count, int m, void* stream);
 int wqaa_chain_plan(const wqaa_chain_item* items, int count, int m, int* launches, wqaa_plan* plan);
-/* test / lab aids (synchronise `stream`): out4 = {generation, first error code of a fused launch (0: none), reserved, reserved} of
- * the stream's hand-off scratch; trace: the [workgroup][wave][32] s_memrealtime stamps of the LAST fused launch made while the
- * environment variable WQAA_CHAIN_TRACE=1 was set at plan time (returns the number of 8-byte words written, <= max_words) */
-int wqaa_debug_chain_status(void* stream, uint32_t* out4);
-int64_t wqaa_debug_chain_trace(void* stream, uint64_t* out, int64_t max_words);
 
 /* measured tuning of the vendor-library GEMM behind (desc, m) - the plain dense pairs, or the second pass of the two-pass
  * member: the heuristic's top candidates are timed on the device (temporary buffers, synchronises `stream`) and the

@@ -294,6 +294,34 @@ def _quantized_zero_difference(codes, qzeros, bit: int, gi) -> np.ndarray:
     return ((d + 128) % 256) - 128
 
 
+# Large matrices (the Llama-70B linears: 235 M elements) are decoded in blocks of weight rows on a thread pool: the same
+# function on every block (a row of B_decode depends on its own codes, Scale and Zeros only), concatenated - numpy's
+# elementwise loops are single-threaded and release the GIL, and whole-output checks at M = 4096 need the decode in seconds.
+_BLOCKED_ABOVE = 1 << 24
+_BLOCK_ROWS = 512
+
+
+def _blocked_rows(fn, codes, bit, scale, zeros, zeros_mode, kw):
+    import concurrent.futures as cf
+    import os
+    N = codes.shape[0]
+    per_byte = max(1, 8 // bit)
+    quantized = zeros is not None and zeros_mode == "quantized"
+    zeros_a = None if zeros is None else np.asarray(zeros)
+    scale_a = None if scale is None else np.asarray(scale)
+
+    def one(n0):
+        n1 = min(N, n0 + _BLOCK_ROWS)
+        z = None
+        if zeros_a is not None:
+            z = zeros_a[:, n0 // per_byte:(n1 + per_byte - 1) // per_byte] if quantized else zeros_a[n0:n1]
+        return fn(codes[n0:n1], scale=None if scale_a is None else scale_a[n0:n1], zeros=z, **kw)
+
+    with cf.ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 4)) as pool:
+        parts = list(pool.map(one, range(0, N, _BLOCK_ROWS)))
+    return np.concatenate(parts, axis=0)
+
+
 def dequantize_weight_exact(codes: np.ndarray, source_format: str, bit: int, *, K: int | None = None,
                             scale=None, zeros=None, zeros_mode: str = "original", group_size: int = -1, lut=None) -> np.ndarray:
     """The real-valued dequantised weight, float64, NO rounding to A_dtype between the steps: what the
@@ -302,6 +330,9 @@ def dequantize_weight_exact(codes: np.ndarray, source_format: str, bit: int, *, 
     codes = np.asarray(codes)
     N, Kc = codes.shape
     K = Kc if K is None else K
+    if N * Kc > _BLOCKED_ABOVE and N >= 2 * _BLOCK_ROWS:
+        return _blocked_rows(dequantize_weight_exact, codes, bit, scale, zeros, zeros_mode,
+                             dict(source_format=source_format, bit=bit, K=K, zeros_mode=zeros_mode, group_size=group_size, lut=lut))
     g = K if group_size in (-1, None) else group_size
     gi = np.arange(K) // g
     if zeros is not None and zeros_mode == "quantized":
@@ -328,8 +359,8 @@ def matmul_dequant_exact(A: np.ndarray, codes: np.ndarray, *, source_format: str
     K = A.shape[-1]
     Wd = dequantize_weight_exact(codes, source_format, bit, K=K, scale=scale, zeros=zeros, zeros_mode=zeros_mode,
                                  group_size=group_size, lut=lut)
-    acc = A.reshape(-1, K).astype(np.float64) @ Wd.T
-    out = acc.astype(np.float32).astype(_OUT_NP[out_dtype])
+    acc = _gemm_nt(A.reshape(-1, K), Wd, np.float64)
+    out = _cast_out(acc, out_dtype)
     if bias is not None:
         out = (out + np.asarray(bias).astype(out.dtype)).astype(out.dtype)
     return out.reshape(*A.shape[:-1], Wd.shape[0])
@@ -349,6 +380,10 @@ def dequantize_weight(codes: np.ndarray, source_format: str, bit: int, *, K: int
     codes = np.asarray(codes)
     N, Kc = codes.shape
     K = Kc if K is None else K
+    if N * Kc > _BLOCKED_ABOVE and N >= 2 * _BLOCK_ROWS:
+        return _blocked_rows(dequantize_weight, codes, bit, scale, zeros, zeros_mode,
+                             dict(source_format=source_format, bit=bit, K=K, zeros_mode=zeros_mode, group_size=group_size,
+                                  a_dtype=a_dtype, strict_reference=strict_reference, lut=lut))
     g = K if group_size in (-1, None) else group_size
     gi = np.arange(K) // g
     if a_dtype == "int8":
@@ -405,6 +440,48 @@ _OUT_NP = {"float16": np.float16, "float32": np.float32, "int32": np.int32, "int
            "bfloat16": np.float32}
 
 
+def _gemm_nt(A: np.ndarray, W: np.ndarray, ct=None) -> np.ndarray:
+    """A @ W^T in the floating type `ct` (default: the arrays' own).  torch's CPU kernels where torch is importable - its
+    threaded BLAS takes a 4096^3 float64 product in well under a second where numpy's bundled one takes ~16 s, and its
+    float16 -> float conversions are vectorised where numpy's are scalar loops - numpy otherwise: the same sums either way
+    up to the order of the additions."""
+    A, W = np.asarray(A), np.asarray(W)
+    ct = np.dtype(ct or A.dtype)
+    try:
+        import torch
+        tt = {np.dtype(np.float64): torch.float64, np.dtype(np.float32): torch.float32}[ct]
+        return torch.matmul(torch.from_numpy(np.ascontiguousarray(A)).to(tt), torch.from_numpy(np.ascontiguousarray(W)).to(tt).T).numpy()
+    except ImportError:
+        return A.astype(ct) @ W.astype(ct).T
+
+
+def _cast_out(acc: np.ndarray, out_dtype: str) -> np.ndarray:
+    """accumulator -> float32 -> out_dtype (the one cast of the TE graph), through torch's vectorised conversions when the
+    array is large and torch is importable (same IEEE round-to-nearest-even conversions, bit for bit)."""
+    if acc.size >= (1 << 22) and out_dtype in ("float16", "float32") and acc.dtype in (np.float64, np.float32):
+        try:
+            import torch
+            t = torch.from_numpy(np.ascontiguousarray(acc)).float()
+            return (t.half() if out_dtype == "float16" else t).numpy()
+        except ImportError:
+            pass
+    return acc.astype(np.float32).astype(_OUT_NP[out_dtype])
+
+
+def exact_int_matmul(A: np.ndarray, W: np.ndarray) -> np.ndarray:
+    """A @ W^T of integer arrays, exact, as int64.  numpy has no BLAS for integer dtypes (a 4096^3 product takes minutes in
+    its loops); every partial sum here is an integer below K * max|a| * max|w|, and while that bound is below 2^53 a float64
+    GEMM adds integers exactly whatever its summation order - so whole M = 4096 outputs can be checked, not sampled rows."""
+    A = np.asarray(A)
+    W = np.asarray(W)
+    K = A.shape[-1]
+    amax = int(np.abs(A.astype(np.int64)).max()) if A.size else 0
+    wmax = int(np.abs(W.astype(np.int64)).max()) if W.size else 0
+    if K * amax * wmax < (1 << 53):
+        return np.rint(_gemm_nt(A, W, np.float64)).astype(np.int64)
+    return A.astype(np.int64) @ W.astype(np.int64).T
+
+
 def matmul_dequant(A: np.ndarray, codes: np.ndarray, *, source_format: str, bit: int,
                    scale=None, zeros=None, zeros_mode="original", group_size=-1, bias=None,
                    a_dtype="float16", out_dtype="float16", strict_reference=True, lut=None,
@@ -422,12 +499,11 @@ def matmul_dequant(A: np.ndarray, codes: np.ndarray, *, source_format: str, bit:
                            strict_reference=strict_reference, lut=lut)
     A2 = A.reshape(-1, K)
     if a_dtype == "int8":
-        acc = A2.astype(np.int64) @ Wd.astype(np.int64).T
+        acc = exact_int_matmul(A2, Wd)
         out = acc.astype(_OUT_NP[out_dtype]) if out_dtype.startswith("int") else acc.astype(_OUT_NP[out_dtype])
     else:
-        ct = np.float64 if wide else np.float32
-        acc = A2.astype(ct) @ Wd.astype(ct).T
-        out = acc.astype(np.float32).astype(_OUT_NP[out_dtype])
+        acc = _gemm_nt(A2, Wd, np.float64 if wide else np.float32)
+        out = _cast_out(acc, out_dtype)
     if bias is not None:
         out = (out + np.asarray(bias).astype(out.dtype)).astype(out.dtype)
     return out.reshape(*A.shape[:-1], Wd.shape[0])
@@ -448,11 +524,11 @@ def matmul_dense(A: np.ndarray, W: np.ndarray, *, a_dtype: str, w_dtype: str | N
     Av, Wv = val(A, a_dtype), val(W, w_dtype)
     K = Av.shape[-1]
     if a_dtype in ("int8", "uint8"):
-        acc = Av.reshape(-1, K).astype(np.int64) @ Wv.astype(np.int64).T
+        acc = exact_int_matmul(Av.reshape(-1, K), Wv)
         out = acc.astype(_OUT_NP[out_dtype])
     else:
-        acc = Av.reshape(-1, K).astype(np.float64) @ Wv.astype(np.float64).T
-        out = acc.astype(np.float32).astype(_OUT_NP[out_dtype])
+        acc = _gemm_nt(Av.reshape(-1, K), Wv, np.float64)
+        out = _cast_out(acc, out_dtype)
     if bias is not None:
         out = (out + np.asarray(bias).astype(out.dtype)).astype(out.dtype)
     return out.reshape(*Av.shape[:-1], Wv.shape[0])

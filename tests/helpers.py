@@ -32,9 +32,13 @@ def make_case(M, N, K, W_dtype="int4", A_dtype="float16", out_dtype="float16", g
         raise NotImplementedError(A_dtype)
     case["A"] = A
     # integer weights as the user would hold them (signed for int formats), and storage codes
+    big = N * K > (1 << 26)      # the Llama-70B linears: draw int8 directly (an int64 draw of 235 M elements takes 10 s)
     if source_format == "uint":
-        w_user = rng.integers(0, 1 << bit, size=(N, K)).astype(np.int8) if bit < 8 else \
-            rng.integers(0, 128, size=(N, K)).astype(np.int8)
+        if big and bit < 8:
+            w_user = rng.integers(0, 1 << bit, size=(N, K), dtype=np.int8)
+        else:
+            w_user = rng.integers(0, 1 << bit, size=(N, K)).astype(np.int8) if bit < 8 else \
+                rng.integers(0, 128, size=(N, K)).astype(np.int8)
         codes = w_user
     elif source_format == "int":
         if bit == 8:
@@ -45,7 +49,7 @@ def make_case(M, N, K, W_dtype="int4", A_dtype="float16", out_dtype="float16", g
             codes = w_user
         else:
             maxq = 1 << (bit - 1)
-            w_user = rng.integers(-maxq, maxq, size=(N, K)).astype(np.int8)
+            w_user = rng.integers(-maxq, maxq, size=(N, K), dtype=np.int8) if big else rng.integers(-maxq, maxq, size=(N, K)).astype(np.int8)
             codes = (w_user + maxq).astype(np.int8)
     elif source_format in ("nf", "fp"):
         w_user = rng.integers(0, 16, size=(N, K)).astype(np.int8)

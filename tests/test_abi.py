@@ -55,7 +55,7 @@ def test_init_is_idempotent_and_error_channel_works():
     L = wlib.load_library()
     L.init()
     L.init()
-    assert L.wqaa_abi_version() == 3
+    assert L.wqaa_abi_version() == 4
     d = wlib.make_desc(N=64, K=64, a_dtype=wlib.F16, w_format=wlib.W_UINT, w_bits=4, out_dtype=wlib.F16)
     d.struct_size = 4  # wrong ABI size must be refused
     assert L.wqaa_matmul(ctypes.byref(d), 1, 1, None, None, None, None, 1, 1, None) == wlib.ERR_BAD_DESC
@@ -315,25 +315,13 @@ def test_vendor_library_is_not_a_link_dependency():
 
 
 def _gfx950_code_objects(path):
-    """the device ELFs inside the library's .hip_fatbin section (one clang offload bundle per translation unit)"""
-    import struct
-    import subprocess
-    blob = subprocess.run(["objcopy", "-O", "binary", "--only-section=.hip_fatbin", path, "/dev/stdout"], capture_output=True).stdout
-    magic, pos = b"__CLANG_OFFLOAD_BUNDLE__", 0
-    while True:
-        i = blob.find(magic, pos)
-        if i < 0:
-            return
-        n, = struct.unpack_from("<Q", blob, i + len(magic))
-        p = i + len(magic) + 8
-        for _ in range(n):
-            off, size, tl = struct.unpack_from("<QQQ", blob, p)
-            p += 24
-            triple = blob[p: p + tl].decode()
-            p += tl
-            if "gfx950" in triple and size:
-                yield blob[i + off: i + off + size]
-        pos = i + len(magic)
+    """the device ELFs inside the library's .hip_fatbin section (one - compressed - clang offload bundle per translation unit;
+    tools/check_vmem_hazards.py knows both the plain and the --offload-compress container)"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("check_vmem_hazards", os.path.join(ROOT, "tools", "check_vmem_hazards.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.code_objects(path)
 
 
 def test_counted_decode_members_keep_their_loads_in_registers(tmp_path):

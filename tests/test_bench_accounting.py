@@ -65,6 +65,9 @@ def test_final_line_is_short_enough_for_the_driver_to_parse():
     assert back["cpu_baseline"]["value"] == 0.1573 and back["cpu_baseline"]["cores"] == 16 and back["cpu_baseline"]["kind"] == "port"
     assert back["value"] == 3605.1235 and back["n_gpus"] == 1 and back["config"]["launches_per_step"] == 16
     assert set(back["members"]) == set(bench.MEMBER_KEYS) and back["members"]["gemm_uint4_m128"] == {"us": 17.12, "frac": 0.101}
+    # the metric's own shapes ride in the contract line, and the line says which numerics the headline is (#8)
+    assert {"gemv_int4_n8192k28672", "gemv_int4_n28672k8192", "gemm_uint4_m4096_n28672k8192"} <= set(back["members"])
+    assert "strict_reference=0" in back["config"]["numerics"] and "1e-3" in back["config"]["numerics"]
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
               "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in back, k

@@ -81,6 +81,13 @@ def test_c5_gemm_m4096_unsharded(name, N, K):
     _check(4096, N, K, want_plan="tcx256x256x128pp", seed=N // 256 + K // 1024)
 
 
+@pytest.mark.parametrize("name,N,K", [("o_proj", 8192, 8192), ("down_proj", 8192, 28672)])
+def test_c5_gemm_m4096_every_output_element(name, N, K):
+    """whole M x N outputs, no sampling: the oracle's exact OCP decode, its product through a threaded float64 GEMM
+    (oracle/wqaa_oracle.py: _gemm_nt) - seconds even for the 1.9 TFLOP down projection"""
+    _check(4096, N, K, want_plan="tcx256x256x128pp", seed=N // 128 + K // 512, n_rows=4096, n_cols=N)
+
+
 @pytest.mark.parametrize("name,N,K", LLAMA3_70B)
 def test_c5_gemm_m4096_per_rank_shard(name, N, K):
     """column shard of 8-way tensor parallelism: N' = N / 8; fp32 output checked exactly"""

@@ -97,7 +97,7 @@ def _worker_window(rank, world, port, ret):
     _setup(rank, world, port)
     try:
         from bitblas_amd.peer import FLAG_REGION, PeerTimeout, ShmPeerWindow
-        win = ShmPeerWindow(None, row_bytes=96, slots=3, timeout_ms=300)
+        win = ShmPeerWindow(None, row_bytes=96, slots=3, timeout_ms=1500)   # (generous: a loaded host must not make the live peer look silent)
         ok = win.row_pitch == 256 and win.window_bytes == FLAG_REGION + 3 * 256 and win.row_offset(2) == FLAG_REGION + 512
         for bad in ((8, 16), (0, 24), (96, 16), (-16, 16), (0, 0)):
             try:
@@ -126,7 +126,7 @@ def _worker_window(rank, world, port, ret):
                 win.check()
                 ok = False
             except PeerTimeout as e:
-                ok = ok and "rank 1" in str(e) and 0.25 < waited < 5.0
+                ok = ok and "rank 1" in str(e) and 1.2 < waited < 30.0
         dist.barrier()
         ret[rank] = ok
     finally:

@@ -27,8 +27,41 @@ OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
 DEFAULT_MATCH = r"wq_gemm_decode_lds_kernelINS_10GemmPolicyILi[04]ELi\dELi0ELi[123]E"   # int4 / lut4, 16-bit activations, Scale (+ Zeros)
 
 
+BUNDLER = "/opt/rocm/lib/llvm/bin/clang-offload-bundler"
+
+
+def _compressed_bundles(blob):
+    """the library is built with --offload-compress (bitblas_amd/build.py): its .hip_fatbin holds one "CCOB" container per
+    translation unit (header: magic, u16 version, u16 method, then the container's size - u32 in version 2, u64 in version 3);
+    clang-offload-bundler unbundles (and decompresses) a container given as a file"""
+    import tempfile
+    pos = 0
+    while True:
+        i = blob.find(b"CCOB", pos)
+        if i < 0:
+            return
+        ver, = struct.unpack_from("<H", blob, i + 4)
+        size = struct.unpack_from("<Q", blob, i + 8)[0] if ver >= 3 else struct.unpack_from("<I", blob, i + 8)[0]
+        if size <= 24 or i + size > len(blob):
+            pos = i + 4
+            continue
+        with tempfile.TemporaryDirectory() as tmp:
+            src, dst = os.path.join(tmp, "bundle.bin"), os.path.join(tmp, "dev.o")
+            with open(src, "wb") as f:
+                f.write(blob[i: i + size])
+            res = subprocess.run([BUNDLER, "--unbundle", "--type=o", f"--input={src}", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950",
+                                  f"--output={dst}"], capture_output=True)
+            if res.returncode == 0 and os.path.exists(dst):
+                with open(dst, "rb") as f:
+                    yield f.read()
+        pos = i + size
+
+
 def code_objects(path):
     blob = subprocess.run(["objcopy", "-O", "binary", "--only-section=.hip_fatbin", path, "/dev/stdout"], capture_output=True).stdout
+    if b"CCOB" in blob[:64] or (b"__CLANG_OFFLOAD_BUNDLE__" not in blob and b"CCOB" in blob):
+        yield from _compressed_bundles(blob)
+        return
     magic, pos = b"__CLANG_OFFLOAD_BUNDLE__", 0
     while True:
         i = blob.find(magic, pos)
