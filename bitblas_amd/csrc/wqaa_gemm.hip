@@ -2,7 +2,6 @@
 // The kernels live in wqaa_gemm_kernel.h; the member tables are instantiated in wqaa_gemm_inst_*.hip.
 #include "wqaa_gemm_mid_kernel.h"
 
-#include <unordered_map>
 #include <vector>
 
 namespace wqaa {
@@ -68,50 +67,6 @@ bool pool_workspace_ready(hipStream_t stream, size_t bytes) {
   hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
   if (hipStreamIsCapturing(stream, &cs) != hipSuccess) (void)hipGetLastError();
   return cs == hipStreamCaptureStatusNone;
-}
-
-// Sync words of the mid-M member's in-launch split-K meeting (wqaa_gemm_mid_kernel.h): kMidSyncWords per output tile, zero
-// between launches (the kernel cleans up after itself).  They are NOT part of the workspace - a caller's scratch may hold
-// anything - but they are keyed BY it: a workspace is never shared by two launches in flight (two streams never share partial
-// sums, see above), so neither are the words that go with it.  One zero-initialised slab per device, carved into regions of
-// kMidMaxTiles tiles; first use of a device allocates (not during stream capture: the caller falls back to the two-launch
-// member then, as it does when the regions run out).
-constexpr int kMidMaxTiles = 256;
-constexpr int kMidRegions = 1024;            // 16 KiB each: a 16 MiB slab per device
-struct MidDev {
-  int dev;
-  unsigned* slab;
-  std::unordered_map<const void*, unsigned*> by_ws;
-};
-static std::vector<MidDev> g_mid;
-static std::mutex g_mid_mu;
-static unsigned* mid_sync_words(hipStream_t stream, const void* ws) {
-  const int dev = current_device();
-  if (dev < 0 || !ws) return nullptr;
-  std::lock_guard<std::mutex> lk(g_mid_mu);
-  MidDev* md = nullptr;
-  for (auto& x : g_mid)
-    if (x.dev == dev) md = &x;
-  if (!md) {
-    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(stream, &cs) != hipSuccess) (void)hipGetLastError();
-    if (cs != hipStreamCaptureStatusNone) return nullptr;
-    const size_t bytes = (size_t)kMidRegions * kMidMaxTiles * kMidSyncWords * sizeof(unsigned);
-    void* p = nullptr;
-    if (hipMalloc(&p, bytes) != hipSuccess || hipMemset(p, 0, bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
-      (void)hipGetLastError();
-      if (p) (void)hipFree(p);
-      return nullptr;
-    }
-    g_mid.push_back(MidDev{dev, reinterpret_cast<unsigned*>(p), {}});
-    md = &g_mid.back();
-  }
-  auto it = md->by_ws.find(ws);
-  if (it != md->by_ws.end()) return it->second;
-  if ((int)md->by_ws.size() >= kMidRegions) return nullptr;
-  unsigned* words = md->slab + md->by_ws.size() * (size_t)kMidMaxTiles * kMidSyncWords;
-  md->by_ws.emplace(ws, words);
-  return words;
 }
 
 static gemm_fn pick_gemm(int kind, int layout, int at, int mode, int flags, int mf) {
@@ -378,7 +333,7 @@ static int gemm_choose(const wqaa_matmul_desc& d, int m, GemmChoice* c, bool fus
     // (128 rows on half a chip of workgroups - N = 2048: 16.0 vs 14.1 us - keeps its member: at least three quarters of a round)
     const bool measured = m <= 128 && (mf == 8 ? (nkh == 2 && wgs <= cus_ && 4 * wgs >= 3L * cus_)
                                                : (nkh == 4 ? wgs <= 3L * cus_ : (nkh == 2 && wgs > cus_ && wgs <= 3L * cus_)));
-    if (fn && meta_ok && (!mf_ || atoi(mf_) != 0) && (force || measured) && tiles <= kMidMaxTiles &&
+    if (fn && meta_ok && (!mf_ || atoi(mf_) != 0) && (force || measured) && tiles <= 256 &&
         (long)m * d.K * 2 < (1L << 32) && d.K < (1 << 23) && m < (1 << 23) && (c->mode != MD_ZQ || d.N % 2 == 0)) {
       c->mid = 1;
       c->mid_nkh = nkh;
@@ -674,11 +629,13 @@ int gemm_launch(const wqaa_matmul_desc& d, const void* A, const void* B, const v
   }
   const int g = d.group_size <= 0 ? d.K : d.group_size;
   GemmArgs a;
-  // the mid-M member needs its exchange buffer and the tiles' sync words; without them (a short caller workspace, a pool that
-  // cannot grow or a device's first use inside a stream capture) the call runs the member it stands in for
+  // the mid-M member (`xmk`) and the K-sliced decode form (`xdlk`) need a buffer for their slices' partial sums; without it (a
+  // short caller workspace, a pool that cannot grow - the first use of a shape inside a stream capture) the call runs the member
+  // it stands in for.  That member is chosen once per (descriptor, m) (memoised like the first choice), and the FIRST fallback of
+  // a process says so on stderr: `wqaa_select` / the plan name keep reporting the member the shape is planned for, and for `xmk`
+  // the stand-in sums K in another order - the output bits of such a call are the stand-in's (include/wqaa.h, wqaa_workspace_bytes:
+  // a caller that needs one set of bits eagerly and under capture passes a workspace of that size, or warms the shape up first)
   void* mid_ws = nullptr;
-  unsigned* mid_sync = nullptr;
-  bool mid_in_launch = false;
   if ((c.mid || c.decode_kslice == 1) && !epi) {
     const size_t need = mid_ws_bytes(c);
     if (opts && opts->workspace) {
@@ -686,23 +643,20 @@ int gemm_launch(const wqaa_matmul_desc& d, const void* A, const void* B, const v
     } else if (pool_workspace_ready(stream, need)) {
       mid_ws = pool_workspace(stream, need);
     }
-    // the seam: 0 (default) = a second launch adds the slices (wq_mid_reduce_kernel); 1 = they meet inside the launch (needs the
-    // tiles' sync words).  Same summation order, same bits; the second launch measured faster
-    static thread_local unsigned seam_seen = ~0u;
-    static thread_local int seam_mode = 0;
-    {
-      const unsigned ep = g_plan_epoch.load(std::memory_order_relaxed);
-      if (ep != seam_seen) {
-        const char* f = getenv("WQAA_GEMM_MID_SEAM");
-        seam_mode = f ? atoi(f) : 0;
-        seam_seen = ep;
+    if (!mid_ws) {
+      static std::atomic<bool> warned{false};
+      if (!warned.exchange(true))
+        fprintf(stderr, "[wqaa] %s: no %zu B of scratch for the slices' partial sums (%s) - this call runs the member it stands in for; "
+                "its bits may differ from a call that has the scratch\n", c.mid ? "mid-M member (xmk)" : "K-sliced decode form (xdlk)", need,
+                (opts && opts->workspace) ? "caller workspace too small or misaligned" : "the library pool cannot grow during stream capture");
+      static thread_local ChoiceMemo<GemmChoice> fallback_memo;
+      if (const GemmChoice* hit = fallback_memo.find(d, m, 2)) {
+        c = *hit;
+      } else {
+        int st = gemm_choose(d, m, &c, false, true);
+        if (st != WQAA_OK) return st;
+        fallback_memo.put(d, m, 2, c);
       }
-    }
-    mid_in_launch = seam_mode == 1 && c.mid;
-    if (mid_ws && mid_in_launch) mid_sync = mid_sync_words(stream, mid_ws);
-    if (!mid_ws || (mid_in_launch && !mid_sync)) {
-      int st = gemm_choose(d, m, &c, false, true);
-      if (st != WQAA_OK) return st;
     }
   }
   a.A = A; a.B = B; a.lut = LUT; a.scale = Scale; a.zeros = Zeros; a.bias = Bias; a.C = C;
@@ -776,26 +730,14 @@ int gemm_launch(const wqaa_matmul_desc& d, const void* A, const void* B, const v
   if (c.decode_kslice == 1) a.ws = mid_ws;
   if (c.mid) {
     a.ws = mid_ws;
-    a.mid_sync = mid_sync;
     a.mg_ntiles = tile_magic((uint32_t)c.tiles_n);          // (this member's tile map: tile -> (tile / tiles_n, tile % tiles_n))
-    // bound of the in-launch wait: 10 ns ticks (WQAA_GEMM_MID_SPIN_US, default 50 us; 0 = nobody waits, every portion takes the
-    // abandon / sweep path - the test aid)
-    static thread_local unsigned seen = ~0u;
-    static thread_local int spin_us = 50;
-    const unsigned ep = g_plan_epoch.load(std::memory_order_relaxed);
-    if (ep != seen) {
-      const char* f = getenv("WQAA_GEMM_MID_SPIN_US");
-      spin_us = f ? atoi(f) : 50;
-      seen = ep;
-    }
-    a.mid_spin = spin_us * 100;
   }
   void* params[] = {&a};
   dim3 grid(c.decode_grid > 0 ? c.decode_grid : c.tiles_m * c.tiles_n * (c.mid ? kMidSlices : c.ksplit), 1, 1), block(64 * c.nwaves, 1, 1);
   hipError_t e;
   if (start || stop) {
     e = hipExtLaunchKernel(reinterpret_cast<const void*>(c.fn), grid, block, params, c.lds, stream, start,
-                           (c.ksplit > 1 || c.tail_fn || (c.mid && !mid_in_launch) || c.decode_kslice == 1) ? nullptr : stop, 0);
+                           (c.ksplit > 1 || c.tail_fn || c.mid || c.decode_kslice == 1) ? nullptr : stop, 0);
   } else {
     e = hipLaunchKernel(reinterpret_cast<const void*>(c.fn), grid, block, params, c.lds, stream);
   }
@@ -812,7 +754,7 @@ int gemm_launch(const wqaa_matmul_desc& d, const void* A, const void* B, const v
     if (start || stop) e = hipExtLaunchKernel(reinterpret_cast<const void*>(c.tail_fn), tgrid, block, tparams, c.tail_lds, stream, nullptr, stop, 0);
     else e = hipLaunchKernel(reinterpret_cast<const void*>(c.tail_fn), tgrid, block, tparams, c.tail_lds, stream);
   }
-  if (e == hipSuccess && c.mid && !mid_in_launch) {
+  if (e == hipSuccess && c.mid) {
     int mfc = c.mf, units = c.tiles_m * c.tiles_n * 8 * c.mf;
     void* rparams[] = {&a, &mfc, &units};
     const dim3 rgrid((unsigned)((units + 3) / 4)), rblock(256);

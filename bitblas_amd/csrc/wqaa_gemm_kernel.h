@@ -73,8 +73,6 @@ struct GemmArgs {
                        // remainder of a partial round goes out as a second launch of the 128-row tile, csrc/wqaa_gemm.hip)
   // mid-M member (wqaa_gemm_mid_kernel.h): the tiles' sync words (library-owned, zero between launches) and the bound of the
   // in-launch wait in 10 ns ticks (0: nobody waits - every portion goes through the abandon / sweep path; test aid)
-  unsigned* mid_sync = nullptr;
-  int mid_spin = 0;
 };
 
 // floor(2^32 / d) + 1: __umulhi(x, magic) == x / d whenever x * d < 2^32 (the host checks the largest x it can meet)

@@ -1,5 +1,5 @@
 // wqaa_gemm_mid_kernel.h - the mid-M member (M = 17 ... 128 per M-tile) of the W_q x A_fp16 MFMA GEMM family: ONE launch,
-// split-K by 8 with the partial sums exchanged INSIDE the launch (round 5; VERDICT r04 "missing" #1 / "next" #2).
+// split-K by 8, the slices summed by a small second launch (round 5; VERDICT r04 "missing" #1 / "next" #2).
 //
 // Replaces, for these shapes, the reference's split-K heuristic + atomicAdd epilogue
 // (bitblas/ops/general_matmul/tilelang/dequantize/matmul_dequantize_mma.py:127-168, :470-500) and this library's own
@@ -15,22 +15,13 @@
 //   * 8 waves = 4 (32 weight rows each: two 16-row fragments share every activation fragment read from LDS) x 2 (halves of
 //     the slice's k-steps): 2 waves per SIMD, 64 MFMAs per wave and k-step, half the LDS reads of the one-fragment form;
 //     the two k-halves add their accumulators through LDS (k-low + k-high: commutative, one order);
-//   * the 8 slices of a tile meet INSIDE the launch: PORTION p of the tile = the 16 output columns of weight fragment p; slice
-//     s owns portion s.  Every workgroup publishes the seven portions it does not own write-through (`sc0 sc1` stores, 1 KiB
-//     per wave instruction in the accumulators' own lane order - writer and reader agree on the map, nothing is transposed),
-//     drains them (`s_waitcnt vmcnt(0)`), takes a ticket on the tile's counter, waits - BOUNDED - until all eight have arrived,
-//     reads its portion of the seven others with `sc0 sc1` loads and adds them IN SLICE ORDER 0 .. 7 (its own partial sum at
-//     its place in that order): deterministic, run to run and placement to placement.  Correctness does not depend on which
-//     XCD a workgroup landed on: write-through stores + cache-bypassing loads are one of MI355X_MICROARCH's valid hand-off forms;
-//   * nobody waits unboundedly, so nothing deadlocks when the eight workgroups of a tile are NOT co-resident (a CU mask, a
-//     concurrent kernel holding LDS): a waiter whose bound expires publishes its own portion too, marks it ABANDONED and
-//     leaves; the LAST arriver of the tile (ticket 7 - everything is in memory by then) sweeps the abandoned portions and
-//     reduces them itself, reading all eight slices in the same order: the same bits.  The hand-back race (owner gives up
-//     just as the last arriver passes) is closed by the owner re-reading the counter after its compare-and-swap and taking the
-//     portion back if everybody has arrived.  `GemmArgs::mid_spin` = 0 forces every non-last workgroup down that path (test aid).
-//   * the tile's ten sync words clean up after themselves (the last portion to finish resets them), so a hipGraph replay - same
-//     kernel arguments - finds them zero again; they live in a library-owned, zero-initialised slab keyed by the workspace
-//     (csrc/wqaa_gemm.hip: mid_sync_words), never in the caller's scratch, which may hold anything.
+//   * the 8 slices of a tile meet BEHIND the launch: PORTION p of the tile = the 16 output columns of weight fragment p; every
+//     workgroup publishes its eight portions write-through (`sc0 sc1` stores, 1 KiB per wave instruction in the accumulators' own
+//     lane order - writer and reader agree on the map, nothing is transposed) and ends; wq_mid_reduce_kernel, behind the kernel
+//     boundary, adds the slices IN SLICE ORDER 0 .. 7: deterministic, run to run and placement to placement.
+//     (Round 5 also built the meeting INSIDE the launch - tickets on per-tile sync words, bounded waits, an abandon / sweep path,
+//     bit-identical to this form - and measured it slower: 6 us of software hand-shake against 5.1 us for the hardware's kernel
+//     boundary + reduce launch, profiles/r05_lab_mid_trace_v1.txt / _v3.txt.  Removed in round 6 with its sync-word slab.)
 #pragma once
 #include "wqaa_gemm_kernel.h"
 
@@ -56,14 +47,12 @@ struct MidPolicy {
   static constexpr bool WIDEMETA = (MODE_ == MD_S || MODE_ == MD_ZO || MODE_ == MD_ZR) && (NKH_ == 2 || NKH_ == 4);
   static constexpr int KEEP = MF >= 2 ? MF / 2 : 1;                 // M-fragments a wave finishes after the k-halves have met
   static constexpr int XCH_BYTES = 8 * KEEP * 2 * 1024;             // what the k-halves hand each other
-  static constexpr int OWN_BYTES = MF * 1024;                       // the workgroup's own portion, for its reducer waves
-  static constexpr int LDS_BYTES = (A_BYTES > XCH_BYTES + OWN_BYTES ? A_BYTES : XCH_BYTES + OWN_BYTES) + 64;
+  static constexpr int LDS_BYTES = (A_BYTES > XCH_BYTES ? A_BYTES : XCH_BYTES) + 64;
   static_assert(BITS == 4, "mid-M member: 4-bit weights");
   static_assert(LDS_BYTES <= 160 * 1024, "the slice must fit the CU's LDS");
 };
 
 constexpr int kMidSlices = 8;
-constexpr int kMidSyncWords = 16;           // per tile: [0] arrivals, [1] portions done, [2..9] portion state (0 free, 1 abandoned, 2 taken)
 
 __device__ __forceinline__ void st_wt(f32x4* dst, const f32x4 v) {      // write-through: visible to every CU once the store has been acknowledged
   // (the wait states: a vector-memory store of more than 64 bits reads its data registers over several cycles after issue, and the
@@ -84,7 +73,7 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_mid_kernel(const GemmArgs 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   // every kernel argument in one scalar round trip (see wq_gemm_decode_lds_kernel)
   asm volatile("" ::"s"(a.A), "s"(a.B), "s"(a.scale), "s"(a.zeros), "s"(a.C), "s"(a.M), "s"(a.N), "s"(a.K), "s"(a.kg), "s"(a.gq_shift),
-               "s"(a.row_bytes), "s"(a.tiles_n), "s"(a.ws), "s"(a.mid_sync), "s"(a.mid_spin), "s"((int)gridDim.x));
+               "s"(a.row_bytes), "s"(a.tiles_n), "s"(a.ws), "s"((int)gridDim.x));
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -298,8 +287,6 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_mid_kernel(const GemmArgs 
   // ---- 4. the k-halves meet: wave (nq, kh) finishes M-fragments [kh KEEP, kh KEEP + KEEP) and hands the others to (nq, 1 - kh) ----
   __syncthreads();                                     // the activation slice is dead: its LDS carries the exchange
   f32x4* xch = reinterpret_cast<f32x4*>(smem_raw);
-  f32x4* own = reinterpret_cast<f32x4*>(smem_raw + P::XCH_BYTES);
-  unsigned* lds_flag = reinterpret_cast<unsigned*>(smem_raw + P::LDS_BYTES - 64);
   const bool keeper = MF >= 2 || kh == 0;              // MF = 1: the k-low waves finish the only fragment
   constexpr int GIVE = MF >= 2 ? KEEP : 1;
   f32x4 fin[KEEP][2];                                   // the slice's partial sums this wave finishes: M-fragment keep_lo + x, fragment nf
@@ -337,190 +324,27 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_mid_kernel(const GemmArgs 
     else fin[0][0] = fin[0][1] = f32x4{0, 0, 0, 0};
   }
 
-  // ---- 5. publish the seven portions the workgroup does not own, keep its own in LDS for its reducer waves ----
+  // ---- 5. publish the workgroup's eight portions ----
   // chunk (tile, portion p, slice s, M-fragment mf): 1 KiB, lane-linear in the accumulator layout
   f32x4* ws = reinterpret_cast<f32x4*>(a.ws);
   auto chunk = [&](int p, int s, int mf) __attribute__((always_inline)) -> f32x4* {
     return ws + ((((long)tile * 8 + p) * kMidSlices + s) * MF + mf) * 64 + lane;
   };
-  if (a.mid_sync == nullptr) {
-    // TWO-LAUNCH seam (the default, round 5's measurement: profiles/r05_lab_mid_trace_v1.txt): all eight portions leave
-    // write-through and the launch ends - wq_mid_reduce_kernel, behind the kernel boundary, adds the slices in the same order.
-    // The hardware's boundary (~1.5 us) turned out cheaper than the software hand-shake it replaces (store acknowledgement 1.2-2.6 us
-    // + ticket 0.75 + poll 0.7 before the first partial sum can be read back)
-    if (keeper) {
-#pragma unroll
-      for (int nf = 0; nf < 2; ++nf)
-#pragma unroll
-        for (int x = 0; x < KEEP; ++x) st_wt(chunk(2 * nq + nf, split, keep_lo + x), fin[x][nf]);
-    }
-    WQ_TRACE(4);
-    WQ_TRACE_DUMP(8);
-    return;
-  }
-  if (keeper) {
-#pragma unroll
-    for (int nf = 0; nf < 2; ++nf) {
-      const int p = 2 * nq + nf;
-#pragma unroll
-      for (int x = 0; x < KEEP; ++x) {
-        if (p != split) st_wt(chunk(p, split, keep_lo + x), fin[x][nf]);
-        else own[(keep_lo + x) * 64 + lane] = fin[x][nf];
-      }
-    }
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the write-through stores have been acknowledged
-  WQ_TRACE(4);
-  __syncthreads();
-
-  unsigned* sync = a.mid_sync + (long)tile * kMidSyncWords;
-  auto bcast = [&](unsigned v) __attribute__((always_inline)) -> unsigned {      // thread 0's value to the workgroup
-    if (tid == 0) *lds_flag = v;
-    __syncthreads();
-    const unsigned r = *lds_flag;
-    __syncthreads();
-    return r;
-  };
-  auto arrivals = [&]() __attribute__((always_inline)) -> unsigned {
-    return __hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  };
-  // reduce portion p (16 columns x BM rows) in slice order; `mine`: slice `split`'s part comes from LDS (the owner's normal path)
-  auto reduce = [&](int p, bool mine) __attribute__((always_inline)) {
-    if (wave < MF) {
-      const int mf = wave;
-      // all eight slices' chunks in ONE asm block - loads and their wait: nothing the compiler schedules can sit between a load
-      // and the arrival of its data.  (The owner's own slot holds whatever an earlier launch left there; it is replaced below.)
-      f32x4 part[kMidSlices];
-      {
-        const f32x4* q0 = chunk(p, 0, mf);
-        const f32x4* q1 = chunk(p, 1, mf);
-        const f32x4* q2 = chunk(p, 2, mf);
-        const f32x4* q3 = chunk(p, 3, mf);
-        const f32x4* q4 = chunk(p, 4, mf);
-        const f32x4* q5 = chunk(p, 5, mf);
-        const f32x4* q6 = chunk(p, 6, mf);
-        const f32x4* q7 = chunk(p, 7, mf);
-        asm volatile(
-            "global_load_dwordx4 %0, %8, off sc0 sc1\n\t"
-            "global_load_dwordx4 %1, %9, off sc0 sc1\n\t"
-            "global_load_dwordx4 %2, %10, off sc0 sc1\n\t"
-            "global_load_dwordx4 %3, %11, off sc0 sc1\n\t"
-            "global_load_dwordx4 %4, %12, off sc0 sc1\n\t"
-            "global_load_dwordx4 %5, %13, off sc0 sc1\n\t"
-            "global_load_dwordx4 %6, %14, off sc0 sc1\n\t"
-            "global_load_dwordx4 %7, %15, off sc0 sc1\n\t"
-            "s_waitcnt vmcnt(0)"
-            : "=&v"(part[0]), "=&v"(part[1]), "=&v"(part[2]), "=&v"(part[3]), "=&v"(part[4]), "=&v"(part[5]), "=&v"(part[6]), "=&v"(part[7])
-            : "v"(q0), "v"(q1), "v"(q2), "v"(q3), "v"(q4), "v"(q5), "v"(q6), "v"(q7)
-            : "memory");
-      }
-      if (mine) {
-        const f32x4 o = own[mf * 64 + lane];
-#pragma unroll
-        for (int s = 0; s < kMidSlices; ++s)
-          if (s == split) part[s] = o;
-      }
-      f32x4 sum = part[0];
-#pragma unroll
-      for (int s = 1; s < kMidSlices; ++s) sum += part[s];
-      const int m = m0 + mf * 16 + fr;
-      const int nb = tile_n * P::BN + p * 16 + kb * 4;
-      if (m < a.M && nb < a.N) store_quad<P>(a, sum, m, nb);
-    }
-  };
-  // a portion is finished: the eighth one puts the tile's sync words back to zero (everybody has left the words alone by then:
-  // each of the eight workgroups either reduced its portion or abandoned it and, at most, fails one compare-and-swap on a
-  // word that is zero again - see the take-back below)
-  auto portion_done = [&]() __attribute__((always_inline)) {
-    if (tid == 0) {
-      const unsigned d = __hip_atomic_fetch_add(sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (d == kMidSlices - 1) {
-#pragma unroll
-        for (int i = 2; i < 2 + kMidSlices; ++i) __hip_atomic_store(sync + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(sync + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(sync, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-    }
-  };
-
-  unsigned ticket = 0;
-  if (tid == 0) ticket = __hip_atomic_fetch_add(sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  ticket = bcast(ticket);
-  WQ_TRACE(5);
-
-  if (ticket == kMidSlices - 1) {
-    // LAST arriver: every slice's published portions are in memory.  Its own portion first, then whatever was abandoned.
-    WQ_TRACE(6);
-    reduce(split, true);
-    WQ_TRACE(7);
-    portion_done();
-    for (int p = 0; p < kMidSlices; ++p) {
-      if (p == split) continue;
-      unsigned got = 0;
-      if (tid == 0) {
-        unsigned expect = 1u;
-        got = __hip_atomic_compare_exchange_strong(sync + 2 + p, &expect, 2u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1u : 0u;
-      }
-      got = bcast(got);
-      if (got) {
-        reduce(p, false);
-        portion_done();
-      }
-    }
-    WQ_TRACE_DUMP(8);
-    return;
-  }
-
-  // the others wait, bounded, for the tile's arrivals to reach eight (one lane polls with cache-bypassing loads and sleeps in between)
-  unsigned all_here = 0;
-  if (tid == 0) {
-    const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();       // 100 MHz
-    const unsigned long long bound = (unsigned long long)(unsigned)a.mid_spin;
-    for (;;) {
-      if (arrivals() >= (unsigned)kMidSlices) { all_here = 1; break; }
-      if (__builtin_amdgcn_s_memrealtime() - t_start >= bound) break;
-      __builtin_amdgcn_s_sleep(2);
-    }
-  }
-  all_here = bcast(all_here);
-  WQ_TRACE(6);
-  if (all_here) {
-    reduce(split, true);
-    WQ_TRACE(7);
-    portion_done();
-    WQ_TRACE_DUMP(8);
-    return;
-  }
-  // ABANDON: publish the own portion as well, mark it, and leave - unless everybody turned up in the meantime
+  // all eight portions leave write-through and the launch ends - wq_mid_reduce_kernel, behind the kernel boundary, adds the
+  // slices in slice order.  The hardware's boundary (~1.5 us) is cheaper than the software hand-shake that could replace it
+  // (store acknowledgement 1.2-2.6 us + ticket 0.75 + poll 0.7 before the first partial sum can be read back: measured, round 5)
   if (keeper) {
 #pragma unroll
     for (int nf = 0; nf < 2; ++nf)
-      if (2 * nq + nf == split) {
 #pragma unroll
-        for (int x = 0; x < KEEP; ++x) st_wt(chunk(split, split, keep_lo + x), fin[x][nf]);
-      }
+      for (int x = 0; x < KEEP; ++x) st_wt(chunk(2 * nq + nf, split, keep_lo + x), fin[x][nf]);
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  unsigned back = 0;
-  if (tid == 0) {
-    unsigned expect = 0u;
-    __hip_atomic_compare_exchange_strong(sync + 2 + split, &expect, 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (arrivals() >= (unsigned)kMidSlices) {          // the last arriver may have swept past this portion already: take it back
-      unsigned e1 = 1u;
-      back = __hip_atomic_compare_exchange_strong(sync + 2 + split, &e1, 2u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1u : 0u;
-    }
-  }
-  back = bcast(back);
-  if (back) {
-    reduce(split, true);
-    portion_done();
-  }
+  WQ_TRACE(4);
   WQ_TRACE_DUMP(8);
 }
 
 // second launch of the two-launch seam: one wave per unit (tile, portion p, M-fragment mf) - the eight slices' chunks (1 KiB each, the
-// accumulators' lane order) added in slice order 0 .. 7, cast, + bias, stored.  Same order as the in-launch meeting: same bits.
+// accumulators' lane order) added in slice order 0 .. 7, cast, + bias, stored.  
 struct MidStorePolicy {
   static constexpr int AT = AT_F16;
   static constexpr bool BF = false;

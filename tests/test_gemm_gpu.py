@@ -11,7 +11,7 @@ import pytest
 import torch
 
 import wqaa_oracle as oracle
-from helpers import contract, assert_fp_parity, hip_output, make_case, oracle_output
+from helpers import case_contract, contract, assert_fp_parity, hip_output, make_case, oracle_output
 
 pytestmark = pytest.mark.gpu
 
@@ -399,4 +399,4 @@ def test_k_split_request_is_honoured_and_exact_enough(M, ks):
     mm = bitblas.MatmulWithSplitK(cfg, enable_tuning=False, strict_reference=M > 2)
     got, _ = hip_output(case, matmul=mm)
     assert mm.plans[M]["split_k"] == ks, mm.plans[M]
-    assert_fp_parity(got, oracle_output(case), **contract(K, default_members=M <= 2, m=M))
+    assert_fp_parity(got, oracle_output(case), **case_contract(case, default_members=M <= 2, m=M))

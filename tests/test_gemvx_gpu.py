@@ -17,7 +17,7 @@ import pytest
 import torch
 
 import wqaa_oracle as oracle
-from helpers import contract, assert_fp_parity, hip_output, make_case, oracle_output
+from helpers import case_contract, contract, assert_fp_parity, hip_output, make_case, oracle_output
 
 pytestmark = pytest.mark.gpu
 
@@ -50,7 +50,7 @@ def check(case, plan_kw=None):
         assert_fp_parity(got, want_exact, rtol=1e-3, atol_frac=6e-4)    # + the float16 bias add
     else:
         assert_fp_parity(got, want_exact, rtol=2e-5, atol_frac=2e-5)
-    assert_fp_parity(got, oracle_output(case), **contract(case["K"], default_members=True, m=M))      # the reference's definition: include/wqaa.h's contract
+    assert_fp_parity(got, oracle_output(case), **case_contract(case, default_members=True, m=M))      # the reference's definition: include/wqaa.h's contract
     return got, mm
 
 

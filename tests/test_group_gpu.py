@@ -11,7 +11,7 @@ import torch
 
 import bitblas_amd as bitblas
 from bitblas_amd import group as wgroup
-from helpers import contract, _to_dev, assert_fp_parity, make_case, oracle_output
+from helpers import case_contract, contract, _to_dev, assert_fp_parity, make_case, oracle_output
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -64,13 +64,13 @@ def test_qkv_and_gate_up_of_a_llama2_7b_layer(strict):
     ops, outs, plan = run_both(qkv, strict)
     assert plan["plan"]["name"].endswith("_x3")
     for c, o in zip(qkv, outs):
-        assert_fp_parity(o.cpu().numpy(), oracle_output(c), **contract(c["K"], default_members=not strict, m=1))
+        assert_fp_parity(o.cpu().numpy(), oracle_output(c), **case_contract(c, default_members=not strict, m=1))
     gu = [int4_case(11008, seed=s) for s in (4, 5)]
     gu[1]["A"] = gu[0]["A"]
     ops, outs, plan = run_both(gu, strict)
     # 2 x 688 row-group blocks, one workgroup each (the grid of a group is not capped at what the chip holds at once)
     for c, o in zip(gu, outs):
-        assert_fp_parity(o.cpu().numpy(), oracle_output(c), **contract(c["K"], default_members=not strict, m=1))
+        assert_fp_parity(o.cpu().numpy(), oracle_output(c), **case_contract(c, default_members=not strict, m=1))
 
 
 @pytest.mark.parametrize("strict", [False, True])
@@ -82,7 +82,7 @@ def test_unequal_members_grouped_query_attention(strict, M):
         c["A"] = cases[0]["A"]
     ops, outs, _ = run_both(cases, strict)
     for c, o in zip(cases, outs):
-        assert_fp_parity(o.cpu().numpy(), oracle_output(c), **contract(c["K"], default_members=not strict, m=1))
+        assert_fp_parity(o.cpu().numpy(), oracle_output(c), **case_contract(c, default_members=not strict, m=1))
 
 
 @pytest.mark.parametrize("kw", [

@@ -65,7 +65,7 @@ def test_weight_only_linear(W_dtype, group_size, zeros_mode, m):
     # One group over all of K (group_size = -1) is where the TE definition's per-element rounding averages out least: here the
     # REAL-valued product (float64 below) sits 1.6e-3 rms from it at one of the 1024 outputs - so that case gets 2e-3 against the
     # definition, and every M <= 2 case is also held to 1e-3 against the real-valued product, which is what the member computes
-    assert_fp_parity(got, want, **contract(K, default_members=True, m=m))
+    assert_fp_parity(got, want, **contract(K, default_members=True, m=m, group_size=g, zeros_mode=zeros_mode))
     if m <= 2 and zeros_mode != "quantized":
         zf = np.repeat(zeros.astype(np.float64), g, axis=1)
         sf = np.repeat(scale.astype(np.float64), g, axis=1)

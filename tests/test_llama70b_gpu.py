@@ -12,7 +12,7 @@ import pytest
 import torch
 
 import wqaa_oracle as oracle
-from helpers import _to_dev, assert_fp_parity, contract, hip_output, make_case, oracle_output
+from helpers import _to_dev, assert_fp_parity, case_contract, hip_output, make_case, oracle_output
 
 import bitblas_amd as bitblas
 
@@ -30,7 +30,7 @@ def test_gemv_int4_m1_llama70b_default_and_strict_members(N, K):
     got, mm = hip_output(case)
     assert mm.plans[1]["kernel_family"] == 1 and "_gemvx_" in mm.plans[1]["name"], mm.plans[1]
     want = oracle_output(case)
-    assert_fp_parity(got, want, **contract(K, default_members=True, m=1))
+    assert_fp_parity(got, want, **case_contract(case, default_members=True, m=1))
     real = oracle.matmul_dequant_exact(case["A"], case["codes"], source_format="int", bit=4, scale=case["scale"], group_size=128,
                                        out_dtype="float32")
     assert_fp_parity(got, real.astype(np.float16), rtol=1e-3, atol_frac=6e-4)
@@ -74,7 +74,7 @@ def test_group_launch_llama70b_bit_identical_to_single_calls(Ns, K):
     for op, c, w, o in zip(ops, cases, Ws, outs):
         assert torch.equal(o, op(A, *w)), plan
         c["A"] = cases[0]["A"]
-        assert_fp_parity(o.cpu().numpy(), oracle_output(c), **contract(K, default_members=True, m=1))
+        assert_fp_parity(o.cpu().numpy(), oracle_output(c), **case_contract(c, default_members=True, m=1))
 
 
 @pytest.mark.parametrize("N,K", LLAMA70B[:3])

@@ -133,4 +133,5 @@ def test_hip_path_reproduces_the_reference_tests_expectation(i, members):
     record_margin(f"optest/{IDS[i]}/{members}/{mm.plans[c['rows']]['name']}", out.float().cpu().numpy(), c["expected"])
     from helpers import contract
     assert_fp_parity(out.float().cpu().numpy(), c["expected"],
-                     **contract(cfg["K"], default_members=members == "default", m=c["rows"], bf16=cfg["A_dtype"] == "bfloat16"))
+                     **contract(cfg["K"], default_members=members == "default", m=c["rows"], bf16=cfg["A_dtype"] == "bfloat16",
+                                group_size=cfg.get("group_size"), zeros_mode=c.get("zeros_mode")))
