@@ -100,13 +100,13 @@ def make_linear(N, K, device, gen):
 # constructs the operator; the contract is include/wqaa.h's (at `strict_reference`), tests/helpers.py: contract
 NUMERICS = "default members (strict_reference=0): exact products, 1e-3 rel + 2e-3 rms vs the TE definition; *_strict members: per-element rounding, 1e-3 + 1e-3"
 
-GRAPH_WARM_MS = float(os.environ.get("WQAA_BENCH_WARM_MS", "25"))
+GRAPH_WARM_MS = 25.0
 
 
 def graph_time(device, launch_all, n_launches, replays=5, warm_ms=None):
     """Capture `launch_all` (a sequence of kernel launches on the current stream) into one hipGraph,
     replay it, return the average duration of one launch in seconds (median over replays), measured
-    with events on the stream the graph runs on.  Untimed replays first, `warm_ms` of them (default 25 ms, WQAA_BENCH_WARM_MS):
+    with events on the stream the graph runs on.  Untimed replays first, `warm_ms` of them (default 25 ms):
     a member is timed at the clocks the chip settles at under its load, not on the ramp out of the idle state the
     host-side set-up left it in (same-box A/B of the M = 4096 GEMM: 117.7 us timed cold against 105.3 sustained,
     profiles/r04_ab_bench_warm.txt)."""

@@ -174,7 +174,9 @@ static bool two_pass_forced() {
   static thread_local bool on = false;
   const unsigned ep = g_plan_epoch.load(std::memory_order_relaxed);
   if (ep != seen_epoch) {
-    on = getenv("WQAA_TWO_PASS") != nullptr;
+    int v;
+    const char* f = getenv("WQAA_TWO_PASS");
+    on = f && (knob("WQAA_TWO_PASS", "min_m", &v) || (*f >= '0' && *f <= '9'));
     seen_epoch = ep;
   }
 
@@ -182,10 +184,11 @@ static bool two_pass_forced() {
 }
 
 // The two-pass member as the PLAN sees it: eligible, and - for the automatic form (no caller threshold, not forced) - its scratch
-// N K sizeof(A_dtype) within the cap (WQAA_TWO_PASS_AUTO_MAX_MB, default 256).  wqaa_select, wqaa_workspace_bytes and the call agree.
+// N K sizeof(A_dtype) within the cap (WQAA_TWO_PASS=auto_max_mb=N, default 256).  wqaa_select, wqaa_workspace_bytes and the call agree.
 static size_t two_pass_auto_cap() {
-  const char* f = getenv("WQAA_TWO_PASS_AUTO_MAX_MB");
-  return (size_t)(f ? atol(f) : 256) << 20;
+  int mb = 256;                                  // WQAA_TWO_PASS=auto_max_mb=N
+  (void)knob("WQAA_TWO_PASS", "auto_max_mb", &mb);
+  return (size_t)(mb < 0 ? 0 : mb) << 20;
 }
 static bool two_pass_planned(const wqaa_matmul_desc& d, int m) {
   if (!gemm_two_pass_eligible(d, m)) return false;
@@ -273,7 +276,7 @@ static int matmul_impl(const wqaa_matmul_desc* desc, const void* A, const void* 
     const bool automatic = desc->two_pass_min_m <= 0 && !two_pass_forced();
     if (tp && automatic) {
       // the AUTOMATIC form never turns a call that used to need no scratch into a refused or a memory-hungry one:
-      //  * its scratch is N K sizeof(A_dtype) per stream - capped (WQAA_TWO_PASS_AUTO_MAX_MB, default 256: a 8192 x 28672 layer
+      //  * its scratch is N K sizeof(A_dtype) per stream - capped (WQAA_TWO_PASS=auto_max_mb=N, default 256: a 8192 x 28672 layer
       //    would pin 470 MB per stream to save ~15 % of a prefill call);
       //  * a caller workspace too small for it (sized for the fused member's needs: none), or a library pool that cannot grow
       //    (stream capture), means the fused member runs;

@@ -145,6 +145,33 @@ int debug_decode_launch(const void* packed, int64_t nwords, int w_format, int bi
 // planning - bumps the epoch, so the tuning variables are PLAN-time switches: a change takes effect at the next
 // wqaa_select() of any operator, not in the middle of a stream of calls.
 extern std::atomic<unsigned> g_plan_epoch;
+
+// Tuning / test aids.  TWO environment variables hold them all, each a comma-separated list of key[=value] tokens read at plan
+// time (the choices are memoised per plan epoch: wqaa_select and the plan queries bump it):
+//   WQAA_GEMV_TUNE   exact=0|1|2  kw=N  grid=N  group_grid=N  areg=0|1  chunk=0
+//   WQAA_GEMM_TUNE   ksplit=N  mid=0|1|2  pp_tile=0|128|256  pp_bn=128  pp_tail=0|1  pp8_wide=0|1  wide=0  ws_policy=BITS
+//                    decode=0|1  decode_force=0|1  decode_persist=0  decode_long=0..4
+// (README.md "Tuning variables" says what each key pins; the parity tests use them to put one member form next to another.)
+// knob(var, key, &v): true and v = the token's value (1 for a bare key) when `var` holds the key.
+inline bool knob(const char* var, const char* key, int* value) {
+  const char* s = getenv(var);
+  if (!s) return false;
+  const size_t kl = strlen(key);
+  while (*s) {
+    const char* e = strchr(s, ',');
+    const size_t n = e ? (size_t)(e - s) : strlen(s);
+    if (n >= kl && strncmp(s, key, kl) == 0 && (n == kl || s[kl] == '=')) {
+      *value = n == kl ? 1 : atoi(s + kl + 1);
+      return true;
+    }
+    if (!e) break;
+    s = e + 1;
+  }
+  return false;
+}
+inline bool gemv_knob(const char* key, int* value) { return knob("WQAA_GEMV_TUNE", key, value); }
+inline bool gemm_knob(const char* key, int* value) { return knob("WQAA_GEMM_TUNE", key, value); }
+inline bool gemm_knob_set(const char* key) { int v; return gemm_knob(key, &v); }
 template <class Choice, int WAYS = 16>
 struct ChoiceMemo {
   struct Entry {

@@ -192,7 +192,7 @@ static int gemm_choose(const wqaa_matmul_desc& d, int m, GemmChoice* c, bool fus
   const int nsteps = d.K / c->ks;
   // The ping-pong members (wqaa_gemm_pp_kernel.h), where one exists: 4-bit weights x float16, 2-bit weights x int8, dense fp8;
   // four k-tiles (256 / 512 / 128 k) per trip, groups of 128 * 2^i (Scale / Zeros rows 4-byte aligned: K / g even), float16 /
-  // int32 output through LDS (N a multiple of 8), 32-bit buffer offsets.  WQAA_GEMM_PP=0: the lockstep members only.
+  // int32 output through LDS (N a multiple of 8), 32-bit buffer offsets.  WQAA_GEMM_TUNE=pp_tile=0: the lockstep members only.
   // Which tile: a workgroup is alone on its CU, so time goes by ROUNDS of the chip.  Same-box medians, uint4 g128 + zeros, K =
   // 4096 (profiles/r03_lab_pp128.txt): a round of x 256 x 256 tiles 80 + 0.113 x us (109 full: the chip is power-limited), of
   // 128 x 256 tiles 55 + 0.052 x (68.5 full), the lockstep 128 x 128 member 12 + 40 per round of 256 tiles, in half rounds.  All
@@ -219,7 +219,7 @@ static int gemm_choose(const wqaa_matmul_desc& d, int m, GemmChoice* c, bool fus
                         : (d.out_dtype == WQAA_F32 || d.out_dtype == ((c->flags & FL_BF16) ? WQAA_BF16 : WQAA_F16));
     const long a_bytes = (long)m * d.K * (c->at == AT_F16 ? 2 : 1), w_bytes = (long)d.N * d.K * c->bits / 8;
     const bool shape_ok = epi_ok && d.K % kb == 0 && meta_ok && out_ok && d.N % 8 == 0 && a_bytes + 256L * d.K * 2 < (1L << 31) &&
-                          w_bytes < (1L << 31) && d.k_split_hint <= 1 && getenv("WQAA_GEMM_KSPLIT") == nullptr;
+                          w_bytes < (1L << 31) && d.k_split_hint <= 1 && !gemm_knob_set("ksplit");
     auto rounds_time = [&](long tiles, double base, double slope) {
       const long full = tiles / cus_, rem = tiles % cus_;
       return (double)full * (base + slope * cus_) + (rem ? base + slope * (double)rem : 0.0);
@@ -243,14 +243,15 @@ static int gemm_choose(const wqaa_matmul_desc& d, int m, GemmChoice* c, bool fus
     // A shape that leaves the last round of 256 x 256 tiles mostly empty (2048 x 11008: 344 tiles = one round + 88) pays a whole
     // tile's latency for it (80 + 0.113 x).  The columns of that remainder go out as a SECOND launch of the 128-row tile - twice
     // the workgroups, 55 + 0.052 x - behind a launch of whole rounds: N-tiles [0, n_main) by the first, the rest by the second
-    // (GemmArgs::tile_n_off); + ~3 us of boundary.  WQAA_GEMM_PP_TAIL=0: never.
+    // (GemmArgs::tile_n_off); + ~3 us of boundary.  WQAA_GEMM_TUNE=pp_tail=0: never.
     int hy_n_main = 0;
     double thy = 1e30;
     {
-      const char* tf = getenv("WQAA_GEMM_PP_TAIL");
+      int tail_on = 1;
+      (void)gemm_knob("pp_tail", &tail_on);
       const long tm256 = (m + 255) / 256, tm128 = (m + 127) / 128;
       const long T = tm256 * tiles_n256;
-      if (fn256 && fn128 && (!tf || atoi(tf) != 0) && T > cus_ && T % cus_ != 0 && tiles_n256 >= 2) {
+      if (fn256 && fn128 && tail_on != 0 && T > cus_ && T % cus_ != 0 && tiles_n256 >= 2) {
         const long n_fit = ((T / cus_) * cus_) / tm256;
         for (long nm = n_fit; nm >= n_fit - 1 && nm >= 1; --nm) {
           if (nm >= tiles_n256) continue;
@@ -260,10 +261,11 @@ static int gemm_choose(const wqaa_matmul_desc& d, int m, GemmChoice* c, bool fus
       }
     }
     int bm = 0, bn = 256;
-    if (const char* f = getenv("WQAA_GEMM_PP_BM")) {               // tuning aid: force a tile (0: the lockstep members; 128 with
-      bm = atoi(f);                                                // WQAA_GEMM_PP_BN=128: the 128 x 128 tile)
-      const char* fb = getenv("WQAA_GEMM_PP_BN");
-      if (bm == 128 && fb && atoi(fb) == 128 && fns) bn = 128;
+    int forced_bm = 0, forced_bn = 0;
+    if (gemm_knob("pp_tile", &forced_bm)) {                        // tuning aid: force a tile (pp_tile=0: the lockstep members; 128 with
+      bm = forced_bm;                                              // pp_bn=128: the 128 x 128 tile)
+      (void)gemm_knob("pp_bn", &forced_bn);
+      if (bm == 128 && forced_bn == 128 && fns) bn = 128;
       else if ((bm == 256 && !fn256) || (bm == 128 && !fn128)) bm = 0;
     } else {
       double best = k_ok ? 0.97 * tlock : 1e30;      // (K off the lockstep members' grid: any ping-pong member that takes it)
@@ -311,13 +313,13 @@ static int gemm_choose(const wqaa_matmul_desc& d, int m, GemmChoice* c, bool fus
   // the old members ran long k ranges or several rounds: 64 x 4096 x 8192 17.9 vs 21.1, 32 x 4096 x 8192 13.8 vs 15.2, 64 x 8192 x 4096
   // 18.4 vs 20.9, 64 x 11008 x 4096 23.9 vs 26.4.  It LOSES at up to 64 rows in one round at K = 4096 (M = 32 11.0 vs 9.6, M = 64 13.8 vs
   // 12.3: the split-K skinny member's smaller workgroups overlap), at 128 rows over several rounds (11008 x 4096 39.0 vs 33.8) and at
-  // K = 2048 (16.4 vs 13.1) - those keep their members.  WQAA_GEMM_MID=0: never; WQAA_GEMM_MID_FORCE=1: wherever the shape fits (the
+  // K = 2048 (16.4 vs 13.1) - those keep their members.  WQAA_GEMM_TUNE=mid=0: never; mid=2: wherever the shape fits (the
   // parity tests run every instantiation that way).
   if (!no_mid && !fused_epilogue && c->at == AT_F16 && !(c->flags & FL_BF16) && c->kind == DK_INT4 && d.k_split_hint <= 1 &&
-      getenv("WQAA_GEMM_KSPLIT") == nullptr && m > 16) {
-    const char* mf_ = getenv("WQAA_GEMM_MID");
-    const char* ff_ = getenv("WQAA_GEMM_MID_FORCE");
-    const bool force = ff_ && atoi(ff_) != 0;
+      !gemm_knob_set("ksplit") && m > 16) {
+    int mid_knob = 1;                                         // WQAA_GEMM_TUNE=mid=0: never; mid=2: wherever a member exists (tests)
+    (void)gemm_knob("mid", &mid_knob);
+    const bool force = mid_knob == 2;
     const int nkh = d.K % 2048 == 0 ? d.K / 2048 : 0;
     const int tm = (m + 127) / 128;
     const int rows = (m + tm - 1) / tm;                       // rows per M-tile
@@ -333,7 +335,7 @@ static int gemm_choose(const wqaa_matmul_desc& d, int m, GemmChoice* c, bool fus
     // (128 rows on half a chip of workgroups - N = 2048: 16.0 vs 14.1 us - keeps its member: at least three quarters of a round)
     const bool measured = m <= 128 && (mf == 8 ? (nkh == 2 && wgs <= cus_ && 4 * wgs >= 3L * cus_)
                                                : (nkh == 4 ? wgs <= 3L * cus_ : (nkh == 2 && wgs > cus_ && wgs <= 3L * cus_)));
-    if (fn && meta_ok && (!mf_ || atoi(mf_) != 0) && (force || measured) && tiles <= 256 &&
+    if (fn && meta_ok && mid_knob != 0 && (force || measured) && tiles <= 256 &&
         (long)m * d.K * 2 < (1L << 32) && d.K < (1 << 23) && m < (1 << 23) && (c->mode != MD_ZQ || d.N % 2 == 0)) {
       c->mid = 1;
       c->mid_nkh = nkh;
@@ -350,7 +352,7 @@ static int gemm_choose(const wqaa_matmul_desc& d, int m, GemmChoice* c, bool fus
     }
   }
   // small decode batches: one launch with K split across the 8 waves of a workgroup, no partial sums
-  // in memory (WQAA_GEMM_DECODE=0: back to the split-K skinny member + reduce launch).  Every
+  // in memory (WQAA_GEMM_TUNE=decode=0: back to the split-K skinny member + reduce launch).  Every
   // workgroup reads all M activation rows, so it pays only while M and the number of 16-row weight
   // fragments are small.  Same-box A/B against the skinny member, uint4 g128 + zeros: 4096^2 M=5
   // 7.6 vs 9.2 us, M=8 8.2 vs 9.3, M=16 9.5 vs 9.9, M=32 13.2 vs 11.6; 11008x4096 M=8 18.3 vs 16.2;
@@ -376,28 +378,30 @@ static int gemm_choose(const wqaa_matmul_desc& d, int m, GemmChoice* c, bool fus
   // float types, 8192 for int8) a workgroup stages the activations once and takes fragments blk, blk + grid, ... with the next
   // fragments' weights in flight; the grid is capped at one workgroup per CU.  Partial rounds no longer cost a round:
   // 11008 x 4096 M = 3 ... 16 13.3-15.1 us (skinny + reduce) -> 11.6-12.6; 8192 9.8-11.3 -> 8.6-9.7; 5120 9.2-10.6 -> 8.2-9.2
-  // (profiles/r04_ab_decode_persistent.txt).  WQAA_GEMM_DECODE_PERSIST=0: off.
+  // (profiles/r04_ab_decode_persistent.txt).  WQAA_GEMM_TUNE=decode_persist=0: off.
   bool persist = false, ksl_ok = false, ksl_take = false, wpf_take = false;
   int ksl_lds = 0, wpf_lds = 0;
   {
-    const char* pf = getenv("WQAA_GEMM_DECODE_PERSIST");
+    int persist_knob = 1, long_knob = 1, force_knob = -1;     // WQAA_GEMM_TUNE=decode_persist=0 / decode_long=N / decode_force=0|1
+    (void)gemm_knob("decode_persist", &persist_knob);
+    const bool have_long = gemm_knob("decode_long", &long_knob);
+    const bool have_force = gemm_knob("decode_force", &force_knob);
     // (float types, up to three rounds of fragments: 22016 x 4096 - 5.4 per workgroup - and int2 x int8 measured no better
     // than the skinny member + reduce)
     // (the hand-counted form - 4-bit weights, one Scale / Zeros group per k-step - takes up to six rounds of fragments, two batches)
     const bool counted = c->at == AT_F16 && (c->kind == DK_INT4 || c->kind == DK_LUT4) && (c->mode == MD_S || c->mode == MD_ZO || c->mode == MD_ZR) &&
                          g == c->ks && ((d.K / g) & 1) == 0 && d.K / g >= 4;     // (8-byte metadata loads as instructions: 4-byte alignment; four groups per load: a row of two would be read 4 bytes past its end)
     const int pgrid = (cus_ / 8) * 8;                 // the persistent grid (whole XCD rounds): what bounds the fragments per workgroup
-    persist = (c->at == AT_F16 || c->at == AT_F8) && frags > cus_ && frags <= (counted ? 6 : 3) * pgrid && nsteps <= 8 * 4 && (!pf || atoi(pf) != 0);
+    persist = (c->at == AT_F16 || c->at == AT_F8) && frags > cus_ && frags <= (counted ? 6 : 3) * pgrid && nsteps <= 8 * 4 && persist_knob != 0;
     // round 4 - WHOLE TILE, K > 4096 (hand-counted formats): a wave's k-range is nbk = 2 or 3 blocks of 4 k-steps; with slots of
     // nq = ceil(M / 4) KiB per k-step (only the row groups below M) it fits the wave's 16 KiB region for M <= 8 (nbk 2: K <= 8192)
-    // and M <= 4 (nbk 3: K <= 12288); units (fragment, block) <= 6 per workgroup.  WQAA_GEMM_DECODE_LONG=0: off.
-    const char* lf = getenv("WQAA_GEMM_DECODE_LONG");
+    // and M <= 4 (nbk 3: K <= 12288); units (fragment, block) <= 6 per workgroup.  WQAA_GEMM_TUNE=decode_long=0: off.
     const int run = (((nsteps + 7) / 8) + 3) & ~3, nbk = run / 4, nq = (m + 3) / 4;
     // Taken where there is more than one fragment per workgroup (12288 x 8192 M = 3 / 8: 22.2 / 23.7 us on the skinny member -> 17.7 /
     // 18.0, 8192^2 15.0 / 16.2 -> 12.7 / 13.4, 10240 x 8192 20.2 / 21.2 -> 17.4 / 17.8); with one fragment each (N <= 4096) asking for
     // everything at once measured the same as block by block - 4096 x 11008 M = 4 10.8 vs 11.0 us - and the old form stays
     // (profiles/r04_ab_decode_long.txt).
-    const int lmode = lf ? atoi(lf) : 1;               // 0: none of round 4 / 5's forms; 1: the measured rules; 2: whole tile only (round 4's selector); 3: K-sliced
+    const int lmode = have_long ? long_knob : 1;               // 0: none of round 4 / 5's forms; 1: the measured rules; 2: whole tile only (round 4's selector); 3: K-sliced
                                                        // wherever it fits; 4: a wave per fragment wherever it fits
     if (counted && nbk >= 2 && nbk <= 3 && run * nq <= 16 && frags > cus_ && frags <= (6 / nbk) * pgrid && lmode != 0) {
       c->decode_long = 1;
@@ -410,7 +414,7 @@ static int gemm_choose(const wqaa_matmul_desc& d, int m, GemmChoice* c, bool fus
     // 128 M / K of the weights' bytes in partial sums - hence long K only.
     ksl_lds = run * nq * 1024 + 4096;
     ksl_ok = !no_mid && counted && !(c->flags & FL_BF16) && nsteps > 32 && ksl_lds <= 160 * 1024 && frags >= 8 && lmode != 0 && lmode != 2 &&
-             d.k_split_hint <= 1 && getenv("WQAA_GEMM_KSPLIT") == nullptr && (long)m * d.K * 2 < (1L << 32) &&
+             d.k_split_hint <= 1 && !gemm_knob_set("ksplit") && (long)m * d.K * 2 < (1L << 32) &&
              pick_gemm(c->kind, c->layout, c->at, c->mode, c->flags, 212) != nullptr;
     // WHERE (same-process A/B against the members it stands in for, uint4 g128 + zeros, us; tools/r05_ab_kslice.py, profiles/r05_ab_kslice.txt):
     // two rounds of fragments or more at K >= 8192 with M = 13 ... 16 - 8192 x 28672 41.1 vs 54.9 (split-K skinny + reduce), 12288 x 8192 22.9
@@ -427,7 +431,7 @@ static int gemm_choose(const wqaa_matmul_desc& d, int m, GemmChoice* c, bool fus
     // round 5 - A WAVE PER FRAGMENT, the whole of K (member 213, plan `xdlw`): the same walk with one slice.  The workgroup's waves share
     // the activation tile (nsteps x nq KiB: K <= 4096 at M <= 16, K <= 8192 at M <= 8) and each adds ALL of K for its own fragments in one
     // accumulator and stores them - no meeting, no barrier behind the tile's, no partial sums (other summation order than the forms whose
-    // eight waves split K: other bits, same contract).  (lab switch WQAA_GEMM_DECODE_LONG=4: wherever it fits)
+    // eight waves split K: other bits, same contract).  (lab switch WQAA_GEMM_TUNE=decode_long=4: wherever it fits)
     wpf_lds = ((nsteps + 3) & ~3) * nq * 1024 + 4096;
     // WHERE (tools/r05_ab_wpf.py, profiles/r05_ab_wpf.txt; uint4 g128 + zeros, us): outputs wider than the persistent / whole-tile forms
     // reach, which went to the split-K skinny member + reduce - 32000 x 4096 (a vocabulary projection) M = 4 / 8 / 16 21.3 / 21.4 / 22.6 vs
@@ -436,8 +440,8 @@ static int gemm_choose(const wqaa_matmul_desc& d, int m, GemmChoice* c, bool fus
     // 22016 x 4096 19.3 vs 17.3, 11008 x 4096 14.2 vs 9.7, 8192^2 22.5 vs 12.5.
     const bool wpf_ok = !ksl_take && counted && !(c->flags & FL_BF16) && wpf_lds <= 160 * 1024 && frags >= 8 && (long)m * d.K * 2 < (1L << 32) &&
                         pick_gemm(c->kind, c->layout, c->at, c->mode, c->flags, 213) != nullptr && lmode != 0 && lmode != 2 && lmode != 3;
-    // (not where the A/B aids of the older forms are in use: WQAA_GEMM_DECODE_PERSIST=0 / WQAA_GEMM_DECODE_FORCE ask for THOSE members)
-    const bool older_forced = (pf && atoi(pf) == 0) || getenv("WQAA_GEMM_DECODE_FORCE") != nullptr;
+    // (not where the A/B aids of the older forms are in use: decode_persist=0 / decode_force ask for THOSE members)
+    const bool older_forced = persist_knob == 0 || have_force;
     wpf_take = wpf_ok && (lmode == 4 || (!older_forced && !decode_fits && !persist && !c->decode_long && frags > 3 * cus_));
     if (wpf_take) {
       c->decode_long = 0;
@@ -446,10 +450,11 @@ static int gemm_choose(const wqaa_matmul_desc& d, int m, GemmChoice* c, bool fus
   }
   const bool fits_one_each = decode_fits;     // (the rule for one fragment per workgroup)
   if (persist || c->decode_long) decode_fits = true;
-  if (const char* f = getenv("WQAA_GEMM_DECODE_FORCE")) decode_fits = atoi(f) != 0;   // tuning aid
+  { int v; if (gemm_knob("decode_force", &v)) decode_fits = v != 0; }   // tuning aid
   if (m <= decode_max_m && m <= 16 && c->mf == 1 && decode_fits) {
-    const char* dflag = getenv("WQAA_GEMM_DECODE");
-    if (!dflag || atoi(dflag) != 0) c->decode = 1;
+    int dflag = 1;
+    (void)gemm_knob("decode", &dflag);
+    if (dflag != 0) c->decode = 1;
   }
   if (c->decode) {
     // activations through LDS-DMA (member 211); packed int4 activations: the direct-load member 201
@@ -504,9 +509,10 @@ static int gemm_choose(const wqaa_matmul_desc& d, int m, GemmChoice* c, bool fus
   // scale-only case LOSE 3-10 % to the four-step unrolled loop, so they keep the per-step form)
   {
     const int dq = g / c->kl;
-    const char* wflag = getenv("WQAA_GEMM_WIDE");
+    int wflag = 1;                                            // WQAA_GEMM_TUNE=wide=0: the per-step metadata loads (test aid)
+    (void)gemm_knob("wide", &wflag);
     if (!c->skinny && c->mf == 4 && (c->mode == MD_ZO || c->mode == MD_ZR) && dq == 4 && ((d.K / g) & 3) == 0 &&
-        (!wflag || atoi(wflag) != 0) && pick_gemm(c->kind, c->layout, c->at, c->mode, c->flags, 404))
+        wflag != 0 && pick_gemm(c->kind, c->layout, c->at, c->mode, c->flags, 404))
       code = 404;
   }
   c->wide = code >= 400;
@@ -530,7 +536,7 @@ static int gemm_choose(const wqaa_matmul_desc& d, int m, GemmChoice* c, bool fus
   int ks = 1;
   while (tiles * ks < cus && ks * 2 <= 16 && nsteps / (ks * 2) >= 1) ks *= 2;
   if (d.k_split_hint > 1) ks = d.k_split_hint;             // the caller's MatmulConfigWithSplitK.k_split
-  if (const char* f = getenv("WQAA_GEMM_KSPLIT")) ks = atoi(f);
+  { int v; if (gemm_knob("ksplit", &v)) ks = v; }
   if (ks > 16) ks = 16;                                     // partial sums cost 4 B per output element per slice
   if (ks > nsteps) ks = nsteps;
   if (ks < 1) ks = 1;
@@ -683,13 +689,13 @@ int gemm_launch(const wqaa_matmul_desc& d, const void* A, const void* B, const v
   fill_tile_magics(a, c.ksplit, d.K);
   {
     // split-K partial sums and large output tiles leave the chip write-through (they are read by another kernel, once):
-    // nothing dirty is left for the kernel boundary to write back.  WQAA_GEMM_WS_POLICY=<bits> overrides (tuning aid, plan time)
+    // nothing dirty is left for the kernel boundary to write back.  WQAA_GEMM_TUNE=ws_policy=<bits> overrides (tuning aid, plan time)
     static thread_local unsigned seen = ~0u;
     static thread_local int policy = -1;
     const unsigned ep = g_plan_epoch.load(std::memory_order_relaxed);
     if (ep != seen) {
-      const char* f = getenv("WQAA_GEMM_WS_POLICY");
-      policy = f ? atoi(f) : -1;
+      int v = -1;
+      policy = gemm_knob("ws_policy", &v) ? v : -1;
       seen = ep;
     }
     const long out_bytes = (long)m * d.N * (d.out_dtype == WQAA_I32 || d.out_dtype == WQAA_F32 ? 4 : 2);
@@ -861,7 +867,6 @@ static bool two_pass_dense_desc(const wqaa_matmul_desc& d, wqaa_matmul_desc* dd)
 // AUTOMATIC for the formats whose fused large-M member is still the lockstep one (float16 / bfloat16 activations x int8, e4m3,
 // 2-bit, 1-bit weights ...): B_decode (HBM-bound, ~11 us at 4096^2) + the dense member beats the lockstep fused member from
 // ~1024 rows on (profiles/r04_ab_two_pass_own.txt).  Never where a fused ping-pong member exists (it wins: DESIGN.md 3.2a').
-// WQAA_TWO_PASS_AUTO=0: off; =n: from n rows on.
 static bool own_dense_second_pass(const wqaa_matmul_desc& dd, int m) {
   if (dd.a_dtype != WQAA_F16 && dd.a_dtype != WQAA_BF16 && dd.a_dtype != WQAA_I8) return false;
   GemmChoice c;
@@ -880,8 +885,16 @@ static bool two_pass_auto(const wqaa_matmul_desc& d, const wqaa_matmul_desc& dd,
 
 bool gemm_two_pass_eligible(const wqaa_matmul_desc& d, int m) {
   int min_m = d.two_pass_min_m;
-  if (const char* f = getenv("WQAA_TWO_PASS")) min_m = atoi(f);      // A/B aid (plan-time): 0 never, n > 0 from n rows on
-  if (getenv("WQAA_TWO_PASS") != nullptr && min_m <= 0) return false;
+  // WQAA_TWO_PASS=min_m=N (or a bare number N): A/B aid (plan-time): 0 never, N > 0 from N rows on
+  {
+    int v = 0;
+    const char* f = getenv("WQAA_TWO_PASS");
+    const bool have = f && (knob("WQAA_TWO_PASS", "min_m", &v) || ((*f >= '0' && *f <= '9') && ((v = atoi(f)), true)));
+    if (have) {
+      min_m = v;
+      if (min_m <= 0) return false;
+    }
+  }
   wqaa_matmul_desc dd;
   if (m < 16 || !two_pass_dense_desc(d, &dd)) return false;
   GemmChoice c;

@@ -57,10 +57,11 @@ gemm_fn pick_gemm_pp(int kind, int layout, int at, int mode, int flags, int bm, 
                : (!ab ? wq_gemm_pp8s_kernel<PP8SPolicy<1, 0>> : wq_gemm_pp8s_kernel<PP8SPolicy<1, 1>>);
   }
   if (bn != 256 || (bm != 256 && bm != 128)) return nullptr;
-  // round 5: the dense 256 x 256 tile on a 2 x 4 wave grid (wq_gemm_pp8w_kernel).  WQAA_GEMM_PP8_WIDE=0: the 1 x 8 grid (plan time)
+  // round 5: the dense 256 x 256 tile on a 2 x 4 wave grid (wq_gemm_pp8w_kernel).  WQAA_GEMM_TUNE=pp8_wide=0: the 1 x 8 grid (plan time)
   static const bool kWideDefault = true;
-  const char* wf_ = getenv("WQAA_GEMM_PP8_WIDE");
-  const bool wide = bm == 256 && (wf_ ? atoi(wf_) != 0 : kWideDefault);
+  int wide_knob = kWideDefault ? 1 : 0;
+  (void)gemm_knob("pp8_wide", &wide_knob);
+  const bool wide = bm == 256 && wide_knob != 0;
   if (wide && mode == MD_NONE) {
     if (at == AT_F8 && (kind == DK_E4M3 || kind == DK_E5M2) && (flags & ~FL_ABF8) == 0) {
       const bool wb = kind == DK_E5M2, ab = (flags & FL_ABF8) != 0;

@@ -2041,7 +2041,7 @@ static gemm_fn pick_mf(int mf) {
     case 104: return wq_gemm_kernel<GemmPolicy<KIND, LAYOUT, AT, MODE, FLAGS, 4, 4, 1, 4>>;
     // 128-row skinny member: 8 waves x one weight fragment each (BN = 128), 4 k-steps per workgroup, every load first
     // (round 5's prune: the direct-load decode member is instantiated only where it is the selector's choice - packed int4 activations,
-    // which the LDS-DMA member does not take; elsewhere it was reachable through the A/B aid WQAA_GEMM_DECODE_LDS=0 alone)
+    // which the LDS-DMA member does not take; elsewhere it was reachable through a round-4 A/B aid alone)
     case 201: if constexpr (AT == AT_I4) return wq_gemm_decode_kernel<GemmPolicy<KIND, LAYOUT, AT, MODE, FLAGS, 1, 8, 1>>; else return nullptr;
     case 211: if constexpr (AT != AT_I4) return wq_gemm_decode_lds_kernel<GemmPolicy<KIND, LAYOUT, AT, MODE, FLAGS, 1, 8, 1>>; else return nullptr;
     // 212: the K-sliced form of 211 (long K; 4-bit weights x float16, Scale (+ Zeros) per 128: the hand-counted formats)

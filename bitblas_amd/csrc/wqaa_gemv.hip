@@ -152,11 +152,12 @@ static int choose(const wqaa_matmul_desc& d, int m, GemvChoice* c, bool quant_in
   // rows with an odd number of lane chunks, integer activations: four rows x one chunk per step instead of two x two (no
   // padding chunk).  Same-process A/B, int2 x int8 (profiles/r03_ab_chunk_tile.txt): 12288 x 4096 5.95 -> 5.25 us, 22016 x 4096
   // 8.78 -> 7.42, 8640 x 3200 5.22 -> 4.53; but 4096 x 11008 (three chunks, 1024 groups of four rows: 4 waves per CU) 5.71 ->
-  // 6.49 - so: one-chunk rows, or enough rows that four per wave still give every CU 8 waves.  WQAA_GEMV_CHUNK=0: the (2, 2) members.
+  // 6.49 - so: one-chunk rows, or enough rows that four per wave still give every CU 8 waves.  WQAA_GEMV_TUNE=chunk=0: the (2, 2) members.
   bool chunk_tile = false;
   if (c->at == AT_I8 && c->bits < 8 && (c->nc & 1) && (c->nc == 1 || (d.N + 3) / 4 >= 8 * cus0)) {
-    const char* f = getenv("WQAA_GEMV_CHUNK");
-    chunk_tile = (!f || atoi(f) != 0) && pick_kernel(c->kind, c->layout, c->at, c->mode, c->flags, kChunkTile + mb) != nullptr;
+    int cv = 1;
+    (void)gemv_knob("chunk", &cv);
+    chunk_tile = cv != 0 && pick_kernel(c->kind, c->layout, c->at, c->mode, c->flags, kChunkTile + mb) != nullptr;
   }
   if (chunk_tile) {
     c->R = 4;
@@ -166,8 +167,10 @@ static int choose(const wqaa_matmul_desc& d, int m, GemvChoice* c, bool quant_in
   // the register-resident member only where its activation slice fits the register file (gemv_direct_fits, wqaa_gemv_kernel.h:
   // the members that spilled are not built; same-process A/B in profiles/r03_ab_direct_fit.txt)
   const bool slice_fits = mb * c->E * (c->at == AT_F16 ? 2 : 1) <= 128 && !(c->kind == DK_LUT4 && mb == 2 && (c->flags & FL_BF16));
+  int areg_knob = 1;                                    // WQAA_GEMV_TUNE=areg=0: the LDS-staged members (A/B and test aid)
+  (void)gemv_knob("areg", &areg_knob);
   const bool direct = mb <= 2 && m == mb && !(c->flags & (FL_A8 | FL_AQ)) && c->at != AT_I4 && c->ncp == c->D && (d.N + c->R - 1) / c->R <= 10 * cus0 &&
-                      slice_fits && !getenv("WQAA_GEMV_NO_DIRECT");
+                      slice_fits && areg_knob != 0;
   // small matrices: one row per wave doubles the waves in flight (same-box A/B: 1024 x 1024 2.87 -> 2.45 us,
   // 2048 x 4096 equal, 4096 x 4096 4.18 -> 4.43 us)
   const bool r1 = direct && mb == 1 && (d.N + 1) / 2 < 3 * cus0 && !chunk_tile;
@@ -218,7 +221,7 @@ static int choose(const wqaa_matmul_desc& d, int m, GemvChoice* c, bool quant_in
       while (kw > 1 && ((nsteps + kw - 1) / kw) * (kw - 1) >= nsteps) --kw;   // every part gets at least one step
     }
     if (can && d.k_split_hint > 1) kw = d.k_split_hint;       // the caller's MatmulConfigWithSplitK.k_split
-    if (const char* f = getenv("WQAA_GEMV_KW")) { if (can && atoi(f) > 0) kw = atoi(f); }   // tuning aid
+    { int v; if (gemv_knob("kw", &v) && can && v > 0) kw = v; }   // tuning aid
     if (kw > nsteps) kw = nsteps;
     if (kw > 16) kw = 16;
     while (kw > 1 && ((nsteps + kw - 1) / kw) * (kw - 1) >= nsteps) --kw;
@@ -244,7 +247,7 @@ static int choose(const wqaa_matmul_desc& d, int m, GemvChoice* c, bool quant_in
   const int cap = cus * blocks_per_cu;
   if (blocks > cap && !gemv_uncapped()) blocks = cap;
   if (blocks < 1) blocks = 1;
-  if (const char* f = getenv("WQAA_GEMV_GRID")) { if (atoi(f) > 0) blocks = atoi(f); }   // tuning aid
+  { int v; if (gemv_knob("grid", &v) && v > 0) blocks = v; }   // tuning aid
   if (blocks >= 8) blocks = (blocks + 7) / 8 * 8;   // whole XCD rounds: keeps the block swizzle on
   c->grid_x = blocks;
   c->grid_y = (m + mb - 1) / mb;
@@ -397,7 +400,7 @@ static int gemv_group_choose(const wqaa_matmul_desc& merged, const int* Ns, int 
     if (blocks > need) need = blocks;
   }
   int gx = need;                         // one row-group block per workgroup, sized by the largest member (see gemvx_group_choose)
-  if (const char* f = getenv("WQAA_GROUP_GRID")) { if (atoi(f) > 0 && atoi(f) < gx) gx = atoi(f); }    // tuning aid
+  { int v; if (gemv_knob("group_grid", &v) && v > 0 && v < gx) gx = v; }    // tuning aid
   if (gx >= 8) gx = (gx + 7) / 8 * 8;
   *grid_x = gx;
   return WQAA_OK;

@@ -12,7 +12,7 @@ struct GemvxChoice {
 };
 
 // sub-byte integer weights x float16 activations, M <= 2, and the caller did not ask for the TE definition's
-// per-element rounding (strict_reference).  WQAA_GEMVX=0 disables the family (A/B aid).
+// per-element rounding (strict_reference).  WQAA_GEMV_TUNE=exact=0 disables the family (A/B aid).
 // what the family can compute at all (the fused pre/post ops of wqaa_matmul_ex exist only here, so they ask this)
 bool gemvx_covers(const wqaa_matmul_desc& d, int m) {
   if (m < 1 || m > 2 || d.a_dtype != WQAA_F16) return false;
@@ -39,9 +39,10 @@ bool gemvx_eligible(const wqaa_matmul_desc& d, int m) {
   static thread_local bool enabled = true, forced = false;
   const unsigned ep = g_plan_epoch.load(std::memory_order_relaxed);
   if (ep != seen_epoch) {
-    const char* f = getenv("WQAA_GEMVX");
-    enabled = !(f && atoi(f) == 0);
-    forced = f && atoi(f) == 2;                               // WQAA_GEMVX=2: A/B aid, ignores the fences
+    int v = 1;
+    const bool have = gemv_knob("exact", &v);
+    enabled = !(have && v == 0);
+    forced = have && v == 2;                                  // WQAA_GEMV_TUNE=exact=2: A/B aid, ignores the fences
     seen_epoch = ep;
   }
   {
@@ -102,7 +103,7 @@ static int gemvx_choose(const wqaa_matmul_desc& d, int m, GemvxChoice* c, int pr
   if (pro == 2 || pro == 4) c->R = 2;
   int kw = c->R == 2 ? k2 : k1;
   if (d.k_split_hint > 1) kw = d.k_split_hint;                                          // the caller's k_split
-  if (const char* f = getenv("WQAA_GEMVX_KW")) kw = atoi(f) > 0 ? atoi(f) : 1;          // tuning aid
+  { int v; if (gemv_knob("kw", &v)) kw = v > 0 ? v : 1; }                              // tuning aid
   if (force_kw > 0) kw = force_kw;                                                      // a pair sums a row as its projection alone does
   if (kw > c->nsteps) kw = c->nsteps;
   if (kw > 16) kw = 16;
@@ -151,10 +152,10 @@ static int gemvx_choose(const wqaa_matmul_desc& d, int m, GemvxChoice* c, int pr
   // static assignment (22016x4096, 1376 blocks: 1024 workgroups 11.5 us, 1376 10.7; tools/ab_grid.py, ab_cap.py)
   if (blocks > cus * blocks_per_cu + cus * blocks_per_cu / 2 && !gemv_uncapped()) blocks = cus * blocks_per_cu;
   if (blocks >= 8) blocks = (blocks + 7) / 8 * 8;       // whole XCD rounds keep the block swizzle on
-  if (const char* f = getenv("WQAA_GEMVX_GRID")) blocks = atoi(f) > 0 ? atoi(f) : 1;
+  { int v; if (gemv_knob("grid", &v)) blocks = v > 0 ? v : 1; }
   c->grid = blocks;
   // register-resident activations (4-bit LOP3, M = 1, K within one step, no K split): no LDS tile, no barrier.
-  // WQAA_GEMVX_AREG=0/1 forces it off/on (A/B aid).
+  // WQAA_GEMV_TUNE=areg=0/1 forces it off/on (A/B aid).
   c->areg = 0;
   if (c->bits == 4 && c->layout == LAYOUT_LOP3 && c->mb == 1 && c->nsteps == 1 && c->kw == 1) {
     // same-call A/B against the LDS-staged member (profiles/r02_ab_gemvx_areg.txt): 1024 rows 2.81 -> 2.62 us, 2048 3.27 ->
@@ -162,7 +163,7 @@ static int gemvx_choose(const wqaa_matmul_desc& d, int m, GemvxChoice* c, int pr
     // activation row through the texture path and sums it itself) - so: few rows, or so many that the barrier of
     // tens of workgroups per CU costs more than the re-reads
     c->areg = (d.N <= 2048 || d.N >= 24576) ? 1 : 0;
-    if (const char* f = getenv("WQAA_GEMVX_AREG")) c->areg = atoi(f) != 0;
+    { int v; if (gemv_knob("areg", &v)) c->areg = v != 0; }
   }
   if (pro) c->areg = 0;                                  // the fused post ops come with the LDS-staged members
   if (c->areg) c->lds = 64;
@@ -389,7 +390,7 @@ static int gemvx_group_choose(const wqaa_matmul_desc& merged, const int* Ns, int
   // headline step (2 x 688 blocks): 1024 workgroups taking up to two blocks each 11.94 us, 1376 workgroups 10.81 us -
   // the hardware dispatcher balances better than a static second round (tools/ab_group.py)
   int gx = need;
-  if (const char* f = getenv("WQAA_GROUP_GRID")) { if (atoi(f) > 0 && atoi(f) < gx) gx = atoi(f); }    // tuning aid: workgroups per member
+  { int v; if (gemv_knob("group_grid", &v) && v > 0 && v < gx) gx = v; }    // tuning aid: workgroups per member
   if (gx >= 8) gx = (gx + 7) / 8 * 8;                 // whole XCD rounds per member: blockIdx.x % 8 stays the XCD
   *grid_x = gx;
   return WQAA_OK;

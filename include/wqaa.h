@@ -350,7 +350,7 @@ int wqaa_dequantize(const wqaa_matmul_desc* desc, const void* B, const void* LUT
 int wqaa_act_quant_int8(const void* X, int64_t rows, int K, void* Q, float* S, void* stream);
 
 /* tile-config selector: replaces roller + tuner (bitblas/base/roller, bitblas/base/tuner.py).  Needs no device.
- * The WQAA_GEMM_* / WQAA_GEMV_* tuning environment variables are read here and at the first wqaa_matmul of a
+ * The WQAA_GEMM_TUNE / WQAA_GEMV_TUNE tuning environment variables (csrc/wqaa_common.h: knob) are read here and at the first wqaa_matmul of a
  * (desc, m) pair per thread; a later change takes effect at the next wqaa_select call. */
 int wqaa_select(const wqaa_matmul_desc* desc, int m, wqaa_plan* plan);
 /* the member wqaa_matmul_ex takes for (desc, m) with an epilogue of these WQAA_EPI_* flags (0: the caller's row / tensor scales

@@ -180,6 +180,36 @@ def case_contract(case, default_members=False, m=None):
     return contract(case["K"], default_members=default_members, m=case["M"] if m is None else m, group_size=gs, zeros_mode=zm)
 
 
+_KNOB_VARS = {"gemv": "WQAA_GEMV_TUNE", "gemm": "WQAA_GEMM_TUNE", "two_pass": "WQAA_TWO_PASS"}
+
+
+def set_knobs(monkeypatch, family, **kv):
+    """tuning / test aids live in ONE variable per family as `key=value,key=value` (csrc/wqaa_common.h: knob): set or replace
+    the given keys, keep the others; a value of None removes the key.  family: "gemv" | "gemm" | "two_pass"."""
+    var = _KNOB_VARS[family]
+    cur = {}
+    for tok in filter(None, os.environ.get(var, "").split(",")):
+        k, _, v = tok.partition("=")
+        cur[k] = v
+    for k, v in kv.items():
+        if v is None:
+            cur.pop(k, None)
+        else:
+            cur[k] = str(v)
+    if cur:
+        monkeypatch.setenv(var, ",".join(f"{k}={v}" for k, v in cur.items()))
+    else:
+        monkeypatch.delenv(var, raising=False)
+
+
+def knob_value(family, key):
+    for tok in filter(None, os.environ.get(_KNOB_VARS[family], "").split(",")):
+        k, _, v = tok.partition("=")
+        if k == key:
+            return v
+    return None
+
+
 def record_margin(tag, got, want):
     """achieved error of one parity case, appended to $WQAA_PARITY_MARGINS (tools/parity_margins.sh -> profiles/r04_parity_margins.txt):
     max |err| / |want| over the elements above 10 % of rms(want), and max |err| / rms(want) over all"""

@@ -6,6 +6,8 @@ import re
 import numpy as np
 import pytest
 
+from helpers import set_knobs
+
 from bitblas_amd import lib as wlib
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -384,8 +386,7 @@ def test_decode_batch_forms_are_chosen_where_they_were_measured(monkeypatch):
     """one-launch decode member, rounds 4 and 5 (no device needed): persistent on wide outputs at K <= 4096 (`xdlp`, up to six rounds of
     fragments for the hand-counted formats), whole tile on long K where M-sized slots fit (`xdlt`: M <= 8 at K <= 8192, M <= 4 at
     K <= 12288, more than one fragment per workgroup), the block-by-block form otherwise"""
-    for k in ("WQAA_GEMM_DECODE_PERSIST", "WQAA_GEMM_DECODE_FORCE", "WQAA_GEMM_DECODE_LONG", "WQAA_GEMM_DECODE"):
-        monkeypatch.delenv(k, raising=False)
+    monkeypatch.delenv("WQAA_GEMM_TUNE", raising=False)
 
     def name(m, N, K):
         d = wlib.make_desc(N=N, K=K, a_dtype=wlib.F16, w_format=wlib.W_UINT, w_bits=4, out_dtype=wlib.F16, group_size=128, with_scaling=True,
@@ -401,13 +402,13 @@ def test_decode_batch_forms_are_chosen_where_they_were_measured(monkeypatch):
                             # round 5, a wave per fragment (`xdlw`): outputs wider than the persistent / whole-tile forms reach, where the tile fits LDS
                             (8, 32000, 4096, "xdlw"), (16, 28672, 4096, "xdlw"), (3, 128256, 4096, "xdlw"), (8, 16384, 8192, "xdlw"), (8, 24576, 4096, "xdlp")):
         assert name(m, N, K).endswith("_f16xu4_tcx16x16x128" + suffix), (m, N, K, name(m, N, K))
-    monkeypatch.setenv("WQAA_GEMM_DECODE_LONG", "0")
+    set_knobs(monkeypatch, "gemm", decode_long="0")
     assert not name(8, 8192, 8192).endswith("xdlt") and not name(16, 8192, 28672).endswith("xdlk")
-    monkeypatch.setenv("WQAA_GEMM_DECODE_LONG", "2")          # the round-4 selector: whole tile, never K-sliced
+    set_knobs(monkeypatch, "gemm", decode_long="2")          # the round-4 selector: whole tile, never K-sliced
     assert name(8, 8192, 8192).endswith("xdlt") and not name(16, 8192, 28672).endswith("xdlk")
-    monkeypatch.setenv("WQAA_GEMM_DECODE_LONG", "3")          # K-sliced wherever the shape fits (the parity tests)
+    set_knobs(monkeypatch, "gemm", decode_long="3")          # K-sliced wherever the shape fits (the parity tests)
     assert name(8, 4096, 11008).endswith("xdlk") and name(3, 512, 8192).endswith("xdlk")
-    monkeypatch.setenv("WQAA_GEMM_DECODE_LONG", "4")          # a wave per fragment wherever the tile fits
+    set_knobs(monkeypatch, "gemm", decode_long="4")          # a wave per fragment wherever the tile fits
     assert name(8, 4096, 4096).endswith("xdlw") and name(5, 1000, 8192).endswith("xdlw") and not name(16, 512, 8192).endswith("xdlw")
-    monkeypatch.setenv("WQAA_GEMM_DECODE_LONG", "2")
+    set_knobs(monkeypatch, "gemm", decode_long="2")
     assert not name(8, 32000, 4096).endswith("xdlw")

@@ -10,14 +10,14 @@ import pytest
 import torch
 
 import bitblas_amd as bitblas
-from helpers import assert_fp_parity, hip_output, make_case, oracle_output
+from helpers import set_knobs, assert_fp_parity, hip_output, make_case, oracle_output
 
 pytestmark = pytest.mark.gpu
 
 
 def _both(case, M, monkeypatch, exact=False):
-    monkeypatch.delenv("WQAA_GEMM_DECODE_PERSIST", raising=False)
-    monkeypatch.delenv("WQAA_GEMM_DECODE_FORCE", raising=False)
+    set_knobs(monkeypatch, "gemm", decode_persist=None)
+    set_knobs(monkeypatch, "gemm", decode_force=None)
     got, mm = hip_output(case)
     assert mm.plans[M]["name"].endswith("xdlp"), mm.plans[M]["name"]
     assert mm.plans[M]["grid"] < (case["N"] + 15) // 16
@@ -26,8 +26,8 @@ def _both(case, M, monkeypatch, exact=False):
         assert np.array_equal(got, want)
     else:
         assert_fp_parity(got, want)
-    monkeypatch.setenv("WQAA_GEMM_DECODE_PERSIST", "0")
-    monkeypatch.setenv("WQAA_GEMM_DECODE_FORCE", "1")
+    set_knobs(monkeypatch, "gemm", decode_persist="0")
+    set_knobs(monkeypatch, "gemm", decode_force="1")
     one, mm1 = hip_output(case)
     assert mm1.plans[M]["name"].endswith("xdl"), mm1.plans[M]["name"]
     assert np.array_equal(got.view(np.uint16) if got.dtype == np.float16 else got, one.view(np.uint16) if one.dtype == np.float16 else one)
@@ -78,7 +78,7 @@ def test_dense_fp8_decode_batches(M, monkeypatch):
     gen.manual_seed(M)
     A = (torch.rand((M, K), device="cuda", generator=gen) * 2 - 1).to(torch.float8_e4m3fn)
     W = (torch.rand((N, K), device="cuda", generator=gen) * 2 - 1).to(torch.float8_e4m3fn)
-    monkeypatch.delenv("WQAA_GEMM_DECODE_PERSIST", raising=False)
+    set_knobs(monkeypatch, "gemm", decode_persist=None)
     mm = bitblas.Matmul(bitblas.MatmulConfig(M=M, N=N, K=K, A_dtype="e4m3_float8", W_dtype="e4m3_float8", accum_dtype="float32", out_dtype="float16"),
                         enable_tuning=False)
     out = mm(A, W)
@@ -86,8 +86,8 @@ def test_dense_fp8_decode_batches(M, monkeypatch):
     want = oracle.matmul_dense(A.view(torch.int8).cpu().numpy(), W.view(torch.int8).cpu().numpy(), a_dtype="e4m3_float8", w_dtype="e4m3_float8", out_dtype="float32")
     assert_fp_parity(out.float().cpu().numpy(), want.astype(np.float16).astype(np.float32), rtol=1e-3, atol_frac=1e-4)
     if mm.plans[M]["name"].endswith("xdlp"):
-        monkeypatch.setenv("WQAA_GEMM_DECODE_PERSIST", "0")
-        monkeypatch.setenv("WQAA_GEMM_DECODE_FORCE", "1")
+        set_knobs(monkeypatch, "gemm", decode_persist="0")
+        set_knobs(monkeypatch, "gemm", decode_force="1")
         mm1 = bitblas.Matmul(bitblas.MatmulConfig(M=M, N=N, K=K, A_dtype="e4m3_float8", W_dtype="e4m3_float8", accum_dtype="float32", out_dtype="float16"),
                              enable_tuning=False)
         assert torch.equal(out, mm1(A, W))
@@ -101,13 +101,12 @@ def test_long_rows_keep_the_one_fragment_form():
 
 def _long_both(case, M, monkeypatch, want_long=True):
     """whole-tile form (`xdlt`) against the oracle and, bit for bit, against the block-by-block form of the same kernel"""
-    for k in ("WQAA_GEMM_DECODE_PERSIST", "WQAA_GEMM_DECODE_FORCE", "WQAA_GEMM_DECODE_LONG"):
-        monkeypatch.delenv(k, raising=False)
+    set_knobs(monkeypatch, "gemm", decode_persist=None, decode_force=None, decode_long=None)
     got, mm = hip_output(case)
     assert mm.plans[M]["name"].endswith("xdlt") == want_long, mm.plans[M]["name"]
     assert_fp_parity(got, oracle_output(case))
-    monkeypatch.setenv("WQAA_GEMM_DECODE_LONG", "0")
-    monkeypatch.setenv("WQAA_GEMM_DECODE_FORCE", "1")
+    set_knobs(monkeypatch, "gemm", decode_long="0")
+    set_knobs(monkeypatch, "gemm", decode_force="1")
     one, mm1 = hip_output(case)
     assert mm1.plans[M]["name"].endswith("xdl"), mm1.plans[M]["name"]
     assert np.array_equal(got.view(np.uint16), one.view(np.uint16))

@@ -11,7 +11,7 @@ import pytest
 import torch
 
 import wqaa_oracle as oracle
-from helpers import case_contract, contract, assert_fp_parity, hip_output, make_case, oracle_output
+from helpers import set_knobs, case_contract, contract, assert_fp_parity, hip_output, make_case, oracle_output
 
 pytestmark = pytest.mark.gpu
 
@@ -157,14 +157,14 @@ def test_prefill_sized_m_int2_int8_bit_exact_every_output_element(M, N, K):
                                       (1024, 1024, 1024, dict(W_dtype="uint4", group_size=128, with_scaling=True, with_zeros=True, scale_mul=0.05))])
 def test_store_policy_of_partial_sums_and_large_outputs_does_not_change_a_bit(M, N, K, kw, monkeypatch):
     """Split-K partial sums and large output tiles leave the chip write-through (sc0 sc1 stores; csrc/wqaa_gemm.hip,
-    `WQAA_GEMM_WS_POLICY`): a cache policy, not arithmetic - plain stores must give the same bits."""
+    `WQAA_GEMM_TUNE=ws_policy`): a cache policy, not arithmetic - plain stores must give the same bits."""
     case = make_case(M, N, K, seed=M + K, **kw)
     got, mm = hip_output(case)
-    monkeypatch.setenv("WQAA_GEMM_WS_POLICY", "0")
+    set_knobs(monkeypatch, "gemm", ws_policy="0")
     plain, mm2 = hip_output(case)
     assert mm.plans[M]["name"] == mm2.plans[M]["name"]
     assert np.array_equal(got, plain)
-    monkeypatch.setenv("WQAA_GEMM_WS_POLICY", "19")
+    set_knobs(monkeypatch, "gemm", ws_policy="19")
     forced, _ = hip_output(case)
     assert np.array_equal(got, forced)
 
@@ -326,7 +326,7 @@ def test_decode_batch_member_against_the_split_k_member(M, N, kw, monkeypatch):
     case = make_case(M, N, 4096 if N <= 1024 else 2048, seed=M, **kw)
     got, mm = hip_output(case)
     assert mm.plans[M]["name"].endswith("xdl")          # activations through LDS-DMA
-    monkeypatch.setenv("WQAA_GEMM_DECODE", "0")
+    set_knobs(monkeypatch, "gemm", decode="0")
     got2, mm2 = hip_output(case)
     assert mm2.plans[M]["name"].endswith("xs")
     want = oracle_output(case)
@@ -349,14 +349,14 @@ def test_block_metadata_member_is_bit_identical(M, kw, N, K, monkeypatch):
     case = make_case(M, N, K, seed=M + N, group_size=128, with_scaling=True, scale_mul=0.05, **kw)
     got, mm = hip_output(case)
     assert mm.plans[M]["name"].endswith("xw")
-    monkeypatch.setenv("WQAA_GEMM_WIDE", "0")
+    set_knobs(monkeypatch, "gemm", wide="0")
     got2, mm2 = hip_output(case)
     assert not mm2.plans[M]["name"].endswith("xw")
     assert np.array_equal(got.view(np.uint16), got2.view(np.uint16))
     assert_fp_parity(got, oracle_output(case))
-    monkeypatch.delenv("WQAA_GEMM_WIDE")
+    set_knobs(monkeypatch, "gemm", wide=None)
     for ks in (3, 5):
-        monkeypatch.setenv("WQAA_GEMM_KSPLIT", str(ks))
+        set_knobs(monkeypatch, "gemm", ksplit=str(ks))
         got3, mm3 = hip_output(case)
         assert mm3.plans[M]["name"].endswith("xw")
         assert_fp_parity(got3, oracle_output(case))

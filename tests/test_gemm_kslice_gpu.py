@@ -8,7 +8,7 @@ be the same BITS as those forms' (`xdl`, `xdlt`), and within the contract of the
 import numpy as np
 import pytest
 
-from helpers import assert_fp_parity, hip_output, make_case, oracle_output
+from helpers import set_knobs, assert_fp_parity, hip_output, make_case, oracle_output
 
 pytestmark = pytest.mark.gpu
 
@@ -18,7 +18,7 @@ def _bits(x):
 
 
 def _run(case, M, monkeypatch):
-    monkeypatch.setenv("WQAA_GEMM_DECODE_LONG", "3")        # the form wherever it fits, not only where it measured ahead
+    set_knobs(monkeypatch, "gemm", decode_long="3")        # the form wherever it fits, not only where it measured ahead
     got, mm = hip_output(case)
     assert mm.plans[M]["name"].endswith("xdlk"), mm.plans[M]["name"]
     assert mm.plans[M]["split_k"] == 8
@@ -26,7 +26,7 @@ def _run(case, M, monkeypatch):
     assert_fp_parity(got, oracle_output(case))
     again, _ = hip_output(case, matmul=mm)
     assert np.array_equal(_bits(got), _bits(again)), "run to run"
-    monkeypatch.setenv("WQAA_GEMM_DECODE_LONG", "2")        # the round-4 selector
+    set_knobs(monkeypatch, "gemm", decode_long="2")        # the round-4 selector
     old, mo = hip_output(case)
     name = mo.plans[M]["name"]
     assert not name.endswith("xdlk"), name
@@ -57,7 +57,7 @@ def test_other_zero_point_forms_ragged_n_and_bias(zeros_mode, monkeypatch):
     case = make_case(5, 1000, 8192, W_dtype="uint4", group_size=128, with_scaling=True, with_zeros=True, zeros_mode=zeros_mode, with_bias=True,
                      scale_mul=0.02, seed=9)
     if zeros_mode == "quantized":
-        monkeypatch.setenv("WQAA_GEMM_DECODE_LONG", "3")
+        set_knobs(monkeypatch, "gemm", decode_long="3")
         got, mm = hip_output(case)
         assert not mm.plans[5]["name"].endswith("xdlk")
         assert_fp_parity(got, oracle_output(case))
@@ -87,7 +87,7 @@ def test_few_fragments_and_other_group_sizes(monkeypatch):
     """N = 128 (8 fragments: one group of workgroups, one fragment per wave); g = 64 is not a hand-counted format: other members"""
     case = make_case(16, 128, 8192, W_dtype="uint4", group_size=128, with_scaling=True, with_zeros=True, zeros_mode="original", scale_mul=0.02, seed=2)
     _run(case, 16, monkeypatch)
-    monkeypatch.setenv("WQAA_GEMM_DECODE_LONG", "3")
+    set_knobs(monkeypatch, "gemm", decode_long="3")
     case = make_case(8, 512, 8192, W_dtype="uint4", group_size=64, with_scaling=True, with_zeros=True, zeros_mode="original", scale_mul=0.02, seed=2)
     got, mm = hip_output(case)
     assert not mm.plans[8]["name"].endswith("xdlk")
@@ -97,7 +97,7 @@ def test_few_fragments_and_other_group_sizes(monkeypatch):
 def test_hipgraph_replays(monkeypatch):
     """captured once (two launches back to back on one buffer of partial sums), replayed"""
     import torch
-    monkeypatch.setenv("WQAA_GEMM_DECODE_LONG", "3")
+    set_knobs(monkeypatch, "gemm", decode_long="3")
     M = 8
     case = make_case(M, 2048, 8192, W_dtype="uint4", group_size=128, with_scaling=True, with_zeros=True, zeros_mode="original", scale_mul=0.02, seed=21)
     ref, mm = hip_output(case)
@@ -125,7 +125,7 @@ def test_caller_workspace_full_and_short(monkeypatch):
     """`wqaa_matmul_opts`: a caller workspace of `wqaa_workspace_bytes` holds the slices' partial sums; one too short for them makes the
     call run the member the form stands in for (a one-launch form here: the same bits) instead of failing"""
     import torch
-    monkeypatch.setenv("WQAA_GEMM_DECODE_LONG", "3")
+    set_knobs(monkeypatch, "gemm", decode_long="3")
     M, N, K = 8, 2048, 8192
     case = make_case(M, N, K, W_dtype="uint4", group_size=128, with_scaling=True, with_zeros=True, zeros_mode="original", scale_mul=0.02, seed=31)
     ref, mm = hip_output(case)

@@ -12,7 +12,7 @@ import pytest
 import torch
 
 import bitblas_amd as bitblas
-from helpers import assert_fp_parity, hip_output, make_case, oracle_output
+from helpers import set_knobs, assert_fp_parity, hip_output, make_case, oracle_output
 
 pytestmark = pytest.mark.gpu
 
@@ -23,8 +23,8 @@ def _bits(x):
 
 def _run(case, M, monkeypatch, check_paths=True):
     """the member against the oracle, and run to run bit for bit"""
-    monkeypatch.delenv("WQAA_GEMM_MID", raising=False)
-    monkeypatch.setenv("WQAA_GEMM_MID_FORCE", "1")         # (every shape the member takes, not only where it measured ahead)
+    set_knobs(monkeypatch, "gemm", mid=None)
+    set_knobs(monkeypatch, "gemm", mid=2)         # (every shape the member takes, not only where it measured ahead)
     got, mm = hip_output(case)
     assert mm.plans[M]["name"].endswith("xmk"), mm.plans[M]["name"]
     assert mm.plans[M]["split_k"] == 8
@@ -58,7 +58,7 @@ def test_int4_both_checkpoint_layouts(cfg, fast, monkeypatch):
 
 
 def test_group_sizes_the_wide_metadata_loads_do_not_take_keep_their_members(monkeypatch):
-    monkeypatch.setenv("WQAA_GEMM_MID_FORCE", "1")
+    set_knobs(monkeypatch, "gemm", mid=2)
     for g in (-1, 32, 256):             # (one load fetches Scale / Zeros of a wave's consecutive k-steps: one group per k-step, g = 128)
         mm = bitblas.Matmul(bitblas.MatmulConfig(M=96, N=1024, K=4096, A_dtype="float16", W_dtype="int4", group_size=g, with_scaling=True), enable_tuning=False)
         assert "xmk" not in mm.plans[96]["name"], mm.plans[96]["name"]
@@ -78,8 +78,8 @@ def test_float32_output(monkeypatch):
 
 def test_hipgraph_replays(monkeypatch):
     """one captured pair of launches replayed: same kernel arguments, same scratch every time"""
-    monkeypatch.delenv("WQAA_GEMM_MID", raising=False)
-    monkeypatch.setenv("WQAA_GEMM_MID_FORCE", "1")
+    set_knobs(monkeypatch, "gemm", mid=None)
+    set_knobs(monkeypatch, "gemm", mid=2)
     M = 128
     case = make_case(M, 4096, 4096, W_dtype="uint4", group_size=128, with_scaling=True, with_zeros=True, scale_mul=0.02, seed=9)
     ref, mm = hip_output(case)
@@ -104,8 +104,8 @@ def test_hipgraph_replays(monkeypatch):
 
 def test_two_streams_do_not_share_partial_sums(monkeypatch):
     """two operators' launches in flight on two streams: each stream's scratch holds its own slices"""
-    monkeypatch.delenv("WQAA_GEMM_MID", raising=False)
-    monkeypatch.setenv("WQAA_GEMM_MID_FORCE", "1")
+    set_knobs(monkeypatch, "gemm", mid=None)
+    set_knobs(monkeypatch, "gemm", mid=2)
     M = 64
     case = make_case(M, 4096, 4096, W_dtype="uint4", group_size=128, with_scaling=True, with_zeros=True, scale_mul=0.02, seed=21)
     ref, mm = hip_output(case)
@@ -127,14 +127,13 @@ def test_two_streams_do_not_share_partial_sums(monkeypatch):
 
 
 def test_the_member_it_stands_in_for_is_still_there(monkeypatch):
-    """WQAA_GEMM_MID=0: the two-launch member (split-K + reduce kernel); both within the oracle's tolerance"""
+    """WQAA_GEMM_TUNE=mid=0: the two-launch member (split-K + reduce kernel); both within the oracle's tolerance"""
     M = 128
     case = make_case(M, 4096, 4096, W_dtype="uint4", group_size=128, with_scaling=True, with_zeros=True, scale_mul=0.02, seed=2)
-    for k in ("WQAA_GEMM_MID", "WQAA_GEMM_MID_FORCE"):
-        monkeypatch.delenv(k, raising=False)
+    set_knobs(monkeypatch, "gemm", mid=None)
     got, mm = hip_output(case)
     assert mm.plans[M]["name"].endswith("xmk")            # (BASELINE c3's M = 128: the selector's own choice)
-    monkeypatch.setenv("WQAA_GEMM_MID", "0")
+    set_knobs(monkeypatch, "gemm", mid="0")
     old, mm0 = hip_output(case)
     assert "xmk" not in mm0.plans[M]["name"] and "xr" in mm0.plans[M]["name"], mm0.plans[M]["name"]
     want = oracle_output(case)
@@ -145,8 +144,7 @@ def test_the_member_it_stands_in_for_is_still_there(monkeypatch):
 def test_where_the_selector_takes_the_member(monkeypatch):
     """the measured rule (csrc/wqaa_gemm.hip, profiles/r05_ab_mid_v3.txt): 65 ... 128 rows in one round at K = 4096; up to 64 rows on long
     K (8192) or over several rounds of workgroups; never at M <= 16, K off the 2048 grid, other formats, 128 rows over several rounds"""
-    for k in ("WQAA_GEMM_MID", "WQAA_GEMM_MID_FORCE"):
-        monkeypatch.delenv(k, raising=False)
+    set_knobs(monkeypatch, "gemm", mid=None)
 
     def name(M, N, K, **kw):
         cfg = dict(A_dtype="float16", W_dtype="uint4", group_size=128, with_scaling=True, with_zeros=True)

@@ -1,6 +1,6 @@
 """The ping-pong MFMA members (csrc/wqaa_gemm_pp_kernel.h: 256 x 256 and 128 x 256 tiles) against the CPU oracle.
 
-The selector takes them for large M by an estimate of the rounds of the chip each tile needs; `WQAA_GEMM_PP_BM=256 / 128` (a
+The selector takes them for large M by an estimate of the rounds of the chip each tile needs; `WQAA_GEMM_TUNE=pp_tile=256 / 128` (a
 plan-time tuning aid) pins the tile so that its edge cases run at sizes the oracle finishes in seconds: ragged M and N, one trip
 of the main loop, every dequant mode it implements, integer and non-integer zero points (two decode paths), both checkpoint
 layouts, bias.  BASELINE c3 / c4 at full size run through the 256-row tile in tests/test_gemm_gpu.py."""
@@ -8,14 +8,14 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import assert_fp_parity, hip_output, make_case, oracle_output
+from helpers import knob_value, set_knobs, assert_fp_parity, hip_output, make_case, oracle_output
 
 pytestmark = pytest.mark.gpu
 
 
 @pytest.fixture(autouse=True, params=[256, 128], ids=["tile256", "tile128"])
 def pin_the_tile(monkeypatch, request):
-    monkeypatch.setenv("WQAA_GEMM_PP_BM", str(request.param))
+    set_knobs(monkeypatch, "gemm", pp_tile=str(request.param))
     return request.param
 
 
@@ -24,7 +24,7 @@ def _run(case, M, exact=False):
     got, mm = hip_output(case)
     plan = mm.plans[M]
     assert plan["kernel_family"] == 2 and plan["name"].endswith("pp"), plan["name"]
-    assert f"_tcx{os.environ['WQAA_GEMM_PP_BM']}x256x" in plan["name"], plan["name"]
+    assert f"_tcx{knob_value('gemm', 'pp_tile')}x256x" in plan["name"], plan["name"]
     want = oracle_output(case)
     if exact:
         assert np.array_equal(got, want)
@@ -70,7 +70,7 @@ def test_bfloat16_activations(M, N, K, wd, g, ws, zm):
     from test_gemm_gpu import _bf16_case
     out, want, mm = _bf16_case(M, N, K, wd, g, ws, zm, seed=M + N)
     import os
-    assert mm.plans[M]["name"].endswith("pp") and f"_tcx{os.environ['WQAA_GEMM_PP_BM']}x256x" in mm.plans[M]["name"], mm.plans[M]["name"]
+    assert mm.plans[M]["name"].endswith("pp") and f"_tcx{knob_value('gemm', 'pp_tile')}x256x" in mm.plans[M]["name"], mm.plans[M]["name"]
     assert_fp_parity(out, want, rtol=1e-5, atol_frac=1e-5)
 
 
@@ -208,8 +208,8 @@ def test_dense_fp8_128x128_tile(a_dt, w_dt, M, N, K, monkeypatch, pin_the_tile):
         pytest.skip("one tile: runs once")
     import bitblas_amd as bitblas
     import wqaa_oracle as oracle
-    monkeypatch.setenv("WQAA_GEMM_PP_BM", "128")
-    monkeypatch.setenv("WQAA_GEMM_PP_BN", "128")
+    set_knobs(monkeypatch, "gemm", pp_tile="128")
+    set_knobs(monkeypatch, "gemm", pp_bn="128")
     tdt = {"e4m3_float8": torch.float8_e4m3fn, "e5m2_float8": torch.float8_e5m2}
     gen = torch.Generator(device="cuda")
     gen.manual_seed(M + K)
@@ -256,7 +256,7 @@ def test_two_launches_of_different_rows_share_nothing():
 @pytest.mark.parametrize("M,N,K", [(300, 520, 512), (512, 512, 1152), (257, 264, 128)])
 def test_dense_2x4_wave_grid_is_bit_identical_to_the_1x8_grid(kind, M, N, K, monkeypatch, pin_the_tile):
     """round 5: the dense 256 x 256 tile on a 2 (m) x 4 (n) wave grid (wq_gemm_pp8w_kernel: both operands shared LDS tiles, a third
-    fewer LDS reads per MFMA) adds every output's products in the same order as the 1 x 8 grid it replaces (WQAA_GEMM_PP8_WIDE=0)"""
+    fewer LDS reads per MFMA) adds every output's products in the same order as the 1 x 8 grid it replaces (WQAA_GEMM_TUNE=pp8_wide=0)"""
     if pin_the_tile != 256:
         pytest.skip("the 256-row tile only")
     import bitblas_amd as bitblas
@@ -279,7 +279,7 @@ def test_dense_2x4_wave_grid_is_bit_identical_to_the_1x8_grid(kind, M, N, K, mon
         cfg = dict(A_dtype=a_dt, W_dtype=w_dt, accum_dtype="float32", out_dtype="float16")
     outs = []
     for wide in ("1", "0"):
-        monkeypatch.setenv("WQAA_GEMM_PP8_WIDE", wide)
+        set_knobs(monkeypatch, "gemm", pp8_wide=wide)
         mm = bitblas.Matmul(bitblas.MatmulConfig(M=M, N=N, K=K, **cfg), enable_tuning=False)
         assert mm.plans[M]["name"].endswith("pp"), mm.plans[M]["name"]
         out = mm(A, W)

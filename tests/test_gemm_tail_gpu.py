@@ -3,7 +3,7 @@ gemm_launch, GemmArgs::tile_n_off; VERDICT r03 item 6).  A launch costs whole ro
 2048 x 11008 (344 tiles = one round + 88) paid a whole tile's latency for the 88.  The selector now hands the last N-tiles to
 the 128 x 256 member: two launches, disjoint column bands of one output.  Checked here at sizes the oracle finishes quickly
 (the band boundary, ragged M, both accumulator types) and, matrix-wide, bit for bit against the single-launch plan
-(`WQAA_GEMM_PP_TAIL=0`) - both tiles add the same products in the same order.
+(`WQAA_GEMM_TUNE=pp_tail=0`) - both tiles add the same products in the same order.
 Reference semantics: bitblas/ops/general_matmul/tilelang/dequantize/matmul_dequantize_mma.py:333-508 (one output element =
 one k-ordered sum, whatever the tiling)."""
 import numpy as np
@@ -12,7 +12,7 @@ import torch
 
 import bitblas_amd as bitblas
 import wqaa_oracle as oracle
-from helpers import assert_fp_parity
+from helpers import set_knobs, assert_fp_parity
 
 pytestmark = pytest.mark.gpu
 
@@ -21,11 +21,11 @@ def _op(M, N, K, monkeypatch, tail, **cfg):
     """an operator planned - and launched: the library plans at the first launch after a select, under the variables of THAT
     moment - with (default) or without the second launch; the caller keeps the environment until it has synchronised"""
     if tail:
-        monkeypatch.delenv("WQAA_GEMM_PP_TAIL", raising=False)
-        monkeypatch.delenv("WQAA_GEMM_PP_BM", raising=False)
+        set_knobs(monkeypatch, "gemm", pp_tail=None)
+        set_knobs(monkeypatch, "gemm", pp_tile=None)
     else:
-        monkeypatch.setenv("WQAA_GEMM_PP_TAIL", "0")
-        monkeypatch.setenv("WQAA_GEMM_PP_BM", "256")      # the same member over the whole output, one launch
+        set_knobs(monkeypatch, "gemm", pp_tail="0")
+        set_knobs(monkeypatch, "gemm", pp_tile="256")      # the same member over the whole output, one launch
     return bitblas.Matmul(bitblas.MatmulConfig(M=M, N=N, K=K, **cfg), enable_tuning=False)
 
 

@@ -9,7 +9,7 @@ checks are the oracle's contract, run-to-run bit identity, and hipGraph replays.
 import numpy as np
 import pytest
 
-from helpers import assert_fp_parity, hip_output, make_case, oracle_output
+from helpers import set_knobs, assert_fp_parity, hip_output, make_case, oracle_output
 
 pytestmark = pytest.mark.gpu
 
@@ -19,7 +19,7 @@ def _bits(x):
 
 
 def _run(case, M, monkeypatch):
-    monkeypatch.setenv("WQAA_GEMM_DECODE_LONG", "4")        # the form wherever it fits
+    set_knobs(monkeypatch, "gemm", decode_long="4")        # the form wherever it fits
     got, mm = hip_output(case)
     assert mm.plans[M]["name"].endswith("xdlw"), mm.plans[M]["name"]
     assert mm.plans[M]["split_k"] == 1 and mm.lib.workspace_bytes(M) == 0
@@ -59,7 +59,7 @@ def test_nf4_and_float32_output(monkeypatch):
 
 def test_where_it_does_not_fit_other_members_run(monkeypatch):
     """M = 16 at K = 8192 needs 256 KiB of tile; g = 64 is not a hand-counted format"""
-    monkeypatch.setenv("WQAA_GEMM_DECODE_LONG", "4")
+    set_knobs(monkeypatch, "gemm", decode_long="4")
     for kw in (dict(M=16, K=8192, g=128), dict(M=8, K=4096, g=64)):
         case = make_case(kw["M"], 512, kw["K"], W_dtype="uint4", group_size=kw["g"], with_scaling=True, with_zeros=True, zeros_mode="original", scale_mul=0.02, seed=2)
         got, mm = hip_output(case)
@@ -69,7 +69,7 @@ def test_where_it_does_not_fit_other_members_run(monkeypatch):
 
 def test_hipgraph_replays(monkeypatch):
     import torch
-    monkeypatch.setenv("WQAA_GEMM_DECODE_LONG", "4")
+    set_knobs(monkeypatch, "gemm", decode_long="4")
     M = 8
     case = make_case(M, 4096, 4096, W_dtype="uint4", group_size=128, with_scaling=True, with_zeros=True, zeros_mode="original", scale_mul=0.02, seed=21)
     ref, mm = hip_output(case)

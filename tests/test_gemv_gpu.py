@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import assert_fp_parity, hip_output, make_case, oracle_output
+from helpers import set_knobs, assert_fp_parity, hip_output, make_case, oracle_output
 
 # this file covers the per-element-rounding GEMV members (`strict_reference=True`: the reference's definition to the letter);
 # the library's default members at M <= 2 - the exact-product family - have tests/test_gemvx_gpu.py, test_group_gpu.py,
@@ -180,7 +180,7 @@ def test_register_and_lds_activation_members_agree(wd, g, ws, wz, zm, M, monkeyp
     # and is no longer built, csrc/wqaa_gemv_kernel.h gemv_direct_fits; the LDS-staged member is the only one)
     fits = not (wd == "uint2" and M == 2)
     assert mm.plans[M]["name"].endswith("_areg") == fits, mm.plans[M]["name"]
-    monkeypatch.setenv("WQAA_GEMV_NO_DIRECT", "1")
+    set_knobs(monkeypatch, "gemv", areg=0)
     got_lds, mm2 = hip_output(case)
     assert not mm2.plans[M]["name"].endswith("_areg")
     assert np.array_equal(got, got_lds)
@@ -197,7 +197,7 @@ def test_lds_staged_low_bit_members_agree_with_the_register_members(wd, ad, M, m
     case = make_case(M, 512, 4096, W_dtype=wd, A_dtype=ad, out_dtype="int32" if int8 else "float16",
                      **({} if int8 else dict(group_size=128, with_scaling=True, scale_mul=0.05)))
     got, mm = hip_output(case)
-    monkeypatch.setenv("WQAA_GEMV_NO_DIRECT", "1")
+    set_knobs(monkeypatch, "gemv", areg=0)
     got_lds, mm2 = hip_output(case)
     assert not mm2.plans[M]["name"].endswith("_areg")
     assert np.array_equal(got, got_lds), (mm.plans[M]["name"], mm2.plans[M]["name"])
@@ -211,12 +211,12 @@ def test_lds_staged_low_bit_members_agree_with_the_register_members(wd, ad, M, m
 @pytest.mark.parametrize("M", [1, 2])
 def test_integer_gemv_one_chunk_rows_agree_with_the_two_chunk_members(wd, N, K, M, monkeypatch):
     """Rows of ONE lane chunk (2-bit weights at K = 4096: 64 lanes x 64 weights; K = 3200 fills 50 lanes of it) run the
-    (4 rows x 1 chunk) integer-activation members (`..._b?r4d1`); `WQAA_GEMV_CHUNK=0` pins the (2 x 2) members that pad the row with
+    (4 rows x 1 chunk) integer-activation members (`..._b?r4d1`); `WQAA_GEMV_TUNE=chunk=0` pins the (2 x 2) members that pad the row with
     a second chunk: same int32 bits, both equal to the oracle."""
     case = make_case(M, N, K, W_dtype=wd, A_dtype="int8", out_dtype="int32", seed=N + K + M)
     got, mm = hip_output(case)
     assert "r4d1" in mm.plans[M]["name"], mm.plans[M]["name"]
-    monkeypatch.setenv("WQAA_GEMV_CHUNK", "0")
+    set_knobs(monkeypatch, "gemv", chunk="0")
     got2, mm2 = hip_output(case)
     assert "d2" in mm2.plans[M]["name"] and "r4d1" not in mm2.plans[M]["name"], mm2.plans[M]["name"]
     assert np.array_equal(got, got2)
@@ -248,7 +248,7 @@ def test_k_split_rounding_members(N, K, kw, monkeypatch):
     """kw = 0: the selector's own choice (must split for these shapes); otherwise forced.  Same parity bound as the
     unsplit member, bit-identical from run to run (the parts meet in LDS in a fixed order)."""
     if kw:
-        monkeypatch.setenv("WQAA_GEMV_KW", str(kw))
+        set_knobs(monkeypatch, "gemv", kw=str(kw))
     case = make_case(1, N, K, W_dtype="uint4", group_size=128, with_scaling=True, with_zeros=True, zeros_mode="original",
                      scale_mul=0.02, seed=kw + N, out_dtype="float32", accum_dtype="float32")
     got, mm = hip_output(case)
@@ -264,7 +264,7 @@ def test_k_split_rounding_members(N, K, kw, monkeypatch):
 @pytest.mark.parametrize("M", [1, 2])                # the K-split twins exist for the M <= 2 tiles (M >= 3 is MFMA territory)
 @pytest.mark.parametrize("zm", [None, "rescale", "quantized"])
 def test_k_split_batches_zero_modes_and_bias(M, zm, monkeypatch):
-    monkeypatch.setenv("WQAA_GEMV_KW", "4")
+    set_knobs(monkeypatch, "gemv", kw="4")
     case = make_case(M, 384 + 2, 16384, W_dtype="uint4" if zm else "int4", group_size=128, with_scaling=True, with_zeros=zm is not None,
                      zeros_mode=zm or "original", with_bias=True, scale_mul=0.02, seed=M)
     got, mm = hip_output(case)
@@ -274,7 +274,7 @@ def test_k_split_batches_zero_modes_and_bias(M, zm, monkeypatch):
 
 @pytest.mark.parametrize("wd", ["int2", "int4"])
 def test_k_split_int8_activations_bit_exact(wd, monkeypatch):
-    monkeypatch.setenv("WQAA_GEMV_KW", "3")
+    set_knobs(monkeypatch, "gemv", kw="3")
     case = make_case(2, 768, 24576, W_dtype=wd, A_dtype="int8", out_dtype="int32", seed=3)
     got, mm = hip_output(case)
     assert mm.plans[2]["split_k"] == 3, mm.plans[2]

@@ -17,7 +17,7 @@ import pytest
 import torch
 
 import wqaa_oracle as oracle
-from helpers import case_contract, contract, assert_fp_parity, hip_output, make_case, oracle_output
+from helpers import set_knobs, case_contract, contract, assert_fp_parity, hip_output, make_case, oracle_output
 
 pytestmark = pytest.mark.gpu
 
@@ -25,10 +25,10 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(autouse=True)
 def exact_members_wherever_they_exist(request, monkeypatch):
     """The selector hands some shapes (M = 2 on few rows, very long K) to the rounding members because those are faster
-    there; the parity tests below are about the exact members themselves, so they lift those fences (WQAA_GEMVX=2).
+    there; the parity tests below are about the exact members themselves, so they lift those fences (WQAA_GEMV_TUNE=exact=2).
     Tests of the selector's own choice opt out with `@pytest.mark.selector_choice`."""
     if request.node.get_closest_marker("selector_choice") is None:
-        monkeypatch.setenv("WQAA_GEMVX", "2")
+        set_knobs(monkeypatch, "gemv", exact="2")
 
 
 def exact_output(case):
@@ -129,7 +129,7 @@ def test_baseline_c2_full_size(N, K):
 def test_k_split_across_the_waves_of_a_workgroup(N, K, kw, monkeypatch):
     """per-rank shards of the multi-GPU split (N / 8 rows x long K) and ragged shapes, every K-split width: the parts
     meet in LDS in a fixed order, so the result is bit-identical run to run; kw > steps is clipped"""
-    monkeypatch.setenv("WQAA_GEMVX_KW", str(kw))
+    set_knobs(monkeypatch, "gemv", kw=str(kw))
     case = make_case(1, N, K, W_dtype="uint4", group_size=128, with_scaling=True, with_zeros=True, zeros_mode="original",
                      scale_mul=0.02, seed=kw + N, out_dtype="float32", accum_dtype="float32")
     got, mm = check(case)
@@ -166,7 +166,7 @@ def test_strict_reference_keeps_the_rounding_members():
 def test_register_resident_activations_member(N, K, zm, areg, monkeypatch):
     """4-bit LOP3 weights, M = 1, K within one step: the lane keeps its own activations in registers (no LDS tile, no
     barrier); forced on and off it must meet the same bounds, ragged K / N and every zero mode included"""
-    monkeypatch.setenv("WQAA_GEMVX_AREG", str(areg))
+    set_knobs(monkeypatch, "gemv", areg=str(areg))
     case = make_case(1, N, K, W_dtype="uint4" if zm else "int4", group_size=64 if K % 128 else 128, with_scaling=True,
                      with_zeros=zm is not None, zeros_mode=zm or "original", scale_mul=0.02, seed=N + areg,
                      out_dtype="float32", accum_dtype="float32")

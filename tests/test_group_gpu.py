@@ -11,7 +11,7 @@ import torch
 
 import bitblas_amd as bitblas
 from bitblas_amd import group as wgroup
-from helpers import case_contract, contract, _to_dev, assert_fp_parity, make_case, oracle_output
+from helpers import set_knobs, case_contract, contract, _to_dev, assert_fp_parity, make_case, oracle_output
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -175,9 +175,9 @@ def test_results_do_not_depend_on_the_grid(monkeypatch):
         base = [op(A, *w) for op, w in zip(ops, ws)]
         gbase = bitblas.matmul_group(ops, A, ws)
         for grid, ggrid in ((344, 344), (504, 200), (8, 16)):
-            monkeypatch.setenv("WQAA_GEMVX_GRID", str(grid))
-            monkeypatch.setenv("WQAA_GEMV_GRID", str(grid))
-            monkeypatch.setenv("WQAA_GROUP_GRID", str(ggrid))
+            set_knobs(monkeypatch, "gemv", grid=str(grid))
+            set_knobs(monkeypatch, "gemv", grid=str(grid))
+            set_knobs(monkeypatch, "gemv", group_grid=str(ggrid))
             plan = ops[0].lib.plan(1)                     # planning re-reads the tuning variables
             assert plan["grid"] == grid
             gplan = wgroup.group_plan(ops, 1)
@@ -186,9 +186,9 @@ def test_results_do_not_depend_on_the_grid(monkeypatch):
                 assert torch.equal(op(A, *w), b)
             for g_, b in zip(bitblas.matmul_group(ops, A, ws), gbase):
                 assert torch.equal(g_, b)
-        monkeypatch.delenv("WQAA_GEMVX_GRID")
-        monkeypatch.delenv("WQAA_GEMV_GRID")
-        monkeypatch.delenv("WQAA_GROUP_GRID")
+        set_knobs(monkeypatch, "gemv", grid=None)
+        set_knobs(monkeypatch, "gemv", grid=None)
+        set_knobs(monkeypatch, "gemv", group_grid=None)
         ops[0].lib.plan(1)
         for g_, b in zip(gbase, base):
             assert torch.equal(g_, b)

@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import assert_fp_parity, make_case, oracle_output
+from helpers import set_knobs, assert_fp_parity, make_case, oracle_output
 
 import bitblas_amd as bitblas
 from bitblas_amd import lib as wl
@@ -204,7 +204,7 @@ def test_automatic_two_pass_does_not_refuse_a_capture_that_needed_no_scratch_bef
 
 def test_automatic_two_pass_is_capped_and_takes_a_short_workspace_as_the_fused_member(monkeypatch):
     """round 5: the automatic two-pass form must not turn a call that needed no scratch into a refused or a memory-hungry
-    one.  Beyond WQAA_TWO_PASS_AUTO_MAX_MB the plan, `workspace_bytes` and the call all say "fused member"; with the cap open, a caller
+    one.  Beyond WQAA_TWO_PASS=auto_max_mb=N the plan, `workspace_bytes` and the call all say "fused member"; with the cap open, a caller
     workspace too small for B_decode runs the fused member instead of returning BAD_DESC; both meet the oracle."""
     import ctypes
     import wqaa_oracle as oracle
@@ -217,7 +217,7 @@ def test_automatic_two_pass_is_capped_and_takes_a_short_workspace_as_the_fused_m
     want = oracle.matmul_dequant(A[rows], W, source_format="int", bit=8, a_dtype="float16", out_dtype="float32").astype(np.float16).astype(np.float32)
     Ad, Wd = torch.from_numpy(A).cuda(), torch.from_numpy(W).cuda()
     # (a) the cap: N K 2 = 4 MiB of scratch against a 1 MiB cap
-    monkeypatch.setenv("WQAA_TWO_PASS_AUTO_MAX_MB", "1")
+    set_knobs(monkeypatch, "two_pass", auto_max_mb="1")
     capped = bitblas.Matmul(cfg, enable_tuning=False)
     assert "_dq_" not in capped.plans[M]["name"], capped.plans[M]["name"]
     fused_need = capped.lib.workspace_bytes(M)
@@ -226,7 +226,7 @@ def test_automatic_two_pass_is_capped_and_takes_a_short_workspace_as_the_fused_m
     torch.cuda.synchronize()
     assert_fp_parity(out.float().cpu().numpy()[rows], want, rtol=1e-3, atol_frac=1e-3)
     # (b) cap open, the caller's workspace holds the fused member's partial sums but not B_decode
-    monkeypatch.delenv("WQAA_TWO_PASS_AUTO_MAX_MB")
+    set_knobs(monkeypatch, "two_pass", auto_max_mb=None)
     mm = bitblas.Matmul(cfg, enable_tuning=False)
     need = mm.lib.workspace_bytes(M)
     assert "_dq_" in mm.plans[M]["name"] and need >= N * K * 2

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """tools/ab_knobs.py "N K" ["N K" ...] -- "VAR=v VAR=v" ["VAR=v" ...]: same-process sweep of tile-selector tuning
-variables on M = 1 int4 g128 GEMVs (exact-product members unless AB_STRICT=1).  hipGraph replays over rotating
+variables (e.g. "WQAA_GEMV_TUNE=kw=2,grid=512") on M = 1 int4 g128 GEMVs (exact-product members unless AB_STRICT=1).  hipGraph replays over rotating
 weight sets, two rounds, microseconds per launch."""
 import os
 import sys
@@ -36,7 +36,7 @@ def main():
         res = {}
         for rnd in range(2):
             for combo in combos:
-                kv = dict(x.split("=") for x in combo.split()) if combo else {}
+                kv = dict(x.split("=", 1) for x in combo.split()) if combo else {}
                 os.environ.update(kv)
                 try:
                     plan = op.lib.plan(1)

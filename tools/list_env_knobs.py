@@ -14,6 +14,8 @@ import os
 import re
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# the two tuning variables hold lists of key[=value] tokens (csrc/wqaa_common.h: knob); their keys are listed under them
+TUNE = {"WQAA_GEMV_TUNE": "gemv_knob", "WQAA_GEMM_TUNE": "gemm_knob"}
 PRODUCT = {
     "WQAA_DENSE_LIB": "opt-in: plain dense pairs / the tuned two-pass member through the vendor library (yardstick; default off)",
     "WQAA_TWO_PASS": "opt-in: B_decode to a scratch + dense GEMM at large M (needs WQAA_DENSE_LIB for the vendor GEMM)",
@@ -30,14 +32,21 @@ def main():
     ap.add_argument("--out")
     args = ap.parse_args()
     seen = collections.defaultdict(list)
+    keys = {v: collections.defaultdict(list) for v in TUNE}
     files = [os.path.join(dp, f) for top in ("bitblas_amd", ".") for dp, _, fs in os.walk(os.path.join(ROOT, top))
              for f in fs if f.endswith((".hip", ".h", ".py")) and "/tools" not in dp and "/tests" not in dp and "/oracle" not in dp
              and "/.git" not in dp and (top != "." or dp == os.path.join(ROOT, "."))]
     for path in sorted(set(files)):
         with open(path) as fh:
             for no, line in enumerate(fh, 1):
-                for m in re.finditer(r'(?:getenv\(|environ(?:\.get|\.pop|\.setdefault)?[\(\[])\s*"(WQAA_[A-Z0-9_]+)"', line):
+                for m in re.finditer(r'(?:getenv\(|knob\(|environ(?:\.get|\.pop|\.setdefault)?[\(\[])\s*"(WQAA_[A-Z0-9_]+)"', line):
                     seen[m.group(1)].append(f"{os.path.relpath(path, ROOT)}:{no}")
+                for var, fn in TUNE.items():
+                    for m in re.finditer(fn + r'(?:_set)?\("([a-z0-9_]+)"', line):
+                        keys[var][m.group(1)].append(f"{os.path.relpath(path, ROOT)}:{no}")
+    for var in TUNE:
+        if keys[var]:
+            seen.setdefault(var, ["csrc/wqaa_common.h (knob)"])
     lines = [f"# {len(seen)} WQAA_* environment variables ({sum(k in PRODUCT for k in seen)} product switches, "
              f"{sum(k not in PRODUCT for k in seen)} A/B aids); tools/list_env_knobs.py"]
     for cls in ("product", "aid"):
@@ -45,6 +54,8 @@ def main():
             if (k in PRODUCT) != (cls == "product"):
                 continue
             lines.append(f"{cls:8s}{k:28s}{', '.join(seen[k])}" + (f"   - {PRODUCT[k]}" if k in PRODUCT else ""))
+            for key in sorted(keys.get(k, {})):
+                lines.append(f"{'':8s}  {key + '=':26s}{', '.join(keys[k][key])}")
     text = "\n".join(lines) + "\n"
     if args.out:
         with open(args.out, "w") as fh:
