@@ -40,6 +40,7 @@ enum : int {
   PPO_ABL_NODEC = 256,   //   no weight decode
   PPO_ABL_NOBAR = 512,   //   no s_barrier in the loop (wqaa_gemm_mm_kernel.h),
   PPO_ABL_NOMFMA = 1024, //   no MFMA (wqaa_gemm_mm_kernel.h)
+  PPO_ABL_METAONCE = 2048, // Scale / Zeros read and converted for the first k-body only (what the per-body metadata handling costs)
 };
 
 // BM_ = 256: the full tile.  BM_ = 128: the same loop on half the activation rows, for shapes whose 256-row tiles would leave the
@@ -352,6 +353,9 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_pp_kernel(const GemmArgs a
     }
   }
   auto meta_read = [&](int b) {            // Scale / Zeros of body b (its window has landed)
+    if constexpr ((P::OPT & PPO_ABL_METAONCE) != 0) {
+      if (b != 0) return;
+    }
     if constexpr (P::HAS_META) {
       const int gi = group_of_body(b);
       const int q8 = gi & ~7;
@@ -573,7 +577,7 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_pp_kernel(const GemmArgs a
 #pragma unroll
         for (int nf = 0; nf < 2; ++nf) decode(ZI, rawc[tq][nf][1], s2c[nf], zAc[nf], zBc[nf], bw[1][nf]);
       } else {
-        if constexpr ((tq & 1) == 1) meta_convert(ZI, s2c, zAc, zBc);
+        if constexpr ((tq & 1) == 1 && !(P::OPT & PPO_ABL_METAONCE)) meta_convert(ZI, s2c, zAc, zBc);
 #pragma unroll
         for (int nf = 0; nf < 2; ++nf) decode(ZI, rawc[(tq + 1) & 3][nf][0], s2c[nf], zAc[nf], zBc[nf], bw[0][nf]);
       }
@@ -589,7 +593,7 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_pp_kernel(const GemmArgs a
       decode(ZI, rawc[tq + 1][nf_dec][0], s2c[nf_dec], zAc[nf_dec], zBc[nf_dec], bw[0][nf_dec]);
     } else {
       // after an odd tile the next tile opens a new k-body: segments 0 and 1 were the last to decode with the old values
-      if constexpr (mh == 0) meta_convert(ZI, s2c, zAc, zBc);
+      if constexpr (mh == 0 && !(P::OPT & PPO_ABL_METAONCE)) meta_convert(ZI, s2c, zAc, zBc);
       decode(ZI, rawc[(tq + 1) & 3][nf_dec][0], s2c[nf_dec], zAc[nf_dec], zBc[nf_dec], bw[0][nf_dec]);   // (tq == 3: the half chunk read in load segment 1)
     }
 #pragma unroll

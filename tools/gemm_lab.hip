@@ -30,6 +30,7 @@ using namespace wqaa;
   X("pp_nozint", DK_INT4, LAYOUT_LOP3, AT_F16, MD_ZO, 0, 3, PPO_ZINT_OFF)                    \
   X("pp_metaslow", DK_INT4, LAYOUT_LOP3, AT_F16, MD_ZO, 0, 3, PPO_META_SLOW)                 \
   X("pp_rw64", DK_INT4, LAYOUT_LOP3, AT_F16, MD_ZO, 0, 3, PPO_RW64)                          \
+  X("pp_metaonce", DK_INT4, LAYOUT_LOP3, AT_F16, MD_ZO, 0, 3, PPO_ABL_METAONCE)             \
   X("pp_scaleonly", DK_INT4, LAYOUT_LOP3, AT_F16, MD_S, 0, 3, 0)                             \
   X("pp_nometa", DK_INT4, LAYOUT_LOP3, AT_F16, MD_NONE, 0, 3, 0)                             \
   X("pp_nometa_r4", DK_INT4, LAYOUT_LOP3, AT_F16, MD_NONE, 0, 4, 0)                          \
