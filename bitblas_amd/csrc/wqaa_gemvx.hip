@@ -367,7 +367,28 @@ int gemvx_pair_launch(const wqaa_matmul_desc& d, const wqaa_group_item* gate, co
 // ---- a group of independent operators in one launch (wqaa_matmul_group) -------------------------------------------------
 // The tile configuration is the one the selector gives the MERGED operator (N = sum of the members' rows: what a caller
 // that concatenates q/k/v or gate/up into one Linear would get); every member then takes gridDim.x workgroups of it.
-static int gemvx_group_choose(const wqaa_matmul_desc& merged, const int* Ns, int count, int m, GemvxChoice* c, int* grid_x, bool norm = false) {
+// The K split across waves member i gets ALONE - the fp32 summation order of its rows in a single call.  Round 6: a group keeps it per
+// member (GemvxArgs::kw / slots / n_rgb are per member; the workgroup width is the group's), so members of very different widths -
+// q (8192 rows) next to k / v (1024 rows each, K split in two when alone) under grouped-query attention - fuse and still give the
+// bits of their single calls.  (Until round 5 every member had to land on the merged operator's split: a 70B layer's q/k/v ran as
+// three launches, 16.1 us where the fused launch takes ~11.5.)
+static int solo_kw(const wqaa_matmul_desc& merged, int N, int m, int* D = nullptr) {
+  wqaa_matmul_desc d = merged;
+  d.N = N;
+  static thread_local ChoiceMemo<GemvxChoice> memo;
+  GemvxChoice c;
+  if (const GemvxChoice* hit = memo.find(d, m, 15)) {
+    c = *hit;
+  } else {
+    if (gemvx_choose(d, m, &c, 0) != WQAA_OK) return 0;
+    memo.put(d, m, 15, c);
+  }
+  if (D) *D = c.D;
+  return c.kw;
+}
+
+static int gemvx_group_choose(const wqaa_matmul_desc& merged, const int* Ns, int count, int m, GemvxChoice* c, int* grid_x, bool norm = false,
+                              int* kws = nullptr) {
   {
     static thread_local ChoiceMemo<GemvxChoice> memo;
     const int q = (norm ? 48 : 16) + count;
@@ -379,9 +400,12 @@ static int gemvx_group_choose(const wqaa_matmul_desc& merged, const int* Ns, int
       memo.put(merged, m, q, *c);
     }
   }
-  const int slots = c->nw / c->kw;
   int need = 1;
   for (int i = 0; i < count; ++i) {
+    int kw = solo_kw(merged, Ns[i], m);
+    if (kw < 1 || c->nw % kw != 0) kw = c->kw;        // (gemvx_group_eligible has refused such groups: defensive)
+    if (kws) kws[i] = kw;
+    const int slots = c->nw / kw;
     const int n_rgb = ((Ns[i] + c->R - 1) / c->R + slots - 1) / slots;
     if (n_rgb > need) need = n_rgb;
   }
@@ -396,10 +420,10 @@ static int gemvx_group_choose(const wqaa_matmul_desc& merged, const int* Ns, int
   return WQAA_OK;
 }
 
-// A fused group must give every member the bits a single call would: the family (exact products vs per-element rounding)
-// and the K split across waves (the fp32 summation order of a row) are chosen from N, so each member ALONE has to land on
-// the merged operator's choice - otherwise the group runs as separate launches.  (Rows per wave, workgroup width, grid and
-// register-resident vs LDS-staged activations do not change a row's arithmetic: tests/test_group_gpu.py.)
+// A fused group must give every member the bits a single call would: the family (exact products vs per-element rounding) is
+// chosen from N, so each member ALONE has to be this family's; its K split across waves (the fp32 summation order of a row) is kept
+// per member and must divide the group's workgroup width.  (Rows per wave, workgroup width, grid and register-resident vs
+// LDS-staged activations do not change a row's arithmetic: tests/test_group_gpu.py.)
 bool gemvx_group_eligible(const wqaa_matmul_desc& merged, const wqaa_matmul_desc* const* descs, int count, int m, bool norm) {
   // (the norm in front exists in this family only: what it covers counts, not where it is the faster one)
   auto takes = [&](const wqaa_matmul_desc& d) { return norm ? gemvx_covers(d, m) : gemvx_eligible(d, m); };
@@ -407,11 +431,12 @@ bool gemvx_group_eligible(const wqaa_matmul_desc& merged, const wqaa_matmul_desc
   GemvxChoice cm;
   if (gemvx_choose(merged, m, &cm, norm ? 3 : 0) != WQAA_OK) return false;
   for (int i = 0; descs && i < count; ++i) {
-    GemvxChoice ci;
     // (the norm's capacity - the rows within the items a workgroup loads ahead - is the MERGED configuration's: a narrow member,
-    // the k / v of grouped-query attention, runs in the group's workgroups; what has to agree is the summation order)
-    if (!takes(*descs[i]) || gemvx_choose(*descs[i], m, &ci, 0) != WQAA_OK) return false;
-    if (ci.kw != cm.kw || ci.D != cm.D) return false;
+    // the k / v of grouped-query attention, runs in the group's workgroups)
+    if (!takes(*descs[i])) return false;
+    int Di = 0;
+    const int kwi = solo_kw(merged, descs[i]->N, m, &Di);
+    if (kwi < 1 || Di != cm.D || cm.nw % kwi != 0) return false;
   }
   return true;
 }
@@ -433,15 +458,17 @@ int gemvx_group_plan(const wqaa_matmul_desc& merged, const int* Ns, int count, i
 
 int gemvx_group_launch(const wqaa_matmul_desc& merged, const wqaa_group_item* items, int count, int m, hipStream_t stream,
                        const wqaa_epilogue* norm) {
-  int Ns[kGemvxGroupMax];
+  int Ns[kGemvxGroupMax], kws[kGemvxGroupMax];
   for (int i = 0; i < count; ++i) Ns[i] = items[i].desc->N;
   GemvxChoice c;
   int gx = 0;
-  int st = gemvx_group_choose(merged, Ns, count, m, &c, &gx, norm != nullptr);
+  int st = gemvx_group_choose(merged, Ns, count, m, &c, &gx, norm != nullptr, kws);
   if (st != WQAA_OK) return st;
   GemvxGroupArgs ga;
   for (int i = 0; i < count; ++i) {
-    gemvx_fill(*items[i].desc, c, items[i].A, items[i].B, items[i].Scale, items[i].Zeros, items[i].Bias, items[i].C, m, &ga.p[i]);
+    GemvxChoice ci = c;
+    ci.kw = kws[i];                                    // the member's own K split: its single call's summation order
+    gemvx_fill(*items[i].desc, ci, items[i].A, items[i].B, items[i].Scale, items[i].Zeros, items[i].Bias, items[i].C, m, &ga.p[i]);
     if (norm) gemvx_set_norm(ga.p[i], norm);          // one norm for the group: its members read the same hidden state
   }
   return gemvx_dispatch(c, ga, gx, count, stream, nullptr, nullptr);

@@ -26,14 +26,26 @@ def member_class(name: str) -> str:
     return re.sub(r"_x\d+$", "_xG", cls)            # group launches: one class whatever the member count
 
 
-def reachable(with_args=False):
-    """class -> a one-line example (or, with_args, the example's arguments: tests/test_member_coverage_gpu.py runs it)"""
+def mode_tag(mode, fd):
+    """the template arguments a plan name does not show: scale / zeros mode and checkpoint layout"""
+    z = {"original": "zo", "rescale": "zr", "quantized": "zq"}[mode["zeros_mode"]] if mode.get("with_zeros") else ("s" if mode.get("with_scaling") else "none")
+    return z + ("" if fd is None else "_plain")
+
+
+def reachable(with_args=False, per_kernel=False):
+    """class -> a one-line example (or, with_args, the example's arguments: tests/test_member_coverage_gpu.py runs it).
+    per_kernel: one entry per (class, scale / zeros mode, layout) - about one per kernel INSTANTIATION a plain call can reach
+    (round 6: a rocprofv3 census of the GPU suite found two thirds of the library's kernels launched by no test,
+    tools/kernel_census.py); examples come from the smallest shape that reaches the entry"""
     f16 = [("float16", w) for w in ("uint4", "int4", "uint2", "int2", "uint1", "int1", "uint8", "int8", "nf4", "fp4_e2m1", "e4m3_float8", "float16")]
     bf16 = [("bfloat16", w) for w in ("uint4", "int4", "uint2", "uint1", "int8", "nf4", "fp4_e2m1", "e4m3_float8", "bfloat16")]
     i8 = [("int8", w) for w in ("int8", "int4", "uint4", "int2", "uint2", "int1")]
     f8 = [("e4m3_float8", "e4m3_float8"), ("e5m2_float8", "e5m2_float8")]
     i4 = [("int4", "int4"), ("int4", "int2")]
     shapes = [(1024, 1024), (4096, 4096), (11008, 4096), (4096, 11008), (1024, 28672), (28672, 8192), (272, 2048), (5120, 4096), (2048, 8192), (4352, 8192)]
+    if per_kernel:
+        shapes = sorted([(64, 256), (48, 128), (100, 384), (272, 512), (528, 1024), (2048, 1024), (8192, 512), (16384, 256), (1024, 8192), (512, 16384), (24, 4096)] + shapes,
+                        key=lambda nk: nk[0] * nk[1])
     ms = [1, 2, 3, 8, 16, 32, 64, 128, 256, 1024, 4096]
     seen = {}
     for (a, w) in f16 + bf16 + i8 + f8 + i4:
@@ -55,10 +67,13 @@ def reachable(with_args=False):
             except Exception:  # noqa: BLE001 - a refused configuration reaches no member
                 continue
             for m in ms:
+                key = member_class(op.plans[m]["name"])
+                if per_kernel:
+                    key += "|" + mode_tag(mode, fd)
                 if with_args:
-                    seen.setdefault(member_class(op.plans[m]["name"]), dict(M=m, N=N, K=K, a=a, w=w, mode=mode, fd=fd, strict=strict, cfg=cfg))
+                    seen.setdefault(key, dict(M=m, N=N, K=K, a=a, w=w, mode=mode, fd=fd, strict=strict, cfg=cfg))
                 else:
-                    seen.setdefault(member_class(op.plans[m]["name"]), f"M={m} N={N} K={K} {a} x {w} {mode} fd={fd} strict={strict}")
+                    seen.setdefault(key, f"M={m} N={N} K={K} {a} x {w} {mode} fd={fd} strict={strict}")
     return seen
 
 
