@@ -1,15 +1,15 @@
-// wqaa_dense_lib.hip - the PLAIN dense GEMMs of the operator (W_dtype == A_dtype, a float type, no scale / zeros / bias:
-// BASELINE c5's e4m3 x e4m3 and the float16 / bfloat16 fallbacks, reference: bitblas/ops/general_matmul/tirscript/
-// matmul_impl.py:50-86, tilelang/dense/matmul.py:62-145) go to the vendor library, hipBLASLt, from M = 16 up.
+// wqaa_dense_lib.hip - the vendor library (hipBLASLt) as an OPT-IN yardstick for the PLAIN dense GEMMs of the operator (W_dtype ==
+// A_dtype, a float type, no scale / zeros / bias: BASELINE c5's e4m3 x e4m3 and the float16 / bfloat16 pairs; reference:
+// bitblas/ops/general_matmul/tirscript/matmul_impl.py:50-86, tilelang/dense/matmul.py:62-145) and as the second pass of the opt-in
+// two-pass member.
 //
-// Nothing is decoded in these: C = A . W^T with fp32 accumulation is exactly what the library's tuned assembly kernels
-// compute, and on MI355X they are ahead of this library's own HIP MFMA members (same operands, hipGraph replays,
-// tools/blaslt_probe.py -> profiles/r02_blaslt_probe.txt): e4m3 M = 4096 on the Llama-3-70B shapes 2.3-2.6 PFLOP/s
-// against 1.6-1.8 (results bit-identical), float16 4096^3 1331 against 889 TFLOP/s, and ahead at every M >= 16 tried.
-// The quantised paths - everything that fuses an unpack / dequant into the loop - stay on the hand-written kernels, as
-// do the dense members for M < 16 (GEMV, decode-batch), with a bias (the reference adds it AFTER the cast to out_dtype,
-// the library's epilogue before), with the callers' fused epilogues, for int8 and for mixed fp8 pairs.
-// WQAA_DENSE_LIB=0 (plan-time) keeps every dense shape on the own members.
+// The DEFAULT for every dense shape is this library's own kernels (wq_gemm_pp8w_kernel and its siblings, csrc/wqaa_gemm_pp_kernel.h):
+// since round 5 they are ahead of the vendor kernels on all four Llama-3-70B e4m3 linears at M = 4096 (0.61 / 0.67 / 0.56 / 0.61 of
+// the fp8 peak against 0.57 / 0.61 / 0.55 / 0.58) and within 3-5 % on float16 4096^3 (round 2, when this file was written, they were
+// 1.5x behind: profiles/r02_blaslt_probe.txt).  WQAA_DENSE_LIB=1 (plan time) routes plain dense shapes from M = 16 up through
+// hipBLASLt - `wqaa_tune` then times its candidates AND the own member and keeps the faster; bench.py's `*_vendor` members are the
+// only callers.  Never routed: everything that fuses an unpack / dequant into the loop, M < 16, a bias (the reference adds it AFTER
+// the cast to out_dtype, the vendor epilogue before), the callers' fused epilogues, int8 and mixed fp8 pairs.
 //
 // Row-major C[m, n] = sum_k A[m, k] W[n, k] is the column-major product C^T = op_T(Wcm) . Acm with Wcm = W's memory
 // read as K x N (ld = K), Acm = A's memory read as K x M (ld = K), C^T = N x M (ld = N): the "TN" form the library's

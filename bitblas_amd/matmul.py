@@ -419,8 +419,8 @@ class Matmul(Operator):
         self.target = target
         self.backend = backend
         self.arch = get_arch(target)
-        if self.arch.platform not in ("CDNA", "CUDA"):
-            raise ValueError("Currently only support cuda and hip target")
+        if self.arch.platform != "CDNA":           # (get_arch refuses everything but hip / gfx950 already; ref :388-389 names cuda and hip)
+            raise ValueError("bitblas_amd only supports the hip (gfx950) target")
         self.source_format, self.bit = self.BITBLAS_TRICK_DTYPE_MAP[config.W_dtype]
         if self.source_format == "int" and config.with_zeros:
             logger.warning("[BitBLAS][Warning] with_zeros is not supported for int source format "

@@ -39,9 +39,16 @@ def summarize(d):
     elif "SQ_INSTS_MFMA" in m and "GRBM_GUI_ACTIVE" in m:
         simds, xcds = 1024, 8
         cyc = m["GRBM_GUI_ACTIVE"] / xcds                      # busy cycles of one XCD
+        # GRBM_GUI_ACTIVE keeps counting past a short kernel's own timestamps (ramp-up / drain of the whole dispatch): round 5's
+        # mid-M row came out at an impossible 3.49 GHz.  Where the quotient exceeds the chip's 2.4 GHz, the kernel's own wall time
+        # at 2.4 GHz bounds its cycles and no clock is reported
+        wall_cyc = out["launch_ns_mean_under_counters"] * 2.4
+        clock = cyc / out["launch_ns_mean_under_counters"]
+        if clock > 2.45:
+            cyc, clock = wall_cyc, None
         out["derived"] = {
             "cycles_per_launch": cyc,
-            "clock_GHz": cyc / out["launch_ns_mean_under_counters"],
+            "clock_GHz": clock,
             "mfma_pipe_busy_frac": m["SQ_VALU_MFMA_BUSY_CYCLES"] / (simds * cyc),
             "cycles_per_mfma": m["SQ_VALU_MFMA_BUSY_CYCLES"] / m["SQ_INSTS_MFMA"],
             "other_valu_per_mfma": (m["SQ_INSTS_VALU"] - m["SQ_INSTS_MFMA"]) / m["SQ_INSTS_MFMA"],
