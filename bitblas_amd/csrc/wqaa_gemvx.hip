@@ -2,47 +2,14 @@
 // selection (rows per wave, K split across the waves of a workgroup, workgroup width, grid) and launch.
 #include "wqaa_gemvx_kernel.h"
 
-#include <mutex>
-#include <vector>
-
 namespace wqaa {
 
 struct GemvxChoice {
   gemvx_fn fn;
   int bits, layout, mode, mb, R, D, kw, nw;
   int E, cpr, nc, nsteps, n_rgb;
-  int grid, lds, areg, dyn;
+  int grid, lds, areg;
 };
-
-// ---- hand-out words of the DYN members: 8 operators x 64 words per (device, stream), zero-initialised once; the kernels leave them
-// zero (the last wave of a launch resets them).  Allocated on first use outside stream capture; a stream first seen while capturing
-// gets none and the launch takes the static members (same bits). ----
-struct DynSlab {
-  int dev;
-  hipStream_t stream;
-  unsigned* ptr;
-};
-static std::vector<DynSlab> g_dyn;
-static std::mutex g_dyn_mu;
-static unsigned* dyn_words(hipStream_t stream) {
-  const int dev = current_device();
-  if (dev < 0) return nullptr;
-  std::lock_guard<std::mutex> lk(g_dyn_mu);
-  for (auto& d : g_dyn)
-    if (d.dev == dev && d.stream == stream) return d.ptr;
-  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-  if (hipStreamIsCapturing(stream, &cs) != hipSuccess) (void)hipGetLastError();
-  if (cs != hipStreamCaptureStatusNone) return nullptr;
-  void* p = nullptr;
-  const size_t bytes = (size_t)kGemvxGroupMax * 64 * sizeof(unsigned);
-  if (hipMalloc(&p, bytes) != hipSuccess || hipMemset(p, 0, bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
-    (void)hipGetLastError();
-    if (p) (void)hipFree(p);
-    return nullptr;
-  }
-  g_dyn.push_back(DynSlab{dev, stream, reinterpret_cast<unsigned*>(p)});
-  return g_dyn.back().ptr;
-}
 
 // sub-byte integer weights x float16 activations, M <= 2, and the caller did not ask for the TE definition's
 // per-element rounding (strict_reference).  WQAA_GEMV_TUNE=exact=0 disables the family (A/B aid).
@@ -200,22 +167,7 @@ static int gemvx_choose(const wqaa_matmul_desc& d, int m, GemvxChoice* c, int pr
   }
   if (pro) c->areg = 0;                                  // the fused post ops come with the LDS-staged members
   if (c->areg) c->lds = 64;
-  // Run-time hand-out of row groups to waves (round 6, members `..._dyn`): a persistent grid - what the chip holds at once - wherever
-  // the row-group blocks exceed it (the waves would otherwise take a second block statically or start late): 4-bit weights, one
-  // activation row, two rows per wave, K unsplit.  WQAA_GEMV_TUNE=dyn=0 / 1 forces it off / on (A/B aid).
-  c->dyn = 0;
-  if (c->bits == 4 && c->mb == 1 && c->R == 2 && c->kw == 1 && pro == 0 && !c->areg) {
-    int v = -1;
-    (void)gemv_knob("dyn", &v);
-    c->dyn = v >= 0 ? (v != 0) : 0;
-    if (c->dyn) {
-      int g = cus * blocks_per_cu;                       // what the chip holds at once ...
-      const int need = (n_rg + c->nw - 1) / c->nw;       // ... but never more waves than row groups
-      if (g > need) g = need;
-      c->grid = g >= 8 ? (g + 7) / 8 * 8 : g;
-    }
-  }
-  const int rd = c->dyn ? 42 : c->R * 10 + c->D + (c->areg ? 1 : 0);
+  const int rd = c->R * 10 + c->D + (c->areg ? 1 : 0);
   if (pro >= 3) {
     // the norm takes sum x^2 over items held in registers: the whole activation tile must fit the items a workgroup loads ahead
     const long items = (long)c->mb * ncp * 256;
@@ -266,7 +218,6 @@ int gemvx_plan(const wqaa_matmul_desc& d, int m, wqaa_plan* plan) {
     snprintf(plan->name, sizeof(plan->name), "matmul_m%dn%dk%d_%sx%s_gemvx_b%dr%dd%dk%d", m, d.N, d.K, short_dtype(d.a_dtype), wd,
              c.mb, c.R, c.D, c.kw);
     if (c.areg) strncat(plan->name, "_areg", sizeof(plan->name) - strlen(plan->name) - 1);
-    if (c.dyn) strncat(plan->name, "_dyn", sizeof(plan->name) - strlen(plan->name) - 1);
   }
   return WQAA_OK;
 }
@@ -296,7 +247,6 @@ static void gemvx_fill(const wqaa_matmul_desc& d, const GemvxChoice& c, const vo
   a.slots = slots;
   a.kw_magic = (65536u + (uint32_t)c.kw - 1u) / (uint32_t)c.kw;
   a.residual = nullptr;
-  a.dyn = nullptr;
   a.norm_weight = nullptr;
   a.norm_eps = 0.f;
   a.norm_inv_k = 1.f / (float)d.K;
@@ -338,21 +288,6 @@ int gemvx_launch(const wqaa_matmul_desc& d, const void* A, const void* B, const 
     }
   }
   GemvxGroupArgs ga;
-  if (c.dyn) {
-    unsigned* words = dyn_words(stream);
-    if (!words) {                                        // (a stream first seen during capture: the static member, same bits)
-      GemvxChoice cs = c;
-      cs.dyn = 0;
-      cs.fn = cs.bits == 4 ? pick_gemvx_int4(cs.layout, cs.mode, cs.mb, cs.R * 10 + cs.D) : nullptr;
-      cs.grid = cs.n_rgb >= 8 ? (cs.n_rgb + 7) / 8 * 8 : cs.n_rgb;
-      if (!cs.fn) return WQAA_ERR_UNSUPPORTED;
-      gemvx_fill(d, cs, A, B, Scale, Zeros, Bias, C, m, &ga.p[0]);
-      return gemvx_dispatch(cs, ga, cs.grid, 1, stream, start, stop);
-    }
-    gemvx_fill(d, c, A, B, Scale, Zeros, Bias, C, m, &ga.p[0]);
-    ga.p[0].dyn = words;
-    return gemvx_dispatch(c, ga, c.grid, 1, stream, start, stop);
-  }
   gemvx_fill(d, c, A, B, Scale, Zeros, Bias, C, m, &ga.p[0]);
   if (pro == 1) ga.p[0].residual = epi->residual;
   if (pro == 3) gemvx_set_norm(ga.p[0], epi);
@@ -530,28 +465,11 @@ int gemvx_group_launch(const wqaa_matmul_desc& merged, const wqaa_group_item* it
   int st = gemvx_group_choose(merged, Ns, count, m, &c, &gx, norm != nullptr, kws);
   if (st != WQAA_OK) return st;
   GemvxGroupArgs ga;
-  unsigned* words = nullptr;
-  if (c.dyn) {
-    // run-time hand-out: every member its own 64 words and its share of the persistent grid; members whose single call splits K
-    // across waves cannot take it (the hand-out is per wave), nor can a stream without words (first seen during capture): static then
-    bool unsplit = true;
-    for (int i = 0; i < count; ++i) unsplit = unsplit && kws[i] == 1;
-    words = unsplit ? dyn_words(stream) : nullptr;
-    if (words) {
-      gx = c.grid / count;
-      gx = gx >= 8 ? (gx + 7) / 8 * 8 : 8;
-    } else {
-      c.dyn = 0;
-      c.fn = pick_gemvx_int4(c.layout, c.mode, c.mb, c.R * 10 + c.D);
-      if (!c.fn) return WQAA_ERR_UNSUPPORTED;
-    }
-  }
   for (int i = 0; i < count; ++i) {
     GemvxChoice ci = c;
     ci.kw = kws[i];                                    // the member's own K split: its single call's summation order
     gemvx_fill(*items[i].desc, ci, items[i].A, items[i].B, items[i].Scale, items[i].Zeros, items[i].Bias, items[i].C, m, &ga.p[i]);
     if (norm) gemvx_set_norm(ga.p[i], norm);          // one norm for the group: its members read the same hidden state
-    if (words) ga.p[i].dyn = words + i * 64;
   }
   return gemvx_dispatch(c, ga, gx, count, stream, nullptr, nullptr);
 }

@@ -61,7 +61,6 @@ struct GemvxArgs {
   const void* residual;  // PRO members (WQAA_EPI_ADD_RESIDUAL): (m, N) float16 added to the float16 result; NULL: none
   const void* norm_weight;   // NORM members (WQAA_EPI_RMSNORM_INPUT): (K,) float16 weight of the RMSNorm in front of the operator
   float norm_eps, norm_inv_k;
-  unsigned* dyn;             // DYN members: this operator's 64 hand-out words ([0, 32) heads, [32] waves done), zero between launches
 };
 
 // One launch serves up to kGemvxGroupMax INDEPENDENT operators of one tile configuration (wqaa_matmul_group: the q/k/v
@@ -93,15 +92,10 @@ struct GemvxGroupArgs {
 //      the items it has just loaded, and stages weight * half(x * rsqrt(mean + eps)) - the reference's BitnetRMSNorm
 //      (= LlamaRMSNorm) - as its activations.  One extra barrier and K / threads multiplies per thread in front of the stream.
 //   4  3 + 2: the norm in front of a gate / up pair
-// DYN_ (round 6): row groups are handed out to WAVES at run time.  A persistent grid (what the chip holds at once); wave w starts on
-// row group w and fetches the next from one of 32 interleaved heads (row group = head + 32 k, k from a returning device-scope
-// atomicAdd asked for a whole row group ahead, so its latency hides behind the stream); the last wave to run dry resets the words, so
-// a hipGraph replay finds them zero.  Only the assignment of rows to waves changes - a row's arithmetic, and its bits, do not.
-template <int BITS_, int LAYOUT_, int MODE_, int MB_, int R_, int D_, int ABL_ = 0, bool AREG_ = false, int PRO_ = 0, bool DYN_ = false>
+template <int BITS_, int LAYOUT_, int MODE_, int MB_, int R_, int D_, int ABL_ = 0, bool AREG_ = false, int PRO_ = 0>
 struct GemvxPolicy {
   static constexpr int BITS = BITS_, LAYOUT = LAYOUT_, MODE = MODE_, MB = MB_, R = R_, D = D_, ABL = ABL_;
-  static constexpr bool AREG = AREG_, DYN = DYN_;
-  static_assert(!DYN_ || (PRO_ == 0 && !AREG_), "run-time hand-out: the plain LDS-staged members");
+  static constexpr bool AREG = AREG_;
   static constexpr bool PRO = PRO_ == 1, PAIR = PRO_ == 2 || PRO_ == 4, NORM = PRO_ >= 3;
   static_assert(!(AREG_ && PRO_ != 0), "the fused post ops come with the LDS-staged members");
   static_assert(!PAIR || R_ == 2, "a gate / up pair is the two rows of a wave");
@@ -210,23 +204,19 @@ __global__ void __launch_bounds__(1024) wq_gemvx_kernel(const GemvxGroupArgs grp
   // this workgroup's row-group blocks rb.first, rb.first + rb.stride, ... < rb.end (XCD-aware, wqaa_kinds.h; many small
   // workgroups and the hardware dispatcher balance better than one persistent workgroup per CU: measured)
   const RowBlocks rb = xcd_row_blocks((int)blockIdx.x, (int)gridDim.x, a.n_rgb);
-  if (!P::DYN && rb.first >= rb.end) return;                   // grid padding / a shorter operator of a group: nothing to load
+  if (rb.first >= rb.end) return;                              // grid padding / a shorter operator of a group: nothing to load
   int iters = 1;                                               // uniform over the workgroup; the usual case: one block, no division
   if (rb.first + rb.stride < rb.end) iters = (rb.end - rb.first + rb.stride - 1) / rb.stride;
-  const int total = P::DYN ? 1 : iters * nmy;                  // (row group, step) positions of this wave
+  const int total = iters * nmy;                               // (row group, step) positions of this wave
 
   struct Stage {
     u32x4 w[R];
     uint32_t s[R], z[R];
   };
-  // DYN: the wave's own hand-out state - head c = global wave % 32 serves row groups c, c + 32, c + 64, ...; the wave starts on
-  // the one of its own index and asks for the next a row group ahead
-  const int dyn_tw = (int)gridDim.x * NW, dyn_gw = (int)blockIdx.x * NW + wave;
-  const int dyn_c = dyn_gw & 31, dyn_wc = (dyn_tw - dyn_c + 31) >> 5;
-  int dyn_rg = dyn_c + 32 * (dyn_gw >> 5);
-  auto rg_of = [&](int it) { return P::DYN ? dyn_rg : (rb.first + it * rb.stride) * slots + rgl; };
+  auto rg_of = [&](int it) { return (rb.first + it * rb.stride) * slots + rgl; };
   // weight loads of chunk d of position (it, si) = (it-th row-group block of this workgroup, si-th own step): unconditional
-  auto issue_rg = [&](Stage& st, int rg, int si, int d) {
+  auto issue = [&](Stage& st, int it, int si, int d) {
+    int rg = rg_of(it);
     rg = rg < n_rg ? rg : n_rg - 1;                 // a clamped slot re-reads the last row group and never stores
     int chunk = ((kpart + si * kw) * D + d) * 64 + lane;
     chunk = chunk < a.cpr ? chunk : 0;              // clamped lanes meet zero activations
@@ -242,7 +232,6 @@ __global__ void __launch_bounds__(1024) wq_gemvx_kernel(const GemvxGroupArgs grp
       if constexpr (MODE == MD_ZQ) st.z[r] = Qp[r][(long)gi * a.zq_row_bytes + n / ZPB];
     }
   };
-  auto issue = [&](Stage& st, int it, int si, int d) { issue_rg(st, rg_of(it), si, d); };
 
   // ---- activations first: their loads (L2 hits after the first workgroups) must not queue behind the weight stream -
   // loads return in order, so an activation load issued after the weights would only be usable after them.
@@ -527,7 +516,7 @@ __global__ void __launch_bounds__(1024) wq_gemvx_kernel(const GemvxGroupArgs grp
   };
 
   // a row group is complete for this wave: reduce over the wave, meet the kw - 1 other waves sharing the rows, store
-  auto finish_rg = [&](int it, int rg_done) {
+  auto finish = [&](int it) {
     float tot[R][MB];
 #pragma unroll
     for (int r = 0; r < R; ++r)
@@ -536,6 +525,7 @@ __global__ void __launch_bounds__(1024) wq_gemvx_kernel(const GemvxGroupArgs grp
         tot[r][mi] = (P::ABL & 4) ? acc[r][mi] : wave_sum_l63(acc[r][mi]);
         acc[r][mi] = 0.f;
       }
+    const int rg_done = rg_of(it);
     if (kw > 1) {
       float* red = red_lds + (it & 1) * (NW * R * MB);       // double buffered: one barrier per row group
       if (lane == 63) {
@@ -673,65 +663,6 @@ __global__ void __launch_bounds__(1024) wq_gemvx_kernel(const GemvxGroupArgs grp
     }
   };
 
-  auto finish = [&](int it) { finish_rg(it, rg_of(it)); };
-
-  if constexpr (P::DYN) {
-    // ---- run-time hand-out (kw == 1: the host takes these members for unsplit rows only) ----
-    unsigned* const ctr = a.dyn;
-    // lane 0 asks; the answer stays in its register until the wave needs it (a row group later: the atomic returns in the order of
-    // the loads around it), then becomes wave-uniform
-    auto grab = [&]() -> unsigned {
-      unsigned k = 0u;
-      if (lane == 0) k = __hip_atomic_fetch_add(ctr + dyn_c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      return k;
-    };
-    auto granted = [&](unsigned kraw) -> int {
-      const unsigned nx = (unsigned)dyn_wc + (unsigned)__builtin_amdgcn_readfirstlane((int)kraw);
-      return nx < 0x03ffffffu ? dyn_c + 32 * (int)nx : n_rg;
-    };
-    if (dyn_rg < n_rg) {
-      unsigned kraw = grab();                       // (behind the first position's loads: returns in their order)
-      int trip = 0;
-      while (true) {
-        int rg_next = n_rg;
-        for (int si = 0; si < nsteps; ++si) {
-          int c = __builtin_amdgcn_readfirstlane(si * D);
-          int si2 = __builtin_amdgcn_readfirstlane(si + 1);
-          int rg_issue = __builtin_amdgcn_readfirstlane(dyn_rg);
-          static_assert(D == 2, "two lane chunks per step");
-          consume(st[0], c, dyn_rg, std::integral_constant<int, 0>{});
-          ++c;
-          asm volatile("" : "+v"(acc[0][0]), "+v"(acc[R - 1][0]), "+v"(acc[0][MB - 1]), "+v"(acc[R - 1][MB - 1]), "+s"(c), "+s"(si2), "+s"(rg_issue));
-          consume(st[1], c, dyn_rg, std::integral_constant<int, 1>{});
-          asm volatile("" : "+v"(acc[0][0]), "+v"(acc[R - 1][0]), "+v"(acc[0][MB - 1]), "+v"(acc[R - 1][MB - 1]), "+s"(c), "+s"(si2), "+s"(rg_issue));
-          if (si2 == nsteps) {                       // the row group's last step: now the next one's index is needed
-            si2 = 0;
-            rg_next = granted(kraw);
-            rg_issue = rg_next;
-          }
-          if (si2 != 0 || rg_issue < n_rg) {
-#pragma unroll
-            for (int d = 0; d < D; ++d) issue_rg(st[d], rg_issue, si2, d);
-          }
-        }
-        finish_rg(trip, dyn_rg);
-        ++trip;
-        if (rg_next >= n_rg) break;
-        dyn_rg = rg_next;
-        kraw = grab();                              // (behind the loads of the row group just started)
-      }
-    }
-    // every wave reports once it has run dry; the last one puts the words back to zero (nobody touches them any more): the next
-    // launch - or the next replay of a captured one - starts from a clean hand-out
-    if (lane == 0) {
-      const unsigned d = __hip_atomic_fetch_add(ctr + 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (d == (unsigned)dyn_tw - 1u) {
-        for (int i = 0; i < 33; ++i) __hip_atomic_store(ctr + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-    }
-    return;
-  }
-
   // positions in order; a position's weight registers are refilled with the next position's loads once all its chunks
   // have been consumed (65 VGPRs: 7 waves per SIMD - a deeper per-wave pipeline (activations prefetched into a
   // register ring, two steps of weights in flight: 105 VGPRs) measured 20-35 % SLOWER on every shape, occupancy wins)
@@ -836,9 +767,6 @@ static gemvx_fn pick_gemvx_rd(int rd) {
   switch (rd) {
     case 12: return wq_gemvx_kernel<GemvxPolicy<BITS, LAYOUT, MODE, MB, 1, 2>>;
     case 22: return wq_gemvx_kernel<GemvxPolicy<BITS, LAYOUT, MODE, MB, 2, 2>>;
-    case 42:   // run-time hand-out of row groups (round 6): 4-bit weights, one activation row, two rows per wave
-      if constexpr (BITS == 4 && MB == 1) return wq_gemvx_kernel<GemvxPolicy<BITS, LAYOUT, MODE, MB, 2, 2, 0, false, 0, true>>;
-      else return nullptr;
     case 13:   // activations in registers
       if constexpr (BITS == 4 && LAYOUT == LAYOUT_LOP3 && MB == 1) return wq_gemvx_kernel<GemvxPolicy<BITS, LAYOUT, MODE, MB, 1, 2, 0, true>>;
       else return nullptr;
