@@ -40,6 +40,7 @@ enum : int {
   PPO_ABL_NODEC = 256,   //   no weight decode
   PPO_ABL_NOBAR = 512,   //   no s_barrier in the loop (wqaa_gemm_mm_kernel.h),
   PPO_ABL_NOMFMA = 1024, //   no MFMA (wqaa_gemm_mm_kernel.h)
+  PPO_PRIO = 4096,       // lab: s_setprio 1 for the second-dispatched role group (waves 4-7) across the main loop
   PPO_ABL_METAONCE = 2048, // Scale / Zeros read and converted for the first k-body only (what the per-body metadata handling costs)
 };
 
@@ -651,8 +652,12 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_pp_kernel(const GemmArgs a
       tile(ZI, ic<3>{}, t + 3);
     }
   };
+  if constexpr ((P::OPT & PPO_PRIO) != 0) {
+    if (grp == 1) __builtin_amdgcn_s_setprio(1);
+  }
   if (zint) main_loop(ic<1>{});
   else main_loop(ic<0>{});
+  if constexpr ((P::OPT & PPO_PRIO) != 0) __builtin_amdgcn_s_setprio(0);
   if (grp == 0) PP_BARRIER();
   if constexpr (P::OPT & PPO_TRACE) {
     if (lane == 0 && a.lut) {

@@ -31,6 +31,7 @@ using namespace wqaa;
   X("pp_metaslow", DK_INT4, LAYOUT_LOP3, AT_F16, MD_ZO, 0, 3, PPO_META_SLOW)                 \
   X("pp_rw64", DK_INT4, LAYOUT_LOP3, AT_F16, MD_ZO, 0, 3, PPO_RW64)                          \
   X("pp_metaonce", DK_INT4, LAYOUT_LOP3, AT_F16, MD_ZO, 0, 3, PPO_ABL_METAONCE)             \
+  X("pp_prio", DK_INT4, LAYOUT_LOP3, AT_F16, MD_ZO, 0, 3, PPO_PRIO)                          \
   X("pp_scaleonly", DK_INT4, LAYOUT_LOP3, AT_F16, MD_S, 0, 3, 0)                             \
   X("pp_nometa", DK_INT4, LAYOUT_LOP3, AT_F16, MD_NONE, 0, 3, 0)                             \
   X("pp_nometa_r4", DK_INT4, LAYOUT_LOP3, AT_F16, MD_NONE, 0, 4, 0)                          \
@@ -42,6 +43,7 @@ using namespace wqaa;
 #define LAB_I8_VARIANTS(X)                                                                  \
   X("pp_i2", DK_INT2, LAYOUT_LOP3, AT_I8, MD_NONE, 0, 3, 0)                                  \
   X("pp_i2_r4", DK_INT2, LAYOUT_LOP3, AT_I8, MD_NONE, 0, 4, 0)                               \
+  X("pp_i2_prio", DK_INT2, LAYOUT_LOP3, AT_I8, MD_NONE, 0, 3, PPO_PRIO)                      \
   X("pp_i2_ntaw", DK_INT2, LAYOUT_LOP3, AT_I8, MD_NONE, 0, 3, 0)           \
   X("abl_i2_nodma", DK_INT2, LAYOUT_LOP3, AT_I8, MD_NONE, 0, 3, PPO_ABL_NODMA)               \
   X("abl_i2_nodec", DK_INT2, LAYOUT_LOP3, AT_I8, MD_NONE, 0, 3, PPO_ABL_NODEC)               \
