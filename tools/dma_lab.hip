@@ -1,5 +1,5 @@
 // dma_lab.hip - what one loader wave per CU can stream into LDS with global_load_lds_dwordx4 on MI355X, by address pattern,
-// cache policy, queue depth and loader count (the weight stream of csrc/wqaa_chain_kernel.h, nothing else in the kernel).
+// cache policy, queue depth and loader count (the weight stream of round 4's persistent chain kernel - removed in round 6 - nothing else in the kernel).
 //   hipcc --offload-arch=gfx950 -O3 -o tools/dma_lab tools/dma_lab.hip && tools/dma_lab
 #include <hip/hip_runtime.h>
 #include <cstdio>

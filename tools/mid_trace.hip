@@ -1,3 +1,4 @@
+// (round 6: the in-launch seam of round 5 was removed from the kernel; phases 5-7 below no longer exist and `spin_us` is ignored)
 // mid_trace.hip - lab harness: per-wave phase timeline of the mid-M member (csrc/wqaa_gemm_mid_kernel.h) built with -DWQAA_TRACE.
 // uint4, LOP3 layout, fp16, scale + zeros "original", g = 128; launches over rotating weight buffers; prints, for the last
 // launch, the distribution over waves of the phase END times since the first wave's start (100 MHz s_memrealtime is taken at entry
@@ -40,7 +41,7 @@ static void run(int M, int N, int K, int spin_us) {
   const int grid = tiles * 8;
   const size_t trace_words = (size_t)grid * nwaves * 16;
   void* WS; CK(hipMalloc(&WS, (size_t)tiles * 64 * MF * 1024));
-  unsigned* SY; CK(hipMalloc(&SY, (size_t)tiles * kMidSyncWords * 4)); CK(hipMemset(SY, 0, (size_t)tiles * kMidSyncWords * 4));
+
   unsigned long long* T;
   CK(hipMalloc(&T, trace_words * 8 * launches)); CK(hipMemset(T, 0, trace_words * 8 * launches));
   hipStream_t st; CK(hipStreamCreate(&st));
@@ -53,7 +54,7 @@ static void run(int M, int N, int K, int spin_us) {
       a.M = M; a.N = N; a.K = K; a.kg = K / g; a.gq_shift = 2; a.row_bytes = K / 2; a.out_dtype = 0; a.is_signed = 0;
       a.tiles_m = tiles_m; a.tiles_n = tiles_n; a.nsteps = K / 128; a.group_m = 1; a.ksplit = 1; a.epi_tensor = 1.f;
       a.mg_ntiles = tile_magic((uint32_t)tiles_n);
-      a.ws = WS; a.mid_sync = spin_us < 0 ? nullptr : SY; a.mid_spin = spin_us * 100;       // spin < 0: the two-launch seam
+      a.ws = WS;       // (round 6: the two-launch seam is the only one; the in-launch seam this harness also timed in round 5 is gone)
       a.lut = T + (size_t)l * trace_words;
       hipLaunchKernelGGL(fn, dim3(grid), dim3(64 * nwaves), lds, st, a);
       if (spin_us < 0) hipLaunchKernelGGL(wq_mid_reduce_kernel<0>, dim3((tiles * 8 * MF + 3) / 4), dim3(256), 0, st, a, MF, tiles * 8 * MF);
