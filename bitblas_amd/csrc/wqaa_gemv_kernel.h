@@ -890,23 +890,35 @@ constexpr bool gemv_direct_fits() {
   return MB * (128 / KindTraits<KIND, AT>::BITS) * (AT == AT_F16 ? 2 : 1) <= 128;
 }
 
+// ... and where GemvPolicy::AD holds at all: fp8 / packed int4 activations and the in-kernel quantiser stage through LDS (round 6: a
+// census of the built library found 31 such instantiations - twins of the LDS-staged members under another name, asked for by no rule)
+template <int KIND, int AT, int MB, int FLAGS = 0>
+constexpr bool gemv_direct_ok() {
+  return gemv_direct_fits<KIND, AT, MB, FLAGS>() && (FLAGS & (FL_A8 | FL_AQ)) == 0 && AT != AT_I4;
+}
+
 template <int KIND, int LAYOUT, int AT, int MODE, int FLAGS>
 static gemv_fn pick_mb(int mb) {
   switch (mb) {
     case 1: return wq_gemv_kernel<GemvPolicy<KIND, LAYOUT, AT, 1, MODE, FLAGS>>;
     case kDirectTile:
-      if constexpr (gemv_direct_fits<KIND, AT, 1, FLAGS>()) return wq_gemv_kernel<GemvPolicy<KIND, LAYOUT, AT, 1, MODE, FLAGS, 2, 2, true>>;
+      if constexpr (gemv_direct_ok<KIND, AT, 1, FLAGS>()) return wq_gemv_kernel<GemvPolicy<KIND, LAYOUT, AT, 1, MODE, FLAGS, 2, 2, true>>;
       else return nullptr;
     case kDirectTile + 1:
-      if constexpr (gemv_direct_fits<KIND, AT, 1, FLAGS>()) return wq_gemv_kernel<GemvPolicy<KIND, LAYOUT, AT, 1, MODE, FLAGS, 1, 2, true>>;
+      if constexpr (gemv_direct_ok<KIND, AT, 1, FLAGS>()) return wq_gemv_kernel<GemvPolicy<KIND, LAYOUT, AT, 1, MODE, FLAGS, 1, 2, true>>;
       else return nullptr;
     case kDirectTile + 2:
-      if constexpr (gemv_direct_fits<KIND, AT, 2, FLAGS>()) return wq_gemv_kernel<GemvPolicy<KIND, LAYOUT, AT, 2, MODE, FLAGS, 2, 2, true>>;
+      if constexpr (gemv_direct_ok<KIND, AT, 2, FLAGS>()) return wq_gemv_kernel<GemvPolicy<KIND, LAYOUT, AT, 2, MODE, FLAGS, 2, 2, true>>;
       else return nullptr;
     case 2: return wq_gemv_kernel<GemvPolicy<KIND, LAYOUT, AT, 2, MODE, FLAGS>>;
     case 4: return wq_gemv_kernel<GemvPolicy<KIND, LAYOUT, AT, 4, MODE, FLAGS>>;
-    case kSplitTile + 1: return wq_gemv_kernel<GemvPolicy<KIND, LAYOUT, AT, 1, MODE, FLAGS, 2, 2, false, true>>;
-    case kSplitTile + 2: return wq_gemv_kernel<GemvPolicy<KIND, LAYOUT, AT, 2, MODE, FLAGS, 2, 2, false, true>>;
+    // (the in-kernel quantiser has no K-split twin: GemvPolicy::KS, and gemv_choose never asks)
+    case kSplitTile + 1:
+      if constexpr ((FLAGS & FL_AQ) == 0) return wq_gemv_kernel<GemvPolicy<KIND, LAYOUT, AT, 1, MODE, FLAGS, 2, 2, false, true>>;
+      else return nullptr;
+    case kSplitTile + 2:
+      if constexpr ((FLAGS & FL_AQ) == 0) return wq_gemv_kernel<GemvPolicy<KIND, LAYOUT, AT, 2, MODE, FLAGS, 2, 2, false, true>>;
+      else return nullptr;
     case kChunkTile + 1:
       if constexpr (AT == AT_I8 && KindTraits<KIND, AT>::SUBBYTE) return wq_gemv_kernel<GemvPolicy<KIND, LAYOUT, AT, 1, MODE, FLAGS, 4, 1>>;
       else return nullptr;

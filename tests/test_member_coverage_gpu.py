@@ -68,7 +68,8 @@ def _check_example(cls, ex):
     src, bit = bitblas.Matmul.BITBLAS_TRICK_DTYPE_MAP[w]
     g = mode.get("group_size", -1)
     gg = K if g == -1 else g
-    native = w == a
+    fp8 = ("e4m3_float8", "e5m2_float8")
+    native = w == a or (a in fp8 and w in fp8)          # (the mixed fp8 pairs compute natively: general_matmul/__init__.py:33-51)
     rows = _sample(M, 24, rng)
     # ---- activations ----
     if a in ("float16", "bfloat16"):
@@ -102,8 +103,8 @@ def _check_example(cls, ex):
             Wt = (torch.from_numpy(rng.random((N, K), dtype=np.float32)) * 2 - 1).to(TDT[w])
             W_or, W_dev = Wt.view(torch.int8).numpy()[cols], Wt.cuda()
     else:
-        if src == "fp_e4m3":
-            w8 = (torch.from_numpy(rng.random((N, K), dtype=np.float32)) * 2 - 1).to(torch.float8_e4m3fn)
+        if src in ("fp_e4m3", "fp_e5m2"):
+            w8 = (torch.from_numpy(rng.random((N, K), dtype=np.float32)) * 2 - 1).to(TDT[w])
             codes = w8.view(torch.int8).numpy()
             W_dev = op.transform_weight(w8.cuda())
         else:
@@ -118,7 +119,7 @@ def _check_example(cls, ex):
         if mode.get("with_zeros"):
             zm = mode["zeros_mode"]
             if zm == "quantized":
-                zint = np.clip((1 << (bit - 1)) + rng.integers(-2, 2, size=(K // gg, N)), 0, (1 << bit) - 1).astype(np.int8)
+                zint = np.clip((1 << (bit - 1)) + rng.integers(-2, 2, size=(K // gg, N)), 0, (1 << bit) - 1).astype(np.uint8).view(np.int8)
                 zeros = oracle.general_compress(zint, bit)
             else:
                 z = ((1 << (bit - 1)) + rng.integers(-2, 3, size=(N, K // gg))).astype(np.float32)

@@ -41,23 +41,35 @@ def reachable(with_args=False, per_kernel=False):
     bf16 = [("bfloat16", w) for w in ("uint4", "int4", "uint2", "uint1", "int8", "nf4", "fp4_e2m1", "e4m3_float8", "bfloat16")]
     i8 = [("int8", w) for w in ("int8", "int4", "uint4", "int2", "uint2", "int1")]
     f8 = [("e4m3_float8", "e4m3_float8"), ("e5m2_float8", "e5m2_float8")]
+    if per_kernel:              # (the mixed pairs of general_matmul/__init__.py:33-51, and e5m2 weights under float16 activations: :344)
+        f8 += [("e4m3_float8", "e5m2_float8"), ("e5m2_float8", "e4m3_float8")]
+        f16 = f16 + [("float16", "e5m2_float8")]
     i4 = [("int4", "int4"), ("int4", "int2")]
     shapes = [(1024, 1024), (4096, 4096), (11008, 4096), (4096, 11008), (1024, 28672), (28672, 8192), (272, 2048), (5120, 4096), (2048, 8192), (4352, 8192)]
     if per_kernel:
-        shapes = sorted([(64, 256), (48, 128), (100, 384), (272, 512), (528, 1024), (2048, 1024), (8192, 512), (16384, 256), (1024, 8192), (512, 16384), (24, 4096)] + shapes,
+        # (N off the MFMA family's multiple of 4, K off its k grid: the GEMV family's 4-row batch tile; few rows x long K: its K-split twins)
+        shapes = sorted([(64, 256), (48, 128), (100, 384), (272, 512), (528, 1024), (2048, 1024), (8192, 512), (16384, 256), (1024, 8192), (512, 16384), (24, 4096),
+                         (50, 256), (50, 2048), (64, 160), (64, 192), (24, 32768), (1024, 320),
+                         (4092, 768)] + shapes,     # (4092: N off the ping-pong members' multiple of 8 at M = 4096 - the 256-row lockstep tile of every format)
                         key=lambda nk: nk[0] * nk[1])
-    ms = [1, 2, 3, 8, 16, 32, 64, 128, 256, 1024, 4096]
+    ms = [1, 2, 3, 8, 16, 32, 64, 128, 256, 1024, 4096] if not per_kernel else [1, 2, 3, 5, 8, 16, 32, 64, 128, 256, 1024, 4096]
     seen = {}
     for (a, w) in f16 + bf16 + i8 + f8 + i4:
         quant = a in ("float16", "bfloat16") and w not in (a, "fp4_e2m1")
         modes = [dict()]
         if quant:
             modes.append(dict(with_scaling=True, group_size=128))
-            if w.startswith("uint") and w != "uint8":
+            if w.startswith("uint") and (w != "uint8" or per_kernel):
                 modes += [dict(with_scaling=True, group_size=128, with_zeros=True, zeros_mode=z) for z in ("original", "rescale", "quantized")]
+            if per_kernel:
+                modes += [dict(with_scaling=True, group_size=32)] + ([dict(with_scaling=True, group_size=32, with_zeros=True, zeros_mode="original")] if w.startswith("uint") else [])
         fds = [None, False] if (w[0] in "ui" and w not in ("uint8", "int8") and a in ("float16", "int8")) else [None]
+        if per_kernel and a == "int8" and w in ("int4", "uint4"):
+            fds = [None, True]          # (the reference's default for this pair is the plain layout: general_matmul/__init__.py:171-173)
         for (N, K), mode, fd, strict in itertools.product(shapes, modes, fds, (True, False)):
-            if not strict and not (a == "float16" and w[0] in "ui" and w not in ("uint8", "int8")):
+            # strict_reference picks other members for sub-byte integers x float16 (per-element rounding) and for e4m3 x float16 (the reference's bit trick)
+            strict_matters = a == "float16" and ((w[0] in "ui" and w not in ("uint8", "int8")) or (per_kernel and w == "e4m3_float8"))
+            if not strict and not strict_matters:
                 continue
             out = "int32" if a in ("int8", "int4") else ("bfloat16" if a == "bfloat16" else "float16")
             acc = "int32" if a in ("int8", "int4") else "float32"
@@ -69,7 +81,8 @@ def reachable(with_args=False, per_kernel=False):
             for m in ms:
                 key = member_class(op.plans[m]["name"])
                 if per_kernel:
-                    key += "|" + mode_tag(mode, fd)
+                    key += "|" + mode_tag(mode, fd) + (f"_g{mode['group_size']}" if mode.get("group_size", 128) != 128 else "") + ("_fd" if fd else "")
+                    key += "|default" if (strict_matters and not strict and w == "e4m3_float8") else ""
                 if with_args:
                     seen.setdefault(key, dict(M=m, N=N, K=K, a=a, w=w, mode=mode, fd=fd, strict=strict, cfg=cfg))
                 else:
