@@ -136,6 +136,12 @@ static bool valid_desc(const wqaa_matmul_desc* d) {
     set_error(WQAA_ERR_BAD_DESC, "N=%d K=%d must be positive", d->N, d->K);
     return false;
   }
+  // packed zero points: a row of Qzeros holds N fields of w_bits in whole bytes (matmul_dequantize_impl.py:375-389 sizes it
+  // N // 8 * bit and reads past it otherwise)
+  if (d->zeros_mode == WQAA_Z_QUANTIZED && d->w_bits > 0 && d->w_bits < 8 && ((long)d->N * d->w_bits) % 8 != 0) {
+    set_error(WQAA_ERR_BAD_DESC, "quantized zero points: N=%d x %d bits must fill whole bytes", d->N, d->w_bits);
+    return false;
+  }
   return true;
 }
 

@@ -2057,7 +2057,8 @@ static gemm_fn pick_mf(int mf) {
       else return nullptr;
     // 900: not a GEMM - B_decode to memory (two-pass member, wqaa_dequantize); launched with (GemmArgs, void* out)
     case 900:
-      if constexpr (AT == AT_F16 || AT == AT_I8) return reinterpret_cast<gemm_fn>(wq_dequant_kernel<GemmPolicy<KIND, LAYOUT, AT, MODE, FLAGS, 1>>);
+      // (a native operator's B_decode is B itself: no member)
+      if constexpr ((AT == AT_F16 || AT == AT_I8) && KIND != DK_NATIVE) return reinterpret_cast<gemm_fn>(wq_dequant_kernel<GemmPolicy<KIND, LAYOUT, AT, MODE, FLAGS, 1>>);
       else return nullptr;
     case 404: if constexpr (KIND == DK_INT4 && AT == AT_F16 && FLAGS == 0 && (MODE == MD_ZO || MODE == MD_ZR)) return wq_gemm_kernel<GemmPolicy<KIND, LAYOUT, AT, MODE, FLAGS, 4, 4, 2, 0, true>>; else return nullptr;
   }

@@ -94,7 +94,7 @@ typedef struct wqaa_matmul_desc {
   int32_t out_dtype;     /* wqaa_dtype of C */
   int32_t group_size;    /* -1 => K       */
   int32_t with_scaling;  /* Scale (N, K/g) in A_dtype */
-  int32_t zeros_mode;    /* wqaa_zeros_mode; Zeros (N,K/g) A_dtype, or QZeros (K/g, N*bits/8) int8 */
+  int32_t zeros_mode;    /* wqaa_zeros_mode; Zeros (N,K/g) A_dtype, or QZeros (K/g, N*bits/8) int8 (N*bits a multiple of 8: BAD_DESC otherwise) */
   int32_t with_bias;     /* Bias (N,) added after the cast to out_dtype */
   int32_t w_layout;      /* wqaa_layout   */
   int32_t strict_reference; /* 1: the reference's definition to the letter - dequantised weight rounded to A_dtype

@@ -252,7 +252,7 @@ def test_two_launches_of_different_rows_share_nothing():
     assert np.array_equal(got[1::2], got[0::2])
 
 
-@pytest.mark.parametrize("kind", ["float16", "bfloat16", "int8", "e4m3_float8", "e5m2_e4m3"])
+@pytest.mark.parametrize("kind", ["float16", "bfloat16", "int8", "e4m3_float8", "e5m2_e4m3", "e4m3_e5m2", "e5m2_float8"])
 @pytest.mark.parametrize("M,N,K", [(300, 520, 512), (512, 512, 1152), (257, 264, 128)])
 def test_dense_2x4_wave_grid_is_bit_identical_to_the_1x8_grid(kind, M, N, K, monkeypatch, pin_the_tile):
     """round 5: the dense 256 x 256 tile on a 2 (m) x 4 (n) wave grid (wq_gemm_pp8w_kernel: both operands shared LDS tiles, a third
@@ -272,7 +272,8 @@ def test_dense_2x4_wave_grid_is_bit_identical_to_the_1x8_grid(kind, M, N, K, mon
         W = (torch.rand((N, K), device="cuda", generator=gen) - 0.5).to(tdt)
         cfg = dict(A_dtype=kind, W_dtype=kind, accum_dtype="float32", out_dtype=kind)
     else:
-        a_dt, w_dt = ("e4m3_float8", "e4m3_float8") if kind == "e4m3_float8" else ("e5m2_float8", "e4m3_float8")
+        a_dt, w_dt = {"e4m3_float8": ("e4m3_float8", "e4m3_float8"), "e5m2_e4m3": ("e5m2_float8", "e4m3_float8"),
+                      "e4m3_e5m2": ("e4m3_float8", "e5m2_float8"), "e5m2_float8": ("e5m2_float8", "e5m2_float8")}[kind]
         tdt = {"e4m3_float8": torch.float8_e4m3fn, "e5m2_float8": torch.float8_e5m2}
         A = (torch.rand((M, K), device="cuda", generator=gen) * 2 - 1).to(tdt[a_dt])
         W = (torch.rand((N, K), device="cuda", generator=gen) * 2 - 1).to(tdt[w_dt])

@@ -43,6 +43,14 @@ def test_ragged_n_bias_and_k_8192(zeros_mode, monkeypatch):
     _run(case, 5, monkeypatch)
 
 
+@pytest.mark.parametrize("zeros_mode", ["original", "rescale"])
+def test_uint4_zero_points_in_the_plain_checkpoint_layout(zeros_mode, monkeypatch):
+    """`fast_decoding=False` checkpoints (general_compress order, no LOP3 interleave) with zero points: their own instantiations"""
+    case = make_case(7, 1536, 4096, W_dtype="uint4", fast_decoding=False, group_size=128, with_scaling=True, with_zeros=True, zeros_mode=zeros_mode,
+                     scale_mul=0.02, seed=17)
+    _run(case, 7, monkeypatch)
+
+
 @pytest.mark.parametrize("fast", [False, True])
 def test_int4_scale_only_both_checkpoint_layouts(fast, monkeypatch):
     case = make_case(12, 2048, 4096, W_dtype="int4", fast_decoding=fast, group_size=128, with_scaling=True, scale_mul=0.02, seed=3)

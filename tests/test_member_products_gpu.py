@@ -35,7 +35,7 @@ MODES = {
 
 # ---- the in-kernel activation quantiser ------------------------------------------------------------------------------------
 @pytest.mark.parametrize("m", [1, 2, 3, 4])
-@pytest.mark.parametrize("N,K", [(512, 2048), (1024, 8192), (96, 4096)])     # one lane chunk per row (the four-row chunk tile) / several / few rows
+@pytest.mark.parametrize("N,K", [(512, 2048), (1024, 8192), (96, 4096), (96, 16384)])     # one lane chunk per row (the four-row chunk tile) / several / few rows / 1-bit rows of two chunks
 @pytest.mark.parametrize("wd,fd", [("int4", None), ("int4", True), ("uint4", None), ("int2", None), ("int2", False), ("uint2", None),
                                    ("int1", None), ("int1", False)])
 def test_in_kernel_activation_quantiser_every_weight_format(wd, fd, N, K, m):
@@ -160,5 +160,37 @@ def test_exact_members_at_two_rows_under_the_ab_switch(mode, fd, bits, monkeypat
     out = mm(torch.from_numpy(case["A"]).cuda(), W, scale=_to_dev(case["scale"], DEV), zeros=_to_dev(case["zeros"], DEV))
     torch.cuda.synchronize()
     want = oracle.matmul_dequant_exact(case["A"], case["codes"], source_format=case["source_format"], bit=bits, scale=case["scale"], zeros=case["zeros"],
+                                       zeros_mode=case["zeros_mode"], group_size=case["g"], out_dtype="float16")
+    assert_fp_parity(out.cpu().numpy(), want, rtol=1e-3, atol_frac=6e-4)
+
+
+# ---- twins the selector takes on large shapes only, reached here through the A/B switches ---------------------------------
+@pytest.mark.parametrize("M", [1, 2])
+@pytest.mark.parametrize("wd,fd,N,K", [("int2", False, 2048, 8192), ("int2", None, 2048, 8192), ("int1", False, 2048, 16384), ("int1", None, 2048, 16384),
+                                       ("int4", None, 2048, 4096)])
+def test_lds_staged_twins_of_the_register_resident_int8_members(wd, fd, N, K, M, monkeypatch):
+    """W_q x A_int8 rows of two lane chunks: the selector keeps the activation slice in registers up to 10 waves per CU of rows and
+    stages it through LDS beyond (N > 5120: csrc/wqaa_gemv.hip choose); WQAA_GEMV_TUNE=areg=0 asks for the LDS-staged twin at a size
+    the oracle takes in a second.  Integer sums: bit exact."""
+    set_knobs(monkeypatch, "gemv", areg=0)
+    case = make_case(M, N, K, W_dtype=wd, A_dtype="int8", out_dtype="int32", fast_decoding=fd, seed=M + K)
+    got, mm = hip_output(case)
+    assert "_areg" not in mm.plans[M]["name"] and "gemv_b" in mm.plans[M]["name"], mm.plans[M]["name"]
+    assert np.array_equal(got, oracle_output(case))
+
+
+@pytest.mark.parametrize("mode", list(MODES))
+def test_exact_member_with_register_resident_activations_two_rows_per_wave(mode, monkeypatch):
+    """4-bit LOP3 weights, K within one step: the selector keeps the activations in registers for N <= 2048 (one row per wave) and
+    N >= 24576 (two rows per wave); WQAA_GEMV_TUNE=areg=1 asks for the latter at 8192 rows"""
+    set_knobs(monkeypatch, "gemv", areg=1)
+    M, N, K = 1, 8192, 4096
+    case = make_case(M, N, K, W_dtype="uint4", scale_mul=0.05, seed=len(mode), **MODES[mode])
+    mm = bitblas.Matmul(case["config"], enable_tuning=False)
+    assert "gemvx_b1r2" in mm.plans[M]["name"] and mm.plans[M]["name"].endswith("_areg"), mm.plans[M]["name"]
+    W = mm.weight_transform(torch.from_numpy(case["codes"])).cuda()
+    out = mm(torch.from_numpy(case["A"]).cuda(), W, scale=_to_dev(case["scale"], DEV), zeros=_to_dev(case["zeros"], DEV))
+    torch.cuda.synchronize()
+    want = oracle.matmul_dequant_exact(case["A"], case["codes"], source_format=case["source_format"], bit=4, scale=case["scale"], zeros=case["zeros"],
                                        zeros_mode=case["zeros_mode"], group_size=case["g"], out_dtype="float16")
     assert_fp_parity(out.cpu().numpy(), want, rtol=1e-3, atol_frac=6e-4)

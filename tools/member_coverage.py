@@ -39,6 +39,8 @@ def reachable(with_args=False, per_kernel=False):
     tools/kernel_census.py); examples come from the smallest shape that reaches the entry"""
     f16 = [("float16", w) for w in ("uint4", "int4", "uint2", "int2", "uint1", "int1", "uint8", "int8", "nf4", "fp4_e2m1", "e4m3_float8", "float16")]
     bf16 = [("bfloat16", w) for w in ("uint4", "int4", "uint2", "uint1", "int8", "nf4", "fp4_e2m1", "e4m3_float8", "bfloat16")]
+    if per_kernel:
+        bf16.append(("bfloat16", "uint8"))
     i8 = [("int8", w) for w in ("int8", "int4", "uint4", "int2", "uint2", "int1")]
     f8 = [("e4m3_float8", "e4m3_float8"), ("e5m2_float8", "e5m2_float8")]
     if per_kernel:              # (the mixed pairs of general_matmul/__init__.py:33-51, and e5m2 weights under float16 activations: :344)
@@ -50,6 +52,7 @@ def reachable(with_args=False, per_kernel=False):
         # (N off the MFMA family's multiple of 4, K off its k grid: the GEMV family's 4-row batch tile; few rows x long K: its K-split twins)
         shapes = sorted([(64, 256), (48, 128), (100, 384), (272, 512), (528, 1024), (2048, 1024), (8192, 512), (16384, 256), (1024, 8192), (512, 16384), (24, 4096),
                          (50, 256), (50, 2048), (64, 160), (64, 192), (24, 32768), (1024, 320),
+                         (50, 4096), (50, 8192), (50, 16384), (2048, 16384), (4096, 384),
                          (4092, 768)] + shapes,     # (4092: N off the ping-pong members' multiple of 8 at M = 4096 - the 256-row lockstep tile of every format)
                         key=lambda nk: nk[0] * nk[1])
     ms = [1, 2, 3, 8, 16, 32, 64, 128, 256, 1024, 4096] if not per_kernel else [1, 2, 3, 5, 8, 16, 32, 64, 128, 256, 1024, 4096]
@@ -63,9 +66,13 @@ def reachable(with_args=False, per_kernel=False):
                 modes += [dict(with_scaling=True, group_size=128, with_zeros=True, zeros_mode=z) for z in ("original", "rescale", "quantized")]
             if per_kernel:
                 modes += [dict(with_scaling=True, group_size=32)] + ([dict(with_scaling=True, group_size=32, with_zeros=True, zeros_mode="original")] if w.startswith("uint") else [])
+                if w == "uint2":            # (K = 192: off the MFMA k grid, groups of 64 = one lane chunk - the 4-row GEMV tile with packed zero points)
+                    modes.append(dict(with_scaling=True, group_size=64, with_zeros=True, zeros_mode="quantized"))
         fds = [None, False] if (w[0] in "ui" and w not in ("uint8", "int8") and a in ("float16", "int8")) else [None]
         if per_kernel and a == "int8" and w in ("int4", "uint4"):
             fds = [None, True]          # (the reference's default for this pair is the plain layout: general_matmul/__init__.py:171-173)
+        if per_kernel and (a, w) == ("int4", "int2"):
+            fds = [None, False]
         for (N, K), mode, fd, strict in itertools.product(shapes, modes, fds, (True, False)):
             # strict_reference picks other members for sub-byte integers x float16 (per-element rounding) and for e4m3 x float16 (the reference's bit trick)
             strict_matters = a == "float16" and ((w[0] in "ui" and w not in ("uint8", "int8")) or (per_kernel and w == "e4m3_float8"))
