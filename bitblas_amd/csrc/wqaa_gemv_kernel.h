@@ -911,7 +911,11 @@ static gemv_fn pick_mb(int mb) {
       if constexpr (gemv_direct_ok<KIND, AT, 2, FLAGS>()) return wq_gemv_kernel<GemvPolicy<KIND, LAYOUT, AT, 2, MODE, FLAGS, 2, 2, true>>;
       else return nullptr;
     case 2: return wq_gemv_kernel<GemvPolicy<KIND, LAYOUT, AT, 2, MODE, FLAGS>>;
-    case 4: return wq_gemv_kernel<GemvPolicy<KIND, LAYOUT, AT, 4, MODE, FLAGS>>;
+    // (the 4-row batch tile runs where the MFMA family refuses a shape - N off its multiple of 4, K off its k-step: wqaa_abi.hip dispatch;
+    // 1-bit weights with packed zero points never get there: a lane chunk is a whole k-step, and N x 1 bit fills whole bytes)
+    case 4:
+      if constexpr (KIND == DK_INT1 && MODE == MD_ZQ && AT == AT_F16) return nullptr;
+      else return wq_gemv_kernel<GemvPolicy<KIND, LAYOUT, AT, 4, MODE, FLAGS>>;
     // (the in-kernel quantiser has no K-split twin: GemvPolicy::KS, and gemv_choose never asks)
     case kSplitTile + 1:
       if constexpr ((FLAGS & FL_AQ) == 0) return wq_gemv_kernel<GemvPolicy<KIND, LAYOUT, AT, 1, MODE, FLAGS, 2, 2, false, true>>;

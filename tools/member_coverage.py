@@ -53,9 +53,10 @@ def reachable(with_args=False, per_kernel=False):
         shapes = sorted([(64, 256), (48, 128), (100, 384), (272, 512), (528, 1024), (2048, 1024), (8192, 512), (16384, 256), (1024, 8192), (512, 16384), (24, 4096),
                          (50, 256), (50, 2048), (64, 160), (64, 192), (24, 32768), (1024, 320),
                          (50, 4096), (50, 8192), (50, 16384), (2048, 16384), (4096, 384),
+                         (32768, 128),               # (a round of 256 x 256 tiles at 512 rows: the lockstep tile of the formats whose 1024 rows go B_decode + dense)
                          (4092, 768)] + shapes,     # (4092: N off the ping-pong members' multiple of 8 at M = 4096 - the 256-row lockstep tile of every format)
                         key=lambda nk: nk[0] * nk[1])
-    ms = [1, 2, 3, 8, 16, 32, 64, 128, 256, 1024, 4096] if not per_kernel else [1, 2, 3, 5, 8, 16, 32, 64, 128, 256, 1024, 4096]
+    ms = [1, 2, 3, 8, 16, 32, 64, 128, 256, 1024, 4096] if not per_kernel else [1, 2, 3, 5, 8, 16, 32, 64, 128, 256, 512, 1024, 4096]
     seen = {}
     for (a, w) in f16 + bf16 + i8 + f8 + i4:
         quant = a in ("float16", "bfloat16") and w not in (a, "fp4_e2m1")
