@@ -110,7 +110,7 @@ def _check_example(cls, ex):
         else:
             hi = (1 << bit) if bit < 8 else 128
             lo = -128 if (bit == 8 and src == "int") else 0
-            codes = rng.integers(lo, hi, size=(N, K)).astype(np.int8)
+            codes = rng.integers(lo, hi, size=(N, K), dtype=np.int8)              # (drawn as int8: an int64 draw of a 32 M matrix costs more than the case)
             W_dev = op.weight_transform(torch.from_numpy(codes)).cuda() if op.weight_transform is not None else torch.from_numpy(codes).cuda()
         W_or = codes[cols]
         sdt = TDT.get(a, torch.float16)
