@@ -42,6 +42,7 @@ enum : int {
   PPO_ABL_NOMFMA = 1024, //   no MFMA (wqaa_gemm_mm_kernel.h)
   PPO_PRIO = 4096,       // lab: s_setprio 1 for the second-dispatched role group (waves 4-7) across the main loop
   PPO_ABL_METAONCE = 2048, // Scale / Zeros read and converted for the first k-body only (what the per-body metadata handling costs)
+  PPO_ABL_LONGSEG = 8192,  // lab: two phases per barrier interval - 32 MFMAs per compute segment, half the barriers, 32 more registers (results unchanged)
 };
 
 // BM_ = 256: the full tile.  BM_ = 128: the same loop on half the activation rows, for shapes whose 256-row tiles would leave the
@@ -333,7 +334,9 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_pp_kernel(const GemmArgs a
 #pragma unroll
     for (int nf = 0; nf < 2; ++nf) acc[f][nf] = acc_t{0, 0, 0, 0};
 
-  u32x4 afrag[8];
+  // (LONGSEG, lab: the odd phases have their own fragment registers - two phases are loaded, then two computed)
+  constexpr int AF2 = (P::OPT & PPO_ABL_LONGSEG) ? 8 : 0;
+  u32x4 afrag[8 + AF2];
   uint32_t bw[2][2][4];                   // decoded weight operands: [pair parity][n fragment]
   uint32_t rawc[4][2][2];                 // packed words of the chunk in hand, read half a chunk at a time: [k-tile][n fragment][MFMA of the tile]
   half2_t s2c[2], zAc[2], zBc[2];         // Scale / Zeros of the k-body being decoded, per weight fragment
@@ -508,7 +511,7 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_pp_kernel(const GemmArgs a
       for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(afrag[i]));
     } else {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) afrag[i] = *reinterpret_cast<const u32x4*>(sl + a_rd[jj] + (mh * 8 + i) * (16 * P::TILE_ROW));
+      for (int i = 0; i < 8; ++i) afrag[(p & 1) * AF2 + i] = *reinterpret_cast<const u32x4*>(sl + a_rd[jj] + (mh * 8 + i) * (16 * P::TILE_ROW));
     }
     if constexpr (!(P::OPT & PPO_ABL_NODMA)) {
       const int dslot = slot + D >= RING ? slot + D - RING : slot + D;
@@ -554,7 +557,7 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_pp_kernel(const GemmArgs a
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if constexpr (tq == 0) stamp(t, p * 4 + 2);
-    PP_BARRIER();
+    if constexpr (!((P::OPT & PPO_ABL_LONGSEG) && (p & 1) == 0)) PP_BARRIER();
   };
   auto compute_segment = [&](auto ZI, auto TQ, auto PH, int t) {
     constexpr int tq = decltype(TQ)::value, p = decltype(PH)::value;
@@ -603,13 +606,13 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_pp_kernel(const GemmArgs a
       for (int nf = 0; nf < 2; ++nf) {
         const u32x4 bv = {bw[par][nf][0], bw[par][nf][1], bw[par][nf][2], bw[par][nf][3]};
         if constexpr (BF)
-          acc[mh * 8 + i][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, bv), __builtin_bit_cast(bf16x8_t, afrag[i]),
+          acc[mh * 8 + i][nf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, bv), __builtin_bit_cast(bf16x8_t, afrag[(p & 1) * AF2 + i]),
                                                                       acc[mh * 8 + i][nf], 0, 0, 0);
         else if constexpr (F16)
-          acc[mh * 8 + i][nf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8_t, bv), __builtin_bit_cast(half8_t, afrag[i]),
+          acc[mh * 8 + i][nf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8_t, bv), __builtin_bit_cast(half8_t, afrag[(p & 1) * AF2 + i]),
                                                                      acc[mh * 8 + i][nf], 0, 0, 0);
         else
-          acc[mh * 8 + i][nf] = __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4, bv), __builtin_bit_cast(i32x4, afrag[i]),
+          acc[mh * 8 + i][nf] = __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4, bv), __builtin_bit_cast(i32x4, afrag[(p & 1) * AF2 + i]),
                                                                     acc[mh * 8 + i][nf], 0, 0, 0);
       }
     }
@@ -619,9 +622,21 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_pp_kernel(const GemmArgs a
       __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
       __builtin_amdgcn_sched_group_barrier(0x002, HALF ? 5 : 3, 0);
     }
-    PP_BARRIER();
+    if constexpr (!((P::OPT & PPO_ABL_LONGSEG) && (p & 1) == 0)) PP_BARRIER();
   };
   auto tile = [&](auto ZI, auto TQ, int t) {
+    if constexpr ((P::OPT & PPO_ABL_LONGSEG) != 0 && NPH == 4) {
+      load_segment(TQ, ic<0>{}, t);
+      load_segment(TQ, ic<1>{}, t);
+      compute_segment(ZI, TQ, ic<0>{}, t);
+      compute_segment(ZI, TQ, ic<1>{}, t);
+      load_segment(TQ, ic<2>{}, t);
+      load_segment(TQ, ic<3>{}, t);
+      compute_segment(ZI, TQ, ic<2>{}, t);
+      compute_segment(ZI, TQ, ic<3>{}, t);
+      slot = slot + 1 == RING ? 0 : slot + 1;
+      return;
+    }
     load_segment(TQ, ic<0>{}, t);
     compute_segment(ZI, TQ, ic<0>{}, t);
     load_segment(TQ, ic<1>{}, t);

@@ -39,7 +39,9 @@ using namespace wqaa;
   X("abl_nodma", DK_INT4, LAYOUT_LOP3, AT_F16, MD_ZO, 0, 3, PPO_ABL_NODMA)                   \
   X("abl_noread", DK_INT4, LAYOUT_LOP3, AT_F16, MD_ZO, 0, 3, PPO_ABL_NOREAD)                 \
   X("abl_nodec", DK_INT4, LAYOUT_LOP3, AT_F16, MD_ZO, 0, 3, PPO_ABL_NODEC)                   \
-  X("abl_all", DK_INT4, LAYOUT_LOP3, AT_F16, MD_ZO, 0, 3, PPO_ABL_NODMA | PPO_ABL_NOREAD | PPO_ABL_NODEC)
+  X("abl_all", DK_INT4, LAYOUT_LOP3, AT_F16, MD_ZO, 0, 3, PPO_ABL_NODMA | PPO_ABL_NOREAD | PPO_ABL_NODEC)      \
+  X("abl_all_long", DK_INT4, LAYOUT_LOP3, AT_F16, MD_ZO, 0, 3, PPO_ABL_NODMA | PPO_ABL_NOREAD | PPO_ABL_NODEC | PPO_ABL_LONGSEG) \
+  X("pp_long", DK_INT4, LAYOUT_LOP3, AT_F16, MD_ZO, 0, 3, PPO_ABL_LONGSEG)
 #define LAB_I8_VARIANTS(X)                                                                  \
   X("pp_i2", DK_INT2, LAYOUT_LOP3, AT_I8, MD_NONE, 0, 3, 0)                                  \
   X("pp_i2_r4", DK_INT2, LAYOUT_LOP3, AT_I8, MD_NONE, 0, 4, 0)                               \
@@ -47,7 +49,9 @@ using namespace wqaa;
   X("pp_i2_ntaw", DK_INT2, LAYOUT_LOP3, AT_I8, MD_NONE, 0, 3, 0)           \
   X("abl_i2_nodma", DK_INT2, LAYOUT_LOP3, AT_I8, MD_NONE, 0, 3, PPO_ABL_NODMA)               \
   X("abl_i2_nodec", DK_INT2, LAYOUT_LOP3, AT_I8, MD_NONE, 0, 3, PPO_ABL_NODEC)               \
-  X("abl_i2_all", DK_INT2, LAYOUT_LOP3, AT_I8, MD_NONE, 0, 3, PPO_ABL_NODMA | PPO_ABL_NOREAD | PPO_ABL_NODEC)
+  X("abl_i2_all", DK_INT2, LAYOUT_LOP3, AT_I8, MD_NONE, 0, 3, PPO_ABL_NODMA | PPO_ABL_NOREAD | PPO_ABL_NODEC)  \
+  X("abl_i2_all_long", DK_INT2, LAYOUT_LOP3, AT_I8, MD_NONE, 0, 3, PPO_ABL_NODMA | PPO_ABL_NOREAD | PPO_ABL_NODEC | PPO_ABL_LONGSEG) \
+  X("pp_i2_long", DK_INT2, LAYOUT_LOP3, AT_I8, MD_NONE, 0, 3, PPO_ABL_LONGSEG)
 #define LAB_PUSH(name, ...) vs.push_back(mk<PPPolicy<__VA_ARGS__>>(name));
 
 
