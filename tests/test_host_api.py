@@ -66,6 +66,17 @@ def test_unsupported_config_fails_at_construction():
         bitblas.Matmul(bitblas.MatmulConfig(M=1, N=64, K=64, layout="nn"), enable_tuning=False)
 
 
+def test_packed_zero_points_must_fill_whole_bytes():
+    """Qzeros is (K / g, N x bits / 8) int8 (tirscript/matmul_dequantize_impl.py:375-389 sizes the row N // 8 * bits): an N that leaves
+    a partial byte would read past the row - refused with BAD_DESC instead (round 6)"""
+    from bitblas_amd.lib import WqaaError
+    kw = dict(K=256, A_dtype="float16", W_dtype="uint2", group_size=128, with_scaling=True, with_zeros=True, zeros_mode="quantized")
+    with pytest.raises(WqaaError, match="whole bytes"):
+        bitblas.Matmul(bitblas.MatmulConfig(M=1, N=50, **kw), enable_tuning=False)
+    bitblas.Matmul(bitblas.MatmulConfig(M=1, N=48, **kw), enable_tuning=False)
+    bitblas.Matmul(bitblas.MatmulConfig(M=1, N=50, **dict(kw, zeros_mode="original")), enable_tuning=False)
+
+
 def test_transform_weight_bytes_are_the_reference_layout():
     import numpy as np
     import wqaa_oracle as oracle
