@@ -482,7 +482,13 @@ __global__ void __launch_bounds__(P::THREADS) wq_gemm_pp_kernel(const GemmArgs a
     }
     zint = __all(ok);
   }
-  pp_wait_vmcnt<(D - 1) * NPH>();         // tiles 1 .. D-1 may stay in flight
+  // 256-row tile: tiles 1 .. D-1 may stay in flight - the loop's counted wait is exact from tile 0 on (the prologue ends with the activation
+  // tiles).  128-row tile (D = 4): the loop's `vmcnt(10)` counts the ten pieces that FOLLOW tile t + 1 in steady state (three tiles of two
+  // activation pieces + one chunk of four weight pieces); behind the prologue only six (tile 0) and six (tile 1) follow, so that wait let
+  // tiles 1 and 2 be read before they had landed whenever their pieces took longer than tile 0's by a few hundred ns - seen as a handful
+  // of wrong outputs about once in 2000 FIRST launches on fresh buffers (round 6, tests/test_member_coverage_gpu.py under repetition).
+  // Here: everything but tile 3; from tile 2 on the loop's count holds (A4, A5, A6 + the chunk = 10 behind A3).
+  pp_wait_vmcnt<HALF ? NPH : (D - 1) * NPH>();
   PP_BARRIER();
   read_words(0, 0);
   meta_read(0);
