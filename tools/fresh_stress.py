@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""tools/fresh_stress.py [regex] [launches]: first launches on freshly uploaded operands, over the selector sweep's per-kernel examples.
+"""tools/fresh_stress.py [regex] [launches] [--large]: first launches on freshly uploaded operands, over the selector sweep's per-kernel examples.
 
 For every (member class, mode, layout) example of tools/member_coverage.py whose class matches `regex` (default: the members with
 hand-counted waits - ping-pong, decode and mid-M forms): build the operator and host operands once, take one launch as the reference,
@@ -68,10 +68,18 @@ def host_operands(ex, rng):
 
 
 def main():
-    pat = re.compile(sys.argv[1] if len(sys.argv) > 1 else r"pp|xdl|xmk")
-    launches = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+    argv = [a for a in sys.argv[1:] if not a.startswith("--")]
+    pat = re.compile(argv[0] if len(argv) > 0 else r"pp|xdl|xmk")
+    launches = int(argv[1]) if len(argv) > 1 else 20
     reach = member_coverage.reachable(with_args=True, per_kernel=True)
-    keys = sorted(k for k, v in reach.items() if pat.search(k.split("|")[0]) and v["N"] * v["K"] <= (1 << 25) and v["M"] * v["N"] <= (1 << 25))
+    small = {k: v for k, v in reach.items() if v["N"] * v["K"] <= (1 << 25) and v["M"] * v["N"] <= (1 << 25)}
+    if "--large" in sys.argv:      # the classes only the large shapes reach (the 28672 x 8192-sized linears: K-split roundings, tail launches)
+        covered = {k.split("|")[0] for k in small}
+        reach = {c: v for c, v in member_coverage.reachable(with_args=True).items() if c not in covered}
+        keys = sorted(k for k in reach if pat.search(k))
+    else:
+        reach = small
+        keys = sorted(k for k in reach if pat.search(k.split("|")[0]))
     bad_keys, total = [], 0
     for k in keys:
         ex = reach[k]
