@@ -158,7 +158,7 @@ def time_member_gemv(device, gen, N, K, n_buf=64, strict=False):
             "frac_of_hbm_peak": nbytes / t / 1e9 / HBM_PEAK_GBS, "buffers": n_buf}
 
 
-def time_member_gemm(device, gen, M=4096, N=4096, K=4096, W_dtype="uint4", A_dtype="float16", n_buf=8, tuned=False, bitnet=False):
+def time_member_gemm(device, gen, M=4096, N=4096, K=4096, W_dtype="uint4", A_dtype="float16", n_buf=8, tuned=False, bitnet=False, frac_zeros=False):
     """MFMA GEMM members (BASELINE configs c3 / c4): TFLOP/s from graph-replayed launches.
     bitnet: the int8 member as a BitNet layer calls it (integration/BitNet/utils_quant.py:205-216) - float16 output through the fused
     `out / si / sw` epilogue (wqaa_matmul_ex) instead of the int32 sums."""
@@ -192,6 +192,10 @@ def time_member_gemm(device, gen, M=4096, N=4096, K=4096, W_dtype="uint4", A_dty
         qw = torch.randint(-128, 128, (N, K * bits // 8), dtype=torch.int8, device=device, generator=gen)
         sc = (torch.rand((N, K // GROUP), device=device, generator=gen) * 0.02).to(torch.float16)
         zr = torch.full((N, K // GROUP), float(1 << (bits - 1)), dtype=torch.float16, device=device)
+        if frac_zeros:
+            # zero points with a fraction (the reference's `original` mode takes any float16): the ping-pong member then decodes by the
+            # general (w - z) * s form instead of the integer-zero-point one GPTQ-style checkpoints get (csrc/wqaa_gemm_pp_kernel.h: zint)
+            zr += 0.3125
         sets.append((qw, sc, zr))
 
     def launch_all():
@@ -959,6 +963,7 @@ def main():
                        int4_us=(members.get(f"gemv_int4_n{N}k{K}") or {}).get("us_per_launch"))
             member("gemm_uint4_m4096", time_member_gemm, device, gen, 4096)
             member("gemm_uint4_m4096_two_pass_vendor", time_member_gemm, device, gen, 4096, tuned=True)
+            member("gemm_uint4_m4096_fractional_zeros", time_member_gemm, device, gen, 4096, frac_zeros=True)
             member("gemm_uint4_m128", time_member_gemm, device, gen, 128)
             member("gemm_uint4_m16", time_member_gemm, device, gen, 16)
             # the rest of the reference's default opt_M steps below the ping-pong tiles ("M = 32 / 64 / 256 reported"), and a
