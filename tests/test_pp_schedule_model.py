@@ -151,3 +151,79 @@ def test_the_model_sees_the_race_of_round_6():
     assert any("('A', 1)" in v for v in bad) and any("('A', 2)" in v for v in bad)
     # ... and the 256-row tile never had it: its prologue ends with the activation tiles, the loop's count is exact from tile 0 on
     assert run_model(False, 16, True, _waits_from_header(), prologue_wait=4) == []
+
+
+# ---- the dense members (wq_gemm_pp8_kernel both tile heights, pp8w, pp8s): their prologues keep "the order the loop keeps" -------------
+def _dense_model(kind, ntiles):
+    w = Wave()
+
+    def tile_ops(tt, order):                       # order: a string of 'A' / 'W' pieces of k-tile tt
+        for ch in order:
+            w.dma((ch, tt))
+
+    if kind == "pp8_128":                          # [A p0, A p1, W x 4] per tile, three tiles ahead; vmcnt(12) = the two younger tiles
+        for tt in range(3):
+            tile_ops(tt, "AAWWWW")
+        w.wait(12)
+        for t in range(ntiles):
+            w.read(("W", t), f"tile {t}")
+            w.read(("A", t), f"tile {t} segment 0")
+            w.dma(("A", t + 3))
+            w.read(("A", t), f"tile {t} segment 1")
+            w.dma(("A", t + 3))
+            tile_ops(t + 3, "WWWW")
+            w.wait(12)
+    elif kind == "pp8_256":                        # W(t + 1) piece 3 with segment 0, W(t + 2) pieces 0..2 with segments 1..3; vmcnt(5) in segment 2
+        tile_ops(0, "WWWW")
+        tile_ops(0, "AAAA")
+        tile_ops(1, "WWW")
+        tile_ops(1, "AAAA")
+        w.wait(7)
+        for t in range(ntiles):
+            for p in range(4):
+                if p == 0:
+                    w.read(("W", t), f"tile {t}")
+                w.read(("A", t), f"tile {t} segment {p}")
+                w.dma(("W", t + 1) if p == 0 else ("W", t + 2))
+                w.dma(("A", t + 2))
+                if p == 2:
+                    w.wait(5)
+    elif kind == "pp8w":                           # [A p0, p1] with segment 0, [A p2, p3, W x 4] with segment 1; vmcnt(8) = tile t + 2's pieces
+        for tt in range(2):
+            tile_ops(tt, "AAAAWWWW")
+        w.wait(8)
+        for t in range(ntiles):
+            for p in range(2):
+                w.read(("A", t), f"tile {t} segment {p}")
+                w.read(("W", t), f"tile {t} segment {p}")
+                tile_ops(t + 2, "AA" if p == 0 else "AAWWWW")
+                if p == 1:
+                    w.wait(8)
+    elif kind == "pp8s":                           # one segment per tile: [A x 2, W x 4] three tiles ahead; vmcnt(12)
+        for tt in range(3):
+            tile_ops(tt, "AAWWWW")
+        w.wait(12)
+        for t in range(ntiles):
+            w.read(("W", t), f"tile {t}")
+            w.read(("A", t), f"tile {t}")
+            tile_ops(t + 3, "AAWWWW")
+            w.wait(12)
+    return w.violations
+
+
+@pytest.mark.parametrize("ntiles", [2, 8, 32])
+@pytest.mark.parametrize("kind", ["pp8_128", "pp8_256", "pp8w", "pp8s"])
+def test_dense_members_keep_the_order_their_waits_count(kind, ntiles):
+    assert _dense_model(kind, ntiles) == []
+
+
+def test_dense_members_waits_are_the_ones_in_the_header():
+    """the constants of the model above, where the header has them (a changed count must come back to this file)"""
+    src = open(HEADER).read()
+    pp8 = src[src.index(" wq_gemm_pp8_kernel(const GemmArgs a) {"):src.index(" wq_gemm_pp8w_kernel(const GemmArgs a) {")]
+    pp8w = src[src.index(" wq_gemm_pp8w_kernel(const GemmArgs a) {"):src.index(" wq_gemm_pp8s_kernel(const GemmArgs a) {")]
+    pp8s = src[src.index(" wq_gemm_pp8s_kernel(const GemmArgs a) {"):]
+    counts = lambda body: [int(x) for x in re.findall(r"pp_wait_vmcnt<(\d+)>\(\);", body)]      # noqa: E731
+    assert counts(pp8) == [12, 7, 12, 5, 0], counts(pp8)
+    assert counts(pp8w) == [8, 8, 0], counts(pp8w)
+    assert counts(pp8s) == [12, 12, 0], counts(pp8s)
